@@ -1,0 +1,1 @@
+"""Empty ``jarvis`` stub so ``alignn/graphs.py`` imports (test infrastructure only)."""
