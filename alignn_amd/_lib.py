@@ -1,0 +1,89 @@
+"""ctypes binding of libalignn_hip.so (the C ABI declared in include/alignn_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a GPU call fails, an
+exception is raised.  PyTorch appears here only as the owner of device memory and streams.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libalignn_hip.so")
+
+_p, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); must mirror include/alignn_hip.h (tests/test_abi.py checks the set)
+SIGNATURES = {
+    "alignn_version": (C.c_char_p, []),
+    "alignn_gemm_nt": (_i32, [_p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _i64, _i32, _i32, _p]),
+    "alignn_gemm_nn": (_i32, [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i32, _i32, _p]),
+    "alignn_gemm_tn_workspace": (_sz, [_i64, _i32, _i32]),
+    "alignn_gemm_tn": (_i32, [_p, _i64, _p, _i64, _p, _i64, _i64, _i32, _i32, _p, _sz, _p]),
+    "alignn_col_stats_slabs": (_i32, [_i64]),
+    "alignn_col_stats": (_i32, [_p, _i64, _i64, _i32, _p, _p]),
+    "alignn_col_sum": (_i32, [_p, _i64, _i64, _i32, _p, _p, _p]),
+    "alignn_bn_finalize": (_i32, [_p, _i32, _i64, _i32, _p, _p, _f32, _f32, _p, _p, _p, _p]),
+    "alignn_bn_silu_fwd": (_i32, [_p, _i64, _p, _i64, _p, _p, _i64, _i64, _i32, _p]),
+    "alignn_bn_silu_bwd_reduce": (_i32, [_p, _i64, _p, _i64, _p, _i64, _i32, _p, _p]),
+    "alignn_bn_bwd_finalize": (_i32, [_p, _i32, _i32, _p, _p]),
+    "alignn_bn_silu_bwd_apply": (_i32, [_p, _i64, _p, _i64, _p, _p, _p, _i32, _p, _i64, _i64, _i32, _p]),
+    "alignn_egc_slabs": (_i32, [_i64]),
+    "alignn_egc_gate_fwd": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p]),
+    "alignn_egc_node_bwd": (_i32, [_p, _i64, _p, _p, _p, _p, _i64, _i32, _p]),
+    "alignn_egc_bwd_dst": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _i32, _i64, _p, _p, _p, _i64, _i32, _p, _p, _p]),
+    "alignn_egc_bwd_src": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p]),
+    "alignn_rbf_fwd": (_i32, [_p, _p, _f32, _p, _i64, _i32, _p]),
+    "alignn_norm3_fwd": (_i32, [_p, _p, _i64, _p]),
+    "alignn_segment_mean_fwd": (_i32, [_p, _p, _p, _i32, _i32, _p]),
+    "alignn_segment_mean_bwd": (_i32, [_p, _p, _p, _i32, _i32, _p]),
+    "alignn_gather_rows": (_i32, [_p, _p, _p, _i64, _i32, _p]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library (once).  Raises if it has not been built - there is no CPU fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -m alignn_amd.build` "
+                "(hipcc --offload-arch=gfx950); alignn_amd has no CPU/eager fallback."
+            )
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"libalignn_hip: {what} failed with hipError {rc}")
+
+
+def require_f32(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if t.dtype != torch.float32 or not t.is_cuda:
+            raise TypeError(
+                f"alignn_amd kernels take float32 CUDA(HIP) tensors, got {t.dtype} on {t.device}; "
+                "there is no CPU fallback"
+            )

@@ -1,0 +1,251 @@
+"""MI355X-native drop-in for ``alignn.models.alignn`` (BatchNorm flavour).
+
+Same classes, constructor arguments, attribute names, ``forward`` signatures and ``state_dict``
+keys as the reference (``/root/reference/alignn/models/alignn.py``: ``ALIGNNConfig`` :19-45,
+``EdgeGatedGraphConv`` :48-129, ``ALIGNNConv`` :132-167, ``MLPLayer`` :170-184, ``ALIGNN``
+:187-349; ``RBFExpansion`` ``alignn/models/utils.py:11-44``), so a reference checkpoint loads with
+``load_state_dict`` and an instance can be handed to ``alignn.train.train_dgl(model=...)``.
+
+The ``nn.Linear`` / ``nn.BatchNorm1d`` children are kept purely as parameter/buffer containers
+(that is what fixes the key names); their ``forward`` is never called.  All arithmetic goes
+through ``alignn_amd.ops`` -> ``libalignn_hip.so``.
+"""
+
+from __future__ import annotations
+
+from typing import Literal, Optional, Sequence, Union
+
+import numpy as np
+import torch
+from torch import nn
+
+try:  # the reference derives its config from pydantic-settings; fall back to plain pydantic
+    from pydantic_settings import BaseSettings as _Base
+
+    _CONFIG = {"extra": "forbid", "env_prefix": "jv_model", "protected_namespaces": ()}
+except Exception:  # pragma: no cover - depends on the image
+    from pydantic import BaseModel as _Base
+
+    _CONFIG = {"extra": "forbid", "protected_namespaces": ()}
+
+from . import ops
+from .graph import CSRGraph, GraphBatch, build_csr
+
+
+class ALIGNNConfig(_Base):
+    """Hyperparameter schema; field-for-field the reference's (alignn/models/alignn.py:22-40)."""
+
+    name: Literal["alignn"]
+    alignn_layers: int = 4
+    gcn_layers: int = 4
+    atom_input_features: int = 92
+    edge_input_features: int = 80
+    triplet_input_features: int = 40
+    embedding_features: int = 64
+    hidden_features: int = 256
+    output_features: int = 1
+    link: Literal["identity", "log", "logit"] = "identity"
+    zero_inflated: bool = False
+    classification: bool = False
+    num_classes: int = 2
+    extra_features: int = 0
+
+    model_config = _CONFIG
+
+
+class RBFExpansion(nn.Module):
+    """exp(-gamma (d - c_k)^2); ``centers`` is a registered buffer (state_dict key ``*.centers``)."""
+
+    def __init__(self, vmin: float = 0, vmax: float = 8, bins: int = 40, lengthscale: Optional[float] = None):
+        super().__init__()
+        self.vmin, self.vmax, self.bins = vmin, vmax, bins
+        self.register_buffer("centers", torch.linspace(self.vmin, self.vmax, self.bins))
+        if lengthscale is None:
+            # gamma = 1 / mean spacing of the centres (NOT squared) - alignn/models/utils.py:30-34
+            # (computed in float32 exactly as numpy does on the float32 buffer: 9.875 / 19.500002)
+            ls32 = np.diff(self.centers.numpy()).mean(dtype=np.float32)
+            self.lengthscale = float(ls32)
+            self.gamma = float(np.float32(1.0) / ls32)
+        else:
+            self.lengthscale = lengthscale
+            self.gamma = 1.0 / (lengthscale**2)
+
+    def forward(self, distance: torch.Tensor) -> torch.Tensor:
+        return ops.rbf_expand(distance, self.centers, self.gamma)
+
+
+def _bump(bn: nn.BatchNorm1d, training: bool):
+    if training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+
+
+class MLPLayer(nn.Module):
+    """Linear + BatchNorm1d + SiLU (alignn/models/alignn.py:170-184)."""
+
+    def __init__(self, in_features: int, out_features: int):
+        super().__init__()
+        self.layer = nn.Sequential(nn.Linear(in_features, out_features), nn.BatchNorm1d(out_features), nn.SiLU())
+
+    def forward(self, x):
+        lin, bn = self.layer[0], self.layer[1]
+        _bump(bn, self.training)
+        return ops.MLPLayerFn.apply(
+            x, lin.weight, lin.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training
+        )
+
+
+def _as_csr(g, device) -> tuple[CSRGraph, bool]:
+    """Accept a canonical CSRGraph, or any DGL-like graph (converted; edge rows then need permuting)."""
+    if isinstance(g, CSRGraph):
+        return g, True
+    cached = getattr(g, "_alignn_amd_csr", None)
+    if cached is not None and cached.src.device == device:
+        return cached, False
+    u, v = g.edges()
+    csr = build_csr(u.to(device), v.to(device), g.num_nodes())
+    try:
+        g._alignn_amd_csr = csr
+    except Exception:
+        pass
+    return csr, False
+
+
+class EdgeGatedGraphConv(nn.Module):
+    """Edge-gated graph convolution (arxiv:1711.07553), alignn/models/alignn.py:48-129.
+
+    ``forward(g, node_feats, edge_feats) -> (x, y)``; ``g`` may be a DGL-like graph (features in
+    the caller's edge order, as in the reference) or a canonical ``CSRGraph`` (features already in
+    slot order - the fast path used inside ``ALIGNN``).
+    """
+
+    def __init__(self, input_features: int, output_features: int, residual: bool = True):
+        super().__init__()
+        self.residual = residual
+        self.src_gate = nn.Linear(input_features, output_features)
+        self.dst_gate = nn.Linear(input_features, output_features)
+        self.edge_gate = nn.Linear(input_features, output_features)
+        self.bn_edges = nn.BatchNorm1d(output_features)
+        self.src_update = nn.Linear(input_features, output_features)
+        self.dst_update = nn.Linear(input_features, output_features)
+        self.bn_nodes = nn.BatchNorm1d(output_features)
+
+    def forward(self, g, node_feats: torch.Tensor, edge_feats: torch.Tensor):
+        csr, canonical = _as_csr(g, node_feats.device)
+        y_in = edge_feats if canonical else edge_feats[csr.perm]
+        # fused node projection: P = x [W_sg; W_dg; W_du; W_su]^T -> A | Bd | Bh | Ux
+        wcat = torch.cat([self.src_gate.weight, self.dst_gate.weight, self.dst_update.weight, self.src_update.weight], 0)
+        bcat = torch.cat([self.src_gate.bias, self.dst_gate.bias, self.dst_update.bias, self.src_update.bias], 0)
+        _bump(self.bn_nodes, self.training)
+        _bump(self.bn_edges, self.training)
+        x, y = ops.EdgeGatedConvFn.apply(
+            csr, node_feats, y_in, wcat, bcat, self.edge_gate.weight, self.edge_gate.bias,
+            self.bn_nodes.weight, self.bn_nodes.bias, self.bn_nodes.running_mean, self.bn_nodes.running_var,
+            self.bn_edges.weight, self.bn_edges.bias, self.bn_edges.running_mean, self.bn_edges.running_var,
+            self.training, self.residual,
+        )
+        if not canonical:
+            y = y[csr.inv]
+        return x, y
+
+
+class ALIGNNConv(nn.Module):
+    """Line graph update (alignn/models/alignn.py:132-167): bond-graph conv, then line-graph conv
+    whose node inputs are the bond messages ``m``."""
+
+    def __init__(self, in_features: int, out_features: int):
+        super().__init__()
+        self.node_update = EdgeGatedGraphConv(in_features, out_features)
+        self.edge_update = EdgeGatedGraphConv(out_features, out_features)
+
+    def forward(self, g, lg, x: torch.Tensor, y: torch.Tensor, z: torch.Tensor):
+        x, m = self.node_update(g, x, y)
+        y, z = self.edge_update(lg, m, z)
+        return x, y, z
+
+
+class ALIGNN(nn.Module):
+    """Atomistic line graph network (alignn/models/alignn.py:187-349)."""
+
+    def __init__(self, config: ALIGNNConfig = ALIGNNConfig(name="alignn")):
+        super().__init__()
+        self.config = config
+        self.classification = config.classification
+        self.atom_embedding = MLPLayer(config.atom_input_features, config.hidden_features)
+        self.edge_embedding = nn.Sequential(
+            RBFExpansion(vmin=0, vmax=8.0, bins=config.edge_input_features),
+            MLPLayer(config.edge_input_features, config.embedding_features),
+            MLPLayer(config.embedding_features, config.hidden_features),
+        )
+        self.angle_embedding = nn.Sequential(
+            RBFExpansion(vmin=-1, vmax=1.0, bins=config.triplet_input_features),
+            MLPLayer(config.triplet_input_features, config.embedding_features),
+            MLPLayer(config.embedding_features, config.hidden_features),
+        )
+        self.alignn_layers = nn.ModuleList(
+            [ALIGNNConv(config.hidden_features, config.hidden_features) for _ in range(config.alignn_layers)]
+        )
+        self.gcn_layers = nn.ModuleList(
+            [EdgeGatedGraphConv(config.hidden_features, config.hidden_features) for _ in range(config.gcn_layers)]
+        )
+        if self.classification:
+            self.fc = nn.Linear(config.hidden_features, config.num_classes)
+            self.softmax = nn.LogSoftmax(dim=1)
+        else:
+            self.fc = nn.Linear(config.hidden_features, config.output_features)
+        if config.extra_features != 0:
+            raise NotImplementedError("extra_features != 0 is outside the MI355X hot-path build (SURVEY.md section 8)")
+        self.link = None
+        self.link_name = config.link
+        if config.link == "identity":
+            self.link = lambda x: x
+        elif config.link == "log":
+            self.link = torch.exp
+            avg_gap = 0.7  # reference initialises the bias to log(average band gap), alignn.py:273-278
+            self.fc.bias.data = torch.tensor(np.log(avg_gap), dtype=torch.float)
+        elif config.link == "logit":
+            self.link = torch.sigmoid
+
+    # ------------------------------------------------------------------
+    def _batch(self, g) -> GraphBatch:
+        dev = self.fc.weight.device
+        if isinstance(g, GraphBatch):
+            return g
+        if isinstance(g, (tuple, list)):
+            if isinstance(g[0], GraphBatch):
+                return g[0]
+            gg, lg = g[0], (g[1] if len(self.alignn_layers) > 0 else None)
+        else:
+            gg, lg = g, None
+        cached = getattr(gg, "_alignn_amd_batch", None)
+        if cached is not None and cached.device == dev:
+            return cached
+        batch = GraphBatch.from_dgl(gg, lg, device=dev)
+        try:
+            gg._alignn_amd_batch = batch
+        except Exception:
+            pass
+        return batch
+
+    def forward(self, g: Union[Sequence, GraphBatch]):
+        """``g`` = ``(g, lg, lat)`` of DGL-like graphs as in the reference (alignn.py:291-295), a bare
+        graph when ``alignn_layers == 0``, or a prebuilt ``GraphBatch``.  Returns ``squeeze(out)``."""
+        b = self._batch(g)
+        if b.atom_features is None or b.r is None:
+            raise ValueError("graph lacks ndata['atom_features'] / edata['r']")
+        if len(self.alignn_layers) > 0:
+            if b.lg is None or b.h is None:
+                raise ValueError("alignn_layers > 0 needs the line graph with edata['h']")
+            z = self.angle_embedding(b.h)
+        x = self.atom_embedding(b.atom_features)
+        y = self.edge_embedding(ops.bond_length(b.r))
+        for layer in self.alignn_layers:
+            x, y, z = layer(b.g, b.lg, x, y, z)
+        for layer in self.gcn_layers:
+            x, y = layer(b.g, x, y)
+        h = ops.AvgPoolFn.apply(x, b.graph_ptr)
+        out = ops.linear(h, self.fc.weight, self.fc.bias.reshape(-1))
+        if self.link:
+            out = self.link(out)
+        if self.classification:
+            out = self.softmax(out)
+        return torch.squeeze(out)

@@ -1,0 +1,37 @@
+"""Build libalignn_hip.so (gfx950) in-tree with hipcc.  ``python -m alignn_amd.build``."""
+
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libalignn_hip.so")
+SOURCES = ["norm.hip", "conv.hip", "gemm_f32.hip", "embed.hip"]
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(os.path.dirname(HERE), "include", "alignn_hip.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into one shared library; returns its path."""
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB]
+    cmd += [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

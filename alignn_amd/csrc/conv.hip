@@ -1,0 +1,354 @@
+// Edge-gated graph convolution core: gather -> gate -> segment-sum, forward and backward.
+//
+// One wavefront (64 lanes) per destination segment; lane l owns features [4l, 4l+4) of each
+// 256-feature chunk, so a feature row of H=256 fp32 is exactly one coalesced 1 KiB access per
+// wave-instruction.  Source-node rows (A[u], Bh[u]) are gathered as whole rows, the segment sum is
+// kept in registers, and the per-feature BatchNorm statistics of the edge pre-activations are
+// accumulated on the fly (wave partials -> fixed-order block sum -> slab).  No atomics anywhere:
+// results are bit-reproducible.
+//
+// Reference: EdgeGatedGraphConv.forward, alignn/models/alignn.py:78-129 (DGL u_add_v / u_mul_e+sum /
+// copy_e+sum at :100,:105-108) and DGL's autograd of the same calls for the backward passes.
+#include "common.h"
+#include "../../include/alignn_hip.h"
+
+namespace {
+
+constexpr int kWavesPerBlock = 4;
+constexpr int kThreads = kWavesPerBlock * ALIGNN_WAVE;
+constexpr int kMaxSlabs = 1024;
+
+__host__ __device__ inline int egc_blocks(int64_t n_seg) {
+    int64_t b = (n_seg + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (b < 1) b = 1;
+    if (b > kMaxSlabs) b = kMaxSlabs;
+    return (int)b;
+}
+
+// Sum the four waves' partial accumulators in wave order and let wave 0 write the slab entry.
+__device__ __forceinline__ void block_slab_store(float4 s, float4 ss, float* slab, int H, int f, bool active,
+                                                 float4 (*sh)[kWavesPerBlock][ALIGNN_WAVE], int wave, int lane) {
+    sh[0][wave][lane] = s;
+    sh[1][wave][lane] = ss;
+    __syncthreads();
+    if (wave == 0 && active) {
+        float4 a = sh[0][0][lane], b = sh[1][0][lane];
+#pragma unroll
+        for (int w = 1; w < kWavesPerBlock; ++w) {
+            a = f4_add(a, sh[0][w][lane]);
+            b = f4_add(b, sh[1][w][lane]);
+        }
+        f4_st(slab + f, a);
+        f4_st(slab + H + f, b);
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void egc_gate_fwd_kernel(
+    const float* __restrict__ P, float* __restrict__ M, const int32_t* __restrict__ seg_ptr,
+    const int32_t* __restrict__ seg_node, const int32_t* __restrict__ src, int n_seg, int H,
+    float* __restrict__ XPRE, float* __restrict__ S0, float* __restrict__ HH, float* __restrict__ e_partial,
+    float* __restrict__ n_partial) {
+    __shared__ float4 sh[2][kWavesPerBlock][ALIGNN_WAVE];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t ldp = 4 * (int64_t)H;
+    const int first = blockIdx.x * kWavesPerBlock + wave;
+    const int stride = gridDim.x * kWavesPerBlock;
+
+    for (int c0 = 0; c0 < H; c0 += 4 * ALIGNN_WAVE) {
+        const int f = c0 + 4 * lane;
+        const bool active = f < H;
+        float4 e_s = f4_zero(), e_ss = f4_zero(), n_s = f4_zero(), n_ss = f4_zero();
+        if (active) {
+            for (int s = first; s < n_seg; s += stride) {
+                const int beg = seg_ptr[s], end = seg_ptr[s + 1];
+                const int i = seg_node ? seg_node[s] : s;
+                const float* Pi = P + (int64_t)i * ldp;
+                const float4 bd = f4_ld(Pi + H + f);
+                const float4 ux = f4_ld(Pi + 3 * H + f);
+                float4 s1 = f4_zero(), s0 = f4_zero();
+                int e = beg;
+                for (; e + 4 <= end; e += 4) {
+                    int u[4];
+                    float4 a[4], bh[4], c[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) u[k] = src[e + k];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float* Pu = P + (int64_t)u[k] * ldp;
+                        a[k] = f4_ld(Pu + f);
+                        bh[k] = f4_ld(Pu + 2 * H + f);
+                        c[k] = f4_ld(M + (int64_t)(e + k) * H + f);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float4 m = f4_add(f4_add(a[k], bd), c[k]);
+                        f4_st(M + (int64_t)(e + k) * H + f, m);
+                        float4 sg = f4_sigmoid(m);
+                        s1 = f4_fma(sg, bh[k], s1);
+                        s0 = f4_add(s0, sg);
+                        e_s = f4_add(e_s, m);
+                        e_ss = f4_fma(m, m, e_ss);
+                    }
+                }
+                for (; e < end; ++e) {
+                    const float* Pu = P + (int64_t)src[e] * ldp;
+                    float4 m = f4_add(f4_add(f4_ld(Pu + f), bd), f4_ld(M + (int64_t)e * H + f));
+                    f4_st(M + (int64_t)e * H + f, m);
+                    float4 sg = f4_sigmoid(m);
+                    s1 = f4_fma(sg, f4_ld(Pu + 2 * H + f), s1);
+                    s0 = f4_add(s0, sg);
+                    e_s = f4_add(e_s, m);
+                    e_ss = f4_fma(m, m, e_ss);
+                }
+                float4 h;
+                h.x = s1.x / (s0.x + ALIGNN_EPS_GATE);
+                h.y = s1.y / (s0.y + ALIGNN_EPS_GATE);
+                h.z = s1.z / (s0.z + ALIGNN_EPS_GATE);
+                h.w = s1.w / (s0.w + ALIGNN_EPS_GATE);
+                float4 xp = f4_add(ux, h);
+                f4_st(XPRE + (int64_t)i * H + f, xp);
+                if (S0) f4_st(S0 + (int64_t)i * H + f, s0);
+                if (HH) f4_st(HH + (int64_t)i * H + f, h);
+                n_s = f4_add(n_s, xp);
+                n_ss = f4_fma(xp, xp, n_ss);
+            }
+        }
+        if (e_partial)
+            block_slab_store(e_s, e_ss, e_partial + (size_t)blockIdx.x * 2 * H, H, f, active, sh, wave, lane);
+        if (n_partial)
+            block_slab_store(n_s, n_ss, n_partial + (size_t)blockIdx.x * 2 * H, H, f, active, sh, wave, lane);
+    }
+}
+
+__global__ __launch_bounds__(256) void egc_node_bwd_kernel(const float* __restrict__ GXPRE, int64_t ldg,
+                                                           const float* __restrict__ S0,
+                                                           const float* __restrict__ HH, float* __restrict__ GS1,
+                                                           float* __restrict__ GS0, int64_t n, int H) {
+    const int Q = H >> 2;
+    const int64_t total = n * Q;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        int64_t r = i / Q;
+        int q = (int)(i - r * Q);
+        float4 g = f4_ld(GXPRE + r * ldg + q * 4);
+        float4 s0 = f4_ld(S0 + r * H + q * 4);
+        float4 h = f4_ld(HH + r * H + q * 4);
+        float4 g1, g0;
+        g1.x = g.x / (s0.x + ALIGNN_EPS_GATE);
+        g1.y = g.y / (s0.y + ALIGNN_EPS_GATE);
+        g1.z = g.z / (s0.z + ALIGNN_EPS_GATE);
+        g1.w = g.w / (s0.w + ALIGNN_EPS_GATE);
+        g0 = make_float4(-g1.x * h.x, -g1.y * h.y, -g1.z * h.z, -g1.w * h.w);
+        f4_st(GS1 + r * H + q * 4, g1);
+        f4_st(GS0 + r * H + q * 4, g0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward, destination order
+// ---------------------------------------------------------------------------------------------
+struct EdgeNorm {
+    float4 mean, rstd, sc, sh, c0, c1;
+};
+
+template <bool HAS_GY>
+__device__ __forceinline__ float4 edge_grad(float4 m, float4 gy, float4 bh, float4 gs1, float4 gs0,
+                                            const EdgeNorm& nrm, float inv_n, int eval_mode) {
+    float4 sg = f4_sigmoid(m);
+    float4 gsig = f4_fma(gs1, bh, gs0);
+    float4 gm;
+    gm.x = gsig.x * sg.x * (1.0f - sg.x);
+    gm.y = gsig.y * sg.y * (1.0f - sg.y);
+    gm.z = gsig.z * sg.z * (1.0f - sg.z);
+    gm.w = gsig.w * sg.w * (1.0f - sg.w);
+    if (HAS_GY) {
+        float4 z = f4_fma(m, nrm.sc, nrm.sh);
+        float4 gz = make_float4(gy.x * dsilu_f(z.x), gy.y * dsilu_f(z.y), gy.z * dsilu_f(z.z), gy.w * dsilu_f(z.w));
+        if (eval_mode) {
+            gm = f4_fma(gz, nrm.sc, gm);
+        } else {
+            float4 xh = f4_mul(f4_sub(m, nrm.mean), nrm.rstd);
+            gm.x += nrm.sc.x * (gz.x - inv_n * (nrm.c0.x + xh.x * nrm.c1.x));
+            gm.y += nrm.sc.y * (gz.y - inv_n * (nrm.c0.y + xh.y * nrm.c1.y));
+            gm.z += nrm.sc.z * (gz.z - inv_n * (nrm.c0.z + xh.z * nrm.c1.z));
+            gm.w += nrm.sc.w * (gz.w - inv_n * (nrm.c0.w + xh.w * nrm.c1.w));
+        }
+    }
+    return gm;
+}
+
+template <bool HAS_GY>
+__global__ __launch_bounds__(kThreads) void egc_bwd_dst_kernel(
+    const float* __restrict__ GY, const float* __restrict__ M, const float* __restrict__ P,
+    const float* __restrict__ GS1, const float* __restrict__ GS0, const float* __restrict__ e_stat,
+    const float* __restrict__ e_red, int e_eval, float inv_n, const int32_t* __restrict__ seg_ptr,
+    const int32_t* __restrict__ seg_node, const int32_t* __restrict__ src, int n_seg, int H,
+    float* __restrict__ GM, float* __restrict__ GP) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t ldp = 4 * (int64_t)H;
+    const int first = blockIdx.x * kWavesPerBlock + wave;
+    const int stride = gridDim.x * kWavesPerBlock;
+    for (int c0 = 0; c0 < H; c0 += 4 * ALIGNN_WAVE) {
+        const int f = c0 + 4 * lane;
+        if (f >= H) continue;
+        EdgeNorm nrm;
+        if (HAS_GY) {
+            nrm.mean = f4_ld(e_stat + f);
+            nrm.rstd = f4_ld(e_stat + H + f);
+            nrm.sc = f4_ld(e_stat + 2 * H + f);
+            nrm.sh = f4_ld(e_stat + 3 * H + f);
+            if (!e_eval) {
+                nrm.c0 = f4_ld(e_red + f);
+                nrm.c1 = f4_ld(e_red + H + f);
+            }
+        }
+        for (int s = first; s < n_seg; s += stride) {
+            const int beg = seg_ptr[s], end = seg_ptr[s + 1];
+            const int i = seg_node ? seg_node[s] : s;
+            const float4 gs1 = f4_ld(GS1 + (int64_t)i * H + f);
+            const float4 gs0 = f4_ld(GS0 + (int64_t)i * H + f);
+            float4 gbd = f4_zero();
+            int e = beg;
+            for (; e + 4 <= end; e += 4) {
+                float4 m[4], bh[4], gy[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int u = src[e + k];
+                    m[k] = f4_ld(M + (int64_t)(e + k) * H + f);
+                    bh[k] = f4_ld(P + (int64_t)u * ldp + 2 * H + f);
+                    if (HAS_GY) gy[k] = f4_ld(GY + (int64_t)(e + k) * H + f);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float4 gm = edge_grad<HAS_GY>(m[k], gy[k], bh[k], gs1, gs0, nrm, inv_n, e_eval);
+                    f4_st(GM + (int64_t)(e + k) * H + f, gm);
+                    gbd = f4_add(gbd, gm);
+                }
+            }
+            for (; e < end; ++e) {
+                const int u = src[e];
+                float4 m = f4_ld(M + (int64_t)e * H + f);
+                float4 bh = f4_ld(P + (int64_t)u * ldp + 2 * H + f);
+                float4 gy = f4_zero();
+                if (HAS_GY) gy = f4_ld(GY + (int64_t)e * H + f);
+                float4 gm = edge_grad<HAS_GY>(m, gy, bh, gs1, gs0, nrm, inv_n, e_eval);
+                f4_st(GM + (int64_t)e * H + f, gm);
+                gbd = f4_add(gbd, gm);
+            }
+            f4_st(GP + (int64_t)i * ldp + H + f, gbd);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward, source order (deterministic scatter-by-source as a segment sum over out-slots)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void egc_bwd_src_kernel(
+    const float* __restrict__ GM, const float* __restrict__ M, const float* __restrict__ GS1,
+    const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_slot, const int32_t* __restrict__ dst,
+    int n_nodes, int H, float* __restrict__ GP) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t ldp = 4 * (int64_t)H;
+    const int first = blockIdx.x * kWavesPerBlock + wave;
+    const int stride = gridDim.x * kWavesPerBlock;
+    for (int c0 = 0; c0 < H; c0 += 4 * ALIGNN_WAVE) {
+        const int f = c0 + 4 * lane;
+        if (f >= H) continue;
+        for (int j = first; j < n_nodes; j += stride) {
+            const int beg = out_ptr[j], end = out_ptr[j + 1];
+            float4 ga = f4_zero(), gbh = f4_zero();
+            int k = beg;
+            for (; k + 4 <= end; k += 4) {
+                float4 gm[4], m[4], g1[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int slot = out_slot[k + t];
+                    const int v = dst[slot];
+                    gm[t] = f4_ld(GM + (int64_t)slot * H + f);
+                    m[t] = f4_ld(M + (int64_t)slot * H + f);
+                    g1[t] = f4_ld(GS1 + (int64_t)v * H + f);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    ga = f4_add(ga, gm[t]);
+                    gbh = f4_fma(f4_sigmoid(m[t]), g1[t], gbh);
+                }
+            }
+            for (; k < end; ++k) {
+                const int slot = out_slot[k];
+                const int v = dst[slot];
+                ga = f4_add(ga, f4_ld(GM + (int64_t)slot * H + f));
+                gbh = f4_fma(f4_sigmoid(f4_ld(M + (int64_t)slot * H + f)), f4_ld(GS1 + (int64_t)v * H + f), gbh);
+            }
+            f4_st(GP + (int64_t)j * ldp + f, ga);
+            f4_st(GP + (int64_t)j * ldp + 2 * H + f, gbh);
+        }
+    }
+}
+
+inline bool h_ok(int H) { return H >= 4 && (H & 3) == 0 && H <= 1024; }
+
+}  // namespace
+
+extern "C" {
+
+int alignn_egc_slabs(int64_t n_seg) { return egc_blocks(n_seg); }
+
+int alignn_egc_gate_fwd(const float* P, float* M, const int32_t* seg_ptr, const int32_t* seg_node,
+                        const int32_t* src, int64_t n_seg, int64_t n_nodes, int H, float* XPRE, float* S0, float* HH,
+                        float* e_partial, float* n_partial, alignn_stream_t stream) {
+    (void)n_nodes;
+    if (!h_ok(H) || n_seg < 0 || n_seg > INT32_MAX) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(egc_gate_fwd_kernel, dim3(egc_blocks(n_seg)), dim3(kThreads), 0, (hipStream_t)stream, P, M,
+                       seg_ptr, seg_node, src, (int)n_seg, H, XPRE, S0, HH, e_partial, n_partial);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_egc_node_bwd(const float* GXPRE, int64_t ldg, const float* S0, const float* HH, float* GS1, float* GS0,
+                        int64_t n_nodes, int H, alignn_stream_t stream) {
+    if (!h_ok(H)) return (int)hipErrorInvalidValue;
+    if (n_nodes == 0) return 0;
+    int64_t g = (n_nodes * (H >> 2) + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(egc_node_bwd_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, GXPRE, ldg, S0, HH, GS1,
+                       GS0, n_nodes, H);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_egc_bwd_dst(const float* GY, const float* M, const float* P, const float* GS1, const float* GS0,
+                       const float* e_stat, const float* e_gamma, const float* e_red, int e_eval, int64_t m_rows,
+                       const int32_t* seg_ptr, const int32_t* seg_node, const int32_t* src, int64_t n_seg, int H,
+                       float* GM, float* GP, alignn_stream_t stream) {
+    (void)e_gamma;
+    if (!h_ok(H) || n_seg > INT32_MAX) return (int)hipErrorInvalidValue;
+    const float inv_n = m_rows > 0 ? 1.0f / (float)m_rows : 0.0f;
+    dim3 grid(egc_blocks(n_seg)), block(kThreads);
+    if (GY)
+        hipLaunchKernelGGL(egc_bwd_dst_kernel<true>, grid, block, 0, (hipStream_t)stream, GY, M, P, GS1, GS0, e_stat,
+                           e_red, e_eval, inv_n, seg_ptr, seg_node, src, (int)n_seg, H, GM, GP);
+    else
+        hipLaunchKernelGGL(egc_bwd_dst_kernel<false>, grid, block, 0, (hipStream_t)stream, GY, M, P, GS1, GS0, e_stat,
+                           e_red, e_eval, inv_n, seg_ptr, seg_node, src, (int)n_seg, H, GM, GP);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_egc_bwd_src(const float* GM, const float* M, const float* GS1, const int32_t* out_ptr,
+                       const int32_t* out_slot, const int32_t* dst, int64_t n_nodes, int H, float* GP,
+                       alignn_stream_t stream) {
+    if (!h_ok(H) || n_nodes > INT32_MAX) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(egc_bwd_src_kernel, dim3(egc_blocks(n_nodes)), dim3(kThreads), 0, (hipStream_t)stream, GM, M,
+                       GS1, out_ptr, out_slot, dst, (int)n_nodes, H, GP);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

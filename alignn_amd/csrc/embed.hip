@@ -1,0 +1,122 @@
+// Featurisation and readout kernels: RBF expansion, bond length, per-graph mean pooling, row gather.
+// All HBM-bound; one float4 (or one scalar) per lane, grid-stride.
+//
+// Reference: RBFExpansion.forward alignn/models/utils.py:40-44; torch.norm(r, dim=1)
+// alignn/models/alignn.py:313; dgl.nn.AvgPooling alignn/models/alignn.py:325.
+#include "common.h"
+#include "../../include/alignn_hip.h"
+
+namespace {
+
+inline int grid_for(int64_t total, int threads = 256, int cap = 2048) {
+    int64_t g = (total + threads - 1) / threads;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+__global__ void rbf_fwd_kernel(const float* __restrict__ d, const float* __restrict__ centers, float gamma,
+                               float* __restrict__ out, int64_t rows, int bins) {
+    const int64_t total = rows * bins;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = i / bins;
+        int k = (int)(i - r * bins);
+        float t = d[r] - centers[k];
+        out[i] = __expf(-gamma * t * t);
+    }
+}
+
+__global__ void norm3_fwd_kernel(const float* __restrict__ v, float* __restrict__ out, int64_t rows) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
+        float x = v[3 * r], y = v[3 * r + 1], z = v[3 * r + 2];
+        out[r] = sqrtf(x * x + y * y + z * z);
+    }
+}
+
+// one block per graph; threads own feature quads and walk the graph's nodes in order
+__global__ void segment_mean_fwd_kernel(const float* __restrict__ X, const int32_t* __restrict__ gptr,
+                                        float* __restrict__ out, int H) {
+    const int b = blockIdx.x;
+    const int beg = gptr[b], end = gptr[b + 1];
+    const float inv = end > beg ? 1.0f / (float)(end - beg) : 0.0f;
+    for (int q = threadIdx.x; q < (H >> 2); q += blockDim.x) {
+        float4 acc = f4_zero();
+        for (int i = beg; i < end; ++i) acc = f4_add(acc, f4_ld(X + (int64_t)i * H + q * 4));
+        f4_st(out + (int64_t)b * H + q * 4, make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv));
+    }
+}
+
+__global__ void segment_mean_bwd_kernel(const float* __restrict__ G, const int32_t* __restrict__ gptr,
+                                        float* __restrict__ GX, int H) {
+    const int b = blockIdx.x;
+    const int beg = gptr[b], end = gptr[b + 1];
+    const float inv = end > beg ? 1.0f / (float)(end - beg) : 0.0f;
+    const int Q = H >> 2;
+    const int total = (end - beg) * Q;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+        int r = i / Q, q = i - r * Q;
+        float4 g = f4_ld(G + (int64_t)b * H + q * 4);
+        f4_st(GX + (int64_t)(beg + r) * H + q * 4, make_float4(g.x * inv, g.y * inv, g.z * inv, g.w * inv));
+    }
+}
+
+__global__ void gather_rows_kernel(const float* __restrict__ in, const int32_t* __restrict__ perm,
+                                   float* __restrict__ out, int64_t rows, int F) {
+    const int64_t total = rows * F;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = i / F;
+        int f = (int)(i - r * F);
+        out[i] = in[(int64_t)perm[r] * F + f];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* alignn_version(void) { return "alignn_hip 0.1 gfx950"; }
+
+int alignn_rbf_fwd(const float* d, const float* centers, float gamma, float* out, int64_t rows, int bins,
+                   alignn_stream_t stream) {
+    if (bins <= 0 || rows < 0) return (int)hipErrorInvalidValue;
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(rbf_fwd_kernel, dim3(grid_for(rows * bins)), dim3(256), 0, (hipStream_t)stream, d, centers,
+                       gamma, out, rows, bins);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_norm3_fwd(const float* v, float* out, int64_t rows, alignn_stream_t stream) {
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(norm3_fwd_kernel, dim3(grid_for(rows)), dim3(256), 0, (hipStream_t)stream, v, out, rows);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_segment_mean_fwd(const float* X, const int32_t* graph_ptr, float* out, int B, int H,
+                            alignn_stream_t stream) {
+    if (B <= 0 || (H & 3)) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(segment_mean_fwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, X, graph_ptr, out, H);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_segment_mean_bwd(const float* G, const int32_t* graph_ptr, float* GX, int B, int H,
+                            alignn_stream_t stream) {
+    if (B <= 0 || (H & 3)) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(segment_mean_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, G, graph_ptr, GX, H);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_gather_rows(const float* in, const int32_t* perm, float* out, int64_t rows, int F,
+                       alignn_stream_t stream) {
+    if (F <= 0) return (int)hipErrorInvalidValue;
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(rows * F)), dim3(256), 0, (hipStream_t)stream, in, perm, out,
+                       rows, F);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,314 @@
+// fp32 GEMMs on the CDNA4 matrix cores: v_mfma_f32_32x32x2_f32 (fp32 in, fp32 accumulate, exact
+// fp32 == an fmaf chain; 157 TF peak on MI355X - there is no TF32/xf32 on gfx950).
+//
+// One kernel template covers the three products a Linear layer needs:
+//   NT  C[M,N] = A[M,K] W[N,K]^T (+bias +addend)   forward      (alignn/models/alignn.py:98-110,175,341)
+//   NN  C[M,K] = G[M,N] W[N,K]   (+addend)         input grad
+//   TN  dW[N,K] = G[M,N]^T A[M,K]                  weight grad  (split over M, fixed-order slab sum)
+// by describing each operand as either "reduction-contiguous" (RC: element (i, r) at S[i*ld + r])
+// or "index-contiguous" (IC: element (i, r) at S[r*ld + i]).  Tiles are staged global -> registers
+// -> LDS (double buffered, one barrier per 32-deep step) as whole 16-byte vectors; RC tiles are
+// stored [i][36] (144-byte rows: conflict-free ds_read_b128 of 4 consecutive r), IC tiles [r][BMN]
+// (conflict-free ds_read_b32 across lanes).  Because a sum over r may be taken in any order as
+// long as both operands agree, MFMA step s of a 32-deep block uses r = 8*(s/4) + 4*(lane/32) + s%4,
+// which lets an RC operand fetch four steps' worth of values with one ds_read_b128.
+#include "common.h"
+#include "../../include/alignn_hip.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+constexpr int RC_LD = BK + 4;  // padded row of an RC tile (floats)
+
+template <int BMN, bool RC>
+struct TileShape {
+    static constexpr int kFloats = RC ? BMN * RC_LD : BK * BMN;
+};
+
+// global -> registers -> LDS staging of one operand tile (BMN indices x BK reduction steps)
+template <int BMN, bool RC, int NT>
+struct Stager {
+    static constexpr int NV = (BMN * BK / 4) / NT;
+    static_assert((BMN * BK / 4) % NT == 0, "tile must divide over the block");
+    float4 v[NV];
+
+    __device__ __forceinline__ void load(const float* __restrict__ S, int64_t ld, int64_t i0, int64_t i_ext,
+                                         int64_t r0, int64_t r_ext, int t) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int id = t + j * NT;
+            int64_t gi, gr;
+            if (RC) {
+                gi = i0 + id / (BK / 4);
+                gr = r0 + (id % (BK / 4)) * 4;
+            } else {
+                gr = r0 + id / (BMN / 4);
+                gi = i0 + (id % (BMN / 4)) * 4;
+            }
+            if (gi < i_ext && gr < r_ext)
+                v[j] = RC ? f4_ld(S + gi * ld + gr) : f4_ld(S + gr * ld + gi);
+            else
+                v[j] = f4_zero();
+        }
+    }
+    __device__ __forceinline__ void store(float* T, int t) const {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int id = t + j * NT;
+            if (RC)
+                f4_st(T + (id / (BK / 4)) * RC_LD + (id % (BK / 4)) * 4, v[j]);
+            else
+                f4_st(T + (id / (BMN / 4)) * BMN + (id % (BMN / 4)) * 4, v[j]);
+        }
+    }
+};
+
+// fetch the fragment values of 4 consecutive MFMA steps (group j) for index row `irow`
+template <int BMN, bool RC>
+__device__ __forceinline__ void fetch4(const float* T, int irow, int j, int half, float (&out)[4]) {
+    if (RC) {
+        float4 q = f4_ld(T + irow * RC_LD + 8 * j + 4 * half);
+        out[0] = q.x;
+        out[1] = q.y;
+        out[2] = q.z;
+        out[3] = q.w;
+    } else {
+        const float* p = T + (8 * j + 4 * half) * BMN + irow;
+        out[0] = p[0];
+        out[1] = p[BMN];
+        out[2] = p[2 * BMN];
+        out[3] = p[3 * BMN];
+    }
+}
+
+struct GemmArgs {
+    const float* A;
+    int64_t lda;
+    const float* B;
+    int64_t ldb;
+    const float* bias;    // [No] or null
+    const float* addend;  // [Mo, No] or null
+    int64_t ldadd;
+    float* C;
+    int64_t ldc;
+    int64_t Mo;      // output rows
+    int No;          // output cols
+    int64_t R;       // reduction length
+    int64_t r_chunk; // reduction rows per blockIdx.z (split-R); C advances by c_split per z
+    int64_t c_split;
+};
+
+template <int BM, int BN, int WM, int WN, bool A_RC, bool B_RC>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_mfma_kernel(GemmArgs g) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int TM = BM / WM, TN = BN / WN;
+    constexpr int RM = TM / 32, RN = TN / 32;
+    constexpr int A_FL = TileShape<BM, A_RC>::kFloats, B_FL = TileShape<BN, B_RC>::kFloats;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int STAGE = A_FL + B_FL;  // stage s: A tile at smem + s*STAGE, B tile right behind it
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int il = lane & 31, half = lane >> 5;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int64_t n0 = (int64_t)blockIdx.y * BN;
+    const int64_t rbeg = (int64_t)blockIdx.z * g.r_chunk;
+    int64_t rend = rbeg + g.r_chunk;
+    if (rend > g.R) rend = g.R;
+    float* C = g.C + (int64_t)blockIdx.z * g.c_split;
+
+    f32x16 acc[RM][RN];
+#pragma unroll
+    for (int a = 0; a < RM; ++a)
+#pragma unroll
+        for (int b = 0; b < RN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    Stager<BM, A_RC, NT> sa;
+    Stager<BN, B_RC, NT> sb;
+    const int nk = rend > rbeg ? (int)((rend - rbeg + BK - 1) / BK) : 0;
+    if (nk > 0) {
+        sa.load(g.A, g.lda, m0, g.Mo, rbeg, rend, t);
+        sb.load(g.B, g.ldb, n0, g.No, rbeg, rend, t);
+        sa.store(smem, t);
+        sb.store(smem + A_FL, t);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            sa.load(g.A, g.lda, m0, g.Mo, rbeg + (int64_t)(kt + 1) * BK, rend, t);
+            sb.load(g.B, g.ldb, n0, g.No, rbeg + (int64_t)(kt + 1) * BK, rend, t);
+        }
+        const float* At = smem + cur * STAGE;
+        const float* Bt = At + A_FL;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float af[RM][4], bf[RN][4];
+#pragma unroll
+            for (int a = 0; a < RM; ++a) fetch4<BM, A_RC>(At, wm * TM + a * 32 + il, j, half, af[a]);
+#pragma unroll
+            for (int b = 0; b < RN; ++b) fetch4<BN, B_RC>(Bt, wn * TN + b * 32 + il, j, half, bf[b]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int a = 0; a < RM; ++a)
+#pragma unroll
+                    for (int b = 0; b < RN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][s], bf[b][s], acc[a][b], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            sa.store(smem + (cur ^ 1) * STAGE, t);
+            sb.store(smem + (cur ^ 1) * STAGE + A_FL, t);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: acc reg r of a 32x32 tile -> row (r&3) + 8*(r>>2) + 4*half, col lane&31
+#pragma unroll
+    for (int a = 0; a < RM; ++a) {
+#pragma unroll
+        for (int b = 0; b < RN; ++b) {
+            const int64_t col = n0 + wn * TN + b * 32 + il;
+            if (col >= g.No) continue;
+            const float bv = g.bias ? g.bias[col] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = m0 + wm * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row < g.Mo) {
+                    float v = acc[a][b][r] + bv;
+                    if (g.addend) v += g.addend[row * g.ldadd + col];
+                    C[row * g.ldc + col] = v;
+                }
+            }
+        }
+    }
+}
+
+// Plain VALU fallback for shapes the MFMA path does not take (tiny or not multiples of 4):
+// element (i, r) of A at A[i*sai + r*sar], of B at B[j*sbj + r*sbr].
+__global__ void gemm_naive_kernel(const float* __restrict__ A, int64_t sai, int64_t sar, const float* __restrict__ B,
+                                  int64_t sbj, int64_t sbr, const float* __restrict__ bias,
+                                  const float* __restrict__ addend, int64_t ldadd, float* __restrict__ C, int64_t ldc,
+                                  int64_t Mo, int No, int64_t R) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Mo * No) return;
+    int64_t i = idx / No;
+    int j = (int)(idx - i * No);
+    float acc = 0.0f;
+    for (int64_t r = 0; r < R; ++r) acc = fmaf(A[i * sai + r * sar], B[j * sbj + r * sbr], acc);
+    if (bias) acc += bias[j];
+    if (addend) acc += addend[i * ldadd + j];
+    C[i * ldc + j] = acc;
+}
+
+__global__ void slab_reduce_kernel(const float* __restrict__ ws, int splits, int64_t count, int cols,
+                                   float* __restrict__ out, int64_t ldo) {
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count) return;
+    double s = 0.0;
+    for (int k = 0; k < splits; ++k) s += (double)ws[(int64_t)k * count + idx];
+    out[(idx / cols) * ldo + (idx % cols)] = (float)s;
+}
+
+template <int BM, int BN, int WM, int WN, bool A_RC, bool B_RC>
+int launch(const GemmArgs& g, int splits, hipStream_t stream) {
+    constexpr int NT = WM * WN * 64;
+    constexpr size_t lds = 2 * (TileShape<BM, A_RC>::kFloats + TileShape<BN, B_RC>::kFloats) * sizeof(float);
+    auto kern = gemm_mfma_kernel<BM, BN, WM, WN, A_RC, B_RC>;
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    dim3 grid(alignn_ceil_div(g.Mo, BM), alignn_ceil_div(g.No, BN), splits);
+    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, stream, g);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int naive(const float* A, int64_t sai, int64_t sar, const float* B, int64_t sbj, int64_t sbr, const float* bias,
+          const float* addend, int64_t ldadd, float* C, int64_t ldc, int64_t Mo, int No, int64_t R,
+          hipStream_t stream) {
+    if (Mo * No == 0) return 0;
+    hipLaunchKernelGGL(gemm_naive_kernel, dim3(alignn_ceil_div(Mo * No, 256)), dim3(256), 0, stream, A, sai, sar, B,
+                       sbj, sbr, bias, addend, ldadd, C, ldc, Mo, No, R);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+constexpr int64_t kTnChunk = 4096;  // reduction rows per split of the weight-gradient GEMM
+inline int tn_splits(int64_t M) {
+    int64_t s = (M + kTnChunk - 1) / kTnChunk;
+    return (int)(s < 1 ? 1 : s);
+}
+
+}  // namespace
+
+extern "C" {
+
+int alignn_gemm_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, const float* addend,
+                   int64_t ldadd, float* C, int64_t ldc, int64_t M, int N, int K, alignn_stream_t stream) {
+    if (M < 0 || N <= 0 || K <= 0) return (int)hipErrorInvalidValue;
+    if (M == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec_ok = (K % 4 == 0) && (lda % 4 == 0) && (ldw % 4 == 0) && aligned16(A) && aligned16(W);
+    if (!vec_ok || N < 16)
+        return naive(A, lda, 1, W, ldw, 1, bias, addend, ldadd, C, ldc, M, N, K, st);
+    GemmArgs g{A, lda, W, ldw, bias, addend, ldadd, C, ldc, M, N, K, K, 0};
+    if (N > 128) return launch<128, 256, 2, 4, true, true>(g, 1, st);
+    if (N > 64) return launch<128, 128, 2, 2, true, true>(g, 1, st);
+    return launch<128, 64, 4, 1, true, true>(g, 1, st);
+}
+
+int alignn_gemm_nn(const float* G, int64_t ldg, const float* W, int64_t ldw, const float* addend, int64_t ldadd,
+                   float* C, int64_t ldc, int64_t M, int N, int K, alignn_stream_t stream) {
+    if (M < 0 || N <= 0 || K <= 0) return (int)hipErrorInvalidValue;
+    if (M == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    // C[M,K] = sum_n G[m,n] W[n,k]: A=G reduction-contiguous, B=W index-contiguous (index k)
+    const bool vec_ok = (N % 4 == 0) && (K % 4 == 0) && (ldg % 4 == 0) && (ldw % 4 == 0) && aligned16(G) && aligned16(W);
+    if (!vec_ok || K < 16)
+        return naive(G, ldg, 1, W, 1, ldw, nullptr, addend, ldadd, C, ldc, M, K, N, st);
+    GemmArgs g{G, ldg, W, ldw, nullptr, addend, ldadd, C, ldc, M, K, N, N, 0};
+    if (K > 128) return launch<128, 256, 2, 4, true, false>(g, 1, st);
+    if (K > 64) return launch<128, 128, 2, 2, true, false>(g, 1, st);
+    return launch<128, 64, 4, 1, true, false>(g, 1, st);
+}
+
+size_t alignn_gemm_tn_workspace(int64_t M, int N, int K) {
+    return (size_t)tn_splits(M) * (size_t)N * (size_t)K * sizeof(float);
+}
+
+int alignn_gemm_tn(const float* G, int64_t ldg, const float* A, int64_t lda, float* dW, int64_t lddw, int64_t M, int N,
+                   int K, void* workspace, size_t workspace_bytes, alignn_stream_t stream) {
+    if (M < 0 || N <= 0 || K <= 0) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    // dW[n,k] = sum_m G[m,n] A[m,k]: both operands index-contiguous, reduction over rows m
+    const bool vec_ok = (N % 4 == 0) && (K % 4 == 0) && (ldg % 4 == 0) && (lda % 4 == 0) && aligned16(G) && aligned16(A);
+    if (!vec_ok || M == 0) return naive(G, 1, ldg, A, 1, lda, nullptr, nullptr, 0, dW, lddw, N, K, M, st);
+    const int splits = tn_splits(M);
+    if (workspace_bytes < alignn_gemm_tn_workspace(M, N, K) || workspace == nullptr) return (int)hipErrorInvalidValue;
+    float* ws = (float*)workspace;
+    GemmArgs g{G, ldg, A, lda, nullptr, nullptr, 0, ws, K, N, K, M, kTnChunk, (int64_t)N * K};
+    int rc;
+    if (K > 64)
+        rc = launch<128, 128, 2, 2, false, false>(g, splits, st);
+    else
+        rc = launch<128, 64, 4, 1, false, false>(g, splits, st);
+    if (rc) return rc;
+    const int64_t count = (int64_t)N * K;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(alignn_ceil_div(count, 256)), dim3(256), 0, st, ws, splits, count, K,
+                       dW, lddw);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,280 @@
+// Column statistics, BatchNorm1d(+SiLU, +residual) forward/backward for [rows, F] fp32 matrices.
+// HBM-bound streaming kernels: float4 per lane, fixed-order two-level reductions (no atomics).
+//
+// Reference semantics: torch.nn.BatchNorm1d in training mode followed by F.silu and the residual
+// add, alignn/models/alignn.py:122-127 (conv) and :175-179 (MLPLayer).
+#include "common.h"
+#include "../../include/alignn_hip.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxSlabs = 1024;
+
+__host__ __device__ inline int slabs_for(int64_t rows) {
+    int64_t s = (rows + 255) / 256;
+    if (s < 1) s = 1;
+    if (s > kMaxSlabs) s = kMaxSlabs;
+    return (int)s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Generic column reduction: every thread owns one feature quad q = t % Q and walks rows
+// rl, rl+RP, ...  (RP = 256 / Q rows in flight per block); the RP row-lanes are then summed
+// through LDS in a fixed order.  Produces two float4 sums per quad (slab layout [2][F]).
+// ---------------------------------------------------------------------------------------------
+template <class Fn>
+__global__ __launch_bounds__(kThreads) void col_reduce_kernel(Fn fn, int64_t rows, int F, int slabs,
+                                                              float* __restrict__ partial) {
+    const int Q = F >> 2;
+    const int RP = kThreads / Q;
+    const int t = threadIdx.x;
+    const int q = t % Q;
+    const int rl = t / Q;
+    const int64_t per = (rows + slabs - 1) / slabs;
+    const int64_t r0 = (int64_t)blockIdx.x * per;
+    int64_t r1 = r0 + per;
+    if (r1 > rows) r1 = rows;
+    float4 a0 = f4_zero(), a1 = f4_zero();
+    if (rl < RP) {
+        for (int64_t r = r0 + rl; r < r1; r += RP) fn(r, q, a0, a1);
+    }
+    __shared__ float4 sh[2][kThreads];
+    sh[0][t] = a0;
+    sh[1][t] = a1;
+    __syncthreads();
+    if (rl == 0) {
+        for (int k = 1; k < RP; ++k) {
+            a0 = f4_add(a0, sh[0][k * Q + q]);
+            a1 = f4_add(a1, sh[1][k * Q + q]);
+        }
+        float* out = partial + (size_t)blockIdx.x * 2 * F;
+        f4_st(out + q * 4, a0);
+        f4_st(out + F + q * 4, a1);
+    }
+}
+
+struct StatsFn {
+    const float* X;
+    int64_t ld;
+    __device__ __forceinline__ void operator()(int64_t r, int q, float4& a0, float4& a1) const {
+        float4 v = f4_ld(X + r * ld + q * 4);
+        a0 = f4_add(a0, v);
+        a1 = f4_fma(v, v, a1);
+    }
+};
+
+struct BwdReduceFn {
+    const float* GY;
+    int64_t ldgy;
+    const float* X;
+    int64_t ldx;
+    const float* stat;  // [4][F]: mean, rstd, scale, shift
+    int F;
+    __device__ __forceinline__ void operator()(int64_t r, int q, float4& a0, float4& a1) const {
+        float4 gy = f4_ld(GY + r * ldgy + q * 4);
+        float4 x = f4_ld(X + r * ldx + q * 4);
+        float4 mean = f4_ld(stat + q * 4), rstd = f4_ld(stat + F + q * 4);
+        float4 sc = f4_ld(stat + 2 * F + q * 4), sh = f4_ld(stat + 3 * F + q * 4);
+        float4 z = f4_fma(x, sc, sh);
+        float4 gz = make_float4(gy.x * dsilu_f(z.x), gy.y * dsilu_f(z.y), gy.z * dsilu_f(z.z), gy.w * dsilu_f(z.w));
+        float4 xh = f4_mul(f4_sub(x, mean), rstd);
+        a0 = f4_add(a0, gz);
+        a1 = f4_fma(gz, xh, a1);
+    }
+};
+
+// partial [slabs][2][F] -> double sums
+__global__ void bn_finalize_kernel(const float* __restrict__ partial, int slabs, int64_t rows, int F,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                   float momentum, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, float* __restrict__ stat) {
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    float mean, var;
+    if (slabs > 0) {
+        double s = 0.0, ss = 0.0;
+        for (int k = 0; k < slabs; ++k) {
+            s += (double)partial[(size_t)k * 2 * F + f];
+            ss += (double)partial[(size_t)k * 2 * F + F + f];
+        }
+        double n = (double)rows;
+        double m = s / n;
+        double v = ss / n - m * m;
+        if (v < 0.0) v = 0.0;
+        mean = (float)m;
+        var = (float)v;
+        if (running_mean != nullptr) {
+            double unbiased = rows > 1 ? v * n / (n - 1.0) : v;
+            running_mean[f] = (1.0f - momentum) * running_mean[f] + momentum * mean;
+            running_var[f] = (1.0f - momentum) * running_var[f] + momentum * (float)unbiased;
+        }
+    } else {
+        mean = running_mean[f];
+        var = running_var[f];
+    }
+    float rstd = 1.0f / sqrtf(var + eps);
+    float g = gamma ? gamma[f] : 1.0f, b = beta ? beta[f] : 0.0f;
+    float scale = g * rstd;
+    stat[f] = mean;
+    stat[F + f] = rstd;
+    stat[2 * F + f] = scale;
+    stat[3 * F + f] = b - mean * scale;
+}
+
+__global__ void slab_sum_kernel(const float* __restrict__ partial, int slabs, int width, int stride,
+                                float* __restrict__ out) {
+    int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= width) return;
+    double s = 0.0;
+    for (int k = 0; k < slabs; ++k) s += (double)partial[(size_t)k * stride + f];
+    out[f] = (float)s;
+}
+
+// Y = R + silu(X*scale + shift)
+template <bool HAS_RES>
+__global__ __launch_bounds__(kThreads) void bn_silu_fwd_kernel(const float* __restrict__ X, int64_t ldx,
+                                                               const float* __restrict__ R, int64_t ldr,
+                                                               const float* __restrict__ stat,
+                                                               float* __restrict__ Y, int64_t ldy,
+                                                               int64_t rows, int F) {
+    const int Q = F >> 2;
+    const int64_t total = rows * Q;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
+        int64_t r = i / Q;
+        int q = (int)(i - r * Q);
+        float4 x = f4_ld(X + r * ldx + q * 4);
+        float4 sc = f4_ld(stat + 2 * F + q * 4), sh = f4_ld(stat + 3 * F + q * 4);
+        float4 z = f4_fma(x, sc, sh);
+        float4 o = make_float4(silu_f(z.x), silu_f(z.y), silu_f(z.z), silu_f(z.w));
+        if (HAS_RES) o = f4_add(o, f4_ld(R + r * ldr + q * 4));
+        f4_st(Y + r * ldy + q * 4, o);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void bn_silu_bwd_apply_kernel(
+    const float* __restrict__ GY, int64_t ldgy, const float* __restrict__ X, int64_t ldx,
+    const float* __restrict__ stat, const float* __restrict__ gamma, const float* __restrict__ red, int eval_mode,
+    float* __restrict__ GX, int64_t ldgx, int64_t rows, int F) {
+    const int Q = F >> 2;
+    const int64_t total = rows * Q;
+    const float inv_n = 1.0f / (float)rows;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
+        int64_t r = i / Q;
+        int q = (int)(i - r * Q);
+        float4 gy = f4_ld(GY + r * ldgy + q * 4);
+        float4 x = f4_ld(X + r * ldx + q * 4);
+        float4 mean = f4_ld(stat + q * 4), rstd = f4_ld(stat + F + q * 4);
+        float4 sc = f4_ld(stat + 2 * F + q * 4), sh = f4_ld(stat + 3 * F + q * 4);
+        float4 z = f4_fma(x, sc, sh);
+        float4 gz = make_float4(gy.x * dsilu_f(z.x), gy.y * dsilu_f(z.y), gy.z * dsilu_f(z.z), gy.w * dsilu_f(z.w));
+        float4 o;
+        if (eval_mode) {
+            o = f4_mul(gz, sc);
+        } else {
+            float4 xh = f4_mul(f4_sub(x, mean), rstd);
+            float4 c0 = f4_ld(red + q * 4), c1 = f4_ld(red + F + q * 4);
+            // gamma*rstd*(gz - c0/n - xh*c1/n) ; scale = gamma*rstd
+            o.x = sc.x * (gz.x - inv_n * (c0.x + xh.x * c1.x));
+            o.y = sc.y * (gz.y - inv_n * (c0.y + xh.y * c1.y));
+            o.z = sc.z * (gz.z - inv_n * (c0.z + xh.z * c1.z));
+            o.w = sc.w * (gz.w - inv_n * (c0.w + xh.w * c1.w));
+        }
+        f4_st(GX + r * ldgx + q * 4, o);
+    }
+}
+
+inline bool feat_ok(int F) { return F >= 4 && (F & 3) == 0 && F <= 1024; }
+inline int stream_grid(int64_t total) {
+    int64_t g = (total + kThreads - 1) / kThreads;
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int alignn_col_stats_slabs(int64_t rows) { return slabs_for(rows); }
+
+int alignn_col_stats(const float* X, int64_t ldx, int64_t rows, int F, float* partial, alignn_stream_t stream) {
+    if (!feat_ok(F) || rows < 0) return (int)hipErrorInvalidValue;
+    int slabs = slabs_for(rows);
+    StatsFn fn{X, ldx};
+    hipLaunchKernelGGL(col_reduce_kernel<StatsFn>, dim3(slabs), dim3(kThreads), 0, (hipStream_t)stream, fn, rows, F,
+                       slabs, partial);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_col_sum(const float* X, int64_t ldx, int64_t rows, int F, float* out, float* workspace,
+                   alignn_stream_t stream) {
+    if (!feat_ok(F) || rows < 0) return (int)hipErrorInvalidValue;
+    int slabs = slabs_for(rows);
+    StatsFn fn{X, ldx};
+    hipLaunchKernelGGL(col_reduce_kernel<StatsFn>, dim3(slabs), dim3(kThreads), 0, (hipStream_t)stream, fn, rows, F,
+                       slabs, workspace);
+    hipLaunchKernelGGL(slab_sum_kernel, dim3(alignn_ceil_div(F, 256)), dim3(256), 0, (hipStream_t)stream, workspace,
+                       slabs, F, 2 * F, out);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_bn_finalize(const float* partial, int slabs, int64_t rows, int F, const float* gamma, const float* beta,
+                       float eps, float momentum, float* running_mean, float* running_var, float* stat,
+                       alignn_stream_t stream) {
+    if (F <= 0 || (slabs == 0 && running_mean == nullptr)) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(alignn_ceil_div(F, 256)), dim3(256), 0, (hipStream_t)stream, partial,
+                       slabs, rows, F, gamma, beta, eps, momentum, running_mean, running_var, stat);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_bn_silu_fwd(const float* X, int64_t ldx, const float* R, int64_t ldr, const float* stat, float* Y,
+                       int64_t ldy, int64_t rows, int F, alignn_stream_t stream) {
+    if (!feat_ok(F)) return (int)hipErrorInvalidValue;
+    if (rows == 0) return 0;
+    int grid = stream_grid(rows * (F >> 2));
+    if (R)
+        hipLaunchKernelGGL(bn_silu_fwd_kernel<true>, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, X, ldx, R, ldr,
+                           stat, Y, ldy, rows, F);
+    else
+        hipLaunchKernelGGL(bn_silu_fwd_kernel<false>, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, X, ldx, R,
+                           ldr, stat, Y, ldy, rows, F);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_bn_silu_bwd_reduce(const float* GY, int64_t ldgy, const float* X, int64_t ldx, const float* stat,
+                              int64_t rows, int F, float* partial, alignn_stream_t stream) {
+    if (!feat_ok(F)) return (int)hipErrorInvalidValue;
+    int slabs = slabs_for(rows);
+    BwdReduceFn fn{GY, ldgy, X, ldx, stat, F};
+    hipLaunchKernelGGL(col_reduce_kernel<BwdReduceFn>, dim3(slabs), dim3(kThreads), 0, (hipStream_t)stream, fn, rows,
+                       F, slabs, partial);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_bn_bwd_finalize(const float* partial, int slabs, int F, float* red, alignn_stream_t stream) {
+    if (F <= 0 || slabs <= 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(slab_sum_kernel, dim3(alignn_ceil_div(2 * F, 256)), dim3(256), 0, (hipStream_t)stream, partial,
+                       slabs, 2 * F, 2 * F, red);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_bn_silu_bwd_apply(const float* GY, int64_t ldgy, const float* X, int64_t ldx, const float* stat,
+                             const float* gamma, const float* red, int eval_mode, float* GX, int64_t ldgx,
+                             int64_t rows, int F, alignn_stream_t stream) {
+    if (!feat_ok(F)) return (int)hipErrorInvalidValue;
+    if (rows == 0) return 0;
+    int grid = stream_grid(rows * (F >> 2));
+    hipLaunchKernelGGL(bn_silu_bwd_apply_kernel, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, GY, ldgy, X, ldx,
+                       stat, gamma, red, eval_mode, GX, ldgx, rows, F);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

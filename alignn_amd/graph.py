@@ -1,0 +1,168 @@
+"""Canonical device layout of a batched (g, L(g)) pair.
+
+The reference hands the model two DGL graphs in arbitrary COO order
+(``alignn/train.py:264-270``; built by ``alignn/graphs.py:472-592`` and batched by
+``alignn/lmdb_dataset.py:87-108``).  The kernels want *segments*: all in-edges of one destination
+stored contiguously, so that one wavefront owns one destination and edge-feature row ``k`` is CSR
+slot ``k`` (see include/alignn_hip.h).  This module converts once per batch (pure index work,
+device agnostic so it is unit-testable on CPU) and the result is cached on the batch.
+
+Layout chosen for locality on MI355X:
+
+* ``g``: edges sorted by destination atom -> the in-edges of atom ``j`` are consecutive rows.
+* ``L(g)``: its nodes are g's edges *in that canonical order*; its segments (one per bond
+  ``e2 = j->k``) are ordered by the bond's source atom ``j``.  All bonds leaving atom ``j`` gather
+  the same block of rows (the in-edges of ``j``), so consecutive wavefronts re-read the same
+  ~13 KiB-per-tensor block from L1/L2 instead of HBM.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+
+@dataclass
+class CSRGraph:
+    """One graph in canonical segment order (all index tensors int32, on the compute device)."""
+
+    n_nodes: int
+    n_edges: int
+    seg_ptr: torch.Tensor  # [n_nodes+1] segment s covers slots [seg_ptr[s], seg_ptr[s+1])
+    seg_node: Optional[torch.Tensor]  # [n_nodes] node of segment s (None: identity)
+    src: torch.Tensor  # [m] source node of slot k
+    dst: torch.Tensor  # [m] destination node of slot k
+    out_ptr: torch.Tensor  # [n_nodes+1] by-source grouping ...
+    out_slot: torch.Tensor  # [m] ... of slot ids
+    perm: torch.Tensor  # [m] int64: slot k holds the caller's edge perm[k]
+    inv: torch.Tensor  # [m] int64: caller's edge e lives in slot inv[e]
+
+
+def _ptr_from_counts(counts: torch.Tensor) -> torch.Tensor:
+    out = torch.zeros(counts.numel() + 1, dtype=torch.int64, device=counts.device)
+    out[1:] = torch.cumsum(counts, 0)
+    return out
+
+
+def build_csr(u: torch.Tensor, v: torch.Tensor, n_nodes: int, seg_order: Optional[torch.Tensor] = None) -> CSRGraph:
+    """Canonicalise COO edges ``u -> v``.
+
+    ``seg_order`` (optional, int64 [n_nodes]) lists the nodes in the order their segments should be
+    stored; default is node order.  Within a segment, edges keep the caller's relative order
+    (stable), so the summation order inside a segment is a deterministic function of the input.
+    """
+    u = u.to(torch.int64)
+    v = v.to(torch.int64)
+    m = int(u.numel())
+    dev = u.device
+    counts = torch.bincount(v, minlength=n_nodes)
+    if seg_order is None:
+        key = v
+        seg_node = None
+        seg_counts = counts
+    else:
+        rank = torch.empty(n_nodes, dtype=torch.int64, device=dev)
+        rank[seg_order] = torch.arange(n_nodes, device=dev)
+        key = rank[v]
+        seg_node = seg_order.to(torch.int32)
+        seg_counts = counts[seg_order]
+    perm = torch.argsort(key, stable=True)
+    inv = torch.empty(m, dtype=torch.int64, device=dev)
+    inv[perm] = torch.arange(m, device=dev)
+    src = u[perm]
+    dst = v[perm]
+    out_slot = torch.argsort(src, stable=True)
+    out_ptr = _ptr_from_counts(torch.bincount(src, minlength=n_nodes))
+    return CSRGraph(
+        n_nodes=n_nodes,
+        n_edges=m,
+        seg_ptr=_ptr_from_counts(seg_counts).to(torch.int32),
+        seg_node=seg_node,
+        src=src.to(torch.int32),
+        dst=dst.to(torch.int32),
+        out_ptr=out_ptr.to(torch.int32),
+        out_slot=out_slot.to(torch.int32),
+        perm=perm,
+        inv=inv,
+    )
+
+
+@dataclass
+class GraphBatch:
+    """Canonical (g, L(g)) batch plus the canonically ordered inputs."""
+
+    g: CSRGraph
+    lg: Optional[CSRGraph]
+    graph_ptr: torch.Tensor  # int32 [B+1] node offsets per crystal
+    batch_size: int
+    atom_features: Optional[torch.Tensor] = None  # [N, F]
+    r: Optional[torch.Tensor] = None  # [E, 3] canonical g-slot order
+    h: Optional[torch.Tensor] = None  # [T]    canonical lg-slot order
+
+    @property
+    def device(self):
+        return self.graph_ptr.device
+
+    @staticmethod
+    def from_coo(u, v, n_nodes, batch_num_nodes, lg_u=None, lg_v=None, atom_features=None, r=None, h=None, device=None):
+        """Build from raw COO tensors (caller's edge order)."""
+        dev = torch.device(device) if device is not None else u.device
+        u = torch.as_tensor(u).to(dev)
+        v = torch.as_tensor(v).to(dev)
+        g = build_csr(u, v, int(n_nodes))
+        lg = None
+        if lg_u is not None:
+            e1 = g.inv[torch.as_tensor(lg_u).to(dev).to(torch.int64)]
+            e2 = g.inv[torch.as_tensor(lg_v).to(dev).to(torch.int64)]
+            m = g.n_edges
+            # order L(g)'s segments (bonds e2) by the bond's source atom, then by bond id
+            seg_order = torch.argsort(g.src.to(torch.int64) * m + torch.arange(m, device=dev), stable=True)
+            lg = build_csr(e1, e2, m, seg_order)
+        bnn = torch.as_tensor(batch_num_nodes).to(dev).to(torch.int64)
+        gp = _ptr_from_counts(bnn).to(torch.int32)
+        out = GraphBatch(g=g, lg=lg, graph_ptr=gp, batch_size=int(bnn.numel()))
+        if atom_features is not None:
+            out.atom_features = torch.as_tensor(atom_features).to(dev).contiguous()
+        if r is not None:
+            out.r = torch.as_tensor(r).to(dev)[g.perm].contiguous()
+        if h is not None and lg is not None:
+            out.h = torch.as_tensor(h).to(dev)[lg.perm].contiguous()
+        return out
+
+    @staticmethod
+    def from_raw(raw, device=None, dtype=torch.float32):
+        """From an ``alignn_amd.synthetic.RawGraph`` (numpy)."""
+        t = torch.from_numpy
+        return GraphBatch.from_coo(
+            t(raw.u),
+            t(raw.v),
+            raw.num_nodes,
+            t(raw.batch_num_nodes),
+            t(raw.lg_u),
+            t(raw.lg_v),
+            t(raw.atom_features).to(dtype),
+            t(raw.r).to(dtype),
+            t(raw.h).to(dtype),
+            device=device,
+        )
+
+    @staticmethod
+    def from_dgl(g, lg=None, device=None):
+        """From DGL-like graphs: anything exposing ``edges()``, ``num_nodes()``, ``batch_num_nodes()``
+        and ``ndata`` / ``edata`` dicts (a real ``dgl.DGLGraph`` or the oracle shim).  Reads
+        ``g.ndata['atom_features']``, ``g.edata['r']``, ``lg.edata['h']`` exactly as
+        ``ALIGNN.forward`` does (alignn/models/alignn.py:298,307,313) without popping them."""
+        u, v = g.edges()
+        dev = torch.device(device) if device is not None else u.device
+        kw = {}
+        if lg is not None:
+            kw["lg_u"], kw["lg_v"] = lg.edges()
+            if "h" in lg.edata:
+                kw["h"] = lg.edata["h"]
+        if "atom_features" in g.ndata:
+            kw["atom_features"] = g.ndata["atom_features"]
+        if "r" in g.edata:
+            kw["r"] = g.edata["r"]
+        return GraphBatch.from_coo(u, v, g.num_nodes(), g.batch_num_nodes(), device=dev, **kw)

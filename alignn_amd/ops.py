@@ -1,0 +1,362 @@
+"""torch.autograd glue over the C ABI of libalignn_hip.so.
+
+Every forward/backward here is a fixed sequence of kernel launches on the current HIP stream;
+torch only provides the tensors (caching allocator) and the autograd tape.  Nothing in this file
+computes on the CPU or through torch kernels (a handful of tiny ``torch.empty`` / ``torch.cat``
+bookkeeping calls aside), and nothing falls back if the library is missing.
+"""
+
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, require_f32, stream
+from .graph import CSRGraph
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def _empty(*shape, like):
+    return torch.empty(*shape, dtype=torch.float32, device=like.device)
+
+
+# ---------------------------------------------------------------------------------------------
+# thin launch wrappers
+# ---------------------------------------------------------------------------------------------
+def gemm_nt(a, w, bias=None, addend=None, out=None):
+    """out[M,N] = a[M,K] @ w[N,K]^T (+bias) (+addend)."""
+    lib = _lib.load()
+    require_f32(a, w, bias, addend)
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = _empty(M, N, like=a)
+    check(
+        lib.alignn_gemm_nt(ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(bias), ptr(addend),
+                           addend.stride(0) if addend is not None else 0, ptr(out), out.stride(0), M, N, K, stream()),
+        "gemm_nt",
+    )
+    return out
+
+
+def gemm_nn(g, w, addend=None, out=None):
+    """out[M,K] = g[M,N] @ w[N,K] (+addend)."""
+    lib = _lib.load()
+    require_f32(g, w, addend)
+    M, N = g.shape
+    K = w.shape[1]
+    if out is None:
+        out = _empty(M, K, like=g)
+    check(
+        lib.alignn_gemm_nn(ptr(g), g.stride(0), ptr(w), w.stride(0), ptr(addend),
+                           addend.stride(0) if addend is not None else 0, ptr(out), out.stride(0), M, N, K, stream()),
+        "gemm_nn",
+    )
+    return out
+
+
+def gemm_tn(g, a):
+    """dW[N,K] = g[M,N]^T @ a[M,K] (deterministic split over M)."""
+    lib = _lib.load()
+    require_f32(g, a)
+    M, N = g.shape
+    K = a.shape[1]
+    out = _empty(N, K, like=g)
+    nbytes = lib.alignn_gemm_tn_workspace(M, N, K)
+    ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=g.device)
+    check(
+        lib.alignn_gemm_tn(ptr(g), g.stride(0), ptr(a), a.stride(0), ptr(out), out.stride(0), M, N, K, ptr(ws), nbytes,
+                           stream()),
+        "gemm_tn",
+    )
+    return out
+
+
+def col_sum(x):
+    lib = _lib.load()
+    rows, F = x.shape
+    out = _empty(F, like=x)
+    ws = _empty(lib.alignn_col_stats_slabs(rows) * 2 * F, like=x)
+    check(lib.alignn_col_sum(ptr(x), x.stride(0), rows, F, ptr(out), ptr(ws), stream()), "col_sum")
+    return out
+
+
+def _bn_finalize(partial, slabs, rows, gamma, beta, running_mean, running_var, update_running):
+    """-> stat [4,F] = mean, rstd, scale, shift.  slabs == 0: evaluation mode (running statistics)."""
+    lib = _lib.load()
+    F = gamma.numel()
+    stat = _empty(4, F, like=gamma)
+    rm = running_mean if (update_running or slabs == 0) else None
+    rv = running_var if (update_running or slabs == 0) else None
+    check(
+        lib.alignn_bn_finalize(ptr(partial), slabs, rows, F, ptr(gamma), ptr(beta), BN_EPS, BN_MOMENTUM, ptr(rm),
+                               ptr(rv), ptr(stat), stream()),
+        "bn_finalize",
+    )
+    return stat
+
+
+def _bn_silu_fwd(x, res, stat):
+    lib = _lib.load()
+    rows, F = x.shape
+    y = _empty(rows, F, like=x)
+    check(
+        lib.alignn_bn_silu_fwd(ptr(x), x.stride(0), ptr(res), res.stride(0) if res is not None else 0, ptr(stat),
+                               ptr(y), y.stride(0), rows, F, stream()),
+        "bn_silu_fwd",
+    )
+    return y
+
+
+def _bn_silu_bwd_reduce(gy, x, stat):
+    """-> red [2,F]: sum gz (= dbeta), sum gz*xhat (= dgamma)."""
+    lib = _lib.load()
+    rows, F = x.shape
+    slabs = lib.alignn_col_stats_slabs(rows)
+    partial = _empty(slabs, 2, F, like=x)
+    check(
+        lib.alignn_bn_silu_bwd_reduce(ptr(gy), gy.stride(0), ptr(x), x.stride(0), ptr(stat), rows, F, ptr(partial),
+                                      stream()),
+        "bn_silu_bwd_reduce",
+    )
+    red = _empty(2, F, like=x)
+    check(lib.alignn_bn_bwd_finalize(ptr(partial), slabs, F, ptr(red), stream()), "bn_bwd_finalize")
+    return red
+
+
+def _bn_silu_bwd_apply(gy, x, stat, gamma, red, eval_mode, out):
+    lib = _lib.load()
+    rows, F = x.shape
+    check(
+        lib.alignn_bn_silu_bwd_apply(ptr(gy), gy.stride(0), ptr(x), x.stride(0), ptr(stat), ptr(gamma), ptr(red),
+                                     int(eval_mode), ptr(out), out.stride(0), rows, F, stream()),
+        "bn_silu_bwd_apply",
+    )
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# Linear
+# ---------------------------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    """nn.Linear on the MFMA GEMMs (alignn/models/alignn.py:341 ``fc`` and stand-alone projections)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        x = x.contiguous()
+        w = w.contiguous()
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return gemm_nt(x, w, b)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = gemm_nn(gy, w) if ctx.needs_input_grad[0] else None
+        gw = gemm_tn(gy, x) if ctx.needs_input_grad[1] else None
+        gb = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            if gy.shape[1] % 4 == 0:
+                gb = col_sum(gy)
+            else:  # e.g. the 1-wide readout fc: gb[n] = (gy^T @ ones)[n]
+                ones = torch.ones(gy.shape[0], 1, dtype=torch.float32, device=gy.device)
+                gb = gemm_tn(gy, ones).reshape(-1)
+        return gx, gw, gb
+
+
+def linear(x, w, b=None):
+    return LinearFn.apply(x, w, b)
+
+
+# ---------------------------------------------------------------------------------------------
+# MLPLayer = Linear + BatchNorm1d + SiLU   (alignn/models/alignn.py:170-184)
+# ---------------------------------------------------------------------------------------------
+class MLPLayerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, gamma, beta, running_mean, running_var, training):
+        lib = _lib.load()
+        x = x.contiguous()
+        w = w.contiguous()
+        pre = gemm_nt(x, w, b)
+        rows, F = pre.shape
+        if training:
+            slabs = lib.alignn_col_stats_slabs(rows)
+            partial = _empty(slabs, 2, F, like=pre)
+            check(lib.alignn_col_stats(ptr(pre), pre.stride(0), rows, F, ptr(partial), stream()), "col_stats")
+            stat = _bn_finalize(partial, slabs, rows, gamma, beta, running_mean, running_var, True)
+        else:
+            stat = _bn_finalize(None, 0, rows, gamma, beta, running_mean, running_var, False)
+        y = _bn_silu_fwd(pre, None, stat)
+        ctx.save_for_backward(x, w, pre, stat, gamma)
+        ctx.training = training
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, pre, stat, gamma = ctx.saved_tensors
+        gy = gy.contiguous()
+        red = None
+        dgamma = dbeta = None
+        red = _bn_silu_bwd_reduce(gy, pre, stat)
+        dbeta, dgamma = red[0], red[1]
+        gpre = _bn_silu_bwd_apply(gy, pre, stat, gamma, red, not ctx.training, torch.empty_like(pre))
+        gx = gemm_nn(gpre, w) if ctx.needs_input_grad[0] else None
+        gw = gemm_tn(gpre, x)
+        gb = col_sum(gpre)
+        return gx, gw, gb, dgamma, dbeta, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------
+# EdgeGatedGraphConv   (alignn/models/alignn.py:78-129)
+# ---------------------------------------------------------------------------------------------
+class EdgeGatedConvFn(torch.autograd.Function):
+    """Whole convolution as one autograd node with a hand-written backward.
+
+    Inputs are in the canonical segment order of ``graph`` (edge row k == CSR slot k).
+    ``wcat`` = cat(src_gate, dst_gate, dst_update, src_update).weight  [4H,H];  ``bcat`` likewise.
+    """
+
+    @staticmethod
+    def forward(ctx, graph: CSRGraph, x, y, wcat, bcat, w_eg, b_eg, n_gamma, n_beta, n_rm, n_rv, e_gamma, e_beta, e_rm,
+                e_rv, training: bool, residual: bool):
+        lib = _lib.load()
+        ctx.set_materialize_grads(False)
+        x = x.contiguous()
+        y = y.contiguous()
+        n, H = x.shape
+        m = y.shape[0]
+        if n != graph.n_nodes or m != graph.n_edges:
+            raise ValueError(f"feature rows ({n},{m}) do not match graph ({graph.n_nodes},{graph.n_edges})")
+        P = gemm_nt(x, wcat, bcat)  # [n,4H] = A | Bd | Bh | Ux
+        M = gemm_nt(y, w_eg, b_eg)  # [m,H]  -> m_pre in place
+        xpre = _empty(n, H, like=x)
+        s0 = _empty(n, H, like=x)
+        hh = _empty(n, H, like=x)
+        slabs = lib.alignn_egc_slabs(n)
+        e_part = _empty(slabs, 2, H, like=x) if training else None
+        n_part = _empty(slabs, 2, H, like=x) if training else None
+        check(
+            lib.alignn_egc_gate_fwd(ptr(P), ptr(M), ptr(graph.seg_ptr), ptr(graph.seg_node), ptr(graph.src), n, n, H,
+                                    ptr(xpre), ptr(s0), ptr(hh), ptr(e_part), ptr(n_part), stream()),
+            "egc_gate_fwd",
+        )
+        if training:
+            n_stat = _bn_finalize(n_part, slabs, n, n_gamma, n_beta, n_rm, n_rv, True)
+            e_stat = _bn_finalize(e_part, slabs, m, e_gamma, e_beta, e_rm, e_rv, True)
+        else:
+            n_stat = _bn_finalize(None, 0, n, n_gamma, n_beta, n_rm, n_rv, False)
+            e_stat = _bn_finalize(None, 0, m, e_gamma, e_beta, e_rm, e_rv, False)
+        x_out = _bn_silu_fwd(xpre, x if residual else None, n_stat)
+        y_out = _bn_silu_fwd(M, y if residual else None, e_stat)
+        ctx.graph = graph
+        ctx.training = training
+        ctx.residual = residual
+        ctx.save_for_backward(x, y, wcat, w_eg, P, M, xpre, s0, hh, n_stat, e_stat, n_gamma, e_gamma)
+        return x_out, y_out
+
+    @staticmethod
+    def backward(ctx, gx_out, gy_out):
+        lib = _lib.load()
+        graph: CSRGraph = ctx.graph
+        x, y, wcat, w_eg, P, M, xpre, s0, hh, n_stat, e_stat, n_gamma, e_gamma = ctx.saved_tensors
+        n, H = x.shape
+        m = y.shape[0]
+        ev = not ctx.training
+        if gx_out is None:
+            gx_out = torch.zeros_like(x)
+        gx_out = gx_out.contiguous()
+        GP = _empty(n, 4 * H, like=x)
+        # node branch: SiLU/BatchNorm backward -> g_xpre (stored as the Ux block of GP)
+        n_red = _bn_silu_bwd_reduce(gx_out, xpre, n_stat)
+        g_xpre = GP[:, 3 * H:]
+        _bn_silu_bwd_apply(gx_out, xpre, n_stat, n_gamma, n_red, ev, g_xpre)
+        gs1 = _empty(n, H, like=x)
+        gs0 = _empty(n, H, like=x)
+        check(lib.alignn_egc_node_bwd(ptr(g_xpre), 4 * H, ptr(s0), ptr(hh), ptr(gs1), ptr(gs0), n, H, stream()),
+              "egc_node_bwd")
+        # edge branch
+        e_red = None
+        if gy_out is not None:
+            gy_out = gy_out.contiguous()
+            e_red = _bn_silu_bwd_reduce(gy_out, M, e_stat)
+        GM = _empty(m, H, like=x)
+        check(
+            lib.alignn_egc_bwd_dst(ptr(gy_out), ptr(M), ptr(P), ptr(gs1), ptr(gs0), ptr(e_stat), ptr(e_gamma),
+                                   ptr(e_red), int(ev), m, ptr(graph.seg_ptr), ptr(graph.seg_node), ptr(graph.src), n,
+                                   H, ptr(GM), ptr(GP), stream()),
+            "egc_bwd_dst",
+        )
+        check(
+            lib.alignn_egc_bwd_src(ptr(GM), ptr(M), ptr(gs1), ptr(graph.out_ptr), ptr(graph.out_slot), ptr(graph.dst),
+                                   n, H, ptr(GP), stream()),
+            "egc_bwd_src",
+        )
+        # projections
+        g_x = gemm_nn(GP, wcat, addend=gx_out if ctx.residual else None)
+        g_wcat = gemm_tn(GP, x)
+        g_bcat = col_sum(GP)
+        g_y = gemm_nn(GM, w_eg, addend=gy_out if (ctx.residual and gy_out is not None) else None)
+        g_weg = gemm_tn(GM, y)
+        g_beg = col_sum(GM)
+        dn_gamma, dn_beta = n_red[1], n_red[0]
+        de_gamma = e_red[1] if e_red is not None else None
+        de_beta = e_red[0] if e_red is not None else None
+        return (None, g_x, g_y, g_wcat, g_bcat, g_weg, g_beg, dn_gamma, dn_beta, None, None, de_gamma, de_beta, None,
+                None, None, None)
+
+
+# ---------------------------------------------------------------------------------------------
+# featurisation / readout
+# ---------------------------------------------------------------------------------------------
+def rbf_expand(d, centers, gamma):
+    """RBFExpansion.forward (alignn/models/utils.py:40-44). Inputs carry no gradient on this path."""
+    lib = _lib.load()
+    if d.requires_grad:
+        raise NotImplementedError("gradient w.r.t. distances (force head) is not part of this build yet")
+    require_f32(d, centers)
+    d = d.contiguous()
+    rows, bins = d.numel(), centers.numel()
+    out = _empty(rows, bins, like=d)
+    check(lib.alignn_rbf_fwd(ptr(d), ptr(centers), float(gamma), ptr(out), rows, bins, stream()), "rbf_fwd")
+    return out
+
+
+def bond_length(r):
+    """torch.norm(r, dim=1) (alignn/models/alignn.py:313)."""
+    lib = _lib.load()
+    if r.requires_grad:
+        raise NotImplementedError("gradient w.r.t. bond vectors (force head) is not part of this build yet")
+    require_f32(r)
+    r = r.contiguous()
+    out = _empty(r.shape[0], like=r)
+    check(lib.alignn_norm3_fwd(ptr(r), ptr(out), r.shape[0], stream()), "norm3_fwd")
+    return out
+
+
+class AvgPoolFn(torch.autograd.Function):
+    """dgl.nn.AvgPooling (alignn/models/alignn.py:325): per-crystal mean over atoms."""
+
+    @staticmethod
+    def forward(ctx, x, graph_ptr):
+        lib = _lib.load()
+        x = x.contiguous()
+        B = graph_ptr.numel() - 1
+        H = x.shape[1]
+        out = _empty(B, H, like=x)
+        check(lib.alignn_segment_mean_fwd(ptr(x), ptr(graph_ptr), ptr(out), B, H, stream()), "segment_mean_fwd")
+        ctx.save_for_backward(graph_ptr)
+        ctx.n = x.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        (graph_ptr,) = ctx.saved_tensors
+        g = g.contiguous()
+        B, H = g.shape
+        gx = _empty(ctx.n, H, like=g)
+        check(lib.alignn_segment_mean_bwd(ptr(g), ptr(graph_ptr), ptr(gx), B, H, stream()), "segment_mean_bwd")
+        return gx, None

@@ -1,0 +1,176 @@
+/*
+ * alignn_hip.h - C ABI of libalignn_hip.so: the MI355X (gfx950) kernels behind the
+ * ALIGNN message-passing hot path.
+ *
+ * Drop-in boundary.  The reference (usnistgov/alignn) is pure Python; the "FFI" it has for this
+ * path is the set of torch / DGL calls its model files make.  Each entry point below names the
+ * reference call site(s) it replaces (paths relative to the reference root).  A maintainer binds
+ * them with ctypes; nothing torch-specific crosses this boundary.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers into buffers owned by the caller (PyTorch's caching
+ *     allocator in our host code); the library never allocates, frees or synchronises;
+ *   - every call only enqueues work on `stream` (graph-capture safe) and returns a hipError_t
+ *     as int (0 == hipSuccess); argument errors return hipErrorInvalidValue (1);
+ *   - matrices are row-major fp32; `ld*` are leading dimensions in ELEMENTS;
+ *   - graph structure is "canonical CSR": the m edges of a graph are stored so that the in-edges
+ *     of one destination node are contiguous ("segment").  Segment s covers edge rows
+ *     [seg_ptr[s], seg_ptr[s+1]) and belongs to node seg_node[s] (seg_node == NULL: node s).
+ *     Edge-feature row k IS CSR slot k.  `src[k]` is the source node of slot k.  The by-source
+ *     view (needed by backward) is out_ptr[n+1] / out_slot[m] (slots grouped by source node) and
+ *     `dst[k]`, the destination node of slot k.  Indices are int32;
+ *   - reductions are atomics-free and run in a fixed order: results are bit-reproducible from
+ *     run to run (the reference trains with torch.use_deterministic_algorithms(True),
+ *     alignn/train.py:164-179).
+ */
+#ifndef ALIGNN_HIP_H
+#define ALIGNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* alignn_stream_t; /* hipStream_t */
+
+/* Library / build identification: returns a static string such as "alignn_hip 0.1 gfx950". */
+const char* alignn_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense projections (fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32; exact fp32).
+ * Replace torch.nn.Linear forward/backward at alignn/models/alignn.py:98-99,101,104,110
+ * (src_gate, dst_gate, edge_gate, dst_update, src_update), :175-177 (MLPLayer) and :341 (fc).
+ * ------------------------------------------------------------------------------------------ */
+
+/* C[M,N] = A[M,K] * W[N,K]^T (+ bias[N]) (+ addend[M,N])      -- nn.Linear forward */
+int alignn_gemm_nt(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
+                   const float* addend, int64_t ldadd, float* C, int64_t ldc,
+                   int64_t M, int N, int K, alignn_stream_t stream);
+
+/* C[M,K] = G[M,N] * W[N,K] (+ addend[M,K])                    -- nn.Linear input gradient */
+int alignn_gemm_nn(const float* G, int64_t ldg, const float* W, int64_t ldw,
+                   const float* addend, int64_t ldadd, float* C, int64_t ldc,
+                   int64_t M, int N, int K, alignn_stream_t stream);
+
+/* dW[N,K] = G[M,N]^T * A[M,K]                                  -- nn.Linear weight gradient.
+ * Split over M in `splits` deterministic slabs; `workspace` holds splits*N*K floats
+ * (alignn_gemm_tn_workspace tells how many bytes for a given shape). */
+size_t alignn_gemm_tn_workspace(int64_t M, int N, int K);
+int alignn_gemm_tn(const float* G, int64_t ldg, const float* A, int64_t lda, float* dW, int64_t lddw,
+                   int64_t M, int N, int K, void* workspace, size_t workspace_bytes,
+                   alignn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Column statistics / BatchNorm1d + SiLU (+ residual).
+ * Replace nn.BatchNorm1d (training: batch statistics over ALL rows; eps 1e-5; momentum 0.1,
+ * unbiased running_var) + F.silu at alignn/models/alignn.py:122-127 and :175-179.
+ * ------------------------------------------------------------------------------------------ */
+
+/* number of partial slabs alignn_col_stats writes for `rows` rows (each slab = 2*F floats) */
+int alignn_col_stats_slabs(int64_t rows);
+/* partial[s][0][f] = sum_r X[r,f], partial[s][1][f] = sum_r X[r,f]^2 over slab s's rows */
+int alignn_col_stats(const float* X, int64_t ldx, int64_t rows, int F, float* partial,
+                     alignn_stream_t stream);
+/* column sums only: out[f] = sum_r X[r,f] (bias gradients); workspace = slabs*2*F floats */
+int alignn_col_sum(const float* X, int64_t ldx, int64_t rows, int F, float* out, float* workspace,
+                   alignn_stream_t stream);
+
+/* Finalise: from `slabs` partial slabs over `rows` rows produce, per feature,
+ *   stat[0]=mean, stat[1]=rstd, stat[2]=scale=gamma*rstd, stat[3]=shift=beta-mean*scale   (stat is [4][F])
+ * and (if running_mean != NULL) update running_mean/var in place with `momentum`.
+ * slabs == 0: evaluation mode - take mean/var from running_mean/running_var. */
+int alignn_bn_finalize(const float* partial, int slabs, int64_t rows, int F, const float* gamma,
+                       const float* beta, float eps, float momentum, float* running_mean,
+                       float* running_var, float* stat, alignn_stream_t stream);
+
+/* Y[r,f] = (R ? R[r,f] : 0) + silu(X[r,f]*scale[f] + shift[f]) */
+int alignn_bn_silu_fwd(const float* X, int64_t ldx, const float* R, int64_t ldr, const float* stat,
+                       float* Y, int64_t ldy, int64_t rows, int F, alignn_stream_t stream);
+
+/* backward, phase 1: partial[s][0][f] = sum_r gz, partial[s][1][f] = sum_r gz*xhat, where
+ * z = X*scale+shift, gz = GY * silu'(z), xhat = (X-mean)*rstd */
+int alignn_bn_silu_bwd_reduce(const float* GY, int64_t ldgy, const float* X, int64_t ldx,
+                              const float* stat, int64_t rows, int F, float* partial,
+                              alignn_stream_t stream);
+/* phase 1b: red[0][f]=sum gz (=dbeta), red[1][f]=sum gz*xhat (=dgamma) from the slabs */
+int alignn_bn_bwd_finalize(const float* partial, int slabs, int F, float* red, alignn_stream_t stream);
+/* phase 2: GX = gamma*rstd*(gz - red0/rows - xhat*red1/rows)   (training-mode BatchNorm backward)
+ * eval_mode != 0: GX = gz*scale (running statistics are constants) */
+int alignn_bn_silu_bwd_apply(const float* GY, int64_t ldgy, const float* X, int64_t ldx,
+                             const float* stat, const float* gamma, const float* red, int eval_mode,
+                             float* GX, int64_t ldgx, int64_t rows, int F, alignn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Edge-gated graph convolution core (gather -> gate -> segment-sum), one wavefront per
+ * destination segment.  Replaces, in EdgeGatedGraphConv.forward (alignn/models/alignn.py:78-129):
+ *   g.apply_edges(fn.u_add_v("e_src","e_dst","e_nodes"))            :100   (DGL g-SDDMM)
+ *   m = e_nodes + edge_gate(edge_feats); sigma = sigmoid(m)           :101-103
+ *   g.update_all(fn.u_mul_e("Bh","sigma","m"), fn.sum(...))           :105-107 (DGL g-SpMM)
+ *   g.update_all(fn.copy_e("sigma","m"), fn.sum("m","sum_sigma"))     :108
+ *   h = sum_sigma_h / (sum_sigma + 1e-6); x = src_update(x) + h       :109-110
+ * and DGL's autograd of those calls (backward).
+ *
+ * P is the fused node projection [n, 4H] = [A | Bd | Bh | Ux] = x * [W_sg;W_dg;W_du;W_su]^T + b.
+ * ------------------------------------------------------------------------------------------ */
+
+/* number of stat slabs the gate kernel writes (each 2*H floats) for a graph with n segments */
+int alignn_egc_slabs(int64_t n_seg);
+
+/* In : P[n,4H]; M[m,H] holds C = y*W_eg^T + b on entry.
+ * Out: M[m,H] = m_pre = A[src] + Bd[dst] + C (in place); XPRE[n,H] = Ux + S1/(S0+1e-6);
+ *      S0[n,H], HH[n,H] = S1/(S0+1e-6) (saved for backward; may be NULL for inference);
+ *      e_partial: column-stat slabs of m_pre; n_partial: column-stat slabs of XPRE (each may be NULL). */
+int alignn_egc_gate_fwd(const float* P, float* M, const int32_t* seg_ptr, const int32_t* seg_node,
+                        const int32_t* src, int64_t n_seg, int64_t n_nodes, int H, float* XPRE,
+                        float* S0, float* HH, float* e_partial, float* n_partial,
+                        alignn_stream_t stream);
+
+/* Node-side backward glue: from g_xpre (BatchNorm-backward output on nodes) produce
+ * GS1 = g_xpre/(S0+eps), GS0 = -g_xpre*HH/(S0+eps).  GXPRE has leading dimension ldg (it usually
+ * lives in the Ux block of the [n,4H] projection gradient). */
+int alignn_egc_node_bwd(const float* GXPRE, int64_t ldg, const float* S0, const float* HH, float* GS1, float* GS0,
+                        int64_t n_nodes, int H, alignn_stream_t stream);
+
+/* Destination-ordered backward pass.  Per slot e (dst i, src u):
+ *   g_mbn = BatchNorm/SiLU backward of the edge branch (skipped when GY == NULL: dead edge output)
+ *   sigma = sigmoid(M[e]);  g_sigma = GS1[i]*Bh[u] + GS0[i]
+ *   GM[e] = g_mbn + g_sigma*sigma*(1-sigma);   GP[i, H:2H] (g_Bd) = sum_e GM[e]
+ * GP is the [n,4H] gradient of the fused node projection; this pass fills its Bd block. */
+int alignn_egc_bwd_dst(const float* GY, const float* M, const float* P, const float* GS1,
+                       const float* GS0, const float* e_stat, const float* e_gamma,
+                       const float* e_red, int e_eval, int64_t m_rows,
+                       const int32_t* seg_ptr, const int32_t* seg_node, const int32_t* src,
+                       int64_t n_seg, int H, float* GM, float* GP, alignn_stream_t stream);
+
+/* Source-ordered backward pass (deterministic scatter-by-source):
+ *   GP[j, 0:H]   (g_A)  = sum_{e: src e = j} GM[e]
+ *   GP[j, 2H:3H] (g_Bh) = sum_{e: src e = j} sigmoid(M[e]) * GS1[dst e] */
+int alignn_egc_bwd_src(const float* GM, const float* M, const float* GS1, const int32_t* out_ptr,
+                       const int32_t* out_slot, const int32_t* dst, int64_t n_nodes, int H,
+                       float* GP, alignn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Featurisation and readout.
+ * ------------------------------------------------------------------------------------------ */
+
+/* RBFExpansion.forward (alignn/models/utils.py:40-44): out[r,k] = exp(-gamma (d[r]-c[k])^2) */
+int alignn_rbf_fwd(const float* d, const float* centers, float gamma, float* out, int64_t rows,
+                   int bins, alignn_stream_t stream);
+/* torch.norm(r, dim=1) (alignn/models/alignn.py:313): out[r] = ||v[r,0:3]|| */
+int alignn_norm3_fwd(const float* v, float* out, int64_t rows, alignn_stream_t stream);
+/* dgl.nn.AvgPooling (alignn/models/alignn.py:325): out[b] = mean_{i in graph b} x[i]; graph_ptr[B+1] */
+int alignn_segment_mean_fwd(const float* X, const int32_t* graph_ptr, float* out, int B, int H,
+                            alignn_stream_t stream);
+/* its backward: GX[i] = G[b(i)] / count[b(i)] */
+int alignn_segment_mean_bwd(const float* G, const int32_t* graph_ptr, float* GX, int B, int H,
+                            alignn_stream_t stream);
+/* row permutation: out[k] = in[perm[k]] (canonical reordering of edge features) */
+int alignn_gather_rows(const float* in, const int32_t* perm, float* out, int64_t rows, int F,
+                       alignn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ALIGNN_HIP_H */

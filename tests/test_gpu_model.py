@@ -1,0 +1,201 @@
+"""End-to-end parity of the HIP ALIGNN against (a) the golden vectors generated from the reference's
+own model code and (b) the CPU oracle on seeded synthetic batches.  Tolerance: 1e-4 relative to the
+tensor scale (BASELINE.json north_star), gradients 1e-3 of the largest gradient."""
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from alignn_amd import ALIGNN, ALIGNNConfig, EdgeGatedGraphConv, GraphBatch  # noqa: E402
+from alignn_amd.synthetic import make_batch  # noqa: E402
+from oracle import alignn_oracle as O  # noqa: E402
+from tests.helpers import load_golden, raw_from_golden, rel_err, sample, state_dict_from_golden  # noqa: E402
+
+DEV = "cuda"
+
+
+def _model_from(sd, **cfg):
+    m = ALIGNN(ALIGNNConfig(name="alignn", **cfg))
+    m.load_state_dict(sd)
+    return m.to(DEV)
+
+
+def test_golden_tiny_train():
+    z = load_golden("alignn_tiny_train.npz")
+    model = _model_from(state_dict_from_golden(z), alignn_layers=2, gcn_layers=2, hidden_features=32, embedding_features=16).train()
+    batch = GraphBatch.from_raw(raw_from_golden(z), device=DEV)
+    pred = model(batch)
+    assert rel_err(pred, z["pred"]) < 1e-4
+    loss = torch.nn.functional.l1_loss(pred, torch.from_numpy(z["target"]).to(DEV))
+    assert abs(loss.item() - float(z["loss"])) < 1e-5
+    loss.backward()
+    nograd = set(z["nograd"].tolist())
+    gfloor = 1e-2 * max(float(np.abs(v).max()) for k, v in z.items() if k.startswith("grad."))
+    n = 0
+    for k, p in model.named_parameters():
+        if k in nograd:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+        else:
+            assert rel_err(p.grad, z["grad." + k], floor=gfloor) < 1e-3, k
+            n += 1
+    assert n > 50
+    sd = model.state_dict()
+    for k, v in z.items():
+        if k.startswith("sd_after."):
+            assert rel_err(sd[k[9:]], v, floor=1e-3) < 1e-4, k
+
+
+def test_golden_tiny_eval():
+    z = load_golden("alignn_tiny_eval.npz")
+    model = _model_from(state_dict_from_golden(z), alignn_layers=2, gcn_layers=2, hidden_features=32, embedding_features=16).eval()
+    with torch.no_grad():
+        pred = model(GraphBatch.from_raw(raw_from_golden(z), device=DEV))
+    assert rel_err(pred, z["pred"]) < 1e-4
+
+
+def test_golden_default_config_train():
+    z = load_golden("alignn_default_train.npz")
+    model = _model_from(O.init_state_dict(seed=0)).train()
+    pred = model(GraphBatch.from_raw(raw_from_golden(z), device=DEV))
+    assert rel_err(pred, z["pred"]) < 1e-4
+    loss = torch.nn.functional.l1_loss(pred, torch.from_numpy(z["target"]).to(DEV))
+    loss.backward()
+    nograd = set(z["nograd"].tolist())
+    gfloor = 1e-2 * max(float(np.abs(v[:-3]).max()) for k, v in z.items() if k.startswith("grad."))
+    for k, p in model.named_parameters():
+        if k not in nograd:
+            assert rel_err(sample(p.grad)[:-3], z["grad." + k][:-3], floor=gfloor) < 1e-3, k
+    sd = model.state_dict()
+    for k, v in z.items():
+        if k.startswith("sd_after."):
+            assert rel_err(sd[k[9:]], v, floor=1e-3) < 1e-4, k
+
+
+def test_golden_conv_dgl_like_edge_order():
+    """Stand-alone EdgeGatedGraphConv on a DGL-like graph (caller's edge order, isolated node, multi-edges)."""
+    z = load_golden("conv_f64.npz")
+
+    class G:  # the duck-typed surface the conv touches
+        def __init__(self, u, v, n):
+            self._u, self._v, self._n = u, v, n
+
+        def edges(self):
+            return self._u, self._v
+
+        def num_nodes(self):
+            return self._n
+
+    conv = EdgeGatedGraphConv(16, 16)
+    conv.load_state_dict({k[3:]: torch.from_numpy(v).float() if v.dtype == np.float64 else torch.from_numpy(v) for k, v in z.items() if k.startswith("sd.")})
+    conv = conv.to(DEV).train()
+    x = torch.from_numpy(z["x"]).float().to(DEV).requires_grad_(True)
+    y = torch.from_numpy(z["y"]).float().to(DEV).requires_grad_(True)
+    g = G(torch.from_numpy(z["u"]), torch.from_numpy(z["v"]), 9)
+    xo, yo = conv(g, x, y)
+    assert rel_err(xo, z["x_out"]) < 2e-5 and rel_err(yo, z["y_out"]) < 2e-5
+    ((xo * torch.from_numpy(z["wx"]).float().to(DEV)).sum() + (yo * torch.from_numpy(z["wy"]).float().to(DEV)).sum()).backward()
+    assert rel_err(x.grad, z["gx"]) < 1e-4 and rel_err(y.grad, z["gy"]) < 1e-4
+    for k, p in conv.named_parameters():
+        assert rel_err(p.grad, z["grad." + k], floor=1e-3) < 2e-4, k
+
+
+@pytest.mark.parametrize("kind,B,n", [("crystal", 8, 24), ("molecule", 16, (9, 27))])
+def test_synthetic_batch_vs_oracle(kind, B, n):
+    raw = make_batch(B, n, seed0=4321, kind=kind)
+    torch.manual_seed(3)
+    model = ALIGNN(ALIGNNConfig(name="alignn", alignn_layers=2, gcn_layers=2, hidden_features=256))
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV).train()
+    target = torch.linspace(-2, 2, B)
+    pred = model(GraphBatch.from_raw(raw, device=DEV))
+    torch.nn.functional.l1_loss(pred, target.to(DEV)).backward()
+    p = O.as_params(sd)
+    stats = {}
+    opred = O.alignn_forward(p, O.TorchGraph(raw), 2, 2, True, stats)
+    torch.nn.functional.l1_loss(opred, target).backward()
+    assert rel_err(pred, opred) < 1e-4
+    gfloor = 1e-2 * max(float(t.grad.abs().max()) for t in p.values() if t.grad is not None)
+    for k, q in model.named_parameters():
+        if p[k].grad is not None:
+            assert rel_err(q.grad, p[k].grad, floor=gfloor) < 1e-3, k
+    after = O.running_stats_after_step(p, stats)
+    sdn = model.state_dict()
+    for k, v in after.items():
+        assert rel_err(sdn[k], v, floor=1e-3) < 1e-4, k
+    assert int(sdn["atom_embedding.layer.1.num_batches_tracked"]) == 1
+
+
+def test_dgl_like_tuple_input_and_edge_order_invariance():
+    """forward((g, lg, lat)) on duck-typed DGL graphs; shuffling the caller's edge order must not change
+    the prediction beyond fp32 summation noise (size-independent property)."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "shims"))
+    import dgl  # the shim: only used here as a DGL-shaped container
+
+    raw = make_batch(4, 16, seed0=99)
+    torch.manual_seed(1)
+    model = ALIGNN(ALIGNNConfig(name="alignn", alignn_layers=1, gcn_layers=1, hidden_features=64)).to(DEV).eval()
+
+    def graphs(perm_e, perm_t):
+        inv_e = np.empty_like(perm_e)
+        inv_e[perm_e] = np.arange(perm_e.size)
+        g = dgl.graph((torch.from_numpy(raw.u[perm_e]), torch.from_numpy(raw.v[perm_e])), num_nodes=raw.num_nodes)
+        g._bnn = torch.from_numpy(raw.batch_num_nodes)
+        g.ndata["atom_features"] = torch.from_numpy(raw.atom_features)
+        g.edata["r"] = torch.from_numpy(raw.r[perm_e])
+        lg = dgl.graph((torch.from_numpy(inv_e[raw.lg_u][perm_t]), torch.from_numpy(inv_e[raw.lg_v][perm_t])), num_nodes=raw.num_edges)
+        lg.edata["h"] = torch.from_numpy(raw.h[perm_t])
+        return g, lg, torch.from_numpy(raw.lattice)
+
+    with torch.no_grad():
+        a = model(graphs(np.arange(raw.num_edges), np.arange(raw.num_triplets)))
+        rng = np.random.default_rng(0)
+        b = model(list(graphs(rng.permutation(raw.num_edges), rng.permutation(raw.num_triplets))))
+    assert a.shape == (4,)
+    assert rel_err(a, b) < 1e-5
+
+
+def test_single_graph_squeezes_to_scalar():
+    raw = make_batch(1, 8, seed0=5)
+    model = ALIGNN(ALIGNNConfig(name="alignn", alignn_layers=1, gcn_layers=1, hidden_features=32, embedding_features=16)).to(DEV).eval()
+    with torch.no_grad():
+        out = model(GraphBatch.from_raw(raw, device=DEV))
+    assert out.dim() == 0
+
+
+def test_product_path_refuses_cpu_tensors():
+    model = ALIGNN(ALIGNNConfig(name="alignn", alignn_layers=1, gcn_layers=0, hidden_features=32, embedding_features=16))
+    raw = make_batch(1, 8, seed0=5)
+    with pytest.raises((TypeError, RuntimeError)):
+        model(GraphBatch.from_raw(raw))  # CPU parameters + CPU batch: no fallback, must raise
+
+
+@pytest.mark.parametrize("B", [64])
+def test_full_size_properties(B):
+    """BASELINE config 2 size (B=64 x 60 atoms, H=256, 4+4): properties that need no oracle run -
+    bit-reproducibility of a training step and permutation-equivariance over the graphs of a batch."""
+    raw = make_batch(B, 60)
+    torch.manual_seed(0)
+    model = ALIGNN(ALIGNNConfig(name="alignn")).to(DEV).train()
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    batch = GraphBatch.from_raw(raw, device=DEV)
+    target = torch.randn(B, generator=torch.Generator().manual_seed(1)).to(DEV)
+    outs = []
+    for _ in range(2):
+        model.load_state_dict(sd0)
+        model.zero_grad(set_to_none=True)
+        pred = model(batch)
+        torch.nn.functional.l1_loss(pred, target).backward()
+        outs.append((pred.detach().clone(), model.alignn_layers[0].edge_update.edge_gate.weight.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.isfinite(outs[0][0]).all()
+    # eval mode: predictions of graphs do not depend on what else is in the batch
+    model.eval()
+    with torch.no_grad():
+        full = model(batch)
+        from alignn_amd.synthetic import batch_raw, _one
+        sub = batch_raw([_one(60, 1234 + i, "crystal", 92) for i in (5, 17)])
+        part = model(GraphBatch.from_raw(sub, device=DEV))
+    assert rel_err(part, full[[5, 17]]) < 1e-4
