@@ -166,12 +166,13 @@ __device__ __forceinline__ float4 edge_grad(float4 m, float4 gy, float4 bh, floa
     gm.z = gsig.z * sg.z * (1.0f - sg.z);
     gm.w = gsig.w * sg.w * (1.0f - sg.w);
     if (HAS_GY) {
-        float4 z = f4_fma(m, nrm.sc, nrm.sh);
+        float4 mc = f4_sub(m, nrm.mean);
+        float4 z = f4_fma(mc, nrm.sc, nrm.sh);  // sh holds beta
         float4 gz = make_float4(gy.x * dsilu_f(z.x), gy.y * dsilu_f(z.y), gy.z * dsilu_f(z.z), gy.w * dsilu_f(z.w));
         if (eval_mode) {
             gm = f4_fma(gz, nrm.sc, gm);
         } else {
-            float4 xh = f4_mul(f4_sub(m, nrm.mean), nrm.rstd);
+            float4 xh = f4_mul(mc, nrm.rstd);
             gm.x += nrm.sc.x * (gz.x - inv_n * (nrm.c0.x + xh.x * nrm.c1.x));
             gm.y += nrm.sc.y * (gz.y - inv_n * (nrm.c0.y + xh.y * nrm.c1.y));
             gm.z += nrm.sc.z * (gz.z - inv_n * (nrm.c0.z + xh.z * nrm.c1.z));

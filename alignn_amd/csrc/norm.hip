@@ -69,16 +69,17 @@ struct BwdReduceFn {
     int64_t ldgy;
     const float* X;
     int64_t ldx;
-    const float* stat;  // [4][F]: mean, rstd, scale, shift
+    const float* stat;  // [4][F]: mean, rstd, scale=gamma*rstd, beta
     int F;
     __device__ __forceinline__ void operator()(int64_t r, int q, float4& a0, float4& a1) const {
         float4 gy = f4_ld(GY + r * ldgy + q * 4);
         float4 x = f4_ld(X + r * ldx + q * 4);
         float4 mean = f4_ld(stat + q * 4), rstd = f4_ld(stat + F + q * 4);
-        float4 sc = f4_ld(stat + 2 * F + q * 4), sh = f4_ld(stat + 3 * F + q * 4);
-        float4 z = f4_fma(x, sc, sh);
+        float4 sc = f4_ld(stat + 2 * F + q * 4), be = f4_ld(stat + 3 * F + q * 4);
+        float4 xc = f4_sub(x, mean);
+        float4 z = f4_fma(xc, sc, be);
         float4 gz = make_float4(gy.x * dsilu_f(z.x), gy.y * dsilu_f(z.y), gy.z * dsilu_f(z.z), gy.w * dsilu_f(z.w));
-        float4 xh = f4_mul(f4_sub(x, mean), rstd);
+        float4 xh = f4_mul(xc, rstd);
         a0 = f4_add(a0, gz);
         a1 = f4_fma(gz, xh, a1);
     }
@@ -119,7 +120,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int slabs,
     stat[f] = mean;
     stat[F + f] = rstd;
     stat[2 * F + f] = scale;
-    stat[3 * F + f] = b - mean * scale;
+    stat[3 * F + f] = b;
 }
 
 __global__ void slab_sum_kernel(const float* __restrict__ partial, int slabs, int width, int stride,
@@ -131,7 +132,7 @@ __global__ void slab_sum_kernel(const float* __restrict__ partial, int slabs, in
     out[f] = (float)s;
 }
 
-// Y = R + silu(X*scale + shift)
+// Y = R + silu((X-mean)*scale + beta)
 template <bool HAS_RES>
 __global__ __launch_bounds__(kThreads) void bn_silu_fwd_kernel(const float* __restrict__ X, int64_t ldx,
                                                                const float* __restrict__ R, int64_t ldr,
@@ -144,8 +145,9 @@ __global__ __launch_bounds__(kThreads) void bn_silu_fwd_kernel(const float* __re
         int64_t r = i / Q;
         int q = (int)(i - r * Q);
         float4 x = f4_ld(X + r * ldx + q * 4);
-        float4 sc = f4_ld(stat + 2 * F + q * 4), sh = f4_ld(stat + 3 * F + q * 4);
-        float4 z = f4_fma(x, sc, sh);
+        float4 mean = f4_ld(stat + q * 4);
+        float4 sc = f4_ld(stat + 2 * F + q * 4), be = f4_ld(stat + 3 * F + q * 4);
+        float4 z = f4_fma(f4_sub(x, mean), sc, be);
         float4 o = make_float4(silu_f(z.x), silu_f(z.y), silu_f(z.z), silu_f(z.w));
         if (HAS_RES) o = f4_add(o, f4_ld(R + r * ldr + q * 4));
         f4_st(Y + r * ldy + q * 4, o);
@@ -165,14 +167,15 @@ __global__ __launch_bounds__(kThreads) void bn_silu_bwd_apply_kernel(
         float4 gy = f4_ld(GY + r * ldgy + q * 4);
         float4 x = f4_ld(X + r * ldx + q * 4);
         float4 mean = f4_ld(stat + q * 4), rstd = f4_ld(stat + F + q * 4);
-        float4 sc = f4_ld(stat + 2 * F + q * 4), sh = f4_ld(stat + 3 * F + q * 4);
-        float4 z = f4_fma(x, sc, sh);
+        float4 sc = f4_ld(stat + 2 * F + q * 4), be = f4_ld(stat + 3 * F + q * 4);
+        float4 xc = f4_sub(x, mean);
+        float4 z = f4_fma(xc, sc, be);
         float4 gz = make_float4(gy.x * dsilu_f(z.x), gy.y * dsilu_f(z.y), gy.z * dsilu_f(z.z), gy.w * dsilu_f(z.w));
         float4 o;
         if (eval_mode) {
             o = f4_mul(gz, sc);
         } else {
-            float4 xh = f4_mul(f4_sub(x, mean), rstd);
+            float4 xh = f4_mul(xc, rstd);
             float4 c0 = f4_ld(red + q * 4), c1 = f4_ld(red + F + q * 4);
             // gamma*rstd*(gz - c0/n - xh*c1/n) ; scale = gamma*rstd
             o.x = sc.x * (gz.x - inv_n * (c0.x + xh.x * c1.x));
@@ -210,13 +213,17 @@ int alignn_col_stats(const float* X, int64_t ldx, int64_t rows, int F, float* pa
 
 int alignn_col_sum(const float* X, int64_t ldx, int64_t rows, int F, float* out, float* workspace,
                    alignn_stream_t stream) {
-    if (!feat_ok(F) || rows < 0) return (int)hipErrorInvalidValue;
+    if (F < 4 || (F & 3) || rows < 0) return (int)hipErrorInvalidValue;
     int slabs = slabs_for(rows);
-    StatsFn fn{X, ldx};
-    hipLaunchKernelGGL(col_reduce_kernel<StatsFn>, dim3(slabs), dim3(kThreads), 0, (hipStream_t)stream, fn, rows, F,
-                       slabs, workspace);
-    hipLaunchKernelGGL(slab_sum_kernel, dim3(alignn_ceil_div(F, 256)), dim3(256), 0, (hipStream_t)stream, workspace,
-                       slabs, F, 2 * F, out);
+    // wide matrices (the [n,4H] projection gradient) go in column panels of <= 1024
+    for (int c = 0; c < F; c += 1024) {
+        const int w = F - c < 1024 ? F - c : 1024;
+        StatsFn fn{X + c, ldx};
+        hipLaunchKernelGGL(col_reduce_kernel<StatsFn>, dim3(slabs), dim3(kThreads), 0, (hipStream_t)stream, fn, rows,
+                           w, slabs, workspace);
+        hipLaunchKernelGGL(slab_sum_kernel, dim3(alignn_ceil_div(w, 256)), dim3(256), 0, (hipStream_t)stream,
+                           workspace, slabs, w, 2 * w, out + c);
+    }
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }

@@ -78,19 +78,19 @@ int alignn_col_sum(const float* X, int64_t ldx, int64_t rows, int F, float* out,
                    alignn_stream_t stream);
 
 /* Finalise: from `slabs` partial slabs over `rows` rows produce, per feature,
- *   stat[0]=mean, stat[1]=rstd, stat[2]=scale=gamma*rstd, stat[3]=shift=beta-mean*scale   (stat is [4][F])
+ *   stat[0]=mean, stat[1]=rstd, stat[2]=scale=gamma*rstd, stat[3]=beta   (stat is [4][F])
  * and (if running_mean != NULL) update running_mean/var in place with `momentum`.
  * slabs == 0: evaluation mode - take mean/var from running_mean/running_var. */
 int alignn_bn_finalize(const float* partial, int slabs, int64_t rows, int F, const float* gamma,
                        const float* beta, float eps, float momentum, float* running_mean,
                        float* running_var, float* stat, alignn_stream_t stream);
 
-/* Y[r,f] = (R ? R[r,f] : 0) + silu(X[r,f]*scale[f] + shift[f]) */
+/* Y[r,f] = (R ? R[r,f] : 0) + silu((X[r,f]-mean[f])*scale[f] + beta[f]) */
 int alignn_bn_silu_fwd(const float* X, int64_t ldx, const float* R, int64_t ldr, const float* stat,
                        float* Y, int64_t ldy, int64_t rows, int F, alignn_stream_t stream);
 
 /* backward, phase 1: partial[s][0][f] = sum_r gz, partial[s][1][f] = sum_r gz*xhat, where
- * z = X*scale+shift, gz = GY * silu'(z), xhat = (X-mean)*rstd */
+ * z = (X-mean)*scale+beta, gz = GY * silu'(z), xhat = (X-mean)*rstd */
 int alignn_bn_silu_bwd_reduce(const float* GY, int64_t ldgy, const float* X, int64_t ldx,
                               const float* stat, int64_t rows, int F, float* partial,
                               alignn_stream_t stream);
