@@ -129,7 +129,9 @@ class EdgeGatedGraphConv(nn.Module):
         self.dst_update = nn.Linear(input_features, output_features)
         self.bn_nodes = nn.BatchNorm1d(output_features)
 
-    def forward(self, g, node_feats: torch.Tensor, edge_feats: torch.Tensor):
+    def forward(self, g, node_feats: torch.Tensor, edge_feats: torch.Tensor, need_edge_out: bool = True):
+        """``need_edge_out=False`` (internal): the caller will discard ``y``; it is then returned as None and
+        its normalise/activate pass is skipped (BatchNorm running statistics are still updated)."""
         csr, canonical = _as_csr(g, node_feats.device)
         y_in = edge_feats if canonical else edge_feats[csr.perm]
         # fused node projection: P = x [W_sg; W_dg; W_du; W_su]^T -> A | Bd | Bh | Ux
@@ -141,9 +143,9 @@ class EdgeGatedGraphConv(nn.Module):
             csr, node_feats, y_in, wcat, bcat, self.edge_gate.weight, self.edge_gate.bias,
             self.bn_nodes.weight, self.bn_nodes.bias, self.bn_nodes.running_mean, self.bn_nodes.running_var,
             self.bn_edges.weight, self.bn_edges.bias, self.bn_edges.running_mean, self.bn_edges.running_var,
-            self.training, self.residual,
+            self.training, self.residual, need_edge_out,
         )
-        if not canonical:
+        if not canonical and y is not None:
             y = y[csr.inv]
         return x, y
 
@@ -157,9 +159,9 @@ class ALIGNNConv(nn.Module):
         self.node_update = EdgeGatedGraphConv(in_features, out_features)
         self.edge_update = EdgeGatedGraphConv(out_features, out_features)
 
-    def forward(self, g, lg, x: torch.Tensor, y: torch.Tensor, z: torch.Tensor):
+    def forward(self, g, lg, x: torch.Tensor, y: torch.Tensor, z: torch.Tensor, need_z: bool = True):
         x, m = self.node_update(g, x, y)
-        y, z = self.edge_update(lg, m, z)
+        y, z = self.edge_update(lg, m, z, need_z)
         return x, y, z
 
 
@@ -238,10 +240,13 @@ class ALIGNN(nn.Module):
             z = self.angle_embedding(b.h)
         x = self.atom_embedding(b.atom_features)
         y = self.edge_embedding(ops.bond_length(b.r))
-        for layer in self.alignn_layers:
-            x, y, z = layer(b.g, b.lg, x, y, z)
-        for layer in self.gcn_layers:
-            x, y = layer(b.g, x, y)
+        # the triplet features of the last ALIGNN layer and the bond features of the last GCN layer are
+        # never read again (alignn.py:317-325): do not materialise them
+        n_a, n_g = len(self.alignn_layers), len(self.gcn_layers)
+        for i, layer in enumerate(self.alignn_layers):
+            x, y, z = layer(b.g, b.lg, x, y, z, need_z=i + 1 < n_a)
+        for i, layer in enumerate(self.gcn_layers):
+            x, y = layer(b.g, x, y, need_edge_out=i + 1 < n_g)
         h = ops.AvgPoolFn.apply(x, b.graph_ptr)
         out = ops.linear(h, self.fc.weight, self.fc.bias.reshape(-1))
         if self.link:

@@ -85,20 +85,43 @@ struct BwdReduceFn {
     }
 };
 
-// partial [slabs][2][F] -> double sums
-__global__ void bn_finalize_kernel(const float* __restrict__ partial, int slabs, int64_t rows, int F,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                   float momentum, float* __restrict__ running_mean,
-                                   float* __restrict__ running_var, float* __restrict__ stat) {
-    int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= F) return;
-    float mean, var;
-    if (slabs > 0) {
-        double s = 0.0, ss = 0.0;
-        for (int k = 0; k < slabs; ++k) {
+// ---------------------------------------------------------------------------------------------
+// Slab reductions: blocks of 64 columns x 16 slab-lanes.  Lane y sums slabs y, y+16, ... in double,
+// then the 16 lanes are combined through LDS in a fixed order (bit-reproducible, ~slabs/16 steps).
+// ---------------------------------------------------------------------------------------------
+constexpr int kRedCols = 64, kRedLanes = 16;
+
+__device__ __forceinline__ double lane_tree_sum(double v, double (*sh)[kRedCols]) {
+    sh[threadIdx.y][threadIdx.x] = v;
+    __syncthreads();
+    double out = 0.0;
+    if (threadIdx.y == 0) {
+#pragma unroll
+        for (int k = 0; k < kRedLanes; ++k) out += sh[k][threadIdx.x];
+    }
+    __syncthreads();
+    return out;
+}
+
+__global__ __launch_bounds__(kRedCols* kRedLanes) void bn_finalize_kernel(
+    const float* __restrict__ partial, int slabs, int64_t rows, int F, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, float momentum, float* __restrict__ running_mean,
+    float* __restrict__ running_var, float* __restrict__ stat) {
+    __shared__ double sh[kRedLanes][kRedCols];
+    const int f = blockIdx.x * kRedCols + threadIdx.x;
+    const bool ok = f < F;
+    double s = 0.0, ss = 0.0;
+    if (ok) {
+        for (int k = threadIdx.y; k < slabs; k += kRedLanes) {
             s += (double)partial[(size_t)k * 2 * F + f];
             ss += (double)partial[(size_t)k * 2 * F + F + f];
         }
+    }
+    s = lane_tree_sum(s, sh);
+    ss = lane_tree_sum(ss, sh);
+    if (!ok || threadIdx.y != 0) return;
+    float mean, var;
+    if (slabs > 0) {
         double n = (double)rows;
         double m = s / n;
         double v = ss / n - m * m;
@@ -116,20 +139,22 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int slabs,
     }
     float rstd = 1.0f / sqrtf(var + eps);
     float g = gamma ? gamma[f] : 1.0f, b = beta ? beta[f] : 0.0f;
-    float scale = g * rstd;
     stat[f] = mean;
     stat[F + f] = rstd;
-    stat[2 * F + f] = scale;
+    stat[2 * F + f] = g * rstd;
     stat[3 * F + f] = b;
 }
 
-__global__ void slab_sum_kernel(const float* __restrict__ partial, int slabs, int width, int stride,
-                                float* __restrict__ out) {
-    int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= width) return;
+__global__ __launch_bounds__(kRedCols* kRedLanes) void slab_sum_kernel(const float* __restrict__ partial, int slabs,
+                                                                        int width, int stride,
+                                                                        float* __restrict__ out) {
+    __shared__ double sh[kRedLanes][kRedCols];
+    const int f = blockIdx.x * kRedCols + threadIdx.x;
     double s = 0.0;
-    for (int k = 0; k < slabs; ++k) s += (double)partial[(size_t)k * stride + f];
-    out[f] = (float)s;
+    if (f < width)
+        for (int k = threadIdx.y; k < slabs; k += kRedLanes) s += (double)partial[(size_t)k * stride + f];
+    s = lane_tree_sum(s, sh);
+    if (f < width && threadIdx.y == 0) out[f] = (float)s;
 }
 
 // Y = R + silu((X-mean)*scale + beta)
@@ -221,8 +246,8 @@ int alignn_col_sum(const float* X, int64_t ldx, int64_t rows, int F, float* out,
         StatsFn fn{X + c, ldx};
         hipLaunchKernelGGL(col_reduce_kernel<StatsFn>, dim3(slabs), dim3(kThreads), 0, (hipStream_t)stream, fn, rows,
                            w, slabs, workspace);
-        hipLaunchKernelGGL(slab_sum_kernel, dim3(alignn_ceil_div(w, 256)), dim3(256), 0, (hipStream_t)stream,
-                           workspace, slabs, w, 2 * w, out + c);
+        hipLaunchKernelGGL(slab_sum_kernel, dim3(alignn_ceil_div(w, kRedCols)), dim3(kRedCols, kRedLanes), 0,
+                           (hipStream_t)stream, workspace, slabs, w, 2 * w, out + c);
     }
     ALIGNN_CHECK_LAUNCH();
     return 0;
@@ -232,8 +257,9 @@ int alignn_bn_finalize(const float* partial, int slabs, int64_t rows, int F, con
                        float eps, float momentum, float* running_mean, float* running_var, float* stat,
                        alignn_stream_t stream) {
     if (F <= 0 || (slabs == 0 && running_mean == nullptr)) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(alignn_ceil_div(F, 256)), dim3(256), 0, (hipStream_t)stream, partial,
-                       slabs, rows, F, gamma, beta, eps, momentum, running_mean, running_var, stat);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(alignn_ceil_div(F, kRedCols)), dim3(kRedCols, kRedLanes), 0,
+                       (hipStream_t)stream, partial, slabs, rows, F, gamma, beta, eps, momentum, running_mean,
+                       running_var, stat);
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }
@@ -266,8 +292,8 @@ int alignn_bn_silu_bwd_reduce(const float* GY, int64_t ldgy, const float* X, int
 
 int alignn_bn_bwd_finalize(const float* partial, int slabs, int F, float* red, alignn_stream_t stream) {
     if (F <= 0 || slabs <= 0) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(slab_sum_kernel, dim3(alignn_ceil_div(2 * F, 256)), dim3(256), 0, (hipStream_t)stream, partial,
-                       slabs, 2 * F, 2 * F, red);
+    hipLaunchKernelGGL(slab_sum_kernel, dim3(alignn_ceil_div(2 * F, kRedCols)), dim3(kRedCols, kRedLanes), 0,
+                       (hipStream_t)stream, partial, slabs, 2 * F, 2 * F, red);
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }

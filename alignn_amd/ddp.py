@@ -20,44 +20,54 @@ import torch.distributed as dist
 
 
 class FlatGradSync:
+    """``zero_grad()`` -> backward -> ``sync()``: gradients are packed into one flat buffer with a single
+    batched copy, all-reduced once, and handed back to the parameters as views (no unpack copy).
+    Parameters that autograd never touched keep ``grad is None`` (the reference's optimizer skips them:
+    e.g. ``bn_edges`` of the last layer, whose edge output is dead)."""
+
     def __init__(self, params: Iterable[torch.nn.Parameter], process_group=None):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.group = process_group
-        total = sum(p.numel() for p in self.params)
-        p0 = self.params[0]
-        self.flat = torch.zeros(total, dtype=p0.dtype, device=p0.device)
-        self.views = []
-        off = 0
-        for p in self.params:
-            self.views.append(self.flat[off : off + p.numel()].view_as(p))
-            off += p.numel()
-        self.used = None  # which parameters actually receive gradients (fixed after the first step)
+        self.flat = None
+        self.views = None
+        self.used = None
 
     def zero_grad(self):
-        """Point every used parameter's .grad at its slice of the (zeroed) flat buffer."""
-        self.flat.zero_()
-        for i, (p, v) in enumerate(zip(self.params, self.views)):
-            if self.used is None or self.used[i]:
-                p.grad = v
-            else:
-                p.grad = None
+        for p in self.params:
+            p.grad = None
+
+    def _world(self):
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(self.group)
+        return 1
 
     def sync(self):
         """Average gradients over ranks with one collective.  Call after backward()."""
+        world = self._world()
+        if world == 1:
+            return
         if self.used is None:
-            # a parameter that autograd never touched still holds the zero view; the reference's
-            # optimizer skips such parameters (grad is None), so detect them once and drop them.
-            # (A parameter whose true gradient is exactly zero everywhere is treated the same.)
-            flags = torch.stack([(v != 0).any() for v in self.views]).to(torch.int32)
-            if dist.is_available() and dist.is_initialized():
-                dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group)
+            # the set of parameters that receive gradients is a property of the model, not of the batch;
+            # agree on it once (MAX over ranks) so every rank packs the same layout
+            flags = torch.tensor([p.grad is not None for p in self.params], dtype=torch.int32, device=self.params[0].device)
+            dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group)
             self.used = [bool(f) for f in flags.tolist()]
-            for p, u in zip(self.params, self.used):
-                if not u:
-                    p.grad = None
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-            self.flat.div_(dist.get_world_size(self.group))
+            live = [p for p, u in zip(self.params, self.used) if u]
+            total = sum(p.numel() for p in live)
+            self.flat = torch.zeros(total, dtype=live[0].dtype, device=live[0].device)
+            self.views, off = [], 0
+            for p in live:
+                self.views.append(self.flat[off : off + p.numel()].view_as(p))
+                off += p.numel()
+            self.live = live
+        grads = [
+            (p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.live
+        ]
+        torch.cat(grads, out=self.flat)  # one batched copy into the bucket
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        self.flat.div_(world)
+        for p, v in zip(self.live, self.views):
+            p.grad = v
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0, process_group=None):

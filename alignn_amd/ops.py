@@ -57,6 +57,15 @@ def gemm_nn(g, w, addend=None, out=None):
     return out
 
 
+def _dgrad(g, w, addend=None):
+    """Input gradient g[M,N] @ w[N,K].  The reduction-contiguous (NT) form of the MFMA kernel is the
+    faster one (both operands fetched with ds_read_b128), so transpose the small weight once and use it;
+    ``gemm_nn`` stays the general entry point for callers that cannot afford the transpose."""
+    if w.shape[0] % 4 == 0 and w.shape[1] >= 16:
+        return gemm_nt(g, w.t().contiguous(), None, addend)
+    return gemm_nn(g, w, addend)
+
+
 def gemm_tn(g, a):
     """dW[N,K] = g[M,N]^T @ a[M,K] (deterministic split over M)."""
     lib = _lib.load()
@@ -155,7 +164,7 @@ class LinearFn(torch.autograd.Function):
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
         gy = gy.contiguous()
-        gx = gemm_nn(gy, w) if ctx.needs_input_grad[0] else None
+        gx = _dgrad(gy, w) if ctx.needs_input_grad[0] else None
         gw = gemm_tn(gy, x) if ctx.needs_input_grad[1] else None
         gb = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -203,7 +212,7 @@ class MLPLayerFn(torch.autograd.Function):
         red = _bn_silu_bwd_reduce(gy, pre, stat)
         dbeta, dgamma = red[0], red[1]
         gpre = _bn_silu_bwd_apply(gy, pre, stat, gamma, red, not ctx.training, torch.empty_like(pre))
-        gx = gemm_nn(gpre, w) if ctx.needs_input_grad[0] else None
+        gx = _dgrad(gpre, w) if ctx.needs_input_grad[0] else None
         gw = gemm_tn(gpre, x)
         gb = col_sum(gpre)
         return gx, gw, gb, dgamma, dbeta, None, None, None
@@ -221,7 +230,7 @@ class EdgeGatedConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, graph: CSRGraph, x, y, wcat, bcat, w_eg, b_eg, n_gamma, n_beta, n_rm, n_rv, e_gamma, e_beta, e_rm,
-                e_rv, training: bool, residual: bool):
+                e_rv, training: bool, residual: bool, need_y: bool = True):
         lib = _lib.load()
         ctx.set_materialize_grads(False)
         x = x.contiguous()
@@ -250,7 +259,9 @@ class EdgeGatedConvFn(torch.autograd.Function):
             n_stat = _bn_finalize(None, 0, n, n_gamma, n_beta, n_rm, n_rv, False)
             e_stat = _bn_finalize(None, 0, m, e_gamma, e_beta, e_rm, e_rv, False)
         x_out = _bn_silu_fwd(xpre, x if residual else None, n_stat)
-        y_out = _bn_silu_fwd(M, y if residual else None, e_stat)
+        # need_y == False: the caller discards the edge output (last layer) - skip the pass, keep the
+        # statistics side effect (running_mean/var of bn_edges are updated exactly as in the reference)
+        y_out = _bn_silu_fwd(M, y if residual else None, e_stat) if need_y else None
         ctx.graph = graph
         ctx.training = training
         ctx.residual = residual
@@ -295,17 +306,17 @@ class EdgeGatedConvFn(torch.autograd.Function):
             "egc_bwd_src",
         )
         # projections
-        g_x = gemm_nn(GP, wcat, addend=gx_out if ctx.residual else None)
+        g_x = _dgrad(GP, wcat, addend=gx_out if ctx.residual else None)
         g_wcat = gemm_tn(GP, x)
         g_bcat = col_sum(GP)
-        g_y = gemm_nn(GM, w_eg, addend=gy_out if (ctx.residual and gy_out is not None) else None)
+        g_y = _dgrad(GM, w_eg, addend=gy_out if (ctx.residual and gy_out is not None) else None)
         g_weg = gemm_tn(GM, y)
         g_beg = col_sum(GM)
         dn_gamma, dn_beta = n_red[1], n_red[0]
         de_gamma = e_red[1] if e_red is not None else None
         de_beta = e_red[0] if e_red is not None else None
         return (None, g_x, g_y, g_wcat, g_bcat, g_weg, g_beg, dn_gamma, dn_beta, None, None, de_gamma, de_beta, None,
-                None, None, None)
+                None, None, None, None)
 
 
 # ---------------------------------------------------------------------------------------------

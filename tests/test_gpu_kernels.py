@@ -63,7 +63,7 @@ def test_gemm_strided_views():
     assert rel_err(out, big[:, 256:512].double().cpu() @ w.double().cpu()) < 2e-6
 
 
-@pytest.mark.parametrize("rows,F", [(2, 64), (1000, 256), (70000, 64), (333, 32), (5, 16), (4096, 92 * 4)])
+@pytest.mark.parametrize("rows,F", [(8, 64), (1000, 256), (70000, 64), (333, 32), (5, 16), (4096, 92 * 4)])
 def test_mlp_layer_fn_matches_torch_batchnorm(rows, F):
     K = 40
     x = r(rows, K, seed=1)
