@@ -168,7 +168,44 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_mfma_kernel(GemmArgs g) {
         __syncthreads();
     }
 
-    // epilogue: acc reg r of a 32x32 tile -> row (r&3) + 8*(r>>2) + 4*half, col lane&31
+    // ---- epilogue.  acc reg r of a 32x32 tile sits at row (r&3) + 8*(r>>2) + 4*half, col lane&31.
+    // Fast path: each wave transposes its 32-row slabs through a private LDS patch ([32][TN+4] floats,
+    // carved out of the now idle staging buffers) and then moves whole 256-byte row segments as float4:
+    // bias / addend loads and the C stores are 16 B per lane and row-contiguous.
+    const bool vec = ((g.No & 3) == 0) && ((g.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
+                     (g.addend == nullptr || (((g.ldadd & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.addend) & 15) == 0)));
+    if (vec) {
+        constexpr int PLD = TN + 4;
+        static_assert(WM * WN * 32 * PLD <= 2 * STAGE, "epilogue patch must fit in the staging LDS");
+        float* patch = smem + wave * (32 * PLD);
+        const int prow = lane >> 4, pc4 = (lane & 15) * 4;  // TN == 64: 16 lanes cover one row segment
+        static_assert(TN == 64, "epilogue assumes 64-column wave tiles");
+#pragma unroll
+        for (int a = 0; a < RM; ++a) {
+            __syncthreads();  // staging buffers (or the previous slab) no longer read
+#pragma unroll
+            for (int b = 0; b < RN; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    patch[((r & 3) + 8 * (r >> 2) + 4 * half) * PLD + b * 32 + il] = acc[a][b][r];
+            __syncthreads();
+            const int64_t col = n0 + wn * TN + pc4;
+            if (col < g.No) {
+                float4 bv = g.bias ? f4_ld(g.bias + col) : f4_zero();
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int lr = i * 4 + prow;
+                    const int64_t row = m0 + wm * TM + a * 32 + lr;
+                    if (row < g.Mo) {
+                        float4 v = f4_add(f4_ld(patch + lr * PLD + pc4), bv);
+                        if (g.addend) v = f4_add(v, f4_ld(g.addend + row * g.ldadd + col));
+                        f4_st(C + row * g.ldc + col, v);
+                    }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int a = 0; a < RM; ++a) {
 #pragma unroll
@@ -244,9 +281,21 @@ int naive(const float* A, int64_t sai, int64_t sar, const float* B, int64_t sbj,
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-constexpr int64_t kTnChunk = 4096;  // reduction rows per split of the weight-gradient GEMM
-inline int tn_splits(int64_t M) {
-    int64_t s = (M + kTnChunk - 1) / kTnChunk;
+// Weight-gradient GEMM: the output is only (N/128)*(K/BN) tiles, so the reduction over the M rows is split
+// into slabs until there are ~768 workgroups (3 per CU); each slab is a multiple of BK rows.
+inline int64_t tn_chunk(int64_t M, int N, int K) {
+    const int bn = K > 64 ? 128 : 64;
+    const int64_t tiles = (int64_t)alignn_ceil_div(N, 128) * alignn_ceil_div(K, bn);
+    int64_t want = (768 + tiles - 1) / tiles;
+    if (want < 1) want = 1;
+    int64_t chunk = (M + want - 1) / want;
+    chunk = ((chunk + BK - 1) / BK) * BK;
+    if (chunk < 4 * BK) chunk = 4 * BK;
+    return chunk;
+}
+inline int tn_splits(int64_t M, int N, int K) {
+    const int64_t c = tn_chunk(M, N, K);
+    int64_t s = (M + c - 1) / c;
     return (int)(s < 1 ? 1 : s);
 }
 
@@ -284,7 +333,7 @@ int alignn_gemm_nn(const float* G, int64_t ldg, const float* W, int64_t ldw, con
 }
 
 size_t alignn_gemm_tn_workspace(int64_t M, int N, int K) {
-    return (size_t)tn_splits(M) * (size_t)N * (size_t)K * sizeof(float);
+    return (size_t)tn_splits(M, N, K) * (size_t)N * (size_t)K * sizeof(float);
 }
 
 int alignn_gemm_tn(const float* G, int64_t ldg, const float* A, int64_t lda, float* dW, int64_t lddw, int64_t M, int N,
@@ -294,10 +343,10 @@ int alignn_gemm_tn(const float* G, int64_t ldg, const float* A, int64_t lda, flo
     // dW[n,k] = sum_m G[m,n] A[m,k]: both operands index-contiguous, reduction over rows m
     const bool vec_ok = (N % 4 == 0) && (K % 4 == 0) && (ldg % 4 == 0) && (lda % 4 == 0) && aligned16(G) && aligned16(A);
     if (!vec_ok || M == 0) return naive(G, 1, ldg, A, 1, lda, nullptr, nullptr, 0, dW, lddw, N, K, M, st);
-    const int splits = tn_splits(M);
+    const int splits = tn_splits(M, N, K);
     if (workspace_bytes < alignn_gemm_tn_workspace(M, N, K) || workspace == nullptr) return (int)hipErrorInvalidValue;
     float* ws = (float*)workspace;
-    GemmArgs g{G, ldg, A, lda, nullptr, nullptr, 0, ws, K, N, K, M, kTnChunk, (int64_t)N * K};
+    GemmArgs g{G, ldg, A, lda, nullptr, nullptr, 0, ws, K, N, K, M, tn_chunk(M, N, K), (int64_t)N * K};
     int rc;
     if (K > 64)
         rc = launch<128, 128, 2, 2, false, false>(g, splits, st);

@@ -37,4 +37,5 @@ def test_host_only_queries():
     assert lib.alignn_col_stats_slabs(1) == 1
     assert lib.alignn_col_stats_slabs(10**7) == 1024
     assert lib.alignn_egc_slabs(0) == 1
-    assert lib.alignn_gemm_tn_workspace(10000, 256, 256) == 3 * 256 * 256 * 4
+    ws = lib.alignn_gemm_tn_workspace(10000, 256, 256)
+    assert ws % (256 * 256 * 4) == 0 and 1 <= ws // (256 * 256 * 4) <= -(-10000 // 128)
