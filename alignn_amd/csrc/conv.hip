@@ -188,7 +188,8 @@ __global__ __launch_bounds__(kThreads) void egc_bwd_dst_kernel(
     const float* __restrict__ GS1, const float* __restrict__ GS0, const float* __restrict__ e_stat,
     const float* __restrict__ e_red, int e_eval, float inv_n, const int32_t* __restrict__ seg_ptr,
     const int32_t* __restrict__ seg_node, const int32_t* __restrict__ src, int n_seg, int H,
-    float* __restrict__ GM, float* __restrict__ GP) {
+    float* __restrict__ GM, float* __restrict__ GP, float* __restrict__ gb_partial) {
+    __shared__ float4 sh[kWavesPerBlock][ALIGNN_WAVE];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t ldp = 4 * (int64_t)H;
@@ -196,7 +197,9 @@ __global__ __launch_bounds__(kThreads) void egc_bwd_dst_kernel(
     const int stride = gridDim.x * kWavesPerBlock;
     for (int c0 = 0; c0 < H; c0 += 4 * ALIGNN_WAVE) {
         const int f = c0 + 4 * lane;
-        if (f >= H) continue;
+        const bool active = f < H;
+        float4 gb = f4_zero();  // column sum of GM over this wave's segments (= edge_gate bias gradient)
+        if (active) {
         EdgeNorm nrm;
         if (HAS_GY) {
             nrm.mean = f4_ld(e_stat + f);
@@ -242,6 +245,19 @@ __global__ __launch_bounds__(kThreads) void egc_bwd_dst_kernel(
                 gbd = f4_add(gbd, gm);
             }
             f4_st(GP + (int64_t)i * ldp + H + f, gbd);
+            gb = f4_add(gb, gbd);
+        }
+        }
+        if (gb_partial) {  // fixed-order block sum of the four waves -> slab [blockIdx.x][H]
+            sh[wave][lane] = gb;
+            __syncthreads();
+            if (wave == 0 && active) {
+                float4 a = sh[0][lane];
+#pragma unroll
+                for (int w = 1; w < kWavesPerBlock; ++w) a = f4_add(a, sh[w][lane]);
+                f4_st(gb_partial + (size_t)blockIdx.x * H + f, a);
+            }
+            __syncthreads();
         }
     }
 }
@@ -327,17 +343,17 @@ int alignn_egc_node_bwd(const float* GXPRE, int64_t ldg, const float* S0, const 
 int alignn_egc_bwd_dst(const float* GY, const float* M, const float* P, const float* GS1, const float* GS0,
                        const float* e_stat, const float* e_gamma, const float* e_red, int e_eval, int64_t m_rows,
                        const int32_t* seg_ptr, const int32_t* seg_node, const int32_t* src, int64_t n_seg, int H,
-                       float* GM, float* GP, alignn_stream_t stream) {
+                       float* GM, float* GP, float* gb_partial, alignn_stream_t stream) {
     (void)e_gamma;
     if (!h_ok(H) || n_seg > INT32_MAX) return (int)hipErrorInvalidValue;
     const float inv_n = m_rows > 0 ? 1.0f / (float)m_rows : 0.0f;
     dim3 grid(egc_blocks(n_seg)), block(kThreads);
     if (GY)
         hipLaunchKernelGGL(egc_bwd_dst_kernel<true>, grid, block, 0, (hipStream_t)stream, GY, M, P, GS1, GS0, e_stat,
-                           e_red, e_eval, inv_n, seg_ptr, seg_node, src, (int)n_seg, H, GM, GP);
+                           e_red, e_eval, inv_n, seg_ptr, seg_node, src, (int)n_seg, H, GM, GP, gb_partial);
     else
         hipLaunchKernelGGL(egc_bwd_dst_kernel<false>, grid, block, 0, (hipStream_t)stream, GY, M, P, GS1, GS0, e_stat,
-                           e_red, e_eval, inv_n, seg_ptr, seg_node, src, (int)n_seg, H, GM, GP);
+                           e_red, e_eval, inv_n, seg_ptr, seg_node, src, (int)n_seg, H, GM, GP, gb_partial);
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }

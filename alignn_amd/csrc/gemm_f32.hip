@@ -243,13 +243,22 @@ __global__ void gemm_naive_kernel(const float* __restrict__ A, int64_t sai, int6
     C[i * ldc + j] = acc;
 }
 
-__global__ void slab_reduce_kernel(const float* __restrict__ ws, int splits, int64_t count, int cols,
-                                   float* __restrict__ out, int64_t ldo) {
-    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= count) return;
+// out[idx] = sum_k ws[k][idx], 64 outputs x 16 slab-lanes per block, fp64 partials, fixed order
+__global__ __launch_bounds__(1024) void slab_reduce_kernel(const float* __restrict__ ws, int splits, int64_t count,
+                                                           int cols, float* __restrict__ out, int64_t ldo) {
+    __shared__ double sh[16][64];
+    const int64_t idx = (int64_t)blockIdx.x * 64 + threadIdx.x;
     double s = 0.0;
-    for (int k = 0; k < splits; ++k) s += (double)ws[(int64_t)k * count + idx];
-    out[(idx / cols) * ldo + (idx % cols)] = (float)s;
+    if (idx < count)
+        for (int k = threadIdx.y; k < splits; k += 16) s += (double)ws[(int64_t)k * count + idx];
+    sh[threadIdx.y][threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.y == 0 && idx < count) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sh[k][threadIdx.x];
+        out[(idx / cols) * ldo + (idx % cols)] = (float)t;
+    }
 }
 
 template <int BM, int BN, int WM, int WN, bool A_RC, bool B_RC>
@@ -312,8 +321,11 @@ int alignn_gemm_nt(const float* A, int64_t lda, const float* W, int64_t ldw, con
     if (!vec_ok || N < 16)
         return naive(A, lda, 1, W, ldw, 1, bias, addend, ldadd, C, ldc, M, N, K, st);
     GemmArgs g{A, lda, W, ldw, bias, addend, ldadd, C, ldc, M, N, K, K, 0};
-    if (N > 128) return launch<128, 256, 2, 4, true, true>(g, 1, st);
-    if (N > 64) return launch<128, 128, 2, 2, true, true>(g, 1, st);
+    // tile choice: the big 128x256 tile (A read once, 1 workgroup/CU) needs >= ~4 waves of workgroups to
+    // amortise its tail; mid-size problems take 64x128 tiles (2-3 workgroups/CU, finer granularity)
+    const int64_t big_blocks = (int64_t)alignn_ceil_div(M, 128) * alignn_ceil_div(N, 256);
+    if (N > 128 && big_blocks >= 1024) return launch<128, 256, 2, 4, true, true>(g, 1, st);
+    if (N > 64) return launch<64, 128, 2, 2, true, true>(g, 1, st);
     return launch<128, 64, 4, 1, true, true>(g, 1, st);
 }
 
@@ -354,7 +366,7 @@ int alignn_gemm_tn(const float* G, int64_t ldg, const float* A, int64_t lda, flo
         rc = launch<128, 64, 4, 1, false, false>(g, splits, st);
     if (rc) return rc;
     const int64_t count = (int64_t)N * K;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(alignn_ceil_div(count, 256)), dim3(256), 0, st, ws, splits, count, K,
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(alignn_ceil_div(count, 64)), dim3(64, 16), 0, st, ws, splits, count, K,
                        dW, lddw);
     ALIGNN_CHECK_LAUNCH();
     return 0;

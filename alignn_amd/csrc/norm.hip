@@ -298,6 +298,14 @@ int alignn_bn_bwd_finalize(const float* partial, int slabs, int F, float* red, a
     return 0;
 }
 
+int alignn_slab_sum(const float* partial, int slabs, int width, float* out, alignn_stream_t stream) {
+    if (width <= 0 || slabs <= 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(slab_sum_kernel, dim3(alignn_ceil_div(width, kRedCols)), dim3(kRedCols, kRedLanes), 0,
+                       (hipStream_t)stream, partial, slabs, width, width, out);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
 int alignn_bn_silu_bwd_apply(const float* GY, int64_t ldgy, const float* X, int64_t ldx, const float* stat,
                              const float* gamma, const float* red, int eval_mode, float* GX, int64_t ldgx,
                              int64_t rows, int F, alignn_stream_t stream) {

@@ -294,10 +294,12 @@ class EdgeGatedConvFn(torch.autograd.Function):
             gy_out = gy_out.contiguous()
             e_red = _bn_silu_bwd_reduce(gy_out, M, e_stat)
         GM = _empty(m, H, like=x)
+        gslabs = lib.alignn_egc_slabs(n)
+        gb_part = _empty(gslabs, H, like=x)
         check(
             lib.alignn_egc_bwd_dst(ptr(gy_out), ptr(M), ptr(P), ptr(gs1), ptr(gs0), ptr(e_stat), ptr(e_gamma),
                                    ptr(e_red), int(ev), m, ptr(graph.seg_ptr), ptr(graph.seg_node), ptr(graph.src), n,
-                                   H, ptr(GM), ptr(GP), stream()),
+                                   H, ptr(GM), ptr(GP), ptr(gb_part), stream()),
             "egc_bwd_dst",
         )
         check(
@@ -311,7 +313,8 @@ class EdgeGatedConvFn(torch.autograd.Function):
         g_bcat = col_sum(GP)
         g_y = _dgrad(GM, w_eg, addend=gy_out if (ctx.residual and gy_out is not None) else None)
         g_weg = gemm_tn(GM, y)
-        g_beg = col_sum(GM)
+        g_beg = _empty(H, like=x)  # column sum of GM, accumulated inside the destination-order pass
+        check(lib.alignn_slab_sum(ptr(gb_part), gslabs, H, ptr(g_beg), stream()), "slab_sum")
         dn_gamma, dn_beta = n_red[1], n_red[0]
         de_gamma = e_red[1] if e_red is not None else None
         de_beta = e_red[0] if e_red is not None else None

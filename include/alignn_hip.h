@@ -96,6 +96,8 @@ int alignn_bn_silu_bwd_reduce(const float* GY, int64_t ldgy, const float* X, int
                               alignn_stream_t stream);
 /* phase 1b: red[0][f]=sum gz (=dbeta), red[1][f]=sum gz*xhat (=dgamma) from the slabs */
 int alignn_bn_bwd_finalize(const float* partial, int slabs, int F, float* red, alignn_stream_t stream);
+/* out[f] = sum_s partial[s][f] over `slabs` slabs of `width` floats (fp64 accumulation, fixed order) */
+int alignn_slab_sum(const float* partial, int slabs, int width, float* out, alignn_stream_t stream);
 /* phase 2: GX = gamma*rstd*(gz - red0/rows - xhat*red1/rows)   (training-mode BatchNorm backward)
  * eval_mode != 0: GX = gz*scale (running statistics are constants) */
 int alignn_bn_silu_bwd_apply(const float* GY, int64_t ldgy, const float* X, int64_t ldx,
@@ -137,12 +139,15 @@ int alignn_egc_node_bwd(const float* GXPRE, int64_t ldg, const float* S0, const 
  *   g_mbn = BatchNorm/SiLU backward of the edge branch (skipped when GY == NULL: dead edge output)
  *   sigma = sigmoid(M[e]);  g_sigma = GS1[i]*Bh[u] + GS0[i]
  *   GM[e] = g_mbn + g_sigma*sigma*(1-sigma);   GP[i, H:2H] (g_Bd) = sum_e GM[e]
- * GP is the [n,4H] gradient of the fused node projection; this pass fills its Bd block. */
+ * GP is the [n,4H] gradient of the fused node projection; this pass fills its Bd block.
+ * gb_partial (optional): [alignn_egc_slabs(n_seg)][H] column-sum slabs of GM (the edge_gate bias gradient,
+ * finished with alignn_slab_sum) - saves a separate pass over GM. */
 int alignn_egc_bwd_dst(const float* GY, const float* M, const float* P, const float* GS1,
                        const float* GS0, const float* e_stat, const float* e_gamma,
                        const float* e_red, int e_eval, int64_t m_rows,
                        const int32_t* seg_ptr, const int32_t* seg_node, const int32_t* src,
-                       int64_t n_seg, int H, float* GM, float* GP, alignn_stream_t stream);
+                       int64_t n_seg, int H, float* GM, float* GP, float* gb_partial,
+                       alignn_stream_t stream);
 
 /* Source-ordered backward pass (deterministic scatter-by-source):
  *   GP[j, 0:H]   (g_A)  = sum_{e: src e = j} GM[e]
