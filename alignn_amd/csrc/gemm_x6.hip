@@ -1,0 +1,299 @@
+// fp32-accurate GEMM on the bf16 matrix cores ("bf16x6"): C[M,N] = A[M,K] W[N,K]^T (+bias +addend).
+//
+// Every fp32 operand is cut into three bf16 slices of 8 mantissa bits each by TRUNCATION
+//     x = h + m + l (+ <2^-24 |x|),   h = x & 0xffff0000,  m = (x-h) & 0xffff0000,  l = upper16(x-h-m)
+// (the subtractions are exact), and the product is taken as the six slice products whose weight is
+// >= 2^-16:  hh + (hm + mh) + (hl + lh + mm), accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  The
+// dropped terms (ml, lm, ll) are < 2^-24 relative, i.e. the result carries fp32-grade error (measured:
+// <= the error of an fp32 FMA chain, see tests/test_gpu_kernels.py::test_gemm_x6_accuracy), while the
+// matrix pipe runs 16/6 = 2.7x faster than v_mfma_f32_32x32x2_f32.  gfx950 has no TF32/xf32; this is how
+// the H x H projections get off the 157 TF fp32-MFMA roof and become HBM-bound.
+//
+// Layout: 128 x 256 block tile, 8 waves (4 x 2) of 32 x 128, K step 16 (one MFMA step), double buffered LDS
+// (2 x 32 KiB -> two workgroups per CU, so one's epilogue/prologue overlaps the other's MFMAs).  Both operands reach LDS by DMA (global_load_lds_dwordx4: no staging VGPRs, no
+// ds_write): the activation tile A stays fp32 and is sliced in registers right before use (and/sub/perm,
+// ~5.5 VALU per element, once per wave row-strip); the weights arrive PRE-SLICED by alignn_split_bf16x3 in the
+// exact 16 KiB-per-(slice, k-block) image the DMA copies linearly (L2-resident: 384 KiB for 256x256).  LDS
+// images are unpadded; bank conflicts are removed by an XOR swizzle of the 16-byte chunk index that is
+// applied to the DMA *source* address (A) or baked into the pre-sliced layout (W) and again on the
+// ds_read_b128 address.  Epilogue as in gemm_f32.hip: per-wave LDS transpose, float4 row-segment stores.
+#include "common.h"
+#include "../../include/alignn_hip.h"
+
+// Ablation switches for tools/ablate_x6.py (never defined in the shipped build)
+#ifndef X6_ABL_NOSLICE
+#define X6_ABL_NOSLICE 0
+#endif
+#ifndef X6_ABL_NOBLOAD
+#define X6_ABL_NOBLOAD 0
+#endif
+#ifndef X6_ABL_NOALOAD
+#define X6_ABL_NOALOAD 0
+#endif
+#ifndef X6_ABL_ONEMFMA
+#define X6_ABL_ONEMFMA 0
+#endif
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int BM = 128, BN = 256, BK = 16;  // one 16-deep MFMA step per stage: 32 KiB stages, 2 workgroups/CU
+constexpr int WM = 4, WN = 2, NT = WM * WN * 64;
+constexpr int TM = BM / WM, TN = BN / WN;  // 32 x 128 per wave
+constexpr int RN = TN / 32;                // 1 x 4 MFMA tiles
+constexpr int A_BYTES = BM * BK * 4;       // 8 KiB fp32 (64-byte rows), XOR-swizzled 16-byte chunks, no padding
+constexpr int B_PLANE = BN * BK * 2;       // 8 KiB per bf16 slice plane (32-byte rows)
+constexpr int STAGE_BYTES = A_BYTES + 3 * B_PLANE;  // 32 KiB
+constexpr int A_DMA = A_BYTES / 1024 / (NT / 64);       // 1 x 1 KiB DMA piece per wave
+constexpr int B_DMA = 3 * B_PLANE / 1024 / (NT / 64);   // 3
+constexpr int B_PIECES = B_PLANE / 1024;                // 8 pieces per plane
+constexpr int EPI_BYTES = (NT / 64) * 32 * (64 + 4) * 4; // per-wave [32][68] fp32 transpose patches (68 KiB)
+constexpr int LDS_BYTES = 2 * STAGE_BYTES > EPI_BYTES ? 2 * STAGE_BYTES : EPI_BYTES;  // 68 KiB -> 2 workgroups/CU
+
+struct X6Args {
+    const float* A;
+    int64_t lda;
+    const unsigned char* Ws;  // [3][K/16][Npad][2 chunks, swizzled][8 bf16]
+    const float* bias;
+    const float* addend;
+    int64_t ldadd;
+    float* C;
+    int64_t ldc;
+    int64_t M;
+    int N;
+    int Npad;
+    int K;
+};
+
+__device__ __forceinline__ unsigned hi_pair(float x1, float x0) {
+    // (upper16(x1) << 16) | upper16(x0): two bf16 (truncated) in one dword
+    return __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
+}
+__device__ __forceinline__ float trunc16(float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
+
+// slice 8 consecutive-k floats into the three bf16x8 MFMA operands
+__device__ __forceinline__ void slice8(const float4& lo, const float4& hi4, bf16x8& h, bf16x8& m, bf16x8& l) {
+#if X6_ABL_NOSLICE
+    h = __builtin_bit_cast(bf16x8, lo);
+    m = __builtin_bit_cast(bf16x8, hi4);
+    l = h;
+    return;
+#endif
+    float x[8] = {lo.x, lo.y, lo.z, lo.w, hi4.x, hi4.y, hi4.z, hi4.w};
+    uint4 hp, mp, lp;
+    unsigned* hpp = reinterpret_cast<unsigned*>(&hp);
+    unsigned* mpp = reinterpret_cast<unsigned*>(&mp);
+    unsigned* lpp = reinterpret_cast<unsigned*>(&lp);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const float x0 = x[2 * p], x1 = x[2 * p + 1];
+        hpp[p] = hi_pair(x1, x0);
+        const float r0 = x0 - trunc16(x0), r1 = x1 - trunc16(x1);
+        mpp[p] = hi_pair(r1, r0);
+        const float q0 = r0 - trunc16(r0), q1 = r1 - trunc16(r1);
+        lpp[p] = hi_pair(q1, q0);
+    }
+    h = __builtin_bit_cast(bf16x8, hp);
+    m = __builtin_bit_cast(bf16x8, mp);
+    l = __builtin_bit_cast(bf16x8, lp);
+}
+
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned char* lds_wave_base) {
+    // 64 lanes x 16 B -> 1 KiB of LDS at lds_wave_base (wave-uniform) + lane*16; source address is per lane
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(NT) void gemm_nt_x6_kernel(X6Args g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int il = lane & 31, half = lane >> 5;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+
+    f32x16 acc[RN];
+#pragma unroll
+    for (int b = 0; b < RN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.0f;
+
+    // ---- DMA addressing (LDS image is lane-linear; the XOR swizzle lives in the SOURCE address)
+    // A: piece q = wave*A_DMA + i holds tile positions p = q*64 + lane -> row p/4, stored chunk p%4, which is
+    //    global chunk (p%4) ^ ((row>>2)&3) of that row.
+    const float* a_src[A_DMA];
+#pragma unroll
+    for (int i = 0; i < A_DMA; ++i) {
+        const int p = (wave * A_DMA + i) * 64 + lane;
+        const int row = p >> 2, c = (p & 3) ^ ((row >> 2) & 3);
+        int64_t grow = m0 + row;
+        if (grow >= g.M) grow = g.M - 1;  // clamp: rows past the end are computed but never stored
+        a_src[i] = g.A + grow * g.lda + c * 4;
+    }
+    // B: the three [Npad][32 B] k-block planes are contiguous 8 KiB runs in global memory (pre-swizzled)
+    const int64_t plane_stride = (int64_t)(g.K / BK) * g.Npad * (BK * 2);  // bytes between slice planes
+    const unsigned char* b_src[B_DMA];
+#pragma unroll
+    for (int i = 0; i < B_DMA; ++i) {
+        const int q = wave * B_DMA + i;  // plane q/8, 1 KiB piece q%8
+        b_src[i] = g.Ws + (int64_t)(q / B_PIECES) * plane_stride + (int64_t)n0 * (BK * 2) + (q % B_PIECES) * 1024 + lane * 16;
+    }
+    auto issue = [&](int kt, unsigned char* stage) {
+#if X6_ABL_NOALOAD
+        if (kt == 0)
+#endif
+#pragma unroll
+        for (int i = 0; i < A_DMA; ++i) dma16(a_src[i] + kt * BK, stage + (wave * A_DMA + i) * 1024);
+#if X6_ABL_NOBLOAD
+        if (kt == 0)
+#endif
+#pragma unroll
+        for (int i = 0; i < B_DMA; ++i)
+            dma16(b_src[i] + (int64_t)kt * g.Npad * (BK * 2), stage + A_BYTES + (wave * B_DMA + i) * 1024);
+    };
+
+    // reader addresses (bytes inside a stage)
+    const int arow = wm * TM + il;
+    const int a_f = (arow >> 2) & 3;
+    const int a_off0 = arow * (BK * 4) + (((2 * half) ^ a_f) << 4);
+    const int a_off1 = arow * (BK * 4) + (((2 * half + 1) ^ a_f) << 4);
+    int b_off[RN];
+#pragma unroll
+    for (int b = 0; b < RN; ++b) {
+        const int n = wn * TN + b * 32 + il;
+        b_off[b] = A_BYTES + n * (BK * 2) + ((half ^ ((n >> 3) & 1)) << 4);
+    }
+
+    const int nk = g.K / BK;
+    issue(0, smem);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) issue(kt + 1, smem + (cur ^ 1) * STAGE_BYTES);
+        const unsigned char* stage = smem + cur * STAGE_BYTES;
+        bf16x8 ah, am, al, bh[RN], bm[RN], bl[RN];
+        slice8(*reinterpret_cast<const float4*>(stage + a_off0), *reinterpret_cast<const float4*>(stage + a_off1), ah,
+               am, al);
+#pragma unroll
+        for (int b = 0; b < RN; ++b) {
+            const unsigned char* q = stage + b_off[b];
+            bh[b] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(q));
+            bm[b] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(q + B_PLANE));
+            bl[b] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(q + 2 * B_PLANE));
+        }
+        // six slice products, smallest first; each pass walks the four independent accumulators so no MFMA
+        // waits on the one issued right before it
+#if !X6_ABL_ONEMFMA
+#pragma unroll
+        for (int b = 0; b < RN; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[b], acc[b], 0, 0, 0);
+#pragma unroll
+        for (int b = 0; b < RN; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[b], acc[b], 0, 0, 0);
+#pragma unroll
+        for (int b = 0; b < RN; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm[b], acc[b], 0, 0, 0);
+#pragma unroll
+        for (int b = 0; b < RN; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh[b], acc[b], 0, 0, 0);
+#pragma unroll
+        for (int b = 0; b < RN; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm[b], acc[b], 0, 0, 0);
+#endif
+#pragma unroll
+        for (int b = 0; b < RN; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[b], acc[b], 0, 0, 0);
+        __syncthreads();  // next stage has landed (the barrier drains the DMA), current one is free
+    }
+
+    // epilogue: per-wave LDS transpose of two 32x32 tiles at a time -> float4 row segments
+    constexpr int PLD = 64 + 4;
+    float* patch = reinterpret_cast<float*>(smem) + wave * (32 * PLD);
+    const int prow = lane >> 4, pc4 = (lane & 15) * 4;
+#pragma unroll
+    for (int hb = 0; hb < RN / 2; ++hb) {
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                patch[((r & 3) + 8 * (r >> 2) + 4 * half) * PLD + b * 32 + il] = acc[2 * hb + b][r];
+        __syncthreads();
+        const int col = n0 + wn * TN + hb * 64 + pc4;
+        if (col < g.N) {
+            const float4 bv = g.bias ? f4_ld(g.bias + col) : f4_zero();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int lr = i * 4 + prow;
+                const int64_t row = m0 + wm * TM + lr;
+                if (row < g.M) {
+                    float4 v = f4_add(f4_ld(patch + lr * PLD + pc4), bv);
+                    if (g.addend) v = f4_add(v, f4_ld(g.addend + row * g.ldadd + col));
+                    f4_st(g.C + row * g.ldc + col, v);
+                }
+            }
+        }
+    }
+}
+
+// Slice W (or W^T) into the kernel's DMA image: out[plane][kb][n][chunk ^ ((n>>3)&1)][8], n < Npad (zero rows
+// beyond N), kb = k/16, chunk = (k%16)/8.
+__global__ void split_bf16x3_kernel(const float* __restrict__ W, int64_t ldw, int N, int Npad, int K, int transpose,
+                                    unsigned short* __restrict__ out) {
+    const int64_t total = (int64_t)Npad * K;
+    const int64_t plane = total;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i / K), k = (int)(i % K);
+        float x = 0.0f;
+        if (n < N) x = transpose ? W[(int64_t)k * ldw + n] : W[(int64_t)n * ldw + k];
+        const float r1 = x - trunc16(x);
+        const float r2 = r1 - trunc16(r1);
+        const int kb = k / BK, c = (k % BK) >> 3, e = k & 7;
+        const int64_t o = ((int64_t)kb * Npad + n) * BK + ((c ^ ((n >> 3) & 1)) << 3) + e;
+        out[o] = (unsigned short)(__float_as_uint(x) >> 16);
+        out[plane + o] = (unsigned short)(__float_as_uint(r1) >> 16);
+        out[2 * plane + o] = (unsigned short)(__float_as_uint(r2) >> 16);
+    }
+}
+
+inline bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+inline int npad(int N) { return ((N + BN - 1) / BN) * BN; }
+
+}  // namespace
+
+extern "C" {
+
+size_t alignn_split_bf16x3_bytes(int N, int K) { return (size_t)3 * npad(N) * (size_t)K * 2; }
+
+int alignn_split_bf16x3(const float* W, int64_t ldw, int N, int K, int transpose, void* out, alignn_stream_t stream) {
+    if (N <= 0 || K <= 0 || (K % BK) != 0 || out == nullptr) return (int)hipErrorInvalidValue;
+    const int64_t total = (int64_t)npad(N) * K;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(split_bf16x3_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, W, ldw, N, npad(N), K,
+                       transpose, (unsigned short*)out);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_gemm_nt_x6_supported(int64_t M, int N, int K) { return (M > 0 && N >= 128 && N % 4 == 0 && K % BK == 0) ? 1 : 0; }
+
+int alignn_gemm_nt_x6(const float* A, int64_t lda, const void* Wsplit, const float* bias, const float* addend,
+                      int64_t ldadd, float* C, int64_t ldc, int64_t M, int N, int K, alignn_stream_t stream) {
+    if (!alignn_gemm_nt_x6_supported(M, N, K)) return (int)hipErrorInvalidValue;
+    if ((lda & 3) || (ldc & 3) || !a16(A) || !a16(C) || !a16(Wsplit) || (bias && !a16(bias)) ||
+        (addend && ((ldadd & 3) || !a16(addend))))
+        return (int)hipErrorInvalidValue;
+    static bool attr_set = false;
+    constexpr int lds = LDS_BYTES;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    X6Args g{A, lda, (const unsigned char*)Wsplit, bias, addend, ldadd, C, ldc, M, N, npad(N), K};
+    dim3 grid(alignn_ceil_div(M, BM), npad(N) / BN);
+    hipLaunchKernelGGL(gemm_nt_x6_kernel, grid, dim3(NT), lds, (hipStream_t)stream, g);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

@@ -41,6 +41,59 @@ def gemm_nt(a, w, bias=None, addend=None, out=None):
     return out
 
 
+X6_MIN_ROWS = 1024  # below this the 128x256-tile bf16x6 kernel has nothing to win
+
+
+class SplitWeight:
+    """A weight pre-sliced into the bf16x6 kernel's DMA image (opaque device buffer + logical shape)."""
+
+    def __init__(self, buf, n, k):
+        self.buf, self.n, self.k = buf, n, k
+
+
+def split_bf16x3(w, transpose=False):
+    """Slice ``w`` [N,K] (or ``w^T`` of a stored [K,N] matrix) into three truncated-bf16 planes."""
+    lib = _lib.load()
+    require_f32(w)
+    n, k = (w.shape[1], w.shape[0]) if transpose else (w.shape[0], w.shape[1])
+    buf = torch.empty(lib.alignn_split_bf16x3_bytes(n, k), dtype=torch.uint8, device=w.device)
+    check(lib.alignn_split_bf16x3(ptr(w), w.stride(0), n, k, int(transpose), ptr(buf), stream()), "split_bf16x3")
+    return SplitWeight(buf, n, k)
+
+
+def gemm_nt_x6(a, ws, bias=None, addend=None, out=None):
+    """out[M,N] = a[M,K] @ W[N,K]^T with W pre-sliced by ``split_bf16x3`` (fp32-grade accuracy, bf16 MFMA)."""
+    lib = _lib.load()
+    require_f32(a, bias, addend)
+    M, K = a.shape
+    N = ws.n
+    if K != ws.k:
+        raise ValueError(f"reduction length mismatch: {K} vs {ws.k}")
+    if out is None:
+        out = _empty(M, N, like=a)
+    check(
+        lib.alignn_gemm_nt_x6(ptr(a), a.stride(0), ptr(ws.buf), ptr(bias), ptr(addend),
+                              addend.stride(0) if addend is not None else 0, ptr(out), out.stride(0), M, N, K, stream()),
+        "gemm_nt_x6",
+    )
+    return out
+
+
+def project(a, w, bias=None, addend=None, transpose_w=False):
+    """a @ W^T (transpose_w: a @ W) choosing the kernel: bf16x6 for the wide, deep products that dominate
+    the step, the exact-fp32 MFMA kernel otherwise."""
+    lib = _lib.load()
+    M = a.shape[0]
+    N, K = (w.shape[1], w.shape[0]) if transpose_w else (w.shape[0], w.shape[1])
+    if M >= X6_MIN_ROWS and a.stride(0) % 4 == 0 and lib.alignn_gemm_nt_x6_supported(M, N, K):
+        return gemm_nt_x6(a, split_bf16x3(w, transpose_w), bias, addend)
+    if transpose_w:
+        if w.shape[0] % 4 == 0 and w.shape[1] >= 16:
+            return gemm_nt(a, w.t().contiguous(), bias, addend)
+        return gemm_nn(a, w, addend)
+    return gemm_nt(a, w, bias, addend)
+
+
 def gemm_nn(g, w, addend=None, out=None):
     """out[M,K] = g[M,N] @ w[N,K] (+addend)."""
     lib = _lib.load()
@@ -58,12 +111,8 @@ def gemm_nn(g, w, addend=None, out=None):
 
 
 def _dgrad(g, w, addend=None):
-    """Input gradient g[M,N] @ w[N,K].  The reduction-contiguous (NT) form of the MFMA kernel is the
-    faster one (both operands fetched with ds_read_b128), so transpose the small weight once and use it;
-    ``gemm_nn`` stays the general entry point for callers that cannot afford the transpose."""
-    if w.shape[0] % 4 == 0 and w.shape[1] >= 16:
-        return gemm_nt(g, w.t().contiguous(), None, addend)
-    return gemm_nn(g, w, addend)
+    """Input gradient g[M,N] @ w[N,K] through the reduction-contiguous (NT) kernels on w^T."""
+    return project(g, w, None, addend, transpose_w=True)
 
 
 def gemm_tn(g, a):
@@ -158,7 +207,7 @@ class LinearFn(torch.autograd.Function):
         w = w.contiguous()
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
-        return gemm_nt(x, w, b)
+        return project(x, w, b)
 
     @staticmethod
     def backward(ctx, gy):
@@ -189,7 +238,7 @@ class MLPLayerFn(torch.autograd.Function):
         lib = _lib.load()
         x = x.contiguous()
         w = w.contiguous()
-        pre = gemm_nt(x, w, b)
+        pre = project(x, w, b)
         rows, F = pre.shape
         if training:
             slabs = lib.alignn_col_stats_slabs(rows)
@@ -239,8 +288,8 @@ class EdgeGatedConvFn(torch.autograd.Function):
         m = y.shape[0]
         if n != graph.n_nodes or m != graph.n_edges:
             raise ValueError(f"feature rows ({n},{m}) do not match graph ({graph.n_nodes},{graph.n_edges})")
-        P = gemm_nt(x, wcat, bcat)  # [n,4H] = A | Bd | Bh | Ux
-        M = gemm_nt(y, w_eg, b_eg)  # [m,H]  -> m_pre in place
+        P = project(x, wcat, bcat)  # [n,4H] = A | Bd | Bh | Ux
+        M = project(y, w_eg, b_eg)  # [m,H]  -> m_pre in place
         xpre = _empty(n, H, like=x)
         s0 = _empty(n, H, like=x)
         hh = _empty(n, H, like=x)

@@ -62,6 +62,23 @@ int alignn_gemm_tn(const float* G, int64_t ldg, const float* A, int64_t lda, flo
                    int64_t M, int N, int K, void* workspace, size_t workspace_bytes,
                    alignn_stream_t stream);
 
+/* fp32-accurate projection on the bf16 matrix cores ("bf16x6", csrc/gemm_x6.hip): every fp32 value is cut
+ * into three truncated bf16 slices and the six slice products of weight >= 2^-16 are accumulated in fp32
+ * (error <= an fp32 FMA chain; 2.7x the fp32-MFMA rate, which makes the HxH projections HBM-bound).
+ *   alignn_split_bf16x3: slices W[N,K] (transpose != 0: the [N,K] matrix W^T of a stored [K,N] W) into the
+ *                        kernel's DMA image (three bf16 planes, k-blocked, rows padded to 256, XOR-swizzled);
+ *                        `out` holds alignn_split_bf16x3_bytes(N, K) bytes; K % 16 == 0.  Run once per
+ *                        weight per step (384 KiB for 256x256).
+ *   alignn_gemm_nt_x6:   C[M,N] = A[M,K] * W[N,K]^T (+bias) (+addend), W given pre-sliced;
+ *                        needs K % 16 == 0, N >= 128, N % 4 == 0 (alignn_gemm_nt_x6_supported). */
+size_t alignn_split_bf16x3_bytes(int N, int K);
+int alignn_split_bf16x3(const float* W, int64_t ldw, int N, int K, int transpose, void* out,
+                        alignn_stream_t stream);
+int alignn_gemm_nt_x6_supported(int64_t M, int N, int K);
+int alignn_gemm_nt_x6(const float* A, int64_t lda, const void* Wsplit, const float* bias,
+                      const float* addend, int64_t ldadd, float* C, int64_t ldc,
+                      int64_t M, int N, int K, alignn_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Column statistics / BatchNorm1d + SiLU (+ residual).
  * Replace nn.BatchNorm1d (training: batch statistics over ALL rows; eps 1e-5; momentum 0.1,

@@ -55,6 +55,38 @@ def test_gemm_tn(M, N, K):
     assert rel_err(out, ref) < 5e-6
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 128, 32), (300, 256, 256), (5000, 1024, 256), (1000, 256, 1024), (129, 132, 64),
+                                   (70000, 256, 256)])
+def test_gemm_x6_accuracy(M, N, K):
+    """bf16x6 split product: error vs float64 must be fp32-grade (not bf16-grade), bias/addend included."""
+    a, w, b, add = r(M, K, seed=1), r(N, K, seed=2, scale=K**-0.5), r(N, seed=3), r(M, N, seed=4)
+    out = ops.gemm_nt_x6(a, ops.split_bf16x3(w), b, add)
+    ref = a.double().cpu() @ w.double().cpu().t() + b.double().cpu() + add.double().cpu()
+    e_x6 = rel_err(out, ref)
+    e_f32 = rel_err(ops.gemm_nt(a, w, b, add), ref)
+    assert e_x6 < 2e-6, (e_x6, e_f32)
+    assert e_x6 < 4 * e_f32 + 2e-7, (e_x6, e_f32)
+    # transposed slicing (what the input-gradient product uses)
+    wt = w.t().contiguous()  # [K,N]
+    out_t = ops.gemm_nt_x6(a, ops.split_bf16x3(wt, transpose=True), b, add)
+    assert torch.equal(out_t, out)
+
+
+def test_gemm_x6_asymmetric_identity_and_extremes():
+    n = 256
+    w = (torch.arange(n * n, dtype=torch.float32, device=DEV).reshape(n, n) - 3000.0) * 1.2345e-3
+    out = ops.gemm_nt_x6(torch.eye(n, device=DEV), ops.split_bf16x3(w))
+    assert rel_err(out, w.t().double().cpu()) < 1e-7  # three slices carry 24 mantissa bits
+    # tiny / huge magnitudes and exact zeros survive the slicing
+    a = torch.zeros(128, 32, device=DEV)
+    a[0, 0], a[1, 1], a[2, 2] = 1e-20, 3e20, -7.0
+    w2 = torch.zeros(128, 32, device=DEV)
+    w2[5, 0], w2[6, 1], w2[7, 2] = 2e10, 1e-15, 0.5
+    o = ops.gemm_nt_x6(a, ops.split_bf16x3(w2))
+    assert abs(float(o[0, 5]) / 2e-10 - 1) < 1e-6 and abs(float(o[1, 6]) / 3e5 - 1) < 1e-6 and float(o[2, 7]) == -3.5
+    assert float(o[3].abs().max()) == 0.0
+
+
 def test_gemm_strided_views():
     # operands that are column blocks of a wider matrix (how the conv backward uses them)
     big = r(500, 1024, seed=5)

@@ -1,0 +1,31 @@
+"""Ablation of the bf16x6 GEMM kernel: builds variants with parts stubbed out and times them
+(T x 256 x 256).  Results are only meaningful as time differences; stubbed variants compute garbage."""
+import ctypes as C, os, subprocess, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "alignn_amd", "csrc", "gemm_x6.hip")
+OUT = os.path.join(ROOT, "gpurun_out")
+VARIANTS = {"base": [], "noslice": ["-DX6_ABL_NOSLICE=1"], "nobload": ["-DX6_ABL_NOBLOAD=1"], "noaload": ["-DX6_ABL_NOALOAD=1"],
+            "onemfma": ["-DX6_ABL_ONEMFMA=1"], "noloads": ["-DX6_ABL_NOBLOAD=1", "-DX6_ABL_NOALOAD=1"],
+            "noloads_noslice": ["-DX6_ABL_NOBLOAD=1", "-DX6_ABL_NOALOAD=1", "-DX6_ABL_NOSLICE=1"]}
+def build():
+    os.makedirs(OUT, exist_ok=True)
+    for k, fl in VARIANTS.items():
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", SRC, "-o", os.path.join(ROOT, "tools", f"_x6_{k}.so")] + fl, check=True)
+def run():
+    M, N, K = 676200, 256, 256
+    a = torch.randn(M, K, device="cuda"); w = torch.randn(3, N, K, device="cuda").to(torch.bfloat16); c = torch.empty(M, N, device="cuda")
+    for k in VARIANTS:
+        lib = C.CDLL(os.path.join(ROOT, "tools", f"_x6_{k}.so"))
+        f = lib.alignn_gemm_nt_x6
+        f.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p]
+        st = torch.cuda.current_stream().cuda_stream
+        call = lambda: f(a.data_ptr(), K, w.data_ptr(), None, None, 0, c.data_ptr(), N, M, N, K, st)
+        for _ in range(3): call()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(10): call()
+        e.record(); torch.cuda.synchronize()
+        print(f"{k:18s} {s.elapsed_time(e)/10*1e3:8.1f} us", flush=True)
+if __name__ == "__main__":
+    build() if sys.argv[1] == "build" else run()
