@@ -23,6 +23,53 @@ def _empty(*shape, like):
 
 
 # ---------------------------------------------------------------------------------------------
+# side stream for weight gradients
+#
+# dW = G^T X is MFMA-bound and nothing in the rest of the backward pass depends on it, while the kernels
+# that follow it on the critical path (BatchNorm reductions, gate backward) are HBM-bound.  Issuing the
+# weight-gradient GEMMs and bias column-sums on a second HIP stream lets the two kinds of work share the
+# CUs.  The main stream joins the side stream once, in a callback the autograd engine runs at the end of
+# backward(), so callers see ordinary semantics (grads are ready for optimizer.step()).
+# ---------------------------------------------------------------------------------------------
+import os as _os
+
+_SIDE = {"enabled": _os.environ.get("ALIGNN_AMD_SIDE_STREAM", "1") != "0", "streams": {}, "armed": False}
+
+
+def _join_side_streams():
+    _SIDE["armed"] = False
+    for dev, side in _SIDE["streams"].items():
+        torch.cuda.current_stream(dev).wait_stream(side)
+
+
+def on_side_stream(fn, inputs):
+    """Run ``fn()`` (kernel launches only) on the side stream; returns its tensors.  ``inputs`` are the
+    tensors it reads (kept alive for the allocator until the side stream has consumed them)."""
+    if not _SIDE["enabled"]:
+        return fn()
+    dev = inputs[0].device
+    main = torch.cuda.current_stream(dev)
+    side = _SIDE["streams"].get(dev)
+    if side is None:
+        side = _SIDE["streams"][dev] = torch.cuda.Stream(device=dev)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        outs = fn()
+    for t in inputs:
+        t.record_stream(side)
+    for o in outs:
+        if o is not None:
+            o.record_stream(main)
+    if not _SIDE["armed"]:
+        _SIDE["armed"] = True
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_join_side_streams)
+        except RuntimeError:  # not inside backward(): join right away
+            _join_side_streams()
+    return outs
+
+
+# ---------------------------------------------------------------------------------------------
 # thin launch wrappers
 # ---------------------------------------------------------------------------------------------
 def gemm_nt(a, w, bias=None, addend=None, out=None):
@@ -261,9 +308,8 @@ class MLPLayerFn(torch.autograd.Function):
         red = _bn_silu_bwd_reduce(gy, pre, stat)
         dbeta, dgamma = red[0], red[1]
         gpre = _bn_silu_bwd_apply(gy, pre, stat, gamma, red, not ctx.training, torch.empty_like(pre))
+        gw, gb = on_side_stream(lambda: (gemm_tn(gpre, x), col_sum(gpre)), [gpre, x])
         gx = _dgrad(gpre, w) if ctx.needs_input_grad[0] else None
-        gw = gemm_tn(gpre, x)
-        gb = col_sum(gpre)
         return gx, gw, gb, dgamma, dbeta, None, None, None
 
 
@@ -356,14 +402,15 @@ class EdgeGatedConvFn(torch.autograd.Function):
                                    n, H, ptr(GP), stream()),
             "egc_bwd_src",
         )
-        # projections
+        # projections: weight gradients on the side stream, input gradients (critical path) on the main one
+        def _wgrads():
+            g_beg_ = _empty(H, like=x)  # column sum of GM, accumulated inside the destination-order pass
+            check(lib.alignn_slab_sum(ptr(gb_part), gslabs, H, ptr(g_beg_), stream()), "slab_sum")
+            return gemm_tn(GM, y), g_beg_, gemm_tn(GP, x), col_sum(GP)
+
+        g_weg, g_beg, g_wcat, g_bcat = on_side_stream(_wgrads, [GM, y, GP, x, gb_part])
         g_x = _dgrad(GP, wcat, addend=gx_out if ctx.residual else None)
-        g_wcat = gemm_tn(GP, x)
-        g_bcat = col_sum(GP)
         g_y = _dgrad(GM, w_eg, addend=gy_out if (ctx.residual and gy_out is not None) else None)
-        g_weg = gemm_tn(GM, y)
-        g_beg = _empty(H, like=x)  # column sum of GM, accumulated inside the destination-order pass
-        check(lib.alignn_slab_sum(ptr(gb_part), gslabs, H, ptr(g_beg), stream()), "slab_sum")
         dn_gamma, dn_beta = n_red[1], n_red[0]
         de_gamma = e_red[1] if e_red is not None else None
         de_beta = e_red[0] if e_red is not None else None
