@@ -74,23 +74,30 @@ class RBFExpansion(nn.Module):
         return ops.rbf_expand(distance, self.centers, self.gamma)
 
 
-def _bump(bn: nn.BatchNorm1d, training: bool):
-    if training and bn.num_batches_tracked is not None:
+def _bump(bn: nn.Module, training: bool):
+    if training and getattr(bn, "num_batches_tracked", None) is not None:
         bn.num_batches_tracked += 1
 
 
 class MLPLayer(nn.Module):
     """Linear + BatchNorm1d + SiLU (alignn/models/alignn.py:170-184)."""
 
+    _norm = "batch"  # the LayerNorm twin lives in alignn_amd.alignn_atomwise
+
+    @staticmethod
+    def _norm_layer(features: int) -> nn.Module:
+        return nn.BatchNorm1d(features)
+
     def __init__(self, in_features: int, out_features: int):
         super().__init__()
-        self.layer = nn.Sequential(nn.Linear(in_features, out_features), nn.BatchNorm1d(out_features), nn.SiLU())
+        self.layer = nn.Sequential(nn.Linear(in_features, out_features), self._norm_layer(out_features), nn.SiLU())
 
     def forward(self, x):
         lin, bn = self.layer[0], self.layer[1]
         _bump(bn, self.training)
         return ops.MLPLayerFn.apply(
-            x, lin.weight, lin.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, self.training
+            x, lin.weight, lin.bias, bn.weight, bn.bias, getattr(bn, "running_mean", None),
+            getattr(bn, "running_var", None), self.training, self._norm,
         )
 
 
@@ -118,16 +125,22 @@ class EdgeGatedGraphConv(nn.Module):
     slot order - the fast path used inside ``ALIGNN``).
     """
 
+    _norm = "batch"
+
+    @staticmethod
+    def _norm_layer(features: int) -> nn.Module:
+        return nn.BatchNorm1d(features)
+
     def __init__(self, input_features: int, output_features: int, residual: bool = True):
         super().__init__()
         self.residual = residual
         self.src_gate = nn.Linear(input_features, output_features)
         self.dst_gate = nn.Linear(input_features, output_features)
         self.edge_gate = nn.Linear(input_features, output_features)
-        self.bn_edges = nn.BatchNorm1d(output_features)
+        self.bn_edges = self._norm_layer(output_features)
         self.src_update = nn.Linear(input_features, output_features)
         self.dst_update = nn.Linear(input_features, output_features)
-        self.bn_nodes = nn.BatchNorm1d(output_features)
+        self.bn_nodes = self._norm_layer(output_features)
 
     def forward(self, g, node_feats: torch.Tensor, edge_feats: torch.Tensor, need_edge_out: bool = True):
         """``need_edge_out=False`` (internal): the caller will discard ``y``; it is then returned as None and
@@ -141,9 +154,11 @@ class EdgeGatedGraphConv(nn.Module):
         _bump(self.bn_edges, self.training)
         x, y = ops.EdgeGatedConvFn.apply(
             csr, node_feats, y_in, wcat, bcat, self.edge_gate.weight, self.edge_gate.bias,
-            self.bn_nodes.weight, self.bn_nodes.bias, self.bn_nodes.running_mean, self.bn_nodes.running_var,
-            self.bn_edges.weight, self.bn_edges.bias, self.bn_edges.running_mean, self.bn_edges.running_var,
-            self.training, self.residual, need_edge_out,
+            self.bn_nodes.weight, self.bn_nodes.bias, getattr(self.bn_nodes, "running_mean", None),
+            getattr(self.bn_nodes, "running_var", None),
+            self.bn_edges.weight, self.bn_edges.bias, getattr(self.bn_edges, "running_mean", None),
+            getattr(self.bn_edges, "running_var", None),
+            self.training, self.residual, need_edge_out, self._norm,
         )
         if not canonical and y is not None:
             y = y[csr.inv]
@@ -154,10 +169,12 @@ class ALIGNNConv(nn.Module):
     """Line graph update (alignn/models/alignn.py:132-167): bond-graph conv, then line-graph conv
     whose node inputs are the bond messages ``m``."""
 
+    _conv = EdgeGatedGraphConv
+
     def __init__(self, in_features: int, out_features: int):
         super().__init__()
-        self.node_update = EdgeGatedGraphConv(in_features, out_features)
-        self.edge_update = EdgeGatedGraphConv(out_features, out_features)
+        self.node_update = self._conv(in_features, out_features)
+        self.edge_update = self._conv(out_features, out_features)
 
     def forward(self, g, lg, x: torch.Tensor, y: torch.Tensor, z: torch.Tensor, need_z: bool = True):
         x, m = self.node_update(g, x, y)

@@ -1,0 +1,227 @@
+"""MI355X-native drop-in for ``alignn.models.alignn_atomwise`` - the LayerNorm flavour that
+``alignn/train.py`` actually trains (``"alignn_" in config.model.name``, train.py:238).
+
+Reference: ``/root/reference/alignn/models/alignn_atomwise.py`` (``ALIGNNAtomWiseConfig`` :28-77,
+``EdgeGatedGraphConv`` with ``nn.LayerNorm`` :127-208, ``ALIGNNConv`` :211-246, ``ALIGNNAtomWise``
+:249-660) and ``alignn/models/utils.py:277-292`` (``MLPLayer`` = Linear + LayerNorm + SiLU).  Same class names,
+constructor arguments, ``state_dict`` keys and result dictionary.
+
+Built in this round: the energy / property path (``calculate_gradient=False`` or ``gradwise_weight == 0``,
+which is what ``examples/sample_data/config_example.json`` runs), including the in-forward recomputation of the
+bond-angle cosines (``lg_on_fly``, :424-431).  The force / stress head (``autograd.grad(..., create_graph=True)``,
+:512-638) needs the kernels to be twice differentiable and raises ``NotImplementedError`` for now
+(DESIGN.md section 7).
+"""
+
+from __future__ import annotations
+
+from typing import Literal, Sequence, Union
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import alignn as _bn
+from . import ops
+from .alignn import _Base, _CONFIG, RBFExpansion  # noqa: F401  (RBFExpansion re-exported like the reference)
+from .graph import GraphBatch
+
+
+class ALIGNNAtomWiseConfig(_Base):
+    """Field-for-field the reference's schema (alignn/models/alignn_atomwise.py:31-72)."""
+
+    name: Literal["alignn_atomwise"]
+    alignn_layers: int = 2
+    gcn_layers: int = 2
+    atom_input_features: int = 1
+    edge_input_features: int = 80
+    triplet_input_features: int = 40
+    embedding_features: int = 64
+    hidden_features: int = 64
+    output_features: int = 1
+    grad_multiplier: int = -1
+    calculate_gradient: bool = True
+    atomwise_output_features: int = 0
+    graphwise_weight: float = 1.0
+    gradwise_weight: float = 1.0
+    stresswise_weight: float = 0.0
+    atomwise_weight: float = 0.0
+    link: Literal["identity", "log", "logit"] = "identity"
+    zero_inflated: bool = False
+    classification: bool = False
+    force_mult_natoms: bool = False
+    energy_mult_natoms: bool = True
+    include_pos_deriv: bool = False
+    use_cutoff_function: bool = False
+    inner_cutoff: float = 3
+    stress_multiplier: float = 1
+    add_reverse_forces: bool = True
+    lg_on_fly: bool = True
+    batch_stress: bool = True
+    multiply_cutoff: bool = False
+    use_penalty: bool = True
+    extra_features: int = 0
+    exponent: int = 5
+    penalty_factor: float = 0.1
+    penalty_threshold: float = 1
+    additional_output_features: int = 0
+    additional_output_weight: float = 0
+
+    model_config = _CONFIG
+
+
+class MLPLayer(_bn.MLPLayer):
+    """Linear + LayerNorm + SiLU (alignn/models/utils.py:277-292)."""
+
+    _norm = "layer"
+
+    @staticmethod
+    def _norm_layer(features: int) -> nn.Module:
+        return nn.LayerNorm(features)
+
+
+class EdgeGatedGraphConv(_bn.EdgeGatedGraphConv):
+    """Edge-gated convolution with LayerNorm on both branches (alignn_atomwise.py:127-208)."""
+
+    _norm = "layer"
+
+    @staticmethod
+    def _norm_layer(features: int) -> nn.Module:
+        return nn.LayerNorm(features)
+
+
+class ALIGNNConv(_bn.ALIGNNConv):
+    _conv = EdgeGatedGraphConv
+
+
+def cutoff_function_based_edges(r, inner_cutoff=4, exponent=3):
+    """Smooth polynomial envelope (alignn_atomwise.py:97-124); a few ops on the [E] bond-length vector."""
+    ratio = r / inner_cutoff
+    c1 = -(exponent + 1) * (exponent + 2) / 2
+    c2 = exponent * (exponent + 2)
+    c3 = -exponent * (exponent + 1) / 2
+    env = 1 + c1 * ratio**exponent + c2 * ratio ** (exponent + 1) + c3 * ratio ** (exponent + 2)
+    return torch.where(r <= inner_cutoff, env, torch.zeros_like(r))
+
+
+class ALIGNNAtomWise(nn.Module):
+    """Atomistic line graph network, LayerNorm flavour (alignn_atomwise.py:249-660)."""
+
+    def __init__(self, config: ALIGNNAtomWiseConfig = ALIGNNAtomWiseConfig(name="alignn_atomwise")):
+        super().__init__()
+        self.classification = config.classification
+        self.config = config
+        if self.config.gradwise_weight == 0:
+            self.config.calculate_gradient = False
+        self.atom_embedding = MLPLayer(config.atom_input_features, config.hidden_features)
+        self.edge_embedding = nn.Sequential(
+            RBFExpansion(vmin=0, vmax=8.0, bins=config.edge_input_features),
+            MLPLayer(config.edge_input_features, config.embedding_features),
+            MLPLayer(config.embedding_features, config.hidden_features),
+        )
+        self.angle_embedding = nn.Sequential(
+            RBFExpansion(vmin=-1, vmax=1.0, bins=config.triplet_input_features),
+            MLPLayer(config.triplet_input_features, config.embedding_features),
+            MLPLayer(config.embedding_features, config.hidden_features),
+        )
+        self.alignn_layers = nn.ModuleList(
+            [ALIGNNConv(config.hidden_features, config.hidden_features) for _ in range(config.alignn_layers)]
+        )
+        self.gcn_layers = nn.ModuleList(
+            [EdgeGatedGraphConv(config.hidden_features, config.hidden_features) for _ in range(config.gcn_layers)]
+        )
+        if config.extra_features != 0:
+            raise NotImplementedError("extra_features != 0 is outside the MI355X hot-path build (SURVEY.md section 8)")
+        if config.atomwise_output_features > 0:
+            self.fc_atomwise = nn.Linear(config.hidden_features, config.atomwise_output_features)
+        if config.additional_output_features:
+            self.fc_additional_output = nn.Linear(config.hidden_features, config.additional_output_features)
+        if self.classification:
+            self.fc = nn.Linear(config.hidden_features, 1)
+            self.softmax = nn.Sigmoid()
+        else:
+            self.fc = nn.Linear(config.hidden_features, config.output_features)
+        self.link = None
+        self.link_name = config.link
+        if config.link == "identity":
+            self.link = lambda x: x
+        elif config.link == "log":
+            self.link = torch.exp
+            self.fc.bias.data = torch.tensor(np.log(0.7), dtype=torch.float)
+        elif config.link == "logit":
+            self.link = torch.sigmoid
+
+    def _batch(self, g) -> GraphBatch:
+        dev = self.fc.weight.device
+        if isinstance(g, GraphBatch):
+            return g
+        if isinstance(g, (tuple, list)) and isinstance(g[0], GraphBatch):
+            return g[0]
+        if len(self.alignn_layers) > 0 and len(g) != 3:
+            raise NotImplementedError(
+                "forward((g, lat)) builds L(g) inside the forward (alignn_atomwise.py:376-386); device-side "
+                "line-graph construction is a 'next' row (SURVEY.md section 8(f) f1) - pass (g, lg, lat)"
+            )
+        gg = g[0]
+        lg = g[1] if len(self.alignn_layers) > 0 else None
+        cached = getattr(gg, "_alignn_amd_batch", None)
+        if cached is not None and cached.device == dev:
+            return cached
+        batch = GraphBatch.from_dgl(gg, lg, device=dev)
+        try:
+            gg._alignn_amd_batch = batch
+        except Exception:
+            pass
+        return batch
+
+    def forward(self, g: Union[Sequence, GraphBatch]):
+        cfg = self.config
+        if cfg.calculate_gradient:
+            raise NotImplementedError(
+                "calculate_gradient=True (force/stress head: autograd.grad with create_graph=True through the conv "
+                "stack, alignn_atomwise.py:512-638) is not built yet; set calculate_gradient=False / gradwise_weight=0"
+            )
+        if cfg.include_pos_deriv:
+            raise NotImplementedError("include_pos_deriv is 'not tested yet' upstream and outside this build")
+        b = self._batch(g)
+        n_a, n_g = len(self.alignn_layers), len(self.gcn_layers)
+        x = self.atom_embedding(b.atom_features)
+        bondlength = ops.bond_length(b.r)
+        if n_a > 0:
+            # lg_on_fly (default): recompute the cosines from r inside the forward (:424-431); otherwise use
+            # the loader's lg.edata["h"] (:370-371)
+            h = ops.bond_cosines(b.r, b.lg.src, b.lg.dst) if cfg.lg_on_fly else b.h
+            z = self.angle_embedding(h)
+        if cfg.use_cutoff_function:
+            if cfg.multiply_cutoff:
+                c_off = cutoff_function_based_edges(bondlength, cfg.inner_cutoff, cfg.exponent).unsqueeze(1)
+                y = self.edge_embedding(bondlength) * c_off
+            else:
+                y = self.edge_embedding(cutoff_function_based_edges(bondlength, cfg.inner_cutoff, cfg.exponent))
+        else:
+            y = self.edge_embedding(bondlength)
+        for i, layer in enumerate(self.alignn_layers):
+            x, y, z = layer(b.g, b.lg, x, y, z, need_z=i + 1 < n_a)
+        for i, layer in enumerate(self.gcn_layers):
+            x, y = layer(b.g, x, y, need_edge_out=i + 1 < n_g)
+        out = torch.empty(1)
+        additional_out = torch.empty(1)
+        if cfg.output_features is not None:
+            hpool = ops.AvgPoolFn.apply(x, b.graph_ptr)
+            out = torch.squeeze(ops.linear(hpool, self.fc.weight, self.fc.bias.reshape(-1)))
+            if cfg.additional_output_features > 0:
+                additional_out = ops.linear(hpool, self.fc_additional_output.weight, self.fc_additional_output.bias)
+        atomwise_pred = torch.empty(1)
+        if cfg.atomwise_output_features > 0 and cfg.atomwise_weight != 0:
+            atomwise_pred = ops.linear(x, self.fc_atomwise.weight, self.fc_atomwise.bias)
+        if self.link:
+            out = self.link(out)
+        if self.classification:
+            out = self.softmax(out)
+        return {
+            "out": out,
+            "additional": additional_out,
+            "grad": torch.empty(1),
+            "stresses": torch.empty(1),
+            "atomwise_pred": atomwise_pred,
+        }

@@ -155,9 +155,12 @@ struct EdgeNorm {
     float4 mean, rstd, sc, sh, c0, c1;
 };
 
-template <bool HAS_GY>
+// MODE 0: edge output dead (no normalised-branch gradient); 1: BatchNorm/SiLU backward fused here from GY;
+// 2: GY already holds the finished normalised-branch gradient (LayerNorm flavour: alignn_ln_silu_bwd).
+template <int MODE>
 __device__ __forceinline__ float4 edge_grad(float4 m, float4 gy, float4 bh, float4 gs1, float4 gs0,
                                             const EdgeNorm& nrm, float inv_n, int eval_mode) {
+    constexpr bool HAS_GY = MODE == 1;
     float4 sg = f4_sigmoid(m);
     float4 gsig = f4_fma(gs1, bh, gs0);
     float4 gm;
@@ -179,10 +182,11 @@ __device__ __forceinline__ float4 edge_grad(float4 m, float4 gy, float4 bh, floa
             gm.w += nrm.sc.w * (gz.w - inv_n * (nrm.c0.w + xh.w * nrm.c1.w));
         }
     }
+    if (MODE == 2) gm = f4_add(gm, gy);
     return gm;
 }
 
-template <bool HAS_GY>
+template <int MODE>
 __global__ __launch_bounds__(kThreads) void egc_bwd_dst_kernel(
     const float* __restrict__ GY, const float* __restrict__ M, const float* __restrict__ P,
     const float* __restrict__ GS1, const float* __restrict__ GS0, const float* __restrict__ e_stat,
@@ -200,8 +204,9 @@ __global__ __launch_bounds__(kThreads) void egc_bwd_dst_kernel(
         const bool active = f < H;
         float4 gb = f4_zero();  // column sum of GM over this wave's segments (= edge_gate bias gradient)
         if (active) {
+        constexpr bool HAS_GY = MODE != 0;
         EdgeNorm nrm;
-        if (HAS_GY) {
+        if (MODE == 1) {
             nrm.mean = f4_ld(e_stat + f);
             nrm.rstd = f4_ld(e_stat + H + f);
             nrm.sc = f4_ld(e_stat + 2 * H + f);
@@ -229,7 +234,7 @@ __global__ __launch_bounds__(kThreads) void egc_bwd_dst_kernel(
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    float4 gm = edge_grad<HAS_GY>(m[k], gy[k], bh[k], gs1, gs0, nrm, inv_n, e_eval);
+                    float4 gm = edge_grad<MODE>(m[k], gy[k], bh[k], gs1, gs0, nrm, inv_n, e_eval);
                     f4_st(GM + (int64_t)(e + k) * H + f, gm);
                     gbd = f4_add(gbd, gm);
                 }
@@ -240,7 +245,7 @@ __global__ __launch_bounds__(kThreads) void egc_bwd_dst_kernel(
                 float4 bh = f4_ld(P + (int64_t)u * ldp + 2 * H + f);
                 float4 gy = f4_zero();
                 if (HAS_GY) gy = f4_ld(GY + (int64_t)e * H + f);
-                float4 gm = edge_grad<HAS_GY>(m, gy, bh, gs1, gs0, nrm, inv_n, e_eval);
+                float4 gm = edge_grad<MODE>(m, gy, bh, gs1, gs0, nrm, inv_n, e_eval);
                 f4_st(GM + (int64_t)e * H + f, gm);
                 gbd = f4_add(gbd, gm);
             }
@@ -348,11 +353,14 @@ int alignn_egc_bwd_dst(const float* GY, const float* M, const float* P, const fl
     if (!h_ok(H) || n_seg > INT32_MAX) return (int)hipErrorInvalidValue;
     const float inv_n = m_rows > 0 ? 1.0f / (float)m_rows : 0.0f;
     dim3 grid(egc_blocks(n_seg)), block(kThreads);
-    if (GY)
-        hipLaunchKernelGGL(egc_bwd_dst_kernel<true>, grid, block, 0, (hipStream_t)stream, GY, M, P, GS1, GS0, e_stat,
+    if (GY && e_stat)
+        hipLaunchKernelGGL(egc_bwd_dst_kernel<1>, grid, block, 0, (hipStream_t)stream, GY, M, P, GS1, GS0, e_stat,
+                           e_red, e_eval, inv_n, seg_ptr, seg_node, src, (int)n_seg, H, GM, GP, gb_partial);
+    else if (GY)  // e_stat == NULL: GY is the finished normalised-branch gradient (LayerNorm flavour)
+        hipLaunchKernelGGL(egc_bwd_dst_kernel<2>, grid, block, 0, (hipStream_t)stream, GY, M, P, GS1, GS0, e_stat,
                            e_red, e_eval, inv_n, seg_ptr, seg_node, src, (int)n_seg, H, GM, GP, gb_partial);
     else
-        hipLaunchKernelGGL(egc_bwd_dst_kernel<false>, grid, block, 0, (hipStream_t)stream, GY, M, P, GS1, GS0, e_stat,
+        hipLaunchKernelGGL(egc_bwd_dst_kernel<0>, grid, block, 0, (hipStream_t)stream, GY, M, P, GS1, GS0, e_stat,
                            e_red, e_eval, inv_n, seg_ptr, seg_node, src, (int)n_seg, H, GM, GP, gb_partial);
     ALIGNN_CHECK_LAUNCH();
     return 0;

@@ -60,6 +60,20 @@ __global__ void segment_mean_bwd_kernel(const float* __restrict__ G, const int32
     }
 }
 
+// compute_bond_cosines (alignn/graphs.py:847-864) on L(g): h = clamp(-r[e1].r[e2] / (|r[e1]||r[e2]|), -1, 1)
+__global__ void bond_cosine_kernel(const float* __restrict__ r, const int32_t* __restrict__ e1,
+                                   const int32_t* __restrict__ e2, float* __restrict__ h, int64_t T) {
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < T; k += (int64_t)gridDim.x * blockDim.x) {
+        const float* a = r + 3 * (int64_t)e1[k];
+        const float* b = r + 3 * (int64_t)e2[k];
+        const float ax = -a[0], ay = -a[1], az = -a[2];
+        const float dot = ax * b[0] + ay * b[1] + az * b[2];
+        const float na = sqrtf(ax * ax + ay * ay + az * az), nb = sqrtf(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]);
+        float c = dot / (na * nb);
+        h[k] = fminf(fmaxf(c, -1.0f), 1.0f);
+    }
+}
+
 __global__ void gather_rows_kernel(const float* __restrict__ in, const int32_t* __restrict__ perm,
                                    float* __restrict__ out, int64_t rows, int F) {
     const int64_t total = rows * F;
@@ -105,6 +119,14 @@ int alignn_segment_mean_bwd(const float* G, const int32_t* graph_ptr, float* GX,
                             alignn_stream_t stream) {
     if (B <= 0 || (H & 3)) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(segment_mean_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, G, graph_ptr, GX, H);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_bond_cosine_fwd(const float* r, const int32_t* e1, const int32_t* e2, float* h, int64_t T,
+                            alignn_stream_t stream) {
+    if (T == 0) return 0;
+    hipLaunchKernelGGL(bond_cosine_kernel, dim3(grid_for(T)), dim3(256), 0, (hipStream_t)stream, r, e1, e2, h, T);
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }

@@ -212,6 +212,152 @@ __global__ __launch_bounds__(kThreads) void bn_silu_bwd_apply_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// LayerNorm(+SiLU, +residual) - the ALIGNNAtomWise flavour (alignn/models/alignn_atomwise.py:151,155 and
+// alignn/models/utils.py:277-292): statistics per ROW over the F features, eps 1e-5, affine gamma/beta.
+// One wavefront per row; lane l owns features [4l, 4l+4) of each 256-feature chunk (NC chunks, F <= 1024);
+// two-pass variance in registers; row sums by __shfl_xor butterflies.  No global barrier is needed, so the
+// forward is one pass and the backward is one pass (+ fixed-order slabs for dgamma/dbeta).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float f4_hsum(float4 a) { return (a.x + a.y) + (a.z + a.w); }
+
+template <int NC, bool HAS_RES>
+__global__ __launch_bounds__(kThreads) void ln_silu_fwd_kernel(const float* __restrict__ X, int64_t ldx,
+                                                               const float* __restrict__ R, int64_t ldr,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float eps,
+                                                               float* __restrict__ Y, int64_t ldy,
+                                                               float* __restrict__ stats, int64_t rows, int F) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+    const int64_t stride = (int64_t)gridDim.x * (kThreads / 64);
+    const float inv_f = 1.0f / (float)F;
+    for (int64_t r = wave0; r < rows; r += stride) {
+        float4 x[NC];
+        float s = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int f = c * 256 + 4 * lane;
+            x[c] = f < F ? f4_ld(X + r * ldx + f) : f4_zero();
+            s += f4_hsum(x[c]);
+        }
+        const float mean = wave_sum(s) * inv_f;
+        float v = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int f = c * 256 + 4 * lane;
+            if (f < F) {
+                float4 d = make_float4(x[c].x - mean, x[c].y - mean, x[c].z - mean, x[c].w - mean);
+                v += f4_hsum(f4_mul(d, d));
+            }
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(v) * inv_f + eps);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int f = c * 256 + 4 * lane;
+            if (f < F) {
+                float4 g = f4_ld(gamma + f), b = f4_ld(beta + f);
+                float4 z;
+                z.x = (x[c].x - mean) * rstd * g.x + b.x;
+                z.y = (x[c].y - mean) * rstd * g.y + b.y;
+                z.z = (x[c].z - mean) * rstd * g.z + b.z;
+                z.w = (x[c].w - mean) * rstd * g.w + b.w;
+                float4 o = make_float4(silu_f(z.x), silu_f(z.y), silu_f(z.z), silu_f(z.w));
+                if (HAS_RES) o = f4_add(o, f4_ld(R + r * ldr + f));
+                f4_st(Y + r * ldy + f, o);
+            }
+        }
+        if (stats && lane == 0) {
+            stats[2 * r] = mean;
+            stats[2 * r + 1] = rstd;
+        }
+    }
+}
+
+template <int NC>
+__global__ __launch_bounds__(kThreads) void ln_silu_bwd_kernel(const float* __restrict__ GY, int64_t ldgy,
+                                                               const float* __restrict__ X, int64_t ldx,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta,
+                                                               const float* __restrict__ stats,
+                                                               float* __restrict__ GX, int64_t ldgx,
+                                                               float* __restrict__ partial, int64_t rows, int F) {
+    __shared__ float4 sh[2][kThreads / 64][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t wave0 = (int64_t)blockIdx.x * (kThreads / 64) + wave;
+    const int64_t stride = (int64_t)gridDim.x * (kThreads / 64);
+    const float inv_f = 1.0f / (float)F;
+    float4 dg[NC], db[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) dg[c] = db[c] = f4_zero();
+    for (int64_t r = wave0; r < rows; r += stride) {
+        const float mean = stats[2 * r], rstd = stats[2 * r + 1];
+        float4 xh[NC], gh[NC];
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int f = c * 256 + 4 * lane;
+            xh[c] = gh[c] = f4_zero();
+            if (f < F) {
+                float4 x = f4_ld(X + r * ldx + f), gy = f4_ld(GY + r * ldgy + f);
+                float4 g = f4_ld(gamma + f), b = f4_ld(beta + f);
+                xh[c] = make_float4((x.x - mean) * rstd, (x.y - mean) * rstd, (x.z - mean) * rstd, (x.w - mean) * rstd);
+                float4 z = f4_fma(xh[c], g, b);
+                float4 gz = make_float4(gy.x * dsilu_f(z.x), gy.y * dsilu_f(z.y), gy.z * dsilu_f(z.z), gy.w * dsilu_f(z.w));
+                db[c] = f4_add(db[c], gz);
+                dg[c] = f4_fma(gz, xh[c], dg[c]);
+                gh[c] = f4_mul(gz, g);
+                s1 += f4_hsum(gh[c]);
+                s2 += f4_hsum(f4_mul(gh[c], xh[c]));
+            }
+        }
+        const float c1 = wave_sum(s1) * inv_f, c2 = wave_sum(s2) * inv_f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int f = c * 256 + 4 * lane;
+            if (f < F) {
+                float4 o;
+                o.x = rstd * (gh[c].x - c1 - xh[c].x * c2);
+                o.y = rstd * (gh[c].y - c1 - xh[c].y * c2);
+                o.z = rstd * (gh[c].z - c1 - xh[c].z * c2);
+                o.w = rstd * (gh[c].w - c1 - xh[c].w * c2);
+                f4_st(GX + r * ldgx + f, o);
+            }
+        }
+    }
+    // slab [blockIdx.x][2][F]: row 0 = dbeta partial (sum gz), row 1 = dgamma partial (sum gz*xhat)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        sh[0][wave][lane] = db[c];
+        sh[1][wave][lane] = dg[c];
+        __syncthreads();
+        const int f = c * 256 + 4 * lane;
+        if (wave == 0 && f < F) {
+            float4 a = sh[0][0][lane], b = sh[1][0][lane];
+#pragma unroll
+            for (int w = 1; w < kThreads / 64; ++w) {
+                a = f4_add(a, sh[0][w][lane]);
+                b = f4_add(b, sh[1][w][lane]);
+            }
+            f4_st(partial + (size_t)blockIdx.x * 2 * F + f, a);
+            f4_st(partial + (size_t)blockIdx.x * 2 * F + F + f, b);
+        }
+        __syncthreads();
+    }
+}
+
+inline int ln_blocks(int64_t rows) {
+    int64_t b = (rows + (kThreads / 64) - 1) / (kThreads / 64);
+    if (b < 1) b = 1;
+    if (b > kMaxSlabs) b = kMaxSlabs;
+    return (int)b;
+}
+
 inline bool feat_ok(int F) { return F >= 4 && (F & 3) == 0 && F <= 1024; }
 inline int stream_grid(int64_t total) {
     int64_t g = (total + kThreads - 1) / kThreads;
@@ -294,6 +440,50 @@ int alignn_bn_bwd_finalize(const float* partial, int slabs, int F, float* red, a
     if (F <= 0 || slabs <= 0) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(slab_sum_kernel, dim3(alignn_ceil_div(2 * F, kRedCols)), dim3(kRedCols, kRedLanes), 0,
                        (hipStream_t)stream, partial, slabs, 2 * F, 2 * F, red);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_ln_slabs(int64_t rows) { return ln_blocks(rows); }
+
+int alignn_ln_silu_fwd(const float* X, int64_t ldx, const float* R, int64_t ldr, const float* gamma, const float* beta,
+                       float eps, float* Y, int64_t ldy, float* stats, int64_t rows, int F, alignn_stream_t stream) {
+    if (!feat_ok(F)) return (int)hipErrorInvalidValue;
+    if (rows == 0) return 0;
+    const int nc = (F + 255) / 256;
+    dim3 grid(ln_blocks(rows)), block(kThreads);
+    hipStream_t st = (hipStream_t)stream;
+#define ALIGNN_LN_FWD(NC_)                                                                                         \
+    if (R)                                                                                                         \
+        hipLaunchKernelGGL((ln_silu_fwd_kernel<NC_, true>), grid, block, 0, st, X, ldx, R, ldr, gamma, beta, eps, Y, \
+                           ldy, stats, rows, F);                                                                   \
+    else                                                                                                           \
+        hipLaunchKernelGGL((ln_silu_fwd_kernel<NC_, false>), grid, block, 0, st, X, ldx, R, ldr, gamma, beta, eps, Y, \
+                           ldy, stats, rows, F);
+    switch (nc) {
+        case 1: ALIGNN_LN_FWD(1) break;
+        case 2: ALIGNN_LN_FWD(2) break;
+        case 3: ALIGNN_LN_FWD(3) break;
+        default: ALIGNN_LN_FWD(4) break;
+    }
+#undef ALIGNN_LN_FWD
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_ln_silu_bwd(const float* GY, int64_t ldgy, const float* X, int64_t ldx, const float* gamma,
+                       const float* beta, const float* stats, float* GX, int64_t ldgx, float* partial, int64_t rows,
+                       int F, alignn_stream_t stream) {
+    if (!feat_ok(F)) return (int)hipErrorInvalidValue;
+    const int nc = (F + 255) / 256;
+    dim3 grid(ln_blocks(rows)), block(kThreads);
+    hipStream_t st = (hipStream_t)stream;
+    switch (nc) {
+        case 1: hipLaunchKernelGGL(ln_silu_bwd_kernel<1>, grid, block, 0, st, GY, ldgy, X, ldx, gamma, beta, stats, GX, ldgx, partial, rows, F); break;
+        case 2: hipLaunchKernelGGL(ln_silu_bwd_kernel<2>, grid, block, 0, st, GY, ldgy, X, ldx, gamma, beta, stats, GX, ldgx, partial, rows, F); break;
+        case 3: hipLaunchKernelGGL(ln_silu_bwd_kernel<3>, grid, block, 0, st, GY, ldgy, X, ldx, gamma, beta, stats, GX, ldgx, partial, rows, F); break;
+        default: hipLaunchKernelGGL(ln_silu_bwd_kernel<4>, grid, block, 0, st, GY, ldgy, X, ldx, gamma, beta, stats, GX, ldgx, partial, rows, F); break;
+    }
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }

@@ -242,6 +242,51 @@ def _bn_silu_bwd_apply(gy, x, stat, gamma, red, eval_mode, out):
     return out
 
 
+LN_EPS = 1e-5
+
+
+def _ln_silu_fwd(x, res, gamma, beta, want_stats=True):
+    """Y = res + silu(LayerNorm(x)); returns (Y, stats[rows,2] = mean, rstd)."""
+    lib = _lib.load()
+    rows, F = x.shape
+    y = _empty(rows, F, like=x)
+    stats = _empty(rows, 2, like=x) if want_stats else None
+    check(
+        lib.alignn_ln_silu_fwd(ptr(x), x.stride(0), ptr(res), res.stride(0) if res is not None else 0, ptr(gamma),
+                               ptr(beta), LN_EPS, ptr(y), y.stride(0), ptr(stats), rows, F, stream()),
+        "ln_silu_fwd",
+    )
+    return y, stats
+
+
+def _ln_silu_bwd(gy, x, gamma, beta, stats, out):
+    """LayerNorm/SiLU backward into ``out``; returns red [2,F] = (dbeta, dgamma)."""
+    lib = _lib.load()
+    rows, F = x.shape
+    slabs = lib.alignn_ln_slabs(rows)
+    partial = _empty(slabs, 2, F, like=x)
+    check(
+        lib.alignn_ln_silu_bwd(ptr(gy), gy.stride(0), ptr(x), x.stride(0), ptr(gamma), ptr(beta), ptr(stats), ptr(out),
+                               out.stride(0), ptr(partial), rows, F, stream()),
+        "ln_silu_bwd",
+    )
+    red = _empty(2, F, like=x)
+    check(lib.alignn_bn_bwd_finalize(ptr(partial), slabs, F, ptr(red), stream()), "ln_bwd_finalize")
+    return red
+
+
+def bond_cosines(r, e1, e2):
+    """compute_bond_cosines on the canonical line graph (alignn/graphs.py:847-864)."""
+    lib = _lib.load()
+    if r.requires_grad:
+        raise NotImplementedError("gradient w.r.t. bond vectors (force head) is not part of this build yet")
+    require_f32(r)
+    r = r.contiguous()
+    h = _empty(e1.numel(), like=r)
+    check(lib.alignn_bond_cosine_fwd(ptr(r), ptr(e1), ptr(e2), ptr(h), e1.numel(), stream()), "bond_cosine_fwd")
+    return h
+
+
 # ---------------------------------------------------------------------------------------------
 # Linear
 # ---------------------------------------------------------------------------------------------
@@ -280,37 +325,45 @@ def linear(x, w, b=None):
 # MLPLayer = Linear + BatchNorm1d + SiLU   (alignn/models/alignn.py:170-184)
 # ---------------------------------------------------------------------------------------------
 class MLPLayerFn(torch.autograd.Function):
+    """``norm`` = "batch" (alignn/models/alignn.py:170-184) or "layer" (alignn/models/utils.py:277-292)."""
+
     @staticmethod
-    def forward(ctx, x, w, b, gamma, beta, running_mean, running_var, training):
+    def forward(ctx, x, w, b, gamma, beta, running_mean, running_var, training, norm="batch"):
         lib = _lib.load()
         x = x.contiguous()
         w = w.contiguous()
         pre = project(x, w, b)
         rows, F = pre.shape
-        if training:
-            slabs = lib.alignn_col_stats_slabs(rows)
-            partial = _empty(slabs, 2, F, like=pre)
-            check(lib.alignn_col_stats(ptr(pre), pre.stride(0), rows, F, ptr(partial), stream()), "col_stats")
-            stat = _bn_finalize(partial, slabs, rows, gamma, beta, running_mean, running_var, True)
+        if norm == "layer":
+            y, stat = _ln_silu_fwd(pre, None, gamma, beta)
         else:
-            stat = _bn_finalize(None, 0, rows, gamma, beta, running_mean, running_var, False)
-        y = _bn_silu_fwd(pre, None, stat)
-        ctx.save_for_backward(x, w, pre, stat, gamma)
+            if training:
+                slabs = lib.alignn_col_stats_slabs(rows)
+                partial = _empty(slabs, 2, F, like=pre)
+                check(lib.alignn_col_stats(ptr(pre), pre.stride(0), rows, F, ptr(partial), stream()), "col_stats")
+                stat = _bn_finalize(partial, slabs, rows, gamma, beta, running_mean, running_var, True)
+            else:
+                stat = _bn_finalize(None, 0, rows, gamma, beta, running_mean, running_var, False)
+            y = _bn_silu_fwd(pre, None, stat)
+        ctx.save_for_backward(x, w, pre, stat, gamma, beta)
         ctx.training = training
+        ctx.norm = norm
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, w, pre, stat, gamma = ctx.saved_tensors
+        x, w, pre, stat, gamma, beta = ctx.saved_tensors
         gy = gy.contiguous()
-        red = None
-        dgamma = dbeta = None
-        red = _bn_silu_bwd_reduce(gy, pre, stat)
+        gpre = torch.empty_like(pre)
+        if ctx.norm == "layer":
+            red = _ln_silu_bwd(gy, pre, gamma, beta, stat, gpre)
+        else:
+            red = _bn_silu_bwd_reduce(gy, pre, stat)
+            _bn_silu_bwd_apply(gy, pre, stat, gamma, red, not ctx.training, gpre)
         dbeta, dgamma = red[0], red[1]
-        gpre = _bn_silu_bwd_apply(gy, pre, stat, gamma, red, not ctx.training, torch.empty_like(pre))
         gw, gb = on_side_stream(lambda: (gemm_tn(gpre, x), col_sum(gpre)), [gpre, x])
         gx = _dgrad(gpre, w) if ctx.needs_input_grad[0] else None
-        return gx, gw, gb, dgamma, dbeta, None, None, None
+        return gx, gw, gb, dgamma, dbeta, None, None, None, None
 
 
 # ---------------------------------------------------------------------------------------------
@@ -325,7 +378,7 @@ class EdgeGatedConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, graph: CSRGraph, x, y, wcat, bcat, w_eg, b_eg, n_gamma, n_beta, n_rm, n_rv, e_gamma, e_beta, e_rm,
-                e_rv, training: bool, residual: bool, need_y: bool = True):
+                e_rv, training: bool, residual: bool, need_y: bool = True, norm: str = "batch"):
         lib = _lib.load()
         ctx.set_materialize_grads(False)
         x = x.contiguous()
@@ -340,59 +393,81 @@ class EdgeGatedConvFn(torch.autograd.Function):
         s0 = _empty(n, H, like=x)
         hh = _empty(n, H, like=x)
         slabs = lib.alignn_egc_slabs(n)
-        e_part = _empty(slabs, 2, H, like=x) if training else None
-        n_part = _empty(slabs, 2, H, like=x) if training else None
+        bn_train = training and norm == "batch"
+        e_part = _empty(slabs, 2, H, like=x) if bn_train else None
+        n_part = _empty(slabs, 2, H, like=x) if bn_train else None
         check(
             lib.alignn_egc_gate_fwd(ptr(P), ptr(M), ptr(graph.seg_ptr), ptr(graph.seg_node), ptr(graph.src), n, n, H,
                                     ptr(xpre), ptr(s0), ptr(hh), ptr(e_part), ptr(n_part), stream()),
             "egc_gate_fwd",
         )
-        if training:
-            n_stat = _bn_finalize(n_part, slabs, n, n_gamma, n_beta, n_rm, n_rv, True)
-            e_stat = _bn_finalize(e_part, slabs, m, e_gamma, e_beta, e_rm, e_rv, True)
+        if norm == "layer":
+            # LayerNorm flavour (alignn_atomwise.py:151,155): per-row statistics, no global barrier
+            x_out, n_stat = _ln_silu_fwd(xpre, x if residual else None, n_gamma, n_beta)
+            if need_y:
+                y_out, e_stat = _ln_silu_fwd(M, y if residual else None, e_gamma, e_beta)
+            else:
+                y_out, e_stat = None, _empty(1, 2, like=x)
         else:
-            n_stat = _bn_finalize(None, 0, n, n_gamma, n_beta, n_rm, n_rv, False)
-            e_stat = _bn_finalize(None, 0, m, e_gamma, e_beta, e_rm, e_rv, False)
-        x_out = _bn_silu_fwd(xpre, x if residual else None, n_stat)
-        # need_y == False: the caller discards the edge output (last layer) - skip the pass, keep the
-        # statistics side effect (running_mean/var of bn_edges are updated exactly as in the reference)
-        y_out = _bn_silu_fwd(M, y if residual else None, e_stat) if need_y else None
+            if training:
+                n_stat = _bn_finalize(n_part, slabs, n, n_gamma, n_beta, n_rm, n_rv, True)
+                e_stat = _bn_finalize(e_part, slabs, m, e_gamma, e_beta, e_rm, e_rv, True)
+            else:
+                n_stat = _bn_finalize(None, 0, n, n_gamma, n_beta, n_rm, n_rv, False)
+                e_stat = _bn_finalize(None, 0, m, e_gamma, e_beta, e_rm, e_rv, False)
+            x_out = _bn_silu_fwd(xpre, x if residual else None, n_stat)
+            # need_y == False: the caller discards the edge output (last layer) - skip the pass, keep the
+            # statistics side effect (running_mean/var of bn_edges are updated exactly as in the reference)
+            y_out = _bn_silu_fwd(M, y if residual else None, e_stat) if need_y else None
         ctx.graph = graph
         ctx.training = training
         ctx.residual = residual
-        ctx.save_for_backward(x, y, wcat, w_eg, P, M, xpre, s0, hh, n_stat, e_stat, n_gamma, e_gamma)
+        ctx.norm = norm
+        ctx.save_for_backward(x, y, wcat, w_eg, P, M, xpre, s0, hh, n_stat, e_stat, n_gamma, e_gamma, n_beta, e_beta)
         return x_out, y_out
 
     @staticmethod
     def backward(ctx, gx_out, gy_out):
         lib = _lib.load()
         graph: CSRGraph = ctx.graph
-        x, y, wcat, w_eg, P, M, xpre, s0, hh, n_stat, e_stat, n_gamma, e_gamma = ctx.saved_tensors
+        x, y, wcat, w_eg, P, M, xpre, s0, hh, n_stat, e_stat, n_gamma, e_gamma, n_beta, e_beta = ctx.saved_tensors
         n, H = x.shape
         m = y.shape[0]
         ev = not ctx.training
+        layer = ctx.norm == "layer"
         if gx_out is None:
             gx_out = torch.zeros_like(x)
         gx_out = gx_out.contiguous()
         GP = _empty(n, 4 * H, like=x)
-        # node branch: SiLU/BatchNorm backward -> g_xpre (stored as the Ux block of GP)
-        n_red = _bn_silu_bwd_reduce(gx_out, xpre, n_stat)
+        # node branch: SiLU/norm backward -> g_xpre (stored as the Ux block of GP)
         g_xpre = GP[:, 3 * H:]
-        _bn_silu_bwd_apply(gx_out, xpre, n_stat, n_gamma, n_red, ev, g_xpre)
+        if layer:
+            n_red = _ln_silu_bwd(gx_out, xpre, n_gamma, n_beta, n_stat, g_xpre)
+        else:
+            n_red = _bn_silu_bwd_reduce(gx_out, xpre, n_stat)
+            _bn_silu_bwd_apply(gx_out, xpre, n_stat, n_gamma, n_red, ev, g_xpre)
         gs1 = _empty(n, H, like=x)
         gs0 = _empty(n, H, like=x)
         check(lib.alignn_egc_node_bwd(ptr(g_xpre), 4 * H, ptr(s0), ptr(hh), ptr(gs1), ptr(gs0), n, H, stream()),
               "egc_node_bwd")
         # edge branch
         e_red = None
+        g_branch, e_stat_arg = gy_out, e_stat
         if gy_out is not None:
             gy_out = gy_out.contiguous()
-            e_red = _bn_silu_bwd_reduce(gy_out, M, e_stat)
+            if layer:
+                # LayerNorm: finish the normalised-branch gradient here, hand it over as-is (e_stat = NULL)
+                g_branch = _empty(m, H, like=x)
+                e_red = _ln_silu_bwd(gy_out, M, e_gamma, e_beta, e_stat, g_branch)
+                e_stat_arg = None
+            else:
+                g_branch = gy_out
+                e_red = _bn_silu_bwd_reduce(gy_out, M, e_stat)
         GM = _empty(m, H, like=x)
         gslabs = lib.alignn_egc_slabs(n)
         gb_part = _empty(gslabs, H, like=x)
         check(
-            lib.alignn_egc_bwd_dst(ptr(gy_out), ptr(M), ptr(P), ptr(gs1), ptr(gs0), ptr(e_stat), ptr(e_gamma),
+            lib.alignn_egc_bwd_dst(ptr(g_branch), ptr(M), ptr(P), ptr(gs1), ptr(gs0), ptr(e_stat_arg), ptr(e_gamma),
                                    ptr(e_red), int(ev), m, ptr(graph.seg_ptr), ptr(graph.seg_node), ptr(graph.src), n,
                                    H, ptr(GM), ptr(GP), ptr(gb_part), stream()),
             "egc_bwd_dst",
@@ -415,7 +490,7 @@ class EdgeGatedConvFn(torch.autograd.Function):
         de_gamma = e_red[1] if e_red is not None else None
         de_beta = e_red[0] if e_red is not None else None
         return (None, g_x, g_y, g_wcat, g_bcat, g_weg, g_beg, dn_gamma, dn_beta, None, None, de_gamma, de_beta, None,
-                None, None, None, None)
+                None, None, None, None, None)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -113,6 +113,18 @@ int alignn_bn_silu_bwd_reduce(const float* GY, int64_t ldgy, const float* X, int
                               alignn_stream_t stream);
 /* phase 1b: red[0][f]=sum gz (=dbeta), red[1][f]=sum gz*xhat (=dgamma) from the slabs */
 int alignn_bn_bwd_finalize(const float* partial, int slabs, int F, float* red, alignn_stream_t stream);
+/* LayerNorm flavour (ALIGNNAtomWise: alignn/models/alignn_atomwise.py:151,155; MLPLayer of
+ * alignn/models/utils.py:277-292): per-ROW statistics over the F features, eps, affine gamma/beta.
+ *   fwd: Y = (R ? R : 0) + silu(LayerNorm(X)); stats[r] = (mean, rstd) (may be NULL for inference)
+ *   bwd: GX = LayerNorm/SiLU backward of GY; partial[alignn_ln_slabs(rows)][2][F] = slabs of
+ *        (sum gz, sum gz*xhat) = (dbeta, dgamma), finished with alignn_bn_bwd_finalize. */
+int alignn_ln_slabs(int64_t rows);
+int alignn_ln_silu_fwd(const float* X, int64_t ldx, const float* R, int64_t ldr, const float* gamma,
+                       const float* beta, float eps, float* Y, int64_t ldy, float* stats, int64_t rows, int F,
+                       alignn_stream_t stream);
+int alignn_ln_silu_bwd(const float* GY, int64_t ldgy, const float* X, int64_t ldx, const float* gamma,
+                       const float* beta, const float* stats, float* GX, int64_t ldgx, float* partial,
+                       int64_t rows, int F, alignn_stream_t stream);
 /* out[f] = sum_s partial[s][f] over `slabs` slabs of `width` floats (fp64 accumulation, fixed order) */
 int alignn_slab_sum(const float* partial, int slabs, int width, float* out, alignn_stream_t stream);
 /* phase 2: GX = gamma*rstd*(gz - red0/rows - xhat*red1/rows)   (training-mode BatchNorm backward)
@@ -153,7 +165,9 @@ int alignn_egc_node_bwd(const float* GXPRE, int64_t ldg, const float* S0, const 
                         int64_t n_nodes, int H, alignn_stream_t stream);
 
 /* Destination-ordered backward pass.  Per slot e (dst i, src u):
- *   g_mbn = BatchNorm/SiLU backward of the edge branch (skipped when GY == NULL: dead edge output)
+ *   g_mbn = BatchNorm/SiLU backward of the edge branch (skipped when GY == NULL: dead edge output;
+ *           when e_stat == NULL, GY is taken to BE g_mbn already - the LayerNorm flavour computes it
+ *           with alignn_ln_silu_bwd)
  *   sigma = sigmoid(M[e]);  g_sigma = GS1[i]*Bh[u] + GS0[i]
  *   GM[e] = g_mbn + g_sigma*sigma*(1-sigma);   GP[i, H:2H] (g_Bd) = sum_e GM[e]
  * GP is the [n,4H] gradient of the fused node projection; this pass fills its Bd block.
@@ -180,6 +194,10 @@ int alignn_egc_bwd_src(const float* GM, const float* M, const float* GS1, const 
 /* RBFExpansion.forward (alignn/models/utils.py:40-44): out[r,k] = exp(-gamma (d[r]-c[k])^2) */
 int alignn_rbf_fwd(const float* d, const float* centers, float gamma, float* out, int64_t rows,
                    int bins, alignn_stream_t stream);
+/* compute_bond_cosines on L(g) (alignn/graphs.py:847-864; re-run inside ALIGNNAtomWise.forward when
+ * lg_on_fly, alignn_atomwise.py:424-431): h[k] = clamp(-r[e1[k]].r[e2[k]] / (|r[e1]| |r[e2]|), -1, 1) */
+int alignn_bond_cosine_fwd(const float* r, const int32_t* e1, const int32_t* e2, float* h, int64_t T,
+                           alignn_stream_t stream);
 /* torch.norm(r, dim=1) (alignn/models/alignn.py:313): out[r] = ||v[r,0:3]|| */
 int alignn_norm3_fwd(const float* v, float* out, int64_t rows, alignn_stream_t stream);
 /* dgl.nn.AvgPooling (alignn/models/alignn.py:325): out[b] = mean_{i in graph b} x[i]; graph_ptr[B+1] */

@@ -58,16 +58,28 @@ def _bn(x, p, prefix, training, stats):
     return (x - rm) * torch.rsqrt(rv + BN_EPS) * w + b
 
 
+LN_EPS = 1e-5
+
+
+def _ln(x, p, prefix):
+    """nn.LayerNorm over the feature dimension (alignn_atomwise.py:151,155; models/utils.py:285)."""
+    return F.layer_norm(x, (x.shape[1],), p[prefix + ".weight"], p[prefix + ".bias"], LN_EPS)
+
+
+def _norm(x, p, prefix, training, stats, norm):
+    return _ln(x, p, prefix) if norm == "layer" else _bn(x, p, prefix, training, stats)
+
+
 def _linear(x, p, prefix):
     return x @ p[prefix + ".weight"].t() + p[prefix + ".bias"]
 
 
-def mlp_layer(x, p, prefix, training, stats):
-    """alignn.py:170-184: SiLU(BatchNorm1d(Linear(x)))."""
-    return F.silu(_bn(_linear(x, p, prefix + ".layer.0"), p, prefix + ".layer.1", training, stats))
+def mlp_layer(x, p, prefix, training, stats, norm="batch"):
+    """alignn.py:170-184: SiLU(BatchNorm1d(Linear(x))); LayerNorm twin: models/utils.py:277-292."""
+    return F.silu(_norm(_linear(x, p, prefix + ".layer.0"), p, prefix + ".layer.1", training, stats, norm))
 
 
-def edge_gated_conv(p, prefix, u, v, x, y, training=True, stats=None, record=None, residual=True):
+def edge_gated_conv(p, prefix, u, v, x, y, training=True, stats=None, record=None, residual=True, norm="batch"):
     """alignn.py:78-129 with the DGL calls spelled out.
 
     ``u_add_v``  (alignn.py:100)      : A[u] + Bd[v]
@@ -87,8 +99,8 @@ def edge_gated_conv(p, prefix, u, v, x, y, training=True, stats=None, record=Non
     if record is not None:
         record[prefix + ".m_pre"] = m.detach()
         record[prefix + ".x_pre"] = xn.detach()
-    xo = F.silu(_bn(xn, p, prefix + ".bn_nodes", training, stats))
-    yo = F.silu(_bn(m, p, prefix + ".bn_edges", training, stats))
+    xo = F.silu(_norm(xn, p, prefix + ".bn_nodes", training, stats, norm))
+    yo = F.silu(_norm(m, p, prefix + ".bn_edges", training, stats, norm))
     if residual:
         xo = x + xo
         yo = y + yo
@@ -152,6 +164,51 @@ def alignn_forward(
     if classification:
         out = F.log_softmax(out, dim=1)
     return torch.squeeze(out)
+
+
+def bond_cosines(r, e1, e2):
+    """alignn/graphs.py:847-864: cos = clamp(-r[e1].r[e2] / (|r[e1]||r[e2]|), -1, 1)."""
+    r1, r2 = -r[e1], r[e2]
+    c = torch.sum(r1 * r2, dim=1) / (torch.norm(r1, dim=1) * torch.norm(r2, dim=1))
+    return torch.clamp(c, -1, 1)
+
+
+def alignn_atomwise_forward(p, graph, alignn_layers=2, gcn_layers=2, lg_on_fly=True, record=None, link="identity"):
+    """alignn_atomwise.py:364-660, energy/property path (calculate_gradient=False): LayerNorm everywhere,
+    bond-angle cosines recomputed from r when lg_on_fly (:424-431); returns result["out"]."""
+    dt = p["fc.weight"].dtype
+    u, v, e1, e2 = graph.u, graph.v, graph.lg_u, graph.lg_v
+    x = mlp_layer(graph.atom_features.to(dt), p, "atom_embedding", True, None, "layer")
+    r = graph.r.to(dt)
+    bondlength = torch.norm(r, dim=1)
+    if alignn_layers > 0:
+        h = bond_cosines(r, e1, e2) if lg_on_fly else graph.h.to(dt)
+        zc = p["angle_embedding.0.centers"]
+        z, _ = rbf_expand(h, -1.0, 1.0, zc.numel(), zc)
+        z = mlp_layer(z, p, "angle_embedding.1", True, None, "layer")
+        z = mlp_layer(z, p, "angle_embedding.2", True, None, "layer")
+    yc = p["edge_embedding.0.centers"]
+    y, _ = rbf_expand(bondlength, 0.0, 8.0, yc.numel(), yc)
+    y = mlp_layer(y, p, "edge_embedding.1", True, None, "layer")
+    y = mlp_layer(y, p, "edge_embedding.2", True, None, "layer")
+    for i in range(alignn_layers):
+        x, m = edge_gated_conv(p, f"alignn_layers.{i}.node_update", u, v, x, y, True, None, record, True, "layer")
+        y, z = edge_gated_conv(p, f"alignn_layers.{i}.edge_update", e1, e2, m, z, True, None, record, True, "layer")
+        if record is not None:
+            record[f"alignn.{i}.x"], record[f"alignn.{i}.y"], record[f"alignn.{i}.z"] = x.detach(), y.detach(), z.detach()
+    for i in range(gcn_layers):
+        x, y = edge_gated_conv(p, f"gcn_layers.{i}", u, v, x, y, True, None, record, True, "layer")
+        if record is not None:
+            record[f"gcn.{i}.x"], record[f"gcn.{i}.y"] = x.detach(), y.detach()
+    bnn = graph.batch_num_nodes
+    seg = torch.repeat_interleave(torch.arange(bnn.numel()), bnn)
+    hsum = torch.zeros(bnn.numel(), x.shape[1], dtype=dt).index_add(0, seg, x)
+    out = torch.squeeze(_linear(hsum / bnn.to(dt).unsqueeze(1), p, "fc"))
+    if link == "log":
+        out = torch.exp(out)
+    elif link == "logit":
+        out = torch.sigmoid(out)
+    return out
 
 
 def running_stats_after_step(p, stats):

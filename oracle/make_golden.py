@@ -154,6 +154,49 @@ def case_default():
     print("default pred", pred.detach().numpy(), "loss", loss.item())
 
 
+def case_atomwise():
+    """LayerNorm flavour (the class alignn/train.py trains), energy path, lg_on_fly cosines."""
+    from alignn.models.alignn_atomwise import ALIGNNAtomWise, ALIGNNAtomWiseConfig
+    from alignn.models.alignn_atomwise import EdgeGatedGraphConv as LNConv
+
+    torch.manual_seed(21)
+    cfg = ALIGNNAtomWiseConfig(name="alignn_atomwise", alignn_layers=2, gcn_layers=2, hidden_features=32,
+                               embedding_features=16, atom_input_features=92, calculate_gradient=False)
+    model = ALIGNNAtomWise(cfg)
+    with torch.no_grad():
+        for n_, p_ in model.named_parameters():
+            if ".bn_" in n_ or ".layer.1." in n_:
+                p_.add_(0.1 * torch.randn_like(p_))
+    raw = batch_raw([_one(n, 300 + i, "crystal", 92) for i, n in enumerate((6, 9, 7))])
+    g, lg, lat = to_dgl(raw)
+    # the loader's cosines are deliberately perturbed: with lg_on_fly the model must ignore them
+    lg.edata["h"] = lg.edata["h"] * 0.5
+    out = {"cfg.alignn_layers": 2, "cfg.gcn_layers": 2, "cfg.hidden_features": 32, "cfg.embedding_features": 16}
+    out.update(raw_arrays(raw))
+    out.update({"sd." + k: v.numpy().copy() for k, v in model.state_dict().items()})
+    target = torch.linspace(-1.0, 1.0, raw.batch_size)
+    out["target"] = target.numpy()
+    acts = {}
+    model.train()
+    for name, mod in model.named_modules():
+        if isinstance(mod, LNConv):
+            def hook(_m, _inp, o, name=name):
+                acts[name + ".x_out"] = o[0].detach().numpy().copy()
+                acts[name + ".y_out"] = o[1].detach().numpy().copy()
+            mod.register_forward_hook(hook)
+    res = model((g, lg, lat))
+    assert set(res) == {"out", "additional", "grad", "stresses", "atomwise_pred"}
+    loss = torch.nn.functional.l1_loss(res["out"], target)
+    loss.backward()
+    out["pred"] = res["out"].detach().numpy()
+    out["loss"] = loss.item()
+    out.update({"grad." + k: p.grad.numpy().copy() for k, p in model.named_parameters() if p.grad is not None})
+    out["nograd"] = np.array([k for k, p in model.named_parameters() if p.grad is None])
+    out.update({"act." + k: v for k, v in acts.items()})
+    np.savez_compressed(os.path.join(OUT, "atomwise_tiny_train.npz"), **out)
+    print("atomwise pred", out["pred"], "loss", out["loss"])
+
+
 def case_conv64():
     """Stand-alone EdgeGatedGraphConv in float64 on a graph with an isolated node and multi-edges
     (the regime of the reference's tests/test_force_reduction.py: BatchNorm conv, train mode, default init)."""
@@ -187,3 +230,4 @@ if __name__ == "__main__":
     case_tiny(False)
     case_default()
     case_conv64()
+    case_atomwise()

@@ -106,3 +106,27 @@ def test_rbf_gamma_matches_reference_constants():
     _, g_e = O.rbf_expand(torch.zeros(1), 0.0, 8.0, 80)
     _, g_a = O.rbf_expand(torch.zeros(1), -1.0, 1.0, 40)
     assert abs(g_e - 9.875) < 1e-4 and abs(g_a - 19.5) < 1e-4
+
+
+def test_atomwise_layernorm_flavour_energy_path():
+    """ALIGNNAtomWise (LayerNorm, lg_on_fly cosines) vs the reference's own class."""
+    z = load_golden("atomwise_tiny_train.npz")
+    raw = raw_from_golden(z)
+    p = O.as_params(state_dict_from_golden(z))
+    rec = {}
+    pred = O.alignn_atomwise_forward(p, O.TorchGraph(raw), 2, 2, True, rec)
+    assert rel_err(pred, z["pred"]) < TOL
+    for i in range(2):
+        assert rel_err(rec[f"alignn.{i}.z"], z[f"act.alignn_layers.{i}.edge_update.y_out"]) < TOL
+        assert rel_err(rec[f"gcn.{i}.x"], z[f"act.gcn_layers.{i}.x_out"]) < TOL
+    loss = torch.nn.functional.l1_loss(pred, torch.from_numpy(z["target"]))
+    assert abs(loss.item() - float(z["loss"])) < 1e-6
+    loss.backward()
+    nograd = set(z["nograd"].tolist())
+    gfloor = 1e-2 * max(float(np.abs(v).max()) for k, v in z.items() if k.startswith("grad."))
+    n = 0
+    for k, t in p.items():
+        if t.requires_grad and k not in nograd:
+            assert rel_err(t.grad, z["grad." + k], floor=gfloor) < 2e-4, k
+            n += 1
+    assert n > 40
