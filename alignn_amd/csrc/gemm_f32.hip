@@ -98,6 +98,9 @@ struct GemmArgs {
     int64_t R;       // reduction length
     int64_t r_chunk; // reduction rows per blockIdx.z (split-R); C advances by c_split per z
     int64_t c_split;
+    int xcd_group;   // != 0: 1-D launch of tiles*splits workgroups, remapped so that all output tiles of one
+                     // reduction slab run back-to-back on ONE XCD (they re-read the same G/A rows: L2 hits)
+    int tiles_m, tiles_n, splits;
 };
 
 template <int BM, int BN, int WM, int WN, bool A_RC, bool B_RC>
@@ -113,12 +116,25 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_mfma_kernel(GemmArgs g) {
     const int lane = t & 63, wave = t >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int il = lane & 31, half = lane >> 5;
-    const int64_t m0 = (int64_t)blockIdx.x * BM;
-    const int64_t n0 = (int64_t)blockIdx.y * BN;
-    const int64_t rbeg = (int64_t)blockIdx.z * g.r_chunk;
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (g.xcd_group) {
+        // hardware deals workgroup L to XCD L % 8.  Give XCD c the slabs z = c, c+8, ...; within an XCD the
+        // tiles of a slab are consecutive in dispatch order.
+        const int tiles = g.tiles_m * g.tiles_n;
+        const int L = blockIdx.x;
+        const int xcd = L & 7, j = L >> 3;          // j-th workgroup of this XCD
+        bz = xcd + 8 * (j / tiles);
+        const int tile = j % tiles;
+        bx = tile % g.tiles_m;
+        by = tile / g.tiles_m;
+        if (bz >= g.splits) return;                  // padding workgroups (uniform per block)
+    }
+    const int64_t m0 = (int64_t)bx * BM;
+    const int64_t n0 = (int64_t)by * BN;
+    const int64_t rbeg = (int64_t)bz * g.r_chunk;
     int64_t rend = rbeg + g.r_chunk;
     if (rend > g.R) rend = g.R;
-    float* C = g.C + (int64_t)blockIdx.z * g.c_split;
+    float* C = g.C + (int64_t)bz * g.c_split;
 
     f32x16 acc[RM][RN];
 #pragma unroll
@@ -273,6 +289,16 @@ int launch(const GemmArgs& g, int splits, hipStream_t stream) {
         attr_set = true;
     }
     dim3 grid(alignn_ceil_div(g.Mo, BM), alignn_ceil_div(g.No, BN), splits);
+    if (g.xcd_group) {
+        GemmArgs h = g;
+        h.tiles_m = grid.x;
+        h.tiles_n = grid.y;
+        h.splits = splits;
+        const int per_xcd = alignn_ceil_div(splits, 8) * h.tiles_m * h.tiles_n;
+        hipLaunchKernelGGL(kern, dim3(per_xcd * 8), dim3(NT), lds, stream, h);
+        ALIGNN_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(kern, grid, dim3(NT), lds, stream, g);
     ALIGNN_CHECK_LAUNCH();
     return 0;
@@ -320,7 +346,7 @@ int alignn_gemm_nt(const float* A, int64_t lda, const float* W, int64_t ldw, con
     const bool vec_ok = (K % 4 == 0) && (lda % 4 == 0) && (ldw % 4 == 0) && aligned16(A) && aligned16(W);
     if (!vec_ok || N < 16)
         return naive(A, lda, 1, W, ldw, 1, bias, addend, ldadd, C, ldc, M, N, K, st);
-    GemmArgs g{A, lda, W, ldw, bias, addend, ldadd, C, ldc, M, N, K, K, 0};
+    GemmArgs g{A, lda, W, ldw, bias, addend, ldadd, C, ldc, M, N, K, K, 0, 0, 0, 0, 0};
     // tile choice: the big 128x256 tile (A read once, 1 workgroup/CU) needs >= ~4 waves of workgroups to
     // amortise its tail; mid-size problems take 64x128 tiles (2-3 workgroups/CU, finer granularity)
     const int64_t big_blocks = (int64_t)alignn_ceil_div(M, 128) * alignn_ceil_div(N, 256);
@@ -338,7 +364,7 @@ int alignn_gemm_nn(const float* G, int64_t ldg, const float* W, int64_t ldw, con
     const bool vec_ok = (N % 4 == 0) && (K % 4 == 0) && (ldg % 4 == 0) && (ldw % 4 == 0) && aligned16(G) && aligned16(W);
     if (!vec_ok || K < 16)
         return naive(G, ldg, 1, W, 1, ldw, nullptr, addend, ldadd, C, ldc, M, K, N, st);
-    GemmArgs g{G, ldg, W, ldw, nullptr, addend, ldadd, C, ldc, M, K, N, N, 0};
+    GemmArgs g{G, ldg, W, ldw, nullptr, addend, ldadd, C, ldc, M, K, N, N, 0, 0, 0, 0, 0};
     if (K > 128) return launch<128, 256, 2, 4, true, false>(g, 1, st);
     if (K > 64) return launch<128, 128, 2, 2, true, false>(g, 1, st);
     return launch<128, 64, 4, 1, true, false>(g, 1, st);
@@ -358,7 +384,7 @@ int alignn_gemm_tn(const float* G, int64_t ldg, const float* A, int64_t lda, flo
     const int splits = tn_splits(M, N, K);
     if (workspace_bytes < alignn_gemm_tn_workspace(M, N, K) || workspace == nullptr) return (int)hipErrorInvalidValue;
     float* ws = (float*)workspace;
-    GemmArgs g{G, ldg, A, lda, nullptr, nullptr, 0, ws, K, N, K, M, tn_chunk(M, N, K), (int64_t)N * K};
+    GemmArgs g{G, ldg, A, lda, nullptr, nullptr, 0, ws, K, N, K, M, tn_chunk(M, N, K), (int64_t)N * K, 1, 0, 0, 0};
     int rc;
     if (K > 64)
         rc = launch<128, 128, 2, 2, false, false>(g, splits, st);

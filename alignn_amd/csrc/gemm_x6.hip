@@ -39,10 +39,14 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int BM = 128, BN = 256, BK = 16;  // one 16-deep MFMA step per stage: 32 KiB stages, 2 workgroups/CU
+#ifndef X6_RM
+#define X6_RM 1
+#endif
+constexpr int RM = X6_RM;                  // 32-row MFMA tiles per wave along M
+constexpr int BM = 128 * RM, BN = 256, BK = 16;  // one 16-deep MFMA step per stage
 constexpr int WM = 4, WN = 2, NT = WM * WN * 64;
-constexpr int TM = BM / WM, TN = BN / WN;  // 32 x 128 per wave
-constexpr int RN = TN / 32;                // 1 x 4 MFMA tiles
+constexpr int TM = BM / WM, TN = BN / WN;  // (32*RM) x 128 per wave
+constexpr int RN = TN / 32;                // RM x 4 MFMA tiles
 constexpr int A_BYTES = BM * BK * 4;       // 8 KiB fp32 (64-byte rows), XOR-swizzled 16-byte chunks, no padding
 constexpr int B_PLANE = BN * BK * 2;       // 8 KiB per bf16 slice plane (32-byte rows)
 constexpr int STAGE_BYTES = A_BYTES + 3 * B_PLANE;  // 32 KiB
@@ -55,7 +59,7 @@ constexpr int LDS_BYTES = 2 * STAGE_BYTES > EPI_BYTES ? 2 * STAGE_BYTES : EPI_BY
 struct X6Args {
     const float* A;
     int64_t lda;
-    const unsigned char* Ws;  // [3][K/16][Npad][2 chunks, swizzled][8 bf16]
+    const unsigned char* Ws;  // [K/16][Npad/256][3 planes][256 rows][2 chunks, swizzled][8 bf16]: 24 KiB per (kb, n-tile)
     const float* bias;
     const float* addend;
     int64_t ldadd;
@@ -116,11 +120,13 @@ __global__ __launch_bounds__(NT) void gemm_nt_x6_kernel(X6Args g) {
     const int64_t m0 = (int64_t)blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
 
-    f32x16 acc[RN];
+    f32x16 acc[RM][RN];
 #pragma unroll
-    for (int b = 0; b < RN; ++b)
+    for (int a = 0; a < RM; ++a)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[b][r] = 0.0f;
+        for (int b = 0; b < RN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
     // ---- DMA addressing (LDS image is lane-linear; the XOR swizzle lives in the SOURCE address)
     // A: piece q = wave*A_DMA + i holds tile positions p = q*64 + lane -> row p/4, stored chunk p%4, which is
@@ -134,13 +140,15 @@ __global__ __launch_bounds__(NT) void gemm_nt_x6_kernel(X6Args g) {
         if (grow >= g.M) grow = g.M - 1;  // clamp: rows past the end are computed but never stored
         a_src[i] = g.A + grow * g.lda + c * 4;
     }
-    // B: the three [Npad][32 B] k-block planes are contiguous 8 KiB runs in global memory (pre-swizzled)
-    const int64_t plane_stride = (int64_t)(g.K / BK) * g.Npad * (BK * 2);  // bytes between slice planes
+    // B: the three slice planes of one (k-block, n-tile) are ONE contiguous 24 KiB run in global memory, in
+    // exactly the LDS image order (pre-swizzled), so a stage is 24 sequential 1 KiB pieces and consecutive
+    // k-blocks walk the 384 KiB weight image linearly (no power-of-two plane strides in the L2).
+    const int64_t kb_stride = (int64_t)(g.Npad / BN) * (3 * B_PLANE);
     const unsigned char* b_src[B_DMA];
 #pragma unroll
     for (int i = 0; i < B_DMA; ++i) {
-        const int q = wave * B_DMA + i;  // plane q/8, 1 KiB piece q%8
-        b_src[i] = g.Ws + (int64_t)(q / B_PIECES) * plane_stride + (int64_t)n0 * (BK * 2) + (q % B_PIECES) * 1024 + lane * 16;
+        const int q = wave * B_DMA + i;  // 1 KiB piece q of the 24 KiB stage image
+        b_src[i] = g.Ws + (int64_t)blockIdx.y * (3 * B_PLANE) + q * 1024 + lane * 16;
     }
     auto issue = [&](int kt, unsigned char* stage) {
 #if X6_ABL_NOALOAD
@@ -153,14 +161,18 @@ __global__ __launch_bounds__(NT) void gemm_nt_x6_kernel(X6Args g) {
 #endif
 #pragma unroll
         for (int i = 0; i < B_DMA; ++i)
-            dma16(b_src[i] + (int64_t)kt * g.Npad * (BK * 2), stage + A_BYTES + (wave * B_DMA + i) * 1024);
+            dma16(b_src[i] + kt * kb_stride, stage + A_BYTES + (wave * B_DMA + i) * 1024);
     };
 
     // reader addresses (bytes inside a stage)
-    const int arow = wm * TM + il;
-    const int a_f = (arow >> 2) & 3;
-    const int a_off0 = arow * (BK * 4) + (((2 * half) ^ a_f) << 4);
-    const int a_off1 = arow * (BK * 4) + (((2 * half + 1) ^ a_f) << 4);
+    int a_off0[RM], a_off1[RM];
+#pragma unroll
+    for (int a = 0; a < RM; ++a) {
+        const int arow = wm * TM + a * 32 + il;
+        const int a_f = (arow >> 2) & 3;
+        a_off0[a] = arow * (BK * 4) + (((2 * half) ^ a_f) << 4);
+        a_off1[a] = arow * (BK * 4) + (((2 * half + 1) ^ a_f) << 4);
+    }
     int b_off[RN];
 #pragma unroll
     for (int b = 0; b < RN; ++b) {
@@ -175,9 +187,11 @@ __global__ __launch_bounds__(NT) void gemm_nt_x6_kernel(X6Args g) {
         const int cur = kt & 1;
         if (kt + 1 < nk) issue(kt + 1, smem + (cur ^ 1) * STAGE_BYTES);
         const unsigned char* stage = smem + cur * STAGE_BYTES;
-        bf16x8 ah, am, al, bh[RN], bm[RN], bl[RN];
-        slice8(*reinterpret_cast<const float4*>(stage + a_off0), *reinterpret_cast<const float4*>(stage + a_off1), ah,
-               am, al);
+        bf16x8 ah[RM], am[RM], al[RM], bh[RN], bm[RN], bl[RN];
+#pragma unroll
+        for (int a = 0; a < RM; ++a)
+            slice8(*reinterpret_cast<const float4*>(stage + a_off0[a]),
+                   *reinterpret_cast<const float4*>(stage + a_off1[a]), ah[a], am[a], al[a]);
 #pragma unroll
         for (int b = 0; b < RN; ++b) {
             const unsigned char* q = stage + b_off[b];
@@ -185,22 +199,20 @@ __global__ __launch_bounds__(NT) void gemm_nt_x6_kernel(X6Args g) {
             bm[b] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(q + B_PLANE));
             bl[b] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(q + 2 * B_PLANE));
         }
-        // six slice products, smallest first; each pass walks the four independent accumulators so no MFMA
-        // waits on the one issued right before it
+        // six slice products, smallest first; each pass walks the independent accumulators so no MFMA waits
+        // on the one issued right before it
+#define X6_PASS(AA, BB)                                                                              \
+    _Pragma("unroll") for (int a = 0; a < RM; ++a) _Pragma("unroll") for (int b = 0; b < RN; ++b)    \
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AA[a], BB[b], acc[a][b], 0, 0, 0);
 #if !X6_ABL_ONEMFMA
-#pragma unroll
-        for (int b = 0; b < RN; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[b], acc[b], 0, 0, 0);
-#pragma unroll
-        for (int b = 0; b < RN; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[b], acc[b], 0, 0, 0);
-#pragma unroll
-        for (int b = 0; b < RN; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm[b], acc[b], 0, 0, 0);
-#pragma unroll
-        for (int b = 0; b < RN; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh[b], acc[b], 0, 0, 0);
-#pragma unroll
-        for (int b = 0; b < RN; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm[b], acc[b], 0, 0, 0);
+        X6_PASS(al, bh)
+        X6_PASS(ah, bl)
+        X6_PASS(am, bm)
+        X6_PASS(am, bh)
+        X6_PASS(ah, bm)
 #endif
-#pragma unroll
-        for (int b = 0; b < RN; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[b], acc[b], 0, 0, 0);
+        X6_PASS(ah, bh)
+#undef X6_PASS
         __syncthreads();  // next stage has landed (the barrier drains the DMA), current one is free
     }
 
@@ -209,13 +221,14 @@ __global__ __launch_bounds__(NT) void gemm_nt_x6_kernel(X6Args g) {
     float* patch = reinterpret_cast<float*>(smem) + wave * (32 * PLD);
     const int prow = lane >> 4, pc4 = (lane & 15) * 4;
 #pragma unroll
-    for (int hb = 0; hb < RN / 2; ++hb) {
+    for (int ahb = 0; ahb < RM * (RN / 2); ++ahb) {
+        const int a = ahb / (RN / 2), hb = ahb % (RN / 2);
         __syncthreads();
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                patch[((r & 3) + 8 * (r >> 2) + 4 * half) * PLD + b * 32 + il] = acc[2 * hb + b][r];
+                patch[((r & 3) + 8 * (r >> 2) + 4 * half) * PLD + b * 32 + il] = acc[a][2 * hb + b][r];
         __syncthreads();
         const int col = n0 + wn * TN + hb * 64 + pc4;
         if (col < g.N) {
@@ -223,7 +236,7 @@ __global__ __launch_bounds__(NT) void gemm_nt_x6_kernel(X6Args g) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int lr = i * 4 + prow;
-                const int64_t row = m0 + wm * TM + lr;
+                const int64_t row = m0 + wm * TM + a * 32 + lr;
                 if (row < g.M) {
                     float4 v = f4_add(f4_ld(patch + lr * PLD + pc4), bv);
                     if (g.addend) v = f4_add(v, f4_ld(g.addend + row * g.ldadd + col));
@@ -234,12 +247,12 @@ __global__ __launch_bounds__(NT) void gemm_nt_x6_kernel(X6Args g) {
     }
 }
 
-// Slice W (or W^T) into the kernel's DMA image: out[plane][kb][n][chunk ^ ((n>>3)&1)][8], n < Npad (zero rows
-// beyond N), kb = k/16, chunk = (k%16)/8.
+// Slice W (or W^T) into the kernel's DMA image: out[kb][n/256][plane][n%256][chunk ^ ((n>>3)&1)][8], n < Npad
+// (zero rows beyond N), kb = k/16, chunk = (k%16)/8.
 __global__ void split_bf16x3_kernel(const float* __restrict__ W, int64_t ldw, int N, int Npad, int K, int transpose,
                                     unsigned short* __restrict__ out) {
     const int64_t total = (int64_t)Npad * K;
-    const int64_t plane = total;
+    const int ntiles = Npad / BN;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int n = (int)(i / K), k = (int)(i % K);
         float x = 0.0f;
@@ -247,10 +260,12 @@ __global__ void split_bf16x3_kernel(const float* __restrict__ W, int64_t ldw, in
         const float r1 = x - trunc16(x);
         const float r2 = r1 - trunc16(r1);
         const int kb = k / BK, c = (k % BK) >> 3, e = k & 7;
-        const int64_t o = ((int64_t)kb * Npad + n) * BK + ((c ^ ((n >> 3) & 1)) << 3) + e;
+        const int nt = n / BN, nin = n % BN;
+        constexpr int plane = BN * BK;  // bf16 elements per slice plane of one (kb, n-tile)
+        const int64_t o = ((int64_t)kb * ntiles + nt) * (3 * plane) + nin * BK + ((c ^ ((n >> 3) & 1)) << 3) + e;
         out[o] = (unsigned short)(__float_as_uint(x) >> 16);
-        out[plane + o] = (unsigned short)(__float_as_uint(r1) >> 16);
-        out[2 * plane + o] = (unsigned short)(__float_as_uint(r2) >> 16);
+        out[o + plane] = (unsigned short)(__float_as_uint(r1) >> 16);
+        out[o + 2 * plane] = (unsigned short)(__float_as_uint(r2) >> 16);
     }
 }
 

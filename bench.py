@@ -24,6 +24,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 H = 256
+# HBM bytes per launch of the dominant kernel at this exact shape (T=676 200 rows), from rocprofv3 PMC passes
+# (profiles/r01_pmc_fetch_size.txt / r01_pmc_write_size.txt; separate --pmc FETCH_SIZE and --pmc WRITE_SIZE
+# runs): FETCH_SIZE 690.2 MiB, doubled as MI355X_MICROARCH.md prescribes for 16 B/lane streaming reads on
+# gfx950, + WRITE_SIZE 660.4 MiB.  PMC cannot be sampled from inside this process, so the measured value is
+# carried here and only reported when the workload matches the one it was measured on.
+PMC_TRAFFIC_X6_T676200 = (2 * 690.2 + 660.4) * 1024 * 1024
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F32_PEAK_TF = 157.3  # v_mfma_f32_32x32x2_f32 dense peak
 
@@ -224,7 +230,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(gbs / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                "traffic": PMC_TRAFFIC_X6_T676200 if T == 676200 else None,
+                "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + --pmc WRITE_SIZE, profiles/r01_pmc_*.txt",
                 "ms_per_launch": round(t_x6, 4),
                 "algorithmic_bytes_per_launch": gemm_bytes,
                 "equivalent_fp32_TFLOPs": round(flops / (t_x6 * 1e-3) / 1e12, 1),
