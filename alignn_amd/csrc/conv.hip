@@ -16,7 +16,7 @@ namespace {
 
 constexpr int kWavesPerBlock = 4;
 constexpr int kThreads = kWavesPerBlock * ALIGNN_WAVE;
-constexpr int kMaxSlabs = 1024;
+constexpr int kMaxSlabs = 1024;  // workgroups of the segment kernels (= statistic slabs they emit)
 
 __host__ __device__ inline int egc_blocks(int64_t n_seg) {
     int64_t b = (n_seg + kWavesPerBlock - 1) / kWavesPerBlock;

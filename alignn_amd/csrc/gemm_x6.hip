@@ -104,10 +104,14 @@ __device__ __forceinline__ void slice8(const float4& lo, const float4& hi4, bf16
     l = __builtin_bit_cast(bf16x8, lp);
 }
 
+#ifndef X6_A_AUX
+#define X6_A_AUX 0  // default cache policy (nt on the read-once activation tile measured 10 % slower)
+#endif
+template <int AUX>
 __device__ __forceinline__ void dma16(const void* gsrc, unsigned char* lds_wave_base) {
     // 64 lanes x 16 B -> 1 KiB of LDS at lds_wave_base (wave-uniform) + lane*16; source address is per lane
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, AUX);
 }
 
 __global__ __launch_bounds__(NT) void gemm_nt_x6_kernel(X6Args g) {
@@ -155,13 +159,13 @@ __global__ __launch_bounds__(NT) void gemm_nt_x6_kernel(X6Args g) {
         if (kt == 0)
 #endif
 #pragma unroll
-        for (int i = 0; i < A_DMA; ++i) dma16(a_src[i] + kt * BK, stage + (wave * A_DMA + i) * 1024);
+        for (int i = 0; i < A_DMA; ++i) dma16<X6_A_AUX>(a_src[i] + kt * BK, stage + (wave * A_DMA + i) * 1024);
 #if X6_ABL_NOBLOAD
         if (kt == 0)
 #endif
 #pragma unroll
         for (int i = 0; i < B_DMA; ++i)
-            dma16(b_src[i] + kt * kb_stride, stage + A_BYTES + (wave * B_DMA + i) * 1024);
+            dma16<0>(b_src[i] + kt * kb_stride, stage + A_BYTES + (wave * B_DMA + i) * 1024);
     };
 
     // reader addresses (bytes inside a stage)

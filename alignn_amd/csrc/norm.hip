@@ -11,8 +11,10 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kMaxSlabs = 1024;
 
+// one slab (= one workgroup) per 32 rows, at most kMaxSlabs: small matrices (3 840 atom rows) still spread over
+// ~120 workgroups instead of crawling through 256 rows each on 15 CUs
 __host__ __device__ inline int slabs_for(int64_t rows) {
-    int64_t s = (rows + 255) / 256;
+    int64_t s = (rows + 31) / 32;
     if (s < 1) s = 1;
     if (s > kMaxSlabs) s = kMaxSlabs;
     return (int)s;
@@ -37,7 +39,16 @@ __global__ __launch_bounds__(kThreads) void col_reduce_kernel(Fn fn, int64_t row
     if (r1 > rows) r1 = rows;
     float4 a0 = f4_zero(), a1 = f4_zero();
     if (rl < RP) {
-        for (int64_t r = r0 + rl; r < r1; r += RP) fn(r, q, a0, a1);
+        // two independent accumulator pairs: two row loads in flight per thread
+        float4 b0 = f4_zero(), b1 = f4_zero();
+        int64_t r = r0 + rl;
+        for (; r + RP < r1; r += 2 * RP) {
+            fn(r, q, a0, a1);
+            fn(r + RP, q, b0, b1);
+        }
+        if (r < r1) fn(r, q, a0, a1);
+        a0 = f4_add(a0, b0);
+        a1 = f4_add(a1, b1);
     }
     __shared__ float4 sh[2][kThreads];
     sh[0][t] = a0;

@@ -88,7 +88,7 @@ def gemm_nt(a, w, bias=None, addend=None, out=None):
     return out
 
 
-X6_MIN_ROWS = 1024  # below this the 128x256-tile bf16x6 kernel has nothing to win
+X6_MIN_TILES = 256  # fewer 128x256 tiles than CUs: the finer-grained fp32-MFMA tiles win
 
 
 class SplitWeight:
@@ -132,7 +132,9 @@ def project(a, w, bias=None, addend=None, transpose_w=False):
     lib = _lib.load()
     M = a.shape[0]
     N, K = (w.shape[1], w.shape[0]) if transpose_w else (w.shape[0], w.shape[1])
-    if M >= X6_MIN_ROWS and a.stride(0) % 4 == 0 and lib.alignn_gemm_nt_x6_supported(M, N, K):
+    # the bf16x6 kernel works in 128 x 256 tiles: it needs enough of them to occupy the 256 CUs
+    x6_tiles = ((M + 127) // 128) * ((N + 255) // 256)
+    if x6_tiles >= X6_MIN_TILES and a.stride(0) % 4 == 0 and lib.alignn_gemm_nt_x6_supported(M, N, K):
         return gemm_nt_x6(a, split_bf16x3(w, transpose_w), bias, addend)
     if transpose_w:
         if w.shape[0] % 4 == 0 and w.shape[1] >= 16:

@@ -35,7 +35,7 @@ def test_ctypes_table_matches_header():
 def test_host_only_queries():
     lib = _lib.load()
     assert lib.alignn_col_stats_slabs(1) == 1
-    assert lib.alignn_col_stats_slabs(10**7) == 1024
+    assert lib.alignn_col_stats_slabs(10**7) == 1024 and lib.alignn_col_stats_slabs(3840) == 120
     assert lib.alignn_egc_slabs(0) == 1
     ws = lib.alignn_gemm_tn_workspace(10000, 256, 256)
     assert ws % (256 * 256 * 4) == 0 and 1 <= ws // (256 * 256 * 4) <= -(-10000 // 128)
