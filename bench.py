@@ -125,12 +125,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
 
+    # ALIGNN_BENCH_BACKEND=gloo + fewer GPUs than ranks is a SMOKE mode for the multi-process code path on a
+    # 1-GPU box (ranks share cuda:0, collectives go through gloo); real runs use nccl (= RCCL) one rank per GPU.
+    backend = os.environ.get("ALIGNN_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = (local_rank % ndev) if world > 1 else 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
 
     from alignn_amd import ALIGNN, ALIGNNConfig, GraphBatch, ops
@@ -171,6 +179,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    t_enq = time.perf_counter() - t0  # host time to ENQUEUE the steps (no device sync inside)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -179,7 +188,7 @@ def main():
         dt = float(t.item())
     ms = dt / args.steps * 1e3
     gps = world * B * args.steps / dt
-    log(f"{ms:.2f} ms/step, {gps:.1f} graphs/s")
+    log(f"{ms:.2f} ms/step, {gps:.1f} graphs/s (host enqueue {t_enq / args.steps * 1e3:.2f} ms/step)")
 
     out = None
     if rank == 0:
@@ -248,6 +257,7 @@ def main():
                 "hbm_frac_of_8TBs": round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "mfma_frac_of_157TF": round(step_flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4),
             },
+            "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3),
             "loss": round(float(loss.item()), 6),
         }
         if not args.no_cpu_baseline and world == 1:
