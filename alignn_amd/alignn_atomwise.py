@@ -6,11 +6,14 @@ Reference: ``/root/reference/alignn/models/alignn_atomwise.py`` (``ALIGNNAtomWis
 :249-660) and ``alignn/models/utils.py:277-292`` (``MLPLayer`` = Linear + LayerNorm + SiLU).  Same class names,
 constructor arguments, ``state_dict`` keys and result dictionary.
 
-Built in this round: the energy / property path (``calculate_gradient=False`` or ``gradwise_weight == 0``,
-which is what ``examples/sample_data/config_example.json`` runs), including the in-forward recomputation of the
-bond-angle cosines (``lg_on_fly``, :424-431).  The force / stress head (``autograd.grad(..., create_graph=True)``,
-:512-638) needs the kernels to be twice differentiable and raises ``NotImplementedError`` for now
-(DESIGN.md section 7).
+Two execution paths:
+
+* energy / property (``calculate_gradient=False`` or ``gradwise_weight == 0`` - what
+  ``examples/sample_data/config_example.json`` runs): the fused kernels (LayerNorm flavour), including the in-forward
+  recomputation of the bond-angle cosines (``lg_on_fly``, :424-431);
+* force / stress head (``calculate_gradient=True``: ``autograd.grad(..., create_graph=True)`` inside the forward,
+  :512-638, differentiated again by the training loss): composed from the twice-differentiable primitives of
+  ``alignn_amd.ff`` (HIP gather / segment-sum / MFMA GEMMs + torch element-wise), same formulas.
 """
 
 from __future__ import annotations
@@ -174,16 +177,83 @@ class ALIGNNAtomWise(nn.Module):
             pass
         return batch
 
+    def _forward_ff(self, b: GraphBatch):
+        """Energy + forces (+ stress): alignn_atomwise.py:364-660 with calculate_gradient=True.  Composed from the
+        twice-differentiable primitives of ``alignn_amd.ff`` so that ``autograd.grad(create_graph=True)`` and the
+        training loss's backward through it both work."""
+        from . import ff
+
+        cfg = self.config
+        n_a = len(self.alignn_layers)
+        x = ff.mlp_layer(b.atom_features, self.atom_embedding)
+        r = b.r.detach().clone().requires_grad_(True)  # canonical bond order; :420
+        bondlength = torch.norm(r, dim=1)
+        if n_a > 0:
+            h = ff.bond_cosines(r, b.lg) if cfg.lg_on_fly else b.h
+            z = ff.mlp_layer(ff.mlp_layer(ff.rbf(h, self.angle_embedding[0]), self.angle_embedding[1]), self.angle_embedding[2])
+        d_in = bondlength
+        c_off = None
+        if cfg.use_cutoff_function:
+            env = cutoff_function_based_edges(bondlength, cfg.inner_cutoff, cfg.exponent)
+            if cfg.multiply_cutoff:
+                c_off = env.unsqueeze(1)
+            else:
+                d_in = env
+        y = ff.mlp_layer(ff.mlp_layer(ff.rbf(d_in, self.edge_embedding[0]), self.edge_embedding[1]), self.edge_embedding[2])
+        if c_off is not None:
+            y = y * c_off
+        for layer in self.alignn_layers:
+            x, m = ff.edge_gated_conv(b.g, x, y, layer.node_update)
+            y, z = ff.edge_gated_conv(b.lg, m, z, layer.edge_update)
+        for layer in self.gcn_layers:
+            x, y = ff.edge_gated_conv(b.g, x, y, layer)
+        counts = (b.graph_ptr[1:] - b.graph_ptr[:-1]).to(torch.float32)
+        hpool = ff.segment_sum(x, ff.by_graph(b.graph_ptr)) / counts.unsqueeze(1)
+        out = torch.squeeze(ff.linear(hpool, self.fc))
+        additional_out = torch.empty(1)
+        if cfg.additional_output_features > 0:
+            additional_out = ff.linear(hpool, self.fc_additional_output)
+        atomwise_pred = torch.empty(1)
+        if cfg.atomwise_output_features > 0 and cfg.atomwise_weight != 0:
+            atomwise_pred = ff.linear(x, self.fc_atomwise)
+        en_out = out * counts if cfg.energy_mult_natoms else out  # :494-497
+        if cfg.use_penalty:  # :498-510
+            pen = torch.where(bondlength < cfg.penalty_threshold,
+                              cfg.penalty_factor * (cfg.penalty_threshold - bondlength), torch.zeros_like(bondlength))
+            en_out = en_out + torch.sum(pen)
+        pair_forces = cfg.grad_multiplier * torch.autograd.grad(
+            en_out, r, grad_outputs=torch.ones_like(en_out), create_graph=True, retain_graph=True)[0]  # :530-539
+        if cfg.force_mult_natoms:
+            pair_forces = pair_forces * b.g.n_nodes
+        forces = torch.squeeze(ff.pair_force_reduce(pair_forces, b.g, cfg.add_reverse_forces))  # :547-565
+        stress = torch.empty(1)
+        if cfg.stresswise_weight != 0:
+            if not cfg.batch_stress:
+                raise NotImplementedError("batch_stress=False (single-crystal virial) is outside this build")
+            if b.volume is None:
+                raise ValueError("stress needs the cell volumes: g.ndata['V'] (or GraphBatch.volume)")
+            # per crystal: -160.21766208 * r_g^T f_g / V_g (:615-638); bonds of a crystal are contiguous slots
+            outer = (r.unsqueeze(2) * pair_forces.unsqueeze(1)).reshape(-1, 9)
+            rel = ff.Relation(None, b.edge_graph_ptr, None, None, b.batch_size)
+            rel.idx = torch.repeat_interleave(
+                torch.arange(b.batch_size, device=r.device, dtype=torch.int32),
+                (b.edge_graph_ptr[1:] - b.edge_graph_ptr[:-1]).to(torch.int64))
+            st = ff.segment_sum(outer, rel).reshape(-1, 3, 3)
+            stress = cfg.stress_multiplier * (-160.21766208) * st / b.volume.reshape(-1, 1, 1)
+        if self.link:
+            out = self.link(out)
+        if self.classification:
+            out = self.softmax(out)
+        return {"out": out, "additional": additional_out, "grad": forces, "stresses": stress,
+                "atomwise_pred": atomwise_pred}
+
     def forward(self, g: Union[Sequence, GraphBatch]):
         cfg = self.config
-        if cfg.calculate_gradient:
-            raise NotImplementedError(
-                "calculate_gradient=True (force/stress head: autograd.grad with create_graph=True through the conv "
-                "stack, alignn_atomwise.py:512-638) is not built yet; set calculate_gradient=False / gradwise_weight=0"
-            )
         if cfg.include_pos_deriv:
             raise NotImplementedError("include_pos_deriv is 'not tested yet' upstream and outside this build")
         b = self._batch(g)
+        if cfg.calculate_gradient:
+            return self._forward_ff(b)
         n_a, n_g = len(self.alignn_layers), len(self.gcn_layers)
         x = self.atom_embedding(b.atom_features)
         bondlength = ops.bond_length(b.r)

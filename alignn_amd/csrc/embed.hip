@@ -74,6 +74,20 @@ __global__ void bond_cosine_kernel(const float* __restrict__ r, const int32_t* _
     }
 }
 
+// out[node(s), f] = sum_{k in [ptr[s], ptr[s+1])} vals[slot ? slot[k] : k, f]   (generic width F, fixed order)
+__global__ void segment_sum_kernel(const float* __restrict__ vals, int64_t ldv, const int32_t* __restrict__ ptr,
+                                   const int32_t* __restrict__ slot, const int32_t* __restrict__ node,
+                                   float* __restrict__ out, int64_t ldo, int64_t n_seg, int F) {
+    const int64_t total = n_seg * F;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = i / F;
+        const int f = (int)(i - s * F);
+        float acc = 0.0f;
+        for (int k = ptr[s]; k < ptr[s + 1]; ++k) acc += vals[(int64_t)(slot ? slot[k] : k) * ldv + f];
+        out[(int64_t)(node ? node[s] : s) * ldo + f] = acc;
+    }
+}
+
 __global__ void gather_rows_kernel(const float* __restrict__ in, const int32_t* __restrict__ perm,
                                    float* __restrict__ out, int64_t rows, int F) {
     const int64_t total = rows * F;
@@ -127,6 +141,16 @@ int alignn_bond_cosine_fwd(const float* r, const int32_t* e1, const int32_t* e2,
                             alignn_stream_t stream) {
     if (T == 0) return 0;
     hipLaunchKernelGGL(bond_cosine_kernel, dim3(grid_for(T)), dim3(256), 0, (hipStream_t)stream, r, e1, e2, h, T);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_segment_sum(const float* vals, int64_t ldv, const int32_t* ptr, const int32_t* slot, const int32_t* node,
+                       float* out, int64_t ldo, int64_t n_seg, int F, alignn_stream_t stream) {
+    if (F <= 0 || n_seg < 0) return (int)hipErrorInvalidValue;
+    if (n_seg == 0) return 0;
+    hipLaunchKernelGGL(segment_sum_kernel, dim3(grid_for(n_seg * F)), dim3(256), 0, (hipStream_t)stream, vals, ldv, ptr,
+                       slot, node, out, ldo, n_seg, F);
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }

@@ -100,13 +100,20 @@ class GraphBatch:
     atom_features: Optional[torch.Tensor] = None  # [N, F]
     r: Optional[torch.Tensor] = None  # [E, 3] canonical g-slot order
     h: Optional[torch.Tensor] = None  # [T]    canonical lg-slot order
+    volume: Optional[torch.Tensor] = None  # [B] cell volumes (g.ndata["V"] of each crystal's first atom)
+
+    @property
+    def edge_graph_ptr(self) -> torch.Tensor:
+        """int32 [B+1]: bond-slot offsets per crystal (bonds are sorted by destination atom, atoms by crystal)."""
+        return self.g.seg_ptr[self.graph_ptr.long()]
 
     @property
     def device(self):
         return self.graph_ptr.device
 
     @staticmethod
-    def from_coo(u, v, n_nodes, batch_num_nodes, lg_u=None, lg_v=None, atom_features=None, r=None, h=None, device=None):
+    def from_coo(u, v, n_nodes, batch_num_nodes, lg_u=None, lg_v=None, atom_features=None, r=None, h=None, device=None,
+                 volume=None):
         """Build from raw COO tensors (caller's edge order)."""
         dev = torch.device(device) if device is not None else u.device
         u = torch.as_tensor(u).to(dev)
@@ -129,6 +136,8 @@ class GraphBatch:
             out.r = torch.as_tensor(r).to(dev)[g.perm].contiguous()
         if h is not None and lg is not None:
             out.h = torch.as_tensor(h).to(dev)[lg.perm].contiguous()
+        if volume is not None:
+            out.volume = torch.as_tensor(volume).to(dev).to(torch.float32).contiguous()
         return out
 
     @staticmethod
@@ -146,6 +155,7 @@ class GraphBatch:
             t(raw.r).to(dtype),
             t(raw.h).to(dtype),
             device=device,
+            volume=torch.linalg.det(t(raw.lattice).double()).abs().float(),
         )
 
     @staticmethod
@@ -165,4 +175,8 @@ class GraphBatch:
             kw["atom_features"] = g.ndata["atom_features"]
         if "r" in g.edata:
             kw["r"] = g.edata["r"]
+        if "V" in g.ndata:  # per-atom copy of the cell volume (alignn/graphs.py:553); take each crystal's first atom
+            bnn = torch.as_tensor(g.batch_num_nodes()).to(torch.int64)
+            first = torch.cumsum(bnn, 0) - bnn
+            kw["volume"] = g.ndata["V"][first.to(g.ndata["V"].device)]
         return GraphBatch.from_coo(u, v, g.num_nodes(), g.batch_num_nodes(), device=dev, **kw)

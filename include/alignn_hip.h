@@ -206,6 +206,13 @@ int alignn_segment_mean_fwd(const float* X, const int32_t* graph_ptr, float* out
 /* its backward: GX[i] = G[b(i)] / count[b(i)] */
 int alignn_segment_mean_bwd(const float* G, const int32_t* graph_ptr, float* GX, int B, int H,
                             alignn_stream_t stream);
+/* Generic segment sum (any width F): out[node ? node[s] : s, :] = sum_{k in [ptr[s], ptr[s+1])}
+ * vals[slot ? slot[k] : k, :].  With alignn_gather_rows it forms the adjoint pair (gather by index <-> sum by
+ * group) from which the twice-differentiable force path is composed: DGL copy_e/sum on g and on dgl.reverse(g)
+ * (alignn/models/alignn_atomwise.py:547-565) and every gather/scatter of the conv when create_graph=True. */
+int alignn_segment_sum(const float* vals, int64_t ldv, const int32_t* ptr, const int32_t* slot,
+                       const int32_t* node, float* out, int64_t ldo, int64_t n_seg, int F,
+                       alignn_stream_t stream);
 /* row permutation: out[k] = in[perm[k]] (canonical reordering of edge features) */
 int alignn_gather_rows(const float* in, const int32_t* perm, float* out, int64_t rows, int F,
                        alignn_stream_t stream);

@@ -173,13 +173,20 @@ def bond_cosines(r, e1, e2):
     return torch.clamp(c, -1, 1)
 
 
-def alignn_atomwise_forward(p, graph, alignn_layers=2, gcn_layers=2, lg_on_fly=True, record=None, link="identity"):
-    """alignn_atomwise.py:364-660, energy/property path (calculate_gradient=False): LayerNorm everywhere,
-    bond-angle cosines recomputed from r when lg_on_fly (:424-431); returns result["out"]."""
+def alignn_atomwise_forward(p, graph, alignn_layers=2, gcn_layers=2, lg_on_fly=True, record=None, link="identity",
+                            calculate_gradient=False, volume=None, batch_num_edges=None, stress=False,
+                            use_penalty=True, penalty_factor=0.1, penalty_threshold=1.0, grad_multiplier=-1,
+                            stress_multiplier=1.0):
+    """alignn_atomwise.py:364-660: LayerNorm everywhere, bond-angle cosines recomputed from r when lg_on_fly
+    (:424-431).  Returns result["out"]; with ``calculate_gradient`` returns (out, forces, stresses) where
+    pair forces = grad_multiplier * dE/dr taken with create_graph=True (:530-539), forces reduced over in- and
+    out-edges (:547-565) and the per-crystal virial stress -160.21766208 r^T f / V (:615-638)."""
     dt = p["fc.weight"].dtype
     u, v, e1, e2 = graph.u, graph.v, graph.lg_u, graph.lg_v
     x = mlp_layer(graph.atom_features.to(dt), p, "atom_embedding", True, None, "layer")
     r = graph.r.to(dt)
+    if calculate_gradient:
+        r = r.detach().clone().requires_grad_(True)
     bondlength = torch.norm(r, dim=1)
     if alignn_layers > 0:
         h = bond_cosines(r, e1, e2) if lg_on_fly else graph.h.to(dt)
@@ -204,10 +211,31 @@ def alignn_atomwise_forward(p, graph, alignn_layers=2, gcn_layers=2, lg_on_fly=T
     seg = torch.repeat_interleave(torch.arange(bnn.numel()), bnn)
     hsum = torch.zeros(bnn.numel(), x.shape[1], dtype=dt).index_add(0, seg, x)
     out = torch.squeeze(_linear(hsum / bnn.to(dt).unsqueeze(1), p, "fc"))
+    forces = stresses = None
+    if calculate_gradient:
+        en_out = out * bnn.to(dt)  # energy_mult_natoms (:494-497)
+        if use_penalty:  # :498-510
+            pen = torch.where(bondlength < penalty_threshold, penalty_factor * (penalty_threshold - bondlength),
+                              torch.zeros_like(bondlength))
+            en_out = en_out + torch.sum(pen)
+        pf = grad_multiplier * torch.autograd.grad(en_out, r, grad_outputs=torch.ones_like(en_out), create_graph=True,
+                                                   retain_graph=True)[0]
+        n = x.shape[0]
+        f_ji = torch.zeros(n, 3, dtype=dt).index_add(0, v, pf)
+        f_ij = torch.zeros(n, 3, dtype=dt).index_add(0, u, pf)
+        forces = f_ji - f_ij
+        if stress:
+            sts, e0 = [], 0
+            for b_, ne in enumerate(batch_num_edges.tolist()):
+                sts.append(-160.21766208 * (r[e0:e0 + ne].t() @ pf[e0:e0 + ne]) / volume[b_])
+                e0 += ne
+            stresses = stress_multiplier * torch.stack(sts)
     if link == "log":
         out = torch.exp(out)
     elif link == "logit":
         out = torch.sigmoid(out)
+    if calculate_gradient:
+        return out, forces, stresses
     return out
 
 

@@ -197,6 +197,49 @@ def case_atomwise():
     print("atomwise pred", out["pred"], "loss", out["loss"])
 
 
+def case_atomwise_ff():
+    """Force + stress head: autograd.grad(create_graph=True) inside the forward, loss over energy, forces and
+    stress, so the parameter gradients are second-order (alignn_atomwise.py:512-638, train.py:291-387)."""
+    from alignn.models.alignn_atomwise import ALIGNNAtomWise, ALIGNNAtomWiseConfig
+
+    torch.manual_seed(31)
+    cfg = ALIGNNAtomWiseConfig(name="alignn_atomwise", alignn_layers=2, gcn_layers=2, hidden_features=32,
+                               embedding_features=16, atom_input_features=92, calculate_gradient=True,
+                               stresswise_weight=0.05)
+    model = ALIGNNAtomWise(cfg)
+    with torch.no_grad():
+        for n_, p_ in model.named_parameters():
+            if ".bn_" in n_ or ".layer.1." in n_:
+                p_.add_(0.1 * torch.randn_like(p_))
+    raw = batch_raw([_one(n, 400 + i, "crystal", 92) for i, n in enumerate((6, 9))])
+    # squeeze one bond below the 1 A penalty threshold so the penalty branch (:498-510) is exercised
+    raw.r[0] *= 0.3
+    raw.r[1] *= 0.3
+    g, lg, lat = to_dgl(raw)
+    vol = np.abs(np.linalg.det(raw.lattice)).astype(np.float32)
+    g.ndata["V"] = torch.from_numpy(np.repeat(vol, raw.batch_num_nodes))
+    out = {"cfg.alignn_layers": 2, "cfg.gcn_layers": 2}
+    out.update(raw_arrays(raw))
+    out["volume"] = vol
+    out.update({"sd." + k: v.numpy().copy() for k, v in model.state_dict().items()})
+    model.train()
+    res = model((g, lg, lat))
+    te = torch.tensor([0.4, -0.3])
+    tf = torch.linspace(-0.5, 0.5, raw.num_nodes * 3).reshape(-1, 3)
+    ts = torch.linspace(-1.0, 1.0, 18).reshape(2, 3, 3)
+    out["t_energy"], out["t_forces"], out["t_stress"] = te.numpy(), tf.numpy(), ts.numpy()
+    L = torch.nn.functional.l1_loss
+    loss = L(res["out"], te) + L(res["grad"], tf) + 0.05 * L(res["stresses"], ts)
+    loss.backward()
+    out["pred"], out["forces"], out["stresses"] = (res["out"].detach().numpy(), res["grad"].detach().numpy(),
+                                                   res["stresses"].detach().numpy())
+    out["loss"] = loss.item()
+    out.update({"grad." + k: p.grad.numpy().copy() for k, p in model.named_parameters() if p.grad is not None})
+    out["nograd"] = np.array([k for k, p in model.named_parameters() if p.grad is None])
+    np.savez_compressed(os.path.join(OUT, "atomwise_ff_tiny.npz"), **out)
+    print("atomwise ff: E", out["pred"], "|F|max", np.abs(out["forces"]).max(), "loss", out["loss"])
+
+
 def case_conv64():
     """Stand-alone EdgeGatedGraphConv in float64 on a graph with an isolated node and multi-edges
     (the regime of the reference's tests/test_force_reduction.py: BatchNorm conv, train mode, default init)."""
@@ -231,3 +274,4 @@ if __name__ == "__main__":
     case_default()
     case_conv64()
     case_atomwise()
+    case_atomwise_ff()

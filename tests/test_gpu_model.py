@@ -255,10 +255,14 @@ def test_atomwise_vs_oracle_wide_and_guards():
     for k, q in model.named_parameters():
         if p[k].grad is not None:
             assert rel_err(q.grad, p[k].grad, floor=gfloor) < 1e-3, k
-    # the force head is not built: it must refuse loudly, not silently return energies only
-    fm = ALIGNNAtomWise(ALIGNNAtomWiseConfig(name="alignn_atomwise", atom_input_features=92)).to(DEV)
+    # options outside the build must refuse loudly, never silently compute something else
+    fm = ALIGNNAtomWise(ALIGNNAtomWiseConfig(name="alignn_atomwise", atom_input_features=92, include_pos_deriv=True)).to(DEV)
     with pytest.raises(NotImplementedError):
         fm(GraphBatch.from_raw(raw, device=DEV))
+    # default config (calculate_gradient=True): forces come back with one row per atom
+    fd = ALIGNNAtomWise(ALIGNNAtomWiseConfig(name="alignn_atomwise", atom_input_features=92)).to(DEV)
+    res = fd(GraphBatch.from_raw(raw, device=DEV))
+    assert res["grad"].shape == (raw.num_nodes, 3) and torch.isfinite(res["grad"]).all()
 
 
 @pytest.mark.parametrize("rows,F", [(5, 16), (1000, 256), (333, 64), (77, 512), (9, 1024)])
@@ -280,3 +284,79 @@ def test_layernorm_silu_kernels(rows, F):
     assert rel_err(y, yd) < 1e-5
     assert rel_err(gx, xd.grad) < 1e-4
     assert rel_err(red[1], gd.grad) < 1e-4 and rel_err(red[0], bd.grad) < 1e-4
+
+
+def test_golden_atomwise_force_stress_head():
+    """ALIGNN-FF head on the GPU: energies, forces, stresses and the second-order parameter gradients of an
+    energy+force+stress loss against the reference's own class (golden), DGL-like tuple input with ndata['V']."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "shims"))
+    import dgl  # shim: DGL-shaped container only
+
+    from alignn_amd import ALIGNNAtomWise, ALIGNNAtomWiseConfig
+
+    z = load_golden("atomwise_ff_tiny.npz")
+    raw = raw_from_golden(z)
+    cfg = ALIGNNAtomWiseConfig(name="alignn_atomwise", alignn_layers=2, gcn_layers=2, hidden_features=32,
+                               embedding_features=16, atom_input_features=92, calculate_gradient=True,
+                               stresswise_weight=0.05)
+    model = ALIGNNAtomWise(cfg)
+    model.load_state_dict(state_dict_from_golden(z))
+    model = model.to(DEV).train()
+    g = dgl.graph((torch.from_numpy(raw.u), torch.from_numpy(raw.v)), num_nodes=raw.num_nodes)
+    g._bnn, g._bne = torch.from_numpy(raw.batch_num_nodes), torch.from_numpy(raw.batch_num_edges)
+    g.ndata["atom_features"] = torch.from_numpy(raw.atom_features)
+    g.edata["r"] = torch.from_numpy(raw.r)
+    g.ndata["V"] = torch.from_numpy(np.repeat(z["volume"], raw.batch_num_nodes))
+    lg = dgl.graph((torch.from_numpy(raw.lg_u), torch.from_numpy(raw.lg_v)), num_nodes=raw.num_edges)
+    lg.edata["h"] = torch.from_numpy(raw.h)
+    res = model([g, lg, torch.from_numpy(raw.lattice)])
+    assert rel_err(res["out"], z["pred"]) < 1e-4
+    assert res["grad"].shape == (raw.num_nodes, 3) and rel_err(res["grad"], z["forces"]) < 2e-4
+    assert res["stresses"].shape == (2, 3, 3) and rel_err(res["stresses"], z["stresses"]) < 2e-4
+    L = torch.nn.functional.l1_loss
+    t = lambda k: torch.from_numpy(z[k]).to(DEV)  # noqa: E731
+    loss = L(res["out"], t("t_energy")) + L(res["grad"], t("t_forces")) + 0.05 * L(res["stresses"], t("t_stress"))
+    assert abs(loss.item() - float(z["loss"])) < 1e-4
+    loss.backward()
+    nograd = set(z["nograd"].tolist())
+    gfloor = 1e-2 * max(float(np.abs(v).max()) for k, v in z.items() if k.startswith("grad."))
+    n = 0
+    for k, p in model.named_parameters():
+        if k in nograd:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+        else:
+            assert rel_err(p.grad, z["grad." + k], floor=gfloor) < 2e-3, k
+            n += 1
+    assert n > 40
+
+
+def test_force_reduction_self_consistency():
+    """Port of the reference's own hot-path test (alignn/tests/test_force_reduction.py:212-229): forces from
+    displacement autograd reduced over in- minus out-edges equal forces from position autograd."""
+    from alignn_amd import ff
+    from alignn_amd.alignn_atomwise import EdgeGatedGraphConv as LNConv
+    from alignn_amd.graph import build_csr
+
+    torch.manual_seed(0)
+    n, width = 32, 16
+    pos = (torch.rand(n, 3) * 6.0).to(DEV).requires_grad_(True)
+    d = torch.cdist(pos.detach(), pos.detach())
+    mask = (d <= 3.5) & ~torch.eye(n, dtype=torch.bool, device=DEV)
+    v_, u_ = torch.nonzero(mask, as_tuple=True)  # u -> v
+    csr = build_csr(u_, v_, n)
+    conv1, conv2 = LNConv(width, width).to(DEV), LNConv(width, width).to(DEV)
+    emb = torch.nn.Linear(1, width).to(DEV)
+    fc = torch.nn.Linear(width, 1).to(DEV)
+    # bond vectors in canonical slot order, as a function of positions
+    bondvec = ff.gather(pos, ff.by_dst(csr)) - ff.gather(pos, ff.by_src(csr))
+    bondlength = torch.norm(bondvec, dim=1)
+    y = ff.linear(bondlength.unsqueeze(-1), emb)
+    x = torch.ones(n, width, device=DEV)
+    x, y = ff.edge_gated_conv(csr, x, y, conv1)
+    x, y = ff.edge_gated_conv(csr, x, y, conv2)
+    energy = ff.linear(x, fc).sum()
+    f_x = -torch.autograd.grad(energy, pos, retain_graph=True)[0]
+    pf = -torch.autograd.grad(energy, bondvec)[0]
+    f_vec = ff.pair_force_reduce(pf, csr)
+    assert rel_err(f_vec, f_x) < 1e-4

@@ -130,3 +130,30 @@ def test_atomwise_layernorm_flavour_energy_path():
             assert rel_err(t.grad, z["grad." + k], floor=gfloor) < 2e-4, k
             n += 1
     assert n > 40
+
+
+def test_atomwise_force_stress_head_second_order():
+    """Oracle FF path (forces by create_graph autograd, stress, penalty) vs the reference's own class,
+    including the second-order parameter gradients of an energy+force+stress loss."""
+    z = load_golden("atomwise_ff_tiny.npz")
+    raw = raw_from_golden(z)
+    p = O.as_params(state_dict_from_golden(z))
+    out, forces, stresses = O.alignn_atomwise_forward(
+        p, O.TorchGraph(raw), 2, 2, True, calculate_gradient=True, stress=True,
+        volume=torch.from_numpy(z["volume"]), batch_num_edges=torch.from_numpy(raw.batch_num_edges))
+    assert rel_err(out, z["pred"]) < TOL
+    assert rel_err(forces, z["forces"]) < 1e-4
+    assert rel_err(stresses, z["stresses"]) < 1e-4
+    L = torch.nn.functional.l1_loss
+    loss = (L(out, torch.from_numpy(z["t_energy"])) + L(forces, torch.from_numpy(z["t_forces"]))
+            + 0.05 * L(stresses, torch.from_numpy(z["t_stress"])))
+    assert abs(loss.item() - float(z["loss"])) < 1e-5
+    loss.backward()
+    nograd = set(z["nograd"].tolist())
+    gfloor = 1e-2 * max(float(np.abs(v).max()) for k, v in z.items() if k.startswith("grad."))
+    n = 0
+    for k, t in p.items():
+        if t.requires_grad and k not in nograd:
+            assert rel_err(t.grad, z["grad." + k], floor=gfloor) < 1e-3, k
+            n += 1
+    assert n > 40
