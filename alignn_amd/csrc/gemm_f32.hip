@@ -103,7 +103,7 @@ struct GemmArgs {
     int tiles_m, tiles_n, splits;
 };
 
-template <int BM, int BN, int WM, int WN, bool A_RC, bool B_RC>
+template <int BM, int BN, int WM, int WN, bool A_RC, bool B_RC, bool HAS_ADD>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_mfma_kernel(GemmArgs g) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM, TN = BN / WN;
@@ -143,6 +143,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_mfma_kernel(GemmArgs g) {
         for (int b = 0; b < RN; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    const bool vec = ((g.No & 3) == 0) && ((g.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
+                     (g.addend == nullptr || (((g.ldadd & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.addend) & 15) == 0)));
+    // vector epilogue: the bias is fetched HERE, ahead of the whole k-loop, so that no load sits between the
+    // epilogue's stores (hipcc would put a vmcnt(0) - a wait for the previous STORE - in front of every store)
+    const int64_t ecol = n0 + wn * TN + (lane & 15) * 4;
+    float4 ebias = f4_zero();
+    if (vec && g.bias && ecol < g.No) ebias = f4_ld(g.bias + ecol);
 
     Stager<BM, A_RC, NT> sa;
     Stager<BN, B_RC, NT> sb;
@@ -188,14 +196,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_mfma_kernel(GemmArgs g) {
     // Fast path: each wave transposes its 32-row slabs through a private LDS patch ([32][TN+4] floats,
     // carved out of the now idle staging buffers) and then moves whole 256-byte row segments as float4:
     // bias / addend loads and the C stores are 16 B per lane and row-contiguous.
-    const bool vec = ((g.No & 3) == 0) && ((g.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
-                     (g.addend == nullptr || (((g.ldadd & 3) == 0) && ((reinterpret_cast<uintptr_t>(g.addend) & 15) == 0)));
     if (vec) {
         constexpr int PLD = TN + 4;
         static_assert(WM * WN * 32 * PLD <= 2 * STAGE, "epilogue patch must fit in the staging LDS");
         float* patch = smem + wave * (32 * PLD);
         const int prow = lane >> 4, pc4 = (lane & 15) * 4;  // TN == 64: 16 lanes cover one row segment
         static_assert(TN == 64, "epilogue assumes 64-column wave tiles");
+        const int64_t col = ecol;
+        const int64_t colc = col < g.No ? col : 0;
+        const float4 bv = ebias;
 #pragma unroll
         for (int a = 0; a < RM; ++a) {
             __syncthreads();  // staging buffers (or the previous slab) no longer read
@@ -205,19 +214,24 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_mfma_kernel(GemmArgs g) {
                 for (int r = 0; r < 16; ++r)
                     patch[((r & 3) + 8 * (r >> 2) + 4 * half) * PLD + b * 32 + il] = acc[a][b][r];
             __syncthreads();
-            const int64_t col = n0 + wn * TN + pc4;
-            if (col < g.No) {
-                float4 bv = g.bias ? f4_ld(g.bias + col) : f4_zero();
+            float4 ov[8], av[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ov[i] = f4_ld(patch + (i * 4 + prow) * PLD + pc4);
+            const int64_t row0 = m0 + wm * TM + a * 32 + prow;
+            if (HAS_ADD) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const int lr = i * 4 + prow;
-                    const int64_t row = m0 + wm * TM + a * 32 + lr;
-                    if (row < g.Mo) {
-                        float4 v = f4_add(f4_ld(patch + lr * PLD + pc4), bv);
-                        if (g.addend) v = f4_add(v, f4_ld(g.addend + row * g.ldadd + col));
-                        f4_st(C + row * g.ldc + col, v);
-                    }
+                    int64_t row = row0 + i * 4;
+                    if (row >= g.Mo) row = g.Mo - 1;
+                    av[i] = f4_ld(g.addend + row * g.ldadd + colc);
                 }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int64_t row = row0 + i * 4;
+                float4 v = f4_add(ov[i], bv);
+                if (HAS_ADD) v = f4_add(v, av[i]);
+                if (row < g.Mo && col < g.No) f4_st(C + row * g.ldc + col, v);
             }
         }
         return;
@@ -234,7 +248,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_mfma_kernel(GemmArgs g) {
                 const int64_t row = m0 + wm * TM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (row < g.Mo) {
                     float v = acc[a][b][r] + bv;
-                    if (g.addend) v += g.addend[row * g.ldadd + col];
+                    if (HAS_ADD) v += g.addend[row * g.ldadd + col];
                     C[row * g.ldc + col] = v;
                 }
             }
@@ -277,11 +291,20 @@ __global__ __launch_bounds__(1024) void slab_reduce_kernel(const float* __restri
     }
 }
 
+template <int BM, int BN, int WM, int WN, bool A_RC, bool B_RC, bool HAS_ADD>
+int launch_k(const GemmArgs& g, int splits, hipStream_t stream);
+
 template <int BM, int BN, int WM, int WN, bool A_RC, bool B_RC>
 int launch(const GemmArgs& g, int splits, hipStream_t stream) {
+    return g.addend ? launch_k<BM, BN, WM, WN, A_RC, B_RC, true>(g, splits, stream)
+                    : launch_k<BM, BN, WM, WN, A_RC, B_RC, false>(g, splits, stream);
+}
+
+template <int BM, int BN, int WM, int WN, bool A_RC, bool B_RC, bool HAS_ADD>
+int launch_k(const GemmArgs& g, int splits, hipStream_t stream) {
     constexpr int NT = WM * WN * 64;
     constexpr size_t lds = 2 * (TileShape<BM, A_RC>::kFloats + TileShape<BN, B_RC>::kFloats) * sizeof(float);
-    auto kern = gemm_mfma_kernel<BM, BN, WM, WN, A_RC, B_RC>;
+    auto kern = gemm_mfma_kernel<BM, BN, WM, WN, A_RC, B_RC, HAS_ADD>;
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

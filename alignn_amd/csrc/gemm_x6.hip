@@ -114,6 +114,7 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned char* lds_wave_
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, AUX);
 }
 
+template <bool HAS_ADD>
 __global__ __launch_bounds__(NT) void gemm_nt_x6_kernel(X6Args g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x;
@@ -184,6 +185,17 @@ __global__ __launch_bounds__(NT) void gemm_nt_x6_kernel(X6Args g) {
         b_off[b] = A_BYTES + n * (BK * 2) + ((half ^ ((n >> 3) & 1)) << 4);
     }
 
+    // bias for this wave's 64-column groups: fetched now, consumed after the k-loop, so the epilogue has no load
+    // of its own in front of its stores (hipcc would otherwise wait vmcnt(0) - i.e. for the previous STORE -
+    // before every store of the epilogue)
+    const int e_prow = lane >> 4, e_pc4 = (lane & 15) * 4;
+    float4 bias_v[RN / 2];
+#pragma unroll
+    for (int hb = 0; hb < RN / 2; ++hb) {
+        const int col = n0 + wn * TN + hb * 64 + e_pc4;
+        bias_v[hb] = (g.bias && col < g.N) ? f4_ld(g.bias + col) : f4_zero();
+    }
+
     const int nk = g.K / BK;
     issue(0, smem);
     __syncthreads();
@@ -220,10 +232,11 @@ __global__ __launch_bounds__(NT) void gemm_nt_x6_kernel(X6Args g) {
         __syncthreads();  // next stage has landed (the barrier drains the DMA), current one is free
     }
 
-    // epilogue: per-wave LDS transpose of two 32x32 tiles at a time -> float4 row segments
+    // epilogue: per-wave LDS transpose of two 32x32 tiles at a time -> float4 row segments.  Per round: all LDS
+    // traffic first, then all addend loads (rows clamped, no per-element branches), then the stores.
     constexpr int PLD = 64 + 4;
     float* patch = reinterpret_cast<float*>(smem) + wave * (32 * PLD);
-    const int prow = lane >> 4, pc4 = (lane & 15) * 4;
+    const int prow = e_prow, pc4 = e_pc4;
 #pragma unroll
     for (int ahb = 0; ahb < RM * (RN / 2); ++ahb) {
         const int a = ahb / (RN / 2), hb = ahb % (RN / 2);
@@ -234,19 +247,26 @@ __global__ __launch_bounds__(NT) void gemm_nt_x6_kernel(X6Args g) {
             for (int r = 0; r < 16; ++r)
                 patch[((r & 3) + 8 * (r >> 2) + 4 * half) * PLD + b * 32 + il] = acc[a][2 * hb + b][r];
         __syncthreads();
+        float4 ov[8], av[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ov[i] = f4_ld(patch + (i * 4 + prow) * PLD + pc4);
         const int col = n0 + wn * TN + hb * 64 + pc4;
-        if (col < g.N) {
-            const float4 bv = g.bias ? f4_ld(g.bias + col) : f4_zero();
+        const int64_t row0 = m0 + wm * TM + a * 32 + prow;
+        if (HAS_ADD) {
+            const int colc = col < g.N ? col : 0;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const int lr = i * 4 + prow;
-                const int64_t row = m0 + wm * TM + a * 32 + lr;
-                if (row < g.M) {
-                    float4 v = f4_add(f4_ld(patch + lr * PLD + pc4), bv);
-                    if (g.addend) v = f4_add(v, f4_ld(g.addend + row * g.ldadd + col));
-                    f4_st(g.C + row * g.ldc + col, v);
-                }
+                int64_t row = row0 + i * 4;
+                if (row >= g.M) row = g.M - 1;
+                av[i] = f4_ld(g.addend + row * g.ldadd + colc);
             }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int64_t row = row0 + i * 4;
+            float4 v = f4_add(ov[i], bias_v[hb]);
+            if (HAS_ADD) v = f4_add(v, av[i]);
+            if (row < g.M && col < g.N) f4_st(g.C + row * g.ldc + col, v);
         }
     }
 }
@@ -304,13 +324,18 @@ int alignn_gemm_nt_x6(const float* A, int64_t lda, const void* Wsplit, const flo
     static bool attr_set = false;
     constexpr int lds = LDS_BYTES;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_x6_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)gemm_nt_x6_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     X6Args g{A, lda, (const unsigned char*)Wsplit, bias, addend, ldadd, C, ldc, M, N, npad(N), K};
     dim3 grid(alignn_ceil_div(M, BM), npad(N) / BN);
-    hipLaunchKernelGGL(gemm_nt_x6_kernel, grid, dim3(NT), lds, (hipStream_t)stream, g);
+    if (addend)
+        hipLaunchKernelGGL(gemm_nt_x6_kernel<true>, grid, dim3(NT), lds, (hipStream_t)stream, g);
+    else
+        hipLaunchKernelGGL(gemm_nt_x6_kernel<false>, grid, dim3(NT), lds, (hipStream_t)stream, g);
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }
