@@ -273,20 +273,20 @@ __global__ void gemm_naive_kernel(const float* __restrict__ A, int64_t sai, int6
     C[i * ldc + j] = acc;
 }
 
-// out[idx] = sum_k ws[k][idx], 64 outputs x 16 slab-lanes per block, fp64 partials, fixed order
+// out[idx] = sum_k ws[k][idx], 32 outputs x 32 slab-lanes per block, fp64 partials, fixed order
 __global__ __launch_bounds__(1024) void slab_reduce_kernel(const float* __restrict__ ws, int splits, int64_t count,
                                                            int cols, float* __restrict__ out, int64_t ldo) {
-    __shared__ double sh[16][64];
-    const int64_t idx = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    __shared__ double sh[32][32];
+    const int64_t idx = (int64_t)blockIdx.x * 32 + threadIdx.x;
     double s = 0.0;
     if (idx < count)
-        for (int k = threadIdx.y; k < splits; k += 16) s += (double)ws[(int64_t)k * count + idx];
+        for (int k = threadIdx.y; k < splits; k += 32) s += (double)ws[(int64_t)k * count + idx];
     sh[threadIdx.y][threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.y == 0 && idx < count) {
         double t = 0.0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) t += sh[k][threadIdx.x];
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) t += sh[k][threadIdx.x];
         out[(idx / cols) * ldo + (idx % cols)] = (float)t;
     }
 }
@@ -415,7 +415,7 @@ int alignn_gemm_tn(const float* G, int64_t ldg, const float* A, int64_t lda, flo
         rc = launch<128, 64, 4, 1, false, false>(g, splits, st);
     if (rc) return rc;
     const int64_t count = (int64_t)N * K;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(alignn_ceil_div(count, 64)), dim3(64, 16), 0, st, ws, splits, count, K,
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(alignn_ceil_div(count, 32)), dim3(32, 32), 0, st, ws, splits, count, K,
                        dW, lddw);
     ALIGNN_CHECK_LAUNCH();
     return 0;

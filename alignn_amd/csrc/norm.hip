@@ -97,17 +97,17 @@ struct BwdReduceFn {
 };
 
 // ---------------------------------------------------------------------------------------------
-// Slab reductions: blocks of 64 columns x 16 slab-lanes.  Lane y sums slabs y, y+16, ... in double,
-// then the 16 lanes are combined through LDS in a fixed order (bit-reproducible, ~slabs/16 steps).
+// Slab reductions: blocks of 16 columns x 64 slab-lanes.  Lane y sums slabs y, y+64, ... in double,
+// then the 64 lanes are combined through LDS in a fixed order (bit-reproducible, ~slabs/64 steps).
 // ---------------------------------------------------------------------------------------------
-constexpr int kRedCols = 64, kRedLanes = 16;
+constexpr int kRedCols = 16, kRedLanes = 64;  // 16 columns x 64 slab-lanes: F/16 workgroups, <= 16 steps per lane
 
 __device__ __forceinline__ double lane_tree_sum(double v, double (*sh)[kRedCols]) {
     sh[threadIdx.y][threadIdx.x] = v;
     __syncthreads();
     double out = 0.0;
     if (threadIdx.y == 0) {
-#pragma unroll
+#pragma unroll 8
         for (int k = 0; k < kRedLanes; ++k) out += sh[k][threadIdx.x];
     }
     __syncthreads();
