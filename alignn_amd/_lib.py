@@ -40,6 +40,7 @@ SIGNATURES = {
     "alignn_egc_node_bwd": (_i32, [_p, _i64, _p, _p, _p, _p, _i64, _i32, _p]),
     "alignn_egc_bwd_dst": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _i32, _i64, _p, _p, _p, _i64, _i32, _p, _p, _p, _p]),
     "alignn_slab_sum": (_i32, [_p, _i32, _i32, _p, _p]),
+    "alignn_egc_bwd_lg_fused": (_i32, [_p, _p, _p, _p, _p, _p, _p, _i32, _i64, _p, _p, _i64, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _p]),
     "alignn_ln_slabs": (_i32, [_i64]),
     "alignn_ln_silu_fwd": (_i32, [_p, _i64, _p, _i64, _p, _p, _f32, _p, _i64, _p, _i64, _i32, _p]),
     "alignn_ln_silu_bwd": (_i32, [_p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _p, _i64, _i32, _p]),

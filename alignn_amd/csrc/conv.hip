@@ -314,6 +314,118 @@ __global__ __launch_bounds__(kThreads) void egc_bwd_src_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// backward on a LINE GRAPH, destination- and source-ordered passes fused.
+//
+// L(g) has e1 -> e2 iff dst(e1) == src(e2) == atom j, so its edges fall into one dense block per atom j:
+// sources = in-edges of j (contiguous L(g) node ids [grp_src_ptr[j], grp_src_ptr[j+1]) in the canonical layout),
+// segments = out-edges of j (contiguous segment ranks [grp_seg_ptr[j], grp_seg_ptr[j+1])).  One workgroup owns one
+// atom: phase 1 walks the block BY SOURCE (one wave per source, as egc_bwd_src does) but computes the edge
+// gradient itself - reading GY and M once, writing GM once and keeping g_A / g_Bh in registers; phase 2 sums GM
+// per segment (g_Bd) straight out of L2, since the same workgroup has just written those rows.  HBM traffic:
+// 2 reads + 1 write per edge row instead of 4 reads + 1 write for the two separate passes; same summation
+// orders, so the results are bit-identical to them.
+// ---------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void egc_bwd_lg_fused_kernel(
+    const float* __restrict__ GY, const float* __restrict__ M, const float* __restrict__ P,
+    const float* __restrict__ GS1, const float* __restrict__ GS0, const float* __restrict__ e_stat,
+    const float* __restrict__ e_red, int e_eval, float inv_n, const int32_t* __restrict__ grp_seg_ptr,
+    const int32_t* __restrict__ grp_src_ptr, const int32_t* __restrict__ seg_ptr,
+    const int32_t* __restrict__ seg_node, const int32_t* __restrict__ dst, const int32_t* __restrict__ out_ptr,
+    const int32_t* __restrict__ out_slot, int H, float* __restrict__ GM, float* __restrict__ GP,
+    float* __restrict__ gb_partial) {
+    __shared__ float4 sh[kWavesPerBlock][ALIGNN_WAVE];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t ldp = 4 * (int64_t)H;
+    const int j = blockIdx.x;
+    const int p_beg = grp_src_ptr[j], p_end = grp_src_ptr[j + 1];
+    const int s_beg = grp_seg_ptr[j], s_end = grp_seg_ptr[j + 1];
+    constexpr bool HAS_GY = MODE != 0;
+    for (int c0 = 0; c0 < H; c0 += 4 * ALIGNN_WAVE) {
+        const int f = c0 + 4 * lane;
+        const bool active = f < H;
+        float4 gb = f4_zero();
+        if (active) {
+            EdgeNorm nrm;
+            if (MODE == 1) {
+                nrm.mean = f4_ld(e_stat + f);
+                nrm.rstd = f4_ld(e_stat + H + f);
+                nrm.sc = f4_ld(e_stat + 2 * H + f);
+                nrm.sh = f4_ld(e_stat + 3 * H + f);
+                if (!e_eval) {
+                    nrm.c0 = f4_ld(e_red + f);
+                    nrm.c1 = f4_ld(e_red + H + f);
+                }
+            }
+            // ---- phase 1: by source
+            for (int p = p_beg + wave; p < p_end; p += kWavesPerBlock) {
+                const float4 bh = f4_ld(P + (int64_t)p * ldp + 2 * H + f);
+                float4 ga = f4_zero(), gbh = f4_zero();
+                const int beg = out_ptr[p], end = out_ptr[p + 1];
+                int k = beg;
+                for (; k + 4 <= end; k += 4) {
+                    float4 m[4], gy[4], g1[4], g0[4];
+                    int slot[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        slot[t] = out_slot[k + t];
+                        const int v = dst[slot[t]];
+                        m[t] = f4_ld(M + (int64_t)slot[t] * H + f);
+                        if (HAS_GY) gy[t] = f4_ld(GY + (int64_t)slot[t] * H + f);
+                        g1[t] = f4_ld(GS1 + (int64_t)v * H + f);
+                        g0[t] = f4_ld(GS0 + (int64_t)v * H + f);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        float4 gm = edge_grad<MODE>(m[t], gy[t], bh, g1[t], g0[t], nrm, inv_n, e_eval);
+                        f4_st(GM + (int64_t)slot[t] * H + f, gm);
+                        ga = f4_add(ga, gm);
+                        gbh = f4_fma(f4_sigmoid(m[t]), g1[t], gbh);
+                    }
+                }
+                for (; k < end; ++k) {
+                    const int slot = out_slot[k];
+                    const int v = dst[slot];
+                    float4 m = f4_ld(M + (int64_t)slot * H + f);
+                    float4 gy = f4_zero();
+                    if (HAS_GY) gy = f4_ld(GY + (int64_t)slot * H + f);
+                    float4 g1 = f4_ld(GS1 + (int64_t)v * H + f), g0 = f4_ld(GS0 + (int64_t)v * H + f);
+                    float4 gm = edge_grad<MODE>(m, gy, bh, g1, g0, nrm, inv_n, e_eval);
+                    f4_st(GM + (int64_t)slot * H + f, gm);
+                    ga = f4_add(ga, gm);
+                    gbh = f4_fma(f4_sigmoid(m), g1, gbh);
+                }
+                f4_st(GP + (int64_t)p * ldp + f, ga);
+                f4_st(GP + (int64_t)p * ldp + 2 * H + f, gbh);
+            }
+        }
+        __syncthreads();  // (waits for the GM stores of every wave: they are in L2 now)
+        // ---- phase 2: by destination segment, GM re-read from L2
+        if (active) {
+            for (int s = s_beg + wave; s < s_end; s += kWavesPerBlock) {
+                const int i = seg_node ? seg_node[s] : s;
+                float4 gbd = f4_zero();
+                for (int e = seg_ptr[s]; e < seg_ptr[s + 1]; ++e) gbd = f4_add(gbd, f4_ld(GM + (int64_t)e * H + f));
+                f4_st(GP + (int64_t)i * ldp + H + f, gbd);
+                gb = f4_add(gb, gbd);
+            }
+        }
+        if (gb_partial) {
+            sh[wave][lane] = gb;
+            __syncthreads();
+            if (wave == 0 && active) {
+                float4 a = sh[0][lane];
+#pragma unroll
+                for (int w = 1; w < kWavesPerBlock; ++w) a = f4_add(a, sh[w][lane]);
+                f4_st(gb_partial + (size_t)blockIdx.x * H + f, a);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 inline bool h_ok(int H) { return H >= 4 && (H & 3) == 0 && H <= 1024; }
 
 }  // namespace
@@ -362,6 +474,31 @@ int alignn_egc_bwd_dst(const float* GY, const float* M, const float* P, const fl
     else
         hipLaunchKernelGGL(egc_bwd_dst_kernel<0>, grid, block, 0, (hipStream_t)stream, GY, M, P, GS1, GS0, e_stat,
                            e_red, e_eval, inv_n, seg_ptr, seg_node, src, (int)n_seg, H, GM, GP, gb_partial);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_egc_bwd_lg_fused(const float* GY, const float* M, const float* P, const float* GS1, const float* GS0,
+                            const float* e_stat, const float* e_red, int e_eval, int64_t m_rows,
+                            const int32_t* grp_seg_ptr, const int32_t* grp_src_ptr, int64_t n_groups,
+                            const int32_t* seg_ptr, const int32_t* seg_node, const int32_t* dst,
+                            const int32_t* out_ptr, const int32_t* out_slot, int H, float* GM, float* GP,
+                            float* gb_partial, alignn_stream_t stream) {
+    if (!h_ok(H) || n_groups <= 0 || n_groups > INT32_MAX) return (int)hipErrorInvalidValue;
+    const float inv_n = m_rows > 0 ? 1.0f / (float)m_rows : 0.0f;
+    dim3 grid((int)n_groups), block(kThreads);
+    hipStream_t st = (hipStream_t)stream;
+#define ALIGNN_LGF(MODE_)                                                                                           \
+    hipLaunchKernelGGL(egc_bwd_lg_fused_kernel<MODE_>, grid, block, 0, st, GY, M, P, GS1, GS0, e_stat, e_red, e_eval,  \
+                       inv_n, grp_seg_ptr, grp_src_ptr, seg_ptr, seg_node, dst, out_ptr, out_slot, H, GM, GP,       \
+                       gb_partial)
+    if (GY && e_stat)
+        ALIGNN_LGF(1);
+    else if (GY)
+        ALIGNN_LGF(2);
+    else
+        ALIGNN_LGF(0);
+#undef ALIGNN_LGF
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }

@@ -38,6 +38,10 @@ class CSRGraph:
     out_slot: torch.Tensor  # [m] ... of slot ids
     perm: torch.Tensor  # [m] int64: slot k holds the caller's edge perm[k]
     inv: torch.Tensor  # [m] int64: caller's edge e lives in slot inv[e]
+    # line graphs only: one dense (sources x segments) block per centre atom j of the parent graph -
+    # segment ranks [grp_seg_ptr[j], grp_seg_ptr[j+1]) and source nodes [grp_src_ptr[j], grp_src_ptr[j+1])
+    grp_seg_ptr: Optional[torch.Tensor] = None
+    grp_src_ptr: Optional[torch.Tensor] = None
 
 
 def _ptr_from_counts(counts: torch.Tensor) -> torch.Tensor:
@@ -127,6 +131,11 @@ class GraphBatch:
             # order L(g)'s segments (bonds e2) by the bond's source atom, then by bond id
             seg_order = torch.argsort(g.src.to(torch.int64) * m + torch.arange(m, device=dev), stable=True)
             lg = build_csr(e1, e2, m, seg_order)
+            # every edge of a true line graph joins an in-edge and an out-edge of the same atom; then the canonical
+            # layout is block structured (see CSRGraph.grp_*) and the fused backward kernel applies.  A filtered
+            # line graph (eALIGNN) would fail this check and simply use the generic two-pass backward.
+            if bool((g.dst[lg.src.long()] == g.src[lg.dst.long()]).all()):
+                lg.grp_seg_ptr, lg.grp_src_ptr = g.out_ptr, g.seg_ptr
         bnn = torch.as_tensor(batch_num_nodes).to(dev).to(torch.int64)
         gp = _ptr_from_counts(bnn).to(torch.int32)
         out = GraphBatch(g=g, lg=lg, graph_ptr=gp, batch_size=int(bnn.numel()))

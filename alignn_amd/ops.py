@@ -16,6 +16,7 @@ from .graph import CSRGraph
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
+FUSED_LG_BACKWARD = True  # tests flip this to compare against the generic two-pass backward
 
 
 def _empty(*shape, like):
@@ -466,19 +467,32 @@ class EdgeGatedConvFn(torch.autograd.Function):
                 g_branch = gy_out
                 e_red = _bn_silu_bwd_reduce(gy_out, M, e_stat)
         GM = _empty(m, H, like=x)
-        gslabs = lib.alignn_egc_slabs(n)
-        gb_part = _empty(gslabs, H, like=x)
-        check(
-            lib.alignn_egc_bwd_dst(ptr(g_branch), ptr(M), ptr(P), ptr(gs1), ptr(gs0), ptr(e_stat_arg), ptr(e_gamma),
-                                   ptr(e_red), int(ev), m, ptr(graph.seg_ptr), ptr(graph.seg_node), ptr(graph.src), n,
-                                   H, ptr(GM), ptr(GP), ptr(gb_part), stream()),
-            "egc_bwd_dst",
-        )
-        check(
-            lib.alignn_egc_bwd_src(ptr(GM), ptr(M), ptr(gs1), ptr(graph.out_ptr), ptr(graph.out_slot), ptr(graph.dst),
-                                   n, H, ptr(GP), stream()),
-            "egc_bwd_src",
-        )
+        if graph.grp_seg_ptr is not None and FUSED_LG_BACKWARD:
+            # line graph: destination- and source-ordered passes in one kernel, one workgroup per centre atom
+            gslabs = graph.grp_seg_ptr.numel() - 1
+            gb_part = _empty(gslabs, H, like=x)
+            check(
+                lib.alignn_egc_bwd_lg_fused(ptr(g_branch), ptr(M), ptr(P), ptr(gs1), ptr(gs0), ptr(e_stat_arg),
+                                            ptr(e_red), int(ev), m, ptr(graph.grp_seg_ptr), ptr(graph.grp_src_ptr),
+                                            gslabs, ptr(graph.seg_ptr), ptr(graph.seg_node), ptr(graph.dst),
+                                            ptr(graph.out_ptr), ptr(graph.out_slot), H, ptr(GM), ptr(GP), ptr(gb_part),
+                                            stream()),
+                "egc_bwd_lg_fused",
+            )
+        else:
+            gslabs = lib.alignn_egc_slabs(n)
+            gb_part = _empty(gslabs, H, like=x)
+            check(
+                lib.alignn_egc_bwd_dst(ptr(g_branch), ptr(M), ptr(P), ptr(gs1), ptr(gs0), ptr(e_stat_arg), ptr(e_gamma),
+                                       ptr(e_red), int(ev), m, ptr(graph.seg_ptr), ptr(graph.seg_node), ptr(graph.src),
+                                       n, H, ptr(GM), ptr(GP), ptr(gb_part), stream()),
+                "egc_bwd_dst",
+            )
+            check(
+                lib.alignn_egc_bwd_src(ptr(GM), ptr(M), ptr(gs1), ptr(graph.out_ptr), ptr(graph.out_slot),
+                                       ptr(graph.dst), n, H, ptr(GP), stream()),
+                "egc_bwd_src",
+            )
         # projections: weight gradients on the side stream, input gradients (critical path) on the main one
         def _wgrads():
             g_beg_ = _empty(H, like=x)  # column sum of GM, accumulated inside the destination-order pass

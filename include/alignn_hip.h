@@ -180,6 +180,18 @@ int alignn_egc_bwd_dst(const float* GY, const float* M, const float* P, const fl
                        int64_t n_seg, int H, float* GM, float* GP, float* gb_partial,
                        alignn_stream_t stream);
 
+/* Line-graph backward with the destination- and source-ordered passes fused (one workgroup per centre atom j;
+ * L(g)'s edges form one dense block per atom: sources = in-edges of j = L(g) nodes [grp_src_ptr[j],
+ * grp_src_ptr[j+1]), segments = out-edges of j = segment ranks [grp_seg_ptr[j], grp_seg_ptr[j+1])).  Same inputs,
+ * outputs and bit-identical results as alignn_egc_bwd_dst followed by alignn_egc_bwd_src, with 2 reads + 1 write
+ * per edge row instead of 4 + 1.  gb_partial: [n_groups][H] column-sum slabs of GM. */
+int alignn_egc_bwd_lg_fused(const float* GY, const float* M, const float* P, const float* GS1,
+                            const float* GS0, const float* e_stat, const float* e_red, int e_eval,
+                            int64_t m_rows, const int32_t* grp_seg_ptr, const int32_t* grp_src_ptr,
+                            int64_t n_groups, const int32_t* seg_ptr, const int32_t* seg_node,
+                            const int32_t* dst, const int32_t* out_ptr, const int32_t* out_slot, int H,
+                            float* GM, float* GP, float* gb_partial, alignn_stream_t stream);
+
 /* Source-ordered backward pass (deterministic scatter-by-source):
  *   GP[j, 0:H]   (g_A)  = sum_{e: src e = j} GM[e]
  *   GP[j, 2H:3H] (g_Bh) = sum_{e: src e = j} sigmoid(M[e]) * GS1[dst e] */

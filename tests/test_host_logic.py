@@ -1,0 +1,70 @@
+"""CPU tests of the host-side logic that needs no GPU: synthetic generator, canonical graph layout."""
+
+import numpy as np
+import torch
+
+from alignn_amd.graph import GraphBatch, build_csr
+from alignn_amd.synthetic import _one, batch_raw, line_graph_coo, make_batch
+
+
+def test_generator_matches_reference_input_contract():
+    raw = make_batch(3, 20, seed0=11)
+    # both directions of every bond are stored consecutively with opposite displacement (graphs.py:253-257)
+    assert (raw.u[0::2] == raw.v[1::2]).all() and (raw.v[0::2] == raw.u[1::2]).all()
+    assert np.allclose(raw.r[0::2], -raw.r[1::2])
+    # k-NN with ties: every atom has at least 12 in-edges
+    assert np.bincount(raw.v, minlength=raw.num_nodes).min() >= 12
+    # line graph: e1 -> e2 iff dst(e1) == src(e2), e1 != e2 (backtracking included)
+    assert (raw.v[raw.lg_u] == raw.u[raw.lg_v]).all() and (raw.lg_u != raw.lg_v).all()
+    assert raw.num_triplets == int(sum(np.bincount(raw.v, minlength=raw.num_nodes)[raw.u]) - (raw.u == raw.v).sum())
+    assert np.abs(raw.h).max() <= 1.0
+    # batching = disjoint union: no edge crosses crystals
+    gid = np.repeat(np.arange(3), raw.batch_num_nodes)
+    assert (gid[raw.u] == gid[raw.v]).all()
+    assert raw.batch_num_edges.sum() == raw.num_edges and raw.batch_num_triplets.sum() == raw.num_triplets
+
+
+def test_one_atom_cell_is_all_self_image_edges():
+    g = _one(1, 7, "crystal", 92)
+    assert g.num_nodes == 1 and g.num_edges >= 24 and (g.u == 0).all() and (g.v == 0).all()
+    assert g.num_triplets == g.num_edges * (g.num_edges - 1)  # every pair except e1 == e2
+
+
+def test_canonical_layout_invariants():
+    raw = batch_raw([_one(n, 90 + i, "crystal", 92) for i, n in enumerate((1, 5, 9))])
+    b = GraphBatch.from_raw(raw)
+    g, lg = b.g, b.lg
+    u, v = torch.from_numpy(raw.u), torch.from_numpy(raw.v)
+    # slot k holds caller edge perm[k]; segments are contiguous and cover each node exactly once
+    assert (u[g.perm] == g.src.long()).all() and (v[g.perm] == g.dst.long()).all()
+    assert (g.inv[g.perm] == torch.arange(g.n_edges)).all()
+    assert (g.dst.long() == torch.repeat_interleave(torch.arange(g.n_nodes), (g.seg_ptr[1:] - g.seg_ptr[:-1]).long())).all()
+    # by-source view lists every slot once, grouped by source
+    assert sorted(g.out_slot.tolist()) == list(range(g.n_edges))
+    assert (g.src[g.out_slot.long()].long() == torch.repeat_interleave(torch.arange(g.n_nodes), (g.out_ptr[1:] - g.out_ptr[:-1]).long())).all()
+    # line graph nodes are g's canonical slots; its segments are ordered by the source atom of the bond
+    e1, e2 = g.inv[torch.from_numpy(raw.lg_u)], g.inv[torch.from_numpy(raw.lg_v)]
+    assert (e1[lg.perm] == lg.src.long()).all() and (e2[lg.perm] == lg.dst.long()).all()
+    seg_src_atom = g.src[lg.seg_node.long()]
+    assert (seg_src_atom[1:] >= seg_src_atom[:-1]).all()
+    # every source of a line-graph segment is an in-edge of that segment's source atom -> one contiguous block of rows
+    for s in range(0, lg.n_nodes, 7):
+        a, z = int(lg.seg_ptr[s]), int(lg.seg_ptr[s + 1])
+        j = int(seg_src_atom[s])
+        srcs = lg.src[a:z].long()
+        assert ((srcs >= int(g.seg_ptr[j])) & (srcs < int(g.seg_ptr[j + 1]))).all()
+    # inputs follow the permutations; volumes and bond offsets per crystal
+    assert torch.allclose(b.r, torch.from_numpy(raw.r)[g.perm]) and torch.allclose(b.h, torch.from_numpy(raw.h)[lg.perm])
+    assert b.edge_graph_ptr.tolist() == [0] + np.cumsum(raw.batch_num_edges).tolist()
+    assert torch.allclose(b.volume, torch.from_numpy(np.abs(np.linalg.det(raw.lattice))).float(), rtol=1e-5)
+
+
+def test_build_csr_with_isolated_nodes_and_custom_segment_order():
+    u = torch.tensor([0, 0, 2, 2, 2])
+    v = torch.tensor([1, 1, 0, 1, 2])
+    order = torch.tensor([3, 1, 0, 2])  # node 3 has no edges at all
+    c = build_csr(u, v, 4, order)
+    assert c.seg_node.tolist() == [3, 1, 0, 2]
+    assert c.seg_ptr.tolist() == [0, 0, 3, 4, 5]
+    assert c.dst.tolist() == [1, 1, 1, 0, 2] and c.src.tolist() == [0, 0, 2, 2, 2]
+    assert c.out_ptr.tolist() == [0, 2, 2, 5, 5]
