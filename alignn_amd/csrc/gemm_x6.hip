@@ -40,11 +40,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #ifndef X6_RM
-#define X6_RM 1
+#define X6_RM 2
+#endif
+#ifndef X6_WM
+#define X6_WM 2
 #endif
 constexpr int RM = X6_RM;                  // 32-row MFMA tiles per wave along M
-constexpr int BM = 128 * RM, BN = 256, BK = 16;  // one 16-deep MFMA step per stage
-constexpr int WM = 4, WN = 2, NT = WM * WN * 64;
+constexpr int WM = X6_WM, WN = 2, NT = WM * WN * 64;
+constexpr int BM = WM * 32 * RM, BN = 256, BK = 16;  // one 16-deep MFMA step per stage
 constexpr int TM = BM / WM, TN = BN / WN;  // (32*RM) x 128 per wave
 constexpr int RN = TN / 32;                // RM x 4 MFMA tiles
 constexpr int A_BYTES = BM * BK * 4;       // 8 KiB fp32 (64-byte rows), XOR-swizzled 16-byte chunks, no padding

@@ -4,7 +4,7 @@ import ctypes as C, os, subprocess, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "alignn_amd", "csrc", "gemm_x6.hip")
 OUT = os.path.join(ROOT, "gpurun_out")
-VARIANTS = {"warm": [], "base": [], "a_default": ["-DX6_A_AUX=0"],  "noslice": ["-DX6_ABL_NOSLICE=1"], "nobload": ["-DX6_ABL_NOBLOAD=1"], "noaload": ["-DX6_ABL_NOALOAD=1"],
+VARIANTS = {"warm": [], "base": [], "big": ["-DX6_WM=2", "-DX6_RM=4"], "big_noloads": ["-DX6_WM=2", "-DX6_RM=4", "-DX6_ABL_NOBLOAD=1", "-DX6_ABL_NOALOAD=1"], "mid": ["-DX6_WM=2", "-DX6_RM=2"],  "noslice": ["-DX6_ABL_NOSLICE=1"], "nobload": ["-DX6_ABL_NOBLOAD=1"], "noaload": ["-DX6_ABL_NOALOAD=1"],
             "onemfma": ["-DX6_ABL_ONEMFMA=1"], "noloads": ["-DX6_ABL_NOBLOAD=1", "-DX6_ABL_NOALOAD=1"],
             "noloads_noslice": ["-DX6_ABL_NOBLOAD=1", "-DX6_ABL_NOALOAD=1", "-DX6_ABL_NOSLICE=1"]}
 def build():
