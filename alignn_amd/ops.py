@@ -364,8 +364,8 @@ class MLPLayerFn(torch.autograd.Function):
             red = _bn_silu_bwd_reduce(gy, pre, stat)
             _bn_silu_bwd_apply(gy, pre, stat, gamma, red, not ctx.training, gpre)
         dbeta, dgamma = red[0], red[1]
-        gw, gb = on_side_stream(lambda: (gemm_tn(gpre, x), col_sum(gpre)), [gpre, x])
         gx = _dgrad(gpre, w) if ctx.needs_input_grad[0] else None
+        gw, gb = on_side_stream(lambda: (gemm_tn(gpre, x), col_sum(gpre)), [gpre, x])
         return gx, gw, gb, dgamma, dbeta, None, None, None, None
 
 
@@ -499,9 +499,12 @@ class EdgeGatedConvFn(torch.autograd.Function):
             check(lib.alignn_slab_sum(ptr(gb_part), gslabs, H, ptr(g_beg_), stream()), "slab_sum")
             return gemm_tn(GM, y), g_beg_, gemm_tn(GP, x), col_sum(GP)
 
-        g_weg, g_beg, g_wcat, g_bcat = on_side_stream(_wgrads, [GM, y, GP, x, gb_part])
+        # order matters: the side stream starts where the main stream stands at the on_side_stream() call.  Issue
+        # the input-gradient GEMMs first, so the weight-gradient GEMMs (LDS-heavy, cannot share a CU with the x6
+        # tiles) run beside the NEXT layer's HBM-bound kernels instead of fighting these GEMMs for whole CUs.
         g_x = _dgrad(GP, wcat, addend=gx_out if ctx.residual else None)
         g_y = _dgrad(GM, w_eg, addend=gy_out if (ctx.residual and gy_out is not None) else None)
+        g_weg, g_beg, g_wcat, g_bcat = on_side_stream(_wgrads, [GM, y, GP, x, gb_part])
         dn_gamma, dn_beta = n_red[1], n_red[0]
         de_gamma = e_red[1] if e_red is not None else None
         de_beta = e_red[0] if e_red is not None else None
