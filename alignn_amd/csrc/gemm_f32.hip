@@ -393,8 +393,24 @@ int alignn_gemm_nn(const float* G, int64_t ldg, const float* W, int64_t ldw, con
     return launch<128, 64, 4, 1, true, false>(g, 1, st);
 }
 
+// bf16x6 variant (csrc/gemm_x6.hip) for the large, aligned weight gradients
+int alignn_gemm_tn_x6_supported(int64_t M, int N, int K);
+size_t alignn_gemm_tn_x6_workspace(int64_t M, int N, int K);
+int alignn_gemm_tn_x6_splits(int64_t M, int N, int K);
+int alignn_gemm_tn_x6_partials(const float* G, int64_t ldg, const float* X, int64_t ldx, int64_t M, int N, int K,
+                               void* workspace, size_t workspace_bytes, alignn_stream_t stream);
+
+static bool tn_use_x6(const float* G, int64_t ldg, const float* A, int64_t lda, int64_t M, int N, int K) {
+    return alignn_gemm_tn_x6_supported(M, N, K) && (ldg % 4 == 0) && (lda % 4 == 0) && aligned16(G) && aligned16(A);
+}
+
 size_t alignn_gemm_tn_workspace(int64_t M, int N, int K) {
-    return (size_t)tn_splits(M, N, K) * (size_t)N * (size_t)K * sizeof(float);
+    const size_t f32 = (size_t)tn_splits(M, N, K) * (size_t)N * (size_t)K * sizeof(float);
+    if (alignn_gemm_tn_x6_supported(M, N, K)) {
+        const size_t x6 = alignn_gemm_tn_x6_workspace(M, N, K);
+        return x6 > f32 ? x6 : f32;
+    }
+    return f32;
 }
 
 int alignn_gemm_tn(const float* G, int64_t ldg, const float* A, int64_t lda, float* dW, int64_t lddw, int64_t M, int N,
@@ -404,9 +420,18 @@ int alignn_gemm_tn(const float* G, int64_t ldg, const float* A, int64_t lda, flo
     // dW[n,k] = sum_m G[m,n] A[m,k]: both operands index-contiguous, reduction over rows m
     const bool vec_ok = (N % 4 == 0) && (K % 4 == 0) && (ldg % 4 == 0) && (lda % 4 == 0) && aligned16(G) && aligned16(A);
     if (!vec_ok || M == 0) return naive(G, 1, ldg, A, 1, lda, nullptr, nullptr, 0, dW, lddw, N, K, M, st);
-    const int splits = tn_splits(M, N, K);
     if (workspace_bytes < alignn_gemm_tn_workspace(M, N, K) || workspace == nullptr) return (int)hipErrorInvalidValue;
     float* ws = (float*)workspace;
+    if (tn_use_x6(G, ldg, A, lda, M, N, K)) {
+        int rc6 = alignn_gemm_tn_x6_partials(G, ldg, A, lda, M, N, K, workspace, workspace_bytes, stream);
+        if (rc6) return rc6;
+        const int64_t count6 = (int64_t)N * K;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(alignn_ceil_div(count6, 32)), dim3(32, 32), 0, st, ws,
+                           alignn_gemm_tn_x6_splits(M, N, K), count6, K, dW, lddw);
+        ALIGNN_CHECK_LAUNCH();
+        return 0;
+    }
+    const int splits = tn_splits(M, N, K);
     GemmArgs g{G, ldg, A, lda, nullptr, nullptr, 0, ws, K, N, K, M, tn_chunk(M, N, K), (int64_t)N * K, 1, 0, 0, 0};
     int rc;
     if (K > 64)

@@ -274,6 +274,166 @@ __global__ __launch_bounds__(NT) void gemm_nt_x6_kernel(X6Args g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Weight gradient on the same split product:  dW[n,k] = sum_m G[m,n] X[m,k]  (both operands are activations,
+// both are sliced in registers).  The reduction index m is the ROW of both inputs, so a 16-row stage is DMA'd
+// as it lies in memory ([16][128] of G, [16][256] of X, fp32) and the MFMA operands - 8 consecutive m for one
+// output index per lane - are column reads: 8 x ds_read_b32 per 32-wide tile, lanes on consecutive columns
+// (conflict-free without any swizzle).  256(n) x 256(k) output tile per workgroup, 8 waves of 64 x 128, the M
+// rows split into slabs (fixed-order fp64 slab sum afterwards, as for the fp32 kernel); tiles of one slab are
+// launched back-to-back on one XCD so the second reader of the X rows hits L2.
+// ---------------------------------------------------------------------------------------------
+namespace tn {
+constexpr int TBN = 256, TBK = 256, TSTEP = 16;        // output tile (n x k), reduction rows per stage
+constexpr int TWM = 4, TWN = 2, TNT = TWM * TWN * 64;  // 8 waves of 64(n) x 128(k): every input row is read ONCE
+constexpr int TRM = 2, TRN = 4;
+constexpr int G_BYTES = TSTEP * TBN * 4;               // 16 KiB
+constexpr int X_BYTES = TSTEP * TBK * 4;               // 16 KiB
+constexpr int TSTAGE = G_BYTES + X_BYTES;              // 32 KiB
+constexpr int G_PIECES = G_BYTES / 1024, X_PIECES = X_BYTES / 1024;     // 16 + 16
+constexpr int PIECES_PER_WAVE = (G_PIECES + X_PIECES) / (TNT / 64);     // 4
+constexpr int TEPI = (TNT / 64) * 32 * (64 + 4) * 4;                    // 68 KiB of transpose patches
+constexpr int TLDS = 2 * TSTAGE > TEPI ? 2 * TSTAGE : TEPI;             // 68 KiB
+
+struct TnArgs {
+    const float* G;
+    int64_t ldg;
+    const float* X;
+    int64_t ldx;
+    float* ws;  // [splits][N][K]
+    int64_t M;
+    int N, K;
+    int64_t chunk;  // reduction rows per slab (multiple of 16)
+    int tiles_n, tiles_k, splits;
+};
+
+__global__ __launch_bounds__(TNT) void gemm_tn_x6_kernel(TnArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / TWN, wn = wave % TWN;
+    const int il = lane & 31, half = lane >> 5;
+    // XCD grouping: workgroup L runs on XCD L % 8; give XCD c the slabs c, c+8, ... with their tiles consecutive
+    const int tiles = g.tiles_n * g.tiles_k;
+    const int L = blockIdx.x;
+    const int z = (L & 7) + 8 * ((L >> 3) / tiles);
+    if (z >= g.splits) return;
+    const int tile = (L >> 3) % tiles;
+    const int n0 = (tile % g.tiles_n) * TBN, k0 = (tile / g.tiles_n) * TBK;
+    const int64_t rbeg = (int64_t)z * g.chunk;
+    int64_t rend = rbeg + g.chunk;
+    if (rend > g.M) rend = g.M;
+    const int nst = rend > rbeg ? (int)((rend - rbeg + TSTEP - 1) / TSTEP) : 0;
+
+    f32x16 acc[TRM][TRN];
+#pragma unroll
+    for (int a = 0; a < TRM; ++a)
+#pragma unroll
+        for (int b = 0; b < TRN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    // DMA: piece q of a stage = 1 KiB = one 256-float row: q < 16 of G, else of X
+    auto issue = [&](int st, unsigned char* stage) {
+#pragma unroll
+        for (int i = 0; i < PIECES_PER_WAVE; ++i) {
+            const int q = wave * PIECES_PER_WAVE + i;
+            const float* src;
+            if (q < G_PIECES) {
+                int64_t row = rbeg + (int64_t)st * TSTEP + q;
+                if (row >= g.M) row = g.M - 1;  // clamped; its contribution is masked below
+                src = g.G + row * g.ldg + n0 + lane * 4;
+            } else {
+                int64_t row = rbeg + (int64_t)st * TSTEP + (q - G_PIECES);
+                if (row >= g.M) row = g.M - 1;
+                src = g.X + row * g.ldx + k0 + lane * 4;
+            }
+            dma16<0>(src, stage + q * 1024);
+        }
+    };
+
+    if (nst > 0) issue(0, smem);
+    __syncthreads();
+    for (int st = 0; st < nst; ++st) {
+        const int cur = st & 1;
+        if (st + 1 < nst) issue(st + 1, smem + (cur ^ 1) * TSTAGE);
+        const float* Gs = reinterpret_cast<const float*>(smem + cur * TSTAGE);
+        const float* Xs = reinterpret_cast<const float*>(smem + cur * TSTAGE + G_BYTES);
+        // rows of this stage that lie past the end of the slab (only in its last stage) contribute nothing
+        const int valid = (int)((rend - (rbeg + (int64_t)st * TSTEP)) < TSTEP ? (rend - (rbeg + (int64_t)st * TSTEP)) : TSTEP);
+        bf16x8 ah[TRM], am[TRM], al[TRM], bh[TRN], bm[TRN], bl[TRN];
+#pragma unroll
+        for (int a = 0; a < TRM; ++a) {
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int m = 8 * half + j;
+                const float v = Gs[m * TBN + wm * 64 + a * 32 + il];
+                x[j] = m < valid ? v : 0.0f;
+            }
+            slice8(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]), ah[a], am[a], al[a]);
+        }
+#pragma unroll
+        for (int b = 0; b < TRN; ++b) {
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = Xs[(8 * half + j) * TBK + wn * 128 + b * 32 + il];
+            slice8(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]), bh[b], bm[b], bl[b]);
+        }
+#define X6_TPASS(AA, BB)                                                                               \
+    _Pragma("unroll") for (int a = 0; a < TRM; ++a) _Pragma("unroll") for (int b = 0; b < TRN; ++b)    \
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AA[a], BB[b], acc[a][b], 0, 0, 0);
+        X6_TPASS(al, bh)
+        X6_TPASS(ah, bl)
+        X6_TPASS(am, bm)
+        X6_TPASS(am, bh)
+        X6_TPASS(ah, bm)
+        X6_TPASS(ah, bh)
+#undef X6_TPASS
+        __syncthreads();
+    }
+
+    // epilogue: slab z of the workspace, rows n, cols k; per-wave LDS transpose -> float4 row segments
+    constexpr int PLD = 64 + 4;
+    float* patch = reinterpret_cast<float*>(smem) + wave * (32 * PLD);
+    const int prow = lane >> 4, pc4 = (lane & 15) * 4;
+    float* out = g.ws + (int64_t)z * g.N * g.K;
+#pragma unroll
+    for (int ahb = 0; ahb < TRM * (TRN / 2); ++ahb) {
+        const int a = ahb / (TRN / 2), hb = ahb % (TRN / 2);
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                patch[((r & 3) + 8 * (r >> 2) + 4 * half) * PLD + b * 32 + il] = acc[a][2 * hb + b][r];
+        __syncthreads();
+        float4 ov[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ov[i] = f4_ld(patch + (i * 4 + prow) * PLD + pc4);
+        const int col = k0 + wn * 128 + hb * 64 + pc4;
+        const int row0 = n0 + wm * 64 + a * 32 + prow;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f4_st(out + (int64_t)(row0 + i * 4) * g.K + col, ov[i]);
+    }
+}
+
+inline int64_t tn_chunk(int64_t M, int N, int K) {
+    const int64_t tiles = (int64_t)(N / TBN) * (K / TBK);
+    int64_t want = (512 + tiles - 1) / tiles;  // ~2 workgroups per CU
+    if (want < 1) want = 1;
+    int64_t chunk = (M + want - 1) / want;
+    chunk = ((chunk + TSTEP - 1) / TSTEP) * TSTEP;
+    if (chunk < 8 * TSTEP) chunk = 8 * TSTEP;
+    return chunk;
+}
+inline int tn_splits(int64_t M, int N, int K) {
+    const int64_t c = tn_chunk(M, N, K);
+    return (int)((M + c - 1) / c);
+}
+}  // namespace tn
+
 // Slice W (or W^T) into the kernel's DMA image: out[kb][n/256][plane][n%256][chunk ^ ((n>>3)&1)][8], n < Npad
 // (zero rows beyond N), kb = k/16, chunk = (k%16)/8.
 __global__ void split_bf16x3_kernel(const float* __restrict__ W, int64_t ldw, int N, int Npad, int K, int transpose,
@@ -312,6 +472,39 @@ int alignn_split_bf16x3(const float* W, int64_t ldw, int N, int K, int transpose
     if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(split_bf16x3_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, W, ldw, N, npad(N), K,
                        transpose, (unsigned short*)out);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_gemm_tn_x6_supported(int64_t M, int N, int K) {
+    return (M >= 4096 && N % tn::TBN == 0 && K % tn::TBK == 0) ? 1 : 0;
+}
+
+size_t alignn_gemm_tn_x6_workspace(int64_t M, int N, int K) {
+    return (size_t)tn::tn_splits(M, N, K) * (size_t)N * (size_t)K * sizeof(float);
+}
+
+int alignn_gemm_tn_x6_splits(int64_t M, int N, int K) { return tn::tn_splits(M, N, K); }
+
+/* slab partials only: ws[z][N][K] for z < alignn_gemm_tn_x6_splits(); the caller sums the slabs */
+int alignn_gemm_tn_x6_partials(const float* G, int64_t ldg, const float* X, int64_t ldx, int64_t M, int N, int K,
+                               void* workspace, size_t workspace_bytes, alignn_stream_t stream) {
+    if (!alignn_gemm_tn_x6_supported(M, N, K)) return (int)hipErrorInvalidValue;
+    if ((ldg & 3) || (ldx & 3) || !a16(G) || !a16(X) || !a16(workspace) ||
+        workspace_bytes < alignn_gemm_tn_x6_workspace(M, N, K))
+        return (int)hipErrorInvalidValue;
+    tn::TnArgs g{G, ldg, X, ldx, (float*)workspace, M, N, K, tn::tn_chunk(M, N, K), N / tn::TBN, K / tn::TBK,
+                 tn::tn_splits(M, N, K)};
+    static bool tn_attr = false;
+    if (!tn_attr && tn::TLDS > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)tn::gemm_tn_x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           tn::TLDS);
+        if (e != hipSuccess) return (int)e;
+        tn_attr = true;
+    }
+    const int tiles = g.tiles_n * g.tiles_k;
+    const int per_xcd = alignn_ceil_div(g.splits, 8) * tiles;
+    hipLaunchKernelGGL(tn::gemm_tn_x6_kernel, dim3(per_xcd * 8), dim3(tn::TNT), tn::TLDS, (hipStream_t)stream, g);
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }

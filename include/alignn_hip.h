@@ -79,6 +79,15 @@ int alignn_gemm_nt_x6(const float* A, int64_t lda, const void* Wsplit, const flo
                       const float* addend, int64_t ldadd, float* C, int64_t ldc,
                       int64_t M, int N, int K, alignn_stream_t stream);
 
+/* Weight gradient on the split product (both operands sliced in registers): slab partials ws[z][N][K] for
+ * z < alignn_gemm_tn_x6_splits(M,N,K); needs N % 256 == 0, K % 256 == 0, M >= 4096.  alignn_gemm_tn uses it
+ * automatically for such shapes and sums the slabs. */
+int alignn_gemm_tn_x6_supported(int64_t M, int N, int K);
+size_t alignn_gemm_tn_x6_workspace(int64_t M, int N, int K);
+int alignn_gemm_tn_x6_splits(int64_t M, int N, int K);
+int alignn_gemm_tn_x6_partials(const float* G, int64_t ldg, const float* X, int64_t ldx, int64_t M, int N,
+                               int K, void* workspace, size_t workspace_bytes, alignn_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Column statistics / BatchNorm1d + SiLU (+ residual).
  * Replace nn.BatchNorm1d (training: batch statistics over ALL rows; eps 1e-5; momentum 0.1,
