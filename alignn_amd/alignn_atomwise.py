@@ -160,17 +160,17 @@ class ALIGNNAtomWise(nn.Module):
             return g
         if isinstance(g, (tuple, list)) and isinstance(g[0], GraphBatch):
             return g[0]
-        if len(self.alignn_layers) > 0 and len(g) != 3:
-            raise NotImplementedError(
-                "forward((g, lat)) builds L(g) inside the forward (alignn_atomwise.py:376-386); device-side "
-                "line-graph construction is a 'next' row (SURVEY.md section 8(f) f1) - pass (g, lg, lat)"
-            )
         gg = g[0]
-        lg = g[1] if len(self.alignn_layers) > 0 else None
+        # (g, lg, lat) as the training loop passes it, or (g, lat): then L(g) is built inside the forward
+        # (alignn_atomwise.py:376-386) - here on the device, straight into the canonical block layout
+        lg = g[1] if (len(self.alignn_layers) > 0 and len(g) == 3) else None
+        need_lg = len(self.alignn_layers) > 0 and lg is None
+        if need_lg and not self.config.lg_on_fly:
+            raise ValueError("forward((g, lat)) has no precomputed bond cosines: it needs lg_on_fly=True")
         cached = getattr(gg, "_alignn_amd_batch", None)
-        if cached is not None and cached.device == dev:
+        if cached is not None and cached.device == dev and (cached.lg is not None or not need_lg):
             return cached
-        batch = GraphBatch.from_dgl(gg, lg, device=dev)
+        batch = GraphBatch.from_dgl(gg, lg, device=dev, build_line_graph=need_lg)
         try:
             gg._alignn_amd_batch = batch
         except Exception:

@@ -93,6 +93,48 @@ def build_csr(u: torch.Tensor, v: torch.Tensor, n_nodes: int, seg_order: Optiona
     )
 
 
+def line_graph_of(g: CSRGraph) -> CSRGraph:
+    """Canonical line graph of a canonical bond graph, built on the device the graph lives on - the
+    ``g.line_graph(shared=True)`` of the reference (alignn/graphs.py:588; rebuilt inside the forward at
+    alignn/models/alignn_atomwise.py:376-386) without ever materialising a COO list in caller order.
+
+    L(g) node i is g's slot i; ``e1 -> e2`` iff ``dst(e1) == src(e2)`` and ``e1 != e2`` (backtracking kept).  In
+    the canonical layout this is one dense block per atom j: segments = out-edges of j in ``out_slot`` order,
+    each listing the in-edges of j (the contiguous slots ``[seg_ptr[j], seg_ptr[j+1])``) minus itself.
+    """
+    dev = g.src.device
+    m = g.n_edges
+    seg_node = g.out_slot.long()  # e2 of every segment: out-edges grouped by source atom, slot order within
+    atom = g.src.long()[seg_node]  # centre atom j of the segment
+    sp = g.seg_ptr.long()
+    din = (sp[1:] - sp[:-1])[atom]  # candidates e1 per segment (before the e1 != e2 exclusion)
+    seg_of = torch.repeat_interleave(torch.arange(m, device=dev), din)
+    first = torch.cumsum(din, 0) - din
+    e1 = sp[atom][seg_of] + (torch.arange(seg_of.numel(), device=dev) - first[seg_of])
+    e2 = seg_node[seg_of]
+    keep = e1 != e2
+    e1, e2, seg_of = e1[keep], e2[keep], seg_of[keep]
+    counts = torch.bincount(seg_of, minlength=m)
+    t = int(e1.numel())
+    out_slot = torch.argsort(e1, stable=True)
+    out_ptr = _ptr_from_counts(torch.bincount(e1, minlength=m))
+    ident = torch.arange(t, device=dev)
+    return CSRGraph(
+        n_nodes=m,
+        n_edges=t,
+        seg_ptr=_ptr_from_counts(counts).to(torch.int32),
+        seg_node=seg_node.to(torch.int32),
+        src=e1.to(torch.int32),
+        dst=e2.to(torch.int32),
+        out_ptr=out_ptr.to(torch.int32),
+        out_slot=out_slot.to(torch.int32),
+        perm=ident,
+        inv=ident,
+        grp_seg_ptr=g.out_ptr,
+        grp_src_ptr=g.seg_ptr,
+    )
+
+
 @dataclass
 class GraphBatch:
     """Canonical (g, L(g)) batch plus the canonically ordered inputs."""
@@ -117,8 +159,9 @@ class GraphBatch:
 
     @staticmethod
     def from_coo(u, v, n_nodes, batch_num_nodes, lg_u=None, lg_v=None, atom_features=None, r=None, h=None, device=None,
-                 volume=None):
-        """Build from raw COO tensors (caller's edge order)."""
+                 volume=None, build_line_graph=False):
+        """Build from raw COO tensors (caller's edge order).  ``build_line_graph``: no ``lg_u/lg_v`` given - derive
+        L(g) on the device (``line_graph_of``); the cosines ``h`` are then left to the model (``lg_on_fly``)."""
         dev = torch.device(device) if device is not None else u.device
         u = torch.as_tensor(u).to(dev)
         v = torch.as_tensor(v).to(dev)
@@ -136,6 +179,8 @@ class GraphBatch:
             # line graph (eALIGNN) would fail this check and simply use the generic two-pass backward.
             if bool((g.dst[lg.src.long()] == g.src[lg.dst.long()]).all()):
                 lg.grp_seg_ptr, lg.grp_src_ptr = g.out_ptr, g.seg_ptr
+        elif build_line_graph:
+            lg = line_graph_of(g)
         bnn = torch.as_tensor(batch_num_nodes).to(dev).to(torch.int64)
         gp = _ptr_from_counts(bnn).to(torch.int32)
         out = GraphBatch(g=g, lg=lg, graph_ptr=gp, batch_size=int(bnn.numel()))
@@ -168,7 +213,7 @@ class GraphBatch:
         )
 
     @staticmethod
-    def from_dgl(g, lg=None, device=None):
+    def from_dgl(g, lg=None, device=None, build_line_graph=False):
         """From DGL-like graphs: anything exposing ``edges()``, ``num_nodes()``, ``batch_num_nodes()``
         and ``ndata`` / ``edata`` dicts (a real ``dgl.DGLGraph`` or the oracle shim).  Reads
         ``g.ndata['atom_features']``, ``g.edata['r']``, ``lg.edata['h']`` exactly as
@@ -188,4 +233,5 @@ class GraphBatch:
             bnn = torch.as_tensor(g.batch_num_nodes()).to(torch.int64)
             first = torch.cumsum(bnn, 0) - bnn
             kw["volume"] = g.ndata["V"][first.to(g.ndata["V"].device)]
-        return GraphBatch.from_coo(u, v, g.num_nodes(), g.batch_num_nodes(), device=dev, **kw)
+        return GraphBatch.from_coo(u, v, g.num_nodes(), g.batch_num_nodes(), device=dev,
+                                   build_line_graph=build_line_graph and lg is None, **kw)

@@ -415,3 +415,33 @@ def test_fused_line_graph_backward_matches_two_pass():
     for k in grads[0]:
         assert rel_err(grads[0][k], grads[1][k], floor=1e-2 * gmax) < 2e-5, k
         assert torch.equal(grads[0][k], grads[2][k]), k  # the fused path reproduces itself bit for bit
+
+
+def test_atomwise_g_lat_input_builds_line_graph_on_device():
+    """forward((g, lat)) - the reference builds L(g) inside the forward (alignn_atomwise.py:376-386); we derive it
+    on the device from g's canonical CSR.  Must give the same energies as the explicit (g, lg, lat) call."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "shims"))
+    import dgl  # shim: DGL-shaped container only
+
+    from alignn_amd import ALIGNNAtomWise, ALIGNNAtomWiseConfig
+
+    raw = make_batch(3, 14, seed0=808)
+    torch.manual_seed(6)
+    model = ALIGNNAtomWise(ALIGNNAtomWiseConfig(name="alignn_atomwise", alignn_layers=2, gcn_layers=1, hidden_features=64,
+                                                atom_input_features=92, calculate_gradient=False)).to(DEV).eval()
+
+    def mk():
+        g = dgl.graph((torch.from_numpy(raw.u), torch.from_numpy(raw.v)), num_nodes=raw.num_nodes)
+        g._bnn = torch.from_numpy(raw.batch_num_nodes)
+        g.ndata["atom_features"] = torch.from_numpy(raw.atom_features)
+        g.edata["r"] = torch.from_numpy(raw.r)
+        return g
+
+    lg = dgl.graph((torch.from_numpy(raw.lg_u), torch.from_numpy(raw.lg_v)), num_nodes=raw.num_edges)
+    lg.edata["h"] = torch.from_numpy(raw.h)
+    lat = torch.from_numpy(raw.lattice)
+    with torch.no_grad():
+        a = model((mk(), lg, lat))["out"]
+        b = model((mk(), lat))["out"]
+    assert rel_err(b, a) < 1e-5

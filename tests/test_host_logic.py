@@ -68,3 +68,20 @@ def test_build_csr_with_isolated_nodes_and_custom_segment_order():
     assert c.seg_ptr.tolist() == [0, 0, 3, 4, 5]
     assert c.dst.tolist() == [1, 1, 1, 0, 2] and c.src.tolist() == [0, 0, 2, 2, 2]
     assert c.out_ptr.tolist() == [0, 2, 2, 5, 5]
+
+
+def test_device_line_graph_equals_callers_line_graph():
+    """line_graph_of(g) (built from g's CSR alone) == canonicalisation of the caller's explicit L(g)."""
+    from alignn_amd.graph import line_graph_of
+
+    raw = batch_raw([_one(n, 120 + i, "crystal", 92) for i, n in enumerate((1, 4, 8))])
+    b = GraphBatch.from_raw(raw)
+    lg2 = line_graph_of(b.g)
+    lg = b.lg
+    assert lg2.n_nodes == lg.n_nodes and lg2.n_edges == lg.n_edges
+    for f in ("seg_ptr", "seg_node", "out_ptr", "grp_seg_ptr", "grp_src_ptr"):
+        assert torch.equal(getattr(lg2, f), getattr(lg, f)), f
+    # same edge multiset per segment (order inside a segment follows the caller in one case, slot order in the other)
+    key = lambda c: torch.sort(c.dst.long() * c.n_nodes + c.src.long()).values  # noqa: E731
+    assert torch.equal(key(lg2), key(lg))
+    assert (b.g.dst[lg2.src.long()] == b.g.src[lg2.dst.long()]).all() and (lg2.src != lg2.dst).all()
