@@ -445,3 +445,35 @@ def test_atomwise_g_lat_input_builds_line_graph_on_device():
         a = model((mk(), lg, lat))["out"]
         b = model((mk(), lat))["out"]
     assert rel_err(b, a) < 1e-5
+
+
+def test_default_config_depth_vs_oracle_on_x6_path():
+    """Default ALIGNNConfig (4+4 layers, hidden 256) on 16 x 60-atom crystals: large enough that every wide
+    projection runs on the bf16x6 kernels and the line-graph kernels see real segment lengths.  Prediction,
+    every parameter gradient and the BatchNorm running statistics vs the CPU oracle (north_star bar 1e-4)."""
+    B = 16
+    raw = make_batch(B, 60, seed0=2024)
+    model = ALIGNN(ALIGNNConfig(name="alignn"))
+    model.load_state_dict(O.init_state_dict(seed=3))
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model = model.to(DEV).train()
+    target = torch.randn(B, generator=torch.Generator().manual_seed(5))
+    pred = model(GraphBatch.from_raw(raw, device=DEV))
+    torch.nn.functional.l1_loss(pred, target.to(DEV)).backward()
+    p = O.as_params(sd)
+    stats = {}
+    opred = O.alignn_forward(p, O.TorchGraph(raw), 4, 4, True, stats)
+    torch.nn.functional.l1_loss(opred, target).backward()
+    assert rel_err(pred, opred) < 1e-4
+    gfloor = 1e-2 * max(float(t.grad.abs().max()) for t in p.values() if t.grad is not None)
+    worst = 0.0
+    for k, q in model.named_parameters():
+        if p[k].grad is not None:
+            e = rel_err(q.grad, p[k].grad, floor=gfloor)
+            worst = max(worst, e)
+            assert e < 1e-3, (k, e)
+    after = O.running_stats_after_step(p, stats)
+    sdn = model.state_dict()
+    for k, v in after.items():
+        assert rel_err(sdn[k], v, floor=1e-3) < 1e-4, k
+    print(f"depth test: pred rel err {rel_err(pred, opred):.2e}, worst grad err {worst:.2e}")
