@@ -421,7 +421,7 @@ __global__ __launch_bounds__(TNT) void gemm_tn_x6_kernel(TnArgs g) {
 
 inline int64_t tn_chunk(int64_t M, int N, int K) {
     const int64_t tiles = (int64_t)(N / TBN) * (K / TBK);
-    int64_t want = (512 + tiles - 1) / tiles;  // ~2 workgroups per CU
+    int64_t want = (256 + tiles - 1) / tiles;  // one workgroup per CU (8 waves fill it); fewer slabs to sum
     if (want < 1) want = 1;
     int64_t chunk = (M + want - 1) / want;
     chunk = ((chunk + TSTEP - 1) / TSTEP) * TSTEP;
