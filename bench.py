@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--atoms", type=int, default=60)
+    ap.add_argument("--kind", default="crystal", choices=["crystal", "molecule"],
+                    help="molecule = BASELINE configs[4] shape (QM9-like, 9-27 atoms, no periodic images); not the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-graphs", type=int, default=8, help="graphs in the CPU-baseline sample")
     return ap.parse_args()
@@ -146,7 +148,8 @@ def main():
     from alignn_amd.synthetic import make_batch
 
     B = args.batch
-    raw = make_batch(B, args.atoms, seed0=1234 + rank * B)  # every rank its own crystals
+    n_atoms = (9, 27) if args.kind == "molecule" else args.atoms
+    raw = make_batch(B, n_atoms, seed0=1234 + rank * B, kind=args.kind)  # every rank its own crystals
     batch = GraphBatch.from_raw(raw, device=dev)  # staged + canonicalised once: inputs resident in HBM
     torch.manual_seed(0)
     model = ALIGNN(ALIGNNConfig(name="alignn")).to(dev).train()

@@ -477,3 +477,35 @@ def test_default_config_depth_vs_oracle_on_x6_path():
     for k, v in after.items():
         assert rel_err(sdn[k], v, floor=1e-3) < 1e-4, k
     print(f"depth test: pred rel err {rel_err(pred, opred):.2e}, worst grad err {worst:.2e}")
+
+
+def test_training_step_is_hipgraph_capturable():
+    """The C-ABI kernels never allocate or synchronise and launch on the current stream only, so a whole
+    training step (fwd + loss + bwd incl. the side stream + fused AdamW) captures into one hipGraph; replays must
+    reproduce the eager loss trajectory bit for bit."""
+    from alignn_amd.graphed import GraphedTrainStep
+
+    raw = make_batch(4, 20, seed0=3)
+    batch = GraphBatch.from_raw(raw, device=DEV)
+    target = torch.tensor([0.2, -0.1, 0.7, 0.0], device=DEV)
+
+    def fresh():
+        torch.manual_seed(0)
+        m = ALIGNN(ALIGNNConfig(name="alignn", alignn_layers=2, gcn_layers=2, hidden_features=64)).to(DEV).train()
+        return m, torch.optim.AdamW(m.parameters(), lr=1e-3, fused=True, capturable=True)
+
+    m, o = fresh()
+    eager = []
+    for _ in range(6):  # 3 warm-up steps inside GraphedTrainStep + 3 replays
+        o.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.l1_loss(m(batch), target)
+        loss.backward()
+        o.step()
+        eager.append(loss.detach().clone())
+    m2, o2 = fresh()
+    step = GraphedTrainStep(m2, batch, target, o2, warmup=3)
+    graphed = [step().detach().clone() for _ in range(3)]
+    for a, b in zip(eager[3:], graphed):
+        assert torch.equal(a, b)
+    for (k, p), (_, q) in zip(m.named_parameters(), m2.named_parameters()):
+        assert torch.equal(p, q), k
