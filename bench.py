@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--atoms", type=int, default=60)
+    ap.add_argument("--model", default="alignn", choices=["alignn", "alignn_atomwise"],
+                    help="alignn = the headline BatchNorm model; alignn_atomwise = LayerNorm flavour, energy path (informational)")
     ap.add_argument("--kind", default="crystal", choices=["crystal", "molecule"],
                     help="molecule = BASELINE configs[4] shape (QM9-like, 9-27 atoms, no periodic images); not the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -152,7 +154,16 @@ def main():
     raw = make_batch(B, n_atoms, seed0=1234 + rank * B, kind=args.kind)  # every rank its own crystals
     batch = GraphBatch.from_raw(raw, device=dev)  # staged + canonicalised once: inputs resident in HBM
     torch.manual_seed(0)
-    model = ALIGNN(ALIGNNConfig(name="alignn")).to(dev).train()
+    if args.model == "alignn":
+        model = ALIGNN(ALIGNNConfig(name="alignn")).to(dev).train()
+        predict = lambda b: model(b)  # noqa: E731
+    else:
+        from alignn_amd import ALIGNNAtomWise, ALIGNNAtomWiseConfig
+
+        model = ALIGNNAtomWise(ALIGNNAtomWiseConfig(name="alignn_atomwise", alignn_layers=4, gcn_layers=4,
+                                                    hidden_features=256, atom_input_features=92,
+                                                    calculate_gradient=False)).to(dev).train()
+        predict = lambda b: model(b)["out"]  # noqa: E731
     broadcast_parameters(model)
     target = torch.randn(B, generator=torch.Generator().manual_seed(1 + rank)).to(dev)
     sync = FlatGradSync(model.parameters())
@@ -160,7 +171,7 @@ def main():
 
     def step():
         sync.zero_grad()
-        loss = torch.nn.functional.l1_loss(model(batch), target)
+        loss = torch.nn.functional.l1_loss(predict(batch), target)
         loss.backward()
         sync.sync()
         opt.step()
@@ -228,7 +239,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"BASELINE configs[1]: default ALIGNNConfig 4+4 layers hidden 256, batch {B}/GPU, "
-                f"{args.atoms}-atom periodic crystals kNN-12/8A, fwd+bwd+allreduce+AdamW",
+                f"{args.atoms}-atom periodic crystals kNN-12/8A, fwd+bwd+allreduce+AdamW"
+                + ("" if (args.model == "alignn" and args.kind == "crystal") else f" [NON-HEADLINE: {args.model}, {args.kind}]"),
                 "global_batch": world * B,
                 "nodes": N,
                 "edges": E,
