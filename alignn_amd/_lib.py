@@ -22,7 +22,7 @@ SIGNATURES = {
     "alignn_gemm_nt": (_i32, [_p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _i64, _i32, _i32, _p]),
     "alignn_gemm_nn": (_i32, [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i32, _i32, _p]),
     "alignn_gemm_tn_workspace": (_sz, [_i64, _i32, _i32]),
-    "alignn_gemm_tn": (_i32, [_p, _i64, _p, _i64, _p, _i64, _i64, _i32, _i32, _p, _sz, _p]),
+    "alignn_gemm_tn": (_i32, [_p, _i64, _p, _p, _i64, _p, _p, _i64, _i64, _i32, _i32, _p, _sz, _p]),
     "alignn_split_bf16x3_bytes": (_sz, [_i32, _i32]),
     "alignn_split_bf16x3": (_i32, [_p, _i64, _i32, _i32, _i32, _p, _p]),
     "alignn_gemm_nt_x6_supported": (_i32, [_i64, _i32, _i32]),
@@ -30,7 +30,11 @@ SIGNATURES = {
     "alignn_gemm_tn_x6_supported": (_i32, [_i64, _i32, _i32]),
     "alignn_gemm_tn_x6_workspace": (_sz, [_i64, _i32, _i32]),
     "alignn_gemm_tn_x6_splits": (_i32, [_i64, _i32, _i32]),
-    "alignn_gemm_tn_x6_partials": (_i32, [_p, _i64, _p, _i64, _i64, _i32, _i32, _p, _sz, _p]),
+    "alignn_gemm_tn_x6_partials": (_i32, [_p, _i64, _p, _p, _i64, _p, _i64, _i32, _i32, _p, _sz, _p]),
+    "alignn_absmax": (_i32, [_p, _i64, _i64, _i32, _p, _p]),
+    "alignn_split_f16x2_bytes": (_sz, [_i32, _i32]),
+    "alignn_split_f16x2": (_i32, [_p, _i64, _i32, _i32, _i32, _p, _p, _p]),
+    "alignn_gemm_nt_f16x3": (_i32, [_p, _i64, _p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _i32, _i32, _p]),
     "alignn_col_stats_slabs": (_i32, [_i64]),
     "alignn_col_stats": (_i32, [_p, _i64, _i64, _i32, _p, _p]),
     "alignn_col_sum": (_i32, [_p, _i64, _i64, _i32, _p, _p, _p]),

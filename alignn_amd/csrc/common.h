@@ -25,6 +25,7 @@ __device__ __forceinline__ float4 f4_add(float4 a, float4 b) {
 __device__ __forceinline__ float4 f4_sub(float4 a, float4 b) {
     return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
 }
+__device__ __forceinline__ float4 f4_scale(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
 __device__ __forceinline__ float4 f4_mul(float4 a, float4 b) {
     return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
 }
@@ -41,3 +42,23 @@ __device__ __forceinline__ float dsilu_f(float z) {
     float s = fast_sigmoid(z);
     return s * (1.0f + z * (1.0f - s));
 }
+
+// Running max|x| of a tensor, tracked by the kernel that produces it (consumed by the f16x3 GEMMs to pick their
+// power-of-two operand scale).  Wave max by DPP-free shuffles, then ONE atomicMax per workgroup on the bit pattern:
+// non-negative floats order like unsigned ints and max is order independent, so the result is deterministic.
+// Every thread of the workgroup must call it (it contains a barrier); `amax` may be null.
+__device__ __forceinline__ void block_amax_commit(float m, float* amax) {
+    if (amax == nullptr) return;  // uniform
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    __shared__ float amax_sh[16];
+    const int wave = threadIdx.x >> 6, nw = (blockDim.x * blockDim.y + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) amax_sh[wave] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float r = amax_sh[0];
+        for (int w = 1; w < nw; ++w) r = fmaxf(r, amax_sh[w]);
+        if (r > 0.0f) atomicMax(reinterpret_cast<unsigned*>(amax), __float_as_uint(r));
+    }
+}
+__device__ __forceinline__ float f4_absmax(float4 v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }

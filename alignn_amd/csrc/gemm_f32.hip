@@ -397,9 +397,6 @@ int alignn_gemm_nn(const float* G, int64_t ldg, const float* W, int64_t ldw, con
 int alignn_gemm_tn_x6_supported(int64_t M, int N, int K);
 size_t alignn_gemm_tn_x6_workspace(int64_t M, int N, int K);
 int alignn_gemm_tn_x6_splits(int64_t M, int N, int K);
-int alignn_gemm_tn_x6_partials(const float* G, int64_t ldg, const float* X, int64_t ldx, int64_t M, int N, int K,
-                               void* workspace, size_t workspace_bytes, alignn_stream_t stream);
-
 static bool tn_use_x6(const float* G, int64_t ldg, const float* A, int64_t lda, int64_t M, int N, int K) {
     return alignn_gemm_tn_x6_supported(M, N, K) && (ldg % 4 == 0) && (lda % 4 == 0) && aligned16(G) && aligned16(A);
 }
@@ -413,8 +410,9 @@ size_t alignn_gemm_tn_workspace(int64_t M, int N, int K) {
     return f32;
 }
 
-int alignn_gemm_tn(const float* G, int64_t ldg, const float* A, int64_t lda, float* dW, int64_t lddw, int64_t M, int N,
-                   int K, void* workspace, size_t workspace_bytes, alignn_stream_t stream) {
+int alignn_gemm_tn(const float* G, int64_t ldg, const float* g_amax, const float* A, int64_t lda, const float* a_amax,
+                   float* dW, int64_t lddw, int64_t M, int N, int K, void* workspace, size_t workspace_bytes,
+                   alignn_stream_t stream) {
     if (M < 0 || N <= 0 || K <= 0) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
     // dW[n,k] = sum_m G[m,n] A[m,k]: both operands index-contiguous, reduction over rows m
@@ -423,7 +421,9 @@ int alignn_gemm_tn(const float* G, int64_t ldg, const float* A, int64_t lda, flo
     if (workspace_bytes < alignn_gemm_tn_workspace(M, N, K) || workspace == nullptr) return (int)hipErrorInvalidValue;
     float* ws = (float*)workspace;
     if (tn_use_x6(G, ldg, A, lda, M, N, K)) {
-        int rc6 = alignn_gemm_tn_x6_partials(G, ldg, A, lda, M, N, K, workspace, workspace_bytes, stream);
+        const bool f16 = g_amax != nullptr && a_amax != nullptr;  // both maxima known: three fp16-slice products
+        int rc6 = alignn_gemm_tn_x6_partials(G, ldg, f16 ? g_amax : nullptr, A, lda, f16 ? a_amax : nullptr, M, N, K,
+                                             workspace, workspace_bytes, stream);
         if (rc6) return rc6;
         const int64_t count6 = (int64_t)N * K;
         hipLaunchKernelGGL(slab_reduce_kernel, dim3(alignn_ceil_div(count6, 32)), dim3(32, 32), 0, st, ws,

@@ -38,6 +38,8 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 #ifndef X6_RM
 #define X6_RM 2
@@ -52,17 +54,23 @@ constexpr int TM = BM / WM, TN = BN / WN;  // (32*RM) x 128 per wave
 constexpr int RN = TN / 32;                // RM x 4 MFMA tiles
 constexpr int A_BYTES = BM * BK * 4;       // 8 KiB fp32 (64-byte rows), XOR-swizzled 16-byte chunks, no padding
 constexpr int B_PLANE = BN * BK * 2;       // 8 KiB per bf16 slice plane (32-byte rows)
-constexpr int STAGE_BYTES = A_BYTES + 3 * B_PLANE;  // 32 KiB
-constexpr int A_DMA = A_BYTES / 1024 / (NT / 64);       // 1 x 1 KiB DMA piece per wave
-constexpr int B_DMA = 3 * B_PLANE / 1024 / (NT / 64);   // 3
-constexpr int B_PIECES = B_PLANE / 1024;                // 8 pieces per plane
-constexpr int EPI_BYTES = (NT / 64) * 32 * (64 + 4) * 4; // per-wave [32][68] fp32 transpose patches (68 KiB)
-constexpr int LDS_BYTES = 2 * STAGE_BYTES > EPI_BYTES ? 2 * STAGE_BYTES : EPI_BYTES;  // 68 KiB -> 2 workgroups/CU
+constexpr int A_DMA = A_BYTES / 1024 / (NT / 64);       // 1 KiB DMA pieces per wave
+constexpr int EPI_BYTES = (NT / 64) * 32 * (64 + 4) * 4; // per-wave [32][68] fp32 transpose patches
+// per scheme: slice planes of the weight image (3 bf16 / 2 fp16), stage and LDS footprint
+template <bool F16>
+struct Sch {
+    static constexpr int NPL = F16 ? 2 : 3;
+    static constexpr int STAGE = A_BYTES + NPL * B_PLANE;            // 32 KiB / 24 KiB
+    static constexpr int B_DMA = NPL * B_PLANE / 1024 / (NT / 64);   // pieces per wave
+    static constexpr int LDS = 2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES;  // two workgroups per CU
+};
 
 struct X6Args {
     const float* A;
     int64_t lda;
-    const unsigned char* Ws;  // [K/16][Npad/256][3 planes][256 rows][2 chunks, swizzled][8 bf16]: 24 KiB per (kb, n-tile)
+    const unsigned char* Ws;  // [K/16][Npad/256][planes][256 rows][2 chunks, swizzled][8 x 16 bit]: 8 KiB per plane
+    const float* a_amax;      // f16x3 only: device scalars max|A| (or an upper bound) and max|W|
+    const float* w_amax;
     const float* bias;
     const float* addend;
     int64_t ldadd;
@@ -107,6 +115,28 @@ __device__ __forceinline__ void slice8(const float4& lo, const float4& hi4, bf16
     l = __builtin_bit_cast(bf16x8, lp);
 }
 
+// power-of-two scale that puts a tensor with the given max|x| just below 2^15 (fp16 max is 65504); 1 for an
+// all-zero / denormal / non-finite tensor (nothing to protect; inf and nan propagate through the fp16 slices)
+__device__ __forceinline__ float f16_scale(float amax) {
+    const int e = (int)((__float_as_uint(amax) >> 23) & 255u);  // amax < 2^(e-126)
+    if (e == 0 || e == 255) return 1.0f;
+    int se = 268 - e;                                           // 2^(141-e)
+    se = se > 254 ? 254 : se;
+    return __uint_as_float((unsigned)se << 23);
+}
+
+// slice 8 consecutive-k floats (scaled by s) into the two fp16x8 MFMA operands
+__device__ __forceinline__ void slice8_f16(const float4& lo, const float4& hi4, float s, f16x8& h, f16x8& l) {
+    const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi4.x, hi4.y, hi4.z, hi4.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float xs = x[j] * s;
+        const _Float16 hj = (_Float16)xs;       // round to nearest even
+        h[j] = hj;
+        l[j] = (_Float16)(xs - (float)hj);      // the subtraction is exact
+    }
+}
+
 #ifndef X6_A_AUX
 #define X6_A_AUX 0  // default cache policy (nt on the read-once activation tile measured 10 % slower)
 #endif
@@ -117,8 +147,9 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned char* lds_wave_
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, AUX);
 }
 
-template <bool HAS_ADD>
+template <bool HAS_ADD, bool F16>
 __global__ __launch_bounds__(NT) void gemm_nt_x6_kernel(X6Args g) {
+    constexpr int NPL = Sch<F16>::NPL, STAGE_BYTES = Sch<F16>::STAGE, B_DMA = Sch<F16>::B_DMA;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -148,15 +179,15 @@ __global__ __launch_bounds__(NT) void gemm_nt_x6_kernel(X6Args g) {
         if (grow >= g.M) grow = g.M - 1;  // clamp: rows past the end are computed but never stored
         a_src[i] = g.A + grow * g.lda + c * 4;
     }
-    // B: the three slice planes of one (k-block, n-tile) are ONE contiguous 24 KiB run in global memory, in
-    // exactly the LDS image order (pre-swizzled), so a stage is 24 sequential 1 KiB pieces and consecutive
-    // k-blocks walk the 384 KiB weight image linearly (no power-of-two plane strides in the L2).
-    const int64_t kb_stride = (int64_t)(g.Npad / BN) * (3 * B_PLANE);
+    // B: the slice planes of one (k-block, n-tile) are ONE contiguous 24 (16) KiB run in global memory, in
+    // exactly the LDS image order (pre-swizzled), so a stage is sequential 1 KiB pieces and consecutive
+    // k-blocks walk the weight image linearly (no power-of-two plane strides in the L2).
+    const int64_t kb_stride = (int64_t)(g.Npad / BN) * (NPL * B_PLANE);
     const unsigned char* b_src[B_DMA];
 #pragma unroll
     for (int i = 0; i < B_DMA; ++i) {
         const int q = wave * B_DMA + i;  // 1 KiB piece q of the 24 KiB stage image
-        b_src[i] = g.Ws + (int64_t)blockIdx.y * (3 * B_PLANE) + q * 1024 + lane * 16;
+        b_src[i] = g.Ws + (int64_t)blockIdx.y * (NPL * B_PLANE) + q * 1024 + lane * 16;
     }
     auto issue = [&](int kt, unsigned char* stage) {
 #if X6_ABL_NOALOAD
@@ -199,6 +230,14 @@ __global__ __launch_bounds__(NT) void gemm_nt_x6_kernel(X6Args g) {
         bias_v[hb] = (g.bias && col < g.N) ? f4_ld(g.bias + col) : f4_zero();
     }
 
+    // f16x3: power-of-two operand scales (device scalars written by the producers), undone in the epilogue
+    float sa = 1.0f, inv_sa = 1.0f, inv_sw = 1.0f;
+    if constexpr (F16) {
+        sa = f16_scale(*g.a_amax);
+        inv_sa = 1.0f / sa;
+        inv_sw = 1.0f / f16_scale(*g.w_amax);
+    }
+
     const int nk = g.K / BK;
     issue(0, smem);
     __syncthreads();
@@ -206,32 +245,53 @@ __global__ __launch_bounds__(NT) void gemm_nt_x6_kernel(X6Args g) {
         const int cur = kt & 1;
         if (kt + 1 < nk) issue(kt + 1, smem + (cur ^ 1) * STAGE_BYTES);
         const unsigned char* stage = smem + cur * STAGE_BYTES;
-        bf16x8 ah[RM], am[RM], al[RM], bh[RN], bm[RN], bl[RN];
+        if constexpr (F16) {
+            f16x8 ah[RM], al[RM], bh[RN], bl[RN];
 #pragma unroll
-        for (int a = 0; a < RM; ++a)
-            slice8(*reinterpret_cast<const float4*>(stage + a_off0[a]),
-                   *reinterpret_cast<const float4*>(stage + a_off1[a]), ah[a], am[a], al[a]);
+            for (int a = 0; a < RM; ++a)
+                slice8_f16(*reinterpret_cast<const float4*>(stage + a_off0[a]),
+                           *reinterpret_cast<const float4*>(stage + a_off1[a]), sa, ah[a], al[a]);
 #pragma unroll
-        for (int b = 0; b < RN; ++b) {
-            const unsigned char* q = stage + b_off[b];
-            bh[b] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(q));
-            bm[b] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(q + B_PLANE));
-            bl[b] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(q + 2 * B_PLANE));
-        }
-        // six slice products, smallest first; each pass walks the independent accumulators so no MFMA waits
-        // on the one issued right before it
+            for (int b = 0; b < RN; ++b) {
+                const unsigned char* q = stage + b_off[b];
+                bh[b] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(q));
+                bl[b] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(q + B_PLANE));
+            }
+#define X6_PASS(AA, BB)                                                                              \
+    _Pragma("unroll") for (int a = 0; a < RM; ++a) _Pragma("unroll") for (int b = 0; b < RN; ++b)    \
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AA[a], BB[b], acc[a][b], 0, 0, 0);
+            X6_PASS(al, bh)
+            X6_PASS(ah, bl)
+            X6_PASS(ah, bh)
+#undef X6_PASS
+        } else {
+            bf16x8 ah[RM], am[RM], al[RM], bh[RN], bm[RN], bl[RN];
+#pragma unroll
+            for (int a = 0; a < RM; ++a)
+                slice8(*reinterpret_cast<const float4*>(stage + a_off0[a]),
+                       *reinterpret_cast<const float4*>(stage + a_off1[a]), ah[a], am[a], al[a]);
+#pragma unroll
+            for (int b = 0; b < RN; ++b) {
+                const unsigned char* q = stage + b_off[b];
+                bh[b] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(q));
+                bm[b] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(q + B_PLANE));
+                bl[b] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(q + 2 * B_PLANE));
+            }
+            // six slice products, smallest first; each pass walks the independent accumulators so no MFMA waits
+            // on the one issued right before it
 #define X6_PASS(AA, BB)                                                                              \
     _Pragma("unroll") for (int a = 0; a < RM; ++a) _Pragma("unroll") for (int b = 0; b < RN; ++b)    \
         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AA[a], BB[b], acc[a][b], 0, 0, 0);
 #if !X6_ABL_ONEMFMA
-        X6_PASS(al, bh)
-        X6_PASS(ah, bl)
-        X6_PASS(am, bm)
-        X6_PASS(am, bh)
-        X6_PASS(ah, bm)
+            X6_PASS(al, bh)
+            X6_PASS(ah, bl)
+            X6_PASS(am, bm)
+            X6_PASS(am, bh)
+            X6_PASS(ah, bm)
 #endif
-        X6_PASS(ah, bh)
+            X6_PASS(ah, bh)
 #undef X6_PASS
+        }
         __syncthreads();  // next stage has landed (the barrier drains the DMA), current one is free
     }
 
@@ -267,7 +327,9 @@ __global__ __launch_bounds__(NT) void gemm_nt_x6_kernel(X6Args g) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int64_t row = row0 + i * 4;
-            float4 v = f4_add(ov[i], bias_v[hb]);
+            float4 v = ov[i];
+            if constexpr (F16) v = f4_scale(f4_scale(v, inv_sa), inv_sw);
+            v = f4_add(v, bias_v[hb]);
             if (HAS_ADD) v = f4_add(v, av[i]);
             if (row < g.M && col < g.N) f4_st(g.C + row * g.ldc + col, v);
         }
@@ -305,8 +367,11 @@ struct TnArgs {
     int N, K;
     int64_t chunk;  // reduction rows per slab (multiple of 16)
     int tiles_n, tiles_k, splits;
+    const float* g_amax;  // f16x3 only: device scalars max|G|, max|X|
+    const float* x_amax;
 };
 
+template <bool F16>
 __global__ __launch_bounds__(TNT) void gemm_tn_x6_kernel(TnArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x;
@@ -353,6 +418,12 @@ __global__ __launch_bounds__(TNT) void gemm_tn_x6_kernel(TnArgs g) {
         }
     };
 
+    float sg = 1.0f, sx = 1.0f;
+    if constexpr (F16) {
+        sg = f16_scale(*g.g_amax);
+        sx = f16_scale(*g.x_amax);
+    }
+
     if (nst > 0) issue(0, smem);
     __syncthreads();
     for (int st = 0; st < nst; ++st) {
@@ -362,35 +433,64 @@ __global__ __launch_bounds__(TNT) void gemm_tn_x6_kernel(TnArgs g) {
         const float* Xs = reinterpret_cast<const float*>(smem + cur * TSTAGE + G_BYTES);
         // rows of this stage that lie past the end of the slab (only in its last stage) contribute nothing
         const int valid = (int)((rend - (rbeg + (int64_t)st * TSTEP)) < TSTEP ? (rend - (rbeg + (int64_t)st * TSTEP)) : TSTEP);
-        bf16x8 ah[TRM], am[TRM], al[TRM], bh[TRN], bm[TRN], bl[TRN];
+        if constexpr (F16) {
+            f16x8 ah[TRM], al[TRM], bh[TRN], bl[TRN];
 #pragma unroll
-        for (int a = 0; a < TRM; ++a) {
-            float x[8];
+            for (int a = 0; a < TRM; ++a) {
+                float x[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int m = 8 * half + j;
-                const float v = Gs[m * TBN + wm * 64 + a * 32 + il];
-                x[j] = m < valid ? v : 0.0f;
+                for (int j = 0; j < 8; ++j) {
+                    const int m = 8 * half + j;
+                    const float v = Gs[m * TBN + wm * 64 + a * 32 + il];
+                    x[j] = m < valid ? v : 0.0f;
+                }
+                slice8_f16(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]), sg, ah[a], al[a]);
             }
-            slice8(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]), ah[a], am[a], al[a]);
-        }
 #pragma unroll
-        for (int b = 0; b < TRN; ++b) {
-            float x[8];
+            for (int b = 0; b < TRN; ++b) {
+                float x[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) x[j] = Xs[(8 * half + j) * TBK + wn * 128 + b * 32 + il];
-            slice8(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]), bh[b], bm[b], bl[b]);
-        }
+                for (int j = 0; j < 8; ++j) x[j] = Xs[(8 * half + j) * TBK + wn * 128 + b * 32 + il];
+                slice8_f16(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]), sx, bh[b], bl[b]);
+            }
+#define X6_TPASS(AA, BB)                                                                               \
+    _Pragma("unroll") for (int a = 0; a < TRM; ++a) _Pragma("unroll") for (int b = 0; b < TRN; ++b)    \
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AA[a], BB[b], acc[a][b], 0, 0, 0);
+            X6_TPASS(al, bh)
+            X6_TPASS(ah, bl)
+            X6_TPASS(ah, bh)
+#undef X6_TPASS
+        } else {
+            bf16x8 ah[TRM], am[TRM], al[TRM], bh[TRN], bm[TRN], bl[TRN];
+#pragma unroll
+            for (int a = 0; a < TRM; ++a) {
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int m = 8 * half + j;
+                    const float v = Gs[m * TBN + wm * 64 + a * 32 + il];
+                    x[j] = m < valid ? v : 0.0f;
+                }
+                slice8(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]), ah[a], am[a], al[a]);
+            }
+#pragma unroll
+            for (int b = 0; b < TRN; ++b) {
+                float x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = Xs[(8 * half + j) * TBK + wn * 128 + b * 32 + il];
+                slice8(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]), bh[b], bm[b], bl[b]);
+            }
 #define X6_TPASS(AA, BB)                                                                               \
     _Pragma("unroll") for (int a = 0; a < TRM; ++a) _Pragma("unroll") for (int b = 0; b < TRN; ++b)    \
         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AA[a], BB[b], acc[a][b], 0, 0, 0);
-        X6_TPASS(al, bh)
-        X6_TPASS(ah, bl)
-        X6_TPASS(am, bm)
-        X6_TPASS(am, bh)
-        X6_TPASS(ah, bm)
-        X6_TPASS(ah, bh)
+            X6_TPASS(al, bh)
+            X6_TPASS(ah, bl)
+            X6_TPASS(am, bm)
+            X6_TPASS(am, bh)
+            X6_TPASS(ah, bm)
+            X6_TPASS(ah, bh)
 #undef X6_TPASS
+        }
         __syncthreads();
     }
 
@@ -415,7 +515,11 @@ __global__ __launch_bounds__(TNT) void gemm_tn_x6_kernel(TnArgs g) {
         const int col = k0 + wn * 128 + hb * 64 + pc4;
         const int row0 = n0 + wm * 64 + a * 32 + prow;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) f4_st(out + (int64_t)(row0 + i * 4) * g.K + col, ov[i]);
+        for (int i = 0; i < 8; ++i) {
+            float4 v = ov[i];
+            if constexpr (F16) v = f4_scale(f4_scale(v, 1.0f / sg), 1.0f / sx);
+            f4_st(out + (int64_t)(row0 + i * 4) * g.K + col, v);
+        }
     }
 }
 
@@ -456,9 +560,75 @@ __global__ void split_bf16x3_kernel(const float* __restrict__ W, int64_t ldw, in
     }
 }
 
+// fp16 two-slice image of W * 2^s (s from max|W|): same index map, two planes
+__global__ void split_f16x2_kernel(const float* __restrict__ W, int64_t ldw, int N, int Npad, int K, int transpose,
+                                   const float* __restrict__ w_amax, _Float16* __restrict__ out) {
+    const int64_t total = (int64_t)Npad * K;
+    const int ntiles = Npad / BN;
+    const float sw = f16_scale(*w_amax);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i / K), k = (int)(i % K);
+        float x = 0.0f;
+        if (n < N) x = transpose ? W[(int64_t)k * ldw + n] : W[(int64_t)n * ldw + k];
+        x *= sw;
+        const _Float16 h = (_Float16)x;
+        const _Float16 l = (_Float16)(x - (float)h);
+        const int kb = k / BK, c = (k % BK) >> 3, e = k & 7;
+        const int nt = n / BN, nin = n % BN;
+        constexpr int plane = BN * BK;
+        const int64_t o = ((int64_t)kb * ntiles + nt) * (2 * plane) + nin * BK + ((c ^ ((n >> 3) & 1)) << 3) + e;
+        out[o] = h;
+        out[o + plane] = l;
+    }
+}
+
+// max|X| of a row-major [rows, F] matrix (F % 4 == 0): one atomicMax per workgroup on the bit pattern
+// (non-negative floats order like unsigned ints; max is order independent, so this is deterministic)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ X, int64_t ldx, int64_t rows, int F,
+                                                      float* __restrict__ amax) {
+    const int Q = F >> 2;
+    const int64_t total = rows * Q;
+    float m = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / Q;
+        const int q = (int)(i - r * Q);
+        const float4 v = f4_ld(X + r * ldx + q * 4);
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    block_amax_commit(m, amax);
+}
+
 inline bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 inline int npad(int N) { return ((N + BN - 1) / BN) * BN; }
 
+}  // namespace
+
+namespace {
+template <bool F16>
+int launch_nt(const X6Args& g, hipStream_t st) {
+    constexpr int lds = Sch<F16>::LDS;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_x6_kernel<false, F16>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)gemm_nt_x6_kernel<true, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    dim3 grid(alignn_ceil_div(g.M, BM), g.Npad / BN);
+    if (g.addend)
+        hipLaunchKernelGGL((gemm_nt_x6_kernel<true, F16>), grid, dim3(NT), lds, st, g);
+    else
+        hipLaunchKernelGGL((gemm_nt_x6_kernel<false, F16>), grid, dim3(NT), lds, st, g);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+inline bool nt_args_ok(const float* A, int64_t lda, const void* Wsplit, const float* bias, const float* addend,
+                       int64_t ldadd, float* C, int64_t ldc) {
+    return !((lda & 3) || (ldc & 3) || !a16(A) || !a16(C) || !a16(Wsplit) || (bias && !a16(bias)) ||
+             (addend && ((ldadd & 3) || !a16(addend))));
+}
 }  // namespace
 
 extern "C" {
@@ -476,6 +646,33 @@ int alignn_split_bf16x3(const float* W, int64_t ldw, int N, int K, int transpose
     return 0;
 }
 
+size_t alignn_split_f16x2_bytes(int N, int K) { return (size_t)2 * npad(N) * (size_t)K * 2; }
+
+int alignn_split_f16x2(const float* W, int64_t ldw, int N, int K, int transpose, const float* w_amax, void* out,
+                       alignn_stream_t stream) {
+    if (N <= 0 || K <= 0 || (K % BK) != 0 || out == nullptr || w_amax == nullptr) return (int)hipErrorInvalidValue;
+    const int64_t total = (int64_t)npad(N) * K;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(split_f16x2_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, W, ldw, N, npad(N), K,
+                       transpose, w_amax, (_Float16*)out);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_absmax(const float* X, int64_t ldx, int64_t rows, int F, float* amax, alignn_stream_t stream) {
+    if (F <= 0 || (F & 3) || (ldx & 3) || rows < 0 || amax == nullptr || !a16(X)) return (int)hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(amax, 0, sizeof(float), (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    if (rows == 0) return 0;
+    int64_t blocks = (rows * (F >> 2) + 256 * 8 - 1) / (256 * 8);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(absmax_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, X, ldx, rows, F, amax);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
 int alignn_gemm_tn_x6_supported(int64_t M, int N, int K) {
     return (M >= 4096 && N % tn::TBN == 0 && K % tn::TBK == 0) ? 1 : 0;
 }
@@ -487,24 +684,32 @@ size_t alignn_gemm_tn_x6_workspace(int64_t M, int N, int K) {
 int alignn_gemm_tn_x6_splits(int64_t M, int N, int K) { return tn::tn_splits(M, N, K); }
 
 /* slab partials only: ws[z][N][K] for z < alignn_gemm_tn_x6_splits(); the caller sums the slabs */
-int alignn_gemm_tn_x6_partials(const float* G, int64_t ldg, const float* X, int64_t ldx, int64_t M, int N, int K,
-                               void* workspace, size_t workspace_bytes, alignn_stream_t stream) {
+int alignn_gemm_tn_x6_partials(const float* G, int64_t ldg, const float* g_amax, const float* X, int64_t ldx,
+                               const float* x_amax, int64_t M, int N, int K, void* workspace, size_t workspace_bytes,
+                               alignn_stream_t stream) {
     if (!alignn_gemm_tn_x6_supported(M, N, K)) return (int)hipErrorInvalidValue;
     if ((ldg & 3) || (ldx & 3) || !a16(G) || !a16(X) || !a16(workspace) ||
         workspace_bytes < alignn_gemm_tn_x6_workspace(M, N, K))
         return (int)hipErrorInvalidValue;
+    if ((g_amax == nullptr) != (x_amax == nullptr)) return (int)hipErrorInvalidValue;
     tn::TnArgs g{G, ldg, X, ldx, (float*)workspace, M, N, K, tn::tn_chunk(M, N, K), N / tn::TBN, K / tn::TBK,
-                 tn::tn_splits(M, N, K)};
+                 tn::tn_splits(M, N, K), g_amax, x_amax};
     static bool tn_attr = false;
     if (!tn_attr && tn::TLDS > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)tn::gemm_tn_x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           tn::TLDS);
+        hipError_t e = hipFuncSetAttribute((const void*)tn::gemm_tn_x6_kernel<false>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, tn::TLDS);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)tn::gemm_tn_x6_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    tn::TLDS);
         if (e != hipSuccess) return (int)e;
         tn_attr = true;
     }
     const int tiles = g.tiles_n * g.tiles_k;
     const int per_xcd = alignn_ceil_div(g.splits, 8) * tiles;
-    hipLaunchKernelGGL(tn::gemm_tn_x6_kernel, dim3(per_xcd * 8), dim3(tn::TNT), tn::TLDS, (hipStream_t)stream, g);
+    if (g_amax)
+        hipLaunchKernelGGL(tn::gemm_tn_x6_kernel<true>, dim3(per_xcd * 8), dim3(tn::TNT), tn::TLDS, (hipStream_t)stream, g);
+    else
+        hipLaunchKernelGGL(tn::gemm_tn_x6_kernel<false>, dim3(per_xcd * 8), dim3(tn::TNT), tn::TLDS, (hipStream_t)stream, g);
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }
@@ -514,26 +719,18 @@ int alignn_gemm_nt_x6_supported(int64_t M, int N, int K) { return (M > 0 && N >=
 int alignn_gemm_nt_x6(const float* A, int64_t lda, const void* Wsplit, const float* bias, const float* addend,
                       int64_t ldadd, float* C, int64_t ldc, int64_t M, int N, int K, alignn_stream_t stream) {
     if (!alignn_gemm_nt_x6_supported(M, N, K)) return (int)hipErrorInvalidValue;
-    if ((lda & 3) || (ldc & 3) || !a16(A) || !a16(C) || !a16(Wsplit) || (bias && !a16(bias)) ||
-        (addend && ((ldadd & 3) || !a16(addend))))
-        return (int)hipErrorInvalidValue;
-    static bool attr_set = false;
-    constexpr int lds = LDS_BYTES;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_x6_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)gemm_nt_x6_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
-    X6Args g{A, lda, (const unsigned char*)Wsplit, bias, addend, ldadd, C, ldc, M, N, npad(N), K};
-    dim3 grid(alignn_ceil_div(M, BM), npad(N) / BN);
-    if (addend)
-        hipLaunchKernelGGL(gemm_nt_x6_kernel<true>, grid, dim3(NT), lds, (hipStream_t)stream, g);
-    else
-        hipLaunchKernelGGL(gemm_nt_x6_kernel<false>, grid, dim3(NT), lds, (hipStream_t)stream, g);
-    ALIGNN_CHECK_LAUNCH();
-    return 0;
+    if (!nt_args_ok(A, lda, Wsplit, bias, addend, ldadd, C, ldc)) return (int)hipErrorInvalidValue;
+    X6Args g{A, lda, (const unsigned char*)Wsplit, nullptr, nullptr, bias, addend, ldadd, C, ldc, M, N, npad(N), K};
+    return launch_nt<false>(g, (hipStream_t)stream);
+}
+
+int alignn_gemm_nt_f16x3(const float* A, int64_t lda, const float* a_amax, const void* Wsplit, const float* w_amax,
+                         const float* bias, const float* addend, int64_t ldadd, float* C, int64_t ldc, int64_t M, int N,
+                         int K, alignn_stream_t stream) {
+    if (!alignn_gemm_nt_x6_supported(M, N, K) || a_amax == nullptr || w_amax == nullptr) return (int)hipErrorInvalidValue;
+    if (!nt_args_ok(A, lda, Wsplit, bias, addend, ldadd, C, ldc)) return (int)hipErrorInvalidValue;
+    X6Args g{A, lda, (const unsigned char*)Wsplit, a_amax, w_amax, bias, addend, ldadd, C, ldc, M, N, npad(N), K};
+    return launch_nt<true>(g, (hipStream_t)stream);
 }
 
 }  // extern "C"

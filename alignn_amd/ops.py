@@ -8,6 +8,8 @@ bookkeeping calls aside), and nothing falls back if the library is missing.
 
 from __future__ import annotations
 
+import weakref
+
 import torch
 
 from . import _lib
@@ -90,6 +92,37 @@ def gemm_nt(a, w, bias=None, addend=None, out=None):
 
 
 X6_MIN_TILES = 256  # fewer 128x256 tiles than CUs: the finer-grained fp32-MFMA tiles win
+F16X3 = True  # use the three-product fp16 scheme wherever max|A| is known (False: always bf16x6)
+
+# max|x| of activations, tracked by the kernels that produce them (one device float per tensor).  Keyed by object
+# identity with a weak reference, so an entry dies with its tensor and can never describe recycled memory; tensors
+# that are modified in place afterwards must not be registered.
+_AMAX = {}
+
+
+def set_amax(t, amax):
+    k = id(t)
+    _AMAX[k] = (weakref.ref(t, lambda _r, k=k: _AMAX.pop(k, None)), amax)
+    return t
+
+
+def get_amax(t):
+    e = _AMAX.get(id(t))
+    return e[1] if e is not None and e[0]() is t else None
+
+
+def new_amax(like):
+    """A zeroed device scalar for a producer kernel to atomicMax into."""
+    return torch.zeros(1, dtype=torch.float32, device=like.device)
+
+
+def absmax(x):
+    """max|x| of a 2-D fp32 tensor as a device scalar (stand-alone pass; the fused producers avoid it)."""
+    lib = _lib.load()
+    require_f32(x)
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    check(lib.alignn_absmax(ptr(x), x.stride(0), x.shape[0], x.shape[1], ptr(out), stream()), "absmax")
+    return out
 
 
 class SplitWeight:
@@ -107,6 +140,38 @@ def split_bf16x3(w, transpose=False):
     buf = torch.empty(lib.alignn_split_bf16x3_bytes(n, k), dtype=torch.uint8, device=w.device)
     check(lib.alignn_split_bf16x3(ptr(w), w.stride(0), n, k, int(transpose), ptr(buf), stream()), "split_bf16x3")
     return SplitWeight(buf, n, k)
+
+
+def split_f16x2(w, transpose=False):
+    """Slice ``w * 2^s`` into two fp16 planes (``s`` from max|w|, kept with the image)."""
+    lib = _lib.load()
+    require_f32(w)
+    n, k = (w.shape[1], w.shape[0]) if transpose else (w.shape[0], w.shape[1])
+    amax = absmax(w if w.stride(0) % 4 == 0 and w.shape[1] % 4 == 0 else w.contiguous().view(1, -1))
+    buf = torch.empty(lib.alignn_split_f16x2_bytes(n, k), dtype=torch.uint8, device=w.device)
+    check(lib.alignn_split_f16x2(ptr(w), w.stride(0), n, k, int(transpose), ptr(amax), ptr(buf), stream()), "split_f16x2")
+    sw = SplitWeight(buf, n, k)
+    sw.amax = amax
+    return sw
+
+
+def gemm_nt_f16x3(a, a_amax, ws, bias=None, addend=None, out=None):
+    """out[M,N] = a[M,K] @ W[N,K]^T with W pre-sliced by ``split_f16x2`` and ``a_amax`` >= max|a| (device scalar)."""
+    lib = _lib.load()
+    require_f32(a, bias, addend)
+    M, K = a.shape
+    N = ws.n
+    if K != ws.k:
+        raise ValueError(f"reduction length mismatch: {K} vs {ws.k}")
+    if out is None:
+        out = _empty(M, N, like=a)
+    check(
+        lib.alignn_gemm_nt_f16x3(ptr(a), a.stride(0), ptr(a_amax), ptr(ws.buf), ptr(ws.amax), ptr(bias), ptr(addend),
+                                 addend.stride(0) if addend is not None else 0, ptr(out), out.stride(0), M, N, K,
+                                 stream()),
+        "gemm_nt_f16x3",
+    )
+    return out
 
 
 def gemm_nt_x6(a, ws, bias=None, addend=None, out=None):
@@ -127,15 +192,20 @@ def gemm_nt_x6(a, ws, bias=None, addend=None, out=None):
     return out
 
 
-def project(a, w, bias=None, addend=None, transpose_w=False):
-    """a @ W^T (transpose_w: a @ W) choosing the kernel: bf16x6 for the wide, deep products that dominate
-    the step, the exact-fp32 MFMA kernel otherwise."""
+def project(a, w, bias=None, addend=None, transpose_w=False, a_amax=None):
+    """a @ W^T (transpose_w: a @ W) choosing the kernel: the split-product kernels for the wide, deep products
+    that dominate the step (three fp16 products when max|a| is known - ``a_amax`` or the producer registry -, six
+    bf16 products otherwise), the exact-fp32 MFMA kernel for the rest."""
     lib = _lib.load()
     M = a.shape[0]
     N, K = (w.shape[1], w.shape[0]) if transpose_w else (w.shape[0], w.shape[1])
-    # the bf16x6 kernel works in 128 x 256 tiles: it needs enough of them to occupy the 256 CUs
+    # the split-product kernel works in 128 x 256 tiles: it needs enough of them to occupy the 256 CUs
     x6_tiles = ((M + 127) // 128) * ((N + 255) // 256)
     if x6_tiles >= X6_MIN_TILES and a.stride(0) % 4 == 0 and lib.alignn_gemm_nt_x6_supported(M, N, K):
+        if a_amax is None:
+            a_amax = get_amax(a)
+        if F16X3 and a_amax is not None:
+            return gemm_nt_f16x3(a, a_amax, split_f16x2(w, transpose_w), bias, addend)
         return gemm_nt_x6(a, split_bf16x3(w, transpose_w), bias, addend)
     if transpose_w:
         if w.shape[0] % 4 == 0 and w.shape[1] >= 16:
@@ -160,13 +230,16 @@ def gemm_nn(g, w, addend=None, out=None):
     return out
 
 
-def _dgrad(g, w, addend=None):
+def _dgrad(g, w, addend=None, g_amax=None):
     """Input gradient g[M,N] @ w[N,K] through the reduction-contiguous (NT) kernels on w^T."""
-    return project(g, w, None, addend, transpose_w=True)
+    return project(g, w, None, addend, transpose_w=True, a_amax=g_amax)
 
 
-def gemm_tn(g, a):
-    """dW[N,K] = g[M,N]^T @ a[M,K] (deterministic split over M)."""
+def gemm_tn(g, a, g_amax=None, a_amax=None):
+    """dW[N,K] = g[M,N]^T @ a[M,K] (deterministic split over M).  With both maxima known (device scalars) the large
+    aligned shapes run the three-product fp16 scheme."""
+    if not F16X3 or g_amax is None or a_amax is None:
+        g_amax = a_amax = None
     lib = _lib.load()
     require_f32(g, a)
     M, N = g.shape
@@ -175,8 +248,8 @@ def gemm_tn(g, a):
     nbytes = lib.alignn_gemm_tn_workspace(M, N, K)
     ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=g.device)
     check(
-        lib.alignn_gemm_tn(ptr(g), g.stride(0), ptr(a), a.stride(0), ptr(out), out.stride(0), M, N, K, ptr(ws), nbytes,
-                           stream()),
+        lib.alignn_gemm_tn(ptr(g), g.stride(0), ptr(g_amax), ptr(a), a.stride(0), ptr(a_amax), ptr(out), out.stride(0),
+                           M, N, K, ptr(ws), nbytes, stream()),
         "gemm_tn",
     )
     return out

@@ -58,9 +58,12 @@ int alignn_gemm_nn(const float* G, int64_t ldg, const float* W, int64_t ldw,
  * Split over M in `splits` deterministic slabs; `workspace` holds splits*N*K floats
  * (alignn_gemm_tn_workspace tells how many bytes for a given shape). */
 size_t alignn_gemm_tn_workspace(int64_t M, int N, int K);
-int alignn_gemm_tn(const float* G, int64_t ldg, const float* A, int64_t lda, float* dW, int64_t lddw,
-                   int64_t M, int N, int K, void* workspace, size_t workspace_bytes,
-                   alignn_stream_t stream);
+/* g_amax / a_amax (both or neither; may be NULL): device scalars holding max|G| and max|A| (upper bounds are
+ * fine) - when both are given and the shape suits the split-product kernel, the three-product fp16 scheme runs
+ * instead of the six-product bf16 one (see alignn_gemm_nt_f16x3). */
+int alignn_gemm_tn(const float* G, int64_t ldg, const float* g_amax, const float* A, int64_t lda,
+                   const float* a_amax, float* dW, int64_t lddw, int64_t M, int N, int K, void* workspace,
+                   size_t workspace_bytes, alignn_stream_t stream);
 
 /* fp32-accurate projection on the bf16 matrix cores ("bf16x6", csrc/gemm_x6.hip): every fp32 value is cut
  * into three truncated bf16 slices and the six slice products of weight >= 2^-16 are accumulated in fp32
@@ -85,8 +88,25 @@ int alignn_gemm_nt_x6(const float* A, int64_t lda, const void* Wsplit, const flo
 int alignn_gemm_tn_x6_supported(int64_t M, int N, int K);
 size_t alignn_gemm_tn_x6_workspace(int64_t M, int N, int K);
 int alignn_gemm_tn_x6_splits(int64_t M, int N, int K);
-int alignn_gemm_tn_x6_partials(const float* G, int64_t ldg, const float* X, int64_t ldx, int64_t M, int N,
-                               int K, void* workspace, size_t workspace_bytes, alignn_stream_t stream);
+int alignn_gemm_tn_x6_partials(const float* G, int64_t ldg, const float* g_amax, const float* X, int64_t ldx,
+                               const float* x_amax, int64_t M, int N, int K, void* workspace,
+                               size_t workspace_bytes, alignn_stream_t stream);
+
+/* Same projection with HALF the matrix-core work ("f16x3"), for callers that know max|A|: operands are scaled
+ * by a power of two into the fp16 range and cut into two fp16 slices (11 + 11 mantissa bits); the three products
+ * hh + hl + lh are accumulated in fp32 and the scales undone in the epilogue - fp32-grade error (dropped term
+ * < 2^-22), sustained-MFMA time 153 us instead of 306 us for T x 256 x 256, i.e. the projection is HBM-bound.
+ *   alignn_absmax:        amax[0] = max|X| (device scalar; the fused producers track it themselves - see the
+ *                         `amax` argument of alignn_bn_silu_fwd, alignn_egc_bwd_dst, alignn_egc_bwd_lg_fused, ...)
+ *   alignn_split_f16x2:   pre-slice W * 2^s (s from *w_amax) into the two-plane DMA image
+ *   alignn_gemm_nt_f16x3: C = A W^T (+bias)(+addend); shapes as alignn_gemm_nt_x6_supported */
+int alignn_absmax(const float* X, int64_t ldx, int64_t rows, int F, float* amax, alignn_stream_t stream);
+size_t alignn_split_f16x2_bytes(int N, int K);
+int alignn_split_f16x2(const float* W, int64_t ldw, int N, int K, int transpose, const float* w_amax, void* out,
+                       alignn_stream_t stream);
+int alignn_gemm_nt_f16x3(const float* A, int64_t lda, const float* a_amax, const void* Wsplit,
+                         const float* w_amax, const float* bias, const float* addend, int64_t ldadd, float* C,
+                         int64_t ldc, int64_t M, int N, int K, alignn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Column statistics / BatchNorm1d + SiLU (+ residual).

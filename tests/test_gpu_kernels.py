@@ -72,6 +72,58 @@ def test_gemm_x6_accuracy(M, N, K):
     assert torch.equal(out_t, out)
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 128, 32), (300, 256, 256), (5000, 1024, 256), (1000, 256, 1024), (129, 132, 64),
+                                   (70000, 256, 256)])
+@pytest.mark.parametrize("a_scale", [1.0, 3e-7, 2e5])
+def test_gemm_f16x3_accuracy(M, N, K, a_scale):
+    """fp16 two-slice / three-product scheme: fp32-grade error vs float64 whatever the magnitude of the operands
+    (gradients live around 1e-7), bias/addend included; an over-estimated maximum only costs bits."""
+    a, w, b, add = r(M, K, seed=1) * a_scale, r(N, K, seed=2, scale=K**-0.5), r(N, seed=3) * a_scale, r(M, N, seed=4) * a_scale
+    amax = ops.absmax(a)
+    assert float(amax) == float(a.abs().max())
+    ws = ops.split_f16x2(w)
+    out = ops.gemm_nt_f16x3(a, amax, ws, b, add)
+    ref = a.double().cpu() @ w.double().cpu().t() + b.double().cpu() + add.double().cpu()
+    e_h = rel_err(out, ref)
+    e_f32 = rel_err(ops.gemm_nt(a, w, b, add), ref)
+    assert e_h < 2e-6, (e_h, e_f32)
+    assert e_h < 4 * e_f32 + 3e-7, (e_h, e_f32)
+    out_hi = ops.gemm_nt_f16x3(a, amax * 37.0, ws, b, add)  # upper bound instead of the exact maximum
+    assert rel_err(out_hi, ref) < 2e-6
+    wt = w.t().contiguous()
+    out_t = ops.gemm_nt_f16x3(a, amax, ops.split_f16x2(wt, transpose=True), b, add)
+    assert torch.equal(out_t, out)
+
+
+def test_gemm_f16x3_dynamic_range_and_zeros():
+    """One huge element next to ordinary ones: the small ones keep an ABSOLUTE error far below fp32 rounding of the
+    dot product; all-zero operands give exact zeros."""
+    a = r(512, 256, seed=11)
+    a[7, 3] = 4.0e4
+    w = r(256, 256, seed=12, scale=1 / 16)
+    out = ops.gemm_nt_f16x3(a, ops.absmax(a), ops.split_f16x2(w))
+    ref = a.double().cpu() @ w.double().cpu().t()
+    assert rel_err(out, ref) < 2e-6
+    rows = torch.arange(512) != 7  # rows without the outlier: still fp32-grade on their own scale
+    assert rel_err(out[rows.to(DEV)], ref[rows]) < 2e-6
+    z = torch.zeros(256, 64, device=DEV)
+    o = ops.gemm_nt_f16x3(z, ops.absmax(z), ops.split_f16x2(r(128, 64, seed=13)))
+    assert float(o.abs().max()) == 0.0
+    o = ops.gemm_nt_f16x3(r(256, 64, seed=14), ops.absmax(r(256, 64, seed=14)), ops.split_f16x2(torch.zeros(128, 64, device=DEV)))
+    assert float(o.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("M,N,K", [(5000, 256, 256), (70001, 256, 256), (20000, 1024, 256), (20000, 256, 1024)])
+@pytest.mark.parametrize("g_scale", [1.0, 1e-6])
+def test_gemm_tn_f16x3_accuracy(M, N, K, g_scale):
+    g, a = r(M, N, seed=21) * g_scale, r(M, K, seed=22)
+    out = ops.gemm_tn(g, a, ops.absmax(g), ops.absmax(a))
+    ref = g.double().cpu().t() @ a.double().cpu()
+    e_h, e_6 = rel_err(out, ref), rel_err(ops.gemm_tn(g, a), ref)
+    assert e_h < 2e-6, (e_h, e_6)
+    assert torch.equal(out, ops.gemm_tn(g, a, ops.absmax(g), ops.absmax(a)))  # fixed-order slabs: reproducible
+
+
 def test_gemm_x6_asymmetric_identity_and_extremes():
     n = 256
     w = (torch.arange(n * n, dtype=torch.float32, device=DEV).reshape(n, n) - 3000.0) * 1.2345e-3

@@ -40,13 +40,21 @@ def gemms():
         t6 = timeit(lambda: ops.gemm_nt_x6(a, ws, b, out=out))
         t6a = timeit(lambda: ops.gemm_nt_x6(a, ws, b, add, out=out))
         tsp = timeit(lambda: ops.split_bf16x3(w))
+        am = ops.absmax(a)
+        wh = ops.split_f16x2(w)
+        th = timeit(lambda: ops.gemm_nt_f16x3(a, am, wh, b, out=out))
+        tha = timeit(lambda: ops.gemm_nt_f16x3(a, am, wh, b, add, out=out))
+        tam = timeit(lambda: ops.absmax(a))
         print(f"NT M={M} N={Nn} K={K}: fp32 {t32*1e3:8.1f} us ({fl/t32/1e9:6.1f} TF) | x6 {t6*1e3:8.1f} us ({fl/t6/1e9:6.1f} TF-eq, "
-              f"{by/t6/1e6:6.0f} GB/s) | x6+addend {t6a*1e3:8.1f} us | split {tsp*1e3:6.1f} us")
+              f"{by/t6/1e6:6.0f} GB/s) | x6+addend {t6a*1e3:8.1f} us | split {tsp*1e3:6.1f} us | f16x3 {th*1e3:8.1f} us "
+              f"({by/th/1e6:6.0f} GB/s) +addend {tha*1e3:8.1f} us | absmax {tam*1e3:6.1f} us")
     for (M, Nn, K) in [(T, 256, 256), (E, 1024, 256), (E, 256, 256), (N, 1024, 256), (T, 256, 64)]:
         g = torch.randn(M, Nn, device=DEV)
         a = torch.randn(M, K, device=DEV)
         t = timeit(lambda: ops.gemm_tn(g, a))
-        print(f"TN M={M} N={Nn} K={K}: {t*1e3:8.1f} us ({2.0*M*Nn*K/t/1e9:6.1f} TF)")
+        gm, am = ops.absmax(g), ops.absmax(a)
+        th = timeit(lambda: ops.gemm_tn(g, a, gm, am))
+        print(f"TN M={M} N={Nn} K={K}: {t*1e3:8.1f} us ({2.0*M*Nn*K/t/1e9:6.1f} TF) | f16x3 {th*1e3:8.1f} us")
 
 
 if __name__ == "__main__":
