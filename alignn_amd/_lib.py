@@ -39,21 +39,21 @@ SIGNATURES = {
     "alignn_col_stats": (_i32, [_p, _i64, _i64, _i32, _p, _p]),
     "alignn_col_sum": (_i32, [_p, _i64, _i64, _i32, _p, _p, _p]),
     "alignn_bn_finalize": (_i32, [_p, _i32, _i64, _i32, _p, _p, _f32, _f32, _p, _p, _p, _p]),
-    "alignn_bn_silu_fwd": (_i32, [_p, _i64, _p, _i64, _p, _p, _i64, _i64, _i32, _p]),
+    "alignn_bn_silu_fwd": (_i32, [_p, _i64, _p, _i64, _p, _p, _i64, _i64, _i32, _p, _p]),
     "alignn_bn_silu_bwd_reduce": (_i32, [_p, _i64, _p, _i64, _p, _i64, _i32, _p, _p]),
     "alignn_bn_bwd_finalize": (_i32, [_p, _i32, _i32, _p, _p]),
-    "alignn_bn_silu_bwd_apply": (_i32, [_p, _i64, _p, _i64, _p, _p, _p, _i32, _p, _i64, _i64, _i32, _p]),
+    "alignn_bn_silu_bwd_apply": (_i32, [_p, _i64, _p, _i64, _p, _p, _p, _i32, _p, _i64, _i64, _i32, _p, _p]),
     "alignn_egc_slabs": (_i32, [_i64]),
     "alignn_egc_gate_fwd": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p]),
     "alignn_egc_node_bwd": (_i32, [_p, _i64, _p, _p, _p, _p, _i64, _i32, _p]),
-    "alignn_egc_bwd_dst": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _i32, _i64, _p, _p, _p, _i64, _i32, _p, _p, _p, _p]),
+    "alignn_egc_bwd_dst": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _i32, _i64, _p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p, _p]),
     "alignn_slab_sum": (_i32, [_p, _i32, _i32, _p, _p]),
-    "alignn_egc_bwd_lg_fused": (_i32, [_p, _p, _p, _p, _p, _p, _p, _i32, _i64, _p, _p, _i64, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _p]),
+    "alignn_egc_bwd_lg_fused": (_i32, [_p, _p, _p, _p, _p, _p, _p, _i32, _i64, _p, _p, _i64, _p, _p, _p, _p, _p, _i32, _p, _p, _p, _p, _p, _p]),
     "alignn_ln_slabs": (_i32, [_i64]),
-    "alignn_ln_silu_fwd": (_i32, [_p, _i64, _p, _i64, _p, _p, _f32, _p, _i64, _p, _i64, _i32, _p]),
-    "alignn_ln_silu_bwd": (_i32, [_p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _p, _i64, _i32, _p]),
+    "alignn_ln_silu_fwd": (_i32, [_p, _i64, _p, _i64, _p, _p, _f32, _p, _i64, _p, _i64, _i32, _p, _p]),
+    "alignn_ln_silu_bwd": (_i32, [_p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _p, _i64, _i32, _p, _p]),
     "alignn_bond_cosine_fwd": (_i32, [_p, _p, _p, _p, _i64, _p]),
-    "alignn_egc_bwd_src": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p]),
+    "alignn_egc_bwd_src": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p]),
     "alignn_rbf_fwd": (_i32, [_p, _p, _f32, _p, _i64, _i32, _p]),
     "alignn_norm3_fwd": (_i32, [_p, _p, _i64, _p]),
     "alignn_segment_mean_fwd": (_i32, [_p, _p, _p, _i32, _i32, _p]),

@@ -60,5 +60,6 @@ __device__ __forceinline__ void block_amax_commit(float m, float* amax) {
         for (int w = 1; w < nw; ++w) r = fmaxf(r, amax_sh[w]);
         if (r > 0.0f) atomicMax(reinterpret_cast<unsigned*>(amax), __float_as_uint(r));
     }
+    __syncthreads();  // the scratch array may be reused by a second commit
 }
 __device__ __forceinline__ float f4_absmax(float4 v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }

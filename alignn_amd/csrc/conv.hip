@@ -192,13 +192,15 @@ __global__ __launch_bounds__(kThreads) void egc_bwd_dst_kernel(
     const float* __restrict__ GS1, const float* __restrict__ GS0, const float* __restrict__ e_stat,
     const float* __restrict__ e_red, int e_eval, float inv_n, const int32_t* __restrict__ seg_ptr,
     const int32_t* __restrict__ seg_node, const int32_t* __restrict__ src, int n_seg, int H,
-    float* __restrict__ GM, float* __restrict__ GP, float* __restrict__ gb_partial) {
+    float* __restrict__ GM, float* __restrict__ GP, float* __restrict__ gb_partial, float* __restrict__ gm_amax,
+    float* __restrict__ gp_amax) {
     __shared__ float4 sh[kWavesPerBlock][ALIGNN_WAVE];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t ldp = 4 * (int64_t)H;
     const int first = blockIdx.x * kWavesPerBlock + wave;
     const int stride = gridDim.x * kWavesPerBlock;
+    float gm_am = 0.0f, gp_am = 0.0f;
     for (int c0 = 0; c0 < H; c0 += 4 * ALIGNN_WAVE) {
         const int f = c0 + 4 * lane;
         const bool active = f < H;
@@ -236,6 +238,7 @@ __global__ __launch_bounds__(kThreads) void egc_bwd_dst_kernel(
                 for (int k = 0; k < 4; ++k) {
                     float4 gm = edge_grad<MODE>(m[k], gy[k], bh[k], gs1, gs0, nrm, inv_n, e_eval);
                     f4_st(GM + (int64_t)(e + k) * H + f, gm);
+                    gm_am = fmaxf(gm_am, f4_absmax(gm));
                     gbd = f4_add(gbd, gm);
                 }
             }
@@ -247,9 +250,11 @@ __global__ __launch_bounds__(kThreads) void egc_bwd_dst_kernel(
                 if (HAS_GY) gy = f4_ld(GY + (int64_t)e * H + f);
                 float4 gm = edge_grad<MODE>(m, gy, bh, gs1, gs0, nrm, inv_n, e_eval);
                 f4_st(GM + (int64_t)e * H + f, gm);
+                gm_am = fmaxf(gm_am, f4_absmax(gm));
                 gbd = f4_add(gbd, gm);
             }
             f4_st(GP + (int64_t)i * ldp + H + f, gbd);
+            gp_am = fmaxf(gp_am, f4_absmax(gbd));
             gb = f4_add(gb, gbd);
         }
         }
@@ -265,6 +270,8 @@ __global__ __launch_bounds__(kThreads) void egc_bwd_dst_kernel(
             __syncthreads();
         }
     }
+    block_amax_commit(gm_am, gm_amax);
+    block_amax_commit(gp_am, gp_amax);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -273,12 +280,13 @@ __global__ __launch_bounds__(kThreads) void egc_bwd_dst_kernel(
 __global__ __launch_bounds__(kThreads) void egc_bwd_src_kernel(
     const float* __restrict__ GM, const float* __restrict__ M, const float* __restrict__ GS1,
     const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_slot, const int32_t* __restrict__ dst,
-    int n_nodes, int H, float* __restrict__ GP) {
+    int n_nodes, int H, float* __restrict__ GP, float* __restrict__ gp_amax) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t ldp = 4 * (int64_t)H;
     const int first = blockIdx.x * kWavesPerBlock + wave;
     const int stride = gridDim.x * kWavesPerBlock;
+    float gp_am = 0.0f;
     for (int c0 = 0; c0 < H; c0 += 4 * ALIGNN_WAVE) {
         const int f = c0 + 4 * lane;
         if (f >= H) continue;
@@ -310,8 +318,10 @@ __global__ __launch_bounds__(kThreads) void egc_bwd_src_kernel(
             }
             f4_st(GP + (int64_t)j * ldp + f, ga);
             f4_st(GP + (int64_t)j * ldp + 2 * H + f, gbh);
+            gp_am = fmaxf(gp_am, fmaxf(f4_absmax(ga), f4_absmax(gbh)));
         }
     }
+    block_amax_commit(gp_am, gp_amax);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -334,12 +344,13 @@ __global__ __launch_bounds__(kThreads) void egc_bwd_lg_fused_kernel(
     const int32_t* __restrict__ grp_src_ptr, const int32_t* __restrict__ seg_ptr,
     const int32_t* __restrict__ seg_node, const int32_t* __restrict__ dst, const int32_t* __restrict__ out_ptr,
     const int32_t* __restrict__ out_slot, int H, float* __restrict__ GM, float* __restrict__ GP,
-    float* __restrict__ gb_partial) {
+    float* __restrict__ gb_partial, float* __restrict__ gm_amax, float* __restrict__ gp_amax) {
     __shared__ float4 sh[kWavesPerBlock][ALIGNN_WAVE];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t ldp = 4 * (int64_t)H;
     const int j = blockIdx.x;
+    float gm_am = 0.0f, gp_am = 0.0f;
     const int p_beg = grp_src_ptr[j], p_end = grp_src_ptr[j + 1];
     const int s_beg = grp_seg_ptr[j], s_end = grp_seg_ptr[j + 1];
     constexpr bool HAS_GY = MODE != 0;
@@ -381,6 +392,7 @@ __global__ __launch_bounds__(kThreads) void egc_bwd_lg_fused_kernel(
                     for (int t = 0; t < 4; ++t) {
                         float4 gm = edge_grad<MODE>(m[t], gy[t], bh, g1[t], g0[t], nrm, inv_n, e_eval);
                         f4_st(GM + (int64_t)slot[t] * H + f, gm);
+                        gm_am = fmaxf(gm_am, f4_absmax(gm));
                         ga = f4_add(ga, gm);
                         gbh = f4_fma(f4_sigmoid(m[t]), g1[t], gbh);
                     }
@@ -394,11 +406,13 @@ __global__ __launch_bounds__(kThreads) void egc_bwd_lg_fused_kernel(
                     float4 g1 = f4_ld(GS1 + (int64_t)v * H + f), g0 = f4_ld(GS0 + (int64_t)v * H + f);
                     float4 gm = edge_grad<MODE>(m, gy, bh, g1, g0, nrm, inv_n, e_eval);
                     f4_st(GM + (int64_t)slot * H + f, gm);
+                    gm_am = fmaxf(gm_am, f4_absmax(gm));
                     ga = f4_add(ga, gm);
                     gbh = f4_fma(f4_sigmoid(m), g1, gbh);
                 }
                 f4_st(GP + (int64_t)p * ldp + f, ga);
                 f4_st(GP + (int64_t)p * ldp + 2 * H + f, gbh);
+                gp_am = fmaxf(gp_am, fmaxf(f4_absmax(ga), f4_absmax(gbh)));
             }
         }
         __syncthreads();  // (waits for the GM stores of every wave: they are in L2 now)
@@ -409,6 +423,7 @@ __global__ __launch_bounds__(kThreads) void egc_bwd_lg_fused_kernel(
                 float4 gbd = f4_zero();
                 for (int e = seg_ptr[s]; e < seg_ptr[s + 1]; ++e) gbd = f4_add(gbd, f4_ld(GM + (int64_t)e * H + f));
                 f4_st(GP + (int64_t)i * ldp + H + f, gbd);
+                gp_am = fmaxf(gp_am, f4_absmax(gbd));
                 gb = f4_add(gb, gbd);
             }
         }
@@ -424,6 +439,8 @@ __global__ __launch_bounds__(kThreads) void egc_bwd_lg_fused_kernel(
         }
         __syncthreads();
     }
+    block_amax_commit(gm_am, gm_amax);
+    block_amax_commit(gp_am, gp_amax);
 }
 
 inline bool h_ok(int H) { return H >= 4 && (H & 3) == 0 && H <= 1024; }
@@ -460,20 +477,24 @@ int alignn_egc_node_bwd(const float* GXPRE, int64_t ldg, const float* S0, const 
 int alignn_egc_bwd_dst(const float* GY, const float* M, const float* P, const float* GS1, const float* GS0,
                        const float* e_stat, const float* e_gamma, const float* e_red, int e_eval, int64_t m_rows,
                        const int32_t* seg_ptr, const int32_t* seg_node, const int32_t* src, int64_t n_seg, int H,
-                       float* GM, float* GP, float* gb_partial, alignn_stream_t stream) {
+                       float* GM, float* GP, float* gb_partial, float* gm_amax, float* gp_amax,
+                       alignn_stream_t stream) {
     (void)e_gamma;
     if (!h_ok(H) || n_seg > INT32_MAX) return (int)hipErrorInvalidValue;
     const float inv_n = m_rows > 0 ? 1.0f / (float)m_rows : 0.0f;
     dim3 grid(egc_blocks(n_seg)), block(kThreads);
     if (GY && e_stat)
         hipLaunchKernelGGL(egc_bwd_dst_kernel<1>, grid, block, 0, (hipStream_t)stream, GY, M, P, GS1, GS0, e_stat,
-                           e_red, e_eval, inv_n, seg_ptr, seg_node, src, (int)n_seg, H, GM, GP, gb_partial);
+                           e_red, e_eval, inv_n, seg_ptr, seg_node, src, (int)n_seg, H, GM, GP, gb_partial,
+                           gm_amax, gp_amax);
     else if (GY)  // e_stat == NULL: GY is the finished normalised-branch gradient (LayerNorm flavour)
         hipLaunchKernelGGL(egc_bwd_dst_kernel<2>, grid, block, 0, (hipStream_t)stream, GY, M, P, GS1, GS0, e_stat,
-                           e_red, e_eval, inv_n, seg_ptr, seg_node, src, (int)n_seg, H, GM, GP, gb_partial);
+                           e_red, e_eval, inv_n, seg_ptr, seg_node, src, (int)n_seg, H, GM, GP, gb_partial,
+                           gm_amax, gp_amax);
     else
         hipLaunchKernelGGL(egc_bwd_dst_kernel<0>, grid, block, 0, (hipStream_t)stream, GY, M, P, GS1, GS0, e_stat,
-                           e_red, e_eval, inv_n, seg_ptr, seg_node, src, (int)n_seg, H, GM, GP, gb_partial);
+                           e_red, e_eval, inv_n, seg_ptr, seg_node, src, (int)n_seg, H, GM, GP, gb_partial,
+                           gm_amax, gp_amax);
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }
@@ -483,7 +504,7 @@ int alignn_egc_bwd_lg_fused(const float* GY, const float* M, const float* P, con
                             const int32_t* grp_seg_ptr, const int32_t* grp_src_ptr, int64_t n_groups,
                             const int32_t* seg_ptr, const int32_t* seg_node, const int32_t* dst,
                             const int32_t* out_ptr, const int32_t* out_slot, int H, float* GM, float* GP,
-                            float* gb_partial, alignn_stream_t stream) {
+                            float* gb_partial, float* gm_amax, float* gp_amax, alignn_stream_t stream) {
     if (!h_ok(H) || n_groups <= 0 || n_groups > INT32_MAX) return (int)hipErrorInvalidValue;
     const float inv_n = m_rows > 0 ? 1.0f / (float)m_rows : 0.0f;
     dim3 grid((int)n_groups), block(kThreads);
@@ -491,7 +512,7 @@ int alignn_egc_bwd_lg_fused(const float* GY, const float* M, const float* P, con
 #define ALIGNN_LGF(MODE_)                                                                                           \
     hipLaunchKernelGGL(egc_bwd_lg_fused_kernel<MODE_>, grid, block, 0, st, GY, M, P, GS1, GS0, e_stat, e_red, e_eval,  \
                        inv_n, grp_seg_ptr, grp_src_ptr, seg_ptr, seg_node, dst, out_ptr, out_slot, H, GM, GP,       \
-                       gb_partial)
+                       gb_partial, gm_amax, gp_amax)
     if (GY && e_stat)
         ALIGNN_LGF(1);
     else if (GY)
@@ -505,10 +526,10 @@ int alignn_egc_bwd_lg_fused(const float* GY, const float* M, const float* P, con
 
 int alignn_egc_bwd_src(const float* GM, const float* M, const float* GS1, const int32_t* out_ptr,
                        const int32_t* out_slot, const int32_t* dst, int64_t n_nodes, int H, float* GP,
-                       alignn_stream_t stream) {
+                       float* gp_amax, alignn_stream_t stream) {
     if (!h_ok(H) || n_nodes > INT32_MAX) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(egc_bwd_src_kernel, dim3(egc_blocks(n_nodes)), dim3(kThreads), 0, (hipStream_t)stream, GM, M,
-                       GS1, out_ptr, out_slot, dst, (int)n_nodes, H, GP);
+                       GS1, out_ptr, out_slot, dst, (int)n_nodes, H, GP, gp_amax);
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }

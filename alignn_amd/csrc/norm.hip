@@ -174,9 +174,10 @@ __global__ __launch_bounds__(kThreads) void bn_silu_fwd_kernel(const float* __re
                                                                const float* __restrict__ R, int64_t ldr,
                                                                const float* __restrict__ stat,
                                                                float* __restrict__ Y, int64_t ldy,
-                                                               int64_t rows, int F) {
+                                                               int64_t rows, int F, float* __restrict__ amax) {
     const int Q = F >> 2;
     const int64_t total = rows * Q;
+    float am = 0.0f;
     for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
         int64_t r = i / Q;
         int q = (int)(i - r * Q);
@@ -187,16 +188,19 @@ __global__ __launch_bounds__(kThreads) void bn_silu_fwd_kernel(const float* __re
         float4 o = make_float4(silu_f(z.x), silu_f(z.y), silu_f(z.z), silu_f(z.w));
         if (HAS_RES) o = f4_add(o, f4_ld(R + r * ldr + q * 4));
         f4_st(Y + r * ldy + q * 4, o);
+        am = fmaxf(am, f4_absmax(o));
     }
+    block_amax_commit(am, amax);
 }
 
 __global__ __launch_bounds__(kThreads) void bn_silu_bwd_apply_kernel(
     const float* __restrict__ GY, int64_t ldgy, const float* __restrict__ X, int64_t ldx,
     const float* __restrict__ stat, const float* __restrict__ gamma, const float* __restrict__ red, int eval_mode,
-    float* __restrict__ GX, int64_t ldgx, int64_t rows, int F) {
+    float* __restrict__ GX, int64_t ldgx, int64_t rows, int F, float* __restrict__ amax) {
     const int Q = F >> 2;
     const int64_t total = rows * Q;
     const float inv_n = 1.0f / (float)rows;
+    float am = 0.0f;
     for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
         int64_t r = i / Q;
         int q = (int)(i - r * Q);
@@ -220,7 +224,9 @@ __global__ __launch_bounds__(kThreads) void bn_silu_bwd_apply_kernel(
             o.w = sc.w * (gz.w - inv_n * (c0.w + xh.w * c1.w));
         }
         f4_st(GX + r * ldgx + q * 4, o);
+        am = fmaxf(am, f4_absmax(o));
     }
+    block_amax_commit(am, amax);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -243,11 +249,13 @@ __global__ __launch_bounds__(kThreads) void ln_silu_fwd_kernel(const float* __re
                                                                const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float eps,
                                                                float* __restrict__ Y, int64_t ldy,
-                                                               float* __restrict__ stats, int64_t rows, int F) {
+                                                               float* __restrict__ stats, int64_t rows, int F,
+                                                               float* __restrict__ amax) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
     const int64_t stride = (int64_t)gridDim.x * (kThreads / 64);
     const float inv_f = 1.0f / (float)F;
+    float am = 0.0f;
     for (int64_t r = wave0; r < rows; r += stride) {
         float4 x[NC];
         float s = 0.0f;
@@ -281,6 +289,7 @@ __global__ __launch_bounds__(kThreads) void ln_silu_fwd_kernel(const float* __re
                 float4 o = make_float4(silu_f(z.x), silu_f(z.y), silu_f(z.z), silu_f(z.w));
                 if (HAS_RES) o = f4_add(o, f4_ld(R + r * ldr + f));
                 f4_st(Y + r * ldy + f, o);
+                am = fmaxf(am, f4_absmax(o));
             }
         }
         if (stats && lane == 0) {
@@ -288,6 +297,7 @@ __global__ __launch_bounds__(kThreads) void ln_silu_fwd_kernel(const float* __re
             stats[2 * r + 1] = rstd;
         }
     }
+    block_amax_commit(am, amax);
 }
 
 template <int NC>
@@ -297,8 +307,10 @@ __global__ __launch_bounds__(kThreads) void ln_silu_bwd_kernel(const float* __re
                                                                const float* __restrict__ beta,
                                                                const float* __restrict__ stats,
                                                                float* __restrict__ GX, int64_t ldgx,
-                                                               float* __restrict__ partial, int64_t rows, int F) {
+                                                               float* __restrict__ partial, int64_t rows, int F,
+                                                               float* __restrict__ amax) {
     __shared__ float4 sh[2][kThreads / 64][64];
+    float am = 0.0f;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t wave0 = (int64_t)blockIdx.x * (kThreads / 64) + wave;
     const int64_t stride = (int64_t)gridDim.x * (kThreads / 64);
@@ -338,9 +350,11 @@ __global__ __launch_bounds__(kThreads) void ln_silu_bwd_kernel(const float* __re
                 o.z = rstd * (gh[c].z - c1 - xh[c].z * c2);
                 o.w = rstd * (gh[c].w - c1 - xh[c].w * c2);
                 f4_st(GX + r * ldgx + f, o);
+                am = fmaxf(am, f4_absmax(o));
             }
         }
     }
+    block_amax_commit(am, amax);
     // slab [blockIdx.x][2][F]: row 0 = dbeta partial (sum gz), row 1 = dgamma partial (sum gz*xhat)
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -422,16 +436,16 @@ int alignn_bn_finalize(const float* partial, int slabs, int64_t rows, int F, con
 }
 
 int alignn_bn_silu_fwd(const float* X, int64_t ldx, const float* R, int64_t ldr, const float* stat, float* Y,
-                       int64_t ldy, int64_t rows, int F, alignn_stream_t stream) {
+                       int64_t ldy, int64_t rows, int F, float* amax, alignn_stream_t stream) {
     if (!feat_ok(F)) return (int)hipErrorInvalidValue;
     if (rows == 0) return 0;
     int grid = stream_grid(rows * (F >> 2));
     if (R)
         hipLaunchKernelGGL(bn_silu_fwd_kernel<true>, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, X, ldx, R, ldr,
-                           stat, Y, ldy, rows, F);
+                           stat, Y, ldy, rows, F, amax);
     else
         hipLaunchKernelGGL(bn_silu_fwd_kernel<false>, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, X, ldx, R,
-                           ldr, stat, Y, ldy, rows, F);
+                           ldr, stat, Y, ldy, rows, F, amax);
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }
@@ -458,7 +472,8 @@ int alignn_bn_bwd_finalize(const float* partial, int slabs, int F, float* red, a
 int alignn_ln_slabs(int64_t rows) { return ln_blocks(rows); }
 
 int alignn_ln_silu_fwd(const float* X, int64_t ldx, const float* R, int64_t ldr, const float* gamma, const float* beta,
-                       float eps, float* Y, int64_t ldy, float* stats, int64_t rows, int F, alignn_stream_t stream) {
+                       float eps, float* Y, int64_t ldy, float* stats, int64_t rows, int F, float* amax,
+                       alignn_stream_t stream) {
     if (!feat_ok(F)) return (int)hipErrorInvalidValue;
     if (rows == 0) return 0;
     const int nc = (F + 255) / 256;
@@ -467,10 +482,10 @@ int alignn_ln_silu_fwd(const float* X, int64_t ldx, const float* R, int64_t ldr,
 #define ALIGNN_LN_FWD(NC_)                                                                                         \
     if (R)                                                                                                         \
         hipLaunchKernelGGL((ln_silu_fwd_kernel<NC_, true>), grid, block, 0, st, X, ldx, R, ldr, gamma, beta, eps, Y, \
-                           ldy, stats, rows, F);                                                                   \
+                           ldy, stats, rows, F, amax);                                                                   \
     else                                                                                                           \
         hipLaunchKernelGGL((ln_silu_fwd_kernel<NC_, false>), grid, block, 0, st, X, ldx, R, ldr, gamma, beta, eps, Y, \
-                           ldy, stats, rows, F);
+                           ldy, stats, rows, F, amax);
     switch (nc) {
         case 1: ALIGNN_LN_FWD(1) break;
         case 2: ALIGNN_LN_FWD(2) break;
@@ -484,16 +499,16 @@ int alignn_ln_silu_fwd(const float* X, int64_t ldx, const float* R, int64_t ldr,
 
 int alignn_ln_silu_bwd(const float* GY, int64_t ldgy, const float* X, int64_t ldx, const float* gamma,
                        const float* beta, const float* stats, float* GX, int64_t ldgx, float* partial, int64_t rows,
-                       int F, alignn_stream_t stream) {
+                       int F, float* amax, alignn_stream_t stream) {
     if (!feat_ok(F)) return (int)hipErrorInvalidValue;
     const int nc = (F + 255) / 256;
     dim3 grid(ln_blocks(rows)), block(kThreads);
     hipStream_t st = (hipStream_t)stream;
     switch (nc) {
-        case 1: hipLaunchKernelGGL(ln_silu_bwd_kernel<1>, grid, block, 0, st, GY, ldgy, X, ldx, gamma, beta, stats, GX, ldgx, partial, rows, F); break;
-        case 2: hipLaunchKernelGGL(ln_silu_bwd_kernel<2>, grid, block, 0, st, GY, ldgy, X, ldx, gamma, beta, stats, GX, ldgx, partial, rows, F); break;
-        case 3: hipLaunchKernelGGL(ln_silu_bwd_kernel<3>, grid, block, 0, st, GY, ldgy, X, ldx, gamma, beta, stats, GX, ldgx, partial, rows, F); break;
-        default: hipLaunchKernelGGL(ln_silu_bwd_kernel<4>, grid, block, 0, st, GY, ldgy, X, ldx, gamma, beta, stats, GX, ldgx, partial, rows, F); break;
+        case 1: hipLaunchKernelGGL(ln_silu_bwd_kernel<1>, grid, block, 0, st, GY, ldgy, X, ldx, gamma, beta, stats, GX, ldgx, partial, rows, F, amax); break;
+        case 2: hipLaunchKernelGGL(ln_silu_bwd_kernel<2>, grid, block, 0, st, GY, ldgy, X, ldx, gamma, beta, stats, GX, ldgx, partial, rows, F, amax); break;
+        case 3: hipLaunchKernelGGL(ln_silu_bwd_kernel<3>, grid, block, 0, st, GY, ldgy, X, ldx, gamma, beta, stats, GX, ldgx, partial, rows, F, amax); break;
+        default: hipLaunchKernelGGL(ln_silu_bwd_kernel<4>, grid, block, 0, st, GY, ldgy, X, ldx, gamma, beta, stats, GX, ldgx, partial, rows, F, amax); break;
     }
     ALIGNN_CHECK_LAUNCH();
     return 0;
@@ -509,12 +524,12 @@ int alignn_slab_sum(const float* partial, int slabs, int width, float* out, alig
 
 int alignn_bn_silu_bwd_apply(const float* GY, int64_t ldgy, const float* X, int64_t ldx, const float* stat,
                              const float* gamma, const float* red, int eval_mode, float* GX, int64_t ldgx,
-                             int64_t rows, int F, alignn_stream_t stream) {
+                             int64_t rows, int F, float* amax, alignn_stream_t stream) {
     if (!feat_ok(F)) return (int)hipErrorInvalidValue;
     if (rows == 0) return 0;
     int grid = stream_grid(rows * (F >> 2));
     hipLaunchKernelGGL(bn_silu_bwd_apply_kernel, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, GY, ldgy, X, ldx,
-                       stat, gamma, red, eval_mode, GX, ldgx, rows, F);
+                       stat, gamma, red, eval_mode, GX, ldgx, rows, F, amax);
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }

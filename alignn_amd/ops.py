@@ -59,7 +59,8 @@ def on_side_stream(fn, inputs):
     with torch.cuda.stream(side):
         outs = fn()
     for t in inputs:
-        t.record_stream(side)
+        if t is not None:
+            t.record_stream(side)
     for o in outs:
         if o is not None:
             o.record_stream(main)
@@ -283,12 +284,13 @@ def _bn_silu_fwd(x, res, stat):
     lib = _lib.load()
     rows, F = x.shape
     y = _empty(rows, F, like=x)
+    amax = new_amax(x) if F16X3 else None  # max|y|, tracked by the kernel for the next projection of y
     check(
         lib.alignn_bn_silu_fwd(ptr(x), x.stride(0), ptr(res), res.stride(0) if res is not None else 0, ptr(stat),
-                               ptr(y), y.stride(0), rows, F, stream()),
+                               ptr(y), y.stride(0), rows, F, ptr(amax), stream()),
         "bn_silu_fwd",
     )
-    return y
+    return set_amax(y, amax) if amax is not None else y
 
 
 def _bn_silu_bwd_reduce(gy, x, stat):
@@ -307,12 +309,13 @@ def _bn_silu_bwd_reduce(gy, x, stat):
     return red
 
 
-def _bn_silu_bwd_apply(gy, x, stat, gamma, red, eval_mode, out):
+def _bn_silu_bwd_apply(gy, x, stat, gamma, red, eval_mode, out, amax=None):
+    """``amax`` (optional device scalar, zeroed by the caller) is raised to max|out|."""
     lib = _lib.load()
     rows, F = x.shape
     check(
         lib.alignn_bn_silu_bwd_apply(ptr(gy), gy.stride(0), ptr(x), x.stride(0), ptr(stat), ptr(gamma), ptr(red),
-                                     int(eval_mode), ptr(out), out.stride(0), rows, F, stream()),
+                                     int(eval_mode), ptr(out), out.stride(0), rows, F, ptr(amax), stream()),
         "bn_silu_bwd_apply",
     )
     return out
@@ -327,23 +330,26 @@ def _ln_silu_fwd(x, res, gamma, beta, want_stats=True):
     rows, F = x.shape
     y = _empty(rows, F, like=x)
     stats = _empty(rows, 2, like=x) if want_stats else None
+    amax = new_amax(x) if F16X3 else None
     check(
         lib.alignn_ln_silu_fwd(ptr(x), x.stride(0), ptr(res), res.stride(0) if res is not None else 0, ptr(gamma),
-                               ptr(beta), LN_EPS, ptr(y), y.stride(0), ptr(stats), rows, F, stream()),
+                               ptr(beta), LN_EPS, ptr(y), y.stride(0), ptr(stats), rows, F, ptr(amax), stream()),
         "ln_silu_fwd",
     )
+    if amax is not None:
+        set_amax(y, amax)
     return y, stats
 
 
-def _ln_silu_bwd(gy, x, gamma, beta, stats, out):
-    """LayerNorm/SiLU backward into ``out``; returns red [2,F] = (dbeta, dgamma)."""
+def _ln_silu_bwd(gy, x, gamma, beta, stats, out, amax=None):
+    """LayerNorm/SiLU backward into ``out`` (``amax``: raised to max|out|); returns red [2,F] = (dbeta, dgamma)."""
     lib = _lib.load()
     rows, F = x.shape
     slabs = lib.alignn_ln_slabs(rows)
     partial = _empty(slabs, 2, F, like=x)
     check(
         lib.alignn_ln_silu_bwd(ptr(gy), gy.stride(0), ptr(x), x.stride(0), ptr(gamma), ptr(beta), ptr(stats), ptr(out),
-                               out.stride(0), ptr(partial), rows, F, stream()),
+                               out.stride(0), ptr(partial), rows, F, ptr(amax), stream()),
         "ln_silu_bwd",
     )
     red = _empty(2, F, like=x)
@@ -408,7 +414,8 @@ class MLPLayerFn(torch.autograd.Function):
         lib = _lib.load()
         x = x.contiguous()
         w = w.contiguous()
-        pre = project(x, w, b)
+        ctx.x_amax = get_amax(x)
+        pre = project(x, w, b, a_amax=ctx.x_amax)
         rows, F = pre.shape
         if norm == "layer":
             y, stat = _ln_silu_fwd(pre, None, gamma, beta)
@@ -431,14 +438,16 @@ class MLPLayerFn(torch.autograd.Function):
         x, w, pre, stat, gamma, beta = ctx.saved_tensors
         gy = gy.contiguous()
         gpre = torch.empty_like(pre)
+        g_amax = new_amax(pre) if F16X3 else None
         if ctx.norm == "layer":
-            red = _ln_silu_bwd(gy, pre, gamma, beta, stat, gpre)
+            red = _ln_silu_bwd(gy, pre, gamma, beta, stat, gpre, g_amax)
         else:
             red = _bn_silu_bwd_reduce(gy, pre, stat)
-            _bn_silu_bwd_apply(gy, pre, stat, gamma, red, not ctx.training, gpre)
+            _bn_silu_bwd_apply(gy, pre, stat, gamma, red, not ctx.training, gpre, g_amax)
         dbeta, dgamma = red[0], red[1]
-        gx = _dgrad(gpre, w) if ctx.needs_input_grad[0] else None
-        gw, gb = on_side_stream(lambda: (gemm_tn(gpre, x), col_sum(gpre)), [gpre, x])
+        gx = _dgrad(gpre, w, g_amax=g_amax) if ctx.needs_input_grad[0] else None
+        x_amax = ctx.x_amax
+        gw, gb = on_side_stream(lambda: (gemm_tn(gpre, x, g_amax, x_amax), col_sum(gpre)), [gpre, x, g_amax, x_amax])
         return gx, gw, gb, dgamma, dbeta, None, None, None, None
 
 
@@ -463,8 +472,9 @@ class EdgeGatedConvFn(torch.autograd.Function):
         m = y.shape[0]
         if n != graph.n_nodes or m != graph.n_edges:
             raise ValueError(f"feature rows ({n},{m}) do not match graph ({graph.n_nodes},{graph.n_edges})")
-        P = project(x, wcat, bcat)  # [n,4H] = A | Bd | Bh | Ux
-        M = project(y, w_eg, b_eg)  # [m,H]  -> m_pre in place
+        ctx.x_amax, ctx.y_amax = get_amax(x), get_amax(y)  # tracked by the kernels that produced x and y
+        P = project(x, wcat, bcat, a_amax=ctx.x_amax)  # [n,4H] = A | Bd | Bh | Ux
+        M = project(y, w_eg, b_eg, a_amax=ctx.y_amax)  # [m,H]  -> m_pre in place
         xpre = _empty(n, H, like=x)
         s0 = _empty(n, H, like=x)
         hh = _empty(n, H, like=x)
@@ -515,13 +525,17 @@ class EdgeGatedConvFn(torch.autograd.Function):
             gx_out = torch.zeros_like(x)
         gx_out = gx_out.contiguous()
         GP = _empty(n, 4 * H, like=x)
+        # max|GP| (all four blocks: every kernel that writes a block raises the same scalar) and max|GM|, so that
+        # the input- and weight-gradient projections below can run the three-product scheme
+        gp_amax = new_amax(x) if F16X3 else None
+        gm_amax = new_amax(x) if F16X3 else None
         # node branch: SiLU/norm backward -> g_xpre (stored as the Ux block of GP)
         g_xpre = GP[:, 3 * H:]
         if layer:
-            n_red = _ln_silu_bwd(gx_out, xpre, n_gamma, n_beta, n_stat, g_xpre)
+            n_red = _ln_silu_bwd(gx_out, xpre, n_gamma, n_beta, n_stat, g_xpre, gp_amax)
         else:
             n_red = _bn_silu_bwd_reduce(gx_out, xpre, n_stat)
-            _bn_silu_bwd_apply(gx_out, xpre, n_stat, n_gamma, n_red, ev, g_xpre)
+            _bn_silu_bwd_apply(gx_out, xpre, n_stat, n_gamma, n_red, ev, g_xpre, gp_amax)
         gs1 = _empty(n, H, like=x)
         gs0 = _empty(n, H, like=x)
         check(lib.alignn_egc_node_bwd(ptr(g_xpre), 4 * H, ptr(s0), ptr(hh), ptr(gs1), ptr(gs0), n, H, stream()),
@@ -549,7 +563,7 @@ class EdgeGatedConvFn(torch.autograd.Function):
                                             ptr(e_red), int(ev), m, ptr(graph.grp_seg_ptr), ptr(graph.grp_src_ptr),
                                             gslabs, ptr(graph.seg_ptr), ptr(graph.seg_node), ptr(graph.dst),
                                             ptr(graph.out_ptr), ptr(graph.out_slot), H, ptr(GM), ptr(GP), ptr(gb_part),
-                                            stream()),
+                                            ptr(gm_amax), ptr(gp_amax), stream()),
                 "egc_bwd_lg_fused",
             )
         else:
@@ -558,26 +572,28 @@ class EdgeGatedConvFn(torch.autograd.Function):
             check(
                 lib.alignn_egc_bwd_dst(ptr(g_branch), ptr(M), ptr(P), ptr(gs1), ptr(gs0), ptr(e_stat_arg), ptr(e_gamma),
                                        ptr(e_red), int(ev), m, ptr(graph.seg_ptr), ptr(graph.seg_node), ptr(graph.src),
-                                       n, H, ptr(GM), ptr(GP), ptr(gb_part), stream()),
+                                       n, H, ptr(GM), ptr(GP), ptr(gb_part), ptr(gm_amax), ptr(gp_amax), stream()),
                 "egc_bwd_dst",
             )
             check(
                 lib.alignn_egc_bwd_src(ptr(GM), ptr(M), ptr(gs1), ptr(graph.out_ptr), ptr(graph.out_slot),
-                                       ptr(graph.dst), n, H, ptr(GP), stream()),
+                                       ptr(graph.dst), n, H, ptr(GP), ptr(gp_amax), stream()),
                 "egc_bwd_src",
             )
         # projections: weight gradients on the side stream, input gradients (critical path) on the main one
         def _wgrads():
             g_beg_ = _empty(H, like=x)  # column sum of GM, accumulated inside the destination-order pass
             check(lib.alignn_slab_sum(ptr(gb_part), gslabs, H, ptr(g_beg_), stream()), "slab_sum")
-            return gemm_tn(GM, y), g_beg_, gemm_tn(GP, x), col_sum(GP)
+            return gemm_tn(GM, y, gm_amax, y_amax), g_beg_, gemm_tn(GP, x, gp_amax, x_amax), col_sum(GP)
+
+        x_amax, y_amax = ctx.x_amax, ctx.y_amax
 
         # order matters: the side stream starts where the main stream stands at the on_side_stream() call.  Issue
         # the input-gradient GEMMs first, so the weight-gradient GEMMs (LDS-heavy, cannot share a CU with the x6
         # tiles) run beside the NEXT layer's HBM-bound kernels instead of fighting these GEMMs for whole CUs.
-        g_x = _dgrad(GP, wcat, addend=gx_out if ctx.residual else None)
-        g_y = _dgrad(GM, w_eg, addend=gy_out if (ctx.residual and gy_out is not None) else None)
-        g_weg, g_beg, g_wcat, g_bcat = on_side_stream(_wgrads, [GM, y, GP, x, gb_part])
+        g_x = _dgrad(GP, wcat, addend=gx_out if ctx.residual else None, g_amax=gp_amax)
+        g_y = _dgrad(GM, w_eg, addend=gy_out if (ctx.residual and gy_out is not None) else None, g_amax=gm_amax)
+        g_weg, g_beg, g_wcat, g_bcat = on_side_stream(_wgrads, [GM, y, GP, x, gb_part, gm_amax, gp_amax, x_amax, y_amax])
         dn_gamma, dn_beta = n_red[1], n_red[0]
         de_gamma = e_red[1] if e_red is not None else None
         de_beta = e_red[0] if e_red is not None else None

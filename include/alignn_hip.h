@@ -131,9 +131,12 @@ int alignn_bn_finalize(const float* partial, int slabs, int64_t rows, int F, con
                        const float* beta, float eps, float momentum, float* running_mean,
                        float* running_var, float* stat, alignn_stream_t stream);
 
-/* Y[r,f] = (R ? R[r,f] : 0) + silu((X[r,f]-mean[f])*scale[f] + beta[f]) */
+/* Y[r,f] = (R ? R[r,f] : 0) + silu((X[r,f]-mean[f])*scale[f] + beta[f])
+ * amax (here and below; may be NULL): device scalar the kernel raises to max|output| with one atomicMax per
+ * workgroup - the caller zeroes it first; several kernels writing parts of one tensor may share it.  It is what
+ * alignn_gemm_nt_f16x3 / alignn_gemm_tn need to run the next projection at half the matrix-core work. */
 int alignn_bn_silu_fwd(const float* X, int64_t ldx, const float* R, int64_t ldr, const float* stat,
-                       float* Y, int64_t ldy, int64_t rows, int F, alignn_stream_t stream);
+                       float* Y, int64_t ldy, int64_t rows, int F, float* amax, alignn_stream_t stream);
 
 /* backward, phase 1: partial[s][0][f] = sum_r gz, partial[s][1][f] = sum_r gz*xhat, where
  * z = (X-mean)*scale+beta, gz = GY * silu'(z), xhat = (X-mean)*rstd */
@@ -150,17 +153,18 @@ int alignn_bn_bwd_finalize(const float* partial, int slabs, int F, float* red, a
 int alignn_ln_slabs(int64_t rows);
 int alignn_ln_silu_fwd(const float* X, int64_t ldx, const float* R, int64_t ldr, const float* gamma,
                        const float* beta, float eps, float* Y, int64_t ldy, float* stats, int64_t rows, int F,
-                       alignn_stream_t stream);
+                       float* amax, alignn_stream_t stream);
 int alignn_ln_silu_bwd(const float* GY, int64_t ldgy, const float* X, int64_t ldx, const float* gamma,
                        const float* beta, const float* stats, float* GX, int64_t ldgx, float* partial,
-                       int64_t rows, int F, alignn_stream_t stream);
+                       int64_t rows, int F, float* amax, alignn_stream_t stream);
 /* out[f] = sum_s partial[s][f] over `slabs` slabs of `width` floats (fp64 accumulation, fixed order) */
 int alignn_slab_sum(const float* partial, int slabs, int width, float* out, alignn_stream_t stream);
 /* phase 2: GX = gamma*rstd*(gz - red0/rows - xhat*red1/rows)   (training-mode BatchNorm backward)
  * eval_mode != 0: GX = gz*scale (running statistics are constants) */
 int alignn_bn_silu_bwd_apply(const float* GY, int64_t ldgy, const float* X, int64_t ldx,
                              const float* stat, const float* gamma, const float* red, int eval_mode,
-                             float* GX, int64_t ldgx, int64_t rows, int F, alignn_stream_t stream);
+                             float* GX, int64_t ldgx, int64_t rows, int F, float* amax,
+                             alignn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Edge-gated graph convolution core (gather -> gate -> segment-sum), one wavefront per
@@ -201,13 +205,14 @@ int alignn_egc_node_bwd(const float* GXPRE, int64_t ldg, const float* S0, const 
  *   GM[e] = g_mbn + g_sigma*sigma*(1-sigma);   GP[i, H:2H] (g_Bd) = sum_e GM[e]
  * GP is the [n,4H] gradient of the fused node projection; this pass fills its Bd block.
  * gb_partial (optional): [alignn_egc_slabs(n_seg)][H] column-sum slabs of GM (the edge_gate bias gradient,
- * finished with alignn_slab_sum) - saves a separate pass over GM. */
+ * finished with alignn_slab_sum) - saves a separate pass over GM.
+ * gm_amax / gp_amax (optional): raised to max|GM| and max|the GP entries written here| (see alignn_bn_silu_fwd). */
 int alignn_egc_bwd_dst(const float* GY, const float* M, const float* P, const float* GS1,
                        const float* GS0, const float* e_stat, const float* e_gamma,
                        const float* e_red, int e_eval, int64_t m_rows,
                        const int32_t* seg_ptr, const int32_t* seg_node, const int32_t* src,
                        int64_t n_seg, int H, float* GM, float* GP, float* gb_partial,
-                       alignn_stream_t stream);
+                       float* gm_amax, float* gp_amax, alignn_stream_t stream);
 
 /* Line-graph backward with the destination- and source-ordered passes fused (one workgroup per centre atom j;
  * L(g)'s edges form one dense block per atom: sources = in-edges of j = L(g) nodes [grp_src_ptr[j],
@@ -219,14 +224,15 @@ int alignn_egc_bwd_lg_fused(const float* GY, const float* M, const float* P, con
                             int64_t m_rows, const int32_t* grp_seg_ptr, const int32_t* grp_src_ptr,
                             int64_t n_groups, const int32_t* seg_ptr, const int32_t* seg_node,
                             const int32_t* dst, const int32_t* out_ptr, const int32_t* out_slot, int H,
-                            float* GM, float* GP, float* gb_partial, alignn_stream_t stream);
+                            float* GM, float* GP, float* gb_partial, float* gm_amax, float* gp_amax,
+                            alignn_stream_t stream);
 
 /* Source-ordered backward pass (deterministic scatter-by-source):
  *   GP[j, 0:H]   (g_A)  = sum_{e: src e = j} GM[e]
  *   GP[j, 2H:3H] (g_Bh) = sum_{e: src e = j} sigmoid(M[e]) * GS1[dst e] */
 int alignn_egc_bwd_src(const float* GM, const float* M, const float* GS1, const int32_t* out_ptr,
                        const int32_t* out_slot, const int32_t* dst, int64_t n_nodes, int H,
-                       float* GP, alignn_stream_t stream);
+                       float* GP, float* gp_amax, alignn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Featurisation and readout.
