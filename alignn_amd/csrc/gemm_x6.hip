@@ -62,8 +62,24 @@ struct Sch {
     static constexpr int NPL = F16 ? 2 : 3;
     static constexpr int STAGE = A_BYTES + NPL * B_PLANE;            // 32 KiB / 24 KiB
     static constexpr int B_DMA = NPL * B_PLANE / 1024 / (NT / 64);   // pieces per wave
-    static constexpr int LDS = 2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES;  // two workgroups per CU
+#ifdef X6_NSTAGE
+    static constexpr int NSTAGE = X6_NSTAGE;
+#else
+    static constexpr int NSTAGE = 2;  // DMA ring depth (3 measured no faster for f16x3: the kernel is HBM-bound)
+#endif
+    static constexpr int LDS = NSTAGE * STAGE > EPI_BYTES ? NSTAGE * STAGE : EPI_BYTES;  // two workgroups per CU
 };
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// s_barrier without the vmcnt(0)/lgkmcnt(0) drain that __syncthreads() implies: DMA stages stay in flight across it
+__device__ __forceinline__ void block_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
 
 struct X6Args {
     const float* A;
@@ -238,13 +254,23 @@ __global__ __launch_bounds__(NT) void gemm_nt_x6_kernel(X6Args g) {
         inv_sw = 1.0f / f16_scale(*g.w_amax);
     }
 
+    // DMA ring of NSTAGE stages: stage kt+NSTAGE-1 is issued at the top of step kt (into the slot every wave has
+    // finished reading), so a stage has NSTAGE-1 k-steps to land; COUNTED vmcnt - only the stage about to be read
+    // must have arrived, younger ones stay in flight across the barrier.
+    constexpr int NSTAGE = Sch<F16>::NSTAGE, PIECES = A_DMA + B_DMA;
+    static_assert(NSTAGE == 2 || NSTAGE == 3, "vmcnt cases below");
     const int nk = g.K / BK;
-    issue(0, smem);
-    __syncthreads();
+#pragma unroll
+    for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
+        if (s0 < nk) issue(s0, smem + s0 * STAGE_BYTES);
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) issue(kt + 1, smem + (cur ^ 1) * STAGE_BYTES);
-        const unsigned char* stage = smem + cur * STAGE_BYTES;
+        if (NSTAGE == 3 && kt + 1 < nk)
+            wait_vmcnt<PIECES>();
+        else
+            wait_vmcnt<0>();
+        block_barrier();
+        if (kt + NSTAGE - 1 < nk) issue(kt + NSTAGE - 1, smem + ((kt + NSTAGE - 1) % NSTAGE) * STAGE_BYTES);
+        const unsigned char* stage = smem + (kt % NSTAGE) * STAGE_BYTES;
         if constexpr (F16) {
             f16x8 ah[RM], al[RM], bh[RN], bl[RN];
 #pragma unroll
@@ -292,7 +318,6 @@ __global__ __launch_bounds__(NT) void gemm_nt_x6_kernel(X6Args g) {
             X6_PASS(ah, bh)
 #undef X6_PASS
         }
-        __syncthreads();  // next stage has landed (the barrier drains the DMA), current one is free
     }
 
     // epilogue: per-wave LDS transpose of two 32x32 tiles at a time -> float4 row segments.  Per round: all LDS
@@ -355,7 +380,13 @@ constexpr int TSTAGE = G_BYTES + X_BYTES;              // 32 KiB
 constexpr int G_PIECES = G_BYTES / 1024, X_PIECES = X_BYTES / 1024;     // 16 + 16
 constexpr int PIECES_PER_WAVE = (G_PIECES + X_PIECES) / (TNT / 64);     // 4
 constexpr int TEPI = (TNT / 64) * 32 * (64 + 4) * 4;                    // 68 KiB of transpose patches
-constexpr int TLDS = 2 * TSTAGE > TEPI ? 2 * TSTAGE : TEPI;             // 68 KiB
+#ifndef X6_TN_NSTAGE
+#define X6_TN_NSTAGE 2
+#endif
+constexpr int TNS = X6_TN_NSTAGE;  // DMA ring depth (4 stages = 128 KiB measured no faster: the column reads, 48
+                                   // ds_read_b32 per wave and stage, bound this kernel, not the bytes in flight; and
+                                   // 68 KiB leaves room for a projection workgroup of the main stream on the same CU)
+constexpr int TLDS = TNS * TSTAGE > TEPI ? TNS * TSTAGE : TEPI;         // 68 KiB
 
 struct TnArgs {
     const float* G;
@@ -424,11 +455,23 @@ __global__ __launch_bounds__(TNT) void gemm_tn_x6_kernel(TnArgs g) {
         sx = f16_scale(*g.x_amax);
     }
 
-    if (nst > 0) issue(0, smem);
-    __syncthreads();
+#pragma unroll
+    for (int s0 = 0; s0 < TNS - 1; ++s0)
+        if (s0 < nst) issue(s0, smem + s0 * TSTAGE);
     for (int st = 0; st < nst; ++st) {
-        const int cur = st & 1;
-        if (st + 1 < nst) issue(st + 1, smem + (cur ^ 1) * TSTAGE);
+        // stage st must have landed; up to TNS-2 younger stages stay in flight across the barrier
+        const int younger = nst - 1 - st < TNS - 2 ? nst - 1 - st : TNS - 2;
+        if (younger >= 3)
+            wait_vmcnt<3 * PIECES_PER_WAVE>();
+        else if (younger == 2)
+            wait_vmcnt<2 * PIECES_PER_WAVE>();
+        else if (younger == 1)
+            wait_vmcnt<PIECES_PER_WAVE>();
+        else
+            wait_vmcnt<0>();
+        block_barrier();
+        if (st + TNS - 1 < nst) issue(st + TNS - 1, smem + ((st + TNS - 1) % TNS) * TSTAGE);
+        const int cur = st % TNS;
         const float* Gs = reinterpret_cast<const float*>(smem + cur * TSTAGE);
         const float* Xs = reinterpret_cast<const float*>(smem + cur * TSTAGE + G_BYTES);
         // rows of this stage that lie past the end of the slab (only in its last stage) contribute nothing
@@ -491,7 +534,6 @@ __global__ __launch_bounds__(TNT) void gemm_tn_x6_kernel(TnArgs g) {
             X6_TPASS(ah, bh)
 #undef X6_TPASS
         }
-        __syncthreads();
     }
 
     // epilogue: slab z of the workspace, rows n, cols k; per-wave LDS transpose -> float4 row segments

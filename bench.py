@@ -25,11 +25,12 @@ if ROOT not in sys.path:
 
 H = 256
 # HBM bytes per launch of the dominant kernel at this exact shape (T=676 200 rows), from rocprofv3 PMC passes
-# (profiles/r01_pmc_fetch_size.txt / r01_pmc_write_size.txt; separate --pmc FETCH_SIZE and --pmc WRITE_SIZE
-# runs): FETCH_SIZE 690.2 MiB, doubled as MI355X_MICROARCH.md prescribes for 16 B/lane streaming reads on
-# gfx950, + WRITE_SIZE 660.4 MiB.  PMC cannot be sampled from inside this process, so the measured value is
-# carried here and only reported when the workload matches the one it was measured on.
-PMC_TRAFFIC_X6_T676200 = (2 * 690.2 + 660.4) * 1024 * 1024
+# (profiles/r01_pmc_split_gemm.txt; separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of tools/x6_once.py):
+# FETCH_SIZE 342.0 MiB (f16x3) / 352.3 MiB (bf16x6), doubled as MI355X_MICROARCH.md prescribes for 16 B/lane
+# streaming reads on gfx950, + WRITE_SIZE 660.4 MiB.  PMC cannot be sampled from inside this process, so the
+# measured value is carried here and only reported when the workload matches the one it was measured on.
+PMC_TRAFFIC_F16X3_T676200 = (2 * 350220.9 + 676200.0) * 1024
+PMC_TRAFFIC_X6_T676200 = (2 * 360721.0 + 676200.0) * 1024
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F32_PEAK_TF = 157.3  # v_mfma_f32_32x32x2_f32 dense peak
 
@@ -207,21 +208,25 @@ def main():
     out = None
     if rank == 0:
         N, E, T = raw.num_nodes, raw.num_edges, raw.num_triplets
-        # ---- roofline of the dominant kernel: the line-graph edge_gate projection C[T,H] = z[T,H] W^T + b.
-        # It runs on the bf16 matrix cores as six slice products (fp32-grade accuracy, csrc/gemm_x6.hip), which
-        # lifts it off the 157 TF fp32-MFMA roof and makes it HBM-bound: algorithmic bytes per launch =
-        # read z + write C = 2*T*H*4 (the 384 KiB of sliced weights stay in L2).  Timed live with HIP events
-        # on the launch stream.  The exact-fp32 MFMA kernel is timed beside it for reference.
+        # ---- roofline of the dominant kernel: the line-graph edge_gate projection C[T,H] = z[T,H] W^T + b
+        # (gemm_nt_x6_kernel<*, true> in csrc/gemm_x6.hip).  It runs on the matrix cores as a split product with
+        # fp32-grade accuracy - three fp16-slice products, because the kernel that produced z tracked max|z| -,
+        # which lifts it off the 157 TF fp32-MFMA roof and makes it HBM-bound: algorithmic bytes per launch =
+        # read z + write C = 2*T*H*4 (the 256 KiB of sliced weights stay in L2).  Timed live with HIP events on
+        # the launch stream.  The six-product bf16 variant (used when max|z| is unknown) and the exact-fp32 MFMA
+        # kernel are timed beside it for reference.
         zt = torch.randn(T, H, device=dev)
         w = torch.randn(H, H, device=dev) / 16
         bz = torch.randn(H, device=dev)
         buf = torch.empty(T, H, device=dev)
         ws = ops.split_bf16x3(w)
+        wh, z_amax = ops.split_f16x2(w), ops.absmax(zt)
+        t_h3 = time_kernel(lambda: ops.gemm_nt_f16x3(zt, z_amax, wh, bz, out=buf))
         t_x6 = time_kernel(lambda: ops.gemm_nt_x6(zt, ws, bz, out=buf))
         t_f32 = time_kernel(lambda: ops.gemm_nt(zt, w, bz, out=buf))
         flops = 2.0 * T * H * H
         gemm_bytes = 2.0 * T * H * 4
-        gbs = gemm_bytes / (t_x6 * 1e-3) / 1e9
+        gbs = gemm_bytes / (t_h3 * 1e-3) / 1e9
         step_bytes = algorithmic_bytes_per_step(N, E, T)
         step_flops = algorithmic_flops_per_step(N, E, T)
         out = {
@@ -235,7 +240,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 (projections: 6 bf16-slice MFMA products, fp32 accumulate, fp32-grade error)",
+            "dtype": "f32 (projections: split-product MFMA - 3 fp16-slice or 6 bf16-slice products, fp32 accumulate, fp32-grade error)",
             "data": "synthetic",
             "config": {
                 "workload": f"BASELINE configs[1]: default ALIGNNConfig 4+4 layers hidden 256, batch {B}/GPU, "
@@ -248,18 +253,24 @@ def main():
                 "parallelism": f"dp{world}",
             },
             "roofline": {
-                "kernel": "gemm_nt_x6_kernel (line-graph edge_gate projection, M=T, N=K=256, bf16x6 split product)",
+                "kernel": "gemm_nt_x6_kernel<*,true> (line-graph edge_gate projection, M=T, N=K=256, f16x3 split product)",
                 "bound": "hbm",
                 "achieved": round(gbs, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(gbs / HBM_PEAK_GBS, 4),
-                "traffic": PMC_TRAFFIC_X6_T676200 if T == 676200 else None,
-                "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + --pmc WRITE_SIZE, profiles/r01_pmc_*.txt",
-                "ms_per_launch": round(t_x6, 4),
+                "traffic": PMC_TRAFFIC_F16X3_T676200 if T == 676200 else None,
+                "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + --pmc WRITE_SIZE, profiles/r01_pmc_split_gemm.txt",
+                "ms_per_launch": round(t_h3, 4),
                 "algorithmic_bytes_per_launch": gemm_bytes,
-                "equivalent_fp32_TFLOPs": round(flops / (t_x6 * 1e-3) / 1e12, 1),
-                "bf16_mfma_frac_of_2500TF": round(6 * flops / (t_x6 * 1e-3) / 1e12 / 2500.0, 4),
+                "equivalent_fp32_TFLOPs": round(flops / (t_h3 * 1e-3) / 1e12, 1),
+                "f16_mfma_frac_of_2500TF": round(3 * flops / (t_h3 * 1e-3) / 1e12 / 2500.0, 4),
+                "bf16x6_kernel_same_shape": {
+                    "ms_per_launch": round(t_x6, 4),
+                    "GBps": round(gemm_bytes / (t_x6 * 1e-3) / 1e9, 1),
+                    "traffic": PMC_TRAFFIC_X6_T676200 if T == 676200 else None,
+                    "bf16_mfma_frac_of_2500TF": round(6 * flops / (t_x6 * 1e-3) / 1e12 / 2500.0, 4),
+                },
                 "fp32_mfma_kernel_same_shape": {
                     "ms_per_launch": round(t_f32, 4),
                     "TFLOPs": round(flops / (t_f32 * 1e-3) / 1e12, 1),
