@@ -380,13 +380,9 @@ constexpr int TSTAGE = G_BYTES + X_BYTES;              // 32 KiB
 constexpr int G_PIECES = G_BYTES / 1024, X_PIECES = X_BYTES / 1024;     // 16 + 16
 constexpr int PIECES_PER_WAVE = (G_PIECES + X_PIECES) / (TNT / 64);     // 4
 constexpr int TEPI = (TNT / 64) * 32 * (64 + 4) * 4;                    // 68 KiB of transpose patches
-#ifndef X6_TN_NSTAGE
-#define X6_TN_NSTAGE 2
-#endif
-constexpr int TNS = X6_TN_NSTAGE;  // DMA ring depth (4 stages = 128 KiB measured no faster: the column reads, 48
-                                   // ds_read_b32 per wave and stage, bound this kernel, not the bytes in flight; and
-                                   // 68 KiB leaves room for a projection workgroup of the main stream on the same CU)
-constexpr int TLDS = TNS * TSTAGE > TEPI ? TNS * TSTAGE : TEPI;         // 68 KiB
+constexpr int TNS = 3;             // DMA ring depth of the ping-pong schedule (a 4-stage ring in lock step measured no
+                                   // faster than 2: the read/slice phases, not the bytes in flight, held the pipe up)
+constexpr int TLDS = TNS * TSTAGE > TEPI ? TNS * TSTAGE : TEPI;         // 96 KiB
 
 struct TnArgs {
     const float* G;
@@ -455,74 +451,70 @@ __global__ __launch_bounds__(TNT) void gemm_tn_x6_kernel(TnArgs g) {
         sx = f16_scale(*g.x_amax);
     }
 
-#pragma unroll
-    for (int s0 = 0; s0 < TNS - 1; ++s0)
-        if (s0 < nst) issue(s0, smem + s0 * TSTAGE);
+    // Ping-pong schedule: the two waves of a SIMD (wave w and w+4) run the SAME loop
+    //     { barrier A; issue DMA(st+2); READ+slice(st); wait DMA(st+1); barrier B; MFMA(st) }
+    // but the trailing group enters it one barrier late, so between any two barriers one of them owns the matrix
+    // pipe while the other does its 24 column reads (ds_read2_b32) and the slicing - in lock step the pipe idles
+    // through every read phase.  Stage st+2 reuses the slot of stage st-1: its last reader (the trailing group)
+    // is done before the barrier that precedes the issue.  3-stage ring, counted vmcnt.
+    static_assert(TNS == 3, "ring depth of the ping-pong schedule");
+    const int group = wave >> 2;
+    if (0 < nst) issue(0, smem);
+    if (1 < nst) issue(1, smem + TSTAGE);
+    if (nst > 1)
+        wait_vmcnt<PIECES_PER_WAVE>();
+    else
+        wait_vmcnt<0>();
+    block_barrier();
+    if (group == 1) block_barrier();
+    f16x8 fah[TRM], fal[TRM], fbh[TRN], fbl[TRN];
+    bf16x8 ah[TRM], am[TRM], al[TRM], bh[TRN], bm[TRN], bl[TRN];
     for (int st = 0; st < nst; ++st) {
-        // stage st must have landed; up to TNS-2 younger stages stay in flight across the barrier
-        const int younger = nst - 1 - st < TNS - 2 ? nst - 1 - st : TNS - 2;
-        if (younger >= 3)
-            wait_vmcnt<3 * PIECES_PER_WAVE>();
-        else if (younger == 2)
-            wait_vmcnt<2 * PIECES_PER_WAVE>();
-        else if (younger == 1)
-            wait_vmcnt<PIECES_PER_WAVE>();
-        else
-            wait_vmcnt<0>();
-        block_barrier();
-        if (st + TNS - 1 < nst) issue(st + TNS - 1, smem + ((st + TNS - 1) % TNS) * TSTAGE);
+        block_barrier();  // A_st
+        if (st + 2 < nst) issue(st + 2, smem + ((st + 2) % TNS) * TSTAGE);
         const int cur = st % TNS;
         const float* Gs = reinterpret_cast<const float*>(smem + cur * TSTAGE);
         const float* Xs = reinterpret_cast<const float*>(smem + cur * TSTAGE + G_BYTES);
         // rows of this stage that lie past the end of the slab (only in its last stage) contribute nothing
         const int valid = (int)((rend - (rbeg + (int64_t)st * TSTEP)) < TSTEP ? (rend - (rbeg + (int64_t)st * TSTEP)) : TSTEP);
+#pragma unroll
+        for (int a = 0; a < TRM; ++a) {
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int m = 8 * half + j;
+                const float v = Gs[m * TBN + wm * 64 + a * 32 + il];
+                x[j] = m < valid ? v : 0.0f;
+            }
+            if constexpr (F16)
+                slice8_f16(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]), sg, fah[a], fal[a]);
+            else
+                slice8(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]), ah[a], am[a], al[a]);
+        }
+#pragma unroll
+        for (int b = 0; b < TRN; ++b) {
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = Xs[(8 * half + j) * TBK + wn * 128 + b * 32 + il];
+            if constexpr (F16)
+                slice8_f16(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]), sx, fbh[b], fbl[b]);
+            else
+                slice8(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]), bh[b], bm[b], bl[b]);
+        }
+        if (st + 2 < nst)
+            wait_vmcnt<PIECES_PER_WAVE>();  // own pieces of stage st+1 have landed (stage st+2 may still fly)
+        else
+            wait_vmcnt<0>();
+        block_barrier();  // B_st
         if constexpr (F16) {
-            f16x8 ah[TRM], al[TRM], bh[TRN], bl[TRN];
-#pragma unroll
-            for (int a = 0; a < TRM; ++a) {
-                float x[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int m = 8 * half + j;
-                    const float v = Gs[m * TBN + wm * 64 + a * 32 + il];
-                    x[j] = m < valid ? v : 0.0f;
-                }
-                slice8_f16(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]), sg, ah[a], al[a]);
-            }
-#pragma unroll
-            for (int b = 0; b < TRN; ++b) {
-                float x[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) x[j] = Xs[(8 * half + j) * TBK + wn * 128 + b * 32 + il];
-                slice8_f16(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]), sx, bh[b], bl[b]);
-            }
 #define X6_TPASS(AA, BB)                                                                               \
     _Pragma("unroll") for (int a = 0; a < TRM; ++a) _Pragma("unroll") for (int b = 0; b < TRN; ++b)    \
         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AA[a], BB[b], acc[a][b], 0, 0, 0);
-            X6_TPASS(al, bh)
-            X6_TPASS(ah, bl)
-            X6_TPASS(ah, bh)
+            X6_TPASS(fal, fbh)
+            X6_TPASS(fah, fbl)
+            X6_TPASS(fah, fbh)
 #undef X6_TPASS
         } else {
-            bf16x8 ah[TRM], am[TRM], al[TRM], bh[TRN], bm[TRN], bl[TRN];
-#pragma unroll
-            for (int a = 0; a < TRM; ++a) {
-                float x[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int m = 8 * half + j;
-                    const float v = Gs[m * TBN + wm * 64 + a * 32 + il];
-                    x[j] = m < valid ? v : 0.0f;
-                }
-                slice8(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]), ah[a], am[a], al[a]);
-            }
-#pragma unroll
-            for (int b = 0; b < TRN; ++b) {
-                float x[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) x[j] = Xs[(8 * half + j) * TBK + wn * 128 + b * 32 + il];
-                slice8(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]), bh[b], bm[b], bl[b]);
-            }
 #define X6_TPASS(AA, BB)                                                                               \
     _Pragma("unroll") for (int a = 0; a < TRM; ++a) _Pragma("unroll") for (int b = 0; b < TRN; ++b)    \
         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AA[a], BB[b], acc[a][b], 0, 0, 0);
@@ -535,6 +527,7 @@ __global__ __launch_bounds__(TNT) void gemm_tn_x6_kernel(TnArgs g) {
 #undef X6_TPASS
         }
     }
+    if (group == 0) block_barrier();
 
     // epilogue: slab z of the workspace, rows n, cols k; per-wave LDS transpose -> float4 row segments
     constexpr int PLD = 64 + 4;
