@@ -18,6 +18,23 @@ __device__ __forceinline__ float fast_sigmoid(float x) { return 1.0f / (1.0f + _
 
 __device__ __forceinline__ float4 f4_ld(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void f4_st(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// streaming (read-once / write-once) variants: nontemporal hint, measured +9 % on a 2-read 1-write pass over 2 GB
+typedef float alignn_v4f __attribute__((ext_vector_type(4)));
+template <bool STREAM>
+__device__ __forceinline__ float4 f4_lds(const float* p) {
+    if (!STREAM) return *reinterpret_cast<const float4*>(p);
+    alignn_v4f v = __builtin_nontemporal_load(reinterpret_cast<const alignn_v4f*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+template <bool STREAM>
+__device__ __forceinline__ void f4_sts(float* p, float4 r) {
+    if (!STREAM) {
+        *reinterpret_cast<float4*>(p) = r;
+        return;
+    }
+    alignn_v4f v = {r.x, r.y, r.z, r.w};
+    __builtin_nontemporal_store(v, reinterpret_cast<alignn_v4f*>(p));
+}
 __device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ float4 f4_add(float4 a, float4 b) {
     return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
@@ -58,7 +75,10 @@ __device__ __forceinline__ void block_amax_commit(float m, float* amax) {
     if (threadIdx.x == 0) {
         float r = amax_sh[0];
         for (int w = 1; w < nw; ++w) r = fmaxf(r, amax_sh[w]);
-        if (r > 0.0f) atomicMax(reinterpret_cast<unsigned*>(amax), __float_as_uint(r));
+        // most workgroups find the running maximum already above their own: look before paying for the atomic (a
+        // stale read only costs a redundant atomicMax)
+        if (r > 0.0f && r > *reinterpret_cast<volatile float*>(amax))
+            atomicMax(reinterpret_cast<unsigned*>(amax), __float_as_uint(r));
     }
     __syncthreads();  // the scratch array may be reused by a second commit
 }

@@ -47,6 +47,7 @@ __device__ __forceinline__ void block_slab_store(float4 s, float4 ss, float* sla
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
+template <bool STREAM>
 __global__ __launch_bounds__(kThreads) void egc_gate_fwd_kernel(
     const float* __restrict__ P, float* __restrict__ M, const int32_t* __restrict__ seg_ptr,
     const int32_t* __restrict__ seg_node, const int32_t* __restrict__ src, int n_seg, int H,
@@ -82,12 +83,12 @@ __global__ __launch_bounds__(kThreads) void egc_gate_fwd_kernel(
                         const float* Pu = P + (int64_t)u[k] * ldp;
                         a[k] = f4_ld(Pu + f);
                         bh[k] = f4_ld(Pu + 2 * H + f);
-                        c[k] = f4_ld(M + (int64_t)(e + k) * H + f);
+                        c[k] = f4_lds<STREAM>(M + (int64_t)(e + k) * H + f);
                     }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         float4 m = f4_add(f4_add(a[k], bd), c[k]);
-                        f4_st(M + (int64_t)(e + k) * H + f, m);
+                        f4_sts<STREAM>(M + (int64_t)(e + k) * H + f, m);
                         float4 sg = f4_sigmoid(m);
                         s1 = f4_fma(sg, bh[k], s1);
                         s0 = f4_add(s0, sg);
@@ -97,8 +98,8 @@ __global__ __launch_bounds__(kThreads) void egc_gate_fwd_kernel(
                 }
                 for (; e < end; ++e) {
                     const float* Pu = P + (int64_t)src[e] * ldp;
-                    float4 m = f4_add(f4_add(f4_ld(Pu + f), bd), f4_ld(M + (int64_t)e * H + f));
-                    f4_st(M + (int64_t)e * H + f, m);
+                    float4 m = f4_add(f4_add(f4_ld(Pu + f), bd), f4_lds<STREAM>(M + (int64_t)e * H + f));
+                    f4_sts<STREAM>(M + (int64_t)e * H + f, m);
                     float4 sg = f4_sigmoid(m);
                     s1 = f4_fma(sg, f4_ld(Pu + 2 * H + f), s1);
                     s0 = f4_add(s0, sg);
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(kThreads) void egc_bwd_src_kernel(
 // 2 reads + 1 write per edge row instead of 4 reads + 1 write for the two separate passes; same summation
 // orders, so the results are bit-identical to them.
 // ---------------------------------------------------------------------------------------------
-template <int MODE>
+template <int MODE, bool STREAM>
 __global__ __launch_bounds__(kThreads) void egc_bwd_lg_fused_kernel(
     const float* __restrict__ GY, const float* __restrict__ M, const float* __restrict__ P,
     const float* __restrict__ GS1, const float* __restrict__ GS0, const float* __restrict__ e_stat,
@@ -383,8 +384,8 @@ __global__ __launch_bounds__(kThreads) void egc_bwd_lg_fused_kernel(
                     for (int t = 0; t < 4; ++t) {
                         slot[t] = out_slot[k + t];
                         const int v = dst[slot[t]];
-                        m[t] = f4_ld(M + (int64_t)slot[t] * H + f);
-                        if (HAS_GY) gy[t] = f4_ld(GY + (int64_t)slot[t] * H + f);
+                        m[t] = f4_lds<STREAM>(M + (int64_t)slot[t] * H + f);
+                        if (HAS_GY) gy[t] = f4_lds<STREAM>(GY + (int64_t)slot[t] * H + f);
                         g1[t] = f4_ld(GS1 + (int64_t)v * H + f);
                         g0[t] = f4_ld(GS0 + (int64_t)v * H + f);
                     }
@@ -400,9 +401,9 @@ __global__ __launch_bounds__(kThreads) void egc_bwd_lg_fused_kernel(
                 for (; k < end; ++k) {
                     const int slot = out_slot[k];
                     const int v = dst[slot];
-                    float4 m = f4_ld(M + (int64_t)slot * H + f);
+                    float4 m = f4_lds<STREAM>(M + (int64_t)slot * H + f);
                     float4 gy = f4_zero();
-                    if (HAS_GY) gy = f4_ld(GY + (int64_t)slot * H + f);
+                    if (HAS_GY) gy = f4_lds<STREAM>(GY + (int64_t)slot * H + f);
                     float4 g1 = f4_ld(GS1 + (int64_t)v * H + f), g0 = f4_ld(GS0 + (int64_t)v * H + f);
                     float4 gm = edge_grad<MODE>(m, gy, bh, g1, g0, nrm, inv_n, e_eval);
                     f4_st(GM + (int64_t)slot * H + f, gm);
@@ -443,6 +444,7 @@ __global__ __launch_bounds__(kThreads) void egc_bwd_lg_fused_kernel(
     block_amax_commit(gp_am, gp_amax);
 }
 
+inline bool big_stream(int64_t rows, int H) { return rows * (int64_t)H * 4 >= (int64_t)128 << 20; }
 inline bool h_ok(int H) { return H >= 4 && (H & 3) == 0 && H <= 1024; }
 
 }  // namespace
@@ -452,12 +454,15 @@ extern "C" {
 int alignn_egc_slabs(int64_t n_seg) { return egc_blocks(n_seg); }
 
 int alignn_egc_gate_fwd(const float* P, float* M, const int32_t* seg_ptr, const int32_t* seg_node,
-                        const int32_t* src, int64_t n_seg, int64_t n_nodes, int H, float* XPRE, float* S0, float* HH,
+                        const int32_t* src, int64_t n_seg, int64_t m_rows, int H, float* XPRE, float* S0, float* HH,
                         float* e_partial, float* n_partial, alignn_stream_t stream) {
-    (void)n_nodes;
-    if (!h_ok(H) || n_seg < 0 || n_seg > INT32_MAX) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(egc_gate_fwd_kernel, dim3(egc_blocks(n_seg)), dim3(kThreads), 0, (hipStream_t)stream, P, M,
-                       seg_ptr, seg_node, src, (int)n_seg, H, XPRE, S0, HH, e_partial, n_partial);
+    if (!h_ok(H) || n_seg < 0 || n_seg > INT32_MAX || m_rows < 0) return (int)hipErrorInvalidValue;
+    if (big_stream(m_rows, H))  // M cannot stay in the last-level cache: read-once / write-once hints
+        hipLaunchKernelGGL(egc_gate_fwd_kernel<true>, dim3(egc_blocks(n_seg)), dim3(kThreads), 0, (hipStream_t)stream, P,
+                           M, seg_ptr, seg_node, src, (int)n_seg, H, XPRE, S0, HH, e_partial, n_partial);
+    else
+        hipLaunchKernelGGL(egc_gate_fwd_kernel<false>, dim3(egc_blocks(n_seg)), dim3(kThreads), 0, (hipStream_t)stream, P,
+                           M, seg_ptr, seg_node, src, (int)n_seg, H, XPRE, S0, HH, e_partial, n_partial);
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }
@@ -510,15 +515,21 @@ int alignn_egc_bwd_lg_fused(const float* GY, const float* M, const float* P, con
     dim3 grid((int)n_groups), block(kThreads);
     hipStream_t st = (hipStream_t)stream;
 #define ALIGNN_LGF(MODE_)                                                                                           \
-    hipLaunchKernelGGL(egc_bwd_lg_fused_kernel<MODE_>, grid, block, 0, st, GY, M, P, GS1, GS0, e_stat, e_red, e_eval,  \
-                       inv_n, grp_seg_ptr, grp_src_ptr, seg_ptr, seg_node, dst, out_ptr, out_slot, H, GM, GP,       \
-                       gb_partial, gm_amax, gp_amax)
-    if (GY && e_stat)
+    if (big_stream(m_rows, H))                                                                                      \
+        hipLaunchKernelGGL((egc_bwd_lg_fused_kernel<MODE_, true>), grid, block, 0, st, GY, M, P, GS1, GS0, e_stat,     \
+                           e_red, e_eval, inv_n, grp_seg_ptr, grp_src_ptr, seg_ptr, seg_node, dst, out_ptr, out_slot, \
+                           H, GM, GP, gb_partial, gm_amax, gp_amax);                                                \
+    else                                                                                                            \
+        hipLaunchKernelGGL((egc_bwd_lg_fused_kernel<MODE_, false>), grid, block, 0, st, GY, M, P, GS1, GS0, e_stat,    \
+                           e_red, e_eval, inv_n, grp_seg_ptr, grp_src_ptr, seg_ptr, seg_node, dst, out_ptr, out_slot, \
+                           H, GM, GP, gb_partial, gm_amax, gp_amax)
+    if (GY && e_stat) {
         ALIGNN_LGF(1);
-    else if (GY)
+    } else if (GY) {
         ALIGNN_LGF(2);
-    else
+    } else {
         ALIGNN_LGF(0);
+    }
 #undef ALIGNN_LGF
     ALIGNN_CHECK_LAUNCH();
     return 0;

@@ -96,6 +96,7 @@ struct X6Args {
     int N;
     int Npad;
     int K;
+    int stream_out;  // C cannot stay in the last-level cache: write-once hint on its stores
 };
 
 __device__ __forceinline__ unsigned hi_pair(float x1, float x0) {
@@ -356,7 +357,12 @@ __global__ __launch_bounds__(NT) void gemm_nt_x6_kernel(X6Args g) {
             if constexpr (F16) v = f4_scale(f4_scale(v, inv_sa), inv_sw);
             v = f4_add(v, bias_v[hb]);
             if (HAS_ADD) v = f4_add(v, av[i]);
-            if (row < g.M && col < g.N) f4_st(g.C + row * g.ldc + col, v);
+            if (row < g.M && col < g.N) {
+                if (g.stream_out)
+                    f4_sts<true>(g.C + row * g.ldc + col, v);
+                else
+                    f4_st(g.C + row * g.ldc + col, v);
+            }
         }
     }
 }
@@ -374,15 +380,14 @@ namespace tn {
 constexpr int TBN = 256, TBK = 256, TSTEP = 16;        // output tile (n x k), reduction rows per stage
 constexpr int TWM = 4, TWN = 2, TNT = TWM * TWN * 64;  // 8 waves of 64(n) x 128(k): every input row is read ONCE
 constexpr int TRM = 2, TRN = 4;
-constexpr int G_BYTES = TSTEP * TBN * 4;               // 16 KiB
-constexpr int X_BYTES = TSTEP * TBK * 4;               // 16 KiB
-constexpr int TSTAGE = G_BYTES + X_BYTES;              // 32 KiB
-constexpr int G_PIECES = G_BYTES / 1024, X_PIECES = X_BYTES / 1024;     // 16 + 16
-constexpr int PIECES_PER_WAVE = (G_PIECES + X_PIECES) / (TNT / 64);     // 4
-constexpr int TEPI = (TNT / 64) * 32 * (64 + 4) * 4;                    // 68 KiB of transpose patches
-constexpr int TNS = 3;             // DMA ring depth of the ping-pong schedule (a 4-stage ring in lock step measured no
-                                   // faster than 2: the read/slice phases, not the bytes in flight, held the pipe up)
-constexpr int TLDS = TNS * TSTAGE > TEPI ? TNS * TSTAGE : TEPI;         // 96 KiB
+constexpr int TPLANE = TBN * TSTEP * 2;                // one 16-bit slice plane of one operand stage: [256][16] = 8 KiB
+constexpr int TEPI = (TNT / 64) * 32 * (64 + 4) * 4;   // 68 KiB of transpose patches
+template <bool F16>
+struct TSch {
+    static constexpr int NPL = F16 ? 2 : 3;
+    static constexpr int BUF = 2 * NPL * TPLANE;       // sliced G planes + sliced X planes of one stage: 32 / 48 KiB
+    static constexpr int LDS = 2 * BUF > TEPI ? 2 * BUF : TEPI;  // 68 / 96 KiB
+};
 
 struct TnArgs {
     const float* G;
@@ -398,9 +403,18 @@ struct TnArgs {
     const float* x_amax;
 };
 
+// dW tile = G_slab^T X_slab.  Both operands are activations, and the MFMA wants, per lane, 8 consecutive reduction
+// rows m of ONE column - a column access of the row-major inputs.  Every thread therefore owns one column of the
+// stage (threads 0-255: G, 256-511: X), fetches its 16 rows with 16 coalesced global_load_dword (a wave reads 256
+// contiguous bytes of one row per instruction; two stages stay in flight in registers), slices them ONCE and writes
+// the 16-bit slices to LDS k-contiguous - the layout the weight image of the NT kernel has - so that every wave then
+// picks up its operands with ds_read_b128.  (The first version DMA'd fp32 rows to LDS and let each wave slice the
+// columns it needed: 3x redundant slicing, and at 4 cycles per wave64 VALU instruction the slicing, not the
+// matrix pipe or HBM, bound the kernel - SQ_ACTIVE_INST_VALU 29 % of all wave cycles.)
 template <bool F16>
 __global__ __launch_bounds__(TNT) void gemm_tn_x6_kernel(TnArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NPL = TSch<F16>::NPL, BUF = TSch<F16>::BUF;
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -426,108 +440,111 @@ __global__ __launch_bounds__(TNT) void gemm_tn_x6_kernel(TnArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
-    // DMA: piece q of a stage = 1 KiB = one 256-float row: q < 16 of G, else of X
-    auto issue = [&](int st, unsigned char* stage) {
-#pragma unroll
-        for (int i = 0; i < PIECES_PER_WAVE; ++i) {
-            const int q = wave * PIECES_PER_WAVE + i;
-            const float* src;
-            if (q < G_PIECES) {
-                int64_t row = rbeg + (int64_t)st * TSTEP + q;
-                if (row >= g.M) row = g.M - 1;  // clamped; its contribution is masked below
-                src = g.G + row * g.ldg + n0 + lane * 4;
-            } else {
-                int64_t row = rbeg + (int64_t)st * TSTEP + (q - G_PIECES);
-                if (row >= g.M) row = g.M - 1;
-                src = g.X + row * g.ldx + k0 + lane * 4;
-            }
-            dma16<0>(src, stage + q * 1024);
-        }
-    };
-
-    float sg = 1.0f, sx = 1.0f;
+    // ---- loader role: one column of G (waves 0-3) or of X (waves 4-7)
+    const bool is_x = wave >= 4;  // wave-uniform
+    const int col = t & 255;
+    const float* src = is_x ? g.X + k0 + col : g.G + n0 + col;
+    const int64_t ld = is_x ? g.ldx : g.ldg;
+    float scale = 1.0f, inv_scale = 1.0f;
     if constexpr (F16) {
-        sg = f16_scale(*g.g_amax);
-        sx = f16_scale(*g.x_amax);
+        const float sg = f16_scale(*g.g_amax), sx = f16_scale(*g.x_amax);
+        scale = is_x ? sx : sg;
+        inv_scale = (1.0f / sg) * (1.0f / sx);
+    }
+    // sliced-stage LDS image, per operand: [plane][column 256][chunk 2, swizzled][8 x 16 bit]
+    const int w_off = (is_x ? NPL * TPLANE : 0) + col * (TSTEP * 2);
+    const int w_swz = (col >> 3) & 1;
+    // ---- consumer role: operand addresses of this wave's tiles
+    int a_off[TRM], b_off[TRN];
+#pragma unroll
+    for (int a = 0; a < TRM; ++a) {
+        const int n = wm * 64 + a * 32 + il;
+        a_off[a] = n * (TSTEP * 2) + ((half ^ ((n >> 3) & 1)) << 4);
+    }
+#pragma unroll
+    for (int b = 0; b < TRN; ++b) {
+        const int k = wn * 128 + b * 32 + il;
+        b_off[b] = NPL * TPLANE + k * (TSTEP * 2) + ((half ^ ((k >> 3) & 1)) << 4);
     }
 
-    // Ping-pong schedule: the two waves of a SIMD (wave w and w+4) run the SAME loop
-    //     { barrier A; issue DMA(st+2); READ+slice(st); wait DMA(st+1); barrier B; MFMA(st) }
-    // but the trailing group enters it one barrier late, so between any two barriers one of them owns the matrix
-    // pipe while the other does its 24 column reads (ds_read2_b32) and the slicing - in lock step the pipe idles
-    // through every read phase.  Stage st+2 reuses the slot of stage st-1: its last reader (the trailing group)
-    // is done before the barrier that precedes the issue.  3-stage ring, counted vmcnt.
-    static_assert(TNS == 3, "ring depth of the ping-pong schedule");
-    const int group = wave >> 2;
-    if (0 < nst) issue(0, smem);
-    if (1 < nst) issue(1, smem + TSTAGE);
-    if (nst > 1)
-        wait_vmcnt<PIECES_PER_WAVE>();
-    else
-        wait_vmcnt<0>();
-    block_barrier();
-    if (group == 1) block_barrier();
-    f16x8 fah[TRM], fal[TRM], fbh[TRN], fbl[TRN];
-    bf16x8 ah[TRM], am[TRM], al[TRM], bh[TRN], bm[TRN], bl[TRN];
-    for (int st = 0; st < nst; ++st) {
-        block_barrier();  // A_st
-        if (st + 2 < nst) issue(st + 2, smem + ((st + 2) % TNS) * TSTAGE);
-        const int cur = st % TNS;
-        const float* Gs = reinterpret_cast<const float*>(smem + cur * TSTAGE);
-        const float* Xs = reinterpret_cast<const float*>(smem + cur * TSTAGE + G_BYTES);
-        // rows of this stage that lie past the end of the slab (only in its last stage) contribute nothing
-        const int valid = (int)((rend - (rbeg + (int64_t)st * TSTEP)) < TSTEP ? (rend - (rbeg + (int64_t)st * TSTEP)) : TSTEP);
-#pragma unroll
-        for (int a = 0; a < TRM; ++a) {
-            float x[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int m = 8 * half + j;
-                const float v = Gs[m * TBN + wm * 64 + a * 32 + il];
-                x[j] = m < valid ? v : 0.0f;
-            }
-            if constexpr (F16)
-                slice8_f16(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]), sg, fah[a], fal[a]);
-            else
-                slice8(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]), ah[a], am[a], al[a]);
-        }
-#pragma unroll
-        for (int b = 0; b < TRN; ++b) {
-            float x[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) x[j] = Xs[(8 * half + j) * TBK + wn * 128 + b * 32 + il];
-            if constexpr (F16)
-                slice8_f16(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]), sx, fbh[b], fbl[b]);
-            else
-                slice8(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]), bh[b], bm[b], bl[b]);
-        }
-        if (st + 2 < nst)
-            wait_vmcnt<PIECES_PER_WAVE>();  // own pieces of stage st+1 have landed (stage st+2 may still fly)
-        else
-            wait_vmcnt<0>();
-        block_barrier();  // B_st
-        if constexpr (F16) {
-#define X6_TPASS(AA, BB)                                                                               \
-    _Pragma("unroll") for (int a = 0; a < TRM; ++a) _Pragma("unroll") for (int b = 0; b < TRN; ++b)    \
-        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AA[a], BB[b], acc[a][b], 0, 0, 0);
-            X6_TPASS(fal, fbh)
-            X6_TPASS(fah, fbl)
-            X6_TPASS(fah, fbh)
-#undef X6_TPASS
-        } else {
-#define X6_TPASS(AA, BB)                                                                               \
-    _Pragma("unroll") for (int a = 0; a < TRM; ++a) _Pragma("unroll") for (int b = 0; b < TRN; ++b)    \
-        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AA[a], BB[b], acc[a][b], 0, 0, 0);
-            X6_TPASS(al, bh)
-            X6_TPASS(ah, bl)
-            X6_TPASS(am, bm)
-            X6_TPASS(am, bh)
-            X6_TPASS(ah, bm)
-            X6_TPASS(ah, bh)
-#undef X6_TPASS
-        }
+    float ra[TSTEP], rb[TSTEP];  // two stages of this thread's column in flight
+#define TN_LOAD(R, ST)                                                             \
+    if ((ST) < nst && (!X6_ABL_NOALOAD || (ST) < 2)) {                                                              \
+        _Pragma("unroll") for (int m = 0; m < TSTEP; ++m) {                        \
+            int64_t row = rbeg + (int64_t)(ST) * TSTEP + m;                        \
+            row = row < g.M ? row : g.M - 1; /* clamped; masked when sliced */     \
+            R[m] = __builtin_nontemporal_load(src + row * ld);                     \
+        }                                                                          \
     }
-    if (group == 0) block_barrier();
+    // slice the landed stage into the LDS image `buf`, refill the registers with stage ST+2, hand over, multiply
+#define TN_STEP(R, ST, BUFI)                                                                                    \
+    if ((ST) < nst) {                                                                                           \
+        if ((ST) + 1 < nst)                                                                                     \
+            wait_vmcnt<TSTEP>();                                                                                \
+        else                                                                                                    \
+            wait_vmcnt<0>();                                                                                    \
+        unsigned char* buf = smem + (BUFI) * BUF;                                                               \
+        const int valid = (int)((rend - (rbeg + (int64_t)(ST) * TSTEP)) < TSTEP ? (rend - (rbeg + (int64_t)(ST) * TSTEP)) : TSTEP); \
+        _Pragma("unroll") for (int c = 0; c < 2; ++c) {                                                         \
+            float x[8];                                                                                         \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) x[j] = (8 * c + j) < valid ? R[8 * c + j] : 0.0f;     \
+            unsigned char* dst = buf + w_off + ((c ^ w_swz) << 4);                                              \
+            if constexpr (F16) {                                                                                \
+                f16x8 h, l;                                                                                     \
+                slice8_f16(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]), scale, h, l); \
+                *reinterpret_cast<f16x8*>(dst) = h;                                                             \
+                *reinterpret_cast<f16x8*>(dst + TPLANE) = l;                                                    \
+            } else {                                                                                            \
+                bf16x8 h, mm, l;                                                                                \
+                slice8(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]), h, mm, l);     \
+                *reinterpret_cast<bf16x8*>(dst) = h;                                                            \
+                *reinterpret_cast<bf16x8*>(dst + TPLANE) = mm;                                                  \
+                *reinterpret_cast<bf16x8*>(dst + 2 * TPLANE) = l;                                               \
+            }                                                                                                   \
+        }                                                                                                       \
+        TN_LOAD(R, (ST) + 2)                                                                                    \
+        block_barrier(); /* slices of stage ST visible; every wave is past its reads of the other buffer */    \
+        if constexpr (F16) {                                                                                    \
+            f16x8 ah[TRM], al[TRM], bh[TRN], bl[TRN];                                                           \
+            _Pragma("unroll") for (int a = 0; a < TRM; ++a) {                                                   \
+                ah[a] = *reinterpret_cast<const f16x8*>(buf + a_off[a]);                                        \
+                al[a] = *reinterpret_cast<const f16x8*>(buf + a_off[a] + TPLANE);                               \
+            }                                                                                                   \
+            _Pragma("unroll") for (int b = 0; b < TRN; ++b) {                                                   \
+                bh[b] = *reinterpret_cast<const f16x8*>(buf + b_off[b]);                                        \
+                bl[b] = *reinterpret_cast<const f16x8*>(buf + b_off[b] + TPLANE);                               \
+            }                                                                                                   \
+            if (!X6_ABL_ONEMFMA) { TN_PASS(f16, al, bh) TN_PASS(f16, ah, bl) }                                  \
+            TN_PASS(f16, ah, bh)                                                                                \
+        } else {                                                                                                \
+            bf16x8 ah[TRM], am[TRM], al[TRM], bh[TRN], bm[TRN], bl[TRN];                                        \
+            _Pragma("unroll") for (int a = 0; a < TRM; ++a) {                                                   \
+                ah[a] = *reinterpret_cast<const bf16x8*>(buf + a_off[a]);                                       \
+                am[a] = *reinterpret_cast<const bf16x8*>(buf + a_off[a] + TPLANE);                              \
+                al[a] = *reinterpret_cast<const bf16x8*>(buf + a_off[a] + 2 * TPLANE);                          \
+            }                                                                                                   \
+            _Pragma("unroll") for (int b = 0; b < TRN; ++b) {                                                   \
+                bh[b] = *reinterpret_cast<const bf16x8*>(buf + b_off[b]);                                       \
+                bm[b] = *reinterpret_cast<const bf16x8*>(buf + b_off[b] + TPLANE);                              \
+                bl[b] = *reinterpret_cast<const bf16x8*>(buf + b_off[b] + 2 * TPLANE);                          \
+            }                                                                                                   \
+            TN_PASS(bf16, al, bh) TN_PASS(bf16, ah, bl) TN_PASS(bf16, am, bm)                                   \
+            TN_PASS(bf16, am, bh) TN_PASS(bf16, ah, bm) TN_PASS(bf16, ah, bh)                                   \
+        }                                                                                                       \
+    }
+#define TN_PASS(TY, AA, BB)                                                                            \
+    _Pragma("unroll") for (int a = 0; a < TRM; ++a) _Pragma("unroll") for (int b = 0; b < TRN; ++b)    \
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_##TY(AA[a], BB[b], acc[a][b], 0, 0, 0);
+
+    TN_LOAD(ra, 0)
+    TN_LOAD(rb, 1)
+    for (int st = 0; st < nst; st += 2) {
+        TN_STEP(ra, st, 0)
+        TN_STEP(rb, st + 1, 1)
+    }
+#undef TN_PASS
+#undef TN_STEP
+#undef TN_LOAD
 
     // epilogue: slab z of the workspace, rows n, cols k; per-wave LDS transpose -> float4 row segments
     constexpr int PLD = 64 + 4;
@@ -547,13 +564,13 @@ __global__ __launch_bounds__(TNT) void gemm_tn_x6_kernel(TnArgs g) {
         float4 ov[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) ov[i] = f4_ld(patch + (i * 4 + prow) * PLD + pc4);
-        const int col = k0 + wn * 128 + hb * 64 + pc4;
+        const int ocol = k0 + wn * 128 + hb * 64 + pc4;
         const int row0 = n0 + wm * 64 + a * 32 + prow;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             float4 v = ov[i];
-            if constexpr (F16) v = f4_scale(f4_scale(v, 1.0f / sg), 1.0f / sx);
-            f4_st(out + (int64_t)(row0 + i * 4) * g.K + col, v);
+            if constexpr (F16) v = f4_scale(v, inv_scale);
+            f4_st(out + (int64_t)(row0 + i * 4) * g.K + ocol, v);
         }
     }
 }
@@ -730,21 +747,21 @@ int alignn_gemm_tn_x6_partials(const float* G, int64_t ldg, const float* g_amax,
     tn::TnArgs g{G, ldg, X, ldx, (float*)workspace, M, N, K, tn::tn_chunk(M, N, K), N / tn::TBN, K / tn::TBK,
                  tn::tn_splits(M, N, K), g_amax, x_amax};
     static bool tn_attr = false;
-    if (!tn_attr && tn::TLDS > 64 * 1024) {
+    if (!tn_attr && true) {
         hipError_t e = hipFuncSetAttribute((const void*)tn::gemm_tn_x6_kernel<false>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, tn::TLDS);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, tn::TSch<false>::LDS);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)tn::gemm_tn_x6_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    tn::TLDS);
+                                    tn::TSch<true>::LDS);
         if (e != hipSuccess) return (int)e;
         tn_attr = true;
     }
     const int tiles = g.tiles_n * g.tiles_k;
     const int per_xcd = alignn_ceil_div(g.splits, 8) * tiles;
     if (g_amax)
-        hipLaunchKernelGGL(tn::gemm_tn_x6_kernel<true>, dim3(per_xcd * 8), dim3(tn::TNT), tn::TLDS, (hipStream_t)stream, g);
+        hipLaunchKernelGGL(tn::gemm_tn_x6_kernel<true>, dim3(per_xcd * 8), dim3(tn::TNT), tn::TSch<true>::LDS, (hipStream_t)stream, g);
     else
-        hipLaunchKernelGGL(tn::gemm_tn_x6_kernel<false>, dim3(per_xcd * 8), dim3(tn::TNT), tn::TLDS, (hipStream_t)stream, g);
+        hipLaunchKernelGGL(tn::gemm_tn_x6_kernel<false>, dim3(per_xcd * 8), dim3(tn::TNT), tn::TSch<false>::LDS, (hipStream_t)stream, g);
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }
@@ -755,7 +772,8 @@ int alignn_gemm_nt_x6(const float* A, int64_t lda, const void* Wsplit, const flo
                       int64_t ldadd, float* C, int64_t ldc, int64_t M, int N, int K, alignn_stream_t stream) {
     if (!alignn_gemm_nt_x6_supported(M, N, K)) return (int)hipErrorInvalidValue;
     if (!nt_args_ok(A, lda, Wsplit, bias, addend, ldadd, C, ldc)) return (int)hipErrorInvalidValue;
-    X6Args g{A, lda, (const unsigned char*)Wsplit, nullptr, nullptr, bias, addend, ldadd, C, ldc, M, N, npad(N), K};
+    X6Args g{A, lda, (const unsigned char*)Wsplit, nullptr, nullptr, bias, addend, ldadd, C, ldc, M, N, npad(N), K,
+             M * (int64_t)N * 4 >= ((int64_t)128 << 20)};
     return launch_nt<false>(g, (hipStream_t)stream);
 }
 
@@ -764,7 +782,8 @@ int alignn_gemm_nt_f16x3(const float* A, int64_t lda, const float* a_amax, const
                          int K, alignn_stream_t stream) {
     if (!alignn_gemm_nt_x6_supported(M, N, K) || a_amax == nullptr || w_amax == nullptr) return (int)hipErrorInvalidValue;
     if (!nt_args_ok(A, lda, Wsplit, bias, addend, ldadd, C, ldc)) return (int)hipErrorInvalidValue;
-    X6Args g{A, lda, (const unsigned char*)Wsplit, a_amax, w_amax, bias, addend, ldadd, C, ldc, M, N, npad(N), K};
+    X6Args g{A, lda, (const unsigned char*)Wsplit, a_amax, w_amax, bias, addend, ldadd, C, ldc, M, N, npad(N), K,
+             M * (int64_t)N * 4 >= ((int64_t)128 << 20)};
     return launch_nt<true>(g, (hipStream_t)stream);
 }
 

@@ -33,20 +33,20 @@ __global__ __launch_bounds__(kThreads) void col_reduce_kernel(Fn fn, int64_t row
     const int t = threadIdx.x;
     const int q = t % Q;
     const int rl = t / Q;
-    const int64_t per = (rows + slabs - 1) / slabs;
-    const int64_t r0 = (int64_t)blockIdx.x * per;
-    int64_t r1 = r0 + per;
-    if (r1 > rows) r1 = rows;
+    // slab b owns the row groups b, b + slabs, b + 2 slabs, ... (RP rows each): all workgroups walk the matrix
+    // together as one moving window (5.4 TB/s at 1024 workgroups in tools/stream_bench.hip) instead of each crawling
+    // through its own contiguous chunk (4.4 TB/s).  The row -> slab map is static, so sums stay bit-reproducible.
+    const int64_t stride = (int64_t)slabs * RP;
     float4 a0 = f4_zero(), a1 = f4_zero();
     if (rl < RP) {
         // two independent accumulator pairs: two row loads in flight per thread
         float4 b0 = f4_zero(), b1 = f4_zero();
-        int64_t r = r0 + rl;
-        for (; r + RP < r1; r += 2 * RP) {
+        int64_t r = (int64_t)blockIdx.x * RP + rl;
+        for (; r + stride < rows; r += 2 * stride) {
             fn(r, q, a0, a1);
-            fn(r + RP, q, b0, b1);
+            fn(r + stride, q, b0, b1);
         }
-        if (r < r1) fn(r, q, a0, a1);
+        if (r < rows) fn(r, q, a0, a1);
         a0 = f4_add(a0, b0);
         a1 = f4_add(a1, b1);
     }
@@ -65,16 +65,18 @@ __global__ __launch_bounds__(kThreads) void col_reduce_kernel(Fn fn, int64_t row
     }
 }
 
+template <bool STREAM>
 struct StatsFn {
     const float* X;
     int64_t ld;
     __device__ __forceinline__ void operator()(int64_t r, int q, float4& a0, float4& a1) const {
-        float4 v = f4_ld(X + r * ld + q * 4);
+        float4 v = f4_lds<STREAM>(X + r * ld + q * 4);
         a0 = f4_add(a0, v);
         a1 = f4_fma(v, v, a1);
     }
 };
 
+template <bool STREAM>
 struct BwdReduceFn {
     const float* GY;
     int64_t ldgy;
@@ -83,8 +85,8 @@ struct BwdReduceFn {
     const float* stat;  // [4][F]: mean, rstd, scale=gamma*rstd, beta
     int F;
     __device__ __forceinline__ void operator()(int64_t r, int q, float4& a0, float4& a1) const {
-        float4 gy = f4_ld(GY + r * ldgy + q * 4);
-        float4 x = f4_ld(X + r * ldx + q * 4);
+        float4 gy = f4_lds<STREAM>(GY + r * ldgy + q * 4);
+        float4 x = f4_lds<STREAM>(X + r * ldx + q * 4);
         float4 mean = f4_ld(stat + q * 4), rstd = f4_ld(stat + F + q * 4);
         float4 sc = f4_ld(stat + 2 * F + q * 4), be = f4_ld(stat + 3 * F + q * 4);
         float4 xc = f4_sub(x, mean);
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(kRedCols* kRedLanes) void slab_sum_kernel(const flo
 }
 
 // Y = R + silu((X-mean)*scale + beta)
-template <bool HAS_RES>
+template <bool HAS_RES, bool STREAM>
 __global__ __launch_bounds__(kThreads) void bn_silu_fwd_kernel(const float* __restrict__ X, int64_t ldx,
                                                                const float* __restrict__ R, int64_t ldr,
                                                                const float* __restrict__ stat,
@@ -181,18 +183,19 @@ __global__ __launch_bounds__(kThreads) void bn_silu_fwd_kernel(const float* __re
     for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
         int64_t r = i / Q;
         int q = (int)(i - r * Q);
-        float4 x = f4_ld(X + r * ldx + q * 4);
+        float4 x = f4_lds<STREAM>(X + r * ldx + q * 4);
         float4 mean = f4_ld(stat + q * 4);
         float4 sc = f4_ld(stat + 2 * F + q * 4), be = f4_ld(stat + 3 * F + q * 4);
         float4 z = f4_fma(f4_sub(x, mean), sc, be);
         float4 o = make_float4(silu_f(z.x), silu_f(z.y), silu_f(z.z), silu_f(z.w));
-        if (HAS_RES) o = f4_add(o, f4_ld(R + r * ldr + q * 4));
-        f4_st(Y + r * ldy + q * 4, o);
+        if (HAS_RES) o = f4_add(o, f4_lds<STREAM>(R + r * ldr + q * 4));
+        f4_sts<STREAM>(Y + r * ldy + q * 4, o);
         am = fmaxf(am, f4_absmax(o));
     }
     block_amax_commit(am, amax);
 }
 
+template <bool STREAM>
 __global__ __launch_bounds__(kThreads) void bn_silu_bwd_apply_kernel(
     const float* __restrict__ GY, int64_t ldgy, const float* __restrict__ X, int64_t ldx,
     const float* __restrict__ stat, const float* __restrict__ gamma, const float* __restrict__ red, int eval_mode,
@@ -204,8 +207,8 @@ __global__ __launch_bounds__(kThreads) void bn_silu_bwd_apply_kernel(
     for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
         int64_t r = i / Q;
         int q = (int)(i - r * Q);
-        float4 gy = f4_ld(GY + r * ldgy + q * 4);
-        float4 x = f4_ld(X + r * ldx + q * 4);
+        float4 gy = f4_lds<STREAM>(GY + r * ldgy + q * 4);
+        float4 x = f4_lds<STREAM>(X + r * ldx + q * 4);
         float4 mean = f4_ld(stat + q * 4), rstd = f4_ld(stat + F + q * 4);
         float4 sc = f4_ld(stat + 2 * F + q * 4), be = f4_ld(stat + 3 * F + q * 4);
         float4 xc = f4_sub(x, mean);
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(kThreads) void bn_silu_bwd_apply_kernel(
             o.z = sc.z * (gz.z - inv_n * (c0.z + xh.z * c1.z));
             o.w = sc.w * (gz.w - inv_n * (c0.w + xh.w * c1.w));
         }
-        f4_st(GX + r * ldgx + q * 4, o);
+        f4_sts<STREAM>(GX + r * ldgx + q * 4, o);
         am = fmaxf(am, f4_absmax(o));
     }
     block_amax_commit(am, amax);
@@ -384,12 +387,17 @@ inline int ln_blocks(int64_t rows) {
 }
 
 inline bool feat_ok(int F) { return F >= 4 && (F & 3) == 0 && F <= 1024; }
+// One float4 per thread: on MI355X a 2-read 1-write pass over 2 GB runs at 6.1 TB/s that way (6.7 with nontemporal
+// accesses) against 4.6-4.8 TB/s for a 2048-workgroup grid-stride loop (tools/stream_bench.hip) - workgroups are
+// dispatched in address order, so the accesses in flight form one moving window instead of drifting apart.
 inline int stream_grid(int64_t total) {
     int64_t g = (total + kThreads - 1) / kThreads;
-    if (g > 2048) g = 2048;
+    if (g > (1 << 22)) g = 1 << 22;
     if (g < 1) g = 1;
     return (int)g;
 }
+// read-once / write-once hint only for tensors that cannot stay in the 256 MiB last-level cache anyway
+inline bool streaming(int64_t rows, int F) { return rows * (int64_t)F * 4 >= (int64_t)128 << 20; }
 
 }  // namespace
 
@@ -400,9 +408,15 @@ int alignn_col_stats_slabs(int64_t rows) { return slabs_for(rows); }
 int alignn_col_stats(const float* X, int64_t ldx, int64_t rows, int F, float* partial, alignn_stream_t stream) {
     if (!feat_ok(F) || rows < 0) return (int)hipErrorInvalidValue;
     int slabs = slabs_for(rows);
-    StatsFn fn{X, ldx};
-    hipLaunchKernelGGL(col_reduce_kernel<StatsFn>, dim3(slabs), dim3(kThreads), 0, (hipStream_t)stream, fn, rows, F,
-                       slabs, partial);
+    if (streaming(rows, F)) {
+        StatsFn<true> fn{X, ldx};
+        hipLaunchKernelGGL(col_reduce_kernel<StatsFn<true>>, dim3(slabs), dim3(kThreads), 0, (hipStream_t)stream, fn,
+                           rows, F, slabs, partial);
+    } else {
+        StatsFn<false> fn{X, ldx};
+        hipLaunchKernelGGL(col_reduce_kernel<StatsFn<false>>, dim3(slabs), dim3(kThreads), 0, (hipStream_t)stream, fn,
+                           rows, F, slabs, partial);
+    }
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }
@@ -414,9 +428,9 @@ int alignn_col_sum(const float* X, int64_t ldx, int64_t rows, int F, float* out,
     // wide matrices (the [n,4H] projection gradient) go in column panels of <= 1024
     for (int c = 0; c < F; c += 1024) {
         const int w = F - c < 1024 ? F - c : 1024;
-        StatsFn fn{X + c, ldx};
-        hipLaunchKernelGGL(col_reduce_kernel<StatsFn>, dim3(slabs), dim3(kThreads), 0, (hipStream_t)stream, fn, rows,
-                           w, slabs, workspace);
+        StatsFn<false> fn{X + c, ldx};
+        hipLaunchKernelGGL(col_reduce_kernel<StatsFn<false>>, dim3(slabs), dim3(kThreads), 0, (hipStream_t)stream, fn,
+                           rows, w, slabs, workspace);
         hipLaunchKernelGGL(slab_sum_kernel, dim3(alignn_ceil_div(w, kRedCols)), dim3(kRedCols, kRedLanes), 0,
                            (hipStream_t)stream, workspace, slabs, w, 2 * w, out + c);
     }
@@ -440,12 +454,15 @@ int alignn_bn_silu_fwd(const float* X, int64_t ldx, const float* R, int64_t ldr,
     if (!feat_ok(F)) return (int)hipErrorInvalidValue;
     if (rows == 0) return 0;
     int grid = stream_grid(rows * (F >> 2));
-    if (R)
-        hipLaunchKernelGGL(bn_silu_fwd_kernel<true>, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, X, ldx, R, ldr,
-                           stat, Y, ldy, rows, F, amax);
-    else
-        hipLaunchKernelGGL(bn_silu_fwd_kernel<false>, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, X, ldx, R,
-                           ldr, stat, Y, ldy, rows, F, amax);
+#define ALIGNN_BNF(RES_, ST_)                                                                                      \
+    hipLaunchKernelGGL((bn_silu_fwd_kernel<RES_, ST_>), dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, X, ldx, R, \
+                       ldr, stat, Y, ldy, rows, F, amax)
+    if (streaming(rows, F)) {
+        if (R) ALIGNN_BNF(true, true); else ALIGNN_BNF(false, true);
+    } else {
+        if (R) ALIGNN_BNF(true, false); else ALIGNN_BNF(false, false);
+    }
+#undef ALIGNN_BNF
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }
@@ -454,9 +471,10 @@ int alignn_bn_silu_bwd_reduce(const float* GY, int64_t ldgy, const float* X, int
                               int64_t rows, int F, float* partial, alignn_stream_t stream) {
     if (!feat_ok(F)) return (int)hipErrorInvalidValue;
     int slabs = slabs_for(rows);
-    BwdReduceFn fn{GY, ldgy, X, ldx, stat, F};
-    hipLaunchKernelGGL(col_reduce_kernel<BwdReduceFn>, dim3(slabs), dim3(kThreads), 0, (hipStream_t)stream, fn, rows,
-                       F, slabs, partial);
+    // (no read-once hint here: alignn_bn_silu_bwd_apply / the conv backward re-read both operands right after)
+    BwdReduceFn<false> fn{GY, ldgy, X, ldx, stat, F};
+    hipLaunchKernelGGL(col_reduce_kernel<BwdReduceFn<false>>, dim3(slabs), dim3(kThreads), 0, (hipStream_t)stream, fn,
+                       rows, F, slabs, partial);
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }
@@ -528,8 +546,12 @@ int alignn_bn_silu_bwd_apply(const float* GY, int64_t ldgy, const float* X, int6
     if (!feat_ok(F)) return (int)hipErrorInvalidValue;
     if (rows == 0) return 0;
     int grid = stream_grid(rows * (F >> 2));
-    hipLaunchKernelGGL(bn_silu_bwd_apply_kernel, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, GY, ldgy, X, ldx,
-                       stat, gamma, red, eval_mode, GX, ldgx, rows, F, amax);
+    if (streaming(rows, F))
+        hipLaunchKernelGGL(bn_silu_bwd_apply_kernel<true>, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, GY, ldgy, X,
+                           ldx, stat, gamma, red, eval_mode, GX, ldgx, rows, F, amax);
+    else
+        hipLaunchKernelGGL(bn_silu_bwd_apply_kernel<false>, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, GY, ldgy,
+                           X, ldx, stat, gamma, red, eval_mode, GX, ldgx, rows, F, amax);
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }

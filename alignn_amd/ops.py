@@ -483,7 +483,7 @@ class EdgeGatedConvFn(torch.autograd.Function):
         e_part = _empty(slabs, 2, H, like=x) if bn_train else None
         n_part = _empty(slabs, 2, H, like=x) if bn_train else None
         check(
-            lib.alignn_egc_gate_fwd(ptr(P), ptr(M), ptr(graph.seg_ptr), ptr(graph.seg_node), ptr(graph.src), n, n, H,
+            lib.alignn_egc_gate_fwd(ptr(P), ptr(M), ptr(graph.seg_ptr), ptr(graph.seg_node), ptr(graph.src), n, m, H,
                                     ptr(xpre), ptr(s0), ptr(hh), ptr(e_part), ptr(n_part), stream()),
             "egc_gate_fwd",
         )

@@ -185,9 +185,10 @@ int alignn_egc_slabs(int64_t n_seg);
 /* In : P[n,4H]; M[m,H] holds C = y*W_eg^T + b on entry.
  * Out: M[m,H] = m_pre = A[src] + Bd[dst] + C (in place); XPRE[n,H] = Ux + S1/(S0+1e-6);
  *      S0[n,H], HH[n,H] = S1/(S0+1e-6) (saved for backward; may be NULL for inference);
- *      e_partial: column-stat slabs of m_pre; n_partial: column-stat slabs of XPRE (each may be NULL). */
+ *      e_partial: column-stat slabs of m_pre; n_partial: column-stat slabs of XPRE (each may be NULL).
+ * m_rows = number of edge rows of M (only decides whether M is streamed with read-once/write-once hints). */
 int alignn_egc_gate_fwd(const float* P, float* M, const int32_t* seg_ptr, const int32_t* seg_node,
-                        const int32_t* src, int64_t n_seg, int64_t n_nodes, int H, float* XPRE,
+                        const int32_t* src, int64_t n_seg, int64_t m_rows, int H, float* XPRE,
                         float* S0, float* HH, float* e_partial, float* n_partial,
                         alignn_stream_t stream);
 
