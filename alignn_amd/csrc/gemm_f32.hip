@@ -291,6 +291,62 @@ __global__ __launch_bounds__(1024) void slab_reduce_kernel(const float* __restri
     }
 }
 
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// same sum, four consecutive outputs per thread: 64 output lanes x 16 slab lanes per workgroup, every slab row read
+// as 1 KiB contiguous per wave, four loads in flight per lane; fp64 partials combined through LDS in lane order
+__global__ __launch_bounds__(1024) void slab_reduce4_kernel(const float* __restrict__ ws, int splits, int64_t count,
+                                                            int cols, float* __restrict__ out, int64_t ldo) {
+    __shared__ double sh[16][64][4];
+    const int64_t idx = ((int64_t)blockIdx.x * 64 + threadIdx.x) * 4;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (idx < count) {
+        int k = threadIdx.y;
+        for (; k + 48 < splits; k += 64) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = f4_ld(ws + (int64_t)(k + 16 * u) * count + idx);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                s0 += (double)v[u].x;
+                s1 += (double)v[u].y;
+                s2 += (double)v[u].z;
+                s3 += (double)v[u].w;
+            }
+        }
+        for (; k < splits; k += 16) {
+            float4 v = f4_ld(ws + (int64_t)k * count + idx);
+            s0 += (double)v.x;
+            s1 += (double)v.y;
+            s2 += (double)v.z;
+            s3 += (double)v.w;
+        }
+    }
+    double* mine = sh[threadIdx.y][threadIdx.x];
+    mine[0] = s0, mine[1] = s1, mine[2] = s2, mine[3] = s3;
+    __syncthreads();
+    if (threadIdx.y == 0 && idx < count) {
+        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+#pragma unroll 4
+        for (int k = 0; k < 16; ++k) {
+            const double* p = sh[k][threadIdx.x];
+            t0 += p[0], t1 += p[1], t2 += p[2], t3 += p[3];
+        }
+        f4_st(out + (idx / cols) * ldo + (idx % cols), make_float4((float)t0, (float)t1, (float)t2, (float)t3));
+    }
+}
+
+// out[N,K] (leading dimension ldo) = sum over `splits` slabs of ws[k][N*K]
+inline void launch_slab_reduce(const float* ws, int splits, int64_t count, int cols, float* out, int64_t ldo,
+                               hipStream_t st) {
+    if ((count & 3) == 0 && (cols & 3) == 0 && (ldo & 3) == 0 && aligned16(out) && aligned16(ws))
+        hipLaunchKernelGGL(slab_reduce4_kernel, dim3(alignn_ceil_div(count, 256)), dim3(64, 16), 0, st, ws, splits, count,
+                           cols, out, ldo);
+    else
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(alignn_ceil_div(count, 32)), dim3(32, 32), 0, st, ws, splits, count,
+                           cols, out, ldo);
+}
+
 template <int BM, int BN, int WM, int WN, bool A_RC, bool B_RC, bool HAS_ADD>
 int launch_k(const GemmArgs& g, int splits, hipStream_t stream);
 
@@ -337,13 +393,13 @@ int naive(const float* A, int64_t sai, int64_t sar, const float* B, int64_t sbj,
     return 0;
 }
 
-inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // Weight-gradient GEMM: the output is only (N/128)*(K/BN) tiles, so the reduction over the M rows is split
 // into slabs until there are ~768 workgroups (3 per CU); each slab is a multiple of BK rows.
 inline int64_t tn_chunk(int64_t M, int N, int K) {
     const int bn = K > 64 ? 128 : 64;
-    const int64_t tiles = (int64_t)alignn_ceil_div(N, 128) * alignn_ceil_div(K, bn);
+    const int bm = (N <= 64 && K <= 64) ? 64 : 128;
+    const int64_t tiles = (int64_t)alignn_ceil_div(N, bm) * alignn_ceil_div(K, bn);
     int64_t want = (768 + tiles - 1) / tiles;
     if (want < 1) want = 1;
     int64_t chunk = (M + want - 1) / want;
@@ -426,8 +482,7 @@ int alignn_gemm_tn(const float* G, int64_t ldg, const float* g_amax, const float
                                              workspace, workspace_bytes, stream);
         if (rc6) return rc6;
         const int64_t count6 = (int64_t)N * K;
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3(alignn_ceil_div(count6, 32)), dim3(32, 32), 0, st, ws,
-                           alignn_gemm_tn_x6_splits(M, N, K), count6, K, dW, lddw);
+        launch_slab_reduce(ws, alignn_gemm_tn_x6_splits(M, N, K), count6, K, dW, lddw, st);
         ALIGNN_CHECK_LAUNCH();
         return 0;
     }
@@ -436,12 +491,13 @@ int alignn_gemm_tn(const float* G, int64_t ldg, const float* g_amax, const float
     int rc;
     if (K > 64)
         rc = launch<128, 128, 2, 2, false, false>(g, splits, st);
-    else
+    else if (N > 64)
         rc = launch<128, 64, 4, 1, false, false>(g, splits, st);
+    else  // the first embedding layers (64 x 40): a 128-row tile would spend half its fp32 MFMAs on padding
+        rc = launch<64, 64, 2, 1, false, false>(g, splits, st);
     if (rc) return rc;
     const int64_t count = (int64_t)N * K;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(alignn_ceil_div(count, 32)), dim3(32, 32), 0, st, ws, splits, count, K,
-                       dW, lddw);
+    launch_slab_reduce(ws, splits, count, K, dW, lddw, st);
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }

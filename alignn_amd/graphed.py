@@ -15,6 +15,8 @@ from __future__ import annotations
 
 import torch
 
+from . import ops
+
 
 class GraphedTrainStep:
     def __init__(self, model, batch, target, optimizer, loss_fn=torch.nn.functional.l1_loss, warmup: int = 3):
@@ -32,10 +34,12 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(s)
         self.graph = torch.cuda.CUDAGraph()
         optimizer.zero_grad(set_to_none=True)
+        ops.reset_amax_arena()  # the arena's zero-fill must be a node of the graph, not something done before it
         with torch.cuda.graph(self.graph):
             self.loss = loss_fn(model(batch), self.target)
             self.loss.backward()
             optimizer.step()
+        ops.reset_amax_arena()  # ... and eager code after the capture must not draw slots from the graph's pool
 
     def set_target(self, target):
         self.target.copy_(target)

@@ -47,7 +47,7 @@ def test_gemm_nn(M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(37, 64, 92), (5000, 256, 256), (20000, 1024, 256), (4097, 40, 64), (100, 1, 256),
-                                   (8192, 256, 80), (1, 16, 16)])
+                                   (8192, 256, 80), (1, 16, 16), (70000, 64, 40), (30001, 8, 64), (3000, 64, 64)])
 def test_gemm_tn(M, N, K):
     g, a = r(M, N, seed=1), r(M, K, seed=2)
     out = ops.gemm_tn(g, a)

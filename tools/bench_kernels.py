@@ -48,7 +48,7 @@ def gemms():
         print(f"NT M={M} N={Nn} K={K}: fp32 {t32*1e3:8.1f} us ({fl/t32/1e9:6.1f} TF) | x6 {t6*1e3:8.1f} us ({fl/t6/1e9:6.1f} TF-eq, "
               f"{by/t6/1e6:6.0f} GB/s) | x6+addend {t6a*1e3:8.1f} us | split {tsp*1e3:6.1f} us | f16x3 {th*1e3:8.1f} us "
               f"({by/th/1e6:6.0f} GB/s) +addend {tha*1e3:8.1f} us | absmax {tam*1e3:6.1f} us")
-    for (M, Nn, K) in [(T, 256, 256), (E, 1024, 256), (E, 256, 256), (N, 1024, 256), (T, 256, 64)]:
+    for (M, Nn, K) in [(T, 256, 256), (E, 1024, 256), (E, 256, 256), (N, 1024, 256), (T, 256, 64), (T, 64, 40), (E, 64, 80)]:
         g = torch.randn(M, Nn, device=DEV)
         a = torch.randn(M, K, device=DEV)
         t = timeit(lambda: ops.gemm_tn(g, a))
