@@ -444,6 +444,127 @@ __global__ __launch_bounds__(kThreads) void egc_bwd_lg_fused_kernel(
     block_amax_commit(gp_am, gp_amax);
 }
 
+// ---------------------------------------------------------------------------------------------
+// backward on a line graph whose blocks are DENSE and source-sorted (CSRGraph.dense_max_src > 0: true line graphs,
+// incl. the ones built on the device): segment s of atom j lists all sources q = 0..P-1 of j in order, minus s
+// itself for a self-image bond, so the row of (q, s) is  seg_ptr[s] + q - (q > self_q)  - no index lists at all.
+// The workgroup of atom j walks its block SEGMENT by segment (rows strictly sequential in memory); wave w owns the
+// sources q = w, w+4, ... and keeps their Bh rows and their g_A / g_Bh sums in registers for the whole block, the
+// segment's gS1 / gS0 rows are loaded once per segment, and g_Bd[s] is the fixed-order sum of the four waves'
+// partial sums (LDS).  Every T-row of GY and M is read once and GM written once: PMC FETCH of the by-source kernel
+// above is 3.6 row passes (GM re-read from HBM - a block's 176 KiB x 8 workgroups per CU overflow the L2 - plus
+// ~0.6 pass of re-fetched gS1/gS0 rows), here 2.
+// ---------------------------------------------------------------------------------------------
+constexpr int kDenseK = 4;  // sources per wave and pass: 16 per workgroup (kNN-12 graphs: 12-16 in-edges per atom)
+
+template <int MODE, bool STREAM>
+__global__ __launch_bounds__(kThreads) void egc_bwd_lg_dense_kernel(
+    const float* __restrict__ GY, const float* __restrict__ M, const float* __restrict__ P,
+    const float* __restrict__ GS1, const float* __restrict__ GS0, const float* __restrict__ e_stat,
+    const float* __restrict__ e_red, int e_eval, float inv_n, const int32_t* __restrict__ grp_seg_ptr,
+    const int32_t* __restrict__ grp_src_ptr, const int32_t* __restrict__ seg_ptr,
+    const int32_t* __restrict__ seg_node, int H, float* __restrict__ GM, float* __restrict__ GP,
+    float* __restrict__ gb_partial, float* __restrict__ gm_amax, float* __restrict__ gp_amax) {
+    constexpr int KMAX = kDenseK;
+    __shared__ float4 sh[2][kWavesPerBlock][ALIGNN_WAVE];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t ldp = 4 * (int64_t)H;
+    const int j = blockIdx.x;
+    const int p_beg = grp_src_ptr[j], n_src = grp_src_ptr[j + 1] - p_beg;
+    const int s_beg = grp_seg_ptr[j], s_end = grp_seg_ptr[j + 1];
+    constexpr bool HAS_GY = MODE != 0;
+    float gm_am = 0.0f, gp_am = 0.0f;
+    for (int c0 = 0; c0 < H; c0 += 4 * ALIGNN_WAVE) {
+        const int f = c0 + 4 * lane;
+        const bool active = f < H;
+        EdgeNorm nrm;
+        if (active && MODE == 1) {
+            nrm.mean = f4_ld(e_stat + f);
+            nrm.rstd = f4_ld(e_stat + H + f);
+            nrm.sc = f4_ld(e_stat + 2 * H + f);
+            nrm.sh = f4_ld(e_stat + 3 * H + f);
+            if (!e_eval) {
+                nrm.c0 = f4_ld(e_red + f);
+                nrm.c1 = f4_ld(e_red + H + f);
+            }
+        }
+        float4 gb = f4_zero();
+        // atoms with more than 16 sources take further passes over their segments, 16 sources at a time (each row
+        // still belongs to exactly one pass; g_Bd accumulates across the passes in pass order)
+        for (int qb = 0; qb < n_src || qb == 0; qb += kWavesPerBlock * KMAX) {
+            float4 bh[KMAX], ga[KMAX], gbh[KMAX];
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                const int q = qb + wave + kWavesPerBlock * k;
+                bh[k] = (active && q < n_src) ? f4_ld(P + (int64_t)(p_beg + q) * ldp + 2 * H + f) : f4_zero();
+                ga[k] = gbh[k] = f4_zero();
+            }
+            for (int s = s_beg; s < s_end; ++s) {
+                const int i = seg_node ? seg_node[s] : s;
+                const int e0 = seg_ptr[s];
+                int self_q = i - p_beg;  // the segment's own bond among the sources (self-image) is not listed
+                if (self_q < 0 || self_q >= n_src || seg_ptr[s + 1] - e0 == n_src) self_q = -1;
+                float4 gbd = f4_zero();
+                if (active) {
+                    const float4 g1 = f4_ld(GS1 + (int64_t)i * H + f), g0 = f4_ld(GS0 + (int64_t)i * H + f);
+                    float4 m[KMAX], gy[KMAX];
+                    int row[KMAX];
+#pragma unroll
+                    for (int k = 0; k < KMAX; ++k) {
+                        const int q = qb + wave + kWavesPerBlock * k;
+                        row[k] = (q < n_src && q != self_q) ? e0 + q - ((self_q >= 0 && q > self_q) ? 1 : 0) : -1;
+                        if (row[k] >= 0) {
+                            m[k] = f4_lds<STREAM>(M + (int64_t)row[k] * H + f);
+                            if (HAS_GY) gy[k] = f4_lds<STREAM>(GY + (int64_t)row[k] * H + f);
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < KMAX; ++k) {
+                        if (row[k] >= 0) {
+                            const float4 gm = edge_grad<MODE>(m[k], gy[k], bh[k], g1, g0, nrm, inv_n, e_eval);
+                            f4_sts<STREAM>(GM + (int64_t)row[k] * H + f, gm);
+                            gm_am = fmaxf(gm_am, f4_absmax(gm));
+                            ga[k] = f4_add(ga[k], gm);
+                            gbh[k] = f4_fma(f4_sigmoid(m[k]), g1, gbh[k]);
+                            gbd = f4_add(gbd, gm);
+                        }
+                    }
+                }
+                // g_Bd[s]: the four waves' partial sums in wave order (double-buffered, one barrier per segment)
+                float4(*buf)[ALIGNN_WAVE] = sh[(s - s_beg) & 1];
+                buf[wave][lane] = gbd;
+                __syncthreads();
+                if (wave == 0 && active) {
+                    float4 a = buf[0][lane];
+#pragma unroll
+                    for (int w = 1; w < kWavesPerBlock; ++w) a = f4_add(a, buf[w][lane]);
+                    gb = f4_add(gb, a);
+                    float* out = GP + (int64_t)i * ldp + H + f;
+                    if (qb > 0) a = f4_add(f4_ld(out), a);  // written by this very thread in the previous pass
+                    f4_st(out, a);
+                    gp_am = fmaxf(gp_am, f4_absmax(a));
+                }
+            }
+            if (active) {
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k) {
+                    const int q = qb + wave + kWavesPerBlock * k;
+                    if (q < n_src) {
+                        f4_st(GP + (int64_t)(p_beg + q) * ldp + f, ga[k]);
+                        f4_st(GP + (int64_t)(p_beg + q) * ldp + 2 * H + f, gbh[k]);
+                        gp_am = fmaxf(gp_am, fmaxf(f4_absmax(ga[k]), f4_absmax(gbh[k])));
+                    }
+                }
+            }
+            __syncthreads();  // sh is reused by the next pass / feature panel
+        }
+        if (active && gb_partial && wave == 0) f4_st(gb_partial + (size_t)blockIdx.x * H + f, gb);
+    }
+    block_amax_commit(gm_am, gm_amax);
+    block_amax_commit(gp_am, gp_amax);
+}
+
 inline bool big_stream(int64_t rows, int H) { return rows * (int64_t)H * 4 >= (int64_t)128 << 20; }
 inline bool h_ok(int H) { return H >= 4 && (H & 3) == 0 && H <= 1024; }
 
@@ -531,6 +652,41 @@ int alignn_egc_bwd_lg_fused(const float* GY, const float* M, const float* P, con
         ALIGNN_LGF(0);
     }
 #undef ALIGNN_LGF
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_egc_bwd_lg_dense_supported(int max_group_src) { return max_group_src > 0 ? 1 : 0; }
+
+int alignn_egc_bwd_lg_dense(const float* GY, const float* M, const float* P, const float* GS1, const float* GS0,
+                            const float* e_stat, const float* e_red, int e_eval, int64_t m_rows,
+                            const int32_t* grp_seg_ptr, const int32_t* grp_src_ptr, int64_t n_groups,
+                            int max_group_src, const int32_t* seg_ptr, const int32_t* seg_node, int H, float* GM,
+                            float* GP, float* gb_partial, float* gm_amax, float* gp_amax, alignn_stream_t stream) {
+    if (!h_ok(H) || n_groups <= 0 || n_groups > INT32_MAX || !alignn_egc_bwd_lg_dense_supported(max_group_src))
+        return (int)hipErrorInvalidValue;
+    const float inv_n = m_rows > 0 ? 1.0f / (float)m_rows : 0.0f;
+    dim3 grid((int)n_groups), block(kThreads);
+    hipStream_t st = (hipStream_t)stream;
+#define ALIGNN_LGD2(MODE_, ST_)                                                                                     \
+    hipLaunchKernelGGL((egc_bwd_lg_dense_kernel<MODE_, ST_>), grid, block, 0, st, GY, M, P, GS1, GS0, e_stat, e_red,   \
+                       e_eval, inv_n, grp_seg_ptr, grp_src_ptr, seg_ptr, seg_node, H, GM, GP, gb_partial, gm_amax,  \
+                       gp_amax)
+#define ALIGNN_LGD(MODE_)                            \
+    if (big_stream(m_rows, H)) {                     \
+        ALIGNN_LGD2(MODE_, true);                    \
+    } else {                                         \
+        ALIGNN_LGD2(MODE_, false);                   \
+    }
+    if (GY && e_stat) {
+        ALIGNN_LGD(1)
+    } else if (GY) {
+        ALIGNN_LGD(2)
+    } else {
+        ALIGNN_LGD(0)
+    }
+#undef ALIGNN_LGD
+#undef ALIGNN_LGD2
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }

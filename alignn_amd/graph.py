@@ -42,6 +42,10 @@ class CSRGraph:
     # segment ranks [grp_seg_ptr[j], grp_seg_ptr[j+1]) and source nodes [grp_src_ptr[j], grp_src_ptr[j+1])
     grp_seg_ptr: Optional[torch.Tensor] = None
     grp_src_ptr: Optional[torch.Tensor] = None
+    # > 0: every block is DENSE and source-sorted - segment s of atom j lists ALL sources of j in ascending order,
+    # minus s itself when the bond is a self-image - so the row of (source q, segment s) is pure index arithmetic
+    # (see alignn_egc_bwd_lg_dense); the value is the largest number of sources of any atom.  0: not established.
+    dense_max_src: int = 0
 
 
 def _ptr_from_counts(counts: torch.Tensor) -> torch.Tensor:
@@ -50,12 +54,14 @@ def _ptr_from_counts(counts: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def build_csr(u: torch.Tensor, v: torch.Tensor, n_nodes: int, seg_order: Optional[torch.Tensor] = None) -> CSRGraph:
+def build_csr(u: torch.Tensor, v: torch.Tensor, n_nodes: int, seg_order: Optional[torch.Tensor] = None,
+              sort_sources: bool = False) -> CSRGraph:
     """Canonicalise COO edges ``u -> v``.
 
     ``seg_order`` (optional, int64 [n_nodes]) lists the nodes in the order their segments should be
     stored; default is node order.  Within a segment, edges keep the caller's relative order
-    (stable), so the summation order inside a segment is a deterministic function of the input.
+    (stable), so the summation order inside a segment is a deterministic function of the input;
+    ``sort_sources`` orders them by source node instead (line graphs: makes the blocks index-addressable).
     """
     u = u.to(torch.int64)
     v = v.to(torch.int64)
@@ -72,6 +78,8 @@ def build_csr(u: torch.Tensor, v: torch.Tensor, n_nodes: int, seg_order: Optiona
         key = rank[v]
         seg_node = seg_order.to(torch.int32)
         seg_counts = counts[seg_order]
+    if sort_sources:
+        key = key * n_nodes + u
     perm = torch.argsort(key, stable=True)
     inv = torch.empty(m, dtype=torch.int64, device=dev)
     inv[perm] = torch.arange(m, device=dev)
@@ -132,7 +140,34 @@ def line_graph_of(g: CSRGraph) -> CSRGraph:
         inv=ident,
         grp_seg_ptr=g.out_ptr,
         grp_src_ptr=g.seg_ptr,
+        dense_max_src=int((sp[1:] - sp[:-1]).max()) if m > 0 else 0,  # dense and source-sorted by construction
     )
+
+
+def _dense_blocks(g: CSRGraph, lg: CSRGraph) -> int:
+    """Largest source count of any block if L(g)'s blocks are dense and source-sorted (CSRGraph.dense_max_src), else 0.
+
+    Segment s (bond e2 = seg_node[s], centre atom j = src(e2)) must list the in-edges of j, i.e. the L(g) nodes
+    [g.seg_ptr[j], g.seg_ptr[j+1]), in ascending order, all of them except e2 itself (present only for self-images)."""
+    if lg.n_edges == 0:
+        return 0
+    dev = lg.src.device
+    sp = lg.seg_ptr.long()
+    seglen = sp[1:] - sp[:-1]
+    e2 = lg.seg_node.long() if lg.seg_node is not None else torch.arange(lg.n_nodes, device=dev)
+    atom = g.src.long()[e2]
+    gsp = g.seg_ptr.long()
+    p_beg, n_src = gsp[atom], gsp[atom + 1] - gsp[atom]
+    self_q = e2 - p_beg
+    has_self = (self_q >= 0) & (self_q < n_src)
+    if not bool((seglen == n_src - has_self.long()).all()):
+        return 0
+    seg_of = torch.repeat_interleave(torch.arange(lg.n_nodes, device=dev), seglen)
+    r = torch.arange(lg.n_edges, device=dev) - sp[:-1][seg_of]
+    q = r + (has_self[seg_of] & (r >= self_q[seg_of])).long()
+    if not bool((lg.src.long() == p_beg[seg_of] + q).all()):
+        return 0
+    return int(n_src.max())
 
 
 @dataclass
@@ -173,12 +208,13 @@ class GraphBatch:
             m = g.n_edges
             # order L(g)'s segments (bonds e2) by the bond's source atom, then by bond id
             seg_order = torch.argsort(g.src.to(torch.int64) * m + torch.arange(m, device=dev), stable=True)
-            lg = build_csr(e1, e2, m, seg_order)
+            lg = build_csr(e1, e2, m, seg_order, sort_sources=True)
             # every edge of a true line graph joins an in-edge and an out-edge of the same atom; then the canonical
             # layout is block structured (see CSRGraph.grp_*) and the fused backward kernel applies.  A filtered
             # line graph (eALIGNN) would fail this check and simply use the generic two-pass backward.
             if bool((g.dst[lg.src.long()] == g.src[lg.dst.long()]).all()):
                 lg.grp_seg_ptr, lg.grp_src_ptr = g.out_ptr, g.seg_ptr
+                lg.dense_max_src = _dense_blocks(g, lg)
         elif build_line_graph:
             lg = line_graph_of(g)
         bnn = torch.as_tensor(batch_num_nodes).to(dev).to(torch.int64)

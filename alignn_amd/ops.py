@@ -19,6 +19,7 @@ from .graph import CSRGraph
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 FUSED_LG_BACKWARD = True  # tests flip this to compare against the generic two-pass backward
+DENSE_LG_BACKWARD = True  # ... and this one to compare the dense-block kernel against the by-source fused kernel
 
 
 def _empty(*shape, like):
@@ -569,7 +570,19 @@ class EdgeGatedConvFn(torch.autograd.Function):
                 g_branch = gy_out
                 e_red = _bn_silu_bwd_reduce(gy_out, M, e_stat)
         GM = _empty(m, H, like=x)
-        if graph.grp_seg_ptr is not None and FUSED_LG_BACKWARD:
+        if (graph.grp_seg_ptr is not None and FUSED_LG_BACKWARD and DENSE_LG_BACKWARD
+                and lib.alignn_egc_bwd_lg_dense_supported(graph.dense_max_src)):
+            # line graph with dense, source-sorted blocks: one pass, rows addressed by index arithmetic
+            gslabs = graph.grp_seg_ptr.numel() - 1
+            gb_part = _empty(gslabs, H, like=x)
+            check(
+                lib.alignn_egc_bwd_lg_dense(ptr(g_branch), ptr(M), ptr(P), ptr(gs1), ptr(gs0), ptr(e_stat_arg),
+                                            ptr(e_red), int(ev), m, ptr(graph.grp_seg_ptr), ptr(graph.grp_src_ptr),
+                                            gslabs, graph.dense_max_src, ptr(graph.seg_ptr), ptr(graph.seg_node), H,
+                                            ptr(GM), ptr(GP), ptr(gb_part), ptr(gm_amax), ptr(gp_amax), stream()),
+                "egc_bwd_lg_dense",
+            )
+        elif graph.grp_seg_ptr is not None and FUSED_LG_BACKWARD:
             # line graph: destination- and source-ordered passes in one kernel, one workgroup per centre atom
             gslabs = graph.grp_seg_ptr.numel() - 1
             gb_part = _empty(gslabs, H, like=x)

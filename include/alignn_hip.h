@@ -228,6 +228,20 @@ int alignn_egc_bwd_lg_fused(const float* GY, const float* M, const float* P, con
                             float* GM, float* GP, float* gb_partial, float* gm_amax, float* gp_amax,
                             alignn_stream_t stream);
 
+/* The same backward for line graphs whose blocks are DENSE and source-sorted (every segment of atom j lists all
+ * in-edges of j in ascending order, minus itself for a self-image bond - true for DGL's g.line_graph() after
+ * alignn_amd.graph's canonicalisation and for graphs built by graph.line_graph_of; max_group_src = the largest
+ * in-degree, > 0 - atoms with more than 16 in-edges take extra passes of 16 sources).  Rows are addressed by index arithmetic, the block is walked segment by segment, every T-row of
+ * GY and M is read once and GM written once (the by-source kernel above re-reads GM: 3.6 row passes of fetch vs 2).
+ * Same outputs; sums in a different but fixed order. */
+int alignn_egc_bwd_lg_dense_supported(int max_group_src);
+int alignn_egc_bwd_lg_dense(const float* GY, const float* M, const float* P, const float* GS1,
+                            const float* GS0, const float* e_stat, const float* e_red, int e_eval,
+                            int64_t m_rows, const int32_t* grp_seg_ptr, const int32_t* grp_src_ptr,
+                            int64_t n_groups, int max_group_src, const int32_t* seg_ptr,
+                            const int32_t* seg_node, int H, float* GM, float* GP, float* gb_partial,
+                            float* gm_amax, float* gp_amax, alignn_stream_t stream);
+
 /* Source-ordered backward pass (deterministic scatter-by-source):
  *   GP[j, 0:H]   (g_A)  = sum_{e: src e = j} GM[e]
  *   GP[j, 2H:3H] (g_Bh) = sum_{e: src e = j} sigmoid(M[e]) * GS1[dst e] */

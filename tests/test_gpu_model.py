@@ -387,34 +387,65 @@ def test_ragged_batch_with_one_atom_cells():
 
 
 def test_fused_line_graph_backward_matches_two_pass():
-    """alignn_egc_bwd_lg_fused (one workgroup per centre atom) vs egc_bwd_dst + egc_bwd_src: identical math and
-    summation orders (only FMA contraction inside the two kernels may differ), so gradients agree to fp32
-    round-off; also covers 1-atom cells (self-loop exclusions); each path is itself bit-reproducible."""
+    """The three line-graph backward paths - alignn_egc_bwd_lg_dense (dense source-sorted blocks, one pass),
+    alignn_egc_bwd_lg_fused (by source, GM re-read) and egc_bwd_dst + egc_bwd_src - are the same math with
+    different (fixed) summation orders: gradients agree to fp32 round-off; also covers 1-atom cells (self-image
+    bonds: the excluded entry of a segment) and cells up to 16 sources per atom; each path reproduces itself bit
+    for bit."""
     from alignn_amd import ops
     from alignn_amd.synthetic import _one, batch_raw
 
     raw = batch_raw([_one(n, 60 + i, "crystal", 92) for i, n in enumerate((1, 6, 12, 2))])
     batch = GraphBatch.from_raw(raw, device=DEV)
-    assert batch.lg.grp_seg_ptr is not None
+    assert batch.lg.grp_seg_ptr is not None and batch.lg.dense_max_src > 0
     torch.manual_seed(2)
     model = ALIGNN(ALIGNNConfig(name="alignn", alignn_layers=2, gcn_layers=1, hidden_features=256)).to(DEV).train()
     sd = {k: v.clone() for k, v in model.state_dict().items()}
     target = torch.tensor([0.1, -0.4, 0.8, 0.3], device=DEV)
     grads = []
     try:
-        for fused in (True, False, True):
-            ops.FUSED_LG_BACKWARD = fused
+        for dense, fused in ((True, True), (False, True), (False, False), (True, True), (False, True)):
+            ops.DENSE_LG_BACKWARD, ops.FUSED_LG_BACKWARD = dense, fused
             model.load_state_dict(sd)
             model.zero_grad(set_to_none=True)
             torch.nn.functional.l1_loss(model(batch), target).backward()
             grads.append({k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
     finally:
-        ops.FUSED_LG_BACKWARD = True
-    assert grads[0].keys() == grads[1].keys()
+        ops.DENSE_LG_BACKWARD = ops.FUSED_LG_BACKWARD = True
+    assert grads[0].keys() == grads[1].keys() == grads[2].keys()
+    gmax = max(float(v.abs().max()) for v in grads[2].values())
+    for k in grads[0]:
+        assert rel_err(grads[0][k], grads[2][k], floor=1e-2 * gmax) < 2e-5, k
+        assert rel_err(grads[1][k], grads[2][k], floor=1e-2 * gmax) < 2e-5, k
+        assert torch.equal(grads[0][k], grads[3][k]), k  # every path reproduces itself bit for bit
+        assert torch.equal(grads[1][k], grads[4][k]), k
+
+
+def test_dense_line_graph_backward_wide_blocks():
+    """Blocks with 17-32 sources per atom take the KMAX=8 instantiation; molecules give uneven blocks."""
+    from alignn_amd import ops
+
+    raw = make_batch(6, (9, 27), seed0=4242, kind="molecule")
+    batch = GraphBatch.from_raw(raw, device=DEV)
+    assert batch.lg.dense_max_src > 0
+    torch.manual_seed(5)
+    model = ALIGNN(ALIGNNConfig(name="alignn", alignn_layers=2, gcn_layers=1, hidden_features=64)).to(DEV).train()
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    target = torch.randn(6, generator=torch.Generator().manual_seed(3)).to(DEV)
+    grads = []
+    try:
+        for dense in (True, False):
+            ops.DENSE_LG_BACKWARD = dense
+            model.load_state_dict(sd)
+            model.zero_grad(set_to_none=True)
+            torch.nn.functional.l1_loss(model(batch), target).backward()
+            grads.append({k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+    finally:
+        ops.DENSE_LG_BACKWARD = True
     gmax = max(float(v.abs().max()) for v in grads[1].values())
     for k in grads[0]:
         assert rel_err(grads[0][k], grads[1][k], floor=1e-2 * gmax) < 2e-5, k
-        assert torch.equal(grads[0][k], grads[2][k]), k  # the fused path reproduces itself bit for bit
+    print("max sources per atom:", batch.lg.dense_max_src)
 
 
 def test_atomwise_g_lat_input_builds_line_graph_on_device():

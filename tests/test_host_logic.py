@@ -85,3 +85,36 @@ def test_device_line_graph_equals_callers_line_graph():
     key = lambda c: torch.sort(c.dst.long() * c.n_nodes + c.src.long()).values  # noqa: E731
     assert torch.equal(key(lg2), key(lg))
     assert (b.g.dst[lg2.src.long()] == b.g.src[lg2.dst.long()]).all() and (lg2.src != lg2.dst).all()
+
+
+def test_line_graph_blocks_are_dense_and_source_sorted():
+    """What alignn_egc_bwd_lg_dense relies on: after canonicalisation every segment of L(g) lists ALL in-edges of its
+    centre atom in ascending order, minus the segment's own bond when it is a self-image - for the caller's COO
+    line graph (any edge order) and for the one derived on the device; a filtered line graph is detected."""
+    import numpy as np
+    import torch
+
+    from alignn_amd.graph import GraphBatch, build_csr, line_graph_of
+    from alignn_amd.synthetic import _one, batch_raw
+
+    raw = batch_raw([_one(n, 11 + i, "crystal", 92) for i, n in enumerate((1, 5, 9))])  # incl. a 1-atom cell
+    rng = np.random.default_rng(0)
+    order = rng.permutation(raw.lg_u.shape[0])  # the caller's line-graph edges in arbitrary order
+    b = GraphBatch.from_coo(torch.from_numpy(raw.u), torch.from_numpy(raw.v), raw.num_nodes,
+                            torch.from_numpy(raw.batch_num_nodes), torch.from_numpy(raw.lg_u[order]),
+                            torch.from_numpy(raw.lg_v[order]), h=torch.from_numpy(raw.h[order]))
+    g, lg = b.g, b.lg
+    indeg = (g.seg_ptr[1:] - g.seg_ptr[:-1]).max().item()
+    assert lg.dense_max_src == indeg > 0
+    lg2 = line_graph_of(g)
+    assert lg2.dense_max_src == indeg
+    assert torch.equal(lg2.src, lg.src) and torch.equal(lg2.dst, lg.dst) and torch.equal(lg2.seg_ptr, lg.seg_ptr)
+    # the cosines followed their edges through the extra within-segment sort
+    ref = GraphBatch.from_raw(raw)
+    assert torch.allclose(b.h, ref.h)
+    # a filtered line graph (drop every 7th edge) is still block structured but no longer dense
+    keep = np.arange(raw.lg_u.shape[0]) % 7 != 0
+    f = GraphBatch.from_coo(torch.from_numpy(raw.u), torch.from_numpy(raw.v), raw.num_nodes,
+                            torch.from_numpy(raw.batch_num_nodes), torch.from_numpy(raw.lg_u[keep]),
+                            torch.from_numpy(raw.lg_v[keep]))
+    assert f.lg.grp_seg_ptr is not None and f.lg.dense_max_src == 0
