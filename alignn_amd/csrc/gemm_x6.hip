@@ -41,26 +41,25 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-#ifndef X6_RM
-#define X6_RM 2
-#endif
-#ifndef X6_WM
-#define X6_WM 2
-#endif
-constexpr int RM = X6_RM;                  // 32-row MFMA tiles per wave along M
-constexpr int WM = X6_WM, WN = 2, NT = WM * WN * 64;
-constexpr int BM = WM * 32 * RM, BN = 256, BK = 16;  // one 16-deep MFMA step per stage
-constexpr int TM = BM / WM, TN = BN / WN;  // (32*RM) x 128 per wave
-constexpr int RN = TN / 32;                // RM x 4 MFMA tiles
-constexpr int A_BYTES = BM * BK * 4;       // 8 KiB fp32 (64-byte rows), XOR-swizzled 16-byte chunks, no padding
-constexpr int B_PLANE = BN * BK * 2;       // 8 KiB per bf16 slice plane (32-byte rows)
-constexpr int A_DMA = A_BYTES / 1024 / (NT / 64);       // 1 KiB DMA pieces per wave
+constexpr int WM = 2, WN = 2, NT = WM * WN * 64;  // 4 waves
+constexpr int BN = 256, BK = 16;                  // one 16-deep MFMA step per stage
+constexpr int TN = BN / WN, RN = TN / 32;         // 128 columns = 4 MFMA tiles per wave
+constexpr int B_PLANE = BN * BK * 2;              // 8 KiB per 16-bit slice plane (32-byte rows)
+// block height: RM 32-row MFMA tiles per wave along M.  RM = 2 (128 x 256 tile, 2 workgroups per CU) halves the
+// weight-slice traffic per activation row - best for the deep T- and E-row products; RM = 1 (64 x 256, 3 per CU)
+// fills the chip with shallow (K <= 64: 6.5 TB/s at T x 256 x 64) or short (atom-row) products.
+template <int RM_>
+struct Geo {
+    static constexpr int RM = RM_, BM = WM * 32 * RM_, TM = BM / WM;
+    static constexpr int A_BYTES = BM * BK * 4;              // fp32 (64-byte rows), XOR-swizzled 16-byte chunks
+    static constexpr int A_DMA = A_BYTES / 1024 / (NT / 64);  // 1 KiB DMA pieces per wave
+};
 constexpr int EPI_BYTES = (NT / 64) * 32 * (64 + 4) * 4; // per-wave [32][68] fp32 transpose patches
 // per scheme: slice planes of the weight image (3 bf16 / 2 fp16), stage and LDS footprint
-template <bool F16>
+template <bool F16, int RM_ = 2>
 struct Sch {
     static constexpr int NPL = F16 ? 2 : 3;
-    static constexpr int STAGE = A_BYTES + NPL * B_PLANE;            // 32 KiB / 24 KiB
+    static constexpr int STAGE = Geo<RM_>::A_BYTES + NPL * B_PLANE;  // RM = 2: 32 KiB / 24 KiB
     static constexpr int B_DMA = NPL * B_PLANE / 1024 / (NT / 64);   // pieces per wave
 #ifdef X6_NSTAGE
     static constexpr int NSTAGE = X6_NSTAGE;
@@ -164,9 +163,11 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned char* lds_wave_
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, AUX);
 }
 
-template <bool HAS_ADD, bool F16>
+template <bool HAS_ADD, bool F16, int RM_>
 __global__ __launch_bounds__(NT) void gemm_nt_x6_kernel(X6Args g) {
-    constexpr int NPL = Sch<F16>::NPL, STAGE_BYTES = Sch<F16>::STAGE, B_DMA = Sch<F16>::B_DMA;
+    constexpr int NPL = Sch<F16, RM_>::NPL, STAGE_BYTES = Sch<F16, RM_>::STAGE, B_DMA = Sch<F16, RM_>::B_DMA;
+    constexpr int RM = Geo<RM_>::RM, BM = Geo<RM_>::BM, TM = Geo<RM_>::TM, A_BYTES = Geo<RM_>::A_BYTES,
+                  A_DMA = Geo<RM_>::A_DMA;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(NT) void gemm_nt_x6_kernel(X6Args g) {
     // DMA ring of NSTAGE stages: stage kt+NSTAGE-1 is issued at the top of step kt (into the slot every wave has
     // finished reading), so a stage has NSTAGE-1 k-steps to land; COUNTED vmcnt - only the stage about to be read
     // must have arrived, younger ones stay in flight across the barrier.
-    constexpr int NSTAGE = Sch<F16>::NSTAGE, PIECES = A_DMA + B_DMA;
+    constexpr int NSTAGE = Sch<F16, RM_>::NSTAGE, PIECES = A_DMA + B_DMA;
     static_assert(NSTAGE == 2 || NSTAGE == 3, "vmcnt cases below");
     const int nk = g.K / BK;
 #pragma unroll
@@ -656,25 +657,33 @@ inline int npad(int N) { return ((N + BN - 1) / BN) * BN; }
 }  // namespace
 
 namespace {
-template <bool F16>
-int launch_nt(const X6Args& g, hipStream_t st) {
-    constexpr int lds = Sch<F16>::LDS;
+template <bool F16, int RM_>
+int launch_nt_rm(const X6Args& g, hipStream_t st) {
+    constexpr int lds = Sch<F16, RM_>::LDS;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_x6_kernel<false, F16>,
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_x6_kernel<false, F16, RM_>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)gemm_nt_x6_kernel<true, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            e = hipFuncSetAttribute((const void*)gemm_nt_x6_kernel<true, F16, RM_>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    dim3 grid(alignn_ceil_div(g.M, BM), g.Npad / BN);
+    dim3 grid(alignn_ceil_div(g.M, Geo<RM_>::BM), g.Npad / BN);
     if (g.addend)
-        hipLaunchKernelGGL((gemm_nt_x6_kernel<true, F16>), grid, dim3(NT), lds, st, g);
+        hipLaunchKernelGGL((gemm_nt_x6_kernel<true, F16, RM_>), grid, dim3(NT), lds, st, g);
     else
-        hipLaunchKernelGGL((gemm_nt_x6_kernel<false, F16>), grid, dim3(NT), lds, st, g);
+        hipLaunchKernelGGL((gemm_nt_x6_kernel<false, F16, RM_>), grid, dim3(NT), lds, st, g);
     ALIGNN_CHECK_LAUNCH();
     return 0;
+}
+template <bool F16>
+int launch_nt(const X6Args& g, hipStream_t st) {
+    // 64-row tiles for shallow products and for products too short to give every CU one 128-row tile
+    const int64_t tiles128 = alignn_ceil_div(g.M, 128) * (int64_t)(g.Npad / BN);
+    if (g.K <= 64 || tiles128 < 256) return launch_nt_rm<F16, 1>(g, st);
+    return launch_nt_rm<F16, 2>(g, st);
 }
 inline bool nt_args_ok(const float* A, int64_t lda, const void* Wsplit, const float* bias, const float* addend,
                        int64_t ldadd, float* C, int64_t ldc) {

@@ -93,7 +93,7 @@ def gemm_nt(a, w, bias=None, addend=None, out=None):
     return out
 
 
-X6_MIN_TILES = 256  # fewer 128x256 tiles than CUs: the finer-grained fp32-MFMA tiles win
+X6_MIN_TILES = 256  # 64x256 tiles below which the fp32-MFMA kernel's finer tiles win (100-512 measured the same)
 F16X3 = True  # use the three-product fp16 scheme wherever max|A| is known (False: always bf16x6)
 
 # max|x| of activations, tracked by the kernels that produce them (one device float per tensor).  Keyed by object
@@ -216,8 +216,8 @@ def project(a, w, bias=None, addend=None, transpose_w=False, a_amax=None):
     lib = _lib.load()
     M = a.shape[0]
     N, K = (w.shape[1], w.shape[0]) if transpose_w else (w.shape[0], w.shape[1])
-    # the split-product kernel works in 128 x 256 tiles: it needs enough of them to occupy the 256 CUs
-    x6_tiles = ((M + 127) // 128) * ((N + 255) // 256)
+    # the split-product kernels work in 128 x 256 (short or shallow products: 64 x 256) tiles and need enough of them
+    x6_tiles = ((M + 63) // 64) * ((N + 255) // 256)
     if x6_tiles >= X6_MIN_TILES and a.stride(0) % 4 == 0 and lib.alignn_gemm_nt_x6_supported(M, N, K):
         if a_amax is None:
             a_amax = get_amax(a)

@@ -27,7 +27,7 @@ def timeit(fn, iters=10):
 
 
 def gemms():
-    for (M, Nn, K) in [(T, 256, 256), (E, 1024, 256), (E, 256, 1024), (E, 256, 256), (T, 256, 64), (N, 1024, 256)]:
+    for (M, Nn, K) in [(T, 256, 256), (E, 1024, 256), (E, 256, 1024), (E, 256, 256), (T, 256, 64), (N, 1024, 256), (N, 256, 1024), (N, 256, 256)]:
         a = torch.randn(M, K, device=DEV)
         w = torch.randn(Nn, K, device=DEV) / K**0.5
         b = torch.randn(Nn, device=DEV)
