@@ -471,10 +471,15 @@ int alignn_bn_silu_bwd_reduce(const float* GY, int64_t ldgy, const float* X, int
                               int64_t rows, int F, float* partial, alignn_stream_t stream) {
     if (!feat_ok(F)) return (int)hipErrorInvalidValue;
     int slabs = slabs_for(rows);
-    // (no read-once hint here: alignn_bn_silu_bwd_apply / the conv backward re-read both operands right after)
-    BwdReduceFn<false> fn{GY, ldgy, X, ldx, stat, F};
-    hipLaunchKernelGGL(col_reduce_kernel<BwdReduceFn<false>>, dim3(slabs), dim3(kThreads), 0, (hipStream_t)stream, fn,
-                       rows, F, slabs, partial);
+    if (streaming(rows, F)) {  // T-sized: the re-read by the apply / conv-backward pass cannot come from cache anyway
+        BwdReduceFn<true> fn{GY, ldgy, X, ldx, stat, F};
+        hipLaunchKernelGGL(col_reduce_kernel<BwdReduceFn<true>>, dim3(slabs), dim3(kThreads), 0, (hipStream_t)stream, fn,
+                           rows, F, slabs, partial);
+    } else {
+        BwdReduceFn<false> fn{GY, ldgy, X, ldx, stat, F};
+        hipLaunchKernelGGL(col_reduce_kernel<BwdReduceFn<false>>, dim3(slabs), dim3(kThreads), 0, (hipStream_t)stream, fn,
+                           rows, F, slabs, partial);
+    }
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }

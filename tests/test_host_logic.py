@@ -118,3 +118,41 @@ def test_line_graph_blocks_are_dense_and_source_sorted():
                             torch.from_numpy(raw.batch_num_nodes), torch.from_numpy(raw.lg_u[keep]),
                             torch.from_numpy(raw.lg_v[keep]))
     assert f.lg.grp_seg_ptr is not None and f.lg.dense_max_src == 0
+
+
+def test_packed_batch_roundtrip_and_staging_on_cpu():
+    """loader.pack -> one buffer -> loader.stage rebuilds the SAME canonical batch GraphBatch.from_raw builds from
+    the explicit line graph (structure bit-identical; cosines are left to the GPU kernel / the model here)."""
+    import numpy as np
+    import torch
+
+    from alignn_amd import loader
+    from alignn_amd.graph import GraphBatch
+    from alignn_amd.synthetic import make_batch
+
+    raw = make_batch(3, 11, seed0=77)
+    tgt = np.array([0.5, -1.0, 2.0], dtype=np.float32)
+    p = loader.pack_raw(raw, target=tgt, pin=False)
+    assert p.nbytes < 0.3 * (raw.lg_u.nbytes + raw.lg_v.nbytes + raw.u.nbytes + raw.v.nbytes)  # no T-sized list crosses
+    assert torch.equal(p.host("u"), torch.from_numpy(raw.u.astype(np.int32)))
+    b, t = loader.stage(p, "cpu", cosines=False)
+    ref = GraphBatch.from_raw(raw)
+    for name in ("seg_ptr", "src", "dst", "out_ptr", "out_slot"):
+        assert torch.equal(getattr(b.g, name), getattr(ref.g, name)), name
+        assert torch.equal(getattr(b.lg, name), getattr(ref.lg, name)), name
+    assert torch.equal(b.lg.seg_node, ref.lg.seg_node) and b.lg.dense_max_src == ref.lg.dense_max_src
+    assert torch.equal(b.r, ref.r) and torch.equal(b.atom_features, ref.atom_features)
+    assert torch.allclose(b.volume, ref.volume) and torch.equal(b.graph_ptr, ref.graph_ptr)
+    assert torch.equal(t, torch.from_numpy(tgt)) and b.h is None
+    # index-compressed atoms: species + a device-resident table
+    table = torch.randn(5, raw.atom_features.shape[1])
+    species = np.arange(raw.num_nodes) % 5
+    p2 = loader.pack(raw.u, raw.v, raw.batch_num_nodes, raw.r, raw.lattice, species=species, pin=False)
+    b2, t2 = loader.stage(p2, "cpu", feature_table=table, cosines=False)
+    assert t2 is None and torch.equal(b2.atom_features, table[torch.from_numpy(species)])
+    assert p2.nbytes < p.nbytes
+    import pytest
+    with pytest.raises(ValueError):
+        loader.pack(raw.u, raw.v + 10_000, raw.batch_num_nodes, raw.r, raw.lattice, species=species, pin=False)
+    got = [x for x in loader.PrefetchLoader([p, p2], "cpu", feature_table=table, cosines=False)]
+    assert len(got) == 2 and torch.equal(got[0][0].lg.src, ref.lg.src)
