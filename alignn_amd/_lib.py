@@ -53,6 +53,9 @@ SIGNATURES = {
     "alignn_ln_silu_fwd": (_i32, [_p, _i64, _p, _i64, _p, _p, _f32, _p, _i64, _p, _i64, _i32, _p, _p]),
     "alignn_ln_silu_bwd": (_i32, [_p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _p, _i64, _i32, _p, _p]),
     "alignn_bond_cosine_fwd": (_i32, [_p, _p, _p, _p, _i64, _p]),
+    "alignn_rbf_bwd": (_i32, [_p, _p, _f32, _p, _p, _i64, _i32, _p]),
+    "alignn_norm3_bwd": (_i32, [_p, _p, _p, _i64, _p]),
+    "alignn_bond_cosine_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _p]),
     "alignn_egc_bwd_lg_dense_supported": (_i32, [_i32]),
     "alignn_egc_bwd_lg_dense": (_i32, [_p, _p, _p, _p, _p, _p, _p, _i32, _i64, _p, _p, _i64, _i32, _p, _p, _i32, _p, _p, _p, _p, _p, _p]),
     "alignn_egc_bwd_src": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p]),

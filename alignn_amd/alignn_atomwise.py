@@ -208,7 +208,9 @@ class ALIGNNAtomWise(nn.Module):
         for layer in self.gcn_layers:
             x, y = ff.edge_gated_conv(b.g, x, y, layer)
         counts = (b.graph_ptr[1:] - b.graph_ptr[:-1]).to(torch.float32)
-        hpool = ff.segment_sum(x, ff.by_graph(b.graph_ptr)) / counts.unsqueeze(1)
+        if "atoms_by_graph" not in b.cache:  # (repeat_interleave sizes its output on the host: once per batch)
+            b.cache["atoms_by_graph"] = ff.by_graph(b.graph_ptr)
+        hpool = ff.segment_sum(x, b.cache["atoms_by_graph"]) / counts.unsqueeze(1)
         out = torch.squeeze(ff.linear(hpool, self.fc))
         additional_out = torch.empty(1)
         if cfg.additional_output_features > 0:
@@ -234,11 +236,9 @@ class ALIGNNAtomWise(nn.Module):
                 raise ValueError("stress needs the cell volumes: g.ndata['V'] (or GraphBatch.volume)")
             # per crystal: -160.21766208 * r_g^T f_g / V_g (:615-638); bonds of a crystal are contiguous slots
             outer = (r.unsqueeze(2) * pair_forces.unsqueeze(1)).reshape(-1, 9)
-            rel = ff.Relation(None, b.edge_graph_ptr, None, None, b.batch_size)
-            rel.idx = torch.repeat_interleave(
-                torch.arange(b.batch_size, device=r.device, dtype=torch.int32),
-                (b.edge_graph_ptr[1:] - b.edge_graph_ptr[:-1]).to(torch.int64))
-            st = ff.segment_sum(outer, rel).reshape(-1, 3, 3)
+            if "bonds_by_graph" not in b.cache:
+                b.cache["bonds_by_graph"] = ff.by_graph(b.edge_graph_ptr)
+            st = ff.segment_sum(outer, b.cache["bonds_by_graph"]).reshape(-1, 3, 3)
             stress = cfg.stress_multiplier * (-160.21766208) * st / b.volume.reshape(-1, 1, 1)
         if self.link:
             out = self.link(out)
@@ -252,15 +252,27 @@ class ALIGNNAtomWise(nn.Module):
         if cfg.include_pos_deriv:
             raise NotImplementedError("include_pos_deriv is 'not tested yet' upstream and outside this build")
         b = self._batch(g)
-        if cfg.calculate_gradient:
+        # Forces: in training the loss differentiates THROUGH them -> composed, twice-differentiable path.  In eval
+        # mode (MD / calculators: alignn/ff/calculators.py) only the first derivative is needed -> the fused kernels
+        # with their hand-written backward, r as a leaf.
+        fused_forces = cfg.calculate_gradient and not self.training and torch.is_grad_enabled()
+        if cfg.calculate_gradient and not fused_forces:
             return self._forward_ff(b)
+        if fused_forces:
+            with ops.no_param_grad():
+                return self._forward_fused(b, True)
+        return self._forward_fused(b, False)
+
+    def _forward_fused(self, b: GraphBatch, fused_forces: bool):
+        cfg = self.config
         n_a, n_g = len(self.alignn_layers), len(self.gcn_layers)
         x = self.atom_embedding(b.atom_features)
-        bondlength = ops.bond_length(b.r)
+        r = b.r.detach().clone().requires_grad_(True) if fused_forces else b.r
+        bondlength = ops.bond_length(r)
         if n_a > 0:
             # lg_on_fly (default): recompute the cosines from r inside the forward (:424-431); otherwise use
             # the loader's lg.edata["h"] (:370-371)
-            h = ops.bond_cosines(b.r, b.lg.src, b.lg.dst) if cfg.lg_on_fly else b.h
+            h = ops.bond_cosines(r, b.lg) if cfg.lg_on_fly else b.h
             z = self.angle_embedding(h)
         if cfg.use_cutoff_function:
             if cfg.multiply_cutoff:
@@ -284,6 +296,10 @@ class ALIGNNAtomWise(nn.Module):
         atomwise_pred = torch.empty(1)
         if cfg.atomwise_output_features > 0 and cfg.atomwise_weight != 0:
             atomwise_pred = ops.linear(x, self.fc_atomwise.weight, self.fc_atomwise.bias)
+        forces, stress = torch.empty(1), torch.empty(1)
+        if fused_forces:
+            forces, stress = self._forces_from_energy(b, out, r, bondlength)
+            out = out.detach()
         if self.link:
             out = self.link(out)
         if self.classification:
@@ -291,7 +307,37 @@ class ALIGNNAtomWise(nn.Module):
         return {
             "out": out,
             "additional": additional_out,
-            "grad": torch.empty(1),
-            "stresses": torch.empty(1),
+            "grad": forces,
+            "stresses": stress,
             "atomwise_pred": atomwise_pred,
         }
+
+    def _forces_from_energy(self, b: GraphBatch, out, r, bondlength):
+        """alignn_atomwise.py:494-638 for inference: E_tot -> pair forces -dE/dr (one fused backward) -> per-atom
+        forces and per-crystal virial stresses.  Nothing here is differentiated again."""
+        cfg = self.config
+        counts = (b.graph_ptr[1:] - b.graph_ptr[:-1]).to(torch.float32)
+        en_out = out * counts if cfg.energy_mult_natoms else out
+        if cfg.use_penalty:
+            pen = torch.where(bondlength < cfg.penalty_threshold,
+                              cfg.penalty_factor * (cfg.penalty_threshold - bondlength), torch.zeros_like(bondlength))
+            en_out = en_out + torch.sum(pen)
+        (g_r,) = torch.autograd.grad(en_out, r, grad_outputs=torch.ones_like(en_out))
+        pair_forces = cfg.grad_multiplier * g_r
+        if cfg.force_mult_natoms:
+            pair_forces = pair_forces * b.g.n_nodes
+        gg = b.g
+        forces = ops._segment_sum_raw(pair_forces, gg.seg_ptr, None, gg.seg_node, gg.n_nodes)  # copy_e / sum by destination
+        if cfg.add_reverse_forces:
+            forces = forces - ops._segment_sum_raw(pair_forces, gg.out_ptr, gg.out_slot, None, gg.n_nodes)
+        forces = torch.squeeze(forces)
+        stress = torch.empty(1)
+        if cfg.stresswise_weight != 0:
+            if not cfg.batch_stress:
+                raise NotImplementedError("batch_stress=False (single-crystal virial) is outside this build")
+            if b.volume is None:
+                raise ValueError("stress needs the cell volumes: g.ndata['V'] (or GraphBatch.volume)")
+            outer = (r.detach().unsqueeze(2) * pair_forces.unsqueeze(1)).reshape(-1, 9)
+            st = ops._segment_sum_raw(outer, b.edge_graph_ptr, None, None, b.batch_size).reshape(-1, 3, 3)
+            stress = cfg.stress_multiplier * (-160.21766208) * st / b.volume.reshape(-1, 1, 1)
+        return forces, stress

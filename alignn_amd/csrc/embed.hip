@@ -74,6 +74,52 @@ __global__ void bond_cosine_kernel(const float* __restrict__ r, const int32_t* _
     }
 }
 
+// ---- first derivatives of the featurisation w.r.t. the geometry (force-field inference: F = -dE/dr) ----
+// gd[r] = sum_k G[r,k] * d/dd exp(-gamma (d-c_k)^2) = sum_k G[r,k] * rbf_k * (-2 gamma (d - c_k))
+__global__ void rbf_bwd_kernel(const float* __restrict__ d, const float* __restrict__ centers, float gamma,
+                               const float* __restrict__ G, float* __restrict__ gd, int64_t rows, int bins) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
+        const float x = d[r];
+        float acc = 0.0f;
+        for (int k = 0; k < bins; ++k) {
+            const float t = x - centers[k];
+            acc += G[r * bins + k] * __expf(-gamma * t * t) * (-2.0f * gamma * t);
+        }
+        gd[r] = acc;
+    }
+}
+
+// gv[r,:] = g[r] * v[r,:] / |v[r]|
+__global__ void norm3_bwd_kernel(const float* __restrict__ v, const float* __restrict__ g, float* __restrict__ gv,
+                                 int64_t rows) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
+        const float x = v[3 * r], y = v[3 * r + 1], z = v[3 * r + 2];
+        const float s = g[r] / sqrtf(x * x + y * y + z * z);
+        gv[3 * r] = s * x, gv[3 * r + 1] = s * y, gv[3 * r + 2] = s * z;
+    }
+}
+
+// per triplet k (a = r[e1], b = r[e2], c = -a.b/(|a||b|)):  ga[k] = gh[k] dc/da,  gb[k] = gh[k] dc/db
+//   dc/da = -b/(|a||b|) - c a/|a|^2 ,  dc/db = -a/(|a||b|) - c b/|b|^2 ;  zero where the clamp is active
+__global__ void bond_cosine_bwd_kernel(const float* __restrict__ r, const int32_t* __restrict__ e1,
+                                       const int32_t* __restrict__ e2, const float* __restrict__ gh,
+                                       float* __restrict__ ga, float* __restrict__ gb, int64_t T) {
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < T; k += (int64_t)gridDim.x * blockDim.x) {
+        const float* a = r + 3 * (int64_t)e1[k];
+        const float* b = r + 3 * (int64_t)e2[k];
+        const float na2 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2], nb2 = b[0] * b[0] + b[1] * b[1] + b[2] * b[2];
+        const float inv = 1.0f / (sqrtf(na2) * sqrtf(nb2));
+        const float c = -(a[0] * b[0] + a[1] * b[1] + a[2] * b[2]) * inv;
+        const float g = (c >= -1.0f && c <= 1.0f) ? gh[k] : 0.0f;
+        const float ca = c / na2, cb = c / nb2;
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {
+            ga[3 * k + x] = g * (-b[x] * inv - ca * a[x]);
+            gb[3 * k + x] = g * (-a[x] * inv - cb * b[x]);
+        }
+    }
+}
+
 // out[node(s), f] = sum_{k in [ptr[s], ptr[s+1])} vals[slot ? slot[k] : k, f]   (generic width F, fixed order)
 __global__ void segment_sum_kernel(const float* __restrict__ vals, int64_t ldv, const int32_t* __restrict__ ptr,
                                    const int32_t* __restrict__ slot, const int32_t* __restrict__ node,
@@ -141,6 +187,32 @@ int alignn_bond_cosine_fwd(const float* r, const int32_t* e1, const int32_t* e2,
                             alignn_stream_t stream) {
     if (T == 0) return 0;
     hipLaunchKernelGGL(bond_cosine_kernel, dim3(grid_for(T)), dim3(256), 0, (hipStream_t)stream, r, e1, e2, h, T);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_rbf_bwd(const float* d, const float* centers, float gamma, const float* G, float* gd, int64_t rows, int bins,
+                   alignn_stream_t stream) {
+    if (bins <= 0) return (int)hipErrorInvalidValue;
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(rbf_bwd_kernel, dim3(grid_for(rows)), dim3(256), 0, (hipStream_t)stream, d, centers, gamma, G, gd,
+                       rows, bins);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_norm3_bwd(const float* v, const float* g, float* gv, int64_t rows, alignn_stream_t stream) {
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(norm3_bwd_kernel, dim3(grid_for(rows)), dim3(256), 0, (hipStream_t)stream, v, g, gv, rows);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_bond_cosine_bwd(const float* r, const int32_t* e1, const int32_t* e2, const float* gh, float* ga, float* gb,
+                           int64_t T, alignn_stream_t stream) {
+    if (T == 0) return 0;
+    hipLaunchKernelGGL(bond_cosine_bwd_kernel, dim3(grid_for(T)), dim3(256), 0, (hipStream_t)stream, r, e1, e2, gh, ga,
+                       gb, T);
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }

@@ -18,7 +18,7 @@ Layout chosen for locality on MI355X:
 
 from __future__ import annotations
 
-from dataclasses import dataclass
+from dataclasses import dataclass, field
 from typing import Optional
 
 import torch
@@ -182,6 +182,7 @@ class GraphBatch:
     r: Optional[torch.Tensor] = None  # [E, 3] canonical g-slot order
     h: Optional[torch.Tensor] = None  # [T]    canonical lg-slot order
     volume: Optional[torch.Tensor] = None  # [B] cell volumes (g.ndata["V"] of each crystal's first atom)
+    cache: dict = field(default_factory=dict)  # derived index structures (built once per batch, outside graph capture)
 
     @property
     def edge_graph_ptr(self) -> torch.Tensor:

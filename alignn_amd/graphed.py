@@ -21,7 +21,9 @@ from . import ops
 class GraphedTrainStep:
     def __init__(self, model, batch, target, optimizer, loss_fn=torch.nn.functional.l1_loss, warmup: int = 3):
         self.model, self.batch, self.optimizer = model, batch, optimizer
-        self.target = target.clone()
+        # ``target`` may be a tensor or a tuple of tensors (energy, forces, stresses for the force-field head);
+        # ``loss_fn(model_output, target)`` gets it back in the same shape
+        self.target = tuple(t.clone() for t in target) if isinstance(target, (tuple, list)) else target.clone()
         self.loss = None
         # warm-up on a side stream (allocator pools, lazy kernel attributes, the side stream itself)
         s = torch.cuda.Stream()
@@ -42,7 +44,11 @@ class GraphedTrainStep:
         ops.reset_amax_arena()  # ... and eager code after the capture must not draw slots from the graph's pool
 
     def set_target(self, target):
-        self.target.copy_(target)
+        if isinstance(self.target, tuple):
+            for dst, src in zip(self.target, target):
+                dst.copy_(src)
+        else:
+            self.target.copy_(target)
 
     def __call__(self):
         """Replay one training step; returns the (static) loss tensor of that step."""

@@ -22,6 +22,21 @@ FUSED_LG_BACKWARD = True  # tests flip this to compare against the generic two-p
 DENSE_LG_BACKWARD = True  # ... and this one to compare the dense-block kernel against the by-source fused kernel
 
 
+# Force-field inference differentiates the energy w.r.t. the geometry only: inside ``no_param_grad()`` the autograd
+# nodes built here skip their weight / bias / norm-parameter gradients (the engine would otherwise compute them - the
+# parameters require grad - and throw them away).
+_PARAM_GRADS = {"on": True}
+
+
+class no_param_grad:
+    def __enter__(self):
+        self.prev = _PARAM_GRADS["on"]
+        _PARAM_GRADS["on"] = False
+
+    def __exit__(self, *exc):
+        _PARAM_GRADS["on"] = self.prev
+
+
 def _empty(*shape, like):
     return torch.empty(*shape, dtype=torch.float32, device=like.device)
 
@@ -373,16 +388,60 @@ def _ln_silu_bwd(gy, x, gamma, beta, stats, out, amax=None):
     return red
 
 
-def bond_cosines(r, e1, e2):
-    """compute_bond_cosines on the canonical line graph (alignn/graphs.py:847-864)."""
+def _bond_cosines_raw(r, e1, e2):
     lib = _lib.load()
-    if r.requires_grad:
-        raise NotImplementedError("gradient w.r.t. bond vectors (force head) is not part of this build yet")
     require_f32(r)
-    r = r.contiguous()
     h = _empty(e1.numel(), like=r)
     check(lib.alignn_bond_cosine_fwd(ptr(r), ptr(e1), ptr(e2), ptr(h), e1.numel(), stream()), "bond_cosine_fwd")
     return h
+
+
+def _segment_sum_raw(vals, seg_ptr, slot, node, n_out):
+    """out[node[s] or s] = sum of vals[slot[k] or k] over k in segment s (any width; fixed order)."""
+    lib = _lib.load()
+    vals = vals.contiguous()
+    out = _empty(n_out, vals.shape[1], like=vals)
+    check(lib.alignn_segment_sum(ptr(vals), vals.stride(0), ptr(seg_ptr), ptr(slot), ptr(node), ptr(out), out.stride(0),
+                                 seg_ptr.numel() - 1, vals.shape[1], stream()), "segment_sum")
+    return out
+
+
+class BondCosFn(torch.autograd.Function):
+    """compute_bond_cosines with its FIRST derivative w.r.t. the bond vectors (force-field inference); the training
+    path that differentiates through the forces uses alignn_amd.ff.bond_cosines instead."""
+
+    @staticmethod
+    def forward(ctx, r, lg):
+        r = r.contiguous()
+        ctx.save_for_backward(r)
+        ctx.lg = lg
+        return _bond_cosines_raw(r, lg.src, lg.dst)
+
+    @staticmethod
+    def backward(ctx, gh):
+        lib = _lib.load()
+        (r,) = ctx.saved_tensors
+        lg = ctx.lg
+        T = lg.n_edges
+        ga, gb = _empty(T, 3, like=r), _empty(T, 3, like=r)
+        check(lib.alignn_bond_cosine_bwd(ptr(r), ptr(lg.src), ptr(lg.dst), ptr(gh.contiguous()), ptr(ga), ptr(gb), T,
+                                         stream()), "bond_cosine_bwd")
+        # dh/dr[e]: the triplets where e is the first bond (by source of L(g)) + those where it is the second (by dst)
+        gr = _segment_sum_raw(ga, lg.out_ptr, lg.out_slot, None, lg.n_nodes)
+        gr = gr + _segment_sum_raw(gb, lg.seg_ptr, None, lg.seg_node, lg.n_nodes)
+        return gr, None
+
+
+def bond_cosines(r, e1, e2=None):
+    """compute_bond_cosines on the canonical line graph (alignn/graphs.py:847-864).  ``bond_cosines(r, lg)`` with a
+    CSRGraph is differentiable w.r.t. ``r`` (first order); the index form ``(r, e1, e2)`` is forward only."""
+    if isinstance(e1, CSRGraph):
+        if r.requires_grad:
+            return BondCosFn.apply(r, e1)
+        return _bond_cosines_raw(r.contiguous(), e1.src, e1.dst)
+    if r.requires_grad:
+        raise NotImplementedError("pass the line graph itself (bond_cosines(r, lg)) to differentiate w.r.t. r")
+    return _bond_cosines_raw(r.contiguous(), e1, e2)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -397,6 +456,7 @@ class LinearFn(torch.autograd.Function):
         w = w.contiguous()
         ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
+        ctx.param_grads = _PARAM_GRADS["on"]
         return project(x, w, b)
 
     @staticmethod
@@ -404,9 +464,9 @@ class LinearFn(torch.autograd.Function):
         x, w = ctx.saved_tensors
         gy = gy.contiguous()
         gx = _dgrad(gy, w) if ctx.needs_input_grad[0] else None
-        gw = gemm_tn(gy, x) if ctx.needs_input_grad[1] else None
+        gw = gemm_tn(gy, x) if (ctx.needs_input_grad[1] and ctx.param_grads) else None
         gb = None
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if ctx.has_bias and ctx.needs_input_grad[2] and ctx.param_grads:
             if gy.shape[1] % 4 == 0:
                 gb = col_sum(gy)
             else:  # e.g. the 1-wide readout fc: gb[n] = (gy^T @ ones)[n]
@@ -447,6 +507,7 @@ class MLPLayerFn(torch.autograd.Function):
         ctx.save_for_backward(x, w, pre, stat, gamma, beta)
         ctx.training = training
         ctx.norm = norm
+        ctx.param_grads = _PARAM_GRADS["on"]
         return y
 
     @staticmethod
@@ -462,6 +523,8 @@ class MLPLayerFn(torch.autograd.Function):
             _bn_silu_bwd_apply(gy, pre, stat, gamma, red, not ctx.training, gpre, g_amax)
         dbeta, dgamma = red[0], red[1]
         gx = _dgrad(gpre, w, g_amax=g_amax) if ctx.needs_input_grad[0] else None
+        if not ctx.param_grads:
+            return gx, None, None, None, None, None, None, None, None
         x_amax = ctx.x_amax
         gw, gb = on_side_stream(lambda: (gemm_tn(gpre, x, g_amax, x_amax), col_sum(gpre)), [gpre, x, g_amax, x_amax])
         return gx, gw, gb, dgamma, dbeta, None, None, None, None
@@ -525,6 +588,7 @@ class EdgeGatedConvFn(torch.autograd.Function):
         ctx.training = training
         ctx.residual = residual
         ctx.norm = norm
+        ctx.param_grads = _PARAM_GRADS["on"]
         ctx.save_for_backward(x, y, wcat, w_eg, P, M, xpre, s0, hh, n_stat, e_stat, n_gamma, e_gamma, n_beta, e_beta)
         return x_out, y_out
 
@@ -621,6 +685,8 @@ class EdgeGatedConvFn(torch.autograd.Function):
         # tiles) run beside the NEXT layer's HBM-bound kernels instead of fighting these GEMMs for whole CUs.
         g_x = _dgrad(GP, wcat, addend=gx_out if ctx.residual else None, g_amax=gp_amax)
         g_y = _dgrad(GM, w_eg, addend=gy_out if (ctx.residual and gy_out is not None) else None, g_amax=gm_amax)
+        if not ctx.param_grads:
+            return (None, g_x, g_y) + (None,) * 16
         g_weg, g_beg, g_wcat, g_bcat = on_side_stream(_wgrads, [GM, y, GP, x, gb_part, gm_amax, gp_amax, x_amax, y_amax])
         dn_gamma, dn_beta = n_red[1], n_red[0]
         de_gamma = e_red[1] if e_red is not None else None
@@ -632,29 +698,72 @@ class EdgeGatedConvFn(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------
 # featurisation / readout
 # ---------------------------------------------------------------------------------------------
-def rbf_expand(d, centers, gamma):
-    """RBFExpansion.forward (alignn/models/utils.py:40-44). Inputs carry no gradient on this path."""
+def _rbf_raw(d, centers, gamma):
     lib = _lib.load()
-    if d.requires_grad:
-        raise NotImplementedError("gradient w.r.t. distances (force head) is not part of this build yet")
     require_f32(d, centers)
-    d = d.contiguous()
     rows, bins = d.numel(), centers.numel()
     out = _empty(rows, bins, like=d)
     check(lib.alignn_rbf_fwd(ptr(d), ptr(centers), float(gamma), ptr(out), rows, bins, stream()), "rbf_fwd")
     return out
 
 
-def bond_length(r):
-    """torch.norm(r, dim=1) (alignn/models/alignn.py:313)."""
+class RbfFn(torch.autograd.Function):
+    """RBF expansion with its first derivative w.r.t. the distance / cosine (force-field inference)."""
+
+    @staticmethod
+    def forward(ctx, d, centers, gamma):
+        d = d.contiguous()
+        ctx.save_for_backward(d, centers)
+        ctx.gamma = float(gamma)
+        return _rbf_raw(d, centers, gamma)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        d, centers = ctx.saved_tensors
+        g = g.contiguous()
+        gd = _empty(d.numel(), like=d)
+        check(lib.alignn_rbf_bwd(ptr(d), ptr(centers), ctx.gamma, ptr(g), ptr(gd), d.numel(), centers.numel(), stream()),
+              "rbf_bwd")
+        return gd.reshape(d.shape), None, None
+
+
+def rbf_expand(d, centers, gamma):
+    """RBFExpansion.forward (alignn/models/utils.py:40-44); differentiable (first order) w.r.t. ``d``."""
+    if d.requires_grad:
+        return RbfFn.apply(d, centers, gamma)
+    return _rbf_raw(d.contiguous(), centers, gamma)
+
+
+def _bond_length_raw(r):
     lib = _lib.load()
-    if r.requires_grad:
-        raise NotImplementedError("gradient w.r.t. bond vectors (force head) is not part of this build yet")
     require_f32(r)
-    r = r.contiguous()
     out = _empty(r.shape[0], like=r)
     check(lib.alignn_norm3_fwd(ptr(r), ptr(out), r.shape[0], stream()), "norm3_fwd")
     return out
+
+
+class BondLengthFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, r):
+        r = r.contiguous()
+        ctx.save_for_backward(r)
+        return _bond_length_raw(r)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        (r,) = ctx.saved_tensors
+        gr = torch.empty_like(r)
+        check(lib.alignn_norm3_bwd(ptr(r), ptr(g.contiguous()), ptr(gr), r.shape[0], stream()), "norm3_bwd")
+        return gr
+
+
+def bond_length(r):
+    """torch.norm(r, dim=1) (alignn/models/alignn.py:313); differentiable (first order) w.r.t. ``r``."""
+    if r.requires_grad:
+        return BondLengthFn.apply(r)
+    return _bond_length_raw(r.contiguous())
 
 
 class AvgPoolFn(torch.autograd.Function):

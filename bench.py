@@ -42,8 +42,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--atoms", type=int, default=60)
-    ap.add_argument("--model", default="alignn", choices=["alignn", "alignn_atomwise"],
-                    help="alignn = the headline BatchNorm model; alignn_atomwise = LayerNorm flavour, energy path (informational)")
+    ap.add_argument("--model", default="alignn", choices=["alignn", "alignn_atomwise", "alignn_ff"],
+                    help="alignn = the headline BatchNorm model; alignn_atomwise = LayerNorm flavour, energy path; alignn_ff = "
+                         "the same with calculate_gradient (forces + stress, BASELINE configs[3]: use --batch 16 --atoms 200) "
+                         "(both informational)")
     ap.add_argument("--kind", default="crystal", choices=["crystal", "molecule"],
                     help="molecule = BASELINE configs[4] shape (QM9-like, 9-27 atoms, no periodic images); not the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -163,22 +165,38 @@ def main():
     else:
         from alignn_amd import ALIGNNAtomWise, ALIGNNAtomWiseConfig
 
+        ff = args.model == "alignn_ff"
         model = ALIGNNAtomWise(ALIGNNAtomWiseConfig(name="alignn_atomwise", alignn_layers=4, gcn_layers=4,
                                                     hidden_features=256, atom_input_features=92,
-                                                    calculate_gradient=False)).to(dev).train()
+                                                    calculate_gradient=ff, stresswise_weight=0.05 if ff else 0.0)).to(dev).train()
         predict = lambda b: model(b)["out"]  # noqa: E731
     broadcast_parameters(model)
     target = torch.randn(B, generator=torch.Generator().manual_seed(1 + rank)).to(dev)
     sync = FlatGradSync(model.parameters())
     opt = torch.optim.AdamW(model.parameters(), lr=1e-3, fused=True)
 
-    def step():
-        sync.zero_grad()
-        loss = torch.nn.functional.l1_loss(predict(batch), target)
-        loss.backward()
-        sync.sync()
-        opt.step()
-        return loss
+    if args.model == "alignn_ff":
+        # SURVEY 8(d) cfg 4: loss = L1(energy) + L1(forces) + L1(stress), differentiating THROUGH the forces
+        f_tgt = torch.randn(raw.num_nodes, 3, generator=torch.Generator().manual_seed(7 + rank)).to(dev)
+        s_tgt = torch.randn(B, 3, 3, generator=torch.Generator().manual_seed(8 + rank)).to(dev)
+
+        def step():
+            sync.zero_grad()
+            o = model(batch)
+            l1 = torch.nn.functional.l1_loss
+            loss = l1(o["out"], target) + l1(o["grad"], f_tgt) + l1(o["stresses"], s_tgt)
+            loss.backward()
+            sync.sync()
+            opt.step()
+            return loss
+    else:
+        def step():
+            sync.zero_grad()
+            loss = torch.nn.functional.l1_loss(predict(batch), target)
+            loss.backward()
+            sync.sync()
+            opt.step()
+            return loss
 
     log(f"rank {rank}: batch N={raw.num_nodes} E={raw.num_edges} T={raw.num_triplets}; warmup")
     for _ in range(args.warmup):

@@ -262,6 +262,17 @@ int alignn_bond_cosine_fwd(const float* r, const int32_t* e1, const int32_t* e2,
                            alignn_stream_t stream);
 /* torch.norm(r, dim=1) (alignn/models/alignn.py:313): out[r] = ||v[r,0:3]|| */
 int alignn_norm3_fwd(const float* v, float* out, int64_t rows, alignn_stream_t stream);
+/* First derivatives of the three featurisation steps w.r.t. the geometry - what torch autograd does for the
+ * reference when ALIGNNAtomWise takes forces = -dE/dr (alignn_atomwise.py:512-539):
+ *   rbf:    gd[r] = sum_k G[r,k] * d/dd exp(-gamma (d[r]-c[k])^2)
+ *   norm3:  gv[r,:] = g[r] * v[r,:]/|v[r]|
+ *   cosine: per triplet k, ga[k,:] = gh[k] dh/dr[e1[k]], gb[k,:] = gh[k] dh/dr[e2[k]] (zero where the clamp is
+ *           active); the caller segment-sums ga by source and gb by destination of L(g) (alignn_segment_sum). */
+int alignn_rbf_bwd(const float* d, const float* centers, float gamma, const float* G, float* gd, int64_t rows,
+                   int bins, alignn_stream_t stream);
+int alignn_norm3_bwd(const float* v, const float* g, float* gv, int64_t rows, alignn_stream_t stream);
+int alignn_bond_cosine_bwd(const float* r, const int32_t* e1, const int32_t* e2, const float* gh, float* ga,
+                           float* gb, int64_t T, alignn_stream_t stream);
 /* dgl.nn.AvgPooling (alignn/models/alignn.py:325): out[b] = mean_{i in graph b} x[i]; graph_ptr[B+1] */
 int alignn_segment_mean_fwd(const float* X, const int32_t* graph_ptr, float* out, int B, int H,
                             alignn_stream_t stream);

@@ -331,6 +331,71 @@ def test_golden_atomwise_force_stress_head():
     assert n > 40
 
 
+def test_golden_atomwise_forces_eval_mode_fused_path():
+    """eval(): forces need only the FIRST derivative -> the fused kernels with their hand-written backward plus the
+    geometry derivatives (alignn_rbf_bwd / norm3_bwd / bond_cosine_bwd).  Same energies, forces and stresses as the
+    reference's class (golden; LayerNorm models have no train/eval difference) and as the composed training path;
+    no parameter gradient is produced."""
+    from alignn_amd import ALIGNNAtomWise, ALIGNNAtomWiseConfig
+
+    z = load_golden("atomwise_ff_tiny.npz")
+    raw = raw_from_golden(z)
+    cfg = ALIGNNAtomWiseConfig(name="alignn_atomwise", alignn_layers=2, gcn_layers=2, hidden_features=32,
+                               embedding_features=16, atom_input_features=92, calculate_gradient=True,
+                               stresswise_weight=0.05)
+    model = ALIGNNAtomWise(cfg)
+    model.load_state_dict(state_dict_from_golden(z))
+    model = model.to(DEV)
+    batch = GraphBatch.from_raw(raw, device=DEV)
+    batch.volume = torch.from_numpy(z["volume"]).to(DEV).float()
+    res = model.eval()(batch)
+    assert rel_err(res["out"], z["pred"]) < 1e-4
+    assert res["grad"].shape == (raw.num_nodes, 3) and rel_err(res["grad"], z["forces"]) < 2e-4
+    assert res["stresses"].shape == (2, 3, 3) and rel_err(res["stresses"], z["stresses"]) < 2e-4
+    assert not res["out"].requires_grad and not res["grad"].requires_grad
+    assert all(p.grad is None for p in model.parameters())
+    comp = model.train()(batch)
+    assert rel_err(res["grad"], comp["grad"].detach()) < 1e-4 and rel_err(res["stresses"], comp["stresses"].detach()) < 1e-4
+    with torch.no_grad():  # no autograd at all: energies only, as the reference's calculators do for energy-only calls
+        model.eval()
+        e_only = ALIGNNAtomWise(cfg.model_copy(update={"calculate_gradient": False})).to(DEV).eval()
+        e_only.load_state_dict(model.state_dict())
+        assert rel_err(e_only(batch)["out"], z["pred"]) < 1e-4
+
+
+def test_geometry_derivative_kernels_match_torch_autograd():
+    from alignn_amd import ops
+    from alignn_amd.graph import line_graph_of, build_csr
+
+    raw = make_batch(2, 9, seed0=91)
+    b = GraphBatch.from_raw(raw, device=DEV)
+    r = b.r.clone().requires_grad_(True)
+    # bond length
+    w = torch.randn(r.shape[0], device=DEV)
+    (ops.bond_length(r) * w).sum().backward()
+    r2 = b.r.clone().requires_grad_(True)
+    (torch.norm(r2, dim=1) * w).sum().backward()
+    assert rel_err(r.grad, r2.grad) < 1e-5
+    # cosines (incl. the clamp) on the canonical line graph
+    r = b.r.clone().requires_grad_(True)
+    wt = torch.randn(b.lg.n_edges, device=DEV)
+    h = ops.bond_cosines(r, b.lg)
+    (h * wt).sum().backward()
+    r2 = b.r.clone().requires_grad_(True)
+    a, c = -r2[b.lg.src.long()], r2[b.lg.dst.long()]
+    h2 = torch.clamp((a * c).sum(1) / (a.norm(dim=1) * c.norm(dim=1)), -1, 1)
+    (h2 * wt).sum().backward()
+    assert rel_err(h, h2) < 1e-6 and rel_err(r.grad, r2.grad) < 2e-5
+    # rbf
+    d = (torch.rand(1000, device=DEV) * 8).requires_grad_(True)
+    centers = torch.linspace(0, 8, 80, device=DEV)
+    G = torch.randn(1000, 80, device=DEV)
+    (ops.rbf_expand(d, centers, 9.875) * G).sum().backward()
+    d2 = d.detach().clone().requires_grad_(True)
+    (torch.exp(-9.875 * (d2.unsqueeze(1) - centers) ** 2) * G).sum().backward()
+    assert rel_err(d.grad, d2.grad) < 2e-5
+
+
 def test_force_reduction_self_consistency():
     """Port of the reference's own hot-path test (alignn/tests/test_force_reduction.py:212-229): forces from
     displacement autograd reduced over in- minus out-edges equal forces from position autograd."""
