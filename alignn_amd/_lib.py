@@ -53,6 +53,7 @@ SIGNATURES = {
     "alignn_ln_silu_fwd": (_i32, [_p, _i64, _p, _i64, _p, _p, _f32, _p, _i64, _p, _i64, _i32, _p, _p]),
     "alignn_ln_silu_bwd": (_i32, [_p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _p, _i64, _i32, _p, _p]),
     "alignn_bond_cosine_fwd": (_i32, [_p, _p, _p, _p, _i64, _p]),
+    "alignn_egc_gate_infer": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p]),
     "alignn_rbf_bwd": (_i32, [_p, _p, _f32, _p, _p, _i64, _i32, _p]),
     "alignn_norm3_bwd": (_i32, [_p, _p, _p, _i64, _p]),
     "alignn_bond_cosine_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _p]),

@@ -150,6 +150,18 @@ class EdgeGatedGraphConv(nn.Module):
         # fused node projection: P = x [W_sg; W_dg; W_du; W_su]^T -> A | Bd | Bh | Ux
         wcat = torch.cat([self.src_gate.weight, self.dst_gate.weight, self.dst_update.weight, self.src_update.weight], 0)
         bcat = torch.cat([self.src_gate.bias, self.dst_gate.bias, self.dst_update.bias, self.src_update.bias], 0)
+        if (self._norm == "batch" and not self.training and ops.INFER_FUSED
+                and not (torch.is_grad_enabled() and (node_feats.requires_grad or edge_feats.requires_grad))):
+            # pure inference (pretrained.py, model.eval() under no_grad): BatchNorm folded into the gate pass
+            with torch.no_grad():
+                x, y = ops.edge_gated_conv_infer(
+                    csr, node_feats, y_in, wcat, bcat, self.edge_gate.weight, self.edge_gate.bias,
+                    self.bn_nodes.weight, self.bn_nodes.bias, self.bn_nodes.running_mean, self.bn_nodes.running_var,
+                    self.bn_edges.weight, self.bn_edges.bias, self.bn_edges.running_mean, self.bn_edges.running_var,
+                    self.residual, need_edge_out)
+            if not canonical and y is not None:
+                y = y[csr.inv]
+            return x, y
         _bump(self.bn_nodes, self.training)
         _bump(self.bn_edges, self.training)
         x, y = ops.EdgeGatedConvFn.apply(

@@ -47,13 +47,19 @@ __device__ __forceinline__ void block_slab_store(float4 s, float4 ss, float* sla
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
-template <bool STREAM>
+// INFER: nothing is kept for a backward pass and the edge normalisation is a fixed affine map (BatchNorm in eval
+// mode: e_stat = mean, rstd, scale, shift from the running statistics), so the edge output
+// y' = y + silu((m - mean) * scale + shift) is written straight from the gate pass and m itself never goes to memory:
+// 1 read of C (+ 1 of y) + 1 write instead of read C, write m, read m, read y, write y'.
+template <bool STREAM, bool INFER>
 __global__ __launch_bounds__(kThreads) void egc_gate_fwd_kernel(
     const float* __restrict__ P, float* __restrict__ M, const int32_t* __restrict__ seg_ptr,
     const int32_t* __restrict__ seg_node, const int32_t* __restrict__ src, int n_seg, int H,
     float* __restrict__ XPRE, float* __restrict__ S0, float* __restrict__ HH, float* __restrict__ e_partial,
-    float* __restrict__ n_partial) {
+    float* __restrict__ n_partial, const float* __restrict__ e_stat, const float* __restrict__ Y,
+    float* __restrict__ YOUT, float* __restrict__ y_amax) {
     __shared__ float4 sh[2][kWavesPerBlock][ALIGNN_WAVE];
+    float y_am = 0.0f;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t ldp = 4 * (int64_t)H;
@@ -64,6 +70,12 @@ __global__ __launch_bounds__(kThreads) void egc_gate_fwd_kernel(
         const int f = c0 + 4 * lane;
         const bool active = f < H;
         float4 e_s = f4_zero(), e_ss = f4_zero(), n_s = f4_zero(), n_ss = f4_zero();
+        float4 e_mean = f4_zero(), e_sc = f4_zero(), e_sh = f4_zero();
+        if (INFER && active && YOUT) {
+            e_mean = f4_ld(e_stat + f);
+            e_sc = f4_ld(e_stat + 2 * H + f);
+            e_sh = f4_ld(e_stat + 3 * H + f);
+        }
         if (active) {
             for (int s = first; s < n_seg; s += stride) {
                 const int beg = seg_ptr[s], end = seg_ptr[s + 1];
@@ -88,7 +100,17 @@ __global__ __launch_bounds__(kThreads) void egc_gate_fwd_kernel(
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         float4 m = f4_add(f4_add(a[k], bd), c[k]);
-                        f4_sts<STREAM>(M + (int64_t)(e + k) * H + f, m);
+                        if (INFER) {
+                            if (YOUT) {
+                                const float4 zz = f4_fma(f4_sub(m, e_mean), e_sc, e_sh);
+                                float4 o = make_float4(silu_f(zz.x), silu_f(zz.y), silu_f(zz.z), silu_f(zz.w));
+                                if (Y) o = f4_add(o, f4_lds<STREAM>(Y + (int64_t)(e + k) * H + f));
+                                f4_sts<STREAM>(YOUT + (int64_t)(e + k) * H + f, o);
+                                y_am = fmaxf(y_am, f4_absmax(o));
+                            }
+                        } else {
+                            f4_sts<STREAM>(M + (int64_t)(e + k) * H + f, m);
+                        }
                         float4 sg = f4_sigmoid(m);
                         s1 = f4_fma(sg, bh[k], s1);
                         s0 = f4_add(s0, sg);
@@ -99,7 +121,17 @@ __global__ __launch_bounds__(kThreads) void egc_gate_fwd_kernel(
                 for (; e < end; ++e) {
                     const float* Pu = P + (int64_t)src[e] * ldp;
                     float4 m = f4_add(f4_add(f4_ld(Pu + f), bd), f4_lds<STREAM>(M + (int64_t)e * H + f));
-                    f4_sts<STREAM>(M + (int64_t)e * H + f, m);
+                    if (INFER) {
+                        if (YOUT) {
+                            const float4 zz = f4_fma(f4_sub(m, e_mean), e_sc, e_sh);
+                            float4 o = make_float4(silu_f(zz.x), silu_f(zz.y), silu_f(zz.z), silu_f(zz.w));
+                            if (Y) o = f4_add(o, f4_lds<STREAM>(Y + (int64_t)e * H + f));
+                            f4_sts<STREAM>(YOUT + (int64_t)e * H + f, o);
+                            y_am = fmaxf(y_am, f4_absmax(o));
+                        }
+                    } else {
+                        f4_sts<STREAM>(M + (int64_t)e * H + f, m);
+                    }
                     float4 sg = f4_sigmoid(m);
                     s1 = f4_fma(sg, f4_ld(Pu + 2 * H + f), s1);
                     s0 = f4_add(s0, sg);
@@ -124,6 +156,7 @@ __global__ __launch_bounds__(kThreads) void egc_gate_fwd_kernel(
         if (n_partial)
             block_slab_store(n_s, n_ss, n_partial + (size_t)blockIdx.x * 2 * H, H, f, active, sh, wave, lane);
     }
+    if (INFER) block_amax_commit(y_am, y_amax);
 }
 
 __global__ __launch_bounds__(256) void egc_node_bwd_kernel(const float* __restrict__ GXPRE, int64_t ldg,
@@ -579,11 +612,30 @@ int alignn_egc_gate_fwd(const float* P, float* M, const int32_t* seg_ptr, const 
                         float* e_partial, float* n_partial, alignn_stream_t stream) {
     if (!h_ok(H) || n_seg < 0 || n_seg > INT32_MAX || m_rows < 0) return (int)hipErrorInvalidValue;
     if (big_stream(m_rows, H))  // M cannot stay in the last-level cache: read-once / write-once hints
-        hipLaunchKernelGGL(egc_gate_fwd_kernel<true>, dim3(egc_blocks(n_seg)), dim3(kThreads), 0, (hipStream_t)stream, P,
-                           M, seg_ptr, seg_node, src, (int)n_seg, H, XPRE, S0, HH, e_partial, n_partial);
+        hipLaunchKernelGGL((egc_gate_fwd_kernel<true, false>), dim3(egc_blocks(n_seg)), dim3(kThreads), 0,
+                           (hipStream_t)stream, P, M, seg_ptr, seg_node, src, (int)n_seg, H, XPRE, S0, HH, e_partial,
+                           n_partial, nullptr, nullptr, nullptr, nullptr);
     else
-        hipLaunchKernelGGL(egc_gate_fwd_kernel<false>, dim3(egc_blocks(n_seg)), dim3(kThreads), 0, (hipStream_t)stream, P,
-                           M, seg_ptr, seg_node, src, (int)n_seg, H, XPRE, S0, HH, e_partial, n_partial);
+        hipLaunchKernelGGL((egc_gate_fwd_kernel<false, false>), dim3(egc_blocks(n_seg)), dim3(kThreads), 0,
+                           (hipStream_t)stream, P, M, seg_ptr, seg_node, src, (int)n_seg, H, XPRE, S0, HH, e_partial,
+                           n_partial, nullptr, nullptr, nullptr, nullptr);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_egc_gate_infer(const float* P, const float* C, const int32_t* seg_ptr, const int32_t* seg_node,
+                          const int32_t* src, int64_t n_seg, int64_t m_rows, int H, float* XPRE, const float* e_stat,
+                          const float* Y, float* YOUT, float* y_amax, alignn_stream_t stream) {
+    if (!h_ok(H) || n_seg < 0 || n_seg > INT32_MAX || m_rows < 0 || (YOUT && !e_stat)) return (int)hipErrorInvalidValue;
+    float* Cm = const_cast<float*>(C);  // the INFER instantiation only reads it
+    if (big_stream(m_rows, H))
+        hipLaunchKernelGGL((egc_gate_fwd_kernel<true, true>), dim3(egc_blocks(n_seg)), dim3(kThreads), 0,
+                           (hipStream_t)stream, P, Cm, seg_ptr, seg_node, src, (int)n_seg, H, XPRE, nullptr, nullptr,
+                           nullptr, nullptr, e_stat, Y, YOUT, y_amax);
+    else
+        hipLaunchKernelGGL((egc_gate_fwd_kernel<false, true>), dim3(egc_blocks(n_seg)), dim3(kThreads), 0,
+                           (hipStream_t)stream, P, Cm, seg_ptr, seg_node, src, (int)n_seg, H, XPRE, nullptr, nullptr,
+                           nullptr, nullptr, e_stat, Y, YOUT, y_amax);
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }

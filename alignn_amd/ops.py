@@ -19,6 +19,7 @@ from .graph import CSRGraph
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 FUSED_LG_BACKWARD = True  # tests flip this to compare against the generic two-pass backward
+INFER_FUSED = True  # eval-mode convs without autograd take the BatchNorm-folded gate pass (tests flip it to compare)
 DENSE_LG_BACKWARD = True  # ... and this one to compare the dense-block kernel against the by-source fused kernel
 
 
@@ -693,6 +694,35 @@ class EdgeGatedConvFn(torch.autograd.Function):
         de_beta = e_red[0] if e_red is not None else None
         return (None, g_x, g_y, g_wcat, g_bcat, g_weg, g_beg, dn_gamma, dn_beta, None, None, de_gamma, de_beta, None,
                 None, None, None, None, None)
+
+
+def edge_gated_conv_infer(graph: CSRGraph, x, y, wcat, bcat, w_eg, b_eg, n_gamma, n_beta, n_rm, n_rv, e_gamma, e_beta,
+                          e_rm, e_rv, residual: bool, need_y: bool = True):
+    """EdgeGatedGraphConv.forward for inference (eval mode, no autograd): BatchNorm is the affine map of its running
+    statistics, so the edge output comes straight out of the gate pass (alignn_egc_gate_infer) - m_pre is never
+    written and nothing is saved.  Same values as the training-capable path in eval mode."""
+    lib = _lib.load()
+    x, y = x.contiguous(), y.contiguous()
+    n, H = x.shape
+    m = y.shape[0]
+    if n != graph.n_nodes or m != graph.n_edges:
+        raise ValueError(f"feature rows ({n},{m}) do not match graph ({graph.n_nodes},{graph.n_edges})")
+    P = project(x, wcat, bcat)
+    C = project(y, w_eg, b_eg)
+    n_stat = _bn_finalize(None, 0, n, n_gamma, n_beta, n_rm, n_rv, False)
+    e_stat = _bn_finalize(None, 0, m, e_gamma, e_beta, e_rm, e_rv, False)
+    xpre = _empty(n, H, like=x)
+    y_out = _empty(m, H, like=x) if need_y else None
+    y_amax = new_amax(x) if (need_y and F16X3) else None
+    check(
+        lib.alignn_egc_gate_infer(ptr(P), ptr(C), ptr(graph.seg_ptr), ptr(graph.seg_node), ptr(graph.src), n, m, H,
+                                  ptr(xpre), ptr(e_stat), ptr(y) if residual else None, ptr(y_out), ptr(y_amax), stream()),
+        "egc_gate_infer",
+    )
+    if y_amax is not None:
+        set_amax(y_out, y_amax)
+    x_out = _bn_silu_fwd(xpre, x if residual else None, n_stat)
+    return x_out, y_out
 
 
 # ---------------------------------------------------------------------------------------------

@@ -192,6 +192,15 @@ int alignn_egc_gate_fwd(const float* P, float* M, const int32_t* seg_ptr, const 
                         float* S0, float* HH, float* e_partial, float* n_partial,
                         alignn_stream_t stream);
 
+/* Inference form of the same pass (no backward, edge normalisation = the fixed affine map of BatchNorm in eval
+ * mode, e_stat = [mean, rstd, scale, shift] from the running statistics): C is only read, m_pre is never written,
+ * and the edge output YOUT = (Y ? Y : 0) + silu((m_pre - mean) * scale + shift) comes straight out of the gate pass
+ * (YOUT == NULL: the edge output is dead; y_amax, optional: raised to max|YOUT|).  XPRE as above. */
+int alignn_egc_gate_infer(const float* P, const float* C, const int32_t* seg_ptr, const int32_t* seg_node,
+                          const int32_t* src, int64_t n_seg, int64_t m_rows, int H, float* XPRE,
+                          const float* e_stat, const float* Y, float* YOUT, float* y_amax,
+                          alignn_stream_t stream);
+
 /* Node-side backward glue: from g_xpre (BatchNorm-backward output on nodes) produce
  * GS1 = g_xpre/(S0+eps), GS0 = -g_xpre*HH/(S0+eps).  GXPRE has leading dimension ldg (it usually
  * lives in the Ux block of the [n,4H] projection gradient). */

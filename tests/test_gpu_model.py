@@ -451,6 +451,42 @@ def test_ragged_batch_with_one_atom_cells():
             assert rel_err(q.grad, p[k].grad, floor=gfloor) < 1e-3, k
 
 
+def test_inference_path_folds_batchnorm_into_gate_pass():
+    """eval() under no_grad: alignn_egc_gate_infer writes the edge output straight from the gate pass (BatchNorm =
+    affine map of the running statistics).  Same predictions as the training-capable kernels in eval mode, as the
+    golden eval vector, and it leaves the running statistics alone."""
+    from alignn_amd import ops
+
+    z = load_golden("alignn_tiny_eval.npz")
+    raw = raw_from_golden(z)
+    model = ALIGNN(ALIGNNConfig(name="alignn", alignn_layers=2, gcn_layers=2, hidden_features=32, embedding_features=16))
+    model.load_state_dict(state_dict_from_golden(z))
+    model = model.to(DEV).eval()
+    batch = GraphBatch.from_raw(raw, device=DEV)
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        fast = model(batch)
+        try:
+            ops.INFER_FUSED = False
+            slow = model(batch)
+        finally:
+            ops.INFER_FUSED = True
+    assert rel_err(fast, z["pred"]) < 1e-4 and rel_err(fast, slow) < 1e-5
+    assert all(torch.equal(v, before[k]) for k, v in model.state_dict().items())
+    # at the benchmark width (exercises the f16x3 projections fed by the amax the inference kernel tracks)
+    torch.manual_seed(9)
+    big = ALIGNN(ALIGNNConfig(name="alignn")).to(DEV).eval()
+    b2 = GraphBatch.from_raw(make_batch(8, 30, seed0=77), device=DEV)
+    with torch.no_grad():
+        fast = big(b2)
+        try:
+            ops.INFER_FUSED = False
+            slow = big(b2)
+        finally:
+            ops.INFER_FUSED = True
+    assert rel_err(fast, slow) < 1e-5
+
+
 def test_fused_line_graph_backward_matches_two_pass():
     """The three line-graph backward paths - alignn_egc_bwd_lg_dense (dense source-sorted blocks, one pass),
     alignn_egc_bwd_lg_fused (by source, GM re-read) and egc_bwd_dst + egc_bwd_src - are the same math with
