@@ -74,6 +74,18 @@ class RBFExpansion(nn.Module):
         return ops.rbf_expand(distance, self.centers, self.gamma)
 
 
+class _TorchMLPLayer(nn.Module):
+    """The reference's MLPLayer verbatim in structure (alignn.py:170-184) for the tiny per-crystal descriptor head of
+    ``extra_features != 0`` - torch modules, same parameter names (``layer.0.*`` Linear, ``layer.1.*`` BatchNorm1d)."""
+
+    def __init__(self, in_features: int, out_features: int):
+        super().__init__()
+        self.layer = nn.Sequential(nn.Linear(in_features, out_features), nn.BatchNorm1d(out_features), nn.SiLU())
+
+    def forward(self, x):
+        return self.layer(x)
+
+
 def _bump(bn: nn.Module, training: bool):
     if training and getattr(bn, "num_batches_tracked", None) is not None:
         bn.num_batches_tracked += 1
@@ -224,7 +236,13 @@ class ALIGNN(nn.Module):
         else:
             self.fc = nn.Linear(config.hidden_features, config.output_features)
         if config.extra_features != 0:
-            raise NotImplementedError("extra_features != 0 is outside the MI355X hot-path build (SURVEY.md section 8)")
+            # per-crystal descriptor head (alignn.py:250-267): [N,k] and [B,H+k] matrices - plain torch modules with the
+            # reference's own layout (Sequential(Linear, BatchNorm1d, SiLU) => identical state_dict keys), off the hot path
+            k = config.extra_features
+            self.extra_feature_embedding = _TorchMLPLayer(k, k)
+            self.fc3 = nn.Linear(config.hidden_features + k, config.output_features)
+            self.fc1 = _TorchMLPLayer(k + config.hidden_features, k + config.hidden_features)
+            self.fc2 = _TorchMLPLayer(k + config.hidden_features, k + config.hidden_features)
         self.link = None
         self.link_name = config.link
         if config.link == "identity":
@@ -277,7 +295,18 @@ class ALIGNN(nn.Module):
         for i, layer in enumerate(self.gcn_layers):
             x, y = layer(b.g, x, y, need_edge_out=i + 1 < n_g)
         h = ops.AvgPoolFn.apply(x, b.graph_ptr)
-        out = ops.linear(h, self.fc.weight, self.fc.bias.reshape(-1))
+        if self.config.extra_features != 0:  # alignn.py:328-339
+            if b.extra_features is None:
+                raise ValueError("extra_features != 0 needs g.ndata['extra_features'] (GraphBatch.extra_features)")
+            feats = self.extra_feature_embedding(b.extra_features)
+            if feats.shape[1] % 4 == 0:
+                h_feat = ops.AvgPoolFn.apply(feats, b.graph_ptr)
+            else:  # the pooling kernel works in float4 columns: pad the k descriptor columns
+                pad = torch.nn.functional.pad(feats, (0, -feats.shape[1] % 4))
+                h_feat = ops.AvgPoolFn.apply(pad, b.graph_ptr)[:, :feats.shape[1]]
+            out = self.fc3(self.fc2(self.fc1(torch.cat((h, h_feat), 1))))
+        else:
+            out = ops.linear(h, self.fc.weight, self.fc.bias.reshape(-1))
         if self.link:
             out = self.link(out)
         if self.classification:

@@ -182,6 +182,7 @@ class GraphBatch:
     r: Optional[torch.Tensor] = None  # [E, 3] canonical g-slot order
     h: Optional[torch.Tensor] = None  # [T]    canonical lg-slot order
     volume: Optional[torch.Tensor] = None  # [B] cell volumes (g.ndata["V"] of each crystal's first atom)
+    extra_features: Optional[torch.Tensor] = None  # [N, k] g.ndata["extra_features"] (ALIGNNConfig.extra_features != 0)
     cache: dict = field(default_factory=dict)  # derived index structures (built once per batch, outside graph capture)
 
     @property
@@ -264,11 +265,15 @@ class GraphBatch:
                 kw["h"] = lg.edata["h"]
         if "atom_features" in g.ndata:
             kw["atom_features"] = g.ndata["atom_features"]
+        extra = g.ndata["extra_features"] if "extra_features" in g.ndata else None
         if "r" in g.edata:
             kw["r"] = g.edata["r"]
         if "V" in g.ndata:  # per-atom copy of the cell volume (alignn/graphs.py:553); take each crystal's first atom
             bnn = torch.as_tensor(g.batch_num_nodes()).to(torch.int64)
             first = torch.cumsum(bnn, 0) - bnn
             kw["volume"] = g.ndata["V"][first.to(g.ndata["V"].device)]
-        return GraphBatch.from_coo(u, v, g.num_nodes(), g.batch_num_nodes(), device=dev,
-                                   build_line_graph=build_line_graph and lg is None, **kw)
+        out = GraphBatch.from_coo(u, v, g.num_nodes(), g.batch_num_nodes(), device=dev,
+                                  build_line_graph=build_line_graph and lg is None, **kw)
+        if extra is not None:
+            out.extra_features = torch.as_tensor(extra).to(dev).to(torch.float32).contiguous()
+        return out

@@ -267,11 +267,45 @@ def case_conv64():
     print("conv64 ok", float(xo.abs().mean()))
 
 
+def case_extra_features():
+    """extra_features != 0 (alignn.py:250-267, 328-339: extra_feature_embedding, fc1, fc2, fc3) in train mode, and a
+    classification head (LogSoftmax over num_classes, :244-246, 346-348)."""
+    torch.manual_seed(21)
+    raw = batch_raw([_one(n, 400 + i, "crystal", 92) for i, n in enumerate((6, 9, 7, 5))])
+    extra = torch.randn(raw.num_nodes, 3, generator=torch.Generator().manual_seed(5))
+    out = dict(raw_arrays(raw))
+    for tag, kw in (("x", dict(extra_features=3)), ("c", dict(classification=True, num_classes=3))):
+        cfg = ALIGNNConfig(name="alignn", alignn_layers=1, gcn_layers=1, hidden_features=32, embedding_features=16, **kw)
+        model = ALIGNN(cfg).train()
+        g, lg, lat = to_dgl(raw)
+        if tag == "x":
+            g.ndata["extra_features"] = extra
+        out.update({f"{tag}.sd." + k: v.numpy().copy() for k, v in model.state_dict().items()})
+        pred = model((g, lg, lat))
+        if tag == "x":
+            target = torch.linspace(-1.0, 1.0, raw.batch_size)
+            loss = torch.nn.functional.l1_loss(pred, target)
+        else:
+            target = torch.tensor([0, 2, 1, 1])
+            loss = torch.nn.functional.nll_loss(pred, target)
+        loss.backward()
+        out[f"{tag}.pred"], out[f"{tag}.loss"], out[f"{tag}.target"] = pred.detach().numpy(), loss.item(), target.numpy()
+        out.update({f"{tag}.grad." + k: p.grad.numpy().copy() for k, p in model.named_parameters() if p.grad is not None})
+        out[f"{tag}.nograd"] = np.array([k for k, p in model.named_parameters() if p.grad is None])
+        print("extra/class case", tag, "pred", pred.detach().numpy().reshape(-1)[:4], "loss", loss.item())
+    out["extra_features"] = extra.numpy()
+    np.savez_compressed(os.path.join(OUT, "alignn_extra_class.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "extra":  # (regenerate only the newest fixture)
+        case_extra_features()
+        sys.exit(0)
     case_tiny(True)
     case_tiny(False)
     case_default()
     case_conv64()
     case_atomwise()
     case_atomwise_ff()
+    case_extra_features()

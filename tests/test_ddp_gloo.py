@@ -48,8 +48,10 @@ def _worker(rank, world, port, q):
         sync.zero_grad()
         torch.nn.functional.mse_loss(net(X[shard]), Y[shard]).backward()
         sync.sync()
-    out = {k: (None if p.grad is None else p.grad.clone()) for k, p in net.named_parameters()}
-    out["w0"] = net.a.weight.detach().clone()
+    # by VALUE (numpy): a torch tensor in a Queue travels as a shared-memory handle that the parent can only open
+    # while this process is still alive - a race once the worker exits right after the barrier
+    out = {k: (None if p.grad is None else p.grad.numpy().copy()) for k, p in net.named_parameters()}
+    out["w0"] = net.a.weight.detach().numpy().copy()
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
@@ -64,6 +66,7 @@ def test_flat_allreduce_matches_full_batch_gradient():
     for p in procs:
         p.start()
     res = dict(q.get(timeout=120) for _ in range(world))
+    res = {r: {k: (None if v is None else torch.from_numpy(v)) for k, v in d.items()} for r, d in res.items()}
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

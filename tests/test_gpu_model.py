@@ -451,6 +451,50 @@ def test_ragged_batch_with_one_atom_cells():
             assert rel_err(q.grad, p[k].grad, floor=gfloor) < 1e-3, k
 
 
+def test_golden_extra_features_and_classification_heads():
+    """ALIGNNConfig.extra_features != 0 (descriptor head: extra_feature_embedding, fc1, fc2, fc3) and
+    classification=True (LogSoftmax over num_classes) against the reference's own class: predictions, loss and every
+    parameter gradient; state_dict keys load unchanged."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "shims"))
+    import dgl  # shim: DGL-shaped container only
+
+    z = load_golden("alignn_extra_class.npz")
+    raw = raw_from_golden(z)
+    for tag, kw in (("x", dict(extra_features=3)), ("c", dict(classification=True, num_classes=3))):
+        cfg = ALIGNNConfig(name="alignn", alignn_layers=1, gcn_layers=1, hidden_features=32, embedding_features=16, **kw)
+        model = ALIGNN(cfg)
+        sd = {k[len(tag) + 4:]: torch.from_numpy(np.asarray(v)) for k, v in z.items() if k.startswith(tag + ".sd.")}
+        model.load_state_dict(sd)  # strict: same keys as the reference
+        model = model.to(DEV).train()
+        g = dgl.graph((torch.from_numpy(raw.u), torch.from_numpy(raw.v)), num_nodes=raw.num_nodes)
+        g._bnn, g._bne = torch.from_numpy(raw.batch_num_nodes), torch.from_numpy(raw.batch_num_edges)
+        g.ndata["atom_features"] = torch.from_numpy(raw.atom_features)
+        g.edata["r"] = torch.from_numpy(raw.r)
+        if tag == "x":
+            g.ndata["extra_features"] = torch.from_numpy(z["extra_features"])
+        lg = dgl.graph((torch.from_numpy(raw.lg_u), torch.from_numpy(raw.lg_v)), num_nodes=raw.num_edges)
+        lg.edata["h"] = torch.from_numpy(raw.h)
+        pred = model((g, lg, torch.from_numpy(raw.lattice)))
+        assert pred.shape == z[tag + ".pred"].shape and rel_err(pred, z[tag + ".pred"]) < 1e-4
+        if tag == "x":
+            loss = torch.nn.functional.l1_loss(pred, torch.from_numpy(z["x.target"]).to(DEV))
+        else:
+            loss = torch.nn.functional.nll_loss(pred, torch.from_numpy(z["c.target"]).to(DEV))
+        assert abs(loss.item() - float(z[tag + ".loss"])) < 1e-4
+        loss.backward()
+        nograd = set(z[tag + ".nograd"].tolist())
+        gfloor = 1e-2 * max(float(np.abs(v).max()) for k, v in z.items() if k.startswith(tag + ".grad."))
+        n = 0
+        for k, p in model.named_parameters():
+            if k in nograd:
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            else:
+                assert rel_err(p.grad, z[tag + ".grad." + k], floor=gfloor) < 1e-3, (tag, k)
+                n += 1
+        assert n > 20
+
+
 def test_inference_path_folds_batchnorm_into_gate_pass():
     """eval() under no_grad: alignn_egc_gate_infer writes the edge output straight from the gate pass (BatchNorm =
     affine map of the running statistics).  Same predictions as the training-capable kernels in eval mode, as the
