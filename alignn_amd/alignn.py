@@ -86,9 +86,28 @@ class _TorchMLPLayer(nn.Module):
         return self.layer(x)
 
 
+_DEFERRED_BUMPS = None  # inside a whole-model forward: the counters to bump, flushed as ONE _foreach kernel
+
+
 def _bump(bn: nn.Module, training: bool):
+    """BatchNorm1d's ``num_batches_tracked += 1`` (29 one-element kernels per training step when done one by one)."""
     if training and getattr(bn, "num_batches_tracked", None) is not None:
-        bn.num_batches_tracked += 1
+        if _DEFERRED_BUMPS is not None:
+            _DEFERRED_BUMPS.append(bn.num_batches_tracked)
+        else:
+            bn.num_batches_tracked += 1
+
+
+class _deferred_bumps:
+    def __enter__(self):
+        global _DEFERRED_BUMPS
+        self.prev, _DEFERRED_BUMPS = _DEFERRED_BUMPS, []
+
+    def __exit__(self, *exc):
+        global _DEFERRED_BUMPS
+        todo, _DEFERRED_BUMPS = _DEFERRED_BUMPS, self.prev
+        if todo:
+            torch._foreach_add_(todo, 1)
 
 
 class MLPLayer(nn.Module):
@@ -278,7 +297,10 @@ class ALIGNN(nn.Module):
     def forward(self, g: Union[Sequence, GraphBatch]):
         """``g`` = ``(g, lg, lat)`` of DGL-like graphs as in the reference (alignn.py:291-295), a bare
         graph when ``alignn_layers == 0``, or a prebuilt ``GraphBatch``.  Returns ``squeeze(out)``."""
-        b = self._batch(g)
+        with _deferred_bumps():
+            return self._forward(self._batch(g))
+
+    def _forward(self, b: GraphBatch):
         if b.atom_features is None or b.r is None:
             raise ValueError("graph lacks ndata['atom_features'] / edata['r']")
         if len(self.alignn_layers) > 0:

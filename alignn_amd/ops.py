@@ -175,12 +175,23 @@ def split_bf16x3(w, transpose=False):
     return SplitWeight(buf, n, k)
 
 
+_W_AMAX = {}
+
+
 def split_f16x2(w, transpose=False):
     """Slice ``w * 2^s`` into two fp16 planes (``s`` from max|w|, kept with the image)."""
     lib = _lib.load()
     require_f32(w)
     n, k = (w.shape[1], w.shape[0]) if transpose else (w.shape[0], w.shape[1])
-    amax = absmax(w if w.stride(0) % 4 == 0 and w.shape[1] % 4 == 0 else w.contiguous().view(1, -1))
+    # max|w| is shared by the forward (W) and the input-gradient (W^T) images of one step: cache it per weight VERSION
+    # (the optimizer's in-place update bumps the version)
+    hit = _W_AMAX.get(id(w))
+    if hit is not None and hit[0]() is w and hit[1] == w._version:
+        amax = hit[2]
+    else:
+        amax = absmax(w if w.stride(0) % 4 == 0 and w.shape[1] % 4 == 0 else w.contiguous().view(1, -1))
+        k_ = id(w)
+        _W_AMAX[k_] = (weakref.ref(w, lambda _r, k_=k_: _W_AMAX.pop(k_, None)), w._version, amax)
     buf = torch.empty(lib.alignn_split_f16x2_bytes(n, k), dtype=torch.uint8, device=w.device)
     check(lib.alignn_split_f16x2(ptr(w), w.stride(0), n, k, int(transpose), ptr(amax), ptr(buf), stream()), "split_f16x2")
     sw = SplitWeight(buf, n, k)
