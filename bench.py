@@ -340,6 +340,7 @@ def main():
                 "mfma_frac_of_157TF": round(step_flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4),
             },
             "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3),
+            "peak_hbm_GB": round(torch.cuda.max_memory_allocated(dev) / 1e9, 2),
             "streamed_batches": streamed,
             "loss": round(float(loss.item()), 6),
         }
