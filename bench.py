@@ -202,7 +202,37 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    log("warmup done; timing")
+
+    # ---- forward + loss + backward of the timed steps as ONE hipGraph (the library never allocates or synchronises and
+    # launches only on the current stream; the side-stream weight gradients are joined inside the capture).  Same ~520
+    # kernels per step, replayed by the GPU front end instead of enqueued from Python: on a box with a slow or busy
+    # host (seen here: 10-20 ms of enqueue per step against 19 ms of GPU work; 8 ranks share one host at N=8) the step
+    # no longer waits for the interpreter.  The flat gradient all-reduce and the fused AdamW step stay eager.
+    # Replays are bit-identical to eager steps (tests/test_gpu_model.py, tools/graph_step_check.py).
+    use_graph = os.environ.get("ALIGNN_BENCH_EAGER", "0") != "1" and args.model != "alignn_ff"
+    if use_graph:
+        params = [p_ for p_ in model.parameters()]
+        for p_ in params:
+            p_.grad = None
+        ops.reset_amax_arena()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            g_loss = torch.nn.functional.l1_loss(predict(batch), target)
+            g_loss.backward()
+        ops.reset_amax_arena()
+        g_grads = [p_.grad for p_ in params]  # static buffers the replays write into (None: parameter unused)
+
+        def step():  # noqa: F811
+            graph.replay()
+            for p_, g_ in zip(params, g_grads):
+                p_.grad = g_
+            sync.sync()
+            opt.step()
+            return g_loss
+
+        step()
+        torch.cuda.synchronize()
+    log(f"warmup done ({'hipGraph replay' if use_graph else 'eager'} steps); timing")
 
     def fence():
         torch.cuda.synchronize()
@@ -340,6 +370,7 @@ def main():
                 "mfma_frac_of_157TF": round(step_flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4),
             },
             "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3),
+            "step_launch": "hipGraph replay of forward+loss+backward, eager all-reduce + fused AdamW" if use_graph else "eager",
             "peak_hbm_GB": round(torch.cuda.max_memory_allocated(dev) / 1e9, 2),
             "streamed_batches": streamed,
             "loss": round(float(loss.item()), 6),
