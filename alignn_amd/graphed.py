@@ -37,7 +37,7 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         optimizer.zero_grad(set_to_none=True)
         ops.reset_amax_arena()  # the arena's zero-fill must be a node of the graph, not something done before it
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):  # (other threads, e.g. RCCL's watchdog, may poll events)
             self.loss = loss_fn(model(batch), self.target)
             self.loss.backward()
             optimizer.step()

@@ -211,27 +211,37 @@ def main():
     # Replays are bit-identical to eager steps (tests/test_gpu_model.py, tools/graph_step_check.py).
     use_graph = os.environ.get("ALIGNN_BENCH_EAGER", "0") != "1" and args.model != "alignn_ff"
     if use_graph:
-        params = [p_ for p_ in model.parameters()]
-        for p_ in params:
-            p_.grad = None
-        ops.reset_amax_arena()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            g_loss = torch.nn.functional.l1_loss(predict(batch), target)
-            g_loss.backward()
-        ops.reset_amax_arena()
-        g_grads = [p_.grad for p_ in params]  # static buffers the replays write into (None: parameter unused)
+        eager_step = step
+        try:
+            params = [p_ for p_ in model.parameters()]
+            for p_ in params:
+                p_.grad = None
+            ops.reset_amax_arena()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):  # (RCCL's watchdog thread polls events)
+                g_loss = torch.nn.functional.l1_loss(predict(batch), target)
+                g_loss.backward()
+            ops.reset_amax_arena()
+            g_grads = [p_.grad for p_ in params]  # static buffers the replays write into (None: parameter unused)
 
-        def step():  # noqa: F811
-            graph.replay()
-            for p_, g_ in zip(params, g_grads):
-                p_.grad = g_
-            sync.sync()
-            opt.step()
-            return g_loss
+            def step():  # noqa: F811
+                graph.replay()
+                for p_, g_ in zip(params, g_grads):
+                    p_.grad = g_
+                sync.sync()
+                opt.step()
+                return g_loss
 
-        step()
-        torch.cuda.synchronize()
+            step()
+            torch.cuda.synchronize()
+        except Exception as e:  # never lose the measurement to a capture problem: say so and time eager launches
+            log(f"hipGraph capture failed ({type(e).__name__}: {e}); timing eager launches instead")
+            use_graph = False
+            step = eager_step
+            ops.reset_amax_arena()
+            torch.cuda.synchronize()
+            step()
+            torch.cuda.synchronize()
     log(f"warmup done ({'hipGraph replay' if use_graph else 'eager'} steps); timing")
 
     def fence():
