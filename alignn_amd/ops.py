@@ -149,6 +149,13 @@ def new_amax(like):
     return a["buf"][i:i + 1]
 
 
+AMAX_MIN_ROWS = 4096  # below this no projection of the tensor can reach X6_MIN_TILES 64-row tiles (N <= 1024): skip tracking
+
+
+def _track(rows):
+    return F16X3 and rows >= AMAX_MIN_ROWS
+
+
 def absmax(x):
     """max|x| of a 2-D fp32 tensor as a device scalar (stand-alone pass; the fused producers avoid it)."""
     lib = _lib.load()
@@ -327,7 +334,7 @@ def _bn_silu_fwd(x, res, stat):
     lib = _lib.load()
     rows, F = x.shape
     y = _empty(rows, F, like=x)
-    amax = new_amax(x) if F16X3 else None  # max|y|, tracked by the kernel for the next projection of y
+    amax = new_amax(x) if _track(rows) else None  # max|y|, tracked by the kernel for the next projection of y
     check(
         lib.alignn_bn_silu_fwd(ptr(x), x.stride(0), ptr(res), res.stride(0) if res is not None else 0, ptr(stat),
                                ptr(y), y.stride(0), rows, F, ptr(amax), stream()),
@@ -373,7 +380,7 @@ def _ln_silu_fwd(x, res, gamma, beta, want_stats=True):
     rows, F = x.shape
     y = _empty(rows, F, like=x)
     stats = _empty(rows, 2, like=x) if want_stats else None
-    amax = new_amax(x) if F16X3 else None
+    amax = new_amax(x) if _track(rows) else None
     check(
         lib.alignn_ln_silu_fwd(ptr(x), x.stride(0), ptr(res), res.stride(0) if res is not None else 0, ptr(gamma),
                                ptr(beta), LN_EPS, ptr(y), y.stride(0), ptr(stats), rows, F, ptr(amax), stream()),
@@ -527,7 +534,7 @@ class MLPLayerFn(torch.autograd.Function):
         x, w, pre, stat, gamma, beta = ctx.saved_tensors
         gy = gy.contiguous()
         gpre = torch.empty_like(pre)
-        g_amax = new_amax(pre) if F16X3 else None
+        g_amax = new_amax(pre) if _track(pre.shape[0]) else None
         if ctx.norm == "layer":
             red = _ln_silu_bwd(gy, pre, gamma, beta, stat, gpre, g_amax)
         else:
@@ -619,8 +626,8 @@ class EdgeGatedConvFn(torch.autograd.Function):
         GP = _empty(n, 4 * H, like=x)
         # max|GP| (all four blocks: every kernel that writes a block raises the same scalar) and max|GM|, so that
         # the input- and weight-gradient projections below can run the three-product scheme
-        gp_amax = new_amax(x) if F16X3 else None
-        gm_amax = new_amax(x) if F16X3 else None
+        gp_amax = new_amax(x) if _track(n) else None
+        gm_amax = new_amax(x) if _track(m) else None
         # node branch: SiLU/norm backward -> g_xpre (stored as the Ux block of GP)
         g_xpre = GP[:, 3 * H:]
         if layer:
@@ -724,7 +731,7 @@ def edge_gated_conv_infer(graph: CSRGraph, x, y, wcat, bcat, w_eg, b_eg, n_gamma
     e_stat = _bn_finalize(None, 0, m, e_gamma, e_beta, e_rm, e_rv, False)
     xpre = _empty(n, H, like=x)
     y_out = _empty(m, H, like=x) if need_y else None
-    y_amax = new_amax(x) if (need_y and F16X3) else None
+    y_amax = new_amax(x) if (need_y and _track(m)) else None
     check(
         lib.alignn_egc_gate_infer(ptr(P), ptr(C), ptr(graph.seg_ptr), ptr(graph.seg_node), ptr(graph.src), n, m, H,
                                   ptr(xpre), ptr(e_stat), ptr(y) if residual else None, ptr(y_out), ptr(y_amax), stream()),
