@@ -107,6 +107,17 @@ def cutoff_function_based_edges(r, inner_cutoff=4, exponent=3):
     return torch.where(r <= inner_cutoff, env, torch.zeros_like(r))
 
 
+class _TorchLNMLPLayer(nn.Module):
+    """models/utils.py:277-292 verbatim in structure, for the tiny descriptor head of ``extra_features != 0``."""
+
+    def __init__(self, in_features: int, out_features: int):
+        super().__init__()
+        self.layer = nn.Sequential(nn.Linear(in_features, out_features), nn.LayerNorm(out_features), nn.SiLU())
+
+    def forward(self, x):
+        return self.layer(x)
+
+
 class ALIGNNAtomWise(nn.Module):
     """Atomistic line graph network, LayerNorm flavour (alignn_atomwise.py:249-660)."""
 
@@ -134,7 +145,13 @@ class ALIGNNAtomWise(nn.Module):
             [EdgeGatedGraphConv(config.hidden_features, config.hidden_features) for _ in range(config.gcn_layers)]
         )
         if config.extra_features != 0:
-            raise NotImplementedError("extra_features != 0 is outside the MI355X hot-path build (SURVEY.md section 8)")
+            # per-crystal descriptor head (alignn_atomwise.py:314-333): tiny [N,k] / [B,H+k] matrices - torch modules
+            # with the reference's layout (Sequential(Linear, LayerNorm, SiLU) => identical state_dict keys)
+            k = config.extra_features
+            self.extra_feature_embedding = _TorchLNMLPLayer(k, k)
+            self.fc3 = nn.Linear(config.hidden_features + k, config.output_features)
+            self.fc1 = _TorchLNMLPLayer(k + config.hidden_features, k + config.hidden_features)
+            self.fc2 = _TorchLNMLPLayer(k + config.hidden_features, k + config.hidden_features)
         if config.atomwise_output_features > 0:
             self.fc_atomwise = nn.Linear(config.hidden_features, config.atomwise_output_features)
         if config.additional_output_features:
@@ -184,6 +201,8 @@ class ALIGNNAtomWise(nn.Module):
         from . import ff
 
         cfg = self.config
+        if cfg.extra_features != 0:
+            raise NotImplementedError("extra_features != 0 together with training through the forces is outside this build")
         n_a = len(self.alignn_layers)
         x = ff.mlp_layer(b.atom_features, self.atom_embedding)
         r = b.r.detach().clone().requires_grad_(True)  # canonical bond order; :420
@@ -290,7 +309,16 @@ class ALIGNNAtomWise(nn.Module):
         additional_out = torch.empty(1)
         if cfg.output_features is not None:
             hpool = ops.AvgPoolFn.apply(x, b.graph_ptr)
-            out = torch.squeeze(ops.linear(hpool, self.fc.weight, self.fc.bias.reshape(-1)))
+            if cfg.extra_features != 0:  # alignn_atomwise.py:468-473 (note: fc3's output is NOT squeezed upstream)
+                if b.extra_features is None:
+                    raise ValueError("extra_features != 0 needs g.ndata['extra_features'] (GraphBatch.extra_features)")
+                feats = self.extra_feature_embedding(b.extra_features)
+                pad = torch.nn.functional.pad(feats, (0, -feats.shape[1] % 4))  # the pooling kernel works in float4 columns
+                h_feat = ops.AvgPoolFn.apply(pad.contiguous(), b.graph_ptr)[:, :feats.shape[1]]
+                hpool = self.fc2(self.fc1(torch.cat((hpool, h_feat), 1)))
+                out = self.fc3(hpool)
+            else:
+                out = torch.squeeze(ops.linear(hpool, self.fc.weight, self.fc.bias.reshape(-1)))
             if cfg.additional_output_features > 0:
                 additional_out = ops.linear(hpool, self.fc_additional_output.weight, self.fc_additional_output.bias)
         atomwise_pred = torch.empty(1)

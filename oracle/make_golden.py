@@ -297,10 +297,37 @@ def case_extra_features():
     np.savez_compressed(os.path.join(OUT, "alignn_extra_class.npz"), **out)
 
 
+def case_atomwise_extra():
+    """ALIGNNAtomWise with extra_features != 0 (alignn_atomwise.py:314-333, 391-393, 468-475), energy path."""
+    from alignn.models.alignn_atomwise import ALIGNNAtomWise, ALIGNNAtomWiseConfig
+
+    torch.manual_seed(31)
+    cfg = ALIGNNAtomWiseConfig(name="alignn_atomwise", alignn_layers=1, gcn_layers=1, hidden_features=32,
+                               embedding_features=16, atom_input_features=92, calculate_gradient=False, extra_features=3)
+    model = ALIGNNAtomWise(cfg).train()
+    raw = batch_raw([_one(n, 500 + i, "crystal", 92) for i, n in enumerate((6, 9, 7))])
+    g, lg, lat = to_dgl(raw)
+    extra = torch.randn(raw.num_nodes, 3, generator=torch.Generator().manual_seed(6))
+    g.ndata["extra_features"] = extra
+    out = dict(raw_arrays(raw))
+    out["extra_features"] = extra.numpy()
+    out.update({"sd." + k: v.numpy().copy() for k, v in model.state_dict().items()})
+    res = model((g, lg, lat))
+    target = torch.linspace(-1.0, 1.0, raw.batch_size).reshape(-1, 1)
+    loss = torch.nn.functional.l1_loss(res["out"], target)
+    loss.backward()
+    out["pred"], out["loss"], out["target"] = res["out"].detach().numpy(), loss.item(), target.numpy()
+    out.update({"grad." + k: p.grad.numpy().copy() for k, p in model.named_parameters() if p.grad is not None})
+    out["nograd"] = np.array([k for k, p in model.named_parameters() if p.grad is None])
+    np.savez_compressed(os.path.join(OUT, "atomwise_extra.npz"), **out)
+    print("atomwise extra pred", out["pred"].reshape(-1), "loss", out["loss"])
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    if len(sys.argv) > 1 and sys.argv[1] == "extra":  # (regenerate only the newest fixture)
+    if len(sys.argv) > 1 and sys.argv[1] == "extra":  # (regenerate only the newest fixtures)
         case_extra_features()
+        case_atomwise_extra()
         sys.exit(0)
     case_tiny(True)
     case_tiny(False)
@@ -309,3 +336,4 @@ if __name__ == "__main__":
     case_atomwise()
     case_atomwise_ff()
     case_extra_features()
+    case_atomwise_extra()

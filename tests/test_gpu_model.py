@@ -495,6 +495,46 @@ def test_golden_extra_features_and_classification_heads():
         assert n > 20
 
 
+def test_golden_atomwise_extra_features_head():
+    """ALIGNNAtomWiseConfig.extra_features != 0 against the reference's class: [B,1] output (fc3 is not squeezed
+    upstream), loss and all parameter gradients."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "shims"))
+    import dgl  # shim: DGL-shaped container only
+
+    from alignn_amd import ALIGNNAtomWise, ALIGNNAtomWiseConfig
+
+    z = load_golden("atomwise_extra.npz")
+    raw = raw_from_golden(z)
+    cfg = ALIGNNAtomWiseConfig(name="alignn_atomwise", alignn_layers=1, gcn_layers=1, hidden_features=32,
+                               embedding_features=16, atom_input_features=92, calculate_gradient=False, extra_features=3)
+    model = ALIGNNAtomWise(cfg)
+    model.load_state_dict(state_dict_from_golden(z))
+    model = model.to(DEV).train()
+    g = dgl.graph((torch.from_numpy(raw.u), torch.from_numpy(raw.v)), num_nodes=raw.num_nodes)
+    g._bnn, g._bne = torch.from_numpy(raw.batch_num_nodes), torch.from_numpy(raw.batch_num_edges)
+    g.ndata["atom_features"] = torch.from_numpy(raw.atom_features)
+    g.ndata["extra_features"] = torch.from_numpy(z["extra_features"])
+    g.edata["r"] = torch.from_numpy(raw.r)
+    lg = dgl.graph((torch.from_numpy(raw.lg_u), torch.from_numpy(raw.lg_v)), num_nodes=raw.num_edges)
+    lg.edata["h"] = torch.from_numpy(raw.h)
+    res = model([g, lg, torch.from_numpy(raw.lattice)])
+    assert res["out"].shape == z["pred"].shape == (3, 1) and rel_err(res["out"], z["pred"]) < 1e-4
+    loss = torch.nn.functional.l1_loss(res["out"], torch.from_numpy(z["target"]).to(DEV))
+    assert abs(loss.item() - float(z["loss"])) < 1e-4
+    loss.backward()
+    nograd = set(z["nograd"].tolist())
+    gfloor = 1e-2 * max(float(np.abs(v).max()) for k, v in z.items() if k.startswith("grad."))
+    n = 0
+    for k, p in model.named_parameters():
+        if k in nograd:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+        else:
+            assert rel_err(p.grad, z["grad." + k], floor=gfloor) < 1e-3, k
+            n += 1
+    assert n > 20
+
+
 def test_inference_path_folds_batchnorm_into_gate_pass():
     """eval() under no_grad: alignn_egc_gate_infer writes the edge output straight from the gate pass (BatchNorm =
     affine map of the running statistics).  Same predictions as the training-capable kernels in eval mode, as the
