@@ -94,7 +94,14 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream():
+    """Raw handle of torch's current HIP stream (what every launch goes to).  ``torch.cuda.current_stream()`` builds a
+    Python Stream object per call (~8 us, ~650 calls per training step); the raw getter is a plain C call."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

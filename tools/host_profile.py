@@ -1,0 +1,21 @@
+"""Where does the HOST time of an eager training step go?  cProfile over 5 steps (GPU work is asynchronous)."""
+import cProfile, os, pstats, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from alignn_amd import ALIGNN, ALIGNNConfig, GraphBatch
+from alignn_amd.synthetic import make_batch
+dev = "cuda"
+batch = GraphBatch.from_raw(make_batch(64, 60), device=dev)
+torch.manual_seed(0)
+model = ALIGNN(ALIGNNConfig(name="alignn")).to(dev).train()
+opt = torch.optim.AdamW(model.parameters(), lr=1e-3, fused=True)
+target = torch.randn(64, device=dev)
+def step():
+    opt.zero_grad(set_to_none=True)
+    torch.nn.functional.l1_loss(model(batch), target).backward()
+    opt.step()
+for _ in range(3): step()
+torch.cuda.synchronize()
+pr = cProfile.Profile(); pr.enable()
+for _ in range(5): step()
+pr.disable(); torch.cuda.synchronize()
+st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(28)
