@@ -201,6 +201,8 @@ def main():
     log(f"rank {rank}: batch N={raw.num_nodes} E={raw.num_edges} T={raw.num_triplets}; warmup")
     for _ in range(args.warmup):
         step()
+    if args.warmup == 0 and os.environ.get("ALIGNN_BENCH_EAGER", "0") != "1" and args.model != "alignn_ff":
+        step()  # capture needs the lazy one-time initialisations (kernel attributes, allocator pools) done eagerly first
     torch.cuda.synchronize()
 
     # ---- forward + loss + backward of the timed steps as ONE hipGraph (the library never allocates or synchronises and
