@@ -156,3 +156,36 @@ def test_packed_batch_roundtrip_and_staging_on_cpu():
         loader.pack(raw.u, raw.v + 10_000, raw.batch_num_nodes, raw.r, raw.lattice, species=species, pin=False)
     got = [x for x in loader.PrefetchLoader([p, p2], "cpu", feature_table=table, cosines=False)]
     assert len(got) == 2 and torch.equal(got[0][0].lg.src, ref.lg.src)
+
+
+def test_device_knn_graph_matches_numpy_builder():
+    """alignn_amd.neighbors.knn_multigraph (torch tensor ops, runs on the device) gives the same bond list, in the
+    same order, as the numpy restatement of the reference's kNN-12 / 8 A builder - incl. 1-atom cells (all bonds are
+    self-images, the search sphere has to be widened) and small cells with many images per pair."""
+    import numpy as np
+    import torch
+
+    from alignn_amd import neighbors
+    from alignn_amd.graph import GraphBatch
+    from alignn_amd.synthetic import _one, batch_raw, knn_multigraph, make_crystal
+
+    for n, seed in ((1, 3), (2, 4), (5, 5), (17, 6), (40, 7)):
+        lat, frac, _ = make_crystal(n, seed)
+        u0, v0, r0 = knn_multigraph(lat, frac)
+        u, v, r = neighbors.knn_multigraph(torch.from_numpy(lat), torch.from_numpy(frac))
+        assert u.dtype == torch.int64 and r.dtype == torch.float32
+        assert np.array_equal(u.numpy(), u0) and np.array_equal(v.numpy(), v0), (n, seed)
+        assert np.allclose(r.numpy(), r0, atol=1e-6)
+    # positions -> canonical batch: the same GraphBatch as the generator + explicit line graph route
+    specs = [(6, 21), (9, 22), (1, 23)]
+    crystals = [make_crystal(n, s) for n, s in specs]
+    raw = batch_raw([_one(n, s, "crystal", 92) for n, s in specs])
+    b = neighbors.crystal_batch([torch.from_numpy(c[0]) for c in crystals], [torch.from_numpy(c[1]) for c in crystals],
+                                atom_features=[torch.from_numpy(raw.atom_features[:6]), torch.from_numpy(raw.atom_features[6:15]),
+                                               torch.from_numpy(raw.atom_features[15:])])
+    ref = GraphBatch.from_raw(raw)
+    for name in ("seg_ptr", "src", "dst", "out_ptr", "out_slot"):
+        assert torch.equal(getattr(b.g, name), getattr(ref.g, name)), name
+        assert torch.equal(getattr(b.lg, name), getattr(ref.lg, name)), name
+    assert torch.allclose(b.r, ref.r, atol=1e-6) and torch.allclose(b.volume, ref.volume, rtol=1e-5)
+    assert torch.equal(b.graph_ptr, ref.graph_ptr) and torch.equal(b.atom_features, ref.atom_features)
