@@ -323,8 +323,64 @@ def case_atomwise_extra():
     print("atomwise extra pred", out["pred"].reshape(-1), "loss", out["loss"])
 
 
+def case_ealignn():
+    """eALIGNNAtomWise (alignn/models/ealignn_atomwise.py): bonds longer than inner_cutoff dropped before the line
+    graph is built (lightweight_line_graph, models/utils.py:129-222), r recomputed from cart_coords + images, forces with
+    net torque removed (remove_net_torque, :316-400).  Train mode, energy + force + stress outputs and loss gradients."""
+    from alignn.models.ealignn_atomwise import eALIGNNAtomWise, eALIGNNAtomWiseConfig
+    from alignn_amd.synthetic import make_crystal, knn_multigraph
+
+    torch.manual_seed(41)
+    cfg = eALIGNNAtomWiseConfig(name="ealignn_atomwise", alignn_layers=2, gcn_layers=2, hidden_features=32,
+                                embedding_features=16, atom_input_features=92, calculate_gradient=True,
+                                stresswise_weight=0.05, inner_cutoff=4.0)
+    model = eALIGNNAtomWise(cfg).train()
+    graphs, lats, out = [], [], {}
+    us, vs, rs, ims, fr, bnn, bne, vols, feats, off = [], [], [], [], [], [], [], [], [], 0
+    for i, n in enumerate((7, 10)):
+        lat, frac, Z = make_crystal(n, 700 + i)
+        u, v, r = knn_multigraph(lat, frac)
+        cart = frac @ lat
+        img = r - (cart[v] - cart[u])  # Cartesian image shift of every bond (what compute_pair_vector_and_distance adds)
+        af = np.random.default_rng(900 + i).standard_normal((n, 92)).astype(np.float32)
+        g = dgl.graph((torch.from_numpy(u), torch.from_numpy(v)), num_nodes=n)
+        g.ndata["atom_features"] = torch.from_numpy(af)
+        g.ndata["frac_coords"] = torch.from_numpy(frac.astype(np.float32))
+        vol = float(abs(np.linalg.det(lat)))
+        g.ndata["V"] = torch.full((n,), vol)
+        g.edata["r"] = torch.from_numpy(r.astype(np.float32))
+        g.edata["images"] = torch.from_numpy(img.astype(np.float32))
+        graphs.append(g)
+        lats.append(torch.from_numpy(lat.astype(np.float32)))
+        us.append(u + off); vs.append(v + off); rs.append(r); ims.append(img); fr.append(frac); feats.append(af)
+        bnn.append(n); bne.append(u.shape[0]); vols.append(vol); off += n
+    g = dgl.batch(graphs)
+    lat = torch.stack(lats)
+    out.update({"in.u": np.concatenate(us), "in.v": np.concatenate(vs), "in.r": np.concatenate(rs).astype(np.float32),
+                "in.images": np.concatenate(ims).astype(np.float32), "in.frac_coords": np.concatenate(fr).astype(np.float32),
+                "in.atom_features": np.concatenate(feats), "in.batch_num_nodes": np.array(bnn), "in.batch_num_edges": np.array(bne),
+                "in.lattice": lat.numpy(), "in.volume": np.array(vols, dtype=np.float32)})
+    out.update({"sd." + k: v.numpy().copy() for k, v in model.state_dict().items()})
+    res = model((g, lat))
+    gen = torch.Generator().manual_seed(9)
+    te, tf, ts = torch.randn(2, generator=gen), torch.randn(off, 3, generator=gen), torch.randn(2, 3, 3, generator=gen)
+    L = torch.nn.functional.l1_loss
+    loss = L(res["out"], te) + L(res["grad"], tf) + 0.05 * L(res["stresses"], ts)
+    loss.backward()
+    out.update({"pred": res["out"].detach().numpy(), "forces": res["grad"].detach().numpy(), "stresses": res["stresses"].detach().numpy(),
+                "loss": loss.item(), "t_energy": te.numpy(), "t_forces": tf.numpy(), "t_stress": ts.numpy()})
+    out.update({"grad." + k: p.grad.numpy().copy() for k, p in model.named_parameters() if p.grad is not None})
+    out["nograd"] = np.array([k for k, p in model.named_parameters() if p.grad is None])
+    np.savez_compressed(os.path.join(OUT, "ealignn_tiny.npz"), **out)
+    kept = int((np.linalg.norm(np.concatenate(rs), axis=1) <= 4.0).sum())
+    print("ealignn pred", out["pred"], "loss", out["loss"], "bonds kept", kept, "of", sum(bne))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "ealignn":
+        case_ealignn()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "extra":  # (regenerate only the newest fixtures)
         case_extra_features()
         case_atomwise_extra()
@@ -337,3 +393,4 @@ if __name__ == "__main__":
     case_atomwise_ff()
     case_extra_features()
     case_atomwise_extra()
+    case_ealignn()

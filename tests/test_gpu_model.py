@@ -535,6 +535,56 @@ def test_golden_atomwise_extra_features_head():
     assert n > 20
 
 
+def test_golden_ealignn_filtered_graph_model():
+    """eALIGNNAtomWise against the reference's own class (alignn/models/ealignn_atomwise.py on the shims): bond
+    vectors recomputed from frac_coords + lattice + images, bonds beyond inner_cutoff dropped before the line graph,
+    torque-free forces, stresses, the loss and every second-order parameter gradient; eval() (fused kernels) agrees
+    with train() (composed path); the reference's state_dict loads unchanged."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "shims"))
+    import dgl  # shim: DGL-shaped container only
+
+    from alignn_amd.ealignn_atomwise import eALIGNNAtomWise, eALIGNNAtomWiseConfig
+
+    z = load_golden("ealignn_tiny.npz")
+    cfg = eALIGNNAtomWiseConfig(name="ealignn_atomwise", alignn_layers=2, gcn_layers=2, hidden_features=32,
+                                embedding_features=16, atom_input_features=92, calculate_gradient=True,
+                                stresswise_weight=0.05, inner_cutoff=4.0)
+    model = eALIGNNAtomWise(cfg)
+    model.load_state_dict(state_dict_from_golden(z))
+    model = model.to(DEV).train()
+    n = int(z["in.batch_num_nodes"].sum())
+    g = dgl.graph((torch.from_numpy(z["in.u"]), torch.from_numpy(z["in.v"])), num_nodes=n)
+    g._bnn, g._bne = torch.from_numpy(z["in.batch_num_nodes"]), torch.from_numpy(z["in.batch_num_edges"])
+    g.ndata["atom_features"] = torch.from_numpy(z["in.atom_features"])
+    g.ndata["frac_coords"] = torch.from_numpy(z["in.frac_coords"])
+    g.ndata["V"] = torch.from_numpy(np.repeat(z["in.volume"], z["in.batch_num_nodes"]))
+    g.edata["r"] = torch.from_numpy(z["in.r"]) * 0.0 + 123.0  # must be ignored: r is recomputed from the positions
+    g.edata["images"] = torch.from_numpy(z["in.images"])
+    res = model((g, torch.from_numpy(z["in.lattice"])))
+    assert rel_err(res["out"], z["pred"]) < 1e-4
+    assert res["grad"].shape == (n, 3) and rel_err(res["grad"], z["forces"]) < 3e-4
+    assert rel_err(res["stresses"], z["stresses"]) < 3e-4
+    L = torch.nn.functional.l1_loss
+    t = lambda k: torch.from_numpy(z[k]).to(DEV)  # noqa: E731
+    loss = L(res["out"], t("t_energy")) + L(res["grad"], t("t_forces")) + 0.05 * L(res["stresses"], t("t_stress"))
+    assert abs(loss.item() - float(z["loss"])) < 2e-4
+    loss.backward()
+    nograd = set(z["nograd"].tolist())
+    gfloor = 1e-2 * max(float(np.abs(v).max()) for k, v in z.items() if k.startswith("grad."))
+    cnt = 0
+    for k, p in model.named_parameters():
+        if k in nograd:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+        else:
+            assert rel_err(p.grad, z["grad." + k], floor=gfloor) < 3e-3, k
+            cnt += 1
+    assert cnt > 40
+    ev = model.eval()((g, torch.from_numpy(z["in.lattice"])))
+    assert rel_err(ev["grad"], z["forces"]) < 3e-4 and rel_err(ev["stresses"], z["stresses"]) < 3e-4
+    assert rel_err(ev["out"], z["pred"]) < 1e-4
+
+
 def test_inference_path_folds_batchnorm_into_gate_pass():
     """eval() under no_grad: alignn_egc_gate_infer writes the edge output straight from the gate pass (BatchNorm =
     affine map of the running statistics).  Same predictions as the training-capable kernels in eval mode, as the
