@@ -215,6 +215,14 @@ def main():
     if use_graph:
         eager_step = step
         try:
+            # torch's capture recipe: the step right before the capture runs on a side stream, so that the parameters'
+            # gradient accumulators are not tied to the default stream
+            warm = torch.cuda.Stream(device=dev)
+            warm.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(warm):
+                eager_step()
+            torch.cuda.current_stream(dev).wait_stream(warm)
+            torch.cuda.synchronize()
             params = [p_ for p_ in model.parameters()]
             for p_ in params:
                 p_.grad = None
