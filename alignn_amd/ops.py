@@ -193,7 +193,10 @@ def split_f16x2(w, transpose=False):
     # max|w| is shared by the forward (W) and the input-gradient (W^T) images of one step: cache it per weight VERSION
     # (the optimizer's in-place update bumps the version)
     hit = _W_AMAX.get(id(w))
-    if hit is not None and hit[0]() is w and hit[1] == w._version:
+    # reuse only on the way BACK (transpose=True: the input-gradient image of the weight the forward just sliced) -
+    # every forward measures afresh, so an in-place edit that bypasses the version counter (w.data.mul_) between
+    # steps can never meet a stale maximum
+    if transpose and hit is not None and hit[0]() is w and hit[1] == w._version:
         amax = hit[2]
     else:
         amax = absmax(w if w.stride(0) % 4 == 0 and w.shape[1] % 4 == 0 else w.contiguous().view(1, -1))
