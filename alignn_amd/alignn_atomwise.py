@@ -107,6 +107,39 @@ def cutoff_function_based_edges(r, inner_cutoff=4, exponent=3):
     return torch.where(r <= inner_cutoff, env, torch.zeros_like(r))
 
 
+def positions_to_bond_vectors(gg, lat, dev):
+    """``compute_cartesian_coordinates`` + ``compute_pair_vector_and_distance`` (alignn/models/utils.py:47-56, 95-126):
+    Cartesian positions from ``g.ndata["frac_coords"]`` and the lattices, bond vectors
+    ``cart[dst] + g.edata["images"] - cart[src]`` in the caller's edge order."""
+    if "frac_coords" not in gg.ndata or "images" not in gg.edata:
+        raise ValueError("this option recomputes the bond vectors from positions: it needs g.ndata['frac_coords'] and "
+                         "g.edata['images'] (Cartesian image shifts), as the reference does")
+    u, v = gg.edges()
+    lat = torch.as_tensor(lat).to(dev, torch.float32)
+    if lat.dim() == 2:
+        lat = lat.unsqueeze(0)
+    bnn = torch.as_tensor(gg.batch_num_nodes()).to(dev, torch.int64)
+    which = torch.repeat_interleave(torch.arange(bnn.numel(), device=dev), bnn)
+    frac = gg.ndata["frac_coords"].to(dev, torch.float32)
+    cart = torch.bmm(frac.unsqueeze(1), lat[which]).squeeze(1)
+    r = cart[torch.as_tensor(v).to(dev).long()] + gg.edata["images"].to(dev, torch.float32) - cart[torch.as_tensor(u).to(dev).long()]
+    return cart, r
+
+
+def _check_pos_deriv(cfg, b):
+    if cfg.stresswise_weight != 0:
+        raise ValueError("include_pos_deriv gives no pair forces, so no virial: upstream fails here too (stresswise_weight must be 0)")
+
+
+def _single_virial(b: GraphBatch, pair_forces):
+    """batch_stress=False (alignn_atomwise.py:572-593): -160.21766208 * r^T f / (2 V[0]) with r from the positions."""
+    r_pos = b.cache.get("r_from_positions")
+    if r_pos is None:
+        raise ValueError("batch_stress=False takes the bond vectors from the positions: pass (g, lg, lat) with "
+                         "g.ndata['frac_coords'] and g.edata['images']")
+    return -160.21766208 * (r_pos.t() @ pair_forces) / (2 * b.volume[0])
+
+
 class _TorchLNMLPLayer(nn.Module):
     """models/utils.py:277-292 verbatim in structure, for the tiny descriptor head of ``extra_features != 0``."""
 
@@ -188,6 +221,15 @@ class ALIGNNAtomWise(nn.Module):
         if cached is not None and cached.device == dev and (cached.lg is not None or not need_lg):
             return cached
         batch = GraphBatch.from_dgl(gg, lg, device=dev, build_line_graph=need_lg)
+        cfg = self.config
+        if cfg.include_pos_deriv or (cfg.calculate_gradient and cfg.stresswise_weight != 0 and not cfg.batch_stress):
+            # these branches take the bond vectors from the positions (alignn_atomwise.py:405-412, 572-577)
+            _, r_pos = positions_to_bond_vectors(gg, g[-1], dev)
+            r_pos = r_pos[batch.g.perm].contiguous()
+            if cfg.include_pos_deriv:
+                batch.r = r_pos
+            else:
+                batch.cache["r_from_positions"] = r_pos
         try:
             gg._alignn_amd_batch = batch
         except Exception:
@@ -244,13 +286,21 @@ class ALIGNNAtomWise(nn.Module):
             en_out = en_out + torch.sum(pen)
         pair_forces = cfg.grad_multiplier * torch.autograd.grad(
             en_out, r, grad_outputs=torch.ones_like(en_out), create_graph=True, retain_graph=True)[0]  # :530-539
+        stress = torch.empty(1)
+        if cfg.include_pos_deriv:
+            # :513-524: grad_multiplier * d(en_out * N)/d(cart_coords); with r_e = cart[dst] + image - cart[src] the
+            # chain rule is the in-minus-out reduction of dE/dr
+            _check_pos_deriv(cfg, b)
+            forces = torch.squeeze(ff.pair_force_reduce(pair_forces, b.g, True)) * b.g.n_nodes
+            return self._finish(out, additional_out, forces, stress, atomwise_pred)
         if cfg.force_mult_natoms:
             pair_forces = pair_forces * b.g.n_nodes
         forces = torch.squeeze(ff.pair_force_reduce(pair_forces, b.g, cfg.add_reverse_forces))  # :547-565
-        stress = torch.empty(1)
         if cfg.stresswise_weight != 0:
-            if not cfg.batch_stress:
-                raise NotImplementedError("batch_stress=False (single-crystal virial) is outside this build")
+            if b.volume is None:
+                raise ValueError("stress needs the cell volumes: g.ndata['V'] (or GraphBatch.volume)")
+            if not cfg.batch_stress:  # :572-593: ONE virial over all bonds, the first crystal's volume, factor 1/2
+                return self._finish(out, additional_out, forces, _single_virial(b, pair_forces), atomwise_pred)
             if b.volume is None:
                 raise ValueError("stress needs the cell volumes: g.ndata['V'] (or GraphBatch.volume)")
             # per crystal: -160.21766208 * r_g^T f_g / V_g (:615-638); bonds of a crystal are contiguous slots
@@ -259,6 +309,9 @@ class ALIGNNAtomWise(nn.Module):
                 b.cache["bonds_by_graph"] = ff.by_graph(b.edge_graph_ptr)
             st = ff.segment_sum(outer, b.cache["bonds_by_graph"]).reshape(-1, 3, 3)
             stress = cfg.stress_multiplier * (-160.21766208) * st / b.volume.reshape(-1, 1, 1)
+        return self._finish(out, additional_out, forces, stress, atomwise_pred)
+
+    def _finish(self, out, additional_out, forces, stress, atomwise_pred):
         if self.link:
             out = self.link(out)
         if self.classification:
@@ -268,8 +321,6 @@ class ALIGNNAtomWise(nn.Module):
 
     def forward(self, g: Union[Sequence, GraphBatch]):
         cfg = self.config
-        if cfg.include_pos_deriv:
-            raise NotImplementedError("include_pos_deriv is 'not tested yet' upstream and outside this build")
         b = self._batch(g)
         # Forces: in training the loss differentiates THROUGH them -> composed, twice-differentiable path.  In eval
         # mode (MD / calculators: alignn/ff/calculators.py) only the first derivative is needed -> the fused kernels
@@ -352,19 +403,24 @@ class ALIGNNAtomWise(nn.Module):
             en_out = en_out + torch.sum(pen)
         (g_r,) = torch.autograd.grad(en_out, r, grad_outputs=torch.ones_like(en_out))
         pair_forces = cfg.grad_multiplier * g_r
+        gg = b.g
+        if cfg.include_pos_deriv:
+            _check_pos_deriv(cfg, b)
+            f = ops._segment_sum_raw(pair_forces, gg.seg_ptr, None, gg.seg_node, gg.n_nodes)
+            f = f - ops._segment_sum_raw(pair_forces, gg.out_ptr, gg.out_slot, None, gg.n_nodes)
+            return torch.squeeze(f) * gg.n_nodes, torch.empty(1)
         if cfg.force_mult_natoms:
             pair_forces = pair_forces * b.g.n_nodes
-        gg = b.g
         forces = ops._segment_sum_raw(pair_forces, gg.seg_ptr, None, gg.seg_node, gg.n_nodes)  # copy_e / sum by destination
         if cfg.add_reverse_forces:
             forces = forces - ops._segment_sum_raw(pair_forces, gg.out_ptr, gg.out_slot, None, gg.n_nodes)
         forces = torch.squeeze(forces)
         stress = torch.empty(1)
         if cfg.stresswise_weight != 0:
-            if not cfg.batch_stress:
-                raise NotImplementedError("batch_stress=False (single-crystal virial) is outside this build")
             if b.volume is None:
                 raise ValueError("stress needs the cell volumes: g.ndata['V'] (or GraphBatch.volume)")
+            if not cfg.batch_stress:
+                return forces, _single_virial(b, pair_forces)
             outer = (r.detach().unsqueeze(2) * pair_forces.unsqueeze(1)).reshape(-1, 9)
             st = ops._segment_sum_raw(outer, b.edge_graph_ptr, None, None, b.batch_size).reshape(-1, 3, 3)
             stress = cfg.stress_multiplier * (-160.21766208) * st / b.volume.reshape(-1, 1, 1)

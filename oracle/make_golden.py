@@ -376,8 +376,76 @@ def case_ealignn():
     print("ealignn pred", out["pred"], "loss", out["loss"], "bonds kept", kept, "of", sum(bne))
 
 
+def _position_graphs(sizes, seed0):
+    """(g batched with frac_coords / images / V / r / atom_features, lat, arrays) for the position-based branches."""
+    from alignn_amd.synthetic import make_crystal, knn_multigraph
+
+    graphs, lats, arr = [], [], {k: [] for k in "u v r images frac_coords atom_features".split()}
+    bnn, bne, vols, off = [], [], [], 0
+    for i, n in enumerate(sizes):
+        lat, frac, Z = make_crystal(n, seed0 + i)
+        u, v, r = knn_multigraph(lat, frac)
+        cart = frac @ lat
+        img = r - (cart[v] - cart[u])
+        af = np.random.default_rng(seed0 + 100 + i).standard_normal((n, 92)).astype(np.float32)
+        g = dgl.graph((torch.from_numpy(u), torch.from_numpy(v)), num_nodes=n)
+        g.ndata["atom_features"] = torch.from_numpy(af)
+        g.ndata["frac_coords"] = torch.from_numpy(frac.astype(np.float32))
+        vol = float(abs(np.linalg.det(lat)))
+        g.ndata["V"] = torch.full((n,), vol)
+        g.edata["r"] = torch.from_numpy(r.astype(np.float32))
+        g.edata["images"] = torch.from_numpy(img.astype(np.float32))
+        graphs.append(g)
+        lats.append(torch.from_numpy(lat.astype(np.float32)))
+        for k, val in (("u", u + off), ("v", v + off), ("r", r.astype(np.float32)), ("images", img.astype(np.float32)),
+                       ("frac_coords", frac.astype(np.float32)), ("atom_features", af)):
+            arr[k].append(val)
+        bnn.append(n); bne.append(u.shape[0]); vols.append(vol); off += n
+    out = {"in." + k: np.concatenate(v) for k, v in arr.items()}
+    out.update({"in.batch_num_nodes": np.array(bnn), "in.batch_num_edges": np.array(bne),
+                "in.lattice": torch.stack(lats).numpy(), "in.volume": np.array(vols, dtype=np.float32)})
+    return dgl.batch(graphs), torch.stack(lats), out, off
+
+
+def case_atomwise_position_branches():
+    """ALIGNNAtomWise with include_pos_deriv=True (forces from d/d cart_coords, alignn_atomwise.py:405-412, 513-524) and
+    with batch_stress=False (one virial over all bonds from position-derived bond vectors, :572-593)."""
+    from alignn.models.alignn_atomwise import ALIGNNAtomWise, ALIGNNAtomWiseConfig
+
+    g, lat, out, n = _position_graphs((6, 9), 800)
+    for tag, kw in (("p", dict(include_pos_deriv=True, stresswise_weight=0.0)),
+                    ("s", dict(batch_stress=False, stresswise_weight=0.05))):
+        torch.manual_seed(51)
+        cfg = ALIGNNAtomWiseConfig(name="alignn_atomwise", alignn_layers=1, gcn_layers=1, hidden_features=32,
+                                   embedding_features=16, atom_input_features=92, calculate_gradient=True, **kw)
+        model = ALIGNNAtomWise(cfg).train()
+        gg = dgl.batch(dgl.unbatch(g))  # fresh copy (the forward attaches cart_coords etc.)
+        lg = gg.line_graph(shared=True)
+        lg.edata["h"] = torch.zeros(lg.num_edges())  # (read once at :378, then recomputed on the fly)
+        res = model((gg, lg, lat))
+        out.update({f"{tag}.sd." + k: v.numpy().copy() for k, v in model.state_dict().items()})
+        gen = torch.Generator().manual_seed(12)
+        te, tf = torch.randn(2, generator=gen), torch.randn(n, 3, generator=gen)
+        L = torch.nn.functional.l1_loss
+        loss = L(res["out"], te) + L(res["grad"], tf)
+        if tag == "s":
+            ts = torch.randn(3, 3, generator=gen)
+            loss = loss + 0.05 * L(res["stresses"], ts)
+            out["s.t_stress"], out["s.stresses"] = ts.numpy(), res["stresses"].detach().numpy()
+        loss.backward()
+        out.update({f"{tag}.pred": res["out"].detach().numpy(), f"{tag}.forces": res["grad"].detach().numpy(),
+                    f"{tag}.loss": loss.item(), f"{tag}.t_energy": te.numpy(), f"{tag}.t_forces": tf.numpy()})
+        out.update({f"{tag}.grad." + k: p.grad.numpy().copy() for k, p in model.named_parameters() if p.grad is not None})
+        out[f"{tag}.nograd"] = np.array([k for k, p in model.named_parameters() if p.grad is None])
+        print("position branch", tag, "pred", out[f"{tag}.pred"], "loss", loss.item())
+    np.savez_compressed(os.path.join(OUT, "atomwise_position_branches.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "pos":
+        case_atomwise_position_branches()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ealignn":
         case_ealignn()
         sys.exit(0)
@@ -394,3 +462,4 @@ if __name__ == "__main__":
     case_extra_features()
     case_atomwise_extra()
     case_ealignn()
+    case_atomwise_position_branches()

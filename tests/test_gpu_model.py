@@ -535,6 +535,60 @@ def test_golden_atomwise_extra_features_head():
     assert n > 20
 
 
+def test_golden_atomwise_position_based_branches():
+    """ALIGNNAtomWise(include_pos_deriv=True) - forces from d/d(cart_coords) - and (batch_stress=False) - one virial over
+    all bonds with position-derived bond vectors and the 1/2 factor - against the reference's own class: energies,
+    forces, stress, loss, second-order parameter gradients; eval() (fused kernels) agrees."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "shims"))
+    import dgl  # shim: DGL-shaped container only
+
+    from alignn_amd import ALIGNNAtomWise, ALIGNNAtomWiseConfig
+
+    z = load_golden("atomwise_position_branches.npz")
+    n = int(z["in.batch_num_nodes"].sum())
+
+    def graphs():
+        g = dgl.graph((torch.from_numpy(z["in.u"]), torch.from_numpy(z["in.v"])), num_nodes=n)
+        g._bnn, g._bne = torch.from_numpy(z["in.batch_num_nodes"]), torch.from_numpy(z["in.batch_num_edges"])
+        g.ndata["atom_features"] = torch.from_numpy(z["in.atom_features"])
+        g.ndata["frac_coords"] = torch.from_numpy(z["in.frac_coords"])
+        g.ndata["V"] = torch.from_numpy(np.repeat(z["in.volume"], z["in.batch_num_nodes"]))
+        g.edata["r"] = torch.from_numpy(z["in.r"])
+        g.edata["images"] = torch.from_numpy(z["in.images"])
+        return g, torch.from_numpy(z["in.lattice"])
+
+    L = torch.nn.functional.l1_loss
+    t = lambda k: torch.from_numpy(z[k]).to(DEV)  # noqa: E731
+    for tag, kw in (("p", dict(include_pos_deriv=True, stresswise_weight=0.0)),
+                    ("s", dict(batch_stress=False, stresswise_weight=0.05))):
+        cfg = ALIGNNAtomWiseConfig(name="alignn_atomwise", alignn_layers=1, gcn_layers=1, hidden_features=32,
+                                   embedding_features=16, atom_input_features=92, calculate_gradient=True, **kw)
+        model = ALIGNNAtomWise(cfg)
+        model.load_state_dict({k[len(tag) + 4:]: torch.from_numpy(np.asarray(v)) for k, v in z.items() if k.startswith(tag + ".sd.")})
+        model = model.to(DEV).train()
+        g, lat = graphs()
+        res = model((g, lat))
+        assert rel_err(res["out"], z[tag + ".pred"]) < 1e-4
+        assert rel_err(res["grad"], z[tag + ".forces"]) < 3e-4, tag
+        loss = L(res["out"], t(tag + ".t_energy")) + L(res["grad"], t(tag + ".t_forces"))
+        if tag == "s":
+            assert res["stresses"].shape == (3, 3) and rel_err(res["stresses"], z["s.stresses"]) < 3e-4
+            loss = loss + 0.05 * L(res["stresses"], t("s.t_stress"))
+        assert abs(loss.item() - float(z[tag + ".loss"])) < 2e-4
+        loss.backward()
+        nograd = set(z[tag + ".nograd"].tolist())
+        gfloor = 1e-2 * max(float(np.abs(v).max()) for k, v in z.items() if k.startswith(tag + ".grad."))
+        for k, p in model.named_parameters():
+            if k not in nograd:
+                assert rel_err(p.grad, z[tag + ".grad." + k], floor=gfloor) < 3e-3, (tag, k)
+        g2, lat2 = graphs()
+        ev = model.eval()((g2, lat2))
+        assert rel_err(ev["grad"], z[tag + ".forces"]) < 3e-4, tag
+        if tag == "s":
+            assert rel_err(ev["stresses"], z["s.stresses"]) < 3e-4
+
+
 def test_golden_ealignn_filtered_graph_model():
     """eALIGNNAtomWise against the reference's own class (alignn/models/ealignn_atomwise.py on the shims): bond
     vectors recomputed from frac_coords + lattice + images, bonds beyond inner_cutoff dropped before the line graph,
