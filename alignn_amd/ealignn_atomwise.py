@@ -23,7 +23,7 @@ from typing import Literal, Sequence, Union
 
 import torch
 
-from .alignn_atomwise import _CONFIG, ALIGNNAtomWise, ALIGNNAtomWiseConfig
+from .alignn_atomwise import _CONFIG, ALIGNNAtomWise, ALIGNNAtomWiseConfig, positions_to_bond_vectors
 from .graph import GraphBatch
 
 try:  # pydantic v2, as the reference's BaseSettings shim
@@ -120,14 +120,8 @@ class eALIGNNAtomWise(ALIGNNAtomWise):
             return cached
         u, v = gg.edges()
         u, v = torch.as_tensor(u).to(dev), torch.as_tensor(v).to(dev)
-        lat = torch.as_tensor(lat).to(dev, torch.float32)
-        if lat.dim() == 2:
-            lat = lat.unsqueeze(0)
         bnn = torch.as_tensor(gg.batch_num_nodes()).to(dev, torch.int64)
-        which = torch.repeat_interleave(torch.arange(bnn.numel(), device=dev), bnn)
-        frac = gg.ndata["frac_coords"].to(dev, torch.float32)
-        cart = torch.bmm(frac.unsqueeze(1), lat[which]).squeeze(1)  # models/utils.py:95-126
-        r = cart[v.long()] + gg.edata["images"].to(dev, torch.float32) - cart[u.long()]  # :47-56
+        cart, r = positions_to_bond_vectors(gg, lat, dev)  # models/utils.py:47-56, 95-126
         keep = torch.linalg.norm(r, dim=1) <= self.ealignn_config.inner_cutoff  # :312-316 drops what is GREATER
         first = torch.cumsum(bnn, 0) - bnn
         batch = GraphBatch.from_coo(u[keep], v[keep], int(bnn.sum()), bnn, atom_features=gg.ndata["atom_features"],
