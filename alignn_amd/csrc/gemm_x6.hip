@@ -1,22 +1,36 @@
-// fp32-accurate GEMM on the bf16 matrix cores ("bf16x6"): C[M,N] = A[M,K] W[N,K]^T (+bias +addend).
+// fp32-accurate GEMMs on the 16-bit matrix cores: C[M,N] = A[M,K] W[N,K]^T (+bias +addend)  (NT, forward/dgrad)
+// and dW[N,K] = G[M,N]^T X[M,K] (TN, wgrad).  gfx950 has no TF32/xf32; split products are how the H x H
+// projections get off the 157 TF fp32-MFMA roof and become HBM-bound.  Two slicing schemes share every kernel:
 //
-// Every fp32 operand is cut into three bf16 slices of 8 mantissa bits each by TRUNCATION
+// bf16x6 (no knowledge of the operand range needed).  Each fp32 operand is cut into three bf16 slices of 8
+// mantissa bits by TRUNCATION
 //     x = h + m + l (+ <2^-24 |x|),   h = x & 0xffff0000,  m = (x-h) & 0xffff0000,  l = upper16(x-h-m)
-// (the subtractions are exact), and the product is taken as the six slice products whose weight is
-// >= 2^-16:  hh + (hm + mh) + (hl + lh + mm), accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  The
-// dropped terms (ml, lm, ll) are < 2^-24 relative, i.e. the result carries fp32-grade error (measured:
-// <= the error of an fp32 FMA chain, see tests/test_gpu_kernels.py::test_gemm_x6_accuracy), while the
-// matrix pipe runs 16/6 = 2.7x faster than v_mfma_f32_32x32x2_f32.  gfx950 has no TF32/xf32; this is how
-// the H x H projections get off the 157 TF fp32-MFMA roof and become HBM-bound.
+// (the subtractions are exact) and the product is the six slice products of weight >= 2^-16:
+// hh + (hm + mh) + (hl + lh + mm), accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  The dropped terms are
+// < 2^-24 relative.
 //
-// Layout: 128 x 256 block tile, 8 waves (4 x 2) of 32 x 128, K step 16 (one MFMA step), double buffered LDS
-// (2 x 32 KiB -> two workgroups per CU, so one's epilogue/prologue overlaps the other's MFMAs).  Both operands reach LDS by DMA (global_load_lds_dwordx4: no staging VGPRs, no
-// ds_write): the activation tile A stays fp32 and is sliced in registers right before use (and/sub/perm,
-// ~5.5 VALU per element, once per wave row-strip); the weights arrive PRE-SLICED by alignn_split_bf16x3 in the
-// exact 16 KiB-per-(slice, k-block) image the DMA copies linearly (L2-resident: 384 KiB for 256x256).  LDS
-// images are unpadded; bank conflicts are removed by an XOR swizzle of the 16-byte chunk index that is
-// applied to the DMA *source* address (A) or baked into the pre-sliced layout (W) and again on the
-// ds_read_b128 address.  Epilogue as in gemm_f32.hip: per-wave LDS transpose, float4 row-segment stores.
+// f16x3 (needs max|A| and max|W|: device scalars that the PRODUCER kernels maintain, see block_amax_commit in
+// common.h).  Each operand is scaled by a power of two that puts its largest element near 2^14 (f16_scale), then
+// cut into two fp16 slices h = RN(x s), l = RN(x s - h) (22 mantissa bits; the scaling keeps l out of the fp16
+// subnormals for everything within 2^-24 of the maximum) and the product is hh + hl + lh by
+// v_mfma_f32_32x32x16_f16; the scales are undone in the epilogue.  Same fp32-grade error as bf16x6 (measured
+// <= 2e-6 relative, tests/test_gpu_kernels.py::test_gemm_f16x3_*), half the matrix-pipe work: at T x 256 x 256
+// the MFMA time (153 us at the measured 1.74 PF) drops below the HBM time (220 us), bf16x6's (306 us) does not.
+//
+// NT layout: 128 x 256 (RM=2) or 64 x 256 (RM=1, small M or K <= 64) block tile, 8 waves (4 x 2), K step 16 (one
+// MFMA step), a 2-deep DMA ring with counted vmcnt waits (2 x 32 KiB -> two workgroups per CU, so one's
+// epilogue/prologue overlaps the other's MFMAs).  Both operands reach LDS by DMA (global_load_lds_dwordx4: no
+// staging VGPRs, no ds_write): the activation tile A stays fp32 and is sliced in registers right before use, once
+// per wave row-strip; the weights arrive PRE-SLICED by alignn_split_bf16x3 / alignn_split_f16x2 in the exact
+// per-(slice, k-block) image the DMA copies linearly (L2-resident: 256-384 KiB for 256 x 256).  LDS images are
+// unpadded; bank conflicts are removed by an XOR swizzle of the 16-byte chunk index that is applied to the DMA
+// *source* address (A) or baked into the pre-sliced layout (W) and again on the ds_read_b128 address.  Epilogue
+// as in gemm_f32.hip: per-wave LDS transpose, float4 row-segment stores (write-once hint on T-sized outputs).
+//
+// TN layout (namespace tn): both operands are activations, so both are sliced in the kernel - cooperatively: every
+// thread owns one column of a 16-row stage (16 coalesced nontemporal dword loads, two stages in flight in
+// registers), slices it ONCE and writes the 16-bit planes k-contiguous to LDS; the waves then fetch MFMA operands
+// with ds_read_b128.  Split-K over M into slabs; the slab partials are summed by gemm_f32.hip's slab_reduce4.
 #include "common.h"
 #include "../../include/alignn_hip.h"
 
