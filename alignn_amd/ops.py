@@ -113,20 +113,21 @@ X6_MIN_TILES = 256  # 64x256 tiles below which the fp32-MFMA kernel's finer tile
 F16X3 = True  # use the three-product fp16 scheme wherever max|A| is known (False: always bf16x6)
 
 # max|x| of activations, tracked by the kernels that produce them (one device float per tensor).  Keyed by object
-# identity with a weak reference, so an entry dies with its tensor and can never describe recycled memory; tensors
-# that are modified in place afterwards must not be registered.
+# identity with a weak reference, so an entry dies with its tensor and can never describe recycled memory, and
+# stamped with the tensor's version counter, so an in-place edit after registration silently drops the bound (the
+# projection then takes the range-free bf16x6 scheme).
 _AMAX = {}
 
 
 def set_amax(t, amax):
     k = id(t)
-    _AMAX[k] = (weakref.ref(t, lambda _r, k=k: _AMAX.pop(k, None)), amax)
+    _AMAX[k] = (weakref.ref(t, lambda _r, k=k: _AMAX.pop(k, None)), amax, t._version)
     return t
 
 
 def get_amax(t):
     e = _AMAX.get(id(t))
-    return e[1] if e is not None and e[0]() is t else None
+    return e[1] if e is not None and e[0]() is t and e[2] == t._version else None
 
 
 _AMAX_ARENA = {"buf": None, "next": 0}

@@ -189,3 +189,37 @@ def test_device_knn_graph_matches_numpy_builder():
         assert torch.equal(getattr(b.lg, name), getattr(ref.lg, name)), name
     assert torch.allclose(b.r, ref.r, atol=1e-6) and torch.allclose(b.volume, ref.volume, rtol=1e-5)
     assert torch.equal(b.graph_ptr, ref.graph_ptr) and torch.equal(b.atom_features, ref.atom_features)
+
+
+def test_amax_registry_follows_identity_and_version():
+    """The activation-range registry that lets a projection choose the three-product fp16 scheme: an entry must
+    survive the autograd wrapping of a Function output, die with its tensor, and be dropped by an in-place edit."""
+    import gc
+
+    from alignn_amd import ops
+
+    bound = torch.tensor([3.0])
+
+    class Produce(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            y = x * 2
+            return ops.set_amax(y, bound)
+
+        @staticmethod
+        def backward(ctx, g):
+            return g * 2
+
+    x = torch.ones(4, 4, requires_grad=True)
+    y = Produce.apply(x)
+    assert ops.get_amax(y) is bound
+    assert ops.get_amax(y.contiguous()) is bound  # the same object when already contiguous
+    assert ops.get_amax(y.clone()) is None
+    with torch.no_grad():
+        y.mul_(100.0)  # the stored bound no longer covers the tensor
+    assert ops.get_amax(y) is None
+    z = ops.set_amax(torch.zeros(2, 2), bound)
+    key = id(z)
+    del z
+    gc.collect()
+    assert key not in ops._AMAX
