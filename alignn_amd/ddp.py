@@ -9,12 +9,17 @@ so there is nothing to gain from finer buckets, and one large message is what th
 links like.  BatchNorm statistics stay per rank, as in the reference (plain BatchNorm1d under DDP).
 
 Works with any backend (``gloo`` on CPU for the tests, ``nccl``==RCCL on the GPUs).
+
+Sharding is by graph (a batch is a disjoint union - no bond crosses crystals), so there is no data-path collective.
+A step costs in proportion to the number of bond PAIRS (rows of the line graph), not to the number of crystals:
+``triplet_count`` + ``shard_by_cost`` hand each rank an equal share of that.
 """
 
 from __future__ import annotations
 
-from typing import Iterable, List
+from typing import Iterable, List, Sequence
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -77,3 +82,29 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, process_group=No
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):
             dist.broadcast(t, src=src, group=process_group)
+
+
+def triplet_count(u, v, num_nodes: int) -> int:
+    """Rows of L(g) of one crystal from its bond list alone: pairs (e1, e2) with dst(e1) == src(e2), e1 != e2
+    (``g.line_graph`` semantics, alignn/graphs.py:588) - what the step time is proportional to."""
+    u = np.asarray(u, dtype=np.int64)
+    v = np.asarray(v, dtype=np.int64)
+    indeg = np.bincount(v, minlength=num_nodes)
+    return int(indeg[u].sum() - np.count_nonzero(u == v))
+
+
+def shard_by_cost(costs: Sequence[float], world: int) -> List[List[int]]:
+    """Split items (crystals of a global batch) into ``world`` shards of near-equal total cost: longest-processing-
+    time-first greedy (largest item to the currently lightest shard; ties -> lower rank, so every rank computes the
+    same partition without communicating).  Returns the item indices of each rank, ascending."""
+    if world < 1:
+        raise ValueError("world must be >= 1")
+    costs = np.asarray(costs, dtype=np.float64)
+    order = np.argsort(-costs, kind="stable")
+    load = np.zeros(world)
+    shards: List[List[int]] = [[] for _ in range(world)]
+    for i in order:
+        r = int(np.argmin(load))
+        shards[r].append(int(i))
+        load[r] += costs[i]
+    return [sorted(s) for s in shards]

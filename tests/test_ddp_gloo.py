@@ -11,7 +11,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from alignn_amd.ddp import FlatGradSync, broadcast_parameters
+from alignn_amd.ddp import FlatGradSync, broadcast_parameters, shard_by_cost, triplet_count
 
 
 def _free_port():
@@ -90,3 +90,26 @@ def test_flat_allreduce_matches_full_batch_gradient():
         if p.grad is not None:
             assert torch.allclose(res[0][k], p.grad, atol=1e-6), k
     assert res[0]["unused.weight"] is None
+
+
+def test_shards_are_balanced_by_triplet_count():
+    """balance ranks by T (rows of the line graph), not by the number of crystals."""
+    import numpy as np
+
+    from alignn_amd.synthetic import _one
+
+    sizes = [8, 40, 12, 60, 9, 33, 21, 50, 10, 45, 14, 27]
+    crystals = [_one(n, 500 + i, "crystal", 4) for i, n in enumerate(sizes)]
+    costs = []
+    for c in crystals:
+        t = triplet_count(c.u, c.v, c.num_nodes)
+        assert t == c.num_triplets  # the closed form counts exactly the rows of the explicit L(g)
+        costs.append(t)
+    for world in (2, 3, 8):
+        shards = shard_by_cost(costs, world)
+        assert sorted(i for s in shards for i in s) == list(range(len(sizes)))  # a partition
+        assert shards == shard_by_cost(costs, world)  # deterministic: every rank derives the same split
+        load = np.array([sum(costs[i] for i in s) for s in shards], dtype=float)
+        rr = np.array([sum(costs[i] for i in range(r, len(sizes), world)) for r in range(world)], dtype=float)
+        assert load.max() <= rr.max()  # never worse than the r::world split
+        assert load.max() - load.min() <= max(costs)  # LPT bound
