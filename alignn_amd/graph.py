@@ -140,7 +140,7 @@ def line_graph_of(g: CSRGraph) -> CSRGraph:
         inv=ident,
         grp_seg_ptr=g.out_ptr,
         grp_src_ptr=g.seg_ptr,
-        dense_max_src=int((sp[1:] - sp[:-1]).max()) if m > 0 else 0,  # dense and source-sorted by construction
+        dense_max_src=int(din.max()) if m > 0 else 0,  # dense and source-sorted by construction (= _dense_blocks)
     )
 
 

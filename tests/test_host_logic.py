@@ -223,3 +223,60 @@ def test_amax_registry_follows_identity_and_version():
     del z
     gc.collect()
     assert key not in ops._AMAX
+
+
+def test_canonical_layout_on_arbitrary_multigraphs():
+    """Property test (hypothesis): self-loops, parallel bonds, isolated atoms, empty graphs - the canonical layout and
+    the device line graph must still be exactly DGL's ``line_graph`` semantics."""
+    from hypothesis import given, settings
+    from hypothesis import strategies as st
+
+    from alignn_amd.graph import _dense_blocks, line_graph_of
+
+    @st.composite
+    def multigraphs(draw):
+        n = draw(st.integers(1, 7))
+        m = draw(st.integers(0, 18))
+        u = draw(st.lists(st.integers(0, n - 1), min_size=m, max_size=m))
+        v = draw(st.lists(st.integers(0, n - 1), min_size=m, max_size=m))
+        return n, torch.tensor(u, dtype=torch.int64), torch.tensor(v, dtype=torch.int64)
+
+    @settings(max_examples=150, deadline=None)
+    @given(multigraphs())
+    def check(case):
+        n, u, v = case
+        m = int(u.numel())
+        g = build_csr(u, v, n)
+        # slot k holds the caller's edge perm[k]; segments are destination-contiguous, stable inside
+        assert torch.equal(g.src.long(), u[g.perm]) and torch.equal(g.dst.long(), v[g.perm])
+        assert torch.equal(g.inv[g.perm], torch.arange(m))
+        sp = g.seg_ptr.long()
+        for j in range(n):
+            seg = g.perm[sp[j]:sp[j + 1]]
+            assert bool((v[seg] == j).all()) and torch.equal(seg, torch.sort(seg).values)
+        op = g.out_ptr.long()
+        for j in range(n):
+            assert bool((g.src.long()[g.out_slot.long()[op[j]:op[j + 1]]] == j).all())
+        # brute-force line graph in canonical slot ids
+        want = {(a, b) for a in range(m) for b in range(m) if a != b and int(g.dst[a]) == int(g.src[b])}
+        lg = line_graph_of(g)
+        got = list(zip(lg.src.tolist(), lg.dst.tolist()))
+        assert len(got) == len(want) and set(got) == want  # no duplicates, nothing missing
+        assert lg.n_nodes == m and lg.n_edges == len(want)
+        if want:
+            assert lg.dense_max_src == _dense_blocks(g, lg) > 0
+        # the caller's-explicit-line-graph route ends in the same canonical arrays
+        if want:
+            pairs = sorted(want, key=lambda p: (p[1] * 7919 + p[0]) % 104729)  # arbitrary caller order
+            cu = g.perm[torch.tensor([p[0] for p in pairs])]  # back to CALLER edge ids
+            cv = g.perm[torch.tensor([p[1] for p in pairs])]
+            b = GraphBatch.from_coo(u, v, n, torch.tensor([n]), lg_u=cu, lg_v=cv)
+            assert torch.equal(b.lg.src, lg.src) and torch.equal(b.lg.dst, lg.dst)
+            assert torch.equal(b.lg.seg_ptr, lg.seg_ptr) and torch.equal(b.lg.seg_node, lg.seg_node)
+            assert b.lg.dense_max_src == lg.dense_max_src
+            # a FILTERED line graph (eALIGNN-style) must not claim the dense block structure
+            if len(pairs) > 1:
+                fb = GraphBatch.from_coo(u, v, n, torch.tensor([n]), lg_u=cu[1:], lg_v=cv[1:])
+                assert fb.lg.dense_max_src == 0
+
+    check()
