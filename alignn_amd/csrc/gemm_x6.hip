@@ -17,8 +17,8 @@
 // <= 2e-6 relative, tests/test_gpu_kernels.py::test_gemm_f16x3_*), half the matrix-pipe work: at T x 256 x 256
 // the MFMA time (153 us at the measured 1.74 PF) drops below the HBM time (220 us), bf16x6's (306 us) does not.
 //
-// NT layout: 128 x 256 (RM=2) or 64 x 256 (RM=1, small M or K <= 64) block tile, 8 waves (4 x 2), K step 16 (one
-// MFMA step), a 2-deep DMA ring with counted vmcnt waits (2 x 32 KiB -> two workgroups per CU, so one's
+// NT layout: 128 x 256 (RM=2) or 64 x 256 (RM=1, small M or K <= 64) block tile, 4 waves (2 x 2) of 64|32 x 128, K step 16 (one
+// MFMA step), a 2-deep DMA ring with counted vmcnt waits (2 x 24-32 KiB -> two or three workgroups per CU, so one's
 // epilogue/prologue overlaps the other's MFMAs).  Both operands reach LDS by DMA (global_load_lds_dwordx4: no
 // staging VGPRs, no ds_write): the activation tile A stays fp32 and is sliced in registers right before use, once
 // per wave row-strip; the weights arrive PRE-SLICED by alignn_split_bf16x3 / alignn_split_f16x2 in the exact
