@@ -10,7 +10,13 @@ VARIANTS = {"warm": [], "base": [], "big": ["-DX6_WM=2", "-DX6_RM=4"], "big_nolo
 def build():
     os.makedirs(OUT, exist_ok=True)
     for k, fl in VARIANTS.items():
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", SRC, "-o", os.path.join(ROOT, "tools", f"_x6_{k}.so")] + fl, check=True)
+        src = SRC
+        if k.startswith("head"):  # the committed version of the kernel, for same-box A/B against the working tree
+            src = os.path.join(ROOT, "alignn_amd", "csrc", "_head_gemm_x6.hip")
+            open(src, "w").write(subprocess.run(["git", "show", "HEAD:alignn_amd/csrc/gemm_x6.hip"], cwd=ROOT, check=True, capture_output=True, text=True).stdout)
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", src, "-o", os.path.join(ROOT, "tools", f"_x6_{k}.so")] + fl, check=True)
+        if src != SRC:
+            os.remove(src)
 def run():
     M, N, K = 676200, 256, 256
     a = torch.randn(M, K, device="cuda"); w = torch.randn(3, N, K, device="cuda").to(torch.bfloat16); c = torch.empty(M, N, device="cuda")
@@ -46,9 +52,53 @@ def run_tn():
         for _ in range(10): call()
         e.record(); torch.cuda.synchronize()
         print(f"TN f16x3 {k:18s} {s.elapsed_time(e)/10*1e3:8.1f} us", flush=True)
+def run_f16():
+    """f16x3 NT kernel, T x 256 x 256 (the roofline kernel of bench.py)."""
+    M, N, K = 676200, 256, 256
+    a = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda"); c = torch.empty(M, N, device="cuda")
+    am = a.abs().max().reshape(1); wm = w.abs().max().reshape(1)
+    calls = {}
+    st = torch.cuda.current_stream().cuda_stream
+    for k in F16V:
+        lib = C.CDLL(os.path.join(ROOT, "tools", f"_x6_{k}.so"))
+        nb = lib.alignn_split_f16x2_bytes; nb.restype = C.c_size_t; nb.argtypes = [C.c_int, C.c_int]
+        img = torch.empty(nb(N, K), dtype=torch.uint8, device="cuda")
+        sp = lib.alignn_split_f16x2
+        sp.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        assert sp(w.data_ptr(), K, N, K, 0, wm.data_ptr(), img.data_ptr(), st) == 0
+        f = lib.alignn_gemm_nt_f16x3
+        f.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p]
+        calls[k] = (lambda f=f, img=img: f(a.data_ptr(), K, am.data_ptr(), img.data_ptr(), wm.data_ptr(), None, None, 0, c.data_ptr(), N, M, N, K, st))
+        for _ in range(3): assert calls[k]() == 0
+    torch.cuda.synchronize()
+    rounds = int(os.environ.get("ABL_ROUNDS", "1"))
+    times = {k: [] for k in calls}
+    for _ in range(rounds):  # variants interleaved round by round, so clock / thermal drift hits all of them alike
+        for k, call in calls.items():
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(10): call()
+            e.record(); torch.cuda.synchronize()
+            times[k].append(s.elapsed_time(e) / 10 * 1e3)
+    for k, ts in times.items():
+        ts = sorted(ts)
+        print(f"NT f16x3 {k:22s} median {ts[len(ts)//2]:8.1f} us   min {ts[0]:8.1f}   max {ts[-1]:8.1f}   ({len(ts)} x 10 launches)", flush=True)
+F16V = {"warm": [], "base": [], "head": [], "base2": [], "head2": [], "nostore": ["-DX6_ABL_NOSTORE=1"], "noepi": ["-DX6_ABL_NOSTORE=2"], "noaload": ["-DX6_ABL_NOALOAD=1"],
+        "nobload": ["-DX6_ABL_NOBLOAD=1"], "noloads": ["-DX6_ABL_NOBLOAD=1", "-DX6_ABL_NOALOAD=1"], "onemfma": ["-DX6_ABL_ONEMFMA=1"],
+        "noslice": ["-DX6_ABL_NOSLICE=1"],
+        "noloads_noepi": ["-DX6_ABL_NOBLOAD=1", "-DX6_ABL_NOALOAD=1", "-DX6_ABL_NOSTORE=2"],
+        "onemfma_noepi": ["-DX6_ABL_ONEMFMA=1", "-DX6_ABL_NOSTORE=2"],
+        "noaload_nostore": ["-DX6_ABL_NOALOAD=1", "-DX6_ABL_NOSTORE=1"],
+        "stage3_noepi": ["-DX6_NSTAGE=3", "-DX6_ABL_NOSTORE=2"], "rm1": ["-DX6_FORCE_RM=1"], "stage3": ["-DX6_NSTAGE=3"], "stage3_nostore": ["-DX6_NSTAGE=3", "-DX6_ABL_NOSTORE=1"]}
 TNV = {"warm": [], "base": [], "noload": ["-DX6_ABL_NOALOAD=1"], "onemfma": ["-DX6_ABL_ONEMFMA=1"], "noload_onemfma": ["-DX6_ABL_NOALOAD=1", "-DX6_ABL_ONEMFMA=1"]}
 if os.environ.get("ABL_TN") == "1":
     VARIANTS = TNV
     run = run_tn
+if os.environ.get("ABL_F16") == "1":
+    VARIANTS = F16V
+    run = run_f16
+if os.environ.get("ABL_ONLY"):
+    VARIANTS = {k: v for k, v in VARIANTS.items() if k in os.environ["ABL_ONLY"].split(",")}
+    F16V = TNV = VARIANTS
 if __name__ == "__main__":
     build() if sys.argv[1] == "build" else run()
