@@ -4,7 +4,7 @@ import numpy as np
 import torch
 
 from alignn_amd.graph import GraphBatch, build_csr
-from alignn_amd.synthetic import _one, batch_raw, line_graph_coo, make_batch
+from alignn_amd.synthetic import _one, batch_raw, make_batch
 
 
 def test_generator_matches_reference_input_contract():

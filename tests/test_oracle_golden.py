@@ -5,7 +5,6 @@ DGL shim (oracle/make_golden.py).  CPU-only; runs everywhere.
 """
 
 import numpy as np
-import pytest
 import torch
 
 from oracle import alignn_oracle as O
