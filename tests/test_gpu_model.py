@@ -365,7 +365,6 @@ def test_golden_atomwise_forces_eval_mode_fused_path():
 
 def test_geometry_derivative_kernels_match_torch_autograd():
     from alignn_amd import ops
-    from alignn_amd.graph import build_csr
 
     raw = make_batch(2, 9, seed0=91)
     b = GraphBatch.from_raw(raw, device=DEV)
