@@ -47,6 +47,9 @@
 #ifndef X6_ABL_ONEMFMA
 #define X6_ABL_ONEMFMA 0
 #endif
+#ifndef X6_PERSIST
+#define X6_PERSIST 0  // 1: long products on 512 persistent workgroups (bit-identical, measured no faster: see PERSIST below)
+#endif
 #ifndef X6_ABL_NOSTORE
 #define X6_ABL_NOSTORE 0  // 1: epilogue without its global stores, 2: no epilogue at all
 #endif
@@ -54,6 +57,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -84,6 +88,8 @@ struct Sch {
     static constexpr int NSTAGE = 2;  // DMA ring depth (3 measured no faster for f16x3: the kernel is HBM-bound)
 #endif
     static constexpr int LDS = NSTAGE * STAGE > EPI_BYTES ? NSTAGE * STAGE : EPI_BYTES;  // two workgroups per CU
+    // persistent walk: ring of two stages, the transpose patches overlay stage 1 and run past the ring's end
+    static constexpr int LDS_PERSIST = 2 * STAGE > STAGE + EPI_BYTES ? 2 * STAGE : STAGE + EPI_BYTES;
 };
 
 template <int N>
@@ -197,7 +203,18 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned char* lds_wave_
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, AUX);
 }
 
-template <bool HAS_ADD, bool F16, int RM_>
+// PERSIST: the launch has fewer workgroups than row tiles; a workgroup walks tiles blockIdx.x, +gridDim.x, ... and
+// DMA-prefetches the first k-stage of its NEXT tile before it issues the stores of the current one.  A one-tile
+// workgroup cannot retire (and free its LDS and registers for the next tile) before every store is acknowledged -
+// two thirds of the measured epilogue cost (profiles/r01_final_f16x3_ablation.txt); here the stores drain under the
+// next tile's first k-step.  vmcnt retires in issue order and counts stores, so that step waits with
+// vmcnt(<stores issued after the prefetch>) instead of vmcnt(0).  Needs an even number of k-steps (the last step
+// reads stage 1, stage 0 is free for the prefetch, the transpose patches overlay stage 1 onwards).
+// STATUS: compiled only with -DX6_PERSIST=1.  Results are bit-identical to the one-tile kernel (tools/ablate_x6.py,
+// ABL_CHECK=1, T x 256 x 256), but it measured no faster (374 vs 378 us, interleaved rounds): the second k-step's
+// vmcnt(0) still meets the stores one step later.  Kept as the base for a deeper walk (three stages: two prefetched
+// ahead of the stores) - see DESIGN.md section 8.
+template <bool HAS_ADD, bool F16, int RM_, bool PERSIST = false>
 __global__ __launch_bounds__(NT) void gemm_nt_x6_kernel(X6Args g) {
     constexpr int NPL = Sch<F16, RM_>::NPL, STAGE_BYTES = Sch<F16, RM_>::STAGE, B_DMA = Sch<F16, RM_>::B_DMA;
     constexpr int RM = Geo<RM_>::RM, BM = Geo<RM_>::BM, TM = Geo<RM_>::TM, A_BYTES = Geo<RM_>::A_BYTES,
@@ -208,29 +225,28 @@ __global__ __launch_bounds__(NT) void gemm_nt_x6_kernel(X6Args g) {
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int il = lane & 31, half = lane >> 5;
-    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int64_t n_mt = (g.M + BM - 1) / BM;  // row tiles (PERSIST walks them; otherwise gridDim.x == n_mt)
+    int64_t tile = blockIdx.x;
+    int64_t m0 = tile * BM;
     const int n0 = blockIdx.y * BN;
 
     f32x16 acc[RM][RN];
-#pragma unroll
-    for (int a = 0; a < RM; ++a)
-#pragma unroll
-        for (int b = 0; b < RN; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
     // ---- DMA addressing (LDS image is lane-linear; the XOR swizzle lives in the SOURCE address)
     // A: piece q = wave*A_DMA + i holds tile positions p = q*64 + lane -> row p/4, stored chunk p%4, which is
     //    global chunk (p%4) ^ ((row>>2)&3) of that row.
     const float* a_src[A_DMA];
+    auto set_rows = [&](int64_t row0) {
 #pragma unroll
-    for (int i = 0; i < A_DMA; ++i) {
-        const int p = (wave * A_DMA + i) * 64 + lane;
-        const int row = p >> 2, c = (p & 3) ^ ((row >> 2) & 3);
-        int64_t grow = m0 + row;
-        if (grow >= g.M) grow = g.M - 1;  // clamp: rows past the end are computed but never stored
-        a_src[i] = g.A + grow * g.lda + c * 4;
-    }
+        for (int i = 0; i < A_DMA; ++i) {
+            const int p = (wave * A_DMA + i) * 64 + lane;
+            const int row = p >> 2, c = (p & 3) ^ ((row >> 2) & 3);
+            int64_t grow = row0 + row;
+            if (grow >= g.M) grow = g.M - 1;  // clamp: rows past the end are computed but never stored
+            a_src[i] = g.A + grow * g.lda + c * 4;
+        }
+    };
+    set_rows(m0);
     // B: the slice planes of one (k-block, n-tile) are ONE contiguous 24 (16) KiB run in global memory, in
     // exactly the LDS image order (pre-swizzled), so a stage is sequential 1 KiB pieces and consecutive
     // k-blocks walk the weight image linearly (no power-of-two plane strides in the L2).
@@ -295,16 +311,31 @@ __global__ __launch_bounds__(NT) void gemm_nt_x6_kernel(X6Args g) {
     // must have arrived, younger ones stay in flight across the barrier.
     constexpr int NSTAGE = Sch<F16, RM_>::NSTAGE, PIECES = A_DMA + B_DMA;
     static_assert(NSTAGE == 2 || NSTAGE == 3, "vmcnt cases below");
+    static_assert(!PERSIST || NSTAGE == 2, "the persistent walk prefetches into stage 0 of a two-stage ring");
+    constexpr int EPI_STORES = RM * (RN / 2) * 8;  // global stores per lane and tile, all issued after the prefetch
+    static_assert(EPI_STORES < 64, "vmcnt is a 6-bit counter");
     const int nk = g.K / BK;
 #pragma unroll
     for (int s0 = 0; s0 < NSTAGE - 1; ++s0)
         if (s0 < nk) issue(s0, smem + s0 * STAGE_BYTES);
+    bool first = true;
+    for (;;) {  // row tiles of this workgroup (one iteration unless PERSIST)
+#pragma unroll
+    for (int a = 0; a < RM; ++a)
+#pragma unroll
+        for (int b = 0; b < RN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
     for (int kt = 0; kt < nk; ++kt) {
-        if (NSTAGE == 3 && kt + 1 < nk)
+        if (PERSIST && kt == 0 && !first)
+            wait_vmcnt<EPI_STORES>();  // stage 0 was prefetched BEFORE the previous tile's stores: leave those in flight
+        else if (NSTAGE == 3 && kt + 1 < nk)
             wait_vmcnt<PIECES>();
         else
             wait_vmcnt<0>();
         block_barrier();
+        // (issuing these DMA pieces between the product passes instead - they cost a wave fewer issue cycles among
+        // MFMAs than in front of LDS reads - measured 3.5 % SLOWER at T x 256 x 256)
         if (kt + NSTAGE - 1 < nk) issue(kt + NSTAGE - 1, smem + ((kt + NSTAGE - 1) % NSTAGE) * STAGE_BYTES);
         const unsigned char* stage = smem + (kt % NSTAGE) * STAGE_BYTES;
         if constexpr (F16) {
@@ -369,8 +400,14 @@ __global__ __launch_bounds__(NT) void gemm_nt_x6_kernel(X6Args g) {
 
     // epilogue: per-wave LDS transpose of two 32x32 tiles at a time -> float4 row segments.  Per round: all LDS
     // traffic first, then all addend loads (rows clamped, no per-element branches), then the stores.
+    const int64_t next = tile + gridDim.x;
+    const bool has_next = PERSIST && next < n_mt;
+    if (has_next) {  // every wave has passed the last k-step's barrier, i.e. nobody reads stage 0 any more
+        set_rows(next * BM);
+        issue(0, smem);
+    }
     constexpr int PLD = 64 + 4;
-    float* patch = reinterpret_cast<float*>(smem) + wave * (32 * PLD);
+    float* patch = reinterpret_cast<float*>(smem + (PERSIST ? STAGE_BYTES : 0)) + wave * (32 * PLD);
     const int prow = e_prow, pc4 = e_pc4;
 #if X6_ABL_NOSTORE == 2
     if (acc[0][0][0] == 12345.678f)  // (keeps the accumulators alive)
@@ -378,16 +415,42 @@ __global__ __launch_bounds__(NT) void gemm_nt_x6_kernel(X6Args g) {
 #pragma unroll
     for (int ahb = 0; ahb < RM * (RN / 2); ++ahb) {
         const int a = ahb / (RN / 2), hb = ahb % (RN / 2);
-        __syncthreads();
+        // the patches are private to a wave (LDS serves one wave's accesses in order): the only cross-wave hazard is
+        // the first overwrite of stage memory other waves may still be reading.  PERSIST must not use
+        // __syncthreads() here - its vmcnt(0) would drain the prefetch just issued.
+        if constexpr (PERSIST) {
+            if (ahb == 0) block_barrier();
+        } else {
+            __syncthreads();
+        }
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 patch[((r & 3) + 8 * (r >> 2) + 4 * half) * PLD + b * 32 + il] = acc[a][2 * hb + b][r];
-        __syncthreads();
+        if constexpr (!PERSIST) __syncthreads();
         float4 ov[8], av[8];
+        if constexpr (PERSIST) {
+            // read the patch behind the compiler's back: it would put s_waitcnt vmcnt(0) in front of LDS reads that
+            // it cannot tell apart from the destination of the DMA prefetch in flight
+            v4f pv[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) ov[i] = f4_ld(patch + (i * 4 + prow) * PLD + pc4);
+            for (int i = 0; i < 8; ++i)
+                asm volatile("ds_read_b128 %0, %1"
+                             : "=v"(pv[i])
+                             : "v"((unsigned)(size_t)(patch + (i * 4 + prow) * PLD + pc4))
+                             : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(pv[0]), "+v"(pv[1]), "+v"(pv[2]), "+v"(pv[3]), "+v"(pv[4]), "+v"(pv[5]), "+v"(pv[6]),
+                           "+v"(pv[7])
+                         :
+                         : "memory");
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ov[i] = make_float4(pv[i].x, pv[i].y, pv[i].z, pv[i].w);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ov[i] = f4_ld(patch + (i * 4 + prow) * PLD + pc4);
+        }
         const int col = n0 + wn * TN + hb * 64 + pc4;
         const int64_t row0 = m0 + wm * TM + a * 32 + prow;
         if (HAS_ADD) {
@@ -414,6 +477,11 @@ __global__ __launch_bounds__(NT) void gemm_nt_x6_kernel(X6Args g) {
             }
         }
     }
+    if (!has_next) break;
+    tile = next;
+    m0 = tile * BM;
+    first = false;
+    }  // row tiles
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -719,6 +787,29 @@ int launch_nt_rm(const X6Args& g, hipStream_t st) {
         attr_set = true;
     }
     dim3 grid(alignn_ceil_div(g.M, Geo<RM_>::BM), g.Npad / BN);
+#if X6_PERSIST
+    // long products (>= 4 tiles per resident workgroup): 512 persistent workgroups (two per CU) walk the row tiles
+    if constexpr (RM_ == 2 && Sch<F16, RM_>::NSTAGE == 2) {
+        constexpr int kResident = 512;
+        const int ny = g.Npad / BN;
+        // (without addend only: the addend variant needs 292 registers per lane in this form - one wave per SIMD)
+        if (!g.addend && g.N == g.Npad && ((g.K / BK) & 1) == 0 && (int64_t)grid.x * ny >= 4 * kResident &&
+            ny <= kResident) {
+            constexpr int plds = Sch<F16, RM_>::LDS_PERSIST;
+            static bool pattr_set = false;
+            if (!pattr_set) {
+                hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_x6_kernel<false, F16, RM_, true>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, plds);
+                if (e != hipSuccess) return (int)e;
+                pattr_set = true;
+            }
+            hipLaunchKernelGGL((gemm_nt_x6_kernel<false, F16, RM_, true>), dim3(kResident / ny, ny), dim3(NT), plds,
+                               st, g);
+            ALIGNN_CHECK_LAUNCH();
+            return 0;
+        }
+    }
+#endif
     if (g.addend)
         hipLaunchKernelGGL((gemm_nt_x6_kernel<true, F16, RM_>), grid, dim3(NT), lds, st, g);
     else

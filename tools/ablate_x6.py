@@ -80,10 +80,22 @@ def run_f16():
             for _ in range(10): call()
             e.record(); torch.cuda.synchronize()
             times[k].append(s.elapsed_time(e) / 10 * 1e3)
+    if os.environ.get("ABL_CHECK") == "1":  # variants that compute the same arithmetic must agree bit for bit
+        ref = None
+        for rep in range(int(os.environ.get("ABL_CHECK_REPS", "6"))):
+            a.normal_(); torch.cuda.synchronize()
+            am.copy_(a.abs().max().reshape(1))
+            outs = {}
+            for k, call in calls.items():
+                c.zero_(); assert call() == 0; torch.cuda.synchronize(); outs[k] = c.clone()
+            ks = list(outs)
+            for k in ks[1:]:
+                same = torch.equal(outs[k], outs[ks[0]])
+                print(f"check rep {rep}: {k} vs {ks[0]}: {'bit-identical' if same else 'DIFFERENT max|d| = %g' % (outs[k] - outs[ks[0]]).abs().max().item()}", flush=True)
     for k, ts in times.items():
         ts = sorted(ts)
         print(f"NT f16x3 {k:22s} median {ts[len(ts)//2]:8.1f} us   min {ts[0]:8.1f}   max {ts[-1]:8.1f}   ({len(ts)} x 10 launches)", flush=True)
-F16V = {"warm": [], "base": [], "head": [], "base2": [], "head2": [], "nostore": ["-DX6_ABL_NOSTORE=1"], "noepi": ["-DX6_ABL_NOSTORE=2"], "noaload": ["-DX6_ABL_NOALOAD=1"],
+F16V = {"warm": [], "base": [], "nolate": ["-DX6_LATE_DMA=0"], "persist": ["-DX6_PERSIST=1"], "head": [], "base2": [], "head2": [], "nostore": ["-DX6_ABL_NOSTORE=1"], "noepi": ["-DX6_ABL_NOSTORE=2"], "noaload": ["-DX6_ABL_NOALOAD=1"],
         "nobload": ["-DX6_ABL_NOBLOAD=1"], "noloads": ["-DX6_ABL_NOBLOAD=1", "-DX6_ABL_NOALOAD=1"], "onemfma": ["-DX6_ABL_ONEMFMA=1"],
         "noslice": ["-DX6_ABL_NOSLICE=1"],
         "noloads_noepi": ["-DX6_ABL_NOBLOAD=1", "-DX6_ABL_NOALOAD=1", "-DX6_ABL_NOSTORE=2"],
