@@ -105,6 +105,26 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def device_guard(t):
+    """Every launch goes to the CURRENT device's current stream (``stream()``): make the tensors' device current for
+    the duration of a module forward when it is not already (a model living on a non-current GPU).  The autograd
+    engine replays backward nodes under the device of their forward, so guarding the forward covers both."""
+    if t.is_cuda and t.device.index != torch.cuda.current_device():
+        return torch.cuda.device(t.device)
+    return _NO_GUARD
+
+
 def check(rc: int, what: str):
     if rc != 0:
         raise RuntimeError(f"libalignn_hip: {what} failed with hipError {rc}")

@@ -28,8 +28,8 @@ except Exception:  # pragma: no cover - depends on the image
 
     _CONFIG = {"extra": "forbid", "protected_namespaces": ()}
 
-from . import ops
-from .graph import CSRGraph, GraphBatch, build_csr
+from . import _lib, ops
+from .graph import CSRGraph, GraphBatch, build_csr, cached_dgl_batch
 
 
 class ALIGNNConfig(_Base):
@@ -126,10 +126,11 @@ class MLPLayer(nn.Module):
     def forward(self, x):
         lin, bn = self.layer[0], self.layer[1]
         _bump(bn, self.training)
-        return ops.MLPLayerFn.apply(
-            x, lin.weight, lin.bias, bn.weight, bn.bias, getattr(bn, "running_mean", None),
-            getattr(bn, "running_var", None), self.training, self._norm,
-        )
+        with _lib.device_guard(x):
+            return ops.MLPLayerFn.apply(
+                x, lin.weight, lin.bias, bn.weight, bn.bias, getattr(bn, "running_mean", None),
+                getattr(bn, "running_var", None), self.training, self._norm,
+            )
 
 
 def _as_csr(g, device) -> tuple[CSRGraph, bool]:
@@ -173,16 +174,52 @@ class EdgeGatedGraphConv(nn.Module):
         self.dst_update = nn.Linear(input_features, output_features)
         self.bn_nodes = self._norm_layer(output_features)
 
+    def _fused_node_projection(self):
+        """(wcat [4H,K], bcat [4H]) = src_gate | dst_gate | dst_update | src_update as ONE buffer whose row blocks
+        ARE the four Linear parameters (their ``.data`` are views into it), so the fused node projection
+        ``P = x wcat^T = A | Bd | Bh | Ux`` needs no per-forward ``torch.cat`` and its weight gradient lands in the four
+        ``.grad``s as row blocks of one GEMM.  ``state_dict`` keys / shapes are the reference's; the aliasing is
+        re-established lazily whenever something re-homed the parameters (``.to()``, ``load_state_dict(assign=True)``)."""
+        lins = (self.src_gate, self.dst_gate, self.dst_update, self.src_update)
+        ws, bs = [m.weight for m in lins], [m.bias for m in lins]
+        fused = self.__dict__.get("_fused_wb")
+        if fused is not None:
+            wcat, bcat = fused
+            rows, wstep, bstep = ws[0].shape[0], ws[0].numel() * 4, bs[0].numel() * 4
+            ok = wcat.device == ws[0].device and wcat.dtype == ws[0].dtype and wcat.shape[0] == 4 * rows
+            for i in range(4):
+                ok = ok and ws[i].data_ptr() == wcat.data_ptr() + i * wstep and bs[i].data_ptr() == bcat.data_ptr() + i * bstep
+            if ok:
+                return fused
+        with torch.no_grad():
+            wcat = torch.cat([w.detach() for w in ws], 0).contiguous()
+            bcat = torch.cat([b.detach() for b in bs], 0).contiguous()
+            rows = ws[0].shape[0]
+            for i in range(4):
+                ws[i].data = wcat[i * rows:(i + 1) * rows]
+                bs[i].data = bcat[i * rows:(i + 1) * rows]
+        self.__dict__["_fused_wb"] = (wcat, bcat)
+        return wcat, bcat
+
+    def _own_params_need_grad(self) -> bool:
+        return any(p.requires_grad for p in self.parameters(recurse=True))
+
     def forward(self, g, node_feats: torch.Tensor, edge_feats: torch.Tensor, need_edge_out: bool = True):
         """``need_edge_out=False`` (internal): the caller will discard ``y``; it is then returned as None and
         its normalise/activate pass is skipped (BatchNorm running statistics are still updated)."""
+        with _lib.device_guard(node_feats):
+            return self._forward(g, node_feats, edge_feats, need_edge_out)
+
+    def _forward(self, g, node_feats, edge_feats, need_edge_out):
         csr, canonical = _as_csr(g, node_feats.device)
         y_in = edge_feats if canonical else edge_feats[csr.perm]
         # fused node projection: P = x [W_sg; W_dg; W_du; W_su]^T -> A | Bd | Bh | Ux
-        wcat = torch.cat([self.src_gate.weight, self.dst_gate.weight, self.dst_update.weight, self.src_update.weight], 0)
-        bcat = torch.cat([self.src_gate.bias, self.dst_gate.bias, self.dst_update.bias, self.src_update.bias], 0)
+        wcat, bcat = self._fused_node_projection()
         if (self._norm == "batch" and not self.training and ops.INFER_FUSED
-                and not (torch.is_grad_enabled() and (node_feats.requires_grad or edge_feats.requires_grad))):
+                and not (torch.is_grad_enabled() and (node_feats.requires_grad or edge_feats.requires_grad
+                                                      or self._own_params_need_grad()))):
+            # (with grad enabled the shortcut is taken only if NOTHING here can receive a gradient: frozen upstream
+            # layers must not silently cost this layer's parameters their gradients)
             # pure inference (pretrained.py, model.eval() under no_grad): BatchNorm folded into the gate pass
             with torch.no_grad():
                 x, y = ops.edge_gated_conv_infer(
@@ -196,7 +233,10 @@ class EdgeGatedGraphConv(nn.Module):
         _bump(self.bn_nodes, self.training)
         _bump(self.bn_edges, self.training)
         x, y = ops.EdgeGatedConvFn.apply(
-            csr, node_feats, y_in, wcat, bcat, self.edge_gate.weight, self.edge_gate.bias,
+            csr, node_feats, y_in, wcat, bcat,
+            self.src_gate.weight, self.dst_gate.weight, self.dst_update.weight, self.src_update.weight,
+            self.src_gate.bias, self.dst_gate.bias, self.dst_update.bias, self.src_update.bias,
+            self.edge_gate.weight, self.edge_gate.bias,
             self.bn_nodes.weight, self.bn_nodes.bias, getattr(self.bn_nodes, "running_mean", None),
             getattr(self.bn_nodes, "running_var", None),
             self.bn_edges.weight, self.bn_edges.bias, getattr(self.bn_edges, "running_mean", None),
@@ -284,20 +324,13 @@ class ALIGNN(nn.Module):
             gg, lg = g[0], (g[1] if len(self.alignn_layers) > 0 else None)
         else:
             gg, lg = g, None
-        cached = getattr(gg, "_alignn_amd_batch", None)
-        if cached is not None and cached.device == dev:
-            return cached
-        batch = GraphBatch.from_dgl(gg, lg, device=dev)
-        try:
-            gg._alignn_amd_batch = batch
-        except Exception:
-            pass
-        return batch
+        # index structures cached on the graph object, features re-read every call (like the reference's forward)
+        return cached_dgl_batch(gg, lg, dev)
 
     def forward(self, g: Union[Sequence, GraphBatch]):
         """``g`` = ``(g, lg, lat)`` of DGL-like graphs as in the reference (alignn.py:291-295), a bare
         graph when ``alignn_layers == 0``, or a prebuilt ``GraphBatch``.  Returns ``squeeze(out)``."""
-        with _deferred_bumps():
+        with _lib.device_guard(self.fc.weight), _deferred_bumps():
             return self._forward(self._batch(g))
 
     def _forward(self, b: GraphBatch):

@@ -27,7 +27,7 @@ from torch import nn
 from . import alignn as _bn
 from . import ops
 from .alignn import _Base, _CONFIG, RBFExpansion  # noqa: F401  (RBFExpansion re-exported like the reference)
-from .graph import GraphBatch
+from .graph import GraphBatch, cached_dgl_batch
 
 
 class ALIGNNAtomWiseConfig(_Base):
@@ -133,7 +133,7 @@ def _check_pos_deriv(cfg, b):
 
 def _single_virial(b: GraphBatch, pair_forces):
     """batch_stress=False (alignn_atomwise.py:572-593): -160.21766208 * r^T f / (2 V[0]) with r from the positions."""
-    r_pos = b.cache.get("r_from_positions")
+    r_pos = b.r_from_positions
     if r_pos is None:
         raise ValueError("batch_stress=False takes the bond vectors from the positions: pass (g, lg, lat) with "
                          "g.ndata['frac_coords'] and g.edata['images']")
@@ -217,10 +217,8 @@ class ALIGNNAtomWise(nn.Module):
         need_lg = len(self.alignn_layers) > 0 and lg is None
         if need_lg and not self.config.lg_on_fly:
             raise ValueError("forward((g, lat)) has no precomputed bond cosines: it needs lg_on_fly=True")
-        cached = getattr(gg, "_alignn_amd_batch", None)
-        if cached is not None and cached.device == dev and (cached.lg is not None or not need_lg):
-            return cached
-        batch = GraphBatch.from_dgl(gg, lg, device=dev, build_line_graph=need_lg)
+        # index structures cached on the graph object; features (r, atom_features, V, positions) re-read every call
+        batch = cached_dgl_batch(gg, lg, dev, build_line_graph=need_lg)
         cfg = self.config
         if cfg.include_pos_deriv or (cfg.calculate_gradient and cfg.stresswise_weight != 0 and not cfg.batch_stress):
             # these branches take the bond vectors from the positions (alignn_atomwise.py:405-412, 572-577)
@@ -229,11 +227,7 @@ class ALIGNNAtomWise(nn.Module):
             if cfg.include_pos_deriv:
                 batch.r = r_pos
             else:
-                batch.cache["r_from_positions"] = r_pos
-        try:
-            gg._alignn_amd_batch = batch
-        except Exception:
-            pass
+                batch.r_from_positions = r_pos
         return batch
 
     def _forward_ff(self, b: GraphBatch):
@@ -259,7 +253,9 @@ class ALIGNNAtomWise(nn.Module):
             if cfg.multiply_cutoff:
                 c_off = env.unsqueeze(1)
             else:
-                d_in = env
+                # upstream OVERWRITES ``bondlength`` with the envelope here (:446-451), so the short-bond penalty
+                # below is taken on the envelope too
+                d_in = bondlength = env
         y = ff.mlp_layer(ff.mlp_layer(ff.rbf(d_in, self.edge_embedding[0]), self.edge_embedding[1]), self.edge_embedding[2])
         if c_off is not None:
             y = y * c_off
@@ -279,11 +275,7 @@ class ALIGNNAtomWise(nn.Module):
         atomwise_pred = torch.empty(1)
         if cfg.atomwise_output_features > 0 and cfg.atomwise_weight != 0:
             atomwise_pred = ff.linear(x, self.fc_atomwise)
-        en_out = out * counts if cfg.energy_mult_natoms else out  # :494-497
-        if cfg.use_penalty:  # :498-510
-            pen = torch.where(bondlength < cfg.penalty_threshold,
-                              cfg.penalty_factor * (cfg.penalty_threshold - bondlength), torch.zeros_like(bondlength))
-            en_out = en_out + torch.sum(pen)
+        en_out, out = self._total_energy(out, counts, bondlength)  # :494-510
         pair_forces = cfg.grad_multiplier * torch.autograd.grad(
             en_out, r, grad_outputs=torch.ones_like(en_out), create_graph=True, retain_graph=True)[0]  # :530-539
         stress = torch.empty(1)
@@ -310,6 +302,20 @@ class ALIGNNAtomWise(nn.Module):
             st = ff.segment_sum(outer, b.cache["bonds_by_graph"]).reshape(-1, 3, 3)
             stress = cfg.stress_multiplier * (-160.21766208) * st / b.volume.reshape(-1, 1, 1)
         return self._finish(out, additional_out, forces, stress, atomwise_pred)
+
+    def _total_energy(self, out, counts, bondlength):
+        """alignn_atomwise.py:494-510 -> (en_out, out): energy per crystal (x atoms if ``energy_mult_natoms``) plus the
+        short-bond penalty summed over ALL bonds of the batch.  Without ``energy_mult_natoms`` upstream's ``en_out`` is
+        the very tensor ``out`` and ``en_out += total_penalty`` is in place: the returned ``out`` carries the penalty."""
+        cfg = self.config
+        en_out = out * counts if cfg.energy_mult_natoms else out
+        if cfg.use_penalty:
+            pen = torch.where(bondlength < cfg.penalty_threshold,
+                              cfg.penalty_factor * (cfg.penalty_threshold - bondlength), torch.zeros_like(bondlength))
+            en_out = en_out + torch.sum(pen)
+            if not cfg.energy_mult_natoms:
+                out = en_out
+        return en_out, out
 
     def _finish(self, out, additional_out, forces, stress, atomwise_pred):
         if self.link:
@@ -348,8 +354,9 @@ class ALIGNNAtomWise(nn.Module):
             if cfg.multiply_cutoff:
                 c_off = cutoff_function_based_edges(bondlength, cfg.inner_cutoff, cfg.exponent).unsqueeze(1)
                 y = self.edge_embedding(bondlength) * c_off
-            else:
-                y = self.edge_embedding(cutoff_function_based_edges(bondlength, cfg.inner_cutoff, cfg.exponent))
+            else:  # ``bondlength`` becomes the envelope from here on (:446-451), also for the penalty
+                bondlength = cutoff_function_based_edges(bondlength, cfg.inner_cutoff, cfg.exponent)
+                y = self.edge_embedding(bondlength)
         else:
             y = self.edge_embedding(bondlength)
         for i, layer in enumerate(self.alignn_layers):
@@ -376,9 +383,12 @@ class ALIGNNAtomWise(nn.Module):
         if cfg.atomwise_output_features > 0 and cfg.atomwise_weight != 0:
             atomwise_pred = ops.linear(x, self.fc_atomwise.weight, self.fc_atomwise.bias)
         forces, stress = torch.empty(1), torch.empty(1)
-        if fused_forces:
-            forces, stress = self._forces_from_energy(b, out, r, bondlength)
-            out = out.detach()
+        if cfg.output_features is not None and (fused_forces or (cfg.use_penalty and not cfg.energy_mult_natoms)):
+            counts = (b.graph_ptr[1:] - b.graph_ptr[:-1]).to(torch.float32)
+            en_out, out = self._total_energy(out, counts, bondlength)  # (the penalty reaches ``out`` without forces too)
+            if fused_forces:
+                forces, stress = self._forces_from_energy(b, en_out, r)
+                out = out.detach()
         if self.link:
             out = self.link(out)
         if self.classification:
@@ -391,16 +401,10 @@ class ALIGNNAtomWise(nn.Module):
             "atomwise_pred": atomwise_pred,
         }
 
-    def _forces_from_energy(self, b: GraphBatch, out, r, bondlength):
-        """alignn_atomwise.py:494-638 for inference: E_tot -> pair forces -dE/dr (one fused backward) -> per-atom
+    def _forces_from_energy(self, b: GraphBatch, en_out, r):
+        """alignn_atomwise.py:512-638 for inference: E_tot -> pair forces -dE/dr (one fused backward) -> per-atom
         forces and per-crystal virial stresses.  Nothing here is differentiated again."""
         cfg = self.config
-        counts = (b.graph_ptr[1:] - b.graph_ptr[:-1]).to(torch.float32)
-        en_out = out * counts if cfg.energy_mult_natoms else out
-        if cfg.use_penalty:
-            pen = torch.where(bondlength < cfg.penalty_threshold,
-                              cfg.penalty_factor * (cfg.penalty_threshold - bondlength), torch.zeros_like(bondlength))
-            en_out = en_out + torch.sum(pen)
         (g_r,) = torch.autograd.grad(en_out, r, grad_outputs=torch.ones_like(en_out))
         pair_forces = cfg.grad_multiplier * g_r
         gg = b.g

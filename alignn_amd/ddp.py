@@ -32,6 +32,13 @@ class FlatGradSync:
 
     def __init__(self, params: Iterable[torch.nn.Parameter], process_group=None):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        # this class reads ``.grad`` only in sync(), after backward() has returned and joined the side stream: tell
+        # alignn_amd.ops that the weight gradients of these parameters may stay on it until then even though a
+        # process group exists (ops._deferred_join_is_safe; under DistributedDataParallel they may not)
+        from .ops import GRAD_READ_AFTER_BACKWARD
+
+        for p in self.params:
+            setattr(p, GRAD_READ_AFTER_BACKWARD, True)
         self.group = process_group
         self.flat = None
         self.views = None

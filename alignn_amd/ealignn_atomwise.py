@@ -114,10 +114,9 @@ class eALIGNNAtomWise(ALIGNNAtomWise):
         if isinstance(g, (tuple, list)) and isinstance(g[0], GraphBatch):
             return g[0]
         gg, lat = g[0], g[-1]
-        cached = getattr(gg, "_alignn_amd_ebatch", None)
+        # nothing is cached on the graph object: which bonds survive the inner cutoff depends on the positions, so the
+        # filtered graph is rebuilt on every forward exactly as upstream does (ealignn_atomwise.py:306-322)
         dev = self.fc.weight.device
-        if cached is not None and cached.device == dev:
-            return cached
         u, v = gg.edges()
         u, v = torch.as_tensor(u).to(dev), torch.as_tensor(v).to(dev)
         bnn = torch.as_tensor(gg.batch_num_nodes()).to(dev, torch.int64)
@@ -129,10 +128,6 @@ class eALIGNNAtomWise(ALIGNNAtomWise):
         batch.cache["cart_coords"] = cart
         if "extra_features" in gg.ndata:
             batch.extra_features = gg.ndata["extra_features"].to(dev, torch.float32).contiguous()
-        try:
-            gg._alignn_amd_ebatch = batch
-        except Exception:
-            pass
         return batch
 
     def forward(self, g: Union[Sequence, GraphBatch]):

@@ -183,6 +183,7 @@ class GraphBatch:
     h: Optional[torch.Tensor] = None  # [T]    canonical lg-slot order
     volume: Optional[torch.Tensor] = None  # [B] cell volumes (g.ndata["V"] of each crystal's first atom)
     extra_features: Optional[torch.Tensor] = None  # [N, k] g.ndata["extra_features"] (ALIGNNConfig.extra_features != 0)
+    r_from_positions: Optional[torch.Tensor] = None  # [E, 3] bond vectors recomputed from frac_coords + images (batch_stress=False)
     cache: dict = field(default_factory=dict)  # derived index structures (built once per batch, outside graph capture)
 
     @property
@@ -194,12 +195,23 @@ class GraphBatch:
     def device(self):
         return self.graph_ptr.device
 
+    def topology_only(self) -> "GraphBatch":
+        """The index structures without any feature tensor (what may be cached on a caller's graph object: features
+        are re-read on every forward, like the reference does, so in-place edits of ``g.edata['r']`` etc. are seen)."""
+        return GraphBatch(g=self.g, lg=self.lg, graph_ptr=self.graph_ptr, batch_size=self.batch_size)
+
     @staticmethod
     def from_coo(u, v, n_nodes, batch_num_nodes, lg_u=None, lg_v=None, atom_features=None, r=None, h=None, device=None,
-                 volume=None, build_line_graph=False):
+                 volume=None, build_line_graph=False, topology: Optional["GraphBatch"] = None):
         """Build from raw COO tensors (caller's edge order).  ``build_line_graph``: no ``lg_u/lg_v`` given - derive
-        L(g) on the device (``line_graph_of``); the cosines ``h`` are then left to the model (``lg_on_fly``)."""
+        L(g) on the device (``line_graph_of``); the cosines ``h`` are then left to the model (``lg_on_fly``).
+        ``topology``: a batch built earlier from the SAME graphs - its index structures are reused and only the
+        features are gathered into canonical order."""
         dev = torch.device(device) if device is not None else u.device
+        if topology is not None:
+            g, lg = topology.g, topology.lg
+            out = GraphBatch(g=g, lg=lg, graph_ptr=topology.graph_ptr, batch_size=topology.batch_size, cache=topology.cache)
+            return GraphBatch._attach(out, dev, atom_features, r, h, volume)
         u = torch.as_tensor(u).to(dev)
         v = torch.as_tensor(v).to(dev)
         g = build_csr(u, v, int(n_nodes))
@@ -222,6 +234,11 @@ class GraphBatch:
         bnn = torch.as_tensor(batch_num_nodes).to(dev).to(torch.int64)
         gp = _ptr_from_counts(bnn).to(torch.int32)
         out = GraphBatch(g=g, lg=lg, graph_ptr=gp, batch_size=int(bnn.numel()))
+        return GraphBatch._attach(out, dev, atom_features, r, h, volume)
+
+    @staticmethod
+    def _attach(out, dev, atom_features, r, h, volume):
+        g, lg = out.g, out.lg
         if atom_features is not None:
             out.atom_features = torch.as_tensor(atom_features).to(dev).contiguous()
         if r is not None:
@@ -251,16 +268,18 @@ class GraphBatch:
         )
 
     @staticmethod
-    def from_dgl(g, lg=None, device=None, build_line_graph=False):
+    def from_dgl(g, lg=None, device=None, build_line_graph=False, topology: Optional["GraphBatch"] = None):
         """From DGL-like graphs: anything exposing ``edges()``, ``num_nodes()``, ``batch_num_nodes()``
         and ``ndata`` / ``edata`` dicts (a real ``dgl.DGLGraph`` or the oracle shim).  Reads
         ``g.ndata['atom_features']``, ``g.edata['r']``, ``lg.edata['h']`` exactly as
-        ``ALIGNN.forward`` does (alignn/models/alignn.py:298,307,313) without popping them."""
-        u, v = g.edges()
-        dev = torch.device(device) if device is not None else u.device
+        ``ALIGNN.forward`` does (alignn/models/alignn.py:298,307,313) without popping them.  ``topology``: see
+        ``from_coo`` (the features are read afresh, the index structures reused)."""
+        u, v = (None, None) if topology is not None else g.edges()
+        dev = torch.device(device) if device is not None else (topology.device if topology is not None else u.device)
         kw = {}
         if lg is not None:
-            kw["lg_u"], kw["lg_v"] = lg.edges()
+            if topology is None:
+                kw["lg_u"], kw["lg_v"] = lg.edges()
             if "h" in lg.edata:
                 kw["h"] = lg.edata["h"]
         if "atom_features" in g.ndata:
@@ -273,7 +292,34 @@ class GraphBatch:
             first = torch.cumsum(bnn, 0) - bnn
             kw["volume"] = g.ndata["V"][first.to(g.ndata["V"].device)]
         out = GraphBatch.from_coo(u, v, g.num_nodes(), g.batch_num_nodes(), device=dev,
-                                  build_line_graph=build_line_graph and lg is None, **kw)
+                                  build_line_graph=build_line_graph and lg is None, topology=topology, **kw)
         if extra is not None:
             out.extra_features = torch.as_tensor(extra).to(dev).to(torch.float32).contiguous()
         return out
+
+
+def cached_dgl_batch(gg, lg, dev, build_line_graph=False) -> GraphBatch:
+    """``GraphBatch.from_dgl`` with the TOPOLOGY (CSR structures, permutations) cached on the caller's graph object -
+    the training loop passes the same DGL graphs every epoch - and the features gathered afresh on every call.  The
+    cache is keyed on the device, the line graph object that was passed and the node / edge counts."""
+    ent = getattr(gg, "_alignn_amd_topology", None)
+    topo = None
+    if ent is not None:
+        t, lg_ref, built = ent
+        same_lg = (lg_ref is None and lg is None) or (lg_ref is not None and lg_ref() is lg)
+        if (t.device == dev and same_lg and (built or not build_line_graph) and t.g.n_nodes == gg.num_nodes()
+                and t.g.n_edges == gg.num_edges()):
+            topo = t
+    batch = GraphBatch.from_dgl(gg, lg, device=dev, build_line_graph=build_line_graph, topology=topo)
+    if topo is None:
+        import weakref
+
+        try:
+            lg_ref = None if lg is None else weakref.ref(lg)
+        except TypeError:  # an object that cannot be weakly referenced: hold it (g and lg travel together anyway)
+            lg_ref = (lambda o: (lambda: o))(lg)
+        try:
+            gg._alignn_amd_topology = (batch.topology_only(), lg_ref, bool(build_line_graph and lg is None))
+        except Exception:
+            pass
+    return batch

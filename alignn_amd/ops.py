@@ -55,6 +55,11 @@ import os as _os
 
 _SIDE = {"enabled": _os.environ.get("ALIGNN_AMD_SIDE_STREAM", "1") != "0", "streams": {}, "armed": False}
 
+# Parameters whose owner promises to read ``.grad`` only after backward() has returned (alignn_amd.ddp.FlatGradSync
+# marks its parameters): under an initialised process group everything else is assumed to sit under
+# DistributedDataParallel, whose reducer copies gradients into its buckets from C++ hooks DURING backward.
+GRAD_READ_AFTER_BACKWARD = "_alignn_grad_read_after_backward"
+
 
 def _join_side_streams():
     _SIDE["armed"] = False
@@ -62,9 +67,33 @@ def _join_side_streams():
         torch.cuda.current_stream(dev).wait_stream(side)
 
 
-def on_side_stream(fn, inputs):
-    """Run ``fn()`` (kernel launches only) on the side stream; returns its tensors.  ``inputs`` are the
-    tensors it reads (kept alive for the allocator until the side stream has consumed them)."""
+def _deferred_join_is_safe(params):
+    """May the gradients ``params`` receive stay on the side stream until the end of backward()?
+
+    The autograd engine believes every output of a node was produced on the node's own (= the main) stream.  That is
+    harmless only if nothing launches a kernel on those gradients before the end-of-backward join: AccumulateGrad of a
+    leaf with ``grad is None`` and grad mode off just keeps the tensor.  Anything else - an existing ``.grad`` to add
+    to (gradient accumulation, ``zero_grad(set_to_none=False)``), tensor / post-accumulate hooks, ``create_graph``
+    (clone), a non-leaf weight (more autograd nodes downstream), DistributedDataParallel's reducer hooks - reads them
+    on the main stream right away, so then the main stream joins the side stream before the node returns."""
+    if torch.is_grad_enabled():
+        return False
+    ddp_possible = torch.distributed.is_available() and torch.distributed.is_initialized()
+    for p in params:
+        if p is None:
+            continue
+        if (not p.is_leaf or p.grad is not None or p._backward_hooks
+                or getattr(p, "_post_accumulate_grad_hooks", None)
+                or (ddp_possible and not getattr(p, GRAD_READ_AFTER_BACKWARD, False))):
+            return False
+    return True
+
+
+def on_side_stream(fn, inputs, params=()):
+    """Run ``fn()`` (kernel launches only) on the side stream; returns its tensors.  ``inputs`` are the tensors it
+    reads (kept alive for the allocator until the side stream has consumed them); ``params`` the leaves whose
+    gradients it computes - they decide whether the join may wait until the end of backward()
+    (``_deferred_join_is_safe``) or has to happen before this call returns."""
     if not _SIDE["enabled"]:
         return fn()
     dev = inputs[0].device
@@ -81,6 +110,9 @@ def on_side_stream(fn, inputs):
     for o in outs:
         if o is not None:
             o.record_stream(main)
+    if not _deferred_join_is_safe(params):
+        main.wait_stream(side)
+        return outs
     if not _SIDE["armed"]:
         _SIDE["armed"] = True
         try:
@@ -210,6 +242,9 @@ def split_f16x2(w, transpose=False):
     return sw
 
 
+KERNEL_TIMER = None  # bench.py: {"min_rows": r, "events": []} -> HIP events around every f16x3 NT launch of >= r rows
+
+
 def gemm_nt_f16x3(a, a_amax, ws, bias=None, addend=None, out=None):
     """out[M,N] = a[M,K] @ W[N,K]^T with W pre-sliced by ``split_f16x2`` and ``a_amax`` >= max|a| (device scalar)."""
     lib = _lib.load()
@@ -220,6 +255,18 @@ def gemm_nt_f16x3(a, a_amax, ws, bias=None, addend=None, out=None):
         raise ValueError(f"reduction length mismatch: {K} vs {ws.k}")
     if out is None:
         out = _empty(M, N, like=a)
+    if KERNEL_TIMER is not None and M >= KERNEL_TIMER["min_rows"]:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        try:
+            return _gemm_nt_f16x3_launch(lib, a, a_amax, ws, bias, addend, out, M, N, K)
+        finally:
+            ev1.record()
+            KERNEL_TIMER["events"].append((N, K, addend is not None, ev0, ev1))
+    return _gemm_nt_f16x3_launch(lib, a, a_amax, ws, bias, addend, out, M, N, K)
+
+
+def _gemm_nt_f16x3_launch(lib, a, a_amax, ws, bias, addend, out, M, N, K):
     check(
         lib.alignn_gemm_nt_f16x3(ptr(a), a.stride(0), ptr(a_amax), ptr(ws.buf), ptr(ws.amax), ptr(bias), ptr(addend),
                                  addend.stride(0) if addend is not None else 0, ptr(out), out.stride(0), M, N, K,
@@ -531,6 +578,7 @@ class MLPLayerFn(torch.autograd.Function):
         ctx.training = training
         ctx.norm = norm
         ctx.param_grads = _PARAM_GRADS["on"]
+        ctx.wb = (w, b)  # the leaves whose gradients come off the side stream (see _deferred_join_is_safe)
         return y
 
     @staticmethod
@@ -549,7 +597,8 @@ class MLPLayerFn(torch.autograd.Function):
         if not ctx.param_grads:
             return gx, None, None, None, None, None, None, None, None
         x_amax = ctx.x_amax
-        gw, gb = on_side_stream(lambda: (gemm_tn(gpre, x, g_amax, x_amax), col_sum(gpre)), [gpre, x, g_amax, x_amax])
+        gw, gb = on_side_stream(lambda: (gemm_tn(gpre, x, g_amax, x_amax), col_sum(gpre)), [gpre, x, g_amax, x_amax],
+                                ctx.wb)
         return gx, gw, gb, dgamma, dbeta, None, None, None, None
 
 
@@ -560,12 +609,16 @@ class EdgeGatedConvFn(torch.autograd.Function):
     """Whole convolution as one autograd node with a hand-written backward.
 
     Inputs are in the canonical segment order of ``graph`` (edge row k == CSR slot k).
-    ``wcat`` = cat(src_gate, dst_gate, dst_update, src_update).weight  [4H,H];  ``bcat`` likewise.
+    ``wcat`` = cat(src_gate, dst_gate, dst_update, src_update).weight  [4H,H];  ``bcat`` likewise: plain tensors
+    (no grad) that ALIAS the storage of the eight leaves ``w4`` / ``b4`` (EdgeGatedGraphConv keeps its four node
+    projections in one fused buffer); the leaves are passed only so that autograd routes their gradients - four row
+    blocks of one [4H,H] weight-gradient GEMM.
     """
 
     @staticmethod
-    def forward(ctx, graph: CSRGraph, x, y, wcat, bcat, w_eg, b_eg, n_gamma, n_beta, n_rm, n_rv, e_gamma, e_beta, e_rm,
-                e_rv, training: bool, residual: bool, need_y: bool = True, norm: str = "batch"):
+    def forward(ctx, graph: CSRGraph, x, y, wcat, bcat, w_sg, w_dg, w_du, w_su, b_sg, b_dg, b_du, b_su, w_eg, b_eg,
+                n_gamma, n_beta, n_rm, n_rv, e_gamma, e_beta, e_rm, e_rv, training: bool, residual: bool,
+                need_y: bool = True, norm: str = "batch"):
         lib = _lib.load()
         ctx.set_materialize_grads(False)
         x = x.contiguous()
@@ -612,6 +665,7 @@ class EdgeGatedConvFn(torch.autograd.Function):
         ctx.residual = residual
         ctx.norm = norm
         ctx.param_grads = _PARAM_GRADS["on"]
+        ctx.leaves = (w_sg, w_dg, w_du, w_su, b_sg, b_dg, b_du, b_su, w_eg, b_eg)
         ctx.save_for_backward(x, y, wcat, w_eg, P, M, xpre, s0, hh, n_stat, e_stat, n_gamma, e_gamma, n_beta, e_beta)
         return x_out, y_out
 
@@ -709,13 +763,28 @@ class EdgeGatedConvFn(torch.autograd.Function):
         g_x = _dgrad(GP, wcat, addend=gx_out if ctx.residual else None, g_amax=gp_amax)
         g_y = _dgrad(GM, w_eg, addend=gy_out if (ctx.residual and gy_out is not None) else None, g_amax=gm_amax)
         if not ctx.param_grads:
-            return (None, g_x, g_y) + (None,) * 16
-        g_weg, g_beg, g_wcat, g_bcat = on_side_stream(_wgrads, [GM, y, GP, x, gb_part, gm_amax, gp_amax, x_amax, y_amax])
+            return (None, g_x, g_y) + (None,) * 24
+        g_weg, g_beg, g_wcat, g_bcat = on_side_stream(_wgrads, [GM, y, GP, x, gb_part, gm_amax, gp_amax, x_amax, y_amax],
+                                                      ctx.leaves)
         dn_gamma, dn_beta = n_red[1], n_red[0]
         de_gamma = e_red[1] if e_red is not None else None
         de_beta = e_red[0] if e_red is not None else None
-        return (None, g_x, g_y, g_wcat, g_bcat, g_weg, g_beg, dn_gamma, dn_beta, None, None, de_gamma, de_beta, None,
-                None, None, None, None, None)
+        gw4 = tuple(g_wcat[i * H:(i + 1) * H] for i in range(4))  # row blocks of the fused gradient (views, no copy)
+        gb4 = tuple(g_bcat[i * H:(i + 1) * H] for i in range(4))
+        return (None, g_x, g_y, None, None) + gw4 + gb4 + (g_weg, g_beg, dn_gamma, dn_beta, None, None, de_gamma,
+                                                            de_beta, None, None, None, None, None, None)
+
+
+def edge_gated_conv_cat(graph: CSRGraph, x, y, wcat, bcat, w_eg, b_eg, n_gamma, n_beta, n_rm, n_rv, e_gamma, e_beta, e_rm,
+                        e_rv, training: bool, residual: bool, need_y: bool = True, norm: str = "batch"):
+    """EdgeGatedConvFn with the fused node projection given as ONE [4H,K] weight and ONE [4H] bias that may themselves
+    require grad (stand-alone use, kernel tests): their row blocks are handed over as views, so autograd adds the four
+    block gradients back into ``wcat.grad`` / ``bcat.grad``."""
+    H = wcat.shape[0] // 4
+    w4 = tuple(wcat[i * H:(i + 1) * H] for i in range(4))
+    b4 = tuple(bcat[i * H:(i + 1) * H] for i in range(4))
+    return EdgeGatedConvFn.apply(graph, x, y, wcat.detach(), bcat.detach(), *w4, *b4, w_eg, b_eg, n_gamma, n_beta, n_rm,
+                                 n_rv, e_gamma, e_beta, e_rm, e_rv, training, residual, need_y, norm)
 
 
 def edge_gated_conv_infer(graph: CSRGraph, x, y, wcat, bcat, w_eg, b_eg, n_gamma, n_beta, n_rm, n_rv, e_gamma, e_beta,

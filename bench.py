@@ -37,7 +37,8 @@ MFMA_F32_PEAK_TF = 157.3  # v_mfma_f32_32x32x2_f32 dense peak
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="GPUs (= ranks) of this node; default 1, or WORLD_SIZE when launched by torch.distributed.run")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64)
@@ -51,8 +52,29 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streamed-steps", type=int, default=8,
                     help="extra informational run with a fresh batch per step through alignn_amd.loader (0: skip)")
-    ap.add_argument("--cpu-graphs", type=int, default=8, help="graphs in the CPU-baseline sample")
+    ap.add_argument("--cpu-graphs", type=int, default=None,
+                    help="graphs in the CPU-baseline sample (default: the same batch as the GPU run)")
+    ap.add_argument("--eager-steps", type=int, default=5,
+                    help="extra informational run of this many eagerly launched steps on the resident batch (0: skip)")
     return ap.parse_args()
+
+
+def spawn_ranks(n):
+    """``python bench.py --gpus N`` without a launcher: start N ranks of this script ourselves (one per GPU, like the
+    reference's own ``mp.spawn`` over ``torch.cuda.device_count()``, alignn/train_alignn.py:432-476) through
+    torch.distributed.run on the loopback address, and pass its exit code on."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"--gpus {n} without WORLD_SIZE: spawning {n} ranks: {' '.join(cmd)}")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def algorithmic_bytes_per_step(N, E, T, la=4, lg=4, h=H, he=64):
@@ -86,40 +108,46 @@ def time_kernel(fn, iters=10):
     return s.elapsed_time(e) / iters
 
 
-def cpu_baseline(n_graphs, atoms):
-    """The CPU oracle (a port of the reference's model code, see oracle/alignn_oracle.py) timed on this
-    host: fwd + bwd + AdamW on a bounded sample of the same workload."""
+def cpu_baseline(n_graphs, n_atoms, kind="crystal"):
+    """The CPU oracle (oracle/alignn_oracle.py: the reference's model arithmetic restated on torch-CPU and pinned to
+    goldens written by the reference's own classes; kind "port" - the reference's files do not exist on the GPU box)
+    timed on this host on the SAME batch the GPU run trains on: one warm-up step on 8 graphs
+    (thread pool, allocator), then ONE timed training step (fwd + bwd + AdamW) of the full batch - ~15-25 s of CPU work.
+    The reference's own classes on the DGL shim, timed in the authoring container on the same batch, are recorded in
+    profiles/r02_cpu_reference_vs_port.json (same speed within a few percent: both are the same torch-CPU kernels)."""
     from alignn_amd.synthetic import make_batch
     from oracle import alignn_oracle as O
 
     cores = min(os.cpu_count() or 1, 32)  # torch-CPU scatter/GEMM stop scaling (and can thrash) beyond this
     torch.set_num_threads(cores)
     log(f"cpu baseline on {cores} threads (host has {os.cpu_count()})")
-    raw = make_batch(n_graphs, atoms)
-    g = O.TorchGraph(raw)
     p = O.as_params(O.init_state_dict(seed=0))
     leaves = [t for t in p.values() if t.requires_grad]
     opt = torch.optim.AdamW(leaves, lr=1e-3)
-    target = torch.randn(n_graphs, generator=torch.Generator().manual_seed(1))
 
-    def step():
+    def step(g, target):
         opt.zero_grad(set_to_none=True)
         loss = torch.nn.functional.l1_loss(O.alignn_forward(p, g, 4, 4, True), target)
         loss.backward()
         opt.step()
 
-    step()
-    n = 3
+    step(O.TorchGraph(make_batch(min(8, n_graphs), n_atoms, kind=kind)), torch.zeros(min(8, n_graphs)))
+    raw = make_batch(n_graphs, n_atoms, kind=kind)
+    g = O.TorchGraph(raw)
+    target = torch.randn(n_graphs, generator=torch.Generator().manual_seed(1))
     t0 = time.perf_counter()
-    for _ in range(n):
-        step()
-    dt = (time.perf_counter() - t0) / n
+    step(g, target)
+    dt = time.perf_counter() - t0
     return {
         "value": round(n_graphs / dt, 3),
         "unit": "graphs/s",
         "cores": cores,
+        "host_cpus": os.cpu_count(),
         "kind": "port",
-        "sample": f"{n} timed steps (fwd+bwd+AdamW) of {n_graphs} graphs x {atoms} atoms, default ALIGNN, torch-CPU oracle",
+        "seconds_per_step": round(dt, 2),
+        "sample": f"1 timed training step (fwd+bwd+AdamW) of the same batch as the GPU run ({n_graphs} graphs, N={raw.num_nodes} "
+                  f"E={raw.num_edges} T={raw.num_triplets}), default ALIGNN, torch-CPU oracle (reference model arithmetic on a "
+                  "torch-only stand-in for the DGL primitives - not DGL's own CPU kernels), after a warm-up step on 8 graphs",
     }
 
 
@@ -129,7 +157,11 @@ def log(*a):
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and (args.gpus or 1) > 1:
+        sys.exit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus is not None and args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
@@ -137,7 +169,20 @@ def main():
     # ALIGNN_BENCH_BACKEND=gloo + fewer GPUs than ranks is a SMOKE mode for the multi-process code path on a
     # 1-GPU box (ranks share cuda:0, collectives go through gloo); real runs use nccl (= RCCL) one rank per GPU.
     backend = os.environ.get("ALIGNN_BENCH_BACKEND", "nccl")
+    if os.environ.get("ALIGNN_BENCH_RENDEZVOUS_ONLY") == "1":
+        # launcher check (tests/test_bench_launch.py, no GPU): every rank joins the group and is counted
+        dist.init_process_group(backend if backend != "nccl" else "gloo", rank=rank, world_size=world)
+        seen = torch.ones(1)
+        dist.all_reduce(seen)
+        if rank == 0:
+            print(json.dumps({"n_gpus": world, "ranks_seen": int(seen.item()), "rendezvous_only": True}), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     ndev = torch.cuda.device_count()
+    if backend == "nccl" and ndev < world:
+        raise SystemExit(f"{world} ranks over RCCL need {world} GPUs, this node shows {ndev} (ALIGNN_BENCH_BACKEND=gloo "
+                         "lets ranks share a GPU for a smoke run)")
     dev_index = (local_rank % ndev) if world > 1 else 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -147,6 +192,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        assert dist.get_world_size() == world
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
 
@@ -212,8 +258,8 @@ def main():
     # no longer waits for the interpreter.  The flat gradient all-reduce and the fused AdamW step stay eager.
     # Replays are bit-identical to eager steps (tests/test_gpu_model.py, tools/graph_step_check.py).
     use_graph = os.environ.get("ALIGNN_BENCH_EAGER", "0") != "1" and args.model != "alignn_ff"
+    eager_step = step
     if use_graph:
-        eager_step = step
         try:
             # torch's capture recipe: the step right before the capture runs on a side stream, so that the parameters'
             # gradient accumulators are not tied to the default stream
@@ -274,6 +320,49 @@ def main():
     ms = dt / args.steps * 1e3
     gps = world * B * args.steps / dt
     log(f"{ms:.2f} ms/step, {gps:.1f} graphs/s (host enqueue {t_enq / args.steps * 1e3:.2f} ms/step)")
+
+    # ---- the same steps launched EAGERLY (informational): what a training loop pays when every batch has its own
+    # (N, E, T) and nothing can be replayed - ~520 launches per step enqueued from Python
+    eager = None
+    if args.eager_steps > 0 and use_graph:
+        for _ in range(2):
+            eager_step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.eager_steps):
+            eager_step()
+        e_enq = time.perf_counter() - t0
+        fence()
+        edt = (time.perf_counter() - t0) / args.eager_steps
+        if world > 1:
+            t = torch.tensor([edt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            edt = float(t.item())
+        eager = {"ms_per_step": round(edt * 1e3, 3), "graphs_per_s": round(world * B / edt, 1), "steps": args.eager_steps,
+                 "host_enqueue_ms_per_step": round(e_enq / args.eager_steps * 1e3, 3)}
+        log(f"eager launches: {edt * 1e3:.2f} ms/step")
+
+    # ---- the dominant kernel INSIDE a training step: HIP events around every T-row launch of the f16x3 NT kernel during
+    # one eagerly launched step (the weight-gradient GEMMs of the previous layer run beside it on the side stream, as
+    # in every real step) - reported in `roofline.in_step` next to the stand-alone micro-timing
+    in_step = None
+    if args.model == "alignn":  # (every rank runs the step: it contains the gradient all-reduce)
+        if rank == 0:
+            ops.KERNEL_TIMER = {"min_rows": raw.num_triplets, "events": []}
+        try:
+            eager_step()
+            torch.cuda.synchronize()
+            ev = ops.KERNEL_TIMER["events"] if rank == 0 else []
+        finally:
+            ops.KERNEL_TIMER = None
+        plain = [a.elapsed_time(b) for (n_, k_, add, a, b) in ev if n_ == H and k_ == H and not add]
+        added = [a.elapsed_time(b) for (n_, k_, add, a, b) in ev if n_ == H and k_ == H and add]
+        if plain:
+            in_step = {"launches": len(plain), "ms_per_launch": round(sum(plain) / len(plain), 4),
+                       "min_ms": round(min(plain), 4), "max_ms": round(max(plain), 4),
+                       "with_residual_addend": {"launches": len(added), "ms_per_launch": round(sum(added) / max(len(added), 1), 4)},
+                       "how": "HIP events on the launch stream around every T-row launch (M=T, N=K=256) of one eagerly "
+                              "launched training step; side-stream weight-gradient GEMMs share the CUs"}
 
     # ---- streamed batches (informational, N=1): a FRESH batch every step through alignn_amd.loader - one pinned
     # 2.4 MB buffer per batch over PCIe, CSR + L(g) + cosines rebuilt on a staging stream under the previous step.
@@ -358,8 +447,12 @@ def main():
                 "triplets": T,
                 "parallelism": f"dp{world}",
             },
+            "eager_launches": eager,
             "roofline": {
                 "kernel": "gemm_nt_x6_kernel<*,true> (line-graph edge_gate projection, M=T, N=K=256, f16x3 split product)",
+                "in_step": None if in_step is None else dict(
+                    in_step, GBps=round(gemm_bytes / (in_step["ms_per_launch"] * 1e-3) / 1e9, 1),
+                    frac=round(gemm_bytes / (in_step["ms_per_launch"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)),
                 "bound": "hbm",
                 "achieved": round(gbs, 1),
                 "peak": HBM_PEAK_GBS,
@@ -396,7 +489,7 @@ def main():
             "loss": round(float(loss.item()), 6),
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_graphs, args.atoms)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_graphs or B, n_atoms, args.kind)
         else:
             out["cpu_baseline"] = None
     if world > 1:

@@ -330,3 +330,49 @@ def as_params(state_dict, dtype=torch.float32, requires_grad=True):
             t.requires_grad_(requires_grad and not is_buffer)
         out[k] = t
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# helpers shared by oracle/make_golden_full.py (writer) and tests/test_gpu_full_size.py (reader)
+# ---------------------------------------------------------------------------------------------
+def perturbed_norm_state_dict(sd, seed=1, scale=0.1):
+    """Non-trivial norm affines (weight 1 + 0.1 N(0,1), bias 0.1 N(0,1)) on top of ``init_state_dict``: with the
+    default gamma = 1 / beta = 0 a wrong gamma/beta gradient path could go unnoticed."""
+    g = torch.Generator().manual_seed(seed)
+    out = dict(sd)
+    for k in sorted(sd):
+        if (".bn_" in k or ".layer.1." in k) and k.endswith((".weight", ".bias")):
+            out[k] = sd[k] + scale * torch.randn(sd[k].shape, generator=g)
+    return out
+
+
+def full_size_sample(t, k=512, row_map=None):
+    """[k strided elements of the row-major tensor, mean, mean|.|, l2 norm, max|.|] in float64.  ``row_map`` (int64
+    [rows]): the tensor is stored with row i of the REFERENCE order at row ``row_map[i]`` (canonical slot order of
+    alignn_amd) - the strided sample is then taken at the reference's positions without permuting the tensor."""
+    t = t.detach()
+    if t.dim() == 0:
+        t = t.reshape(1)
+    n = t.numel()
+    idx = torch.linspace(0, n - 1, min(k, n), dtype=torch.float64).long().to(t.device)
+    if row_map is None or t.dim() < 2:
+        vals = t.reshape(-1)[idx]
+    else:
+        w = t.shape[1]
+        vals = t[row_map.to(t.device)[idx // w], idx % w]
+    f = t.reshape(-1).double()
+    mom = torch.stack([f.mean(), f.abs().mean(), f.norm(), f.abs().max()])
+    return torch.cat([vals.double().reshape(-1), mom]).cpu().numpy()
+
+
+def input_signature(raw):
+    """A few exact integers + float sums of a RawGraph: pins that make_batch regenerated the golden's inputs."""
+    import numpy as np
+
+    def h(a):
+        a = np.asarray(a).astype(np.uint64)
+        w = (np.arange(a.shape[0], dtype=np.uint64) % np.uint64(1000003)) + np.uint64(1)
+        return float(int(np.sum((a + np.uint64(1)) * w, dtype=np.uint64)) % (1 << 52))
+
+    return np.array([raw.num_nodes, raw.num_edges, raw.num_triplets, h(raw.u), h(raw.v), h(raw.lg_u), h(raw.lg_v),
+                     float(np.abs(raw.r.astype(np.float64)).sum()), float(raw.h.astype(np.float64).sum())], dtype=np.float64)

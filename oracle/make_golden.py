@@ -441,8 +441,54 @@ def case_atomwise_position_branches():
     np.savez_compressed(os.path.join(OUT, "atomwise_position_branches.npz"), **out)
 
 
+def case_atomwise_cutoff_penalty():
+    """The switches around the short-bond penalty (alignn_atomwise.py:435-510): ``use_cutoff_function`` with
+    ``multiply_cutoff`` on ("m") and off ("e": the bond length is OVERWRITTEN by the envelope, which then also feeds the
+    penalty), ``energy_mult_natoms=False`` with forces ("n") and on the energy-only path ("q"): there ``en_out`` IS
+    ``out``, so the in-place ``en_out += total_penalty`` shows up in the returned energies."""
+    from alignn.models.alignn_atomwise import ALIGNNAtomWise, ALIGNNAtomWiseConfig
+
+    raw = batch_raw([_one(n, 600 + i, "crystal", 92) for i, n in enumerate((6, 8))])
+    raw.r[0] *= 0.3
+    raw.r[1] *= 0.3
+    vol = np.abs(np.linalg.det(raw.lattice)).astype(np.float32)
+    out = dict(raw_arrays(raw))
+    out["volume"] = vol
+    variants = (("m", dict(use_cutoff_function=True, multiply_cutoff=True, inner_cutoff=6.0)),
+                ("e", dict(use_cutoff_function=True, multiply_cutoff=False, inner_cutoff=6.0)),
+                ("n", dict(energy_mult_natoms=False)),
+                ("q", dict(energy_mult_natoms=False, calculate_gradient=False)))
+    for tag, kw in variants:
+        torch.manual_seed(61)
+        base = dict(name="alignn_atomwise", alignn_layers=1, gcn_layers=1, hidden_features=32, embedding_features=16,
+                    atom_input_features=92, calculate_gradient=True, stresswise_weight=0.05)
+        base.update(kw)
+        model = ALIGNNAtomWise(ALIGNNAtomWiseConfig(**base)).train()
+        g, lg, lat = to_dgl(raw)
+        g.ndata["V"] = torch.from_numpy(np.repeat(vol, raw.batch_num_nodes))
+        res = model((g, lg, lat))
+        out.update({f"{tag}.sd." + k: v.numpy().copy() for k, v in model.state_dict().items()})
+        gen = torch.Generator().manual_seed(13)
+        te, tf, ts = torch.randn(2, generator=gen), torch.randn(raw.num_nodes, 3, generator=gen), torch.randn(2, 3, 3, generator=gen)
+        L = torch.nn.functional.l1_loss
+        loss = L(res["out"], te)
+        if base["calculate_gradient"]:
+            loss = loss + L(res["grad"], tf) + 0.05 * L(res["stresses"], ts)
+            out[f"{tag}.forces"], out[f"{tag}.stresses"] = res["grad"].detach().numpy(), res["stresses"].detach().numpy()
+        loss.backward()
+        out.update({f"{tag}.pred": res["out"].detach().numpy(), f"{tag}.loss": loss.item(), f"{tag}.t_energy": te.numpy(),
+                    f"{tag}.t_forces": tf.numpy(), f"{tag}.t_stress": ts.numpy()})
+        out.update({f"{tag}.grad." + k: p.grad.numpy().copy() for k, p in model.named_parameters() if p.grad is not None})
+        out[f"{tag}.nograd"] = np.array([k for k, p in model.named_parameters() if p.grad is None])
+        print("cutoff/penalty variant", tag, "pred", out[f"{tag}.pred"], "loss", loss.item())
+    np.savez_compressed(os.path.join(OUT, "atomwise_cutoff_penalty.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "cutoff":
+        case_atomwise_cutoff_penalty()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "pos":
         case_atomwise_position_branches()
         sys.exit(0)
@@ -463,3 +509,4 @@ if __name__ == "__main__":
     case_atomwise_extra()
     case_ealignn()
     case_atomwise_position_branches()
+    case_atomwise_cutoff_penalty()

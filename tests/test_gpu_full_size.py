@@ -1,0 +1,223 @@
+"""Parity at the EXACT sizes BASELINE.json quotes, against goldens written by the REFERENCE's own model classes
+(oracle/make_golden_full.py imports /root/reference/alignn/models/*.py unmodified on oracle/shims):
+
+* cfg 1  ALIGNN default (4+4, H=256),  8 x 60-atom crystals
+* cfg 2  the same,                      64 x 60-atom crystals - the benchmarked batch (N=3 840, E=50 712, T=676 200)
+* cfg 5  the same,                      256 molecules of 9-27 atoms (segments of 2-12)
+* cfg 4  ALIGNNAtomWise 4+4 / H=256 with forces + stresses, 16 x 200-atom crystals, second-order parameter gradients
+
+Error metrics (both printed, both asserted):
+
+* ``normwise``      max|a-b| / max|b|  - BASELINE.json's "1e-4 rel" read against the tensor's own scale;
+* ``elementwise``   max_i |a_i-b_i| / (|b_i| + floor), floor = 1 % of mean|b|: a relative error per element that
+  stays finite at zero crossings.
+
+Parameter gradients are judged PER PARAMETER: max|a-b| over the parameter's 512 samples against that parameter's own
+largest reference gradient, floored at 0.1 % of the largest gradient of the whole model (rounding noise of T-row
+reductions does not shrink with the gradient), plus the parameter's l2 norm; the error against the own scale alone is
+printed.  Parameters whose gradient is mathematically zero (a Linear bias feeding straight into BatchNorm) hold only
+rounding noise on both sides and are checked to be noise on ours as well.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from alignn_amd import ALIGNN, ALIGNNConfig, GraphBatch  # noqa: E402
+from alignn_amd.alignn import EdgeGatedGraphConv  # noqa: E402
+from alignn_amd.synthetic import batch_raw, make_batch, _one  # noqa: E402
+from oracle import alignn_oracle as O  # noqa: E402
+from tests.helpers import load_golden  # noqa: E402
+
+DEV = "cuda"
+K = 512  # strided samples per tensor in the goldens (oracle.alignn_oracle.full_size_sample)
+
+
+def normwise(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def elementwise(a, b, floor):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float((np.abs(a - b) / (np.abs(b) + floor)).max())
+
+
+def _emit(tag, report):
+    """Print the measured errors and leave them under gpurun_out/ (scratch; summaries are copied into profiles/)."""
+    import os
+
+    text = "\n".join(report)
+    print(text)
+    try:
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, f"parity_full_{tag}.txt"), "w") as f:
+            f.write(text + "\n")
+    except OSError:
+        pass
+
+
+def _split(v):
+    """golden entry -> (samples, dict of moments)"""
+    n = v.shape[0] - 4
+    return v[:n], {"mean": v[n], "absmean": v[n + 1], "l2": v[n + 2], "absmax": v[n + 3]}
+
+
+def _check_grads(model, z, tol, report):
+    nograd = set(z["nograd"].tolist())
+    gmax = max(_split(v)[1]["absmax"] for k, v in z.items() if k.startswith("grad."))
+    worst, worst_own = (0.0, None), (0.0, None)
+    n, fails = 0, []
+    for k, p in model.named_parameters():
+        if k in nograd:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        ref, mom = _split(z["grad." + k])
+        mine, mmom = _split(O.full_size_sample(p.grad, K))
+        if mom["absmax"] < 1e-5 * gmax:
+            # mathematically zero (bias in front of a batch statistic): rounding noise on both sides
+            assert mmom["absmax"] < 1e-4 * gmax, (k, mmom["absmax"], gmax)
+            continue
+        err = float(np.abs(mine - ref).max())
+        e_own = err / mom["absmax"]  # against the parameter's OWN largest gradient (reported)
+        e = err / max(mom["absmax"], 1e-3 * gmax)  # asserted: own scale, floored at 0.1 % of the largest gradient overall
+        el2 = abs(mmom["l2"] - mom["l2"]) / mom["l2"]
+        worst = max(worst, (e, k))
+        worst_own = max(worst_own, (e_own, k))
+        if not e < tol:
+            fails.append((k, "sample", e, e_own))
+        if mom["absmax"] > 1e-3 * gmax and not el2 < tol:
+            fails.append((k, "l2", el2))
+        n += 1
+    report.append(f"grads: {n} parameters, worst error vs max(own scale, 1e-3 global) {worst[0]:.2e} ({worst[1]}); "
+                  f"vs own scale alone {worst_own[0]:.2e} ({worst_own[1]})")
+    if fails:
+        report.append(f"grad FAILURES (tol {tol}): {fails[:12]}")
+    assert not fails, fails[:12]
+    return n
+
+
+def _check_acts(acts, z, batch, report, tol_norm=1e-4, tol_elem=2e-3):
+    g_inv, lg_inv = batch.g.inv, (batch.lg.inv if batch.lg is not None else None)
+    worst_n, worst_e, n, fails = (0.0, None), (0.0, None), 0, []
+    for name, (x, y) in acts.items():
+        lg_conv = name.endswith("edge_update")
+        for what, t, rmap in (("x_out", x, g_inv if lg_conv else None), ("y_out", y, lg_inv if lg_conv else g_inv)):
+            if t is None:  # dead output of the last layer: never materialised here
+                continue
+            ref, mom = _split(z[f"act.{name}.{what}"])
+            mine, mmom = _split(O.full_size_sample(t, K, row_map=rmap))
+            en = float(np.abs(mine - ref).max() / mom["absmax"])
+            ee = elementwise(mine, ref, 0.01 * mom["absmean"])
+            worst_n, worst_e = max(worst_n, (en, f"{name}.{what}")), max(worst_e, (ee, f"{name}.{what}"))
+            if not en < tol_norm:
+                fails.append((name, what, "normwise", en))
+            if not ee < tol_elem:
+                fails.append((name, what, "elementwise", ee))
+            for key in ("absmean", "l2"):
+                em = abs(mmom[key] - mom[key]) / mom[key]
+                if not em < 1e-4:
+                    fails.append((name, what, key, em))
+            n += 1
+    report.append(f"activations: {n} tensors, worst normwise {worst_n[0]:.2e} ({worst_n[1]}), "
+                  f"worst elementwise {worst_e[0]:.2e} ({worst_e[1]})")
+    if fails:
+        report.append(f"activation FAILURES: {fails[:12]}")
+    assert not fails, fails[:12]
+    return n
+
+
+def _hook(model):
+    acts = {}
+    for name, mod in model.named_modules():
+        if isinstance(mod, EdgeGatedGraphConv):
+            mod.register_forward_hook(lambda _m, _i, out, name=name: acts.__setitem__(name, (out[0].detach(), None if out[1] is None else out[1].detach())))
+    return acts
+
+
+@pytest.mark.parametrize("tag,mk", [
+    ("cfg1", lambda: make_batch(8, 60)),
+    ("cfg2", lambda: make_batch(64, 60)),
+    ("cfg5", lambda: make_batch(256, (9, 27), kind="molecule")),
+])
+def test_alignn_training_step_at_baseline_size_vs_reference_class(tag, mk):
+    z = load_golden(f"full_{tag}.npz")
+    raw = mk()
+    assert np.array_equal(O.input_signature(raw), z["in.sig"]), "make_batch did not regenerate the golden's inputs"
+    seed = int(z["seed"])
+    model = ALIGNN(ALIGNNConfig(name="alignn"))
+    model.load_state_dict(O.perturbed_norm_state_dict(O.init_state_dict(seed=seed), seed=seed + 1))
+    model = model.to(DEV).train()
+    acts = _hook(model)
+    batch = GraphBatch.from_raw(raw, device=DEV)
+    target = torch.from_numpy(z["target"]).to(DEV)
+    pred = model(batch)
+    loss = torch.nn.functional.l1_loss(pred, target)
+    loss.backward()
+    torch.cuda.synchronize()
+    report = [f"{tag}: N={raw.num_nodes} E={raw.num_edges} T={raw.num_triplets}"]
+    try:
+        p, pr = pred.detach().cpu().numpy(), z["pred"]
+        e_n, e_e = normwise(p, pr), elementwise(p, pr, 0.01 * np.abs(pr).mean())
+        report.append(f"pred: normwise {e_n:.2e}, elementwise {e_e:.2e}; loss {loss.item():.6f} vs {float(z['loss']):.6f}")
+        assert e_n < 1e-4 and e_e < 1e-3
+        assert abs(loss.item() - float(z["loss"])) < 1e-4 * max(1.0, abs(float(z["loss"])))
+        assert _check_acts(acts, z, batch, report) >= 20
+        assert _check_grads(model, z, 1e-3, report) > 80
+        sd = model.state_dict()
+        worst = 0.0
+        for k, v in z.items():
+            if k.startswith("sd_after."):
+                mine = sd[k[9:]].cpu().numpy()
+                e = elementwise(mine, v, 1e-3 * max(np.abs(v).mean(), 1e-3))
+                worst = max(worst, e)
+                assert e < 1e-3, (k, e)
+        report.append(f"running statistics: worst elementwise {worst:.2e}")
+    finally:
+        _emit(tag, report)
+
+
+def test_alignn_ff_training_step_at_cfg4_size_vs_reference_class():
+    """BASELINE configs[3]: 16 x 200-atom supercells, energy + forces + stresses and the loss gradient THROUGH the forces."""
+    from alignn_amd import ALIGNNAtomWise, ALIGNNAtomWiseConfig
+
+    z = load_golden("full_cfg4.npz")
+    B, atoms = 16, 200
+    raw = batch_raw([_one(atoms, 1234 + i, "crystal", 92) for i in range(B)])
+    assert np.array_equal(O.input_signature(raw), z["in.sig"])
+    seed = int(z["seed"])
+    cfg = ALIGNNAtomWiseConfig(name="alignn_atomwise", alignn_layers=4, gcn_layers=4, hidden_features=256,
+                               atom_input_features=92, calculate_gradient=True, stresswise_weight=0.05)
+    model = ALIGNNAtomWise(cfg)
+    sd = O.perturbed_norm_state_dict(O.init_state_dict(seed=seed), seed=seed + 1)
+    model.load_state_dict({k: v for k, v in sd.items() if "running" not in k and "tracked" not in k})
+    model = model.to(DEV).train()
+    batch = GraphBatch.from_raw(raw, device=DEV)
+    res = model(batch)
+    L = torch.nn.functional.l1_loss
+    t = lambda k: torch.from_numpy(z[k]).to(DEV)  # noqa: E731
+    loss = L(res["out"], t("t_energy")) + L(res["grad"], t("t_forces")) + L(res["stresses"], t("t_stress"))
+    loss.backward()
+    torch.cuda.synchronize()
+    report = [f"cfg4: N={raw.num_nodes} E={raw.num_edges} T={raw.num_triplets}"]
+    try:
+        for key, mine, tol in (("pred", res["out"], 1e-4), ("forces", res["grad"], 2e-4), ("stresses", res["stresses"], 2e-4)):
+            a, b = mine.detach().cpu().numpy(), z[key]
+            assert a.shape == b.shape, (key, a.shape, b.shape)
+            e_n, e_e = normwise(a, b), elementwise(a, b, 0.01 * np.abs(b).mean())
+            report.append(f"{key}: normwise {e_n:.2e}, elementwise {e_e:.2e}")
+            assert e_n < tol and e_e < 5e-3, (key, e_n, e_e)
+        assert abs(loss.item() - float(z["loss"])) < 2e-4 * abs(float(z["loss"]))
+        assert _check_grads(model, z, 2e-3, report) > 100
+        # inference path (eval(): first derivative only, fused kernels): same energies / forces / stresses
+        model.eval()
+        ev = model(batch)
+        for key, mine in (("pred", ev["out"]), ("forces", ev["grad"]), ("stresses", ev["stresses"])):
+            e_n = normwise(mine.detach().cpu().numpy(), z[key])
+            report.append(f"eval {key}: normwise {e_n:.2e}")
+            assert e_n < 2e-4, (key, e_n)
+    finally:
+        _emit("cfg4", report)

@@ -243,7 +243,7 @@ def test_edge_gated_conv_fwd_bwd(H, n, m, seed):
     wcat = torch.cat([P["sg_w"], P["dg_w"], P["du_w"], P["su_w"]], 0)
     bcat = torch.cat([P["sg_b"], P["dg_b"], P["du_b"], P["su_b"]], 0)
     rm_n, rv_n, rm_e, rv_e = (torch.zeros(H, device=DEV), torch.ones(H, device=DEV), torch.zeros(H, device=DEV), torch.ones(H, device=DEV))
-    xo_g, yo_g = ops.EdgeGatedConvFn.apply(csr, xg, yg, wcat, bcat, P["eg_w"], P["eg_b"], P["n_g"], P["n_b"], rm_n, rv_n,
+    xo_g, yo_g = ops.edge_gated_conv_cat(csr, xg, yg, wcat, bcat, P["eg_w"], P["eg_b"], P["n_g"], P["n_b"], rm_n, rv_n,
                                            P["e_g"], P["e_b"], rm_e, rv_e, True, True)
     ((xo_g * f(wx)).sum() + (yo_g * f(wy)[csr.perm]).sum()).backward()
     assert rel_err(xo_g, xo) < 2e-5
@@ -267,13 +267,13 @@ def test_edge_gated_conv_dead_edge_output():
     ng, nb, eg, eb = mk(H), mk(H), mk(H), mk(H)
     z = lambda: torch.zeros(H, device=DEV)  # noqa: E731
     o = lambda: torch.ones(H, device=DEV)  # noqa: E731
-    xo, yo = ops.EdgeGatedConvFn.apply(csr, x, y, wcat, bcat, weg, beg, ng, nb, z(), o(), eg, eb, z(), o(), True, True)
+    xo, yo = ops.edge_gated_conv_cat(csr, x, y, wcat, bcat, weg, beg, ng, nb, z(), o(), eg, eb, z(), o(), True, True)
     xo.sum().backward()
     g1 = [t.grad.clone() for t in (x, y, wcat, weg)]
     assert eg.grad is None and eb.grad is None
     for t in (x, y, wcat, bcat, weg, beg, ng, nb):
         t.grad = None
-    xo, yo = ops.EdgeGatedConvFn.apply(csr, x, y, wcat, bcat, weg, beg, ng, nb, z(), o(), eg, eb, z(), o(), True, True)
+    xo, yo = ops.edge_gated_conv_cat(csr, x, y, wcat, bcat, weg, beg, ng, nb, z(), o(), eg, eb, z(), o(), True, True)
     (xo.sum() + 0.0 * yo.sum()).backward()
     g2 = [t.grad for t in (x, y, wcat, weg)]
     for a_, b_ in zip(g1, g2):
@@ -310,7 +310,7 @@ def test_bitwise_reproducible():
         leaves = [a.clone().requires_grad_(True) for a in args]
         x, y, wcat, bcat, weg, beg, ng, nb = leaves
         z, o = torch.zeros(H, device=DEV), torch.ones(H, device=DEV)
-        xo, yo = ops.EdgeGatedConvFn.apply(csr, x, y, wcat, bcat, weg, beg, ng, nb, z, o, ng, nb, z.clone(), o.clone(), True, True)
+        xo, yo = ops.edge_gated_conv_cat(csr, x, y, wcat, bcat, weg, beg, ng, nb, z, o, ng, nb, z.clone(), o.clone(), True, True)
         (xo.square().sum() + yo.square().sum()).backward()
         outs.append([xo.detach(), yo.detach()] + [t.grad for t in leaves])
     for a_, b_ in zip(*outs):

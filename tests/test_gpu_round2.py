@@ -1,0 +1,240 @@
+"""Round-2 regression tests on the GPU: the code-review findings (side-stream gradients under gradient accumulation /
+DistributedDataParallel, stale feature caches, the eval shortcut dropping parameter gradients, the cutoff / penalty
+branches of ALIGNNAtomWise) and the fused node-projection parameters."""
+
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle", "shims"))
+
+from alignn_amd import ALIGNN, ALIGNNConfig, GraphBatch, ops  # noqa: E402
+from alignn_amd.synthetic import make_batch  # noqa: E402
+from tests.helpers import load_golden, raw_from_golden, rel_err, state_dict_from_golden  # noqa: E402
+
+DEV = "cuda"
+
+
+def _dgl_pair(raw, volume=None):
+    import dgl  # the torch-only shim: a DGL-shaped container
+
+    t = torch.from_numpy
+    g = dgl.graph((t(raw.u), t(raw.v)), num_nodes=raw.num_nodes)
+    g._bnn, g._bne = t(raw.batch_num_nodes), t(raw.batch_num_edges)
+    g.ndata["atom_features"] = t(raw.atom_features)
+    g.edata["r"] = t(raw.r.copy())
+    if volume is not None:
+        g.ndata["V"] = t(np.repeat(volume, raw.batch_num_nodes))
+    lg = dgl.graph((t(raw.lg_u), t(raw.lg_v)), num_nodes=raw.num_edges)
+    lg.edata["h"] = t(raw.h.copy())
+    return g, lg, t(raw.lattice)
+
+
+def _small_model(seed=0, **kw):
+    torch.manual_seed(seed)
+    cfg = dict(name="alignn", alignn_layers=2, gcn_layers=1, hidden_features=64, embedding_features=32)
+    cfg.update(kw)
+    return ALIGNN(ALIGNNConfig(**cfg)).to(DEV).train()
+
+
+# ---------------------------------------------------------------------------------------------
+# side-stream weight gradients: gradient accumulation, hooks, DDP
+# ---------------------------------------------------------------------------------------------
+def _two_backwards_without_zero_grad(side):
+    prev = ops._SIDE["enabled"]
+    ops._SIDE["enabled"] = side
+    try:
+        model = _small_model(3)
+        b1 = GraphBatch.from_raw(make_batch(6, 20, seed0=11), device=DEV)
+        b2 = GraphBatch.from_raw(make_batch(6, 20, seed0=29), device=DEV)
+        for b in (b1, b2):  # second backward ADDS to existing .grad tensors: AccumulateGrad launches kernels on them
+            model(b).sum().backward()
+        torch.cuda.synchronize()
+        return {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    finally:
+        ops._SIDE["enabled"] = prev
+
+
+def test_gradient_accumulation_with_side_stream_equals_single_stream():
+    a = _two_backwards_without_zero_grad(True)
+    b = _two_backwards_without_zero_grad(False)
+    assert a.keys() == b.keys() and len(a) > 40
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
+def test_deferred_join_policy():
+    w = torch.nn.Parameter(torch.randn(4, 4, device=DEV))
+    not_a_leaf = w * 2
+    with torch.no_grad():
+        assert ops._deferred_join_is_safe([w, None])
+        w.grad = torch.zeros_like(w)
+        assert not ops._deferred_join_is_safe([w])  # would be accumulated into on the main stream
+        w.grad = None
+        h = w.register_hook(lambda g: g)
+        assert not ops._deferred_join_is_safe([w])  # a hook reads the gradient during backward
+        h.remove()
+        assert ops._deferred_join_is_safe([w])
+        assert not ops._deferred_join_is_safe([not_a_leaf])  # not a leaf: more autograd nodes consume the gradient
+    assert not ops._deferred_join_is_safe([w])  # grad mode on (create_graph): AccumulateGrad clones
+
+
+def test_distributed_data_parallel_wrap_matches_unwrapped():
+    """alignn/train.py:207 wraps the model in DistributedDataParallel(find_unused_parameters=True): the reducer's
+    hooks copy every gradient into its buckets DURING backward - the side-stream gradients must be complete by then."""
+    import torch.distributed as dist
+
+    model = _small_model(5)
+    ref = _small_model(5)
+    ref.load_state_dict(model.state_dict())
+    raw = make_batch(6, 20, seed0=41)
+    batch = GraphBatch.from_raw(raw, device=DEV)
+    target = torch.randn(6, device=DEV)
+    torch.nn.functional.l1_loss(ref(batch), target).backward()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[torch.cuda.current_device()],
+                                                        find_unused_parameters=True)
+        for _ in range(2):  # second iteration: buckets rebuilt, .grad tensors exist
+            ddp.zero_grad(set_to_none=False)
+            torch.nn.functional.l1_loss(ddp(batch), target).backward()
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    n = 0
+    for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        if q.grad is not None:
+            assert p.grad is not None and torch.equal(p.grad, q.grad), k
+            n += 1
+    assert n > 40
+
+
+# ---------------------------------------------------------------------------------------------
+# feature cache / eval shortcut / fused parameters
+# ---------------------------------------------------------------------------------------------
+def test_in_place_feature_edits_are_seen_on_the_next_forward():
+    """The reference re-reads g.edata['r'] / lg.edata['h'] on every forward; only the index structures may be cached."""
+    model = _small_model(7).eval()
+    raw = make_batch(3, 12, seed0=5)
+    g, lg, lat = _dgl_pair(raw)
+    with torch.no_grad():
+        a = model((g, lg, lat)).clone()
+        assert getattr(g, "_alignn_amd_topology", None) is not None
+        g.edata["r"].mul_(1.05)  # in-place edit of the caller's tensors (finite differences, relaxation loops)
+        lg.edata["h"].mul_(0.9)
+        b = model((g, lg, lat))
+        raw2 = make_batch(3, 12, seed0=5)
+        raw2.r *= 1.05
+        raw2.h *= 0.9
+        c = model(GraphBatch.from_raw(raw2, device=DEV))
+    assert rel_err(b, c) < 1e-6
+    assert rel_err(a, c) > 1e-4  # (the edit does change the prediction)
+
+
+def test_eval_shortcut_never_drops_parameter_gradients():
+    model = _small_model(9).eval()
+    batch = GraphBatch.from_raw(make_batch(4, 14, seed0=3), device=DEV)
+    conv = model.gcn_layers[0]
+    x = torch.randn(batch.g.n_nodes, 64, device=DEV)
+    y = torch.randn(batch.g.n_edges, 64, device=DEV)
+    xo, yo = conv(batch.g, x, y)  # eval mode, grad enabled, inputs without grad, parameters WITH grad
+    (xo.sum() + yo.sum()).backward()
+    assert conv.edge_gate.weight.grad is not None and float(conv.edge_gate.weight.grad.abs().max()) > 0
+    assert conv.src_update.weight.grad is not None
+    with torch.no_grad():
+        xi, yi = conv(batch.g, x, y)  # the BatchNorm-folded inference pass gives the same values
+    assert rel_err(xi, xo) < 1e-5 and rel_err(yi, yo) < 1e-5
+    for p in conv.parameters():
+        p.requires_grad_(False)
+    xf, yf = conv(batch.g, x, y)  # nothing can receive a gradient: shortcut allowed even with grad mode on
+    assert not xf.requires_grad and rel_err(xf, xo) < 1e-5
+
+
+def test_fused_node_projection_parameters_alias_one_buffer():
+    model = _small_model(13)
+    batch = GraphBatch.from_raw(make_batch(4, 14, seed0=8), device=DEV)
+    keys = list(model.state_dict().keys())
+    target = torch.randn(4, device=DEV)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-2, fused=True)
+    torch.nn.functional.l1_loss(model(batch), target).backward()
+    conv = model.alignn_layers[0].edge_update
+    wcat, bcat = conv._fused_wb
+    H = conv.src_gate.weight.shape[0]
+    for i, lin in enumerate((conv.src_gate, conv.dst_gate, conv.dst_update, conv.src_update)):
+        assert lin.weight.data_ptr() == wcat.data_ptr() + i * H * H * 4
+        assert lin.bias.data_ptr() == bcat.data_ptr() + i * H * 4
+        assert lin.weight.grad is not None and lin.weight.grad.shape == lin.weight.shape
+    before = wcat.clone()
+    opt.step()
+    assert not torch.equal(before, wcat)  # the optimizer updates the fused buffer through the four views
+    assert torch.equal(wcat[H:2 * H], conv.dst_gate.weight.detach())
+    assert list(model.state_dict().keys()) == keys  # no new entries
+    # a state_dict round trip and a device move keep values; the aliasing is re-established on the next forward
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model2 = _small_model(99)
+    model2.load_state_dict(sd)
+    model2 = model2.cpu().to(DEV)
+    with torch.no_grad():
+        p1, p2 = model.eval()(batch), model2.eval()(batch)
+    assert torch.equal(p1, p2)
+    assert model2.alignn_layers[0].edge_update.dst_gate.weight.data_ptr() == model2.alignn_layers[0].edge_update._fused_wb[0].data_ptr() + H * H * 4
+
+
+# ---------------------------------------------------------------------------------------------
+# ALIGNNAtomWise: cutoff function / penalty / energy_mult_natoms branches (alignn_atomwise.py:435-510)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["m", "e", "n", "q"])
+def test_golden_atomwise_cutoff_and_penalty_branches(tag):
+    from alignn_amd import ALIGNNAtomWise, ALIGNNAtomWiseConfig
+
+    z = load_golden("atomwise_cutoff_penalty.npz")
+    raw = raw_from_golden(z)
+    kw = {"m": dict(use_cutoff_function=True, multiply_cutoff=True, inner_cutoff=6.0),
+          "e": dict(use_cutoff_function=True, multiply_cutoff=False, inner_cutoff=6.0),
+          "n": dict(energy_mult_natoms=False),
+          "q": dict(energy_mult_natoms=False, calculate_gradient=False)}[tag]
+    base = dict(name="alignn_atomwise", alignn_layers=1, gcn_layers=1, hidden_features=32, embedding_features=16,
+                atom_input_features=92, calculate_gradient=True, stresswise_weight=0.05)
+    base.update(kw)
+    model = ALIGNNAtomWise(ALIGNNAtomWiseConfig(**base))
+    model.load_state_dict(state_dict_from_golden(z, prefix=f"{tag}.sd."))
+    model = model.to(DEV).train()
+    g, lg, lat = _dgl_pair(raw, z["volume"])
+    res = model([g, lg, lat])
+    assert rel_err(res["out"], z[f"{tag}.pred"]) < 1e-4
+    L = torch.nn.functional.l1_loss
+    t = lambda k: torch.from_numpy(z[f"{tag}.{k}"]).to(DEV)  # noqa: E731
+    loss = L(res["out"], t("t_energy"))
+    if base["calculate_gradient"]:
+        assert rel_err(res["grad"], z[f"{tag}.forces"]) < 2e-4
+        assert rel_err(res["stresses"], z[f"{tag}.stresses"]) < 2e-4
+        loss = loss + L(res["grad"], t("t_forces")) + 0.05 * L(res["stresses"], t("t_stress"))
+    assert abs(loss.item() - float(z[f"{tag}.loss"])) < 1e-4
+    loss.backward()
+    nograd = set(z[f"{tag}.nograd"].tolist())
+    gfloor = 1e-2 * max(float(np.abs(v).max()) for k, v in z.items() if k.startswith(f"{tag}.grad."))
+    n = 0
+    for k, p in model.named_parameters():
+        if k in nograd:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+        else:
+            assert rel_err(p.grad, z[f"{tag}.grad." + k], floor=gfloor) < 2e-3, k
+            n += 1
+    assert n > 20
+    if base["calculate_gradient"]:  # inference path (fused kernels, first derivative only): same E / F / stress
+        model.eval()
+        ev = model([g, lg, lat])
+        assert rel_err(ev["out"], z[f"{tag}.pred"]) < 1e-4
+        assert rel_err(ev["grad"], z[f"{tag}.forces"]) < 2e-4
+        assert rel_err(ev["stresses"], z[f"{tag}.stresses"]) < 2e-4
