@@ -38,10 +38,14 @@ def _all_neighbors(lat: torch.Tensor, frac: torch.Tensor, cutoff: float):
     reach = torch.ceil(cutoff / spacing).to(torch.int64).tolist()  # 3 small integers (host)
     rng = [torch.arange(-k, k + 1, device=lat.device) for k in reach]
     images = torch.stack(torch.meshgrid(*rng, indexing="ij"), -1).reshape(-1, 3)
-    cart = frac @ lat
-    shift = images.to(lat.dtype) @ lat
-    d = cart[None, :, None, :] + shift[None, None, :, :] - cart[:, None, None, :]  # d[i, j, I] = cart[j] + shift[I] - cart[i]
-    dist = torch.linalg.norm(d, dim=-1)
+    # explicit elementwise float64 operations in the same fixed order as alignn_amd.synthetic._all_neighbors (separate
+    # multiply / add kernels, no matmul, no fused multiply-add): identical distance bits, identical tie decisions
+    cart = frac[:, 0:1] * lat[0] + frac[:, 1:2] * lat[1] + frac[:, 2:3] * lat[2]
+    imf = images.to(lat.dtype)
+    shift = imf[:, 0:1] * lat[0] + imf[:, 1:2] * lat[1] + imf[:, 2:3] * lat[2]
+    d = (cart[None, :, None, :] + shift[None, None, :, :]) - cart[:, None, None, :]  # d[i, j, I] = cart[j] + shift[I] - cart[i]
+    dx, dy, dz = d[..., 0], d[..., 1], d[..., 2]
+    dist = torch.sqrt(dx * dx + dy * dy + dz * dz)
     src, dst, img = torch.nonzero((dist <= cutoff) & (dist > 1e-8), as_tuple=True)
     return src, dst, images[img], dist[src, dst, img]
 

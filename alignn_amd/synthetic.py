@@ -129,11 +129,15 @@ def _all_neighbors(lat, frac, cutoff):
     reach = np.ceil(cutoff / spacing).astype(int)
     rng_ = [np.arange(-k, k + 1) for k in reach]
     images = np.stack(np.meshgrid(*rng_, indexing="ij"), -1).reshape(-1, 3)
-    cart = frac @ lat
-    shift = images @ lat  # [I,3]
-    # d[i, j, I] = cart[j] + shift[I] - cart[i]
-    d = cart[None, :, None, :] + shift[None, None, :, :] - cart[:, None, None, :]
-    dist = np.linalg.norm(d, axis=-1)
+    # distances as explicit elementwise float64 operations in a FIXED order (no BLAS, no fused multiply-add): the tie
+    # decisions at the shell of the 12th neighbour then agree bit for bit with the oracle's neighbour list
+    # (oracle/shims/jarvis/core/atoms.py) and with the device builder (alignn_amd/neighbors.py)
+    cart = frac[:, 0:1] * lat[0] + frac[:, 1:2] * lat[1] + frac[:, 2:3] * lat[2]
+    imf = images.astype(np.float64)
+    shift = imf[:, 0:1] * lat[0] + imf[:, 1:2] * lat[1] + imf[:, 2:3] * lat[2]  # [I,3]
+    # d[i, j, I] = (cart[j] + shift[I]) - cart[i]
+    d = (cart[None, :, None, :] + shift[None, None, :, :]) - cart[:, None, None, :]
+    dist = np.sqrt(d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1] + d[..., 2] * d[..., 2])
     mask = (dist <= cutoff) & (dist > 1e-8)
     src, dst, img = np.nonzero(mask)
     return src, dst, images[img], dist[src, dst, img], n

@@ -131,15 +131,15 @@ def test_in_place_feature_edits_are_seen_on_the_next_forward():
     with torch.no_grad():
         a = model((g, lg, lat)).clone()
         assert getattr(g, "_alignn_amd_topology", None) is not None
-        g.edata["r"].mul_(1.05)  # in-place edit of the caller's tensors (finite differences, relaxation loops)
-        lg.edata["h"].mul_(0.9)
+        g.edata["r"].mul_(1.5)  # in-place edit of the caller's tensors (finite differences, relaxation loops)
+        lg.edata["h"].mul_(-1.0)
         b = model((g, lg, lat))
         raw2 = make_batch(3, 12, seed0=5)
-        raw2.r *= 1.05
-        raw2.h *= 0.9
+        raw2.r *= 1.5
+        raw2.h *= -1.0
         c = model(GraphBatch.from_raw(raw2, device=DEV))
     assert rel_err(b, c) < 1e-6
-    assert rel_err(a, c) > 1e-4  # (the edit does change the prediction)
+    assert rel_err(a, c) > 1e-5  # (the edit does change the prediction)
 
 
 def test_eval_shortcut_never_drops_parameter_gradients():

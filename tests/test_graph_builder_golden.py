@@ -1,0 +1,75 @@
+"""kNN bond-graph builders against edge sets written by the REFERENCE's own builder (oracle/make_golden_graphs.py:
+``nearest_neighbor_edges`` + ``build_undirected_edgedata`` + ``canonize_edge``, alignn/graphs.py:128-264, imported
+unmodified) over the reference's 70 example structures (alignn/examples/sample_data/*.vasp).
+
+Index work => the bar is BIT-EXACT: the multiset of directed bonds (src, dst, periodic image) must be identical; the
+bond vectors (float32 in the reference) agree to rounding.  The order of the bonds is not compared: the reference's is
+Python dict-insertion order, ours is sorted by (min id, max id, image) - the model is invariant to it
+(tests/test_gpu_model.py::test_dgl_like_tuple_input_and_edge_order_invariance)."""
+
+import numpy as np
+import pytest
+import torch
+
+from alignn_amd import neighbors
+from alignn_amd.synthetic import knn_multigraph
+from tests.helpers import load_golden
+
+
+def _multiset(u, v, r, lat, frac):
+    """sorted list of (u, v, image) with the image of v measured from u, recovered from the bond vector"""
+    cart = frac @ lat
+    img = np.rint((np.asarray(r, np.float64) - (cart[v] - cart[u])) @ np.linalg.inv(lat)).astype(np.int64)
+    return sorted(zip(u.tolist(), v.tolist(), map(tuple, img.tolist())))
+
+
+def _golden_cases():
+    z = load_golden("graphs_sample_data.npz")
+    for i, name in enumerate(z["names"].tolist()):
+        lat, frac = z[f"{i}.lat"], z[f"{i}.frac"]
+        u, v, image = z[f"{i}.u"].astype(np.int64), z[f"{i}.v"].astype(np.int64), z[f"{i}.image"].astype(np.int64).copy()
+        image[1::2] *= -1  # the reference stores the forward image for both directions of a bond
+        ref = sorted(zip(u.tolist(), v.tolist(), map(tuple, image.tolist())))
+        yield name, lat, frac, ref, (u, v, z[f"{i}.r"])
+
+
+def _check(build, tol=2e-5):
+    n = 0
+    for name, lat, frac, ref, (gu, gv, gr) in _golden_cases():
+        u, v, r = build(lat, frac)
+        assert _multiset(u, v, r, lat, frac) == ref, name
+        assert np.array_equal(u[0::2], v[1::2]) and np.array_equal(v[0::2], u[1::2]), name  # consecutive direction pairs
+        # bond vectors: match every reference bond to ours through the (u, v, image) key
+        mine = {k: r[i] for i, k in enumerate(zip(u.tolist(), v.tolist(), map(tuple, np.rint(
+            (np.asarray(r, np.float64) - ((frac @ lat)[v] - (frac @ lat)[u])) @ np.linalg.inv(lat)).astype(np.int64).tolist())))}
+        for i, k in enumerate(ref_keys(gu, gv, gr, lat, frac)):
+            assert np.abs(mine[k] - gr[i]).max() < tol * max(1.0, np.abs(gr[i]).max()), (name, k)
+        n += 1
+    assert n == 70
+
+
+def ref_keys(u, v, r, lat, frac):
+    cart = frac @ lat
+    img = np.rint((np.asarray(r, np.float64) - (cart[v] - cart[u])) @ np.linalg.inv(lat)).astype(np.int64)
+    return list(zip(u.tolist(), v.tolist(), map(tuple, img.tolist())))
+
+
+def test_numpy_builder_reproduces_the_reference_edge_sets():
+    _check(lambda lat, frac: knn_multigraph(lat, frac))
+
+
+def test_torch_builder_reproduces_the_reference_edge_sets_cpu():
+    def build(lat, frac):
+        u, v, r = neighbors.knn_multigraph(torch.from_numpy(lat), torch.from_numpy(frac))
+        return u.numpy(), v.numpy(), r.numpy()
+
+    _check(build)
+
+
+@pytest.mark.gpu
+def test_device_builder_reproduces_the_reference_edge_sets():
+    def build(lat, frac):
+        u, v, r = neighbors.knn_multigraph(torch.from_numpy(lat), torch.from_numpy(frac), device="cuda")
+        return u.cpu().numpy(), v.cpu().numpy(), r.cpu().numpy()
+
+    _check(build)
