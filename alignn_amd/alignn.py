@@ -330,7 +330,7 @@ class ALIGNN(nn.Module):
     def forward(self, g: Union[Sequence, GraphBatch]):
         """``g`` = ``(g, lg, lat)`` of DGL-like graphs as in the reference (alignn.py:291-295), a bare
         graph when ``alignn_layers == 0``, or a prebuilt ``GraphBatch``.  Returns ``squeeze(out)``."""
-        with _lib.device_guard(self.fc.weight), _deferred_bumps():
+        with _lib.device_guard(self.fc.weight), _deferred_bumps(), ops.lanes(self.fc.weight.device):
             return self._forward(self._batch(g))
 
     def _forward(self, b: GraphBatch):

@@ -337,7 +337,8 @@ class ALIGNNAtomWise(nn.Module):
         if fused_forces:
             with ops.no_param_grad():
                 return self._forward_fused(b, True)
-        return self._forward_fused(b, False)
+        with ops.lanes(self.fc.weight.device):
+            return self._forward_fused(b, False)
 
     def _forward_fused(self, b: GraphBatch, fused_forces: bool):
         cfg = self.config

@@ -65,6 +65,8 @@ def _join_side_streams():
     _SIDE["armed"] = False
     for dev, side in _SIDE["streams"].items():
         torch.cuda.current_stream(dev).wait_stream(side)
+    for dev, lane in _LANE["streams"].items():
+        torch.cuda.current_stream(dev).wait_stream(lane)
 
 
 def _deferred_join_is_safe(params):
@@ -89,7 +91,7 @@ def _deferred_join_is_safe(params):
     return True
 
 
-def on_side_stream(fn, inputs, params=()):
+def on_side_stream(fn, inputs, params=(), wait=()):
     """Run ``fn()`` (kernel launches only) on the side stream; returns its tensors.  ``inputs`` are the tensors it
     reads (kept alive for the allocator until the side stream has consumed them); ``params`` the leaves whose
     gradients it computes - they decide whether the join may wait until the end of backward()
@@ -100,8 +102,11 @@ def on_side_stream(fn, inputs, params=()):
     main = torch.cuda.current_stream(dev)
     side = _SIDE["streams"].get(dev)
     if side is None:
-        side = _SIDE["streams"][dev] = torch.cuda.Stream(device=dev)
+        side = _SIDE["streams"][dev] = torch.cuda.Stream(device=dev, priority=int(_os.environ.get("ALIGNN_AMD_SIDE_PRIORITY", "0")))
     side.wait_stream(main)
+    for ev in wait:  # work of lane T that ``fn`` reads
+        if ev is not None:
+            side.wait_event(ev)
     with torch.cuda.stream(side):
         outs = fn()
     for t in inputs:
@@ -120,6 +125,139 @@ def on_side_stream(fn, inputs, params=()):
         except RuntimeError:  # not inside backward(): join right away
             _join_side_streams()
     return outs
+
+
+# ---------------------------------------------------------------------------------------------
+# two lanes: the triplet-row (line-graph edge) kernels on their own stream
+#
+# A training step is two interleaved chains.  The T-row chain (T = rows of the line graph's edge features, 676 k at the
+# benchmark batch) is a dozen HBM-bound kernels of 0.3-0.4 ms per line-graph convolution; the atom / bond chain (N and
+# E rows: the bond-graph convolutions, the node half of the line-graph convolutions, their projections and norms) is
+# ~400 launches of 5-100 us that are latency-bound and leave most of the chip idle.  The two meet only at a few points
+# per layer (the gate pass needs the node projection P; the node norm needs the gate pass' sums; in backward the
+# block kernel needs gS1 / gS0 and hands back GP), so inside ``lanes()`` the T-row kernels go to a second stream
+# ("lane T") and the small ones stay on the caller's stream, with events at exactly those meeting points.  Both
+# lanes are part of a hipGraph capture (fork / join by events).  The caller's stream joins lane T at the end of the
+# model forward and at the end of backward (same engine callback as the weight-gradient side stream), or right away
+# where a gradient computed on lane T could be read earlier (``_deferred_join_is_safe``).
+# ---------------------------------------------------------------------------------------------
+# ALIGNN_AMD_LANES: "auto" (default) = only while the step is being captured into a hipGraph - there the fork / join
+# events cost nothing at replay; eagerly launched steps are bound by the host's enqueue rate on most hosts and the extra
+# event / stream calls (+1-4 ms per step) cost more than the overlap returns (-0.5 ms) -, "1" = always, "0" = never.
+_LANE = {"enabled": _os.environ.get("ALIGNN_AMD_LANES", "auto"), "min_rows": 131072, "active": False,
+         "streams": {}, "main": None, "T": None, "priority": int(_os.environ.get("ALIGNN_AMD_LANE_PRIORITY", "0"))}
+_ON_T = {}  # id -> weakref: tensors whose producer kernel ran on lane T (consumers on lane T need no event)
+
+
+def _mark_on_T(t):
+    if t is not None:
+        k = id(t)
+        _ON_T[k] = weakref.ref(t, lambda _r, k=k: _ON_T.pop(k, None))
+    return t
+
+
+def _is_on_T(t):
+    e = _ON_T.get(id(t))
+    return e is not None and e() is t
+
+
+class lanes:
+    """``with ops.lanes(device):`` around a whole-model forward: T-row kernels of the convolutions / embeddings inside
+    run on lane T (see above).  Nesting and ``ALIGNN_AMD_LANES=0`` make it a no-op."""
+
+    def __init__(self, device):
+        dev = torch.device(device)
+        if dev.type == "cuda" and dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        self.dev = dev
+        self.on = False
+
+    def __enter__(self):
+        mode = _LANE["enabled"]
+        if mode in ("0", False) or _LANE["active"] or self.dev.type != "cuda":
+            return self
+        if mode == "auto" and not torch.cuda.is_current_stream_capturing():
+            return self
+        self.on = True
+        main = torch.cuda.current_stream(self.dev)
+        T = _LANE["streams"].get(self.dev)
+        if T is None:
+            T = _LANE["streams"][self.dev] = torch.cuda.Stream(device=self.dev, priority=_LANE["priority"])
+        _LANE.update(active=True, main=main, T=T)
+        new_amax_arena(self.dev)  # zero-filled on the caller's stream, before the fork
+        T.wait_stream(main)  # parameters (optimizer step), inputs, the arena
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            _LANE["main"].wait_stream(_LANE["T"])
+            _LANE["active"] = False
+        return False
+
+
+def _lane_for(rows, *tensors):
+    """-> (main, T) if a kernel over ``rows`` rows should go to lane T now, else None.  In backward the lanes context is
+    gone: the Function remembers (``ctx.lane``) and passes ``force=True`` through ``_lane_streams``."""
+    if _LANE["active"] and rows >= _LANE["min_rows"]:
+        return _LANE["main"], _LANE["T"]
+    return None
+
+
+def _lane_streams(dev):
+    """(main, T) for a backward node whose forward ran with lanes: main = the stream the engine runs the node on."""
+    main, T = torch.cuda.current_stream(dev), _LANE["streams"][dev]
+    _LANE.update(main=main, T=T)
+    return main, T
+
+
+def _event_after(stream):
+    ev = torch.cuda.Event()
+    ev.record(stream)
+    return ev
+
+
+class _on_T:
+    """Run the enclosed launches (and allocations) on lane T.  ``wait``: events lane T waits for first; tensors in
+    ``reads`` that were not produced on lane T make it wait for the main stream's current position instead."""
+
+    def __init__(self, main, T, wait=(), reads=()):
+        self.main, self.T, self.wait, self.reads = main, T, wait, reads
+
+    def __enter__(self):
+        if any(t is not None and not _is_on_T(t) for t in self.reads):
+            self.T.wait_event(_event_after(self.main))
+        for ev in self.wait:
+            if ev is not None:
+                self.T.wait_event(ev)
+        for t in self.reads:
+            if t is not None and not _is_on_T(t):
+                t.record_stream(self.T)
+        self.ctx = torch.cuda.stream(self.T)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        return self.ctx.__exit__(*exc)
+
+
+def _main_reads(*tensors):
+    """The caller's stream is about to read these: wait for lane T if one of them was produced there."""
+    if _ON_T and any(t is not None and _is_on_T(t) for t in tensors):
+        T = _LANE["T"]
+        cur = torch.cuda.current_stream(T.device)
+        cur.wait_event(_event_after(T))
+        for t in tensors:
+            if t is not None and _is_on_T(t):
+                t.record_stream(cur)  # (allocated in lane T's pool)
+
+
+def _arm_backward_join():
+    if not _SIDE["armed"]:
+        _SIDE["armed"] = True
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_join_side_streams)
+        except RuntimeError:  # not inside backward(): join right away
+            _join_side_streams()
 
 
 # ---------------------------------------------------------------------------------------------
@@ -170,13 +308,27 @@ def reset_amax_arena():
     _AMAX_ARENA["buf"] = None
 
 
+def new_amax_arena(device):
+    """Zero-fill a fresh arena.  With two lanes the fill goes to the main stream and lane T is made to wait for it, so
+    that whichever lane's kernel raises a slot first finds it zeroed."""
+    a = _AMAX_ARENA
+    main, T = _LANE["main"], _LANE["T"]
+    if main is not None and main.device == torch.device(device) and (_LANE["active"] or torch.cuda.current_stream(device) == T):
+        with torch.cuda.stream(main):
+            a["buf"] = torch.zeros(512, dtype=torch.float32, device=device)
+        a["buf"].record_stream(T)
+        T.wait_event(_event_after(main))
+    else:
+        a["buf"] = torch.zeros(512, dtype=torch.float32, device=device)
+    a["next"] = 0
+
+
 def new_amax(like):
-    """A zeroed device scalar for a producer kernel to atomicMax into: a slot of a 256-float arena, so a training
-    step pays one fill kernel instead of ~60."""
+    """A zeroed device scalar for a producer kernel to atomicMax into: a slot of a 512-float arena, so a training
+    step pays one or two fill kernels instead of ~60."""
     a = _AMAX_ARENA
     if a["buf"] is None or a["next"] >= a["buf"].numel() or a["buf"].device != like.device:
-        a["buf"] = torch.zeros(256, dtype=torch.float32, device=like.device)
-        a["next"] = 0
+        new_amax_arena(like.device)
     i = a["next"]
     a["next"] = i + 1
     return a["buf"][i:i + 1]
@@ -553,13 +705,12 @@ def linear(x, w, b=None):
 # MLPLayer = Linear + BatchNorm1d + SiLU   (alignn/models/alignn.py:170-184)
 # ---------------------------------------------------------------------------------------------
 class MLPLayerFn(torch.autograd.Function):
-    """``norm`` = "batch" (alignn/models/alignn.py:170-184) or "layer" (alignn/models/utils.py:277-292)."""
+    """``norm`` = "batch" (alignn/models/alignn.py:170-184) or "layer" (alignn/models/utils.py:277-292).  T-row layers
+    (the angle embedding) run on lane T inside ``lanes()``."""
 
     @staticmethod
-    def forward(ctx, x, w, b, gamma, beta, running_mean, running_var, training, norm="batch"):
+    def _fwd(ctx, x, w, b, gamma, beta, running_mean, running_var, training, norm):
         lib = _lib.load()
-        x = x.contiguous()
-        w = w.contiguous()
         ctx.x_amax = get_amax(x)
         pre = project(x, w, b, a_amax=ctx.x_amax)
         rows, F = pre.shape
@@ -574,6 +725,22 @@ class MLPLayerFn(torch.autograd.Function):
             else:
                 stat = _bn_finalize(None, 0, rows, gamma, beta, running_mean, running_var, False)
             y = _bn_silu_fwd(pre, None, stat)
+        return y, pre, stat
+
+    @staticmethod
+    def forward(ctx, x, w, b, gamma, beta, running_mean, running_var, training, norm="batch"):
+        x = x.contiguous()
+        w = w.contiguous()
+        lane = _lane_for(x.shape[0])
+        ctx.lane = lane is not None
+        ctx.x_on_T = _is_on_T(x)  # then x's producer is lane-aware and takes its gradient on lane T
+        if lane is not None:
+            with _on_T(*lane, reads=(x,)):
+                y, pre, stat = MLPLayerFn._fwd(ctx, x, w, b, gamma, beta, running_mean, running_var, training, norm)
+            _mark_on_T(y)
+        else:
+            _main_reads(x)
+            y, pre, stat = MLPLayerFn._fwd(ctx, x, w, b, gamma, beta, running_mean, running_var, training, norm)
         ctx.save_for_backward(x, w, pre, stat, gamma, beta)
         ctx.training = training
         ctx.norm = norm
@@ -582,9 +749,7 @@ class MLPLayerFn(torch.autograd.Function):
         return y
 
     @staticmethod
-    def backward(ctx, gy):
-        x, w, pre, stat, gamma, beta = ctx.saved_tensors
-        gy = gy.contiguous()
+    def _bwd(ctx, gy, x, w, pre, stat, gamma, beta):
         gpre = torch.empty_like(pre)
         g_amax = new_amax(pre) if _track(pre.shape[0]) else None
         if ctx.norm == "layer":
@@ -592,13 +757,38 @@ class MLPLayerFn(torch.autograd.Function):
         else:
             red = _bn_silu_bwd_reduce(gy, pre, stat)
             _bn_silu_bwd_apply(gy, pre, stat, gamma, red, not ctx.training, gpre, g_amax)
-        dbeta, dgamma = red[0], red[1]
         gx = _dgrad(gpre, w, g_amax=g_amax) if ctx.needs_input_grad[0] else None
+        return gpre, g_amax, red, gx
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, pre, stat, gamma, beta = ctx.saved_tensors
+        gy = gy.contiguous()
+        ev = None
+        if ctx.lane:
+            main, T = _lane_streams(gy.device)
+            with _on_T(main, T, reads=(gy,)):
+                gpre, g_amax, red, gx = MLPLayerFn._bwd(ctx, gy, x, w, pre, stat, gamma, beta)
+            ev = _event_after(T)
+            # dgamma / dbeta (``red``) come off lane T: same rule as the side-stream gradients; the input gradient stays
+            # on lane T only for a producer that is lane-aware itself
+            if (gx is None or ctx.x_on_T) and (not ctx.param_grads or _deferred_join_is_safe((gamma, beta))):
+                _arm_backward_join()
+                _mark_on_T(gx)
+            else:
+                main.wait_event(ev)
+                for t in (gx, red):
+                    if t is not None:
+                        t.record_stream(main)
+        else:
+            _main_reads(gy)
+            gpre, g_amax, red, gx = MLPLayerFn._bwd(ctx, gy, x, w, pre, stat, gamma, beta)
+        dbeta, dgamma = red[0], red[1]
         if not ctx.param_grads:
             return gx, None, None, None, None, None, None, None, None
         x_amax = ctx.x_amax
         gw, gb = on_side_stream(lambda: (gemm_tn(gpre, x, g_amax, x_amax), col_sum(gpre)), [gpre, x, g_amax, x_amax],
-                                ctx.wb)
+                                ctx.wb, wait=(ev,))
         return gx, gw, gb, dgamma, dbeta, None, None, None, None
 
 
@@ -613,6 +803,10 @@ class EdgeGatedConvFn(torch.autograd.Function):
     (no grad) that ALIAS the storage of the eight leaves ``w4`` / ``b4`` (EdgeGatedGraphConv keeps its four node
     projections in one fused buffer); the leaves are passed only so that autograd routes their gradients - four row
     blocks of one [4H,H] weight-gradient GEMM.
+
+    Inside ``lanes()`` a convolution with many edge rows (the line graph) splits over the two lanes: edge projection,
+    gate pass and edge norm on lane T, node projection and node norm on the caller's stream, meeting at the gate pass
+    (needs P) and after it (the node norm needs its sums); backward mirrors that around the block kernel.
     """
 
     @staticmethod
@@ -627,39 +821,68 @@ class EdgeGatedConvFn(torch.autograd.Function):
         m = y.shape[0]
         if n != graph.n_nodes or m != graph.n_edges:
             raise ValueError(f"feature rows ({n},{m}) do not match graph ({graph.n_nodes},{graph.n_edges})")
+        lane = _lane_for(m)
+        ctx.lane = lane is not None
+        ctx.y_on_T = _is_on_T(y)
         ctx.x_amax, ctx.y_amax = get_amax(x), get_amax(y)  # tracked by the kernels that produced x and y
-        P = project(x, wcat, bcat, a_amax=ctx.x_amax)  # [n,4H] = A | Bd | Bh | Ux
-        M = project(y, w_eg, b_eg, a_amax=ctx.y_amax)  # [m,H]  -> m_pre in place
+        bn_train = training and norm == "batch"
+        slabs = lib.alignn_egc_slabs(n)
+        _main_reads(x, None if lane is not None else y)
+        # ---- node side, part 1 (caller's stream): P = [A | Bd | Bh | Ux]
+        P = project(x, wcat, bcat, a_amax=ctx.x_amax)  # [n,4H]
         xpre = _empty(n, H, like=x)
         s0 = _empty(n, H, like=x)
         hh = _empty(n, H, like=x)
-        slabs = lib.alignn_egc_slabs(n)
-        bn_train = training and norm == "batch"
-        e_part = _empty(slabs, 2, H, like=x) if bn_train else None
         n_part = _empty(slabs, 2, H, like=x) if bn_train else None
-        check(
-            lib.alignn_egc_gate_fwd(ptr(P), ptr(M), ptr(graph.seg_ptr), ptr(graph.seg_node), ptr(graph.src), n, m, H,
-                                    ptr(xpre), ptr(s0), ptr(hh), ptr(e_part), ptr(n_part), stream()),
-            "egc_gate_fwd",
-        )
-        if norm == "layer":
-            # LayerNorm flavour (alignn_atomwise.py:151,155): per-row statistics, no global barrier
-            x_out, n_stat = _ln_silu_fwd(xpre, x if residual else None, n_gamma, n_beta)
-            if need_y:
-                y_out, e_stat = _ln_silu_fwd(M, y if residual else None, e_gamma, e_beta)
-            else:
-                y_out, e_stat = None, _empty(1, 2, like=x)
-        else:
-            if training:
-                n_stat = _bn_finalize(n_part, slabs, n, n_gamma, n_beta, n_rm, n_rv, True)
-                e_stat = _bn_finalize(e_part, slabs, m, e_gamma, e_beta, e_rm, e_rv, True)
-            else:
-                n_stat = _bn_finalize(None, 0, n, n_gamma, n_beta, n_rm, n_rv, False)
-                e_stat = _bn_finalize(None, 0, m, e_gamma, e_beta, e_rm, e_rv, False)
-            x_out = _bn_silu_fwd(xpre, x if residual else None, n_stat)
+
+        def edge_side():
+            M = project(y, w_eg, b_eg, a_amax=ctx.y_amax)  # [m,H]  -> m_pre in place
+            e_part = _empty(slabs, 2, H, like=x) if bn_train else None
+            return M, e_part
+
+        def gate(M, e_part):
+            check(
+                lib.alignn_egc_gate_fwd(ptr(P), ptr(M), ptr(graph.seg_ptr), ptr(graph.seg_node), ptr(graph.src), n, m, H,
+                                        ptr(xpre), ptr(s0), ptr(hh), ptr(e_part), ptr(n_part), stream()),
+                "egc_gate_fwd",
+            )
+
+        def edge_norm(M, e_part):
+            if norm == "layer":  # LayerNorm flavour (alignn_atomwise.py:151,155): per-row statistics, no global barrier
+                if need_y:
+                    return _ln_silu_fwd(M, y if residual else None, e_gamma, e_beta)
+                return None, _empty(1, 2, like=x)
+            e_stat = (_bn_finalize(e_part, slabs, m, e_gamma, e_beta, e_rm, e_rv, True) if training
+                      else _bn_finalize(None, 0, m, e_gamma, e_beta, e_rm, e_rv, False))
             # need_y == False: the caller discards the edge output (last layer) - skip the pass, keep the
             # statistics side effect (running_mean/var of bn_edges are updated exactly as in the reference)
-            y_out = _bn_silu_fwd(M, y if residual else None, e_stat) if need_y else None
+            return (_bn_silu_fwd(M, y if residual else None, e_stat) if need_y else None), e_stat
+
+        if lane is not None:
+            main, T = lane
+            ev_p = _event_after(main)
+            for t in (P, xpre, s0, hh, n_part):
+                if t is not None:
+                    t.record_stream(T)
+            with _on_T(main, T, reads=(y,)):
+                M, e_part = edge_side()
+                T.wait_event(ev_p)
+                gate(M, e_part)
+                ev_g = _event_after(T)
+                y_out, e_stat = edge_norm(M, e_part)
+            _mark_on_T(y_out)
+            main.wait_event(ev_g)
+        else:
+            M, e_part = edge_side()
+            gate(M, e_part)
+            y_out, e_stat = edge_norm(M, e_part)
+        # ---- node side, part 2 (caller's stream)
+        if norm == "layer":
+            x_out, n_stat = _ln_silu_fwd(xpre, x if residual else None, n_gamma, n_beta)
+        else:
+            n_stat = (_bn_finalize(n_part, slabs, n, n_gamma, n_beta, n_rm, n_rv, True) if training
+                      else _bn_finalize(None, 0, n, n_gamma, n_beta, n_rm, n_rv, False))
+            x_out = _bn_silu_fwd(xpre, x if residual else None, n_stat)
         ctx.graph = graph
         ctx.training = training
         ctx.residual = residual
@@ -680,13 +903,14 @@ class EdgeGatedConvFn(torch.autograd.Function):
         layer = ctx.norm == "layer"
         if gx_out is None:
             gx_out = torch.zeros_like(x)
+        _main_reads(gx_out, None if ctx.lane else gy_out)
         gx_out = gx_out.contiguous()
         GP = _empty(n, 4 * H, like=x)
         # max|GP| (all four blocks: every kernel that writes a block raises the same scalar) and max|GM|, so that
         # the input- and weight-gradient projections below can run the three-product scheme
         gp_amax = new_amax(x) if _track(n) else None
         gm_amax = new_amax(x) if _track(m) else None
-        # node branch: SiLU/norm backward -> g_xpre (stored as the Ux block of GP)
+        # ---- node branch (caller's stream): SiLU/norm backward -> g_xpre (stored as the Ux block of GP)
         g_xpre = GP[:, 3 * H:]
         if layer:
             n_red = _ln_silu_bwd(gx_out, xpre, n_gamma, n_beta, n_stat, g_xpre, gp_amax)
@@ -697,58 +921,97 @@ class EdgeGatedConvFn(torch.autograd.Function):
         gs0 = _empty(n, H, like=x)
         check(lib.alignn_egc_node_bwd(ptr(g_xpre), 4 * H, ptr(s0), ptr(hh), ptr(gs1), ptr(gs0), n, H, stream()),
               "egc_node_bwd")
-        # edge branch
-        e_red = None
-        g_branch, e_stat_arg = gy_out, e_stat
         if gy_out is not None:
             gy_out = gy_out.contiguous()
-            if layer:
-                # LayerNorm: finish the normalised-branch gradient here, hand it over as-is (e_stat = NULL)
-                g_branch = _empty(m, H, like=x)
-                e_red = _ln_silu_bwd(gy_out, M, e_gamma, e_beta, e_stat, g_branch)
-                e_stat_arg = None
+        lg_blocks = graph.grp_seg_ptr is not None and FUSED_LG_BACKWARD
+        dense = lg_blocks and DENSE_LG_BACKWARD and lib.alignn_egc_bwd_lg_dense_supported(graph.dense_max_src)
+
+        def edge_branch():
+            """norm backward of the edge output, then the gate backward: writes GM [m,H], the A | Bd | Bh blocks of GP and
+            the column-sum slabs of GM.  Everything here touches T rows."""
+            e_red = None
+            g_branch, e_stat_arg = gy_out, e_stat
+            if gy_out is not None:
+                if layer:
+                    # LayerNorm: finish the normalised-branch gradient here, hand it over as-is (e_stat = NULL)
+                    g_branch = _empty(m, H, like=x)
+                    e_red = _ln_silu_bwd(gy_out, M, e_gamma, e_beta, e_stat, g_branch)
+                    e_stat_arg = None
+                else:
+                    e_red = _bn_silu_bwd_reduce(gy_out, M, e_stat)
+            return e_red, g_branch, e_stat_arg
+
+        def gate_backward(e_red, g_branch, e_stat_arg):
+            GM = _empty(m, H, like=x)
+            if dense:
+                # line graph with dense, source-sorted blocks: one pass, rows addressed by index arithmetic
+                gslabs = graph.grp_seg_ptr.numel() - 1
+                gb_part = _empty(gslabs, H, like=x)
+                check(
+                    lib.alignn_egc_bwd_lg_dense(ptr(g_branch), ptr(M), ptr(P), ptr(gs1), ptr(gs0), ptr(e_stat_arg),
+                                                ptr(e_red), int(ev), m, ptr(graph.grp_seg_ptr), ptr(graph.grp_src_ptr),
+                                                gslabs, graph.dense_max_src, ptr(graph.seg_ptr), ptr(graph.seg_node), H,
+                                                ptr(GM), ptr(GP), ptr(gb_part), ptr(gm_amax), ptr(gp_amax), stream()),
+                    "egc_bwd_lg_dense",
+                )
+            elif lg_blocks:
+                # line graph: destination- and source-ordered passes in one kernel, one workgroup per centre atom
+                gslabs = graph.grp_seg_ptr.numel() - 1
+                gb_part = _empty(gslabs, H, like=x)
+                check(
+                    lib.alignn_egc_bwd_lg_fused(ptr(g_branch), ptr(M), ptr(P), ptr(gs1), ptr(gs0), ptr(e_stat_arg),
+                                                ptr(e_red), int(ev), m, ptr(graph.grp_seg_ptr), ptr(graph.grp_src_ptr),
+                                                gslabs, ptr(graph.seg_ptr), ptr(graph.seg_node), ptr(graph.dst),
+                                                ptr(graph.out_ptr), ptr(graph.out_slot), H, ptr(GM), ptr(GP), ptr(gb_part),
+                                                ptr(gm_amax), ptr(gp_amax), stream()),
+                    "egc_bwd_lg_fused",
+                )
             else:
-                g_branch = gy_out
-                e_red = _bn_silu_bwd_reduce(gy_out, M, e_stat)
-        GM = _empty(m, H, like=x)
-        if (graph.grp_seg_ptr is not None and FUSED_LG_BACKWARD and DENSE_LG_BACKWARD
-                and lib.alignn_egc_bwd_lg_dense_supported(graph.dense_max_src)):
-            # line graph with dense, source-sorted blocks: one pass, rows addressed by index arithmetic
-            gslabs = graph.grp_seg_ptr.numel() - 1
-            gb_part = _empty(gslabs, H, like=x)
-            check(
-                lib.alignn_egc_bwd_lg_dense(ptr(g_branch), ptr(M), ptr(P), ptr(gs1), ptr(gs0), ptr(e_stat_arg),
-                                            ptr(e_red), int(ev), m, ptr(graph.grp_seg_ptr), ptr(graph.grp_src_ptr),
-                                            gslabs, graph.dense_max_src, ptr(graph.seg_ptr), ptr(graph.seg_node), H,
-                                            ptr(GM), ptr(GP), ptr(gb_part), ptr(gm_amax), ptr(gp_amax), stream()),
-                "egc_bwd_lg_dense",
-            )
-        elif graph.grp_seg_ptr is not None and FUSED_LG_BACKWARD:
-            # line graph: destination- and source-ordered passes in one kernel, one workgroup per centre atom
-            gslabs = graph.grp_seg_ptr.numel() - 1
-            gb_part = _empty(gslabs, H, like=x)
-            check(
-                lib.alignn_egc_bwd_lg_fused(ptr(g_branch), ptr(M), ptr(P), ptr(gs1), ptr(gs0), ptr(e_stat_arg),
-                                            ptr(e_red), int(ev), m, ptr(graph.grp_seg_ptr), ptr(graph.grp_src_ptr),
-                                            gslabs, ptr(graph.seg_ptr), ptr(graph.seg_node), ptr(graph.dst),
-                                            ptr(graph.out_ptr), ptr(graph.out_slot), H, ptr(GM), ptr(GP), ptr(gb_part),
-                                            ptr(gm_amax), ptr(gp_amax), stream()),
-                "egc_bwd_lg_fused",
-            )
+                gslabs = lib.alignn_egc_slabs(n)
+                gb_part = _empty(gslabs, H, like=x)
+                check(
+                    lib.alignn_egc_bwd_dst(ptr(g_branch), ptr(M), ptr(P), ptr(gs1), ptr(gs0), ptr(e_stat_arg), ptr(e_gamma),
+                                           ptr(e_red), int(ev), m, ptr(graph.seg_ptr), ptr(graph.seg_node), ptr(graph.src),
+                                           n, H, ptr(GM), ptr(GP), ptr(gb_part), ptr(gm_amax), ptr(gp_amax), stream()),
+                    "egc_bwd_dst",
+                )
+                check(
+                    lib.alignn_egc_bwd_src(ptr(GM), ptr(M), ptr(gs1), ptr(graph.out_ptr), ptr(graph.out_slot),
+                                           ptr(graph.dst), n, H, ptr(GP), ptr(gp_amax), stream()),
+                    "egc_bwd_src",
+                )
+            return GM, gb_part, gslabs
+
+        def edge_dgrad(GM):
+            return _dgrad(GM, w_eg, addend=gy_out if (ctx.residual and gy_out is not None) else None, g_amax=gm_amax)
+
+        ev_d = None
+        if ctx.lane:
+            main, T = _lane_streams(x.device)
+            ev_n = _event_after(main)  # gs1, gs0, the Ux block of GP and its amax are ready
+            for t in (GP, gs1, gs0, gp_amax, gm_amax, P):
+                if t is not None:
+                    t.record_stream(T)
+            with _on_T(main, T, reads=(gy_out,)):
+                e_red, g_branch, e_stat_arg = edge_branch()  # (independent of the node branch: no wait yet)
+                T.wait_event(ev_n)
+                GM, gb_part, gslabs = gate_backward(e_red, g_branch, e_stat_arg)
+                ev_d = _event_after(T)
+                g_y = edge_dgrad(GM)
+            main.wait_event(ev_d)  # GP complete: the node input gradient below reads it
+            # de_gamma / de_beta (e_red) and g_y come off lane T: they may stay there if y's producer takes its gradient
+            # on lane T itself and nothing reads the two norm gradients before the end-of-backward join
+            if ctx.y_on_T and (not ctx.param_grads or _deferred_join_is_safe((e_gamma, e_beta))):
+                _arm_backward_join()
+                _mark_on_T(g_y)
+            else:
+                main.wait_stream(T)
+                for t in (g_y, e_red):
+                    if t is not None:
+                        t.record_stream(main)
         else:
-            gslabs = lib.alignn_egc_slabs(n)
-            gb_part = _empty(gslabs, H, like=x)
-            check(
-                lib.alignn_egc_bwd_dst(ptr(g_branch), ptr(M), ptr(P), ptr(gs1), ptr(gs0), ptr(e_stat_arg), ptr(e_gamma),
-                                       ptr(e_red), int(ev), m, ptr(graph.seg_ptr), ptr(graph.seg_node), ptr(graph.src),
-                                       n, H, ptr(GM), ptr(GP), ptr(gb_part), ptr(gm_amax), ptr(gp_amax), stream()),
-                "egc_bwd_dst",
-            )
-            check(
-                lib.alignn_egc_bwd_src(ptr(GM), ptr(M), ptr(gs1), ptr(graph.out_ptr), ptr(graph.out_slot),
-                                       ptr(graph.dst), n, H, ptr(GP), ptr(gp_amax), stream()),
-                "egc_bwd_src",
-            )
+            e_red, g_branch, e_stat_arg = edge_branch()
+            GM, gb_part, gslabs = gate_backward(e_red, g_branch, e_stat_arg)
         # projections: weight gradients on the side stream, input gradients (critical path) on the main one
         def _wgrads():
             g_beg_ = _empty(H, like=x)  # column sum of GM, accumulated inside the destination-order pass
@@ -761,11 +1024,12 @@ class EdgeGatedConvFn(torch.autograd.Function):
         # the input-gradient GEMMs first, so the weight-gradient GEMMs (LDS-heavy, cannot share a CU with the x6
         # tiles) run beside the NEXT layer's HBM-bound kernels instead of fighting these GEMMs for whole CUs.
         g_x = _dgrad(GP, wcat, addend=gx_out if ctx.residual else None, g_amax=gp_amax)
-        g_y = _dgrad(GM, w_eg, addend=gy_out if (ctx.residual and gy_out is not None) else None, g_amax=gm_amax)
+        if not ctx.lane:
+            g_y = edge_dgrad(GM)
         if not ctx.param_grads:
             return (None, g_x, g_y) + (None,) * 24
         g_weg, g_beg, g_wcat, g_bcat = on_side_stream(_wgrads, [GM, y, GP, x, gb_part, gm_amax, gp_amax, x_amax, y_amax],
-                                                      ctx.leaves)
+                                                      ctx.leaves, wait=(ev_d,))
         dn_gamma, dn_beta = n_red[1], n_red[0]
         de_gamma = e_red[1] if e_red is not None else None
         de_beta = e_red[0] if e_red is not None else None

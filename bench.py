@@ -244,6 +244,12 @@ def main():
             opt.step()
             return loss
 
+    main_prio = os.environ.get("ALIGNN_BENCH_MAIN_PRIORITY")
+    run_stream = torch.cuda.Stream(device=dev, priority=int(main_prio)) if main_prio is not None else None
+    if run_stream is not None:  # experiment: the whole step on a stream of the given priority (lane T / side keep theirs)
+        log(f"priority range {torch.cuda.Stream.priority_range()}, steps run on a priority-{main_prio} stream")
+        run_stream.wait_stream(torch.cuda.current_stream(dev))
+        torch.cuda.set_stream(run_stream)
     log(f"rank {rank}: batch N={raw.num_nodes} E={raw.num_edges} T={raw.num_triplets}; warmup")
     for _ in range(args.warmup):
         step()
@@ -274,7 +280,8 @@ def main():
                 p_.grad = None
             ops.reset_amax_arena()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):  # (RCCL's watchdog thread polls events)
+            gkw = {} if run_stream is None else {"stream": torch.cuda.Stream(device=dev, priority=int(main_prio))}
+            with torch.cuda.graph(graph, capture_error_mode="thread_local", **gkw):  # (RCCL's watchdog thread polls events)
                 g_loss = torch.nn.functional.l1_loss(predict(batch), target)
                 g_loss.backward()
             ops.reset_amax_arena()

@@ -79,6 +79,23 @@ def case_alignn(tag, raw, seed):
     for k, v in model.state_dict().items():
         if "running" in k:
             out["sd_after." + k] = v.numpy().copy()
+    # the same forward in float64 (no autograd: train-mode BatchNorm statistics and the prediction only): separates our
+    # rounding from the reference's own float32 rounding - its BatchNorm sums 676 k rows per feature in float32
+    m64 = ALIGNN(ALIGNNConfig(name="alignn")).double()
+    m64.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in
+                         perturbed_norm_state_dict(init_state_dict(seed=seed), seed=seed + 1).items()})
+    m64.train()
+    g64, lg64, lat64 = to_dgl(raw)
+    for d in (g64.ndata, g64.edata, lg64.edata):
+        for k in list(d.keys()):
+            if d[k].is_floating_point():
+                d[k] = d[k].double()
+    with torch.no_grad():
+        out["pred64"] = m64((g64, lg64, lat64.double())).numpy()
+    for k, v in m64.state_dict().items():
+        if "running" in k:
+            out["sd_after64." + k] = v.numpy().copy()
+    del m64
     np.savez_compressed(os.path.join(OUT, f"full_{tag}.npz"), **out)
     print(f"{tag}: N={raw.num_nodes} E={raw.num_edges} T={raw.num_triplets} loss {loss.item():.6f} "
           f"pred[:3] {pred.detach().numpy()[:3]} ({time.time() - t0:.0f} s)", flush=True)

@@ -169,15 +169,25 @@ def test_alignn_training_step_at_baseline_size_vs_reference_class(tag, mk):
         assert abs(loss.item() - float(z["loss"])) < 1e-4 * max(1.0, abs(float(z["loss"])))
         assert _check_acts(acts, z, batch, report) >= 20
         assert _check_grads(model, z, 1e-3, report) > 80
+        # BatchNorm running statistics after the step.  The reference (float32 torch-CPU) sums up to 676 k rows per feature
+        # in float32, so its own statistics carry ~1e-4 of rounding; the goldens therefore also hold the same forward
+        # evaluated by the reference class in float64 (train-mode statistics + prediction): we assert against THAT and
+        # report the float32 reference's distance from it beside ours.
         sd = model.state_dict()
-        worst = 0.0
-        for k, v in z.items():
-            if k.startswith("sd_after."):
-                mine = sd[k[9:]].cpu().numpy()
-                e = elementwise(mine, v, 1e-3 * max(np.abs(v).mean(), 1e-3))
-                worst = max(worst, e)
-                assert e < 1e-3, (k, e)
-        report.append(f"running statistics: worst elementwise {worst:.2e}")
+        w64 = w32 = r32 = 0.0
+        for k, v64 in z.items():
+            if k.startswith("sd_after64."):
+                name = k[len("sd_after64."):]
+                mine, v32 = sd[name].cpu().numpy(), z["sd_after." + name]
+                e64, e32, ref32 = normwise(mine, v64), normwise(mine, v32), normwise(v32, v64)
+                w64, w32, r32 = max(w64, e64), max(w32, e32), max(r32, ref32)
+                assert e64 < 1e-4, (k, e64)
+                assert e32 < 1e-3, (k, e32)
+        report.append(f"running statistics (normwise): ours vs float64 reference {w64:.2e}, ours vs float32 reference {w32:.2e}, "
+                      f"float32 reference vs float64 reference {r32:.2e}")
+        e64 = normwise(p, z["pred64"])
+        report.append(f"pred vs float64 reference: ours {e64:.2e}, float32 reference {normwise(pr, z['pred64']):.2e}")
+        assert e64 < 1e-4
     finally:
         _emit(tag, report)
 

@@ -238,3 +238,83 @@ def test_golden_atomwise_cutoff_and_penalty_branches(tag):
         assert rel_err(ev["out"], z[f"{tag}.pred"]) < 1e-4
         assert rel_err(ev["grad"], z[f"{tag}.forces"]) < 2e-4
         assert rel_err(ev["stresses"], z[f"{tag}.stresses"]) < 2e-4
+
+
+# ---------------------------------------------------------------------------------------------
+# two lanes (T-row kernels on their own stream): same bits as one stream, eager and captured
+# ---------------------------------------------------------------------------------------------
+def _train_step_state(lanes_on, min_rows, mk_model, batch, target, steps=2):
+    prev = (ops._LANE["enabled"], ops._LANE["min_rows"])
+    ops._LANE["enabled"], ops._LANE["min_rows"] = ("1" if lanes_on else "0"), min_rows
+    try:
+        model = mk_model()
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, fused=True)
+        for _ in range(steps):
+            opt.zero_grad(set_to_none=True)
+            pred = model(batch)
+            torch.nn.functional.l1_loss(pred, target).backward()
+            opt.step()
+        torch.cuda.synchronize()
+        out = {"pred": pred.detach().clone()}
+        out.update({"g." + k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+        out.update({"s." + k: v.clone() for k, v in model.state_dict().items()})
+        return out
+    finally:
+        ops._LANE["enabled"], ops._LANE["min_rows"] = prev
+
+
+@pytest.mark.parametrize("case", ["default_config_16x60", "every_kernel_on_a_lane"])
+def test_two_lanes_give_the_same_bits_as_one_stream(case):
+    if case == "default_config_16x60":  # T ~ 169 k rows: the production split (line-graph rows on lane T)
+        raw, min_rows = make_batch(16, 60, seed0=77), 131072
+
+        def mk():
+            torch.manual_seed(0)
+            return ALIGNN(ALIGNNConfig(name="alignn")).to(DEV).train()
+    else:  # stress: threshold 1 -> every convolution and embedding layer takes the lane code path
+        raw, min_rows = make_batch(5, 16, seed0=78), 1
+
+        def mk():
+            return _small_model(21)
+    batch = GraphBatch.from_raw(raw, device=DEV)
+    target = torch.randn(raw.batch_size, generator=torch.Generator().manual_seed(2)).to(DEV)
+    for trial in range(3):  # (a race would show up as run-to-run noise)
+        a = _train_step_state(True, min_rows, mk, batch, target)
+        b = _train_step_state(False, min_rows, mk, batch, target)
+        assert a.keys() == b.keys()
+        for k in a:
+            assert torch.equal(a[k], b[k]), (case, trial, k)
+
+
+def test_two_lanes_inside_a_hipgraph_capture():
+    from alignn_amd.graphed import GraphedTrainStep
+
+    prev = ops._LANE["min_rows"]
+    ops._LANE["min_rows"] = 1  # small batch, but every layer forks to lane T inside the capture ("auto": capture only)
+    assert ops._LANE["enabled"] == "auto"
+    try:
+        raw = make_batch(4, 20, seed0=3)
+        batch = GraphBatch.from_raw(raw, device=DEV)
+        target = torch.tensor([0.2, -0.1, 0.7, 0.0], device=DEV)
+
+        def fresh():
+            m = _small_model(0)
+            return m, torch.optim.AdamW(m.parameters(), lr=1e-3, fused=True, capturable=True)
+
+        m, o = fresh()
+        eager = []
+        for _ in range(6):
+            o.zero_grad(set_to_none=True)
+            loss = torch.nn.functional.l1_loss(m(batch), target)
+            loss.backward()
+            o.step()
+            eager.append(loss.detach().clone())
+        m2, o2 = fresh()
+        step = GraphedTrainStep(m2, batch, target, o2, warmup=3)
+        graphed = [step().detach().clone() for _ in range(3)]
+        for a, b in zip(eager[3:], graphed):
+            assert torch.equal(a, b)
+        for (k, p), (_, q) in zip(m.named_parameters(), m2.named_parameters()):
+            assert torch.equal(p, q), k
+    finally:
+        ops._LANE["min_rows"] = prev
