@@ -76,6 +76,7 @@ struct Geo {
     static constexpr int A_DMA = A_BYTES / 1024 / (NT / 64);  // 1 KiB DMA pieces per wave
 };
 constexpr int EPI_BYTES = (NT / 64) * 32 * (64 + 4) * 4; // per-wave [32][68] fp32 transpose patches
+constexpr int EPI1_LDS = EPI_BYTES + (NT / 64) * 2 * 2 * 256 * 4;  // ... + the EPI == 1 column-sum slots of every lane (50 KiB)
 // per scheme: slice planes of the weight image (3 bf16 / 2 fp16), stage and LDS footprint
 template <bool F16, int RM_ = 2>
 struct Sch {
@@ -119,6 +120,11 @@ struct X6Args {
     int Npad;
     int K;
     int stream_out;  // C cannot stay in the last-level cache: write-once hint on its stores
+    // EPI == 1 (BatchNorm-backward reductions of the tensor this product's OUTPUT is the gradient of, see the kernel):
+    const float* xn;     // [M, N] pre-activation of that BatchNorm (m_pre of the producing convolution / MLP layer)
+    int64_t ldxn;
+    const float* nstat;  // [4][N]: mean, rstd, gamma*rstd, beta
+    float* red_partial;  // [row tiles][2][N]: per-tile column sums of gz and gz*xhat
 };
 
 __device__ __forceinline__ unsigned hi_pair(float x1, float x0) {
@@ -214,8 +220,16 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned char* lds_wave_
 // ABL_CHECK=1, T x 256 x 256), but it measured no faster (374 vs 378 us, interleaved rounds): the second k-step's
 // vmcnt(0) still meets the stores one step later.  Kept as the base for a deeper walk (three stages: two prefetched
 // ahead of the stores) - see DESIGN.md section 8.
-template <bool HAS_ADD, bool F16, int RM_, bool PERSIST = false>
+// EPI == 1: the output C is a gradient g_y = dL/dy of a tensor y = r + silu(BatchNorm(xn)) (the edge output of the previous
+// line-graph convolution, or an MLPLayer output without r).  BatchNorm's backward needs the column sums
+// sum_rows gz and sum_rows gz*xhat (gz = g_y * silu'(z)) over ALL rows before anything else can happen - a separate
+// 2-row-pass kernel (col_reduce<BwdReduceFn>) when done on its own.  Here the tile that has just been computed is still
+// in registers: read the matching xn tile (one row pass instead of two), form gz and accumulate the two sums per
+// column in a fixed order (lane -> the 4 row groups of a wave by shuffles -> the 2 wave rows through LDS); one [2][N]
+// slab per row tile, summed afterwards by alignn_bn_bwd_finalize (fp64, fixed order): bit-reproducible.
+template <bool HAS_ADD, bool F16, int RM_, bool PERSIST = false, int EPI = 0>
 __global__ __launch_bounds__(NT) void gemm_nt_x6_kernel(X6Args g) {
+    static_assert(EPI == 0 || !PERSIST, "the reduction epilogue exists for the one-tile kernel only");
     constexpr int NPL = Sch<F16, RM_>::NPL, STAGE_BYTES = Sch<F16, RM_>::STAGE, B_DMA = Sch<F16, RM_>::B_DMA;
     constexpr int RM = Geo<RM_>::RM, BM = Geo<RM_>::BM, TM = Geo<RM_>::TM, A_BYTES = Geo<RM_>::A_BYTES,
                   A_DMA = Geo<RM_>::A_DMA;
@@ -408,6 +422,9 @@ __global__ __launch_bounds__(NT) void gemm_nt_x6_kernel(X6Args g) {
     }
     constexpr int PLD = 64 + 4;
     float* patch = reinterpret_cast<float*>(smem + (PERSIST ? STAGE_BYTES : 0)) + wave * (32 * PLD);
+    // EPI == 1: every lane's running column sums (4 columns x its rows, per 64-column half), behind the transpose patches
+    float* red_acc = reinterpret_cast<float*>(smem + EPI_BYTES);
+    static_assert(EPI_BYTES + (NT / 64) * (RN / 2) * 2 * 256 * 4 == EPI1_LDS, "LDS for the reduction slots (see launch_nt_rm)");
     const int prow = e_prow, pc4 = e_pc4;
 #if X6_ABL_NOSTORE == 2
     if (acc[0][0][0] == 12345.678f)  // (keeps the accumulators alive)
@@ -429,7 +446,10 @@ __global__ __launch_bounds__(NT) void gemm_nt_x6_kernel(X6Args g) {
             for (int r = 0; r < 16; ++r)
                 patch[((r & 3) + 8 * (r >> 2) + 4 * half) * PLD + b * 32 + il] = acc[a][2 * hb + b][r];
         if constexpr (!PERSIST) __syncthreads();
-        float4 ov[8], av[8];
+        const int col = n0 + wn * TN + hb * 64 + pc4;
+        const int colc = col < g.N ? col : 0;
+        const int64_t row0 = m0 + wm * TM + a * 32 + prow;
+        float4 ov[EPI == 1 ? 1 : 8], av[8], xv[EPI == 1 ? 8 : 1];
         if constexpr (PERSIST) {
             // read the patch behind the compiler's back: it would put s_waitcnt vmcnt(0) in front of LDS reads that
             // it cannot tell apart from the destination of the DMA prefetch in flight
@@ -446,15 +466,14 @@ __global__ __launch_bounds__(NT) void gemm_nt_x6_kernel(X6Args g) {
                          :
                          : "memory");
 #pragma unroll
-            for (int i = 0; i < 8; ++i) ov[i] = make_float4(pv[i].x, pv[i].y, pv[i].z, pv[i].w);
-        } else {
+            for (int i = 0; i < 8; ++i) ov[EPI == 1 ? 0 : i] = make_float4(pv[i].x, pv[i].y, pv[i].z, pv[i].w);
+        } else if constexpr (EPI != 1) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) ov[i] = f4_ld(patch + (i * 4 + prow) * PLD + pc4);
         }
-        const int col = n0 + wn * TN + hb * 64 + pc4;
-        const int64_t row0 = m0 + wm * TM + a * 32 + prow;
+        // all global loads of the round are issued before its first store (vmcnt retires in order and counts stores: a
+        // load behind a store would make its consumer wait for that store)
         if (HAS_ADD) {
-            const int colc = col < g.N ? col : 0;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 int64_t row = row0 + i * 4;
@@ -462,10 +481,22 @@ __global__ __launch_bounds__(NT) void gemm_nt_x6_kernel(X6Args g) {
                 av[i] = f4_ld(g.addend + row * g.ldadd + colc);
             }
         }
+        float4 n_mean, n_sc, n_be, s0, s1;
+        if constexpr (EPI == 1) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                int64_t row = row0 + i * 4;
+                if (row >= g.M) row = g.M - 1;
+                xv[i] = f4_lds<true>(g.xn + row * g.ldxn + colc);
+            }
+            n_mean = f4_ld(g.nstat + colc), n_sc = f4_ld(g.nstat + 2 * g.N + colc), n_be = f4_ld(g.nstat + 3 * g.N + colc);
+            s0 = s1 = f4_zero();
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int64_t row = row0 + i * 4;
-            float4 v = ov[i];
+            if constexpr (EPI == 1) ov[0] = f4_ld(patch + (i * 4 + prow) * PLD + pc4);  // (LDS: just in time, 4 registers)
+            float4 v = ov[EPI == 1 ? 0 : i];
             if constexpr (F16) v = f4_scale(f4_scale(v, inv_sa), inv_sw);
             v = f4_add(v, bias_v[hb]);
             if (HAS_ADD) v = f4_add(v, av[i]);
@@ -474,6 +505,47 @@ __global__ __launch_bounds__(NT) void gemm_nt_x6_kernel(X6Args g) {
                     f4_sts<true>(g.C + row * g.ldc + col, v);
                 else
                     f4_st(g.C + row * g.ldc + col, v);
+                if constexpr (EPI == 1) {
+                    const float4 xc = f4_sub(xv[i], n_mean);
+                    const float4 z = f4_fma(xc, n_sc, n_be);
+                    const float4 gz = make_float4(v.x * dsilu_f(z.x), v.y * dsilu_f(z.y), v.z * dsilu_f(z.z), v.w * dsilu_f(z.w));
+                    s0 = f4_add(s0, gz);
+                    s1 = f4_fma(gz, xc, s1);  // (x rstd once, at the end)
+                }
+            }
+        }
+        if constexpr (EPI == 1) {
+            // the lane's running column sums live in LDS between rounds (registers: two waves per SIMD is the budget)
+            float* acc_sh = red_acc + ((wave * (RN / 2) + hb) * 2) * 256 + lane * 4;  // [wave][half][2][64 lanes][4]
+            if (a != 0) {
+                s0 = f4_add(f4_ld(acc_sh), s0);
+                s1 = f4_add(f4_ld(acc_sh + 256), s1);
+            }
+            f4_st(acc_sh, s0);
+            f4_st(acc_sh + 256, s1);
+        }
+    }
+    if constexpr (EPI == 1) {
+        // column sums: the 4 row groups of a wave (lanes l, l+16, l+32, l+48), then the 2 wave rows - fixed order
+        __syncthreads();
+        if (wm == 0 && lane < 16) {
+#pragma unroll
+            for (int hb = 0; hb < RN / 2; ++hb) {
+                const int col = n0 + wn * TN + hb * 64 + lane * 4;
+                if (col < g.N) {
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        float4 sum = f4_zero();
+#pragma unroll
+                        for (int w = 0; w < WM; ++w)
+#pragma unroll
+                            for (int pr = 0; pr < 4; ++pr)
+                                sum = f4_add(sum, f4_ld(red_acc + (((w * WN + wn) * (RN / 2) + hb) * 2 + k) * 256 +
+                                                        (pr * 16 + lane) * 4));
+                        if (k == 1) sum = f4_mul(sum, f4_ld(g.nstat + g.N + col));  // sum gz*(x-mean) -> sum gz*xhat
+                        f4_st(g.red_partial + ((size_t)tile * 2 + k) * g.N + col, sum);
+                    }
+                }
             }
         }
     }
@@ -793,7 +865,7 @@ int launch_nt_rm(const X6Args& g, hipStream_t st) {
         constexpr int kResident = 512;
         const int ny = g.Npad / BN;
         // (without addend only: the addend variant needs 292 registers per lane in this form - one wave per SIMD)
-        if (!g.addend && g.N == g.Npad && ((g.K / BK) & 1) == 0 && (int64_t)grid.x * ny >= 4 * kResident &&
+        if (!g.addend && !g.red_partial && g.N == g.Npad && ((g.K / BK) & 1) == 0 && (int64_t)grid.x * ny >= 4 * kResident &&
             ny <= kResident) {
             constexpr int plds = Sch<F16, RM_>::LDS_PERSIST;
             static bool pattr_set = false;
@@ -810,12 +882,41 @@ int launch_nt_rm(const X6Args& g, hipStream_t st) {
         }
     }
 #endif
+    if constexpr (F16) {
+        if (g.red_partial != nullptr) {  // BatchNorm-backward reductions in the epilogue (EPI == 1)
+            constexpr int lds = Sch<F16, RM_>::LDS > EPI1_LDS ? Sch<F16, RM_>::LDS : EPI1_LDS;
+            static bool eattr_set = false;
+            if (!eattr_set) {
+                hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_x6_kernel<false, true, RM_, false, 1>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                if (e == hipSuccess)
+                    e = hipFuncSetAttribute((const void*)gemm_nt_x6_kernel<true, true, RM_, false, 1>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                if (e != hipSuccess) return (int)e;
+                eattr_set = true;
+            }
+            if (g.addend)
+                hipLaunchKernelGGL((gemm_nt_x6_kernel<true, true, RM_, false, 1>), grid, dim3(NT), lds, st, g);
+            else
+                hipLaunchKernelGGL((gemm_nt_x6_kernel<false, true, RM_, false, 1>), grid, dim3(NT), lds, st, g);
+            ALIGNN_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     if (g.addend)
         hipLaunchKernelGGL((gemm_nt_x6_kernel<true, F16, RM_>), grid, dim3(NT), lds, st, g);
     else
         hipLaunchKernelGGL((gemm_nt_x6_kernel<false, F16, RM_>), grid, dim3(NT), lds, st, g);
     ALIGNN_CHECK_LAUNCH();
     return 0;
+}
+// rows per block tile the dispatcher below picks (the EPI == 1 variant writes one reduction slab per row tile)
+inline int nt_block_rows(int64_t M, int N, int K) {
+#ifdef X6_FORCE_RM
+    return 64 * X6_FORCE_RM;
+#endif
+    const int64_t tiles128 = alignn_ceil_div(M, 128) * (int64_t)(npad(N) / BN);
+    return (K <= 64 || tiles128 < 256) ? 64 : 128;
 }
 template <bool F16>
 int launch_nt(const X6Args& g, hipStream_t st) {
@@ -924,7 +1025,7 @@ int alignn_gemm_nt_x6(const float* A, int64_t lda, const void* Wsplit, const flo
     if (!alignn_gemm_nt_x6_supported(M, N, K)) return (int)hipErrorInvalidValue;
     if (!nt_args_ok(A, lda, Wsplit, bias, addend, ldadd, C, ldc)) return (int)hipErrorInvalidValue;
     X6Args g{A, lda, (const unsigned char*)Wsplit, nullptr, nullptr, bias, addend, ldadd, C, ldc, M, N, npad(N), K,
-             M * (int64_t)N * 4 >= ((int64_t)128 << 20)};
+             M * (int64_t)N * 4 >= ((int64_t)128 << 20), nullptr, 0, nullptr, nullptr};
     return launch_nt<false>(g, (hipStream_t)stream);
 }
 
@@ -934,7 +1035,23 @@ int alignn_gemm_nt_f16x3(const float* A, int64_t lda, const float* a_amax, const
     if (!alignn_gemm_nt_x6_supported(M, N, K) || a_amax == nullptr || w_amax == nullptr) return (int)hipErrorInvalidValue;
     if (!nt_args_ok(A, lda, Wsplit, bias, addend, ldadd, C, ldc)) return (int)hipErrorInvalidValue;
     X6Args g{A, lda, (const unsigned char*)Wsplit, a_amax, w_amax, bias, addend, ldadd, C, ldc, M, N, npad(N), K,
-             M * (int64_t)N * 4 >= ((int64_t)128 << 20)};
+             M * (int64_t)N * 4 >= ((int64_t)128 << 20), nullptr, 0, nullptr, nullptr};
+    return launch_nt<true>(g, (hipStream_t)stream);
+}
+
+int alignn_gemm_nt_x6_row_tiles(int64_t M, int N, int K) { return alignn_ceil_div(M, nt_block_rows(M, N, K)); }
+
+int alignn_gemm_nt_f16x3_bnred(const float* A, int64_t lda, const float* a_amax, const void* Wsplit, const float* w_amax,
+                               const float* bias, const float* addend, int64_t ldadd, float* C, int64_t ldc, int64_t M,
+                               int N, int K, const float* Xn, int64_t ldxn, const float* nstat, float* red_partial,
+                               alignn_stream_t stream) {
+    if (!alignn_gemm_nt_x6_supported(M, N, K) || a_amax == nullptr || w_amax == nullptr) return (int)hipErrorInvalidValue;
+    if (!nt_args_ok(A, lda, Wsplit, bias, addend, ldadd, C, ldc)) return (int)hipErrorInvalidValue;
+    if (Xn == nullptr || nstat == nullptr || red_partial == nullptr || (ldxn & 3) || !a16(Xn) || !a16(nstat) ||
+        !a16(red_partial))
+        return (int)hipErrorInvalidValue;
+    X6Args g{A, lda, (const unsigned char*)Wsplit, a_amax, w_amax, bias, addend, ldadd, C, ldc, M, N, npad(N), K,
+             M * (int64_t)N * 4 >= ((int64_t)128 << 20), Xn, ldxn, nstat, red_partial};
     return launch_nt<true>(g, (hipStream_t)stream);
 }
 

@@ -428,6 +428,32 @@ def _gemm_nt_f16x3_launch(lib, a, a_amax, ws, bias, addend, out, M, N, K):
     return out
 
 
+def gemm_nt_f16x3_bnred(a, a_amax, ws, xn, nstat, bias=None, addend=None, out=None):
+    """``gemm_nt_f16x3`` whose output is the gradient of ``r + silu(BatchNorm(xn))``: also returns ``red`` [2,N] =
+    (sum gz, sum gz*xhat) over the rows - the reductions BatchNorm's backward starts with (``_bn_silu_bwd_reduce``) -
+    taken in the product's epilogue while the tile is still in registers (one pass over ``xn`` instead of two passes
+    over ``xn`` and the gradient)."""
+    lib = _lib.load()
+    require_f32(a, bias, addend, xn, nstat)
+    M, K = a.shape
+    N = ws.n
+    if K != ws.k or xn.shape != (M, N):
+        raise ValueError(f"shape mismatch: a {tuple(a.shape)}, W [{N},{ws.k}], xn {tuple(xn.shape)}")
+    if out is None:
+        out = _empty(M, N, like=a)
+    tiles = lib.alignn_gemm_nt_x6_row_tiles(M, N, K)
+    partial = _empty(tiles, 2, N, like=a)
+    check(
+        lib.alignn_gemm_nt_f16x3_bnred(ptr(a), a.stride(0), ptr(a_amax), ptr(ws.buf), ptr(ws.amax), ptr(bias), ptr(addend),
+                                       addend.stride(0) if addend is not None else 0, ptr(out), out.stride(0), M, N, K,
+                                       ptr(xn), xn.stride(0), ptr(nstat), ptr(partial), stream()),
+        "gemm_nt_f16x3_bnred",
+    )
+    red = _empty(2, N, like=a)
+    check(lib.alignn_bn_bwd_finalize(ptr(partial), tiles, N, ptr(red), stream()), "bn_bwd_finalize")
+    return out, red
+
+
 def gemm_nt_x6(a, ws, bias=None, addend=None, out=None):
     """out[M,N] = a[M,K] @ W[N,K]^T with W pre-sliced by ``split_bf16x3`` (fp32-grade accuracy, bf16 MFMA)."""
     lib = _lib.load()

@@ -108,6 +108,19 @@ int alignn_gemm_nt_f16x3(const float* A, int64_t lda, const float* a_amax, const
                          const float* w_amax, const float* bias, const float* addend, int64_t ldadd, float* C,
                          int64_t ldc, int64_t M, int N, int K, alignn_stream_t stream);
 
+/* The same projection when its OUTPUT is the gradient g_y of y = r + silu(BatchNorm(Xn)) (the next thing autograd does
+ * with g_y is BatchNorm's backward: alignn/models/alignn.py:126 bn_edges / :178 MLPLayer's BatchNorm1d under
+ * torch.autograd): additionally writes, per row tile of the product, the column sums over the tile's rows of
+ *   gz = g_y * silu'((Xn - mean) * scale + beta)   and   gz * (Xn - mean) * rstd
+ * into red_partial [row_tiles][2][N] (nstat = [4][N] as written by alignn_bn_finalize).  alignn_bn_bwd_finalize
+ * over `alignn_gemm_nt_x6_row_tiles(M, N, K)` slabs then gives dbeta / dgamma - what alignn_bn_silu_bwd_reduce
+ * computes with two more passes over g_y and Xn. */
+int alignn_gemm_nt_x6_row_tiles(int64_t M, int N, int K);
+int alignn_gemm_nt_f16x3_bnred(const float* A, int64_t lda, const float* a_amax, const void* Wsplit,
+                               const float* w_amax, const float* bias, const float* addend, int64_t ldadd,
+                               float* C, int64_t ldc, int64_t M, int N, int K, const float* Xn, int64_t ldxn,
+                               const float* nstat, float* red_partial, alignn_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Column statistics / BatchNorm1d + SiLU (+ residual).
  * Replace nn.BatchNorm1d (training: batch statistics over ALL rows; eps 1e-5; momentum 0.1,
