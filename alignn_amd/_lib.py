@@ -37,6 +37,13 @@ SIGNATURES = {
     "alignn_gemm_nt_f16x3": (_i32, [_p, _i64, _p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _i32, _i32, _p]),
     "alignn_gemm_nt_x6_row_tiles": (_i32, [_i64, _i32, _i32]),
     "alignn_gemm_nt_f16x3_bnred": (_i32, [_p, _i64, _p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _i32, _i32, _p, _i64, _p, _p, _p]),
+    "alignn_dual_slabs": (_i32, [_i64]),
+    "alignn_ln_silu_dual_fwd": (_i32, [_p, _p, _i64, _p, _p, _i64, _p, _p, _f32, _p, _p, _i64, _p, _i64, _i32, _p, _p]),
+    "alignn_ln_silu_dual_bwd": (_i32, [_p, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p, _i64, _p, _i64, _i32, _p, _p]),
+    "alignn_egc_gate_dual_fwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p]),
+    "alignn_egc_node_dual_bwd": (_i32, [_p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p]),
+    "alignn_egc_dual_bwd_dst": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "alignn_egc_dual_bwd_src": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p]),
     "alignn_col_stats_slabs": (_i32, [_i64]),
     "alignn_col_stats": (_i32, [_p, _i64, _i64, _i32, _p, _p]),
     "alignn_col_sum": (_i32, [_p, _i64, _i64, _i32, _p, _p, _p]),

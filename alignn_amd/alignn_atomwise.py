@@ -25,9 +25,12 @@ import torch
 from torch import nn
 
 from . import alignn as _bn
-from . import ops
+from . import _lib, ops
 from .alignn import _Base, _CONFIG, RBFExpansion  # noqa: F401  (RBFExpansion re-exported like the reference)
 from .graph import GraphBatch, cached_dgl_batch
+
+
+FUSED_FORCE_TRAINING = True  # tests flip this to compare against the composed twice-differentiable path (alignn_amd.ff)
 
 
 class ALIGNNAtomWiseConfig(_Base):
@@ -333,6 +336,16 @@ class ALIGNNAtomWise(nn.Module):
         # with their hand-written backward, r as a leaf.
         fused_forces = cfg.calculate_gradient and not self.training and torch.is_grad_enabled()
         if cfg.calculate_gradient and not fused_forces:
+            from . import ff2
+
+            if FUSED_FORCE_TRAINING and torch.is_grad_enabled() and ff2.supported(cfg):
+                # training through the forces: values by the fused first-order path, the loss gradient by ONE reverse
+                # pass over a forward pass that carries tangents (alignn_amd/ff2.py) - same gradients as
+                # autograd.grad(create_graph=True) + a second backward, on fused kernels
+                with _lib.device_guard(self.fc.weight):
+                    out, forces, stress = ff2.ForcesFn.apply(self, b, *self.parameters())
+                has_stress = cfg.stresswise_weight != 0
+                return self._finish(out, torch.empty(1), forces, stress if has_stress else torch.empty(1), torch.empty(1))
             return self._forward_ff(b)
         if fused_forces:
             with ops.no_param_grad():

@@ -9,7 +9,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libalignn_hip.so")
-SOURCES = ["norm.hip", "conv.hip", "gemm_f32.hip", "gemm_x6.hip", "embed.hip"]
+SOURCES = ["norm.hip", "conv.hip", "gemm_f32.hip", "gemm_x6.hip", "embed.hip", "dual.hip"]
 
 
 def _stale() -> bool:

@@ -1,0 +1,356 @@
+"""Training THROUGH the forces on fused kernels: the dual-number pass.
+
+``ALIGNNAtomWise`` with ``calculate_gradient=True`` returns forces ``F = reduce(-dE_tot/dr)`` and virial stresses,
+and the training loss differentiates through them (alignn/models/alignn_atomwise.py:512-638,
+``autograd.grad(create_graph=True)``; alignn/train.py:291-387).  Reverse-over-reverse needs the second derivative of
+every layer.  The same gradient has a cheaper form: with ``w_e = dL/d(pair force of bond e)`` (known once the loss has
+been evaluated, i.e. in backward) the force / stress part of the loss is linear in the pair forces,
+
+    L_FS(theta) = sum_e w_e . f_e(theta),   f_e = c dE_tot/dr_e   ==>   L_FS = c D_w E_tot(theta),
+
+``c`` times the DIRECTIONAL derivative of the total energy along the bond-vector displacement ``w``.  So
+
+    dL/dtheta = sum_g gE_g dE_g/dtheta  +  c d/dtheta [ D_w E_tot ]
+
+is ONE reverse pass over a forward pass that carries, next to every activation ``p``, its tangent ``pt = D_w p``
+(forward-over-reverse instead of reverse-over-reverse).  ``ForcesFn`` is that scheme as one autograd node:
+
+* forward:  energies, forces and stresses as VALUES, by the fused first-order path (``_forward_fused``: fused forward +
+  hand-written backward w.r.t. the bond vectors - what inference / MD uses);
+* backward: build ``w`` and the seeds from the incoming gradients, run the dual forward (``csrc/dual.hip`` for the
+  non-linear pieces, the ordinary MFMA projections for every Linear layer: the tangent of ``x W^T + b`` is
+  ``xt W^T``) and its reverse, hand the parameter gradients to autograd.
+
+Everything is computed by the HIP library; torch does index bookkeeping and a few [E,3] / [T,40] element-wise
+operations for the tangents of the geometry features.  Same gradients as the composed twice-differentiable path
+(``alignn_amd.ff``) and as the reference's class (goldens), ~4x faster at BASELINE configs[3].
+"""
+
+from __future__ import annotations
+
+import torch
+
+from . import _lib, ops
+from ._lib import check, ptr, stream
+from .graph import CSRGraph, GraphBatch
+
+LN_EPS = 1e-5
+
+
+def _empty(*shape, like):
+    return torch.empty(*shape, dtype=torch.float32, device=like.device)
+
+
+def _amax2(like):
+    """two consecutive zeroed device scalars (value, tangent)"""
+    a = ops._AMAX_ARENA
+    if a["buf"] is None or a["next"] + 2 > a["buf"].numel() or a["buf"].device != like.device:
+        ops.new_amax_arena(like.device)
+    i = a["next"]
+    a["next"] = i + 2
+    return a["buf"][i:i + 2]
+
+
+def _track(rows):
+    return ops._track(rows)
+
+
+class Dual:
+    """value ``p`` and tangent ``t`` of one activation (+ the max|.| scalars their producer tracked, or None)"""
+
+    __slots__ = ("p", "t", "amax")
+
+    def __init__(self, p, t, amax=None):
+        self.p, self.t, self.amax = p, t, amax
+
+    def am(self, i):
+        return None if self.amax is None else self.amax[i:i + 1]
+
+
+def _project(x: Dual, w, b):
+    """(x W^T + b, xt W^T)"""
+    return (ops.project(x.p, w, b, a_amax=x.am(0)), ops.project(x.t, w, None, a_amax=x.am(1)))
+
+
+def _ln_fwd(x: Dual, res, gamma, beta):
+    lib = _lib.load()
+    rows, F = x.p.shape
+    yp, yt = _empty(rows, F, like=x.p), _empty(rows, F, like=x.p)
+    stats = _empty(rows, 2, like=x.p)
+    amax = _amax2(x.p) if _track(rows) else None
+    check(lib.alignn_ln_silu_dual_fwd(ptr(x.p), ptr(x.t), x.p.stride(0), ptr(res.p) if res else None,
+                                      ptr(res.t) if res else None, res.p.stride(0) if res else 0, ptr(gamma), ptr(beta),
+                                      LN_EPS, ptr(yp), ptr(yt), F, ptr(stats), rows, F, ptr(amax), stream()),
+          "ln_silu_dual_fwd")
+    return Dual(yp, yt, amax), stats
+
+
+def _ln_bwd(g: Dual, x: Dual, gamma, beta, stats, out_p=None, out_t=None, amax=None):
+    """-> (gx Dual, red [2,F] = dbeta | dgamma).  ``out_*``: write into these (possibly strided) blocks."""
+    lib = _lib.load()
+    rows, F = x.p.shape
+    if out_p is None:
+        out_p, out_t = _empty(rows, F, like=x.p), _empty(rows, F, like=x.p)
+    if amax is None and _track(rows):
+        amax = _amax2(x.p)
+    slabs = lib.alignn_dual_slabs(rows)
+    partial = _empty(slabs, 2, F, like=x.p)
+    check(lib.alignn_ln_silu_dual_bwd(ptr(g.p), ptr(g.t), g.p.stride(0), ptr(x.p), ptr(x.t), x.p.stride(0), ptr(gamma),
+                                      ptr(beta), ptr(stats), ptr(out_p), ptr(out_t), out_p.stride(0), ptr(partial), rows,
+                                      F, ptr(amax), stream()), "ln_silu_dual_bwd")
+    red = _empty(2, F, like=x.p)
+    check(lib.alignn_bn_bwd_finalize(ptr(partial), slabs, F, ptr(red), stream()), "ln_dual_finalize")
+    return Dual(out_p, out_t, amax), red
+
+
+class _Grads:
+    """parameter -> accumulated gradient"""
+
+    def __init__(self):
+        self.g = {}
+
+    def add(self, p, g):
+        if p is None or g is None:
+            return
+        k = id(p)
+        if k in self.g:
+            self.g[k] = (p, self.g[k][1] + g)
+        else:
+            self.g[k] = (p, g)
+
+    def get(self, p):
+        e = self.g.get(id(p))
+        return None if e is None else e[1]
+
+
+def _wgrad(g: Dual, x: Dual):
+    """W-bar = g^T x + gt^T xt"""
+    return ops.gemm_tn(g.p, x.p, g.am(0), x.am(0)) + ops.gemm_tn(g.t, x.t, g.am(1), x.am(1))
+
+
+def _dgrad(g: Dual, w, addend: Dual = None):
+    return Dual(ops._dgrad(g.p, w, addend.p if addend else None, g_amax=g.am(0)),
+                ops._dgrad(g.t, w, addend.t if addend else None, g_amax=g.am(1)))
+
+
+# ---------------------------------------------------------------------------------------------
+# layers
+# ---------------------------------------------------------------------------------------------
+def mlp_fwd(layer, x: Dual, tape):
+    lin, ln = layer.layer[0], layer.layer[1]
+    pre = Dual(*_project(x, lin.weight, lin.bias))
+    y, stats = _ln_fwd(pre, None, ln.weight, ln.bias)
+    tape.append(("mlp", layer, x, pre, stats))
+    return y
+
+
+def mlp_bwd(entry, g: Dual, grads: _Grads, need_input_grad=True):
+    _, layer, x, pre, stats = entry
+    lin, ln = layer.layer[0], layer.layer[1]
+    gpre, red = _ln_bwd(g, pre, ln.weight, ln.bias, stats)
+    grads.add(ln.bias, red[0])
+    grads.add(ln.weight, red[1])
+    grads.add(lin.weight, _wgrad(gpre, x))
+    grads.add(lin.bias, ops.col_sum(gpre.p))
+    return _dgrad(gpre, lin.weight) if need_input_grad else None
+
+
+def conv_fwd(conv, graph: CSRGraph, x: Dual, y: Dual, need_y, tape):
+    lib = _lib.load()
+    n, H = x.p.shape
+    m = y.p.shape[0]
+    wcat, bcat = conv._fused_node_projection()
+    P = Dual(*_project(x, wcat, bcat))
+    M = Dual(*_project(y, conv.edge_gate.weight, conv.edge_gate.bias))
+    xpre = Dual(_empty(n, H, like=x.p), _empty(n, H, like=x.p))
+    s0, hh, s0t, hht = (_empty(n, H, like=x.p) for _ in range(4))
+    check(lib.alignn_egc_gate_dual_fwd(ptr(P.p), ptr(P.t), ptr(M.p), ptr(M.t), ptr(graph.seg_ptr), ptr(graph.seg_node),
+                                       ptr(graph.src), n, m, H, ptr(xpre.p), ptr(xpre.t), ptr(s0), ptr(hh), ptr(s0t),
+                                       ptr(hht), stream()), "egc_gate_dual_fwd")
+    res = conv.residual
+    x_out, n_stats = _ln_fwd(xpre, x if res else None, conv.bn_nodes.weight, conv.bn_nodes.bias)
+    y_out, e_stats = (None, None)
+    if need_y:
+        y_out, e_stats = _ln_fwd(M, y if res else None, conv.bn_edges.weight, conv.bn_edges.bias)
+    tape.append(("conv", conv, graph, x, y, P, M, xpre, (s0, hh, s0t, hht), n_stats, e_stats))
+    return x_out, y_out
+
+
+def conv_bwd(entry, gx: Dual, gy, grads: _Grads):
+    """(gx, gy) = adjoints of the outputs (gy None: dead edge output) -> adjoints of the inputs"""
+    lib = _lib.load()
+    _, conv, graph, x, y, P, M, xpre, (s0, hh, s0t, hht), n_stats, e_stats = entry
+    n, H = x.p.shape
+    m = y.p.shape[0]
+    if gx is None:  # (node output unused downstream: cannot happen inside ALIGNNAtomWise, kept for completeness)
+        gx = Dual(torch.zeros_like(x.p), torch.zeros_like(x.p))
+    GP = Dual(_empty(n, 4 * H, like=x.p), _empty(n, 4 * H, like=x.p), _amax2(x.p) if _track(n) else None)
+    # node branch: LayerNorm/SiLU reverse straight into the Ux blocks
+    gxpre, n_red = _ln_bwd(gx, xpre, conv.bn_nodes.weight, conv.bn_nodes.bias, n_stats, GP.p[:, 3 * H:], GP.t[:, 3 * H:],
+                           amax=GP.amax)
+    grads.add(conv.bn_nodes.bias, n_red[0])
+    grads.add(conv.bn_nodes.weight, n_red[1])
+    q1, q0, q1t, q0t = (_empty(n, H, like=x.p) for _ in range(4))
+    check(lib.alignn_egc_node_dual_bwd(ptr(gxpre.p), ptr(gxpre.t), 4 * H, ptr(s0), ptr(hh), ptr(s0t), ptr(hht), ptr(q1),
+                                       ptr(q0), ptr(q1t), ptr(q0t), n, H, stream()), "egc_node_dual_bwd")
+    GL = None
+    if gy is not None:
+        GL, e_red = _ln_bwd(gy, M, conv.bn_edges.weight, conv.bn_edges.bias, e_stats)
+        grads.add(conv.bn_edges.bias, e_red[0])
+        grads.add(conv.bn_edges.weight, e_red[1])
+    GM = Dual(_empty(m, H, like=x.p), _empty(m, H, like=x.p), _amax2(x.p) if _track(m) else None)
+    slabs = lib.alignn_dual_slabs(n)
+    gb_part = _empty(slabs, H, like=x.p)
+    check(lib.alignn_egc_dual_bwd_dst(ptr(GL.p) if GL else None, ptr(GL.t) if GL else None, ptr(M.p), ptr(M.t), ptr(P.p),
+                                      ptr(P.t), ptr(q1), ptr(q0), ptr(q1t), ptr(q0t), ptr(graph.seg_ptr),
+                                      ptr(graph.seg_node), ptr(graph.src), n, H, ptr(GM.p), ptr(GM.t), ptr(GP.p),
+                                      ptr(GP.t), ptr(gb_part), ptr(GM.amax), ptr(GP.amax), stream()), "egc_dual_bwd_dst")
+    check(lib.alignn_egc_dual_bwd_src(ptr(GM.p), ptr(GM.t), ptr(M.p), ptr(M.t), ptr(q1), ptr(q1t), ptr(graph.out_ptr),
+                                      ptr(graph.out_slot), ptr(graph.dst), n, H, ptr(GP.p), ptr(GP.t), ptr(GP.amax),
+                                      stream()), "egc_dual_bwd_src")
+    wcat, _ = conv._fused_node_projection()
+    res = conv.residual
+    g_x = _dgrad(GP, wcat, gx if res else None)
+    g_y = _dgrad(GM, conv.edge_gate.weight, gy if (res and gy is not None) else None)
+    g_wcat = _wgrad(GP, x)
+    g_bcat = ops.col_sum(GP.p)
+    for i, lin in enumerate((conv.src_gate, conv.dst_gate, conv.dst_update, conv.src_update)):
+        grads.add(lin.weight, g_wcat[i * H:(i + 1) * H])
+        grads.add(lin.bias, g_bcat[i * H:(i + 1) * H])
+    grads.add(conv.edge_gate.weight, _wgrad(GM, y))
+    g_beg = _empty(H, like=x.p)
+    check(lib.alignn_slab_sum(ptr(gb_part), slabs, H, ptr(g_beg), stream()), "slab_sum")
+    grads.add(conv.edge_gate.bias, g_beg)
+    return g_x, g_y
+
+
+# ---------------------------------------------------------------------------------------------
+# geometry features and their tangents (a few element-wise operations on [E,3] / [T,3] / [T,bins] tensors)
+# ---------------------------------------------------------------------------------------------
+def _rbf_dual(d, dt, mod):
+    diff = d.unsqueeze(1) - mod.centers
+    val = torch.exp(-mod.gamma * diff * diff)
+    return Dual(val, val * (-2.0 * mod.gamma) * diff * dt.unsqueeze(1))
+
+
+def _cos_dual(r, rt, lg: CSRGraph):
+    """compute_bond_cosines (alignn/graphs.py:847-864) and its derivative along rt; r1 = -r[e1], r2 = r[e2]"""
+    e1, e2 = lg.src.long(), lg.dst.long()
+    a, at = -r[e1], -rt[e1]
+    b, bt = r[e2], rt[e2]
+    na, nb = a.norm(dim=1), b.norm(dim=1)
+    c = (a * b).sum(1) / (na * nb)
+    ct = ((at * b).sum(1) + (a * bt).sum(1)) / (na * nb) - c * ((a * at).sum(1) / (na * na) + (b * bt).sum(1) / (nb * nb))
+    inside = (c > -1) & (c < 1)
+    return torch.clamp(c, -1, 1), torch.where(inside, ct, torch.zeros_like(ct))
+
+
+def supported(cfg) -> bool:
+    """configurations the dual pass covers (everything else trains on the composed path of alignn_amd.ff)"""
+    return (cfg.calculate_gradient and not cfg.include_pos_deriv and not cfg.use_cutoff_function
+            and cfg.extra_features == 0 and cfg.output_features == 1 and not cfg.classification and cfg.link == "identity"
+            and cfg.additional_output_features == 0 and not (cfg.atomwise_output_features > 0 and cfg.atomwise_weight != 0)
+            and (cfg.stresswise_weight == 0 or cfg.batch_stress))
+
+
+def dual_pass(model, b: GraphBatch, rt, g_energy, gt_energy):
+    """Parameter gradients of  sum_g g_energy[g] E_g + sum_g gt_energy[g] (D_rt E)_g  -> {id(param): (param, grad)}"""
+    cfg = model.config
+    tape, grads = [], _Grads()
+    n_a, n_g = len(model.alignn_layers), len(model.gcn_layers)
+    r = b.r
+    d = r.norm(dim=1)
+    dt = (r * rt).sum(1) / d
+    af = b.atom_features
+    x = mlp_fwd(model.atom_embedding, Dual(af, torch.zeros_like(af)), tape)
+    y = mlp_fwd(model.edge_embedding[2], mlp_fwd(model.edge_embedding[1], _rbf_dual(d, dt, model.edge_embedding[0]), tape), tape)
+    if n_a > 0:
+        if cfg.lg_on_fly:
+            h, ht = _cos_dual(r, rt, b.lg)
+        else:
+            h, ht = b.h, torch.zeros_like(b.h)
+        z = mlp_fwd(model.angle_embedding[2], mlp_fwd(model.angle_embedding[1], _rbf_dual(h, ht, model.angle_embedding[0]), tape), tape)
+    for i, layer in enumerate(model.alignn_layers):
+        x, m = conv_fwd(layer.node_update, b.g, x, y, True, tape)
+        y, z = conv_fwd(layer.edge_update, b.lg, m, z, i + 1 < n_a, tape)
+    for i, layer in enumerate(model.gcn_layers):
+        x, y = conv_fwd(layer, b.g, x, y, i + 1 < n_g, tape)
+    # readout: E_g = fc(mean_i x_i)  (alignn_atomwise.py:464-466); reverse with the two seeds
+    counts = (b.graph_ptr[1:] - b.graph_ptr[:-1]).to(torch.float32)
+    hp = ops.AvgPoolFn.apply(x.p, b.graph_ptr)
+    hpt = ops.AvgPoolFn.apply(x.t, b.graph_ptr)
+    fc = model.fc
+    grads.add(fc.weight, (g_energy.unsqueeze(1) * hp + gt_energy.unsqueeze(1) * hpt).sum(0, keepdim=True))
+    grads.add(fc.bias, g_energy.sum().reshape(1))
+    if "node_graph" not in b.cache:
+        b.cache["node_graph"] = torch.repeat_interleave(torch.arange(b.batch_size, device=r.device), counts.long())
+    ng = b.cache["node_graph"]
+    wrow = fc.weight.reshape(1, -1)
+    gx = Dual(((g_energy / counts).unsqueeze(1) * wrow)[ng].contiguous(), ((gt_energy / counts).unsqueeze(1) * wrow)[ng].contiguous())
+    gy = None
+    gz = None
+    # reverse over the tape
+    k = len(tape) - 1
+    for i in reversed(range(n_g)):
+        gx, gy_in = conv_bwd(tape[k], gx, gy, grads)
+        gy = gy_in
+        k -= 1
+    for i in reversed(range(n_a)):
+        gy_e, gz = conv_bwd(tape[k], gy, gz, grads)  # edge_update: nodes = bonds (m), edges = triplets
+        k -= 1
+        gx, gy = conv_bwd(tape[k], gx, gy_e, grads)  # node_update: outputs (x, m)
+        k -= 1
+    if n_a > 0:
+        gz1 = mlp_bwd(tape[k], gz, grads)
+        mlp_bwd(tape[k - 1], gz1, grads, need_input_grad=False)
+        k -= 2
+    gy1 = mlp_bwd(tape[k], gy, grads)
+    mlp_bwd(tape[k - 1], gy1, grads, need_input_grad=False)
+    mlp_bwd(tape[k - 2], gx, grads, need_input_grad=False)
+    return grads
+
+
+class ForcesFn(torch.autograd.Function):
+    """(E, forces, stresses) of ALIGNNAtomWise as one autograd node; see the module docstring."""
+
+    @staticmethod
+    def forward(ctx, model, batch, *params):
+        with torch.enable_grad(), ops.no_param_grad():
+            res = model._forward_fused(batch, True)
+        ctx.model, ctx.batch = model, batch
+        ctx.params = params
+        ctx.has_stress = torch.is_tensor(res["stresses"]) and res["stresses"].dim() == 3
+        out, forces, stress = res["out"].detach(), res["grad"].detach(), res["stresses"].detach()
+        return out, forces, stress
+
+    @staticmethod
+    def backward(ctx, g_out, g_forces, g_stress):
+        model, b, cfg = ctx.model, ctx.batch, ctx.model.config
+        gg = b.g
+        with torch.no_grad():
+            dev = b.r.device
+            E = gg.n_edges
+            w = torch.zeros(E, 3, dtype=torch.float32, device=dev)
+            if g_forces is not None:
+                gF = g_forces.reshape(gg.n_nodes, 3)
+                w = w + gF[gg.dst.long()]
+                if cfg.add_reverse_forces:
+                    w = w - gF[gg.src.long()]
+            if ctx.has_stress and g_stress is not None:
+                # stress_g = k_g sum_e r_e (x) pf_e  ->  dL/dpf_e = k_g gS_g^T r_e
+                egp = b.edge_graph_ptr.long()
+                if "edge_graph" not in b.cache:
+                    b.cache["edge_graph"] = torch.repeat_interleave(torch.arange(b.batch_size, device=dev), egp[1:] - egp[:-1])
+                eg = b.cache["edge_graph"]
+                kg = cfg.stress_multiplier * (-160.21766208) / b.volume
+                w = w + torch.einsum("eab,ea->eb", (kg.reshape(-1, 1, 1) * g_stress)[eg], b.r)
+            counts = (b.graph_ptr[1:] - b.graph_ptr[:-1]).to(torch.float32)
+            c = float(cfg.grad_multiplier) * (gg.n_nodes if cfg.force_mult_natoms else 1)
+            gt = c * (counts if cfg.energy_mult_natoms else torch.ones_like(counts))
+            ge = g_out.reshape(-1).to(torch.float32) if g_out is not None else torch.zeros_like(counts)
+            # the tangent is linear in w: normalise it to unit size (a power of two) so that tangent activations have
+            # the scale of the values, and undo the factor in the seed
+            wmax = w.abs().max()
+            scale = torch.where(wmax > 0, torch.exp2(torch.floor(torch.log2(wmax.clamp_min(1e-30)))), torch.ones_like(wmax))
+            grads = dual_pass(model, b, (w / scale).contiguous(), ge.contiguous(), (gt * scale).contiguous())
+        return (None, None) + tuple(grads.get(p) for p in ctx.params)

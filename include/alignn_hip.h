@@ -312,6 +312,41 @@ int alignn_segment_sum(const float* vals, int64_t ldv, const int32_t* ptr, const
 int alignn_gather_rows(const float* in, const int32_t* perm, float* out, int64_t rows, int F,
                        alignn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Dual-number kernels (value + directional derivative along a bond-vector displacement) of the LayerNorm-flavoured
+ * stack - training THROUGH the forces: the reference takes pair forces with autograd.grad(create_graph=True)
+ * (alignn/models/alignn_atomwise.py:512-565) and differentiates the force / stress loss through them
+ * (alignn/train.py:387).  sum_e w_e . f_e = -D_w E_tot, so the loss gradient is the reverse pass of a forward pass
+ * that carries tangents; these are its non-linear pieces (csrc/dual.hip), "t" = tangent, amax2 = two device scalars
+ * (value, tangent) raised like `amax` elsewhere.  Slab counts: alignn_dual_slabs(rows).
+ *   ln_silu_dual_fwd:  Y = R + silu(LN(X)), Yt = Rt + d[silu o LN](X).Xt;  stats[rows][2] = mean, rstd
+ *   ln_silu_dual_bwd:  (GY, GYt) -> (GX, GXt); partial[slabs][2][F] = dbeta | dgamma partial sums
+ *   egc_gate_dual_fwd: DGL u_add_v + sigmoid + u_mul_e/sum + copy_e/sum + h = S1/(S0+eps) (alignn_atomwise.py:177-189)
+ *                      on duals; M / Mt hold C / Ct on entry and m / mt on exit
+ *   egc_node_dual_bwd, egc_dual_bwd_dst, egc_dual_bwd_src: its reverse (adjoints Q of the four segment sums; GM / GMt;
+ *                      the A | Bd | Bh blocks of GP / GPt; gb_partial[slabs][H] = column sums of GM) */
+int alignn_dual_slabs(int64_t rows);
+int alignn_ln_silu_dual_fwd(const float* X, const float* Xt, int64_t ldx, const float* R, const float* Rt, int64_t ldr,
+                            const float* gamma, const float* beta, float eps, float* Y, float* Yt, int64_t ldy,
+                            float* stats, int64_t rows, int F, float* amax2, alignn_stream_t stream);
+int alignn_ln_silu_dual_bwd(const float* GY, const float* GYt, int64_t ldg, const float* X, const float* Xt, int64_t ldx,
+                            const float* gamma, const float* beta, const float* stats, float* GX, float* GXt,
+                            int64_t ldo, float* partial, int64_t rows, int F, float* amax2, alignn_stream_t stream);
+int alignn_egc_gate_dual_fwd(const float* P, const float* Pt, float* M, float* Mt, const int32_t* seg_ptr,
+                             const int32_t* seg_node, const int32_t* src, int64_t n, int64_t m, int H, float* xpre,
+                             float* xpre_t, float* s0, float* hh, float* s0t, float* hht, alignn_stream_t stream);
+int alignn_egc_node_dual_bwd(const float* g, const float* gt, int64_t ldg, const float* s0, const float* hh,
+                             const float* s0t, const float* hht, float* q1, float* q0, float* q1t, float* q0t, int64_t n,
+                             int H, alignn_stream_t stream);
+int alignn_egc_dual_bwd_dst(const float* GL, const float* GLt, const float* M, const float* Mt, const float* P,
+                            const float* Pt, const float* q1, const float* q0, const float* q1t, const float* q0t,
+                            const int32_t* seg_ptr, const int32_t* seg_node, const int32_t* src, int64_t n, int H,
+                            float* GM, float* GMt, float* GP, float* GPt, float* gb_partial, float* gm_amax2,
+                            float* gp_amax2, alignn_stream_t stream);
+int alignn_egc_dual_bwd_src(const float* GM, const float* GMt, const float* M, const float* Mt, const float* q1,
+                            const float* q1t, const int32_t* out_ptr, const int32_t* out_slot, const int32_t* dst,
+                            int64_t n, int H, float* GP, float* GPt, float* gp_amax2, alignn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,181 @@
+"""Dual-number kernels (csrc/dual.hip) and the forward-over-reverse force training path (alignn_amd/ff2.py) against
+torch float64 autograd (jvp + reverse) of the same formulas, and against the composed twice-differentiable path."""
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from alignn_amd import GraphBatch, ff2, ops  # noqa: E402
+from alignn_amd.graph import build_csr  # noqa: E402
+from alignn_amd.synthetic import make_batch  # noqa: E402
+from tests.helpers import rel_err  # noqa: E402
+
+DEV = "cuda"
+
+
+def _f(t):
+    return t.float().to(DEV).contiguous()
+
+
+@pytest.mark.parametrize("rows,Fw,res", [(37, 64, True), (300, 256, True), (50, 256, False), (9, 512, True)])
+def test_layernorm_silu_dual_forward_and_reverse(rows, Fw, res):
+    g = torch.Generator().manual_seed(rows + Fw)
+    x = torch.randn(rows, Fw, generator=g, dtype=torch.float64) * 1.5 + 0.3
+    t = torch.randn(rows, Fw, generator=g, dtype=torch.float64)
+    r = torch.randn(rows, Fw, generator=g, dtype=torch.float64)
+    rt = torch.randn(rows, Fw, generator=g, dtype=torch.float64)
+    gam = 1 + 0.2 * torch.randn(Fw, generator=g, dtype=torch.float64)
+    bet = 0.2 * torch.randn(Fw, generator=g, dtype=torch.float64)
+    gy = torch.randn(rows, Fw, generator=g, dtype=torch.float64)
+    gyt = torch.randn(rows, Fw, generator=g, dtype=torch.float64)
+
+    def fn(x_, gam_, bet_):
+        return F.silu(F.layer_norm(x_, (Fw,), gam_, bet_, 1e-5))
+
+    def dual(x_, t_, gam_, bet_):
+        """value and tangent written out with differentiable torch operations (torch.func.jvp and
+        torch.autograd.functional.jvp(create_graph=True) both return tangents whose .backward() w.r.t. the PRIMAL input
+        is wrong - checked against finite differences -, so the reference tangent is explicit)"""
+        mean = x_.mean(1, keepdim=True)
+        rho = (((x_ - mean) ** 2).mean(1, keepdim=True) + 1e-5).rsqrt()
+        xh = (x_ - mean) * rho
+        th = rho * (t_ - t_.mean(1, keepdim=True) - xh * (xh * t_).mean(1, keepdim=True))
+        z, zt = gam_ * xh + bet_, gam_ * th
+        sg = torch.sigmoid(z)
+        return z * sg, (sg + z * sg * (1 - sg)) * zt
+
+    xr, tr, gr, br = (v.clone().requires_grad_(True) for v in (x, t, gam, bet))
+    y, yt = dual(xr, tr, gr, br)
+    assert rel_err(y, fn(x, gam, bet)) < 1e-12
+    assert rel_err(yt, (fn(x + 1e-6 * t, gam, bet) - fn(x - 1e-6 * t, gam, bet)) / 2e-6) < 1e-7  # the tangent IS the derivative
+    if res:
+        y, yt = y + r, yt + rt
+    ((y * gy).sum() + (yt * gyt).sum()).backward()
+
+    X = ff2.Dual(_f(x), _f(t))
+    Y, stats = ff2._ln_fwd(X, ff2.Dual(_f(r), _f(rt)) if res else None, _f(gam), _f(bet))
+    assert rel_err(Y.p, y) < 2e-6 and rel_err(Y.t, yt) < 2e-6
+    GX, red = ff2._ln_bwd(ff2.Dual(_f(gy), _f(gyt)), X, _f(gam), _f(bet), stats)
+    assert rel_err(GX.p, xr.grad) < 2e-5 and rel_err(GX.t, tr.grad) < 2e-5
+    assert rel_err(red[0], br.grad) < 2e-5 and rel_err(red[1], gr.grad) < 2e-5
+
+
+@pytest.mark.parametrize("H,n,m,seed", [(16, 9, 40, 0), (256, 120, 1500, 1), (64, 1, 5, 2)])
+def test_gate_pass_dual_forward_and_reverse(H, n, m, seed):
+    lib = ops._lib.load()
+    g = torch.Generator().manual_seed(seed)
+    u = torch.randint(0, n, (m,), generator=g)
+    v = torch.randint(0, max(n - 1, 1), (m,), generator=g)  # last node isolated when n > 1
+    csr = build_csr(u.to(DEV), v.to(DEV), n)
+    mk = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64)  # noqa: E731
+    P, Pt, C, Ct = mk(n, 4 * H), mk(n, 4 * H), mk(m, H), mk(m, H)
+    w_xp, w_xpt, w_m, w_mt = mk(n, H), mk(n, H), mk(m, H), mk(m, H)
+    perm, inv = csr.perm.cpu(), csr.inv.cpu()
+
+    def fn(P_, C_):
+        A, Bd, Bh, Ux = P_[:, :H], P_[:, H:2 * H], P_[:, 2 * H:3 * H], P_[:, 3 * H:]
+        mm = A[u] + Bd[v] + C_
+        sg = torch.sigmoid(mm)
+        s1 = torch.zeros(n, H, dtype=P_.dtype).index_add(0, v, sg * Bh[u])
+        s0 = torch.zeros(n, H, dtype=P_.dtype).index_add(0, v, sg)
+        return Ux + s1 / (s0 + 1e-6), mm
+
+    def dual(P_, Pt_, C_, Ct_):
+        """value and tangent as explicit differentiable torch operations (see the LayerNorm test)"""
+        A, Bd, Bh, Ux = P_[:, :H], P_[:, H:2 * H], P_[:, 2 * H:3 * H], P_[:, 3 * H:]
+        At, Bdt, Bht, Uxt = Pt_[:, :H], Pt_[:, H:2 * H], Pt_[:, 2 * H:3 * H], Pt_[:, 3 * H:]
+        mm, mmt = A[u] + Bd[v] + C_, At[u] + Bdt[v] + Ct_
+        sg = torch.sigmoid(mm)
+        sgt = sg * (1 - sg) * mmt
+        z = lambda: torch.zeros(n, H, dtype=P_.dtype)  # noqa: E731
+        s1, s0 = z().index_add(0, v, sg * Bh[u]), z().index_add(0, v, sg)
+        s1t, s0t = z().index_add(0, v, sgt * Bh[u] + sg * Bht[u]), z().index_add(0, v, sgt)
+        h = s1 / (s0 + 1e-6)
+        return (Ux + h, mm), (Uxt + (s1t - h * s0t) / (s0 + 1e-6), mmt)
+
+    Pr, Ptr, Cr, Ctr = (t.clone().requires_grad_(True) for t in (P, Pt, C, Ct))
+    (xp, mm), (xpt, mmt) = dual(Pr, Ptr, Cr, Ctr)
+    fd = [(a_ - b_) / 2e-6 for a_, b_ in zip(fn(P + 1e-6 * Pt, C + 1e-6 * Ct), fn(P - 1e-6 * Pt, C - 1e-6 * Ct))]
+    assert rel_err(xpt, fd[0]) < 1e-6 and rel_err(mmt, fd[1]) < 1e-7
+    ((xp * w_xp).sum() + (xpt * w_xpt).sum() + (mm * w_m).sum() + (mmt * w_mt).sum()).backward()
+
+    Pd = ff2.Dual(_f(P), _f(Pt))
+    Md = ff2.Dual(_f(C[perm]), _f(Ct[perm]))  # canonical slot order
+    xpre = ff2.Dual(torch.empty(n, H, device=DEV), torch.empty(n, H, device=DEV))
+    s0, hh, s0t, hht = (torch.empty(n, H, device=DEV) for _ in range(4))
+    ff2.check(lib.alignn_egc_gate_dual_fwd(ff2.ptr(Pd.p), ff2.ptr(Pd.t), ff2.ptr(Md.p), ff2.ptr(Md.t), ff2.ptr(csr.seg_ptr),
+                                           ff2.ptr(csr.seg_node), ff2.ptr(csr.src), n, m, H, ff2.ptr(xpre.p), ff2.ptr(xpre.t),
+                                           ff2.ptr(s0), ff2.ptr(hh), ff2.ptr(s0t), ff2.ptr(hht), ff2.stream()), "gate")
+    assert rel_err(xpre.p, xp) < 2e-5 and rel_err(xpre.t, xpt) < 2e-5
+    assert rel_err(Md.p[inv], mm) < 2e-6 and rel_err(Md.t[inv], mmt) < 2e-6
+    # reverse: adjoints of (xpre, xpre_t) = (w_xp, w_xpt), of (m, mt) = (w_m, w_mt) as the "LayerNorm branch" input
+    q1, q0, q1t, q0t = (torch.empty(n, H, device=DEV) for _ in range(4))
+    gxp, gxpt = _f(w_xp), _f(w_xpt)
+    ff2.check(lib.alignn_egc_node_dual_bwd(ff2.ptr(gxp), ff2.ptr(gxpt), H, ff2.ptr(s0), ff2.ptr(hh), ff2.ptr(s0t), ff2.ptr(hht),
+                                           ff2.ptr(q1), ff2.ptr(q0), ff2.ptr(q1t), ff2.ptr(q0t), n, H, ff2.stream()), "node")
+    GL = ff2.Dual(_f(w_m[perm]), _f(w_mt[perm]))
+    GM = ff2.Dual(torch.empty(m, H, device=DEV), torch.empty(m, H, device=DEV))
+    GP = ff2.Dual(torch.zeros(n, 4 * H, device=DEV), torch.zeros(n, 4 * H, device=DEV))
+    slabs = lib.alignn_dual_slabs(n)
+    gb = torch.empty(slabs, H, device=DEV)
+    ff2.check(lib.alignn_egc_dual_bwd_dst(ff2.ptr(GL.p), ff2.ptr(GL.t), ff2.ptr(Md.p), ff2.ptr(Md.t), ff2.ptr(Pd.p), ff2.ptr(Pd.t),
+                                          ff2.ptr(q1), ff2.ptr(q0), ff2.ptr(q1t), ff2.ptr(q0t), ff2.ptr(csr.seg_ptr),
+                                          ff2.ptr(csr.seg_node), ff2.ptr(csr.src), n, H, ff2.ptr(GM.p), ff2.ptr(GM.t),
+                                          ff2.ptr(GP.p), ff2.ptr(GP.t), ff2.ptr(gb), None, None, ff2.stream()), "dst")
+    ff2.check(lib.alignn_egc_dual_bwd_src(ff2.ptr(GM.p), ff2.ptr(GM.t), ff2.ptr(Md.p), ff2.ptr(Md.t), ff2.ptr(q1), ff2.ptr(q1t),
+                                          ff2.ptr(csr.out_ptr), ff2.ptr(csr.out_slot), ff2.ptr(csr.dst), n, H, ff2.ptr(GP.p),
+                                          ff2.ptr(GP.t), None, ff2.stream()), "src")
+    GP.p[:, 3 * H:] = gxp  # the Ux block is the adjoint of xpre itself
+    GP.t[:, 3 * H:] = gxpt
+    fl = 1e-2 * float(Pr.grad.abs().max())
+    assert rel_err(GM.p[inv], Cr.grad, fl) < 5e-5 and rel_err(GM.t[inv], Ctr.grad, fl) < 5e-5
+    assert rel_err(GP.p, Pr.grad, fl) < 5e-5 and rel_err(GP.t, Ptr.grad, fl) < 5e-5
+    assert rel_err(gb.sum(0), Cr.grad.sum(0), fl) < 5e-5
+
+
+def test_forward_over_reverse_equals_reverse_over_reverse():
+    """ForcesFn (dual pass) against the composed twice-differentiable path: same energies / forces / stresses, same
+    parameter gradients of an energy + force + stress loss."""
+    from alignn_amd import ALIGNNAtomWise, ALIGNNAtomWiseConfig
+    from alignn_amd import alignn_atomwise as AW
+
+    raw = make_batch(3, 14, seed0=31)
+    raw.r[0] *= 0.3  # one short bond: the penalty branch contributes to the forces
+    raw.r[1] *= 0.3
+    batch = GraphBatch.from_raw(raw, device=DEV)
+    gen = torch.Generator().manual_seed(4)
+    te, tf, ts = (torch.randn(3, generator=gen).to(DEV), torch.randn(raw.num_nodes, 3, generator=gen).to(DEV),
+                  torch.randn(3, 3, 3, generator=gen).to(DEV))
+    outs = []
+    for fused in (True, False):
+        torch.manual_seed(7)
+        cfg = ALIGNNAtomWiseConfig(name="alignn_atomwise", alignn_layers=2, gcn_layers=2, hidden_features=64,
+                                   embedding_features=32, atom_input_features=92, calculate_gradient=True,
+                                   stresswise_weight=0.05)
+        model = ALIGNNAtomWise(cfg).to(DEV).train()
+        with torch.no_grad():
+            for k, p in model.named_parameters():
+                if ".bn_" in k or ".layer.1." in k:
+                    p.add_(0.1 * torch.randn_like(p))
+        AW.FUSED_FORCE_TRAINING = fused
+        try:
+            res = model(batch)
+            L = F.l1_loss
+            loss = L(res["out"], te) + L(res["grad"], tf) + 0.05 * L(res["stresses"], ts)
+            loss.backward()
+        finally:
+            AW.FUSED_FORCE_TRAINING = True
+        outs.append((res, loss.item(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
+    (ra, la, ga), (rb, lb, gb) = outs
+    assert rel_err(ra["out"], rb["out"]) < 1e-5 and rel_err(ra["grad"], rb["grad"]) < 1e-4
+    assert rel_err(ra["stresses"], rb["stresses"]) < 1e-4 and abs(la - lb) < 1e-5
+    assert ga.keys() == gb.keys() and len(ga) > 60
+    gmax = max(float(v.abs().max()) for v in gb.values())
+    worst = 0.0
+    for k in ga:
+        e = float((ga[k] - gb[k]).abs().max()) / max(float(gb[k].abs().max()), 1e-3 * gmax)
+        worst = max(worst, e)
+        assert e < 2e-3, (k, e)
+    print("forward-over-reverse vs reverse-over-reverse: worst per-parameter gradient difference", worst)
