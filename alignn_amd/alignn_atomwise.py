@@ -240,8 +240,6 @@ class ALIGNNAtomWise(nn.Module):
         from . import ff
 
         cfg = self.config
-        if cfg.extra_features != 0:
-            raise NotImplementedError("extra_features != 0 together with training through the forces is outside this build")
         n_a = len(self.alignn_layers)
         x = ff.mlp_layer(b.atom_features, self.atom_embedding)
         r = b.r.detach().clone().requires_grad_(True)  # canonical bond order; :420
@@ -271,7 +269,17 @@ class ALIGNNAtomWise(nn.Module):
         if "atoms_by_graph" not in b.cache:  # (repeat_interleave sizes its output on the host: once per batch)
             b.cache["atoms_by_graph"] = ff.by_graph(b.graph_ptr)
         hpool = ff.segment_sum(x, b.cache["atoms_by_graph"]) / counts.unsqueeze(1)
-        out = torch.squeeze(ff.linear(hpool, self.fc))
+        if cfg.extra_features != 0:
+            # :391-393, 468-475: per-crystal descriptor head (torch modules: twice differentiable as they are).  fc3's
+            # [B,1] output is NOT squeezed upstream, so ``out * natoms`` below broadcasts to [B,B] exactly as it does there
+            if b.extra_features is None:
+                raise ValueError("extra_features != 0 needs g.ndata['extra_features'] (GraphBatch.extra_features)")
+            feats = self.extra_feature_embedding(b.extra_features)
+            h_feat = ff.segment_sum(feats, b.cache["atoms_by_graph"]) / counts.unsqueeze(1)
+            hpool = self.fc2(self.fc1(torch.cat((hpool, h_feat), 1)))
+            out = self.fc3(hpool)
+        else:
+            out = torch.squeeze(ff.linear(hpool, self.fc))
         additional_out = torch.empty(1)
         if cfg.additional_output_features > 0:
             additional_out = ff.linear(hpool, self.fc_additional_output)

@@ -484,8 +484,46 @@ def case_atomwise_cutoff_penalty():
     np.savez_compressed(os.path.join(OUT, "atomwise_cutoff_penalty.npz"), **out)
 
 
+def case_atomwise_extra_forces():
+    """extra_features != 0 TOGETHER with calculate_gradient (alignn_atomwise.py:314-333, 391-393, 468-475 feeding
+    :494-565).  fc3's [B,1] output is not squeezed upstream, so ``en_out = out * natoms`` broadcasts to [B,B] and the
+    pair forces are the gradient of its sum - reproduced as is."""
+    from alignn.models.alignn_atomwise import ALIGNNAtomWise, ALIGNNAtomWiseConfig
+
+    torch.manual_seed(71)
+    cfg = ALIGNNAtomWiseConfig(name="alignn_atomwise", alignn_layers=1, gcn_layers=1, hidden_features=32,
+                               embedding_features=16, atom_input_features=92, calculate_gradient=True,
+                               stresswise_weight=0.05, extra_features=3)
+    model = ALIGNNAtomWise(cfg).train()
+    raw = batch_raw([_one(n, 650 + i, "crystal", 92) for i, n in enumerate((6, 9))])
+    g, lg, lat = to_dgl(raw)
+    vol = np.abs(np.linalg.det(raw.lattice)).astype(np.float32)
+    g.ndata["V"] = torch.from_numpy(np.repeat(vol, raw.batch_num_nodes))
+    extra = torch.randn(raw.num_nodes, 3, generator=torch.Generator().manual_seed(8))
+    g.ndata["extra_features"] = extra
+    out = dict(raw_arrays(raw))
+    out["volume"], out["extra_features"] = vol, extra.numpy()
+    out.update({"sd." + k: v.numpy().copy() for k, v in model.state_dict().items()})
+    res = model((g, lg, lat))
+    gen = torch.Generator().manual_seed(14)
+    te, tf, ts = torch.randn(2, 1, generator=gen), torch.randn(raw.num_nodes, 3, generator=gen), torch.randn(2, 3, 3, generator=gen)
+    L = torch.nn.functional.l1_loss
+    loss = L(res["out"], te) + L(res["grad"], tf) + 0.05 * L(res["stresses"], ts)
+    loss.backward()
+    out.update({"pred": res["out"].detach().numpy(), "forces": res["grad"].detach().numpy(),
+                "stresses": res["stresses"].detach().numpy(), "loss": loss.item(), "t_energy": te.numpy(),
+                "t_forces": tf.numpy(), "t_stress": ts.numpy()})
+    out.update({"grad." + k: p.grad.numpy().copy() for k, p in model.named_parameters() if p.grad is not None})
+    out["nograd"] = np.array([k for k, p in model.named_parameters() if p.grad is None])
+    np.savez_compressed(os.path.join(OUT, "atomwise_extra_forces.npz"), **out)
+    print("extra features + forces: pred", out["pred"].reshape(-1), "|F|max", np.abs(out["forces"]).max(), "loss", loss.item())
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "extraff":
+        case_atomwise_extra_forces()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "cutoff":
         case_atomwise_cutoff_penalty()
         sys.exit(0)
@@ -510,3 +548,4 @@ if __name__ == "__main__":
     case_ealignn()
     case_atomwise_position_branches()
     case_atomwise_cutoff_penalty()
+    case_atomwise_extra_forces()

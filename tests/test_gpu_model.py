@@ -255,9 +255,9 @@ def test_atomwise_vs_oracle_wide_and_guards():
     for k, q in model.named_parameters():
         if p[k].grad is not None:
             assert rel_err(q.grad, p[k].grad, floor=gfloor) < 1e-3, k
-    # options outside the build must refuse loudly, never silently compute something else
+    # the descriptor head needs its input: a batch without extra_features must refuse loudly
     fm = ALIGNNAtomWise(ALIGNNAtomWiseConfig(name="alignn_atomwise", atom_input_features=92, extra_features=3)).to(DEV).train()
-    with pytest.raises(NotImplementedError):  # descriptor head + training through the forces
+    with pytest.raises(ValueError):
         fm(GraphBatch.from_raw(raw, device=DEV))
     # default config (calculate_gradient=True): forces come back with one row per atom
     fd = ALIGNNAtomWise(ALIGNNAtomWiseConfig(name="alignn_atomwise", atom_input_features=92)).to(DEV)
