@@ -228,7 +228,7 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned char* lds_wave_
 // column in a fixed order (lane -> the 4 row groups of a wave by shuffles -> the 2 wave rows through LDS); one [2][N]
 // slab per row tile, summed afterwards by alignn_bn_bwd_finalize (fp64, fixed order): bit-reproducible.
 template <bool HAS_ADD, bool F16, int RM_, bool PERSIST = false, int EPI = 0>
-__global__ __launch_bounds__(NT) void gemm_nt_x6_kernel(X6Args g) {
+__device__ __forceinline__ void gemm_nt_x6_body(const X6Args& g) {
     static_assert(EPI == 0 || !PERSIST, "the reduction epilogue exists for the one-tile kernel only");
     constexpr int NPL = Sch<F16, RM_>::NPL, STAGE_BYTES = Sch<F16, RM_>::STAGE, B_DMA = Sch<F16, RM_>::B_DMA;
     constexpr int RM = Geo<RM_>::RM, BM = Geo<RM_>::BM, TM = Geo<RM_>::TM, A_BYTES = Geo<RM_>::A_BYTES,
@@ -554,6 +554,18 @@ __global__ __launch_bounds__(NT) void gemm_nt_x6_kernel(X6Args g) {
     m0 = tile * BM;
     first = false;
     }  // row tiles
+}
+
+template <bool HAS_ADD, bool F16, int RM_, bool PERSIST = false>
+__global__ __launch_bounds__(NT) void gemm_nt_x6_kernel(X6Args g) {
+    gemm_nt_x6_body<HAS_ADD, F16, RM_, PERSIST, 0>(g);
+}
+// the EPI == 1 variant needs more registers than the compiler's default target leaves for two waves per SIMD (it would
+// settle for one: 170 + 128 accumulator registers); pinning the occupancy makes it allocate within 256 (a handful of
+// spills with an addend).  Not applied to the plain kernel: there it measured 2.6 % slower (356 vs 347 us).
+template <bool HAS_ADD, int RM_>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void gemm_nt_x6_bnred_kernel(X6Args g) {
+    gemm_nt_x6_body<HAS_ADD, true, RM_, false, 1>(g);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -887,18 +899,18 @@ int launch_nt_rm(const X6Args& g, hipStream_t st) {
             constexpr int lds = Sch<F16, RM_>::LDS > EPI1_LDS ? Sch<F16, RM_>::LDS : EPI1_LDS;
             static bool eattr_set = false;
             if (!eattr_set) {
-                hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_x6_kernel<false, true, RM_, false, 1>,
+                hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_x6_bnred_kernel<false, RM_>,
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds);
                 if (e == hipSuccess)
-                    e = hipFuncSetAttribute((const void*)gemm_nt_x6_kernel<true, true, RM_, false, 1>,
+                    e = hipFuncSetAttribute((const void*)gemm_nt_x6_bnred_kernel<true, RM_>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds);
                 if (e != hipSuccess) return (int)e;
                 eattr_set = true;
             }
             if (g.addend)
-                hipLaunchKernelGGL((gemm_nt_x6_kernel<true, true, RM_, false, 1>), grid, dim3(NT), lds, st, g);
+                hipLaunchKernelGGL((gemm_nt_x6_bnred_kernel<true, RM_>), grid, dim3(NT), lds, st, g);
             else
-                hipLaunchKernelGGL((gemm_nt_x6_kernel<false, true, RM_, false, 1>), grid, dim3(NT), lds, st, g);
+                hipLaunchKernelGGL((gemm_nt_x6_bnred_kernel<false, RM_>), grid, dim3(NT), lds, st, g);
             ALIGNN_CHECK_LAUNCH();
             return 0;
         }

@@ -515,6 +515,56 @@ def _dgrad(g, w, addend=None, g_amax=None):
     return project(g, w, None, addend, transpose_w=True, a_amax=g_amax)
 
 
+# BatchNorm-backward reductions taken in the epilogue of the projection that PRODUCES the gradient (see
+# alignn_gemm_nt_f16x3_bnred).  A layer whose output is y = r + silu(BatchNorm(xn)) registers (xn, stat) under y; the layer
+# that consumes y looks the record up in its forward and, in its backward, lets the input-gradient projection of y also
+# reduce gz / gz*xhat over the rows; the result travels to the producer's backward under the identity of the gradient
+# tensor.  Any mismatch (another consumer of y, gradients summed by autograd, a different kernel path) simply finds
+# no record and the producer reduces on its own.
+BNRED_FUSED = True
+BNRED_STATS = {"fused": 0, "used": 0}  # (tests: how often the fused reduction was produced / consumed)
+_NORM_SRC = {}  # id(y)  -> (weakref(y), xn, stat)
+_PRE_RED = {}  # id(gy) -> (weakref(gy), xn, red)
+
+
+def _register_norm_src(y, xn, stat):
+    if y is not None and BNRED_FUSED:
+        k = id(y)
+        _NORM_SRC[k] = (weakref.ref(y, lambda _r, k=k: _NORM_SRC.pop(k, None)), xn, stat)
+
+
+def _norm_src_of(y):
+    e = _NORM_SRC.get(id(y))
+    return (e[1], e[2]) if e is not None and e[0]() is y else None
+
+
+def _take_pre_red(gy, xn):
+    if gy is None:
+        return None
+    e = _PRE_RED.pop(id(gy), None)
+    if e is not None and e[0]() is gy and e[1] is xn:
+        BNRED_STATS["used"] += 1
+        return e[2]
+    return None
+
+
+def _dgrad_bnred(g, w, addend, g_amax, src):
+    """``_dgrad`` that also leaves the BatchNorm-backward reductions of ``src = (xn, stat)`` for the producer of the
+    tensor this gradient belongs to - when the product takes the f16x3 kernel; otherwise plain ``_dgrad``."""
+    lib = _lib.load()
+    M, N, K = g.shape[0], w.shape[1], w.shape[0]
+    ok = (src is not None and BNRED_FUSED and F16X3 and g_amax is not None and g.stride(0) % 4 == 0
+          and ((M + 63) // 64) * ((N + 255) // 256) >= X6_MIN_TILES and lib.alignn_gemm_nt_x6_supported(M, N, K)
+          and tuple(src[0].shape) == (M, N) and src[0].stride(0) % 4 == 0)
+    if not ok:
+        return _dgrad(g, w, addend, g_amax)
+    out, red = gemm_nt_f16x3_bnred(g, g_amax, split_f16x2(w, True), src[0], src[1], None, addend)
+    BNRED_STATS["fused"] += 1
+    k = id(out)
+    _PRE_RED[k] = (weakref.ref(out, lambda _r, k=k: _PRE_RED.pop(k, None)), src[0], red)
+    return out
+
+
 def gemm_tn(g, a, g_amax=None, a_amax=None):
     """dW[N,K] = g[M,N]^T @ a[M,K] (deterministic split over M).  With both maxima known (device scalars) the large
     aligned shapes run the three-product fp16 scheme."""
@@ -751,6 +801,7 @@ class MLPLayerFn(torch.autograd.Function):
             else:
                 stat = _bn_finalize(None, 0, rows, gamma, beta, running_mean, running_var, False)
             y = _bn_silu_fwd(pre, None, stat)
+            _register_norm_src(y, pre, stat)
         return y, pre, stat
 
     @staticmethod
@@ -760,6 +811,7 @@ class MLPLayerFn(torch.autograd.Function):
         lane = _lane_for(x.shape[0])
         ctx.lane = lane is not None
         ctx.x_on_T = _is_on_T(x)  # then x's producer is lane-aware and takes its gradient on lane T
+        ctx.x_src = _norm_src_of(x)  # x = silu(BatchNorm(.)) of the previous layer: see _dgrad_bnred
         if lane is not None:
             with _on_T(*lane, reads=(x,)):
                 y, pre, stat = MLPLayerFn._fwd(ctx, x, w, b, gamma, beta, running_mean, running_var, training, norm)
@@ -781,9 +833,11 @@ class MLPLayerFn(torch.autograd.Function):
         if ctx.norm == "layer":
             red = _ln_silu_bwd(gy, pre, gamma, beta, stat, gpre, g_amax)
         else:
-            red = _bn_silu_bwd_reduce(gy, pre, stat)
+            red = _take_pre_red(gy, pre)
+            if red is None:
+                red = _bn_silu_bwd_reduce(gy, pre, stat)
             _bn_silu_bwd_apply(gy, pre, stat, gamma, red, not ctx.training, gpre, g_amax)
-        gx = _dgrad(gpre, w, g_amax=g_amax) if ctx.needs_input_grad[0] else None
+        gx = _dgrad_bnred(gpre, w, None, g_amax, ctx.x_src) if ctx.needs_input_grad[0] else None
         return gpre, g_amax, red, gx
 
     @staticmethod
@@ -850,6 +904,7 @@ class EdgeGatedConvFn(torch.autograd.Function):
         lane = _lane_for(m)
         ctx.lane = lane is not None
         ctx.y_on_T = _is_on_T(y)
+        ctx.y_src = _norm_src_of(y)  # y = r + silu(BatchNorm(.)) of the previous layer: see _dgrad_bnred
         ctx.x_amax, ctx.y_amax = get_amax(x), get_amax(y)  # tracked by the kernels that produced x and y
         bn_train = training and norm == "batch"
         slabs = lib.alignn_egc_slabs(n)
@@ -882,7 +937,9 @@ class EdgeGatedConvFn(torch.autograd.Function):
                       else _bn_finalize(None, 0, m, e_gamma, e_beta, e_rm, e_rv, False))
             # need_y == False: the caller discards the edge output (last layer) - skip the pass, keep the
             # statistics side effect (running_mean/var of bn_edges are updated exactly as in the reference)
-            return (_bn_silu_fwd(M, y if residual else None, e_stat) if need_y else None), e_stat
+            y_o = _bn_silu_fwd(M, y if residual else None, e_stat) if need_y else None
+            _register_norm_src(y_o, M, e_stat)
+            return y_o, e_stat
 
         if lane is not None:
             main, T = lane
@@ -964,7 +1021,9 @@ class EdgeGatedConvFn(torch.autograd.Function):
                     e_red = _ln_silu_bwd(gy_out, M, e_gamma, e_beta, e_stat, g_branch)
                     e_stat_arg = None
                 else:
-                    e_red = _bn_silu_bwd_reduce(gy_out, M, e_stat)
+                    e_red = _take_pre_red(gy_out, M)  # left by the layer that produced gy_out, if it could
+                    if e_red is None:
+                        e_red = _bn_silu_bwd_reduce(gy_out, M, e_stat)
             return e_red, g_branch, e_stat_arg
 
         def gate_backward(e_red, g_branch, e_stat_arg):
@@ -1009,7 +1068,7 @@ class EdgeGatedConvFn(torch.autograd.Function):
             return GM, gb_part, gslabs
 
         def edge_dgrad(GM):
-            return _dgrad(GM, w_eg, addend=gy_out if (ctx.residual and gy_out is not None) else None, g_amax=gm_amax)
+            return _dgrad_bnred(GM, w_eg, gy_out if (ctx.residual and gy_out is not None) else None, gm_amax, ctx.y_src)
 
         ev_d = None
         if ctx.lane:
