@@ -51,7 +51,9 @@ __device__ __forceinline__ void block_slab_store(float4 s, float4 ss, float* sla
 // mode: e_stat = mean, rstd, scale, shift from the running statistics), so the edge output
 // y' = y + silu((m - mean) * scale + shift) is written straight from the gate pass and m itself never goes to memory:
 // 1 read of C (+ 1 of y) + 1 write instead of read C, write m, read m, read y, write y'.
-template <bool STREAM, bool INFER>
+// PRE: M already holds m = A[u] + Bd[v] + C (the edge projection added the two gathered rows in its epilogue,
+// alignn_gemm_nt_f16x3_gather): the pass only reads it - no A / Bd loads, no store of m.
+template <bool STREAM, bool INFER, bool PRE = false>
 __global__ __launch_bounds__(kThreads) void egc_gate_fwd_kernel(
     const float* __restrict__ P, float* __restrict__ M, const int32_t* __restrict__ seg_ptr,
     const int32_t* __restrict__ seg_node, const int32_t* __restrict__ src, int n_seg, int H,
@@ -93,13 +95,13 @@ __global__ __launch_bounds__(kThreads) void egc_gate_fwd_kernel(
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const float* Pu = P + (int64_t)u[k] * ldp;
-                        a[k] = f4_ld(Pu + f);
+                        if (!PRE) a[k] = f4_ld(Pu + f);
                         bh[k] = f4_ld(Pu + 2 * H + f);
                         c[k] = f4_lds<STREAM>(M + (int64_t)(e + k) * H + f);
                     }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        float4 m = f4_add(f4_add(a[k], bd), c[k]);
+                        float4 m = PRE ? c[k] : f4_add(f4_add(a[k], bd), c[k]);
                         if (INFER) {
                             if (YOUT) {
                                 const float4 zz = f4_fma(f4_sub(m, e_mean), e_sc, e_sh);
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(kThreads) void egc_gate_fwd_kernel(
                                 f4_sts<STREAM>(YOUT + (int64_t)(e + k) * H + f, o);
                                 y_am = fmaxf(y_am, f4_absmax(o));
                             }
-                        } else {
+                        } else if (!PRE) {
                             f4_sts<STREAM>(M + (int64_t)(e + k) * H + f, m);
                         }
                         float4 sg = f4_sigmoid(m);
@@ -120,7 +122,8 @@ __global__ __launch_bounds__(kThreads) void egc_gate_fwd_kernel(
                 }
                 for (; e < end; ++e) {
                     const float* Pu = P + (int64_t)src[e] * ldp;
-                    float4 m = f4_add(f4_add(f4_ld(Pu + f), bd), f4_lds<STREAM>(M + (int64_t)e * H + f));
+                    float4 m = f4_lds<STREAM>(M + (int64_t)e * H + f);
+                    if (!PRE) m = f4_add(f4_add(f4_ld(Pu + f), bd), m);
                     if (INFER) {
                         if (YOUT) {
                             const float4 zz = f4_fma(f4_sub(m, e_mean), e_sc, e_sh);
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(kThreads) void egc_gate_fwd_kernel(
                             f4_sts<STREAM>(YOUT + (int64_t)e * H + f, o);
                             y_am = fmaxf(y_am, f4_absmax(o));
                         }
-                    } else {
+                    } else if (!PRE) {
                         f4_sts<STREAM>(M + (int64_t)e * H + f, m);
                     }
                     float4 sg = f4_sigmoid(m);
@@ -617,6 +620,22 @@ int alignn_egc_gate_fwd(const float* P, float* M, const int32_t* seg_ptr, const 
                            n_partial, nullptr, nullptr, nullptr, nullptr);
     else
         hipLaunchKernelGGL((egc_gate_fwd_kernel<false, false>), dim3(egc_blocks(n_seg)), dim3(kThreads), 0,
+                           (hipStream_t)stream, P, M, seg_ptr, seg_node, src, (int)n_seg, H, XPRE, S0, HH, e_partial,
+                           n_partial, nullptr, nullptr, nullptr, nullptr);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_egc_gate_fwd_pre(const float* P, float* M, const int32_t* seg_ptr, const int32_t* seg_node,
+                            const int32_t* src, int64_t n_seg, int64_t m_rows, int H, float* XPRE, float* S0, float* HH,
+                            float* e_partial, float* n_partial, alignn_stream_t stream) {
+    if (!h_ok(H) || n_seg < 0 || n_seg > INT32_MAX || m_rows < 0) return (int)hipErrorInvalidValue;
+    if (big_stream(m_rows, H))
+        hipLaunchKernelGGL((egc_gate_fwd_kernel<true, false, true>), dim3(egc_blocks(n_seg)), dim3(kThreads), 0,
+                           (hipStream_t)stream, P, M, seg_ptr, seg_node, src, (int)n_seg, H, XPRE, S0, HH, e_partial,
+                           n_partial, nullptr, nullptr, nullptr, nullptr);
+    else
+        hipLaunchKernelGGL((egc_gate_fwd_kernel<false, false, true>), dim3(egc_blocks(n_seg)), dim3(kThreads), 0,
                            (hipStream_t)stream, P, M, seg_ptr, seg_node, src, (int)n_seg, H, XPRE, S0, HH, e_partial,
                            n_partial, nullptr, nullptr, nullptr, nullptr);
     ALIGNN_CHECK_LAUNCH();

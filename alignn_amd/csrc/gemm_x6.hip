@@ -125,6 +125,11 @@ struct X6Args {
     int64_t ldxn;
     const float* nstat;  // [4][N]: mean, rstd, gamma*rstd, beta
     float* red_partial;  // [row tiles][2][N]: per-tile column sums of gz and gz*xhat
+    // EPI == 2 (edge-gate projection of EdgeGatedGraphConv: the output row e also gets A[src e] + Bd[dst e]):
+    const float* gp;      // node projection P = [A | Bd | Bh | Ux], rows of ldgp floats; A at column 0, Bd at column N
+    int64_t ldgp;
+    const int32_t* gsrc;  // [M] source node of edge row e
+    const int32_t* gdst;  // [M] destination node of edge row e
 };
 
 __device__ __forceinline__ unsigned hi_pair(float x1, float x0) {
@@ -230,6 +235,10 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned char* lds_wave_
 template <bool HAS_ADD, bool F16, int RM_, bool PERSIST = false, int EPI = 0>
 __device__ __forceinline__ void gemm_nt_x6_body(const X6Args& g) {
     static_assert(EPI == 0 || !PERSIST, "the reduction epilogue exists for the one-tile kernel only");
+    static_assert(EPI != 2 || !HAS_ADD, "EPI == 2 has its own two addends");
+    // EPI == 2: C[e] = A-row . W + b  +  P[src e].A + P[dst e].Bd  - the u_add_v of the convolution
+    // (alignn/models/alignn.py:100-101) folded into the projection that produces the third addend, so that m never
+    // makes the round trip "write C, read C, write m".  (a + bd) + c is evaluated as c + (a + bd): same bits.
     constexpr int NPL = Sch<F16, RM_>::NPL, STAGE_BYTES = Sch<F16, RM_>::STAGE, B_DMA = Sch<F16, RM_>::B_DMA;
     constexpr int RM = Geo<RM_>::RM, BM = Geo<RM_>::BM, TM = Geo<RM_>::TM, A_BYTES = Geo<RM_>::A_BYTES,
                   A_DMA = Geo<RM_>::A_DMA;
@@ -473,6 +482,19 @@ __device__ __forceinline__ void gemm_nt_x6_body(const X6Args& g) {
         }
         // all global loads of the round are issued before its first store (vmcnt retires in order and counts stores: a
         // load behind a store would make its consumer wait for that store)
+        if constexpr (EPI == 2) {
+            int ui[8], vi[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                int64_t row = row0 + i * 4;
+                if (row >= g.M) row = g.M - 1;
+                ui[i] = g.gsrc[row];
+                vi[i] = g.gdst[row];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                av[i] = f4_add(f4_ld(g.gp + (int64_t)ui[i] * g.ldgp + colc), f4_ld(g.gp + (int64_t)vi[i] * g.ldgp + g.N + colc));
+        }
         if (HAS_ADD) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -499,7 +521,7 @@ __device__ __forceinline__ void gemm_nt_x6_body(const X6Args& g) {
             float4 v = ov[EPI == 1 ? 0 : i];
             if constexpr (F16) v = f4_scale(f4_scale(v, inv_sa), inv_sw);
             v = f4_add(v, bias_v[hb]);
-            if (HAS_ADD) v = f4_add(v, av[i]);
+            if (HAS_ADD || EPI == 2) v = f4_add(v, av[i]);
             if (row < g.M && col < g.N && (!X6_ABL_NOSTORE || v.x == 12345.678f)) {
                 if (g.stream_out)
                     f4_sts<true>(g.C + row * g.ldc + col, v);
@@ -566,6 +588,10 @@ __global__ __launch_bounds__(NT) void gemm_nt_x6_kernel(X6Args g) {
 template <bool HAS_ADD, int RM_>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void gemm_nt_x6_bnred_kernel(X6Args g) {
     gemm_nt_x6_body<HAS_ADD, true, RM_, false, 1>(g);
+}
+template <int RM_>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void gemm_nt_x6_gather_kernel(X6Args g) {
+    gemm_nt_x6_body<false, true, RM_, false, 2>(g);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -877,7 +903,7 @@ int launch_nt_rm(const X6Args& g, hipStream_t st) {
         constexpr int kResident = 512;
         const int ny = g.Npad / BN;
         // (without addend only: the addend variant needs 292 registers per lane in this form - one wave per SIMD)
-        if (!g.addend && !g.red_partial && g.N == g.Npad && ((g.K / BK) & 1) == 0 && (int64_t)grid.x * ny >= 4 * kResident &&
+        if (!g.addend && !g.red_partial && !g.gp && g.N == g.Npad && ((g.K / BK) & 1) == 0 && (int64_t)grid.x * ny >= 4 * kResident &&
             ny <= kResident) {
             constexpr int plds = Sch<F16, RM_>::LDS_PERSIST;
             static bool pattr_set = false;
@@ -911,6 +937,20 @@ int launch_nt_rm(const X6Args& g, hipStream_t st) {
                 hipLaunchKernelGGL((gemm_nt_x6_bnred_kernel<true, RM_>), grid, dim3(NT), lds, st, g);
             else
                 hipLaunchKernelGGL((gemm_nt_x6_bnred_kernel<false, RM_>), grid, dim3(NT), lds, st, g);
+            ALIGNN_CHECK_LAUNCH();
+            return 0;
+        }
+    }
+    if constexpr (F16) {
+        if (g.gp != nullptr) {  // gather-add of the two node rows in the epilogue (EPI == 2)
+            static bool gattr_set = false;
+            if (!gattr_set) {
+                hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_x6_gather_kernel<RM_>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                if (e != hipSuccess) return (int)e;
+                gattr_set = true;
+            }
+            hipLaunchKernelGGL((gemm_nt_x6_gather_kernel<RM_>), grid, dim3(NT), lds, st, g);
             ALIGNN_CHECK_LAUNCH();
             return 0;
         }
@@ -1037,7 +1077,7 @@ int alignn_gemm_nt_x6(const float* A, int64_t lda, const void* Wsplit, const flo
     if (!alignn_gemm_nt_x6_supported(M, N, K)) return (int)hipErrorInvalidValue;
     if (!nt_args_ok(A, lda, Wsplit, bias, addend, ldadd, C, ldc)) return (int)hipErrorInvalidValue;
     X6Args g{A, lda, (const unsigned char*)Wsplit, nullptr, nullptr, bias, addend, ldadd, C, ldc, M, N, npad(N), K,
-             M * (int64_t)N * 4 >= ((int64_t)128 << 20), nullptr, 0, nullptr, nullptr};
+             M * (int64_t)N * 4 >= ((int64_t)128 << 20), nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr};
     return launch_nt<false>(g, (hipStream_t)stream);
 }
 
@@ -1047,7 +1087,19 @@ int alignn_gemm_nt_f16x3(const float* A, int64_t lda, const float* a_amax, const
     if (!alignn_gemm_nt_x6_supported(M, N, K) || a_amax == nullptr || w_amax == nullptr) return (int)hipErrorInvalidValue;
     if (!nt_args_ok(A, lda, Wsplit, bias, addend, ldadd, C, ldc)) return (int)hipErrorInvalidValue;
     X6Args g{A, lda, (const unsigned char*)Wsplit, a_amax, w_amax, bias, addend, ldadd, C, ldc, M, N, npad(N), K,
-             M * (int64_t)N * 4 >= ((int64_t)128 << 20), nullptr, 0, nullptr, nullptr};
+             M * (int64_t)N * 4 >= ((int64_t)128 << 20), nullptr, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr};
+    return launch_nt<true>(g, (hipStream_t)stream);
+}
+
+int alignn_gemm_nt_f16x3_gather(const float* A, int64_t lda, const float* a_amax, const void* Wsplit, const float* w_amax,
+                                const float* bias, float* C, int64_t ldc, int64_t M, int N, int K, const float* P, int64_t ldp,
+                                const int32_t* src, const int32_t* dst, alignn_stream_t stream) {
+    if (!alignn_gemm_nt_x6_supported(M, N, K) || a_amax == nullptr || w_amax == nullptr) return (int)hipErrorInvalidValue;
+    if (!nt_args_ok(A, lda, Wsplit, bias, nullptr, 0, C, ldc)) return (int)hipErrorInvalidValue;
+    if (P == nullptr || src == nullptr || dst == nullptr || (ldp & 3) || !a16(P) || (N & 3) || ldp < 2 * (int64_t)N)
+        return (int)hipErrorInvalidValue;
+    X6Args g{A, lda, (const unsigned char*)Wsplit, a_amax, w_amax, bias, nullptr, 0, C, ldc, M, N, npad(N), K,
+             M * (int64_t)N * 4 >= ((int64_t)128 << 20), nullptr, 0, nullptr, nullptr, P, ldp, src, dst};
     return launch_nt<true>(g, (hipStream_t)stream);
 }
 
@@ -1063,7 +1115,7 @@ int alignn_gemm_nt_f16x3_bnred(const float* A, int64_t lda, const float* a_amax,
         !a16(red_partial))
         return (int)hipErrorInvalidValue;
     X6Args g{A, lda, (const unsigned char*)Wsplit, a_amax, w_amax, bias, addend, ldadd, C, ldc, M, N, npad(N), K,
-             M * (int64_t)N * 4 >= ((int64_t)128 << 20), Xn, ldxn, nstat, red_partial};
+             M * (int64_t)N * 4 >= ((int64_t)128 << 20), Xn, ldxn, nstat, red_partial, nullptr, 0, nullptr, nullptr};
     return launch_nt<true>(g, (hipStream_t)stream);
 }
 

@@ -454,6 +454,33 @@ def gemm_nt_f16x3_bnred(a, a_amax, ws, xn, nstat, bias=None, addend=None, out=No
     return out, red
 
 
+GATHER_FUSED = True  # EdgeGatedGraphConv: u_add_v folded into the edge-gate projection (tests flip it to compare: same bits)
+
+
+def _f16x3_applies(a, a_amax, N, K):
+    """Would ``project`` run this product on the three-product fp16 kernel?"""
+    lib = _lib.load()
+    M = a.shape[0]
+    return (F16X3 and a_amax is not None and a.stride(0) % 4 == 0 and ((M + 63) // 64) * ((N + 255) // 256) >= X6_MIN_TILES
+            and bool(lib.alignn_gemm_nt_x6_supported(M, N, K)))
+
+
+def gemm_nt_f16x3_gather(a, a_amax, ws, bias, P, src, dst, out=None):
+    """out[e] = a[e] @ W^T + bias + P[src[e], 0:N] + P[dst[e], N:2N]  (edge-gate projection + DGL u_add_v in one pass)."""
+    lib = _lib.load()
+    require_f32(a, bias, P)
+    M, K = a.shape
+    N = ws.n
+    if out is None:
+        out = _empty(M, N, like=a)
+    check(
+        lib.alignn_gemm_nt_f16x3_gather(ptr(a), a.stride(0), ptr(a_amax), ptr(ws.buf), ptr(ws.amax), ptr(bias), ptr(out),
+                                        out.stride(0), M, N, K, ptr(P), P.stride(0), ptr(src), ptr(dst), stream()),
+        "gemm_nt_f16x3_gather",
+    )
+    return out
+
+
 def gemm_nt_x6(a, ws, bias=None, addend=None, out=None):
     """out[M,N] = a[M,K] @ W[N,K]^T with W pre-sliced by ``split_bf16x3`` (fp32-grade accuracy, bf16 MFMA)."""
     lib = _lib.load()
@@ -916,15 +943,23 @@ class EdgeGatedConvFn(torch.autograd.Function):
         hh = _empty(n, H, like=x)
         n_part = _empty(slabs, 2, H, like=x) if bn_train else None
 
+        # u_add_v inside the edge projection's epilogue when that projection runs on the f16x3 kernel (the T- and E-row
+        # convolutions of a real batch): M leaves the GEMM as m = A[u] + Bd[v] + C and the gate pass only reads it
+        pre_added = GATHER_FUSED and w_eg.shape[0] == H and _f16x3_applies(y, ctx.y_amax, H, w_eg.shape[1])
+
         def edge_side():
-            M = project(y, w_eg, b_eg, a_amax=ctx.y_amax)  # [m,H]  -> m_pre in place
+            if pre_added:
+                M = gemm_nt_f16x3_gather(y, ctx.y_amax, split_f16x2(w_eg), b_eg, P, graph.src, graph.dst)
+            else:
+                M = project(y, w_eg, b_eg, a_amax=ctx.y_amax)  # [m,H]  -> m_pre in place
             e_part = _empty(slabs, 2, H, like=x) if bn_train else None
             return M, e_part
 
         def gate(M, e_part):
+            fn = lib.alignn_egc_gate_fwd_pre if pre_added else lib.alignn_egc_gate_fwd
             check(
-                lib.alignn_egc_gate_fwd(ptr(P), ptr(M), ptr(graph.seg_ptr), ptr(graph.seg_node), ptr(graph.src), n, m, H,
-                                        ptr(xpre), ptr(s0), ptr(hh), ptr(e_part), ptr(n_part), stream()),
+                fn(ptr(P), ptr(M), ptr(graph.seg_ptr), ptr(graph.seg_node), ptr(graph.src), n, m, H, ptr(xpre), ptr(s0),
+                   ptr(hh), ptr(e_part), ptr(n_part), stream()),
                 "egc_gate_fwd",
             )
 
@@ -948,6 +983,8 @@ class EdgeGatedConvFn(torch.autograd.Function):
                 if t is not None:
                     t.record_stream(T)
             with _on_T(main, T, reads=(y,)):
+                if pre_added:
+                    T.wait_event(ev_p)  # (the projection itself reads P now)
                 M, e_part = edge_side()
                 T.wait_event(ev_p)
                 gate(M, e_part)

@@ -115,6 +115,18 @@ int alignn_gemm_nt_f16x3(const float* A, int64_t lda, const float* a_amax, const
  * into red_partial [row_tiles][2][N] (nstat = [4][N] as written by alignn_bn_finalize).  alignn_bn_bwd_finalize
  * over `alignn_gemm_nt_x6_row_tiles(M, N, K)` slabs then gives dbeta / dgamma - what alignn_bn_silu_bwd_reduce
  * computes with two more passes over g_y and Xn. */
+/* The edge-gate projection of EdgeGatedGraphConv with DGL's u_add_v folded in (alignn/models/alignn.py:98-101:
+ * m = src_gate(x)[u] + dst_gate(x)[v] + edge_gate(y)):  C[e] = A[e] W^T + bias + P[src[e]][0:N] + P[dst[e]][N:2N],
+ * P = the fused node projection [n, ldp] = A | Bd | Bh | Ux.  alignn_egc_gate_fwd_pre is the gate pass that takes such
+ * an M (already m: it neither gathers A / Bd nor stores m) - same values, one write and one gather of a T-row
+ * tensor less than alignn_gemm_nt_f16x3 + alignn_egc_gate_fwd. */
+int alignn_gemm_nt_f16x3_gather(const float* A, int64_t lda, const float* a_amax, const void* Wsplit,
+                                const float* w_amax, const float* bias, float* C, int64_t ldc, int64_t M, int N, int K,
+                                const float* P, int64_t ldp, const int32_t* src, const int32_t* dst,
+                                alignn_stream_t stream);
+int alignn_egc_gate_fwd_pre(const float* P, float* M, const int32_t* seg_ptr, const int32_t* seg_node,
+                            const int32_t* src, int64_t n_seg, int64_t m_rows, int H, float* XPRE, float* S0, float* HH,
+                            float* e_partial, float* n_partial, alignn_stream_t stream);
 int alignn_gemm_nt_x6_row_tiles(int64_t M, int N, int K);
 int alignn_gemm_nt_f16x3_bnred(const float* A, int64_t lda, const float* a_amax, const void* Wsplit,
                                const float* w_amax, const float* bias, const float* addend, int64_t ldadd,

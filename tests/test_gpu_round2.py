@@ -476,3 +476,29 @@ def test_training_loop_of_the_reference_with_the_drop_in_model():
         err = np.abs(mine - ref).max() / np.abs(ref).max()
         print(f"history_{name}: ours {mine[:, 0].tolist()} reference {ref[:, 0].tolist()} (max rel. difference {err:.2e})")
         assert err < 1e-3, (name, mine, ref)
+
+
+def test_u_add_v_in_the_projection_epilogue_gives_the_same_bits():
+    """alignn_gemm_nt_f16x3_gather + alignn_egc_gate_fwd_pre against alignn_gemm_nt_f16x3 + alignn_egc_gate_fwd:
+    m = (A[u] + Bd[v]) + C either way, so a whole training step is bit-identical."""
+    raw = make_batch(16, 60, seed0=92)
+    batch = GraphBatch.from_raw(raw, device=DEV)
+    target = torch.randn(16, generator=torch.Generator().manual_seed(4)).to(DEV)
+    res = {}
+    for fused in (True, False):
+        ops.GATHER_FUSED = fused
+        try:
+            torch.manual_seed(0)
+            model = ALIGNN(ALIGNNConfig(name="alignn")).to(DEV).train()
+            pred = model(batch)
+            torch.nn.functional.l1_loss(pred, target).backward()
+            torch.cuda.synchronize()
+        finally:
+            ops.GATHER_FUSED = True
+        res[fused] = (pred.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None},
+                      {k: v.clone() for k, v in model.state_dict().items() if "running" in k})
+    assert torch.equal(res[True][0], res[False][0])
+    for k in res[False][1]:
+        assert torch.equal(res[True][1][k], res[False][1][k]), k
+    for k in res[False][2]:
+        assert torch.equal(res[True][2][k], res[False][2][k]), k
