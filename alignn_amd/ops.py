@@ -397,6 +397,20 @@ def split_f16x2(w, transpose=False):
 KERNEL_TIMER = None  # bench.py: {"min_rows": r, "events": []} -> HIP events around every f16x3 NT launch of >= r rows
 
 
+def _timed(label, M, N, K, launch):
+    """Run ``launch()``; with bench.py's KERNEL_TIMER armed and M large enough, bracket it with HIP events."""
+    t = KERNEL_TIMER
+    if t is None or M < t["min_rows"]:
+        return launch()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    try:
+        return launch()
+    finally:
+        ev1.record()
+        t["events"].append((label, N, K, ev0, ev1))
+
+
 def gemm_nt_f16x3(a, a_amax, ws, bias=None, addend=None, out=None):
     """out[M,N] = a[M,K] @ W[N,K]^T with W pre-sliced by ``split_f16x2`` and ``a_amax`` >= max|a| (device scalar)."""
     lib = _lib.load()
@@ -407,15 +421,8 @@ def gemm_nt_f16x3(a, a_amax, ws, bias=None, addend=None, out=None):
         raise ValueError(f"reduction length mismatch: {K} vs {ws.k}")
     if out is None:
         out = _empty(M, N, like=a)
-    if KERNEL_TIMER is not None and M >= KERNEL_TIMER["min_rows"]:
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
-        try:
-            return _gemm_nt_f16x3_launch(lib, a, a_amax, ws, bias, addend, out, M, N, K)
-        finally:
-            ev1.record()
-            KERNEL_TIMER["events"].append((N, K, addend is not None, ev0, ev1))
-    return _gemm_nt_f16x3_launch(lib, a, a_amax, ws, bias, addend, out, M, N, K)
+    return _timed("addend" if addend is not None else "plain", M, N, K,
+                  lambda: _gemm_nt_f16x3_launch(lib, a, a_amax, ws, bias, addend, out, M, N, K))
 
 
 def _gemm_nt_f16x3_launch(lib, a, a_amax, ws, bias, addend, out, M, N, K):
@@ -443,12 +450,12 @@ def gemm_nt_f16x3_bnred(a, a_amax, ws, xn, nstat, bias=None, addend=None, out=No
         out = _empty(M, N, like=a)
     tiles = lib.alignn_gemm_nt_x6_row_tiles(M, N, K)
     partial = _empty(tiles, 2, N, like=a)
-    check(
+    _timed("bnred_addend" if addend is not None else "bnred", M, N, K, lambda: check(
         lib.alignn_gemm_nt_f16x3_bnred(ptr(a), a.stride(0), ptr(a_amax), ptr(ws.buf), ptr(ws.amax), ptr(bias), ptr(addend),
                                        addend.stride(0) if addend is not None else 0, ptr(out), out.stride(0), M, N, K,
                                        ptr(xn), xn.stride(0), ptr(nstat), ptr(partial), stream()),
         "gemm_nt_f16x3_bnred",
-    )
+    ))
     red = _empty(2, N, like=a)
     check(lib.alignn_bn_bwd_finalize(ptr(partial), tiles, N, ptr(red), stream()), "bn_bwd_finalize")
     return out, red
@@ -473,11 +480,11 @@ def gemm_nt_f16x3_gather(a, a_amax, ws, bias, P, src, dst, out=None):
     N = ws.n
     if out is None:
         out = _empty(M, N, like=a)
-    check(
+    _timed("gather", M, N, K, lambda: check(
         lib.alignn_gemm_nt_f16x3_gather(ptr(a), a.stride(0), ptr(a_amax), ptr(ws.buf), ptr(ws.amax), ptr(bias), ptr(out),
                                         out.stride(0), M, N, K, ptr(P), P.stride(0), ptr(src), ptr(dst), stream()),
         "gemm_nt_f16x3_gather",
-    )
+    ))
     return out
 
 

@@ -24,12 +24,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 H = 256
-# HBM bytes per launch of the dominant kernel at this exact shape (T=676 200 rows), from rocprofv3 PMC passes
-# (profiles/r01_pmc_split_gemm.txt; separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of tools/x6_once.py):
-# FETCH_SIZE 342.0 MiB (f16x3) / 352.3 MiB (bf16x6), doubled as MI355X_MICROARCH.md prescribes for 16 B/lane
-# streaming reads on gfx950, + WRITE_SIZE 660.4 MiB.  PMC cannot be sampled from inside this process, so the
-# measured value is carried here and only reported when the workload matches the one it was measured on.
-PMC_TRAFFIC_F16X3_T676200 = (2 * 350220.9 + 676200.0) * 1024
+# HBM bytes per launch of the dominant kernel at this exact shape (T=676 200 rows), from rocprofv3 PMC passes over
+# bench.py itself (separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs, profiles/r02_pmc_fetch_size.txt /
+# r02_pmc_write_size.txt: the 32 T-row launches of gemm_nt_x6_kernel<false,true,2>): FETCH_SIZE 335.0 MiB, doubled as
+# MI355X_MICROARCH.md prescribes for 16 B/lane streaming reads on gfx950, + WRITE_SIZE 660.6 MiB = 1.395 GB against
+# 1.385 GB algorithmic.  (bf16x6 variant: round-1 measurement, profiles/r01_pmc_split_gemm.txt.)  PMC cannot be sampled
+# from inside this process, so the measured value is carried here and only reported when the workload matches.
+PMC_TRAFFIC_F16X3_T676200 = (2 * 335.0 + 660.6) * 1048576
 PMC_TRAFFIC_X6_T676200 = (2 * 360721.0 + 676200.0) * 1024
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F32_PEAK_TF = 157.3  # v_mfma_f32_32x32x2_f32 dense peak
@@ -362,14 +363,24 @@ def main():
             ev = ops.KERNEL_TIMER["events"] if rank == 0 else []
         finally:
             ops.KERNEL_TIMER = None
-        plain = [a.elapsed_time(b) for (n_, k_, add, a, b) in ev if n_ == H and k_ == H and not add]
-        added = [a.elapsed_time(b) for (n_, k_, add, a, b) in ev if n_ == H and k_ == H and add]
-        if plain:
-            in_step = {"launches": len(plain), "ms_per_launch": round(sum(plain) / len(plain), 4),
-                       "min_ms": round(min(plain), 4), "max_ms": round(max(plain), 4),
-                       "with_residual_addend": {"launches": len(added), "ms_per_launch": round(sum(added) / max(len(added), 1), 4)},
-                       "how": "HIP events on the launch stream around every T-row launch (M=T, N=K=256) of one eagerly "
-                              "launched training step; side-stream weight-gradient GEMMs share the CUs"}
+        # T-row launches of the f16x3 NT kernel family by epilogue variant; algorithmic rows moved per output row:
+        # plain (read A, write C) 2; addend 3; gather (+ the A[u] row per edge, Bd[v] is constant per segment) 3;
+        # bnred (+ the pre-activation read for the BatchNorm-backward sums) 3, with addend 4
+        rows_moved = {"plain": 2, "addend": 3, "gather": 3, "bnred": 3, "bnred_addend": 4}
+        by = {}
+        for (label, n_, k_, e0, e1) in ev:
+            if n_ == H and k_ == H:
+                by.setdefault(label, []).append(e0.elapsed_time(e1))
+        if by:
+            row_bytes = raw.num_triplets * H * 4.0
+            in_step = {"how": "HIP events on the launch stream around every T-row launch (M=T, N=K=256) of one eagerly "
+                              "launched training step, by epilogue variant; side-stream weight-gradient GEMMs share the CUs"}
+            for label, ts in sorted(by.items()):
+                ms_ = sum(ts) / len(ts)
+                gbs_ = rows_moved[label] * row_bytes / (ms_ * 1e-3) / 1e9
+                in_step[label] = {"launches": len(ts), "ms_per_launch": round(ms_, 4), "min_ms": round(min(ts), 4),
+                                  "max_ms": round(max(ts), 4), "algorithmic_rows_per_output_row": rows_moved[label],
+                                  "GBps": round(gbs_, 1), "frac": round(gbs_ / HBM_PEAK_GBS, 4)}
 
     # ---- streamed batches (informational, N=1): a FRESH batch every step through alignn_amd.loader - one pinned
     # 2.4 MB buffer per batch over PCIe, CSR + L(g) + cosines rebuilt on a staging stream under the previous step.
@@ -457,16 +468,14 @@ def main():
             "eager_launches": eager,
             "roofline": {
                 "kernel": "gemm_nt_x6_kernel<*,true> (line-graph edge_gate projection, M=T, N=K=256, f16x3 split product)",
-                "in_step": None if in_step is None else dict(
-                    in_step, GBps=round(gemm_bytes / (in_step["ms_per_launch"] * 1e-3) / 1e9, 1),
-                    frac=round(gemm_bytes / (in_step["ms_per_launch"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)),
+                "in_step": in_step,
                 "bound": "hbm",
                 "achieved": round(gbs, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(gbs / HBM_PEAK_GBS, 4),
                 "traffic": PMC_TRAFFIC_F16X3_T676200 if T == 676200 else None,
-                "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + --pmc WRITE_SIZE, profiles/r01_pmc_split_gemm.txt",
+                "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + --pmc WRITE_SIZE over bench.py, profiles/r02_pmc_fetch_size.txt + r02_pmc_write_size.txt",
                 "ms_per_launch": round(t_h3, 4),
                 "algorithmic_bytes_per_launch": gemm_bytes,
                 "equivalent_fp32_TFLOPs": round(flops / (t_h3 * 1e-3) / 1e12, 1),
