@@ -29,7 +29,7 @@ import torch
 
 from .graph import GraphBatch, _ptr_from_counts, build_csr, line_graph_of
 
-__all__ = ["knn_multigraph", "crystal_batch"]
+__all__ = ["knn_multigraph", "knn_multigraph_batch", "crystal_batch"]
 
 
 def _all_neighbors(lat: torch.Tensor, frac: torch.Tensor, cutoff: float):
@@ -88,21 +88,74 @@ def knn_multigraph(lat, frac, cutoff: float = 8.0, max_neighbors: int = 12, devi
     return u, v, r
 
 
+def knn_multigraph_batch(lattices: Sequence, fracs: Sequence, cutoff: float = 8.0, max_neighbors: int = 12, device=None):
+    """``knn_multigraph`` for a whole batch of crystals at once: -> ``(u, v, r, num_nodes)`` with the bonds of crystal
+    0, 1, ... concatenated (atom ids offset): the same bond list in the same order as running ``knn_multigraph`` per
+    crystal and concatenating (index arrays equal, bond vectors equal to the last bit or two).  The crystals are padded to a common atom count and share one image grid (the largest
+    reach of the batch), so the host is consulted twice per BATCH (that reach; "does any site still lack neighbours")
+    instead of twice per crystal."""
+    dev = torch.device(device) if device is not None else torch.as_tensor(fracs[0]).device
+    B = len(fracs)
+    ns = [int(torch.as_tensor(f).shape[0]) for f in fracs]
+    nmax = max(ns)
+    lat = torch.stack([torch.as_tensor(x).to(dev, torch.float64) for x in lattices])  # [B,3,3]
+    frac = torch.zeros(B, nmax, 3, dtype=torch.float64, device=dev)
+    for b, f in enumerate(fracs):
+        frac[b, :ns[b]] = torch.as_tensor(f).to(dev, torch.float64)
+    n_t = torch.tensor(ns, device=dev)
+    real = torch.arange(nmax, device=dev)[None, :] < n_t[:, None]  # [B,nmax]
+    k = max_neighbors
+    cut = torch.full((B,), float(cutoff), dtype=torch.float64, device=dev)
+    longest = torch.linalg.norm(lat, dim=2).max(dim=1).values
+    spacing = 1.0 / torch.linalg.norm(torch.linalg.inv(lat), dim=1)  # [B,3]: plane spacings (column norms of the inverse)
+    # same fixed-order float64 arithmetic as knn_multigraph / synthetic._all_neighbors
+    cart = frac[..., 0:1] * lat[:, None, 0, :] + frac[..., 1:2] * lat[:, None, 1, :] + frac[..., 2:3] * lat[:, None, 2, :]
+    while True:
+        reach = torch.ceil(cut[:, None] / spacing).to(torch.int64)  # [B,3]
+        rmax = reach.max(dim=0).values.tolist()  # host: three integers per batch
+        rng = [torch.arange(-q, q + 1, device=dev) for q in rmax]
+        images = torch.stack(torch.meshgrid(*rng, indexing="ij"), -1).reshape(-1, 3)  # [I,3]
+        inside = (images.abs()[None, :, :] <= reach[:, None, :]).all(-1)  # [B,I]: the images crystal b itself would scan
+        imf = images.to(torch.float64)
+        shift = imf[None, :, 0:1] * lat[:, None, 0, :] + imf[None, :, 1:2] * lat[:, None, 1, :] + imf[None, :, 2:3] * lat[:, None, 2, :]
+        d = (cart[:, None, :, None, :] + shift[:, None, None, :, :]) - cart[:, :, None, None, :]  # [B,i,j,I,3]
+        dx, dy, dz = d[..., 0], d[..., 1], d[..., 2]
+        dist = torch.sqrt(dx * dx + dy * dy + dz * dz)
+        ok = ((dist <= cut[:, None, None, None]) & (dist > 1e-8) & real[:, :, None, None] & real[:, None, :, None]
+              & inside[:, None, None, :])
+        counts = ok.sum(dim=(2, 3))  # [B,nmax] neighbours per site
+        short = ((counts < k) & real).any(dim=1)  # [B]
+        if not bool(short.any()):  # host: one flag per batch
+            break
+        cut = torch.where(short, torch.where(cut < longest, longest, 2.0 * cut), cut)
+    # per site: everything out to the shell of the k-th neighbour
+    dm = torch.where(ok, dist, torch.full_like(dist, float("inf"))).reshape(B, nmax, -1)
+    kth = torch.sort(dm, dim=2).values[:, :, k - 1]  # [B,nmax]
+    keep = ok & (dist <= kth[:, :, None, None])
+    b_i, src, dst, img = torch.nonzero(keep, as_tuple=True)
+    im = images[img]
+    swap = dst < src
+    a_ = torch.where(swap, dst, src)
+    c_ = torch.where(swap, src, dst)
+    im = torch.where(swap[:, None], -im, im)
+    key = torch.unique(torch.cat([b_i[:, None], a_[:, None], c_[:, None], im], 1), dim=0)  # sorted by (crystal, a, b, image)
+    kb, a_, c_, im = key[:, 0], key[:, 1], key[:, 2], key[:, 3:6]
+    disp = (frac[kb, c_] + im.to(torch.float64) - frac[kb, a_])
+    dvec = torch.bmm(disp.unsqueeze(1), lat[kb]).squeeze(1)
+    off = (torch.cumsum(n_t, 0) - n_t)[kb]
+    u = torch.stack([a_ + off, c_ + off], 1).reshape(-1)
+    v = torch.stack([c_ + off, a_ + off], 1).reshape(-1)
+    r = torch.stack([dvec, -dvec], 1).reshape(-1, 3).to(torch.float32)
+    return u, v, r, ns
+
+
 def crystal_batch(lattices: Sequence, fracs: Sequence, atom_features: Optional[Sequence] = None, device=None,
                   cutoff: float = 8.0, max_neighbors: int = 12, line_graph: bool = True) -> GraphBatch:
     """Positions -> canonical (g, L(g)) batch, all on the device: one crystal per (lattice, frac) pair; the bond cosines
     are left to the model (``lg_on_fly``) or to ``ops.bond_cosines(batch.r, batch.lg)``."""
     dev = torch.device(device) if device is not None else torch.as_tensor(fracs[0]).device
-    us, vs, rs, nn, off = [], [], [], [], 0
-    for lat, frac in zip(lattices, fracs):
-        u, v, r = knn_multigraph(lat, frac, cutoff, max_neighbors, device=dev)
-        us.append(u + off)
-        vs.append(v + off)
-        rs.append(r)
-        n = int(torch.as_tensor(frac).shape[0])
-        nn.append(n)
-        off += n
-    u, v, r = torch.cat(us), torch.cat(vs), torch.cat(rs)
+    u, v, r, nn = knn_multigraph_batch(lattices, fracs, cutoff, max_neighbors, device=dev)
+    off = sum(nn)
     g = build_csr(u, v, off)
     lg = line_graph_of(g) if line_graph else None
     bnn = torch.tensor(nn, dtype=torch.int64, device=dev)

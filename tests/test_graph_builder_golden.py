@@ -66,6 +66,35 @@ def test_torch_builder_reproduces_the_reference_edge_sets_cpu():
     _check(build)
 
 
+def _batched(device):
+    """knn_multigraph_batch over ragged groups of the 70 structures: split back per crystal"""
+    cases = list(_golden_cases())
+    out = {}
+    for lo in range(0, len(cases), 9):
+        grp = cases[lo:lo + 9]
+        u, v, r, nn = neighbors.knn_multigraph_batch([torch.from_numpy(c[1]) for c in grp], [torch.from_numpy(c[2]) for c in grp],
+                                                     device=device)
+        u, v, r = u.cpu().numpy(), v.cpu().numpy(), r.cpu().numpy()
+        off = 0
+        for c, n in zip(grp, nn):
+            sel = (u >= off) & (u < off + n)
+            assert ((v[sel] >= off) & (v[sel] < off + n)).all()
+            out[c[0]] = (u[sel] - off, v[sel] - off, r[sel])
+            off += n
+    return out
+
+
+def test_batched_builder_reproduces_the_reference_edge_sets_cpu():
+    res = _batched("cpu")
+    _check(lambda lat, frac, _it=iter(list(_golden_cases())): res[next(_it)[0]])
+
+
+@pytest.mark.gpu
+def test_batched_device_builder_reproduces_the_reference_edge_sets():
+    res = _batched("cuda")
+    _check(lambda lat, frac, _it=iter(list(_golden_cases())): res[next(_it)[0]])
+
+
 @pytest.mark.gpu
 def test_device_builder_reproduces_the_reference_edge_sets():
     def build(lat, frac):
