@@ -50,6 +50,9 @@
 #ifndef X6_PERSIST
 #define X6_PERSIST 0  // 1: long products on 512 persistent workgroups (bit-identical, measured no faster: see PERSIST below)
 #endif
+#ifndef X6_EPI_NOSYNC
+#define X6_EPI_NOSYNC 0  // 1: no per-round __syncthreads() in the epilogue (see there)
+#endif
 #ifndef X6_ABL_NOSTORE
 #define X6_ABL_NOSTORE 0  // 1: epilogue without its global stores, 2: no epilogue at all
 #endif
@@ -444,17 +447,26 @@ __device__ __forceinline__ void gemm_nt_x6_body(const X6Args& g) {
         // the patches are private to a wave (LDS serves one wave's accesses in order): the only cross-wave hazard is
         // the first overwrite of stage memory other waves may still be reading.  PERSIST must not use
         // __syncthreads() here - its vmcnt(0) would drain the prefetch just issued.
+#if X6_EPI_NOSYNC
+        // one barrier in front of the first overwrite of stage memory; afterwards every wave works on its own patch
+        // (LDS serves one wave's accesses in order) and the stores of round r stay in flight under the transposes of
+        // round r+1 - __syncthreads() would drain them (it waits vmcnt(0)) four times per tile
+        if (ahb == 0) block_barrier();
+#else
         if constexpr (PERSIST) {
             if (ahb == 0) block_barrier();
         } else {
             __syncthreads();
         }
+#endif
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 patch[((r & 3) + 8 * (r >> 2) + 4 * half) * PLD + b * 32 + il] = acc[a][2 * hb + b][r];
+#if !X6_EPI_NOSYNC
         if constexpr (!PERSIST) __syncthreads();
+#endif
         const int col = n0 + wn * TN + hb * 64 + pc4;
         const int colc = col < g.N ? col : 0;
         const int64_t row0 = m0 + wm * TM + a * 32 + prow;

@@ -115,7 +115,7 @@ def cpu_baseline(n_graphs, n_atoms, kind="crystal"):
     timed on this host on the SAME batch the GPU run trains on: one warm-up step on 8 graphs
     (thread pool, allocator), then ONE timed training step (fwd + bwd + AdamW) of the full batch - ~15-25 s of CPU work.
     The reference's own classes on the DGL shim, timed in the authoring container on the same batch, are recorded in
-    profiles/r02_cpu_reference_vs_port.json (same speed within a few percent: both are the same torch-CPU kernels)."""
+    profiles/r02_cpu_reference_vs_port.json (8 cores: 2.1 vs 1.8 graphs/s - both are the same torch-CPU kernels)."""
     from alignn_amd.synthetic import make_batch
     from oracle import alignn_oracle as O
 

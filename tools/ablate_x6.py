@@ -95,7 +95,7 @@ def run_f16():
     for k, ts in times.items():
         ts = sorted(ts)
         print(f"NT f16x3 {k:22s} median {ts[len(ts)//2]:8.1f} us   min {ts[0]:8.1f}   max {ts[-1]:8.1f}   ({len(ts)} x 10 launches)", flush=True)
-F16V = {"warm": [], "base": [], "nolate": ["-DX6_LATE_DMA=0"], "persist": ["-DX6_PERSIST=1"], "head": [], "base2": [], "head2": [], "nostore": ["-DX6_ABL_NOSTORE=1"], "noepi": ["-DX6_ABL_NOSTORE=2"], "noaload": ["-DX6_ABL_NOALOAD=1"],
+F16V = {"warm": [], "base": [], "nosync": ["-DX6_EPI_NOSYNC=1"], "nolate": ["-DX6_LATE_DMA=0"], "persist": ["-DX6_PERSIST=1"], "head": [], "base2": [], "head2": [], "nostore": ["-DX6_ABL_NOSTORE=1"], "noepi": ["-DX6_ABL_NOSTORE=2"], "noaload": ["-DX6_ABL_NOALOAD=1"],
         "nobload": ["-DX6_ABL_NOBLOAD=1"], "noloads": ["-DX6_ABL_NOBLOAD=1", "-DX6_ABL_NOALOAD=1"], "onemfma": ["-DX6_ABL_ONEMFMA=1"],
         "noslice": ["-DX6_ABL_NOSLICE=1"],
         "noloads_noepi": ["-DX6_ABL_NOBLOAD=1", "-DX6_ABL_NOALOAD=1", "-DX6_ABL_NOSTORE=2"],
