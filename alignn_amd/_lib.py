@@ -35,7 +35,9 @@ SIGNATURES = {
     "alignn_split_f16x2_bytes": (_sz, [_i32, _i32]),
     "alignn_split_f16x2": (_i32, [_p, _i64, _i32, _i32, _i32, _p, _p, _p]),
     "alignn_gemm_nt_f16x3": (_i32, [_p, _i64, _p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _i32, _i32, _p]),
-    "alignn_gemm_nt_f16x3_gather": (_i32, [_p, _i64, _p, _p, _p, _p, _p, _i64, _i64, _i32, _i32, _p, _i64, _p, _p, _p]),
+    "alignn_gemm_nt_f16x3_gather": (_i32, [_p, _i64, _p, _p, _p, _p, _p, _i64, _i64, _i32, _i32, _p, _i64, _p, _p, _p, _p]),
+    "alignn_gemm_nt_f16x3_stats": (_i32, [_p, _i64, _p, _p, _p, _p, _p, _i64, _i64, _i32, _i32, _p, _p]),
+    "alignn_egc_gate_fwd_pre_norm": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "alignn_egc_gate_fwd_pre": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p]),
     "alignn_gemm_nt_x6_row_tiles": (_i32, [_i64, _i32, _i32]),
     "alignn_gemm_nt_f16x3_bnred": (_i32, [_p, _i64, _p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _i32, _i32, _p, _i64, _p, _p, _p]),

@@ -642,6 +642,24 @@ int alignn_egc_gate_fwd_pre(const float* P, float* M, const int32_t* seg_ptr, co
     return 0;
 }
 
+int alignn_egc_gate_fwd_pre_norm(const float* P, const float* M, const int32_t* seg_ptr, const int32_t* seg_node,
+                                 const int32_t* src, int64_t n_seg, int64_t m_rows, int H, float* XPRE, float* S0,
+                                 float* HH, float* n_partial, const float* e_stat, const float* Y, float* YOUT,
+                                 float* y_amax, alignn_stream_t stream) {
+    if (!h_ok(H) || n_seg < 0 || n_seg > INT32_MAX || m_rows < 0 || !e_stat || !YOUT) return (int)hipErrorInvalidValue;
+    float* Mm = const_cast<float*>(M);  // the <INFER, PRE> instantiation only reads it
+    if (big_stream(m_rows, H))
+        hipLaunchKernelGGL((egc_gate_fwd_kernel<true, true, true>), dim3(egc_blocks(n_seg)), dim3(kThreads), 0,
+                           (hipStream_t)stream, P, Mm, seg_ptr, seg_node, src, (int)n_seg, H, XPRE, S0, HH, nullptr,
+                           n_partial, e_stat, Y, YOUT, y_amax);
+    else
+        hipLaunchKernelGGL((egc_gate_fwd_kernel<false, true, true>), dim3(egc_blocks(n_seg)), dim3(kThreads), 0,
+                           (hipStream_t)stream, P, Mm, seg_ptr, seg_node, src, (int)n_seg, H, XPRE, S0, HH, nullptr,
+                           n_partial, e_stat, Y, YOUT, y_amax);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
 int alignn_egc_gate_infer(const float* P, const float* C, const int32_t* seg_ptr, const int32_t* seg_node,
                           const int32_t* src, int64_t n_seg, int64_t m_rows, int H, float* XPRE, const float* e_stat,
                           const float* Y, float* YOUT, float* y_amax, alignn_stream_t stream) {

@@ -235,10 +235,15 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned char* lds_wave_
 // in registers: read the matching xn tile (one row pass instead of two), form gz and accumulate the two sums per
 // column in a fixed order (lane -> the 4 row groups of a wave by shuffles -> the 2 wave rows through LDS); one [2][N]
 // slab per row tile, summed afterwards by alignn_bn_bwd_finalize (fp64, fixed order): bit-reproducible.
+// EPI is a set of flags: 1 = BNRED (above), 2 = GATHER (C[e] += P[src e].A + P[dst e].Bd, below), 4 = STATS (per-tile
+// column sums of C and C^2 into red_partial: the BatchNorm statistics of the tensor this product writes, so that no
+// separate pass has to read it back for them).
 template <bool HAS_ADD, bool F16, int RM_, bool PERSIST = false, int EPI = 0>
 __device__ __forceinline__ void gemm_nt_x6_body(const X6Args& g) {
+    constexpr bool BNRED = (EPI & 1) != 0, GATHER = (EPI & 2) != 0, STATS = (EPI & 4) != 0;
+    static_assert(!(BNRED && STATS), "one set of column sums per launch");
     static_assert(EPI == 0 || !PERSIST, "the reduction epilogue exists for the one-tile kernel only");
-    static_assert(EPI != 2 || !HAS_ADD, "EPI == 2 has its own two addends");
+    static_assert(!GATHER || !HAS_ADD, "the gather variant has its own two addends");
     // EPI == 2: C[e] = A-row . W + b  +  P[src e].A + P[dst e].Bd  - the u_add_v of the convolution
     // (alignn/models/alignn.py:100-101) folded into the projection that produces the third addend, so that m never
     // makes the round trip "write C, read C, write m".  (a + bd) + c is evaluated as c + (a + bd): same bits.
@@ -470,7 +475,7 @@ __device__ __forceinline__ void gemm_nt_x6_body(const X6Args& g) {
         const int col = n0 + wn * TN + hb * 64 + pc4;
         const int colc = col < g.N ? col : 0;
         const int64_t row0 = m0 + wm * TM + a * 32 + prow;
-        float4 ov[EPI == 1 ? 1 : 8], av[8], xv[EPI == 1 ? 8 : 1];
+        float4 ov[BNRED ? 1 : 8], av[8], xv[BNRED ? 8 : 1];
         if constexpr (PERSIST) {
             // read the patch behind the compiler's back: it would put s_waitcnt vmcnt(0) in front of LDS reads that
             // it cannot tell apart from the destination of the DMA prefetch in flight
@@ -487,14 +492,14 @@ __device__ __forceinline__ void gemm_nt_x6_body(const X6Args& g) {
                          :
                          : "memory");
 #pragma unroll
-            for (int i = 0; i < 8; ++i) ov[EPI == 1 ? 0 : i] = make_float4(pv[i].x, pv[i].y, pv[i].z, pv[i].w);
-        } else if constexpr (EPI != 1) {
+            for (int i = 0; i < 8; ++i) ov[BNRED ? 0 : i] = make_float4(pv[i].x, pv[i].y, pv[i].z, pv[i].w);
+        } else if constexpr (!BNRED) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) ov[i] = f4_ld(patch + (i * 4 + prow) * PLD + pc4);
         }
         // all global loads of the round are issued before its first store (vmcnt retires in order and counts stores: a
         // load behind a store would make its consumer wait for that store)
-        if constexpr (EPI == 2) {
+        if constexpr (GATHER) {
             int ui[8], vi[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -516,7 +521,8 @@ __device__ __forceinline__ void gemm_nt_x6_body(const X6Args& g) {
             }
         }
         float4 n_mean, n_sc, n_be, s0, s1;
-        if constexpr (EPI == 1) {
+        if constexpr (STATS) s0 = s1 = f4_zero();
+        if constexpr (BNRED) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 int64_t row = row0 + i * 4;
@@ -529,17 +535,21 @@ __device__ __forceinline__ void gemm_nt_x6_body(const X6Args& g) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int64_t row = row0 + i * 4;
-            if constexpr (EPI == 1) ov[0] = f4_ld(patch + (i * 4 + prow) * PLD + pc4);  // (LDS: just in time, 4 registers)
-            float4 v = ov[EPI == 1 ? 0 : i];
+            if constexpr (BNRED) ov[0] = f4_ld(patch + (i * 4 + prow) * PLD + pc4);  // (LDS: just in time, 4 registers)
+            float4 v = ov[BNRED ? 0 : i];
             if constexpr (F16) v = f4_scale(f4_scale(v, inv_sa), inv_sw);
             v = f4_add(v, bias_v[hb]);
-            if (HAS_ADD || EPI == 2) v = f4_add(v, av[i]);
+            if (HAS_ADD || GATHER) v = f4_add(v, av[i]);
             if (row < g.M && col < g.N && (!X6_ABL_NOSTORE || v.x == 12345.678f)) {
                 if (g.stream_out)
                     f4_sts<true>(g.C + row * g.ldc + col, v);
                 else
                     f4_st(g.C + row * g.ldc + col, v);
-                if constexpr (EPI == 1) {
+                if constexpr (STATS) {
+                    s0 = f4_add(s0, v);
+                    s1 = f4_fma(v, v, s1);
+                }
+                if constexpr (BNRED) {
                     const float4 xc = f4_sub(xv[i], n_mean);
                     const float4 z = f4_fma(xc, n_sc, n_be);
                     const float4 gz = make_float4(v.x * dsilu_f(z.x), v.y * dsilu_f(z.y), v.z * dsilu_f(z.z), v.w * dsilu_f(z.w));
@@ -548,7 +558,7 @@ __device__ __forceinline__ void gemm_nt_x6_body(const X6Args& g) {
                 }
             }
         }
-        if constexpr (EPI == 1) {
+        if constexpr (BNRED || STATS) {
             // the lane's running column sums live in LDS between rounds (registers: two waves per SIMD is the budget)
             float* acc_sh = red_acc + ((wave * (RN / 2) + hb) * 2) * 256 + lane * 4;  // [wave][half][2][64 lanes][4]
             if (a != 0) {
@@ -559,7 +569,7 @@ __device__ __forceinline__ void gemm_nt_x6_body(const X6Args& g) {
             f4_st(acc_sh + 256, s1);
         }
     }
-    if constexpr (EPI == 1) {
+    if constexpr (BNRED || STATS) {
         // column sums: the 4 row groups of a wave (lanes l, l+16, l+32, l+48), then the 2 wave rows - fixed order
         __syncthreads();
         if (wm == 0 && lane < 16) {
@@ -576,7 +586,7 @@ __device__ __forceinline__ void gemm_nt_x6_body(const X6Args& g) {
                             for (int pr = 0; pr < 4; ++pr)
                                 sum = f4_add(sum, f4_ld(red_acc + (((w * WN + wn) * (RN / 2) + hb) * 2 + k) * 256 +
                                                         (pr * 16 + lane) * 4));
-                        if (k == 1) sum = f4_mul(sum, f4_ld(g.nstat + g.N + col));  // sum gz*(x-mean) -> sum gz*xhat
+                        if (BNRED && k == 1) sum = f4_mul(sum, f4_ld(g.nstat + g.N + col));  // sum gz*(x-mean) -> sum gz*xhat
                         f4_st(g.red_partial + ((size_t)tile * 2 + k) * g.N + col, sum);
                     }
                 }
@@ -601,9 +611,13 @@ template <bool HAS_ADD, int RM_>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void gemm_nt_x6_bnred_kernel(X6Args g) {
     gemm_nt_x6_body<HAS_ADD, true, RM_, false, 1>(g);
 }
-template <int RM_>
+template <int RM_, bool STATS>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void gemm_nt_x6_gather_kernel(X6Args g) {
-    gemm_nt_x6_body<false, true, RM_, false, 2>(g);
+    gemm_nt_x6_body<false, true, RM_, false, 2 | (STATS ? 4 : 0)>(g);
+}
+template <int RM_>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void gemm_nt_x6_stats_kernel(X6Args g) {
+    gemm_nt_x6_body<false, true, RM_, false, 4>(g);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -933,7 +947,37 @@ int launch_nt_rm(const X6Args& g, hipStream_t st) {
     }
 #endif
     if constexpr (F16) {
-        if (g.red_partial != nullptr) {  // BatchNorm-backward reductions in the epilogue (EPI == 1)
+        constexpr int slds = Sch<F16, RM_>::LDS > EPI1_LDS ? Sch<F16, RM_>::LDS : EPI1_LDS;  // + the column-sum slots
+        static bool fattr_set = false;
+        if (!fattr_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_x6_gather_kernel<RM_, false>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute((const void*)gemm_nt_x6_gather_kernel<RM_, true>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, slds);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute((const void*)gemm_nt_x6_stats_kernel<RM_>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, slds);
+            if (e != hipSuccess) return (int)e;
+            fattr_set = true;
+        }
+        if (g.gp != nullptr) {  // gather-add of the two node rows in the epilogue (+ column statistics of the result)
+            if (g.red_partial)
+                hipLaunchKernelGGL((gemm_nt_x6_gather_kernel<RM_, true>), grid, dim3(NT), slds, st, g);
+            else
+                hipLaunchKernelGGL((gemm_nt_x6_gather_kernel<RM_, false>), grid, dim3(NT), lds, st, g);
+            ALIGNN_CHECK_LAUNCH();
+            return 0;
+        }
+        if (g.red_partial != nullptr && g.xn == nullptr) {  // column statistics of the output only
+            if (g.addend) return (int)hipErrorInvalidValue;
+            hipLaunchKernelGGL((gemm_nt_x6_stats_kernel<RM_>), grid, dim3(NT), slds, st, g);
+            ALIGNN_CHECK_LAUNCH();
+            return 0;
+        }
+    }
+    if constexpr (F16) {
+        if (g.red_partial != nullptr && g.xn != nullptr) {  // BatchNorm-backward reductions in the epilogue (EPI == 1)
             constexpr int lds = Sch<F16, RM_>::LDS > EPI1_LDS ? Sch<F16, RM_>::LDS : EPI1_LDS;
             static bool eattr_set = false;
             if (!eattr_set) {
@@ -949,20 +993,6 @@ int launch_nt_rm(const X6Args& g, hipStream_t st) {
                 hipLaunchKernelGGL((gemm_nt_x6_bnred_kernel<true, RM_>), grid, dim3(NT), lds, st, g);
             else
                 hipLaunchKernelGGL((gemm_nt_x6_bnred_kernel<false, RM_>), grid, dim3(NT), lds, st, g);
-            ALIGNN_CHECK_LAUNCH();
-            return 0;
-        }
-    }
-    if constexpr (F16) {
-        if (g.gp != nullptr) {  // gather-add of the two node rows in the epilogue (EPI == 2)
-            static bool gattr_set = false;
-            if (!gattr_set) {
-                hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_x6_gather_kernel<RM_>,
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                if (e != hipSuccess) return (int)e;
-                gattr_set = true;
-            }
-            hipLaunchKernelGGL((gemm_nt_x6_gather_kernel<RM_>), grid, dim3(NT), lds, st, g);
             ALIGNN_CHECK_LAUNCH();
             return 0;
         }
@@ -1105,13 +1135,25 @@ int alignn_gemm_nt_f16x3(const float* A, int64_t lda, const float* a_amax, const
 
 int alignn_gemm_nt_f16x3_gather(const float* A, int64_t lda, const float* a_amax, const void* Wsplit, const float* w_amax,
                                 const float* bias, float* C, int64_t ldc, int64_t M, int N, int K, const float* P, int64_t ldp,
-                                const int32_t* src, const int32_t* dst, alignn_stream_t stream) {
+                                const int32_t* src, const int32_t* dst, float* stats_partial, alignn_stream_t stream) {
     if (!alignn_gemm_nt_x6_supported(M, N, K) || a_amax == nullptr || w_amax == nullptr) return (int)hipErrorInvalidValue;
     if (!nt_args_ok(A, lda, Wsplit, bias, nullptr, 0, C, ldc)) return (int)hipErrorInvalidValue;
-    if (P == nullptr || src == nullptr || dst == nullptr || (ldp & 3) || !a16(P) || (N & 3) || ldp < 2 * (int64_t)N)
+    if (P == nullptr || src == nullptr || dst == nullptr || (ldp & 3) || !a16(P) || (N & 3) || ldp < 2 * (int64_t)N ||
+        (stats_partial && !a16(stats_partial)))
         return (int)hipErrorInvalidValue;
     X6Args g{A, lda, (const unsigned char*)Wsplit, a_amax, w_amax, bias, nullptr, 0, C, ldc, M, N, npad(N), K,
-             M * (int64_t)N * 4 >= ((int64_t)128 << 20), nullptr, 0, nullptr, nullptr, P, ldp, src, dst};
+             M * (int64_t)N * 4 >= ((int64_t)128 << 20), nullptr, 0, nullptr, stats_partial, P, ldp, src, dst};
+    return launch_nt<true>(g, (hipStream_t)stream);
+}
+
+int alignn_gemm_nt_f16x3_stats(const float* A, int64_t lda, const float* a_amax, const void* Wsplit, const float* w_amax,
+                               const float* bias, float* C, int64_t ldc, int64_t M, int N, int K, float* stats_partial,
+                               alignn_stream_t stream) {
+    if (!alignn_gemm_nt_x6_supported(M, N, K) || a_amax == nullptr || w_amax == nullptr) return (int)hipErrorInvalidValue;
+    if (!nt_args_ok(A, lda, Wsplit, bias, nullptr, 0, C, ldc)) return (int)hipErrorInvalidValue;
+    if (stats_partial == nullptr || !a16(stats_partial) || (N & 3)) return (int)hipErrorInvalidValue;
+    X6Args g{A, lda, (const unsigned char*)Wsplit, a_amax, w_amax, bias, nullptr, 0, C, ldc, M, N, npad(N), K,
+             M * (int64_t)N * 4 >= ((int64_t)128 << 20), nullptr, 0, nullptr, stats_partial, nullptr, 0, nullptr, nullptr};
     return launch_nt<true>(g, (hipStream_t)stream);
 }
 

@@ -462,6 +462,7 @@ def gemm_nt_f16x3_bnred(a, a_amax, ws, xn, nstat, bias=None, addend=None, out=No
 
 
 GATHER_FUSED = True  # EdgeGatedGraphConv: u_add_v folded into the edge-gate projection (tests flip it to compare: same bits)
+STATS_FUSED = True  # BatchNorm statistics from the epilogue of the projection that writes the tensor (tests flip it)
 
 
 def _f16x3_applies(a, a_amax, N, K):
@@ -472,20 +473,43 @@ def _f16x3_applies(a, a_amax, N, K):
             and bool(lib.alignn_gemm_nt_x6_supported(M, N, K)))
 
 
-def gemm_nt_f16x3_gather(a, a_amax, ws, bias, P, src, dst, out=None):
-    """out[e] = a[e] @ W^T + bias + P[src[e], 0:N] + P[dst[e], N:2N]  (edge-gate projection + DGL u_add_v in one pass)."""
+def gemm_nt_f16x3_gather(a, a_amax, ws, bias, P, src, dst, out=None, want_stats=False):
+    """out[e] = a[e] @ W^T + bias + P[src[e], 0:N] + P[dst[e], N:2N]  (edge-gate projection + DGL u_add_v in one pass).
+    ``want_stats``: -> (out, partial [tiles,2,N], tiles): per-tile column sums of out and out^2 (alignn_bn_finalize's slabs)."""
     lib = _lib.load()
     require_f32(a, bias, P)
     M, K = a.shape
     N = ws.n
     if out is None:
         out = _empty(M, N, like=a)
+    tiles = lib.alignn_gemm_nt_x6_row_tiles(M, N, K) if want_stats else 0
+    partial = _empty(tiles, 2, N, like=a) if want_stats else None
     _timed("gather", M, N, K, lambda: check(
         lib.alignn_gemm_nt_f16x3_gather(ptr(a), a.stride(0), ptr(a_amax), ptr(ws.buf), ptr(ws.amax), ptr(bias), ptr(out),
-                                        out.stride(0), M, N, K, ptr(P), P.stride(0), ptr(src), ptr(dst), stream()),
+                                        out.stride(0), M, N, K, ptr(P), P.stride(0), ptr(src), ptr(dst), ptr(partial),
+                                        stream()),
         "gemm_nt_f16x3_gather",
     ))
-    return out
+    return (out, partial, tiles) if want_stats else out
+
+
+def gemm_nt_f16x3_stats(a, a_amax, ws, bias=None, out=None):
+    """-> (out = a @ W^T + bias, partial [tiles,2,N], tiles): the projection with the column sums of its output and of its
+    square per row tile - the BatchNorm statistics of ``out`` without another pass over it."""
+    lib = _lib.load()
+    require_f32(a, bias)
+    M, K = a.shape
+    N = ws.n
+    if out is None:
+        out = _empty(M, N, like=a)
+    tiles = lib.alignn_gemm_nt_x6_row_tiles(M, N, K)
+    partial = _empty(tiles, 2, N, like=a)
+    _timed("stats", M, N, K, lambda: check(
+        lib.alignn_gemm_nt_f16x3_stats(ptr(a), a.stride(0), ptr(a_amax), ptr(ws.buf), ptr(ws.amax), ptr(bias), ptr(out),
+                                       out.stride(0), M, N, K, ptr(partial), stream()),
+        "gemm_nt_f16x3_stats",
+    ))
+    return out, partial, tiles
 
 
 def gemm_nt_x6(a, ws, bias=None, addend=None, out=None):
@@ -822,15 +846,21 @@ class MLPLayerFn(torch.autograd.Function):
     def _fwd(ctx, x, w, b, gamma, beta, running_mean, running_var, training, norm):
         lib = _lib.load()
         ctx.x_amax = get_amax(x)
-        pre = project(x, w, b, a_amax=ctx.x_amax)
+        fused_stats = (norm == "batch" and training and STATS_FUSED
+                       and _f16x3_applies(x, ctx.x_amax, w.shape[0], w.shape[1]))
+        if fused_stats:  # the projection's epilogue leaves the column sums BatchNorm needs
+            pre, partial, slabs = gemm_nt_f16x3_stats(x, ctx.x_amax, split_f16x2(w), b)
+        else:
+            pre = project(x, w, b, a_amax=ctx.x_amax)
         rows, F = pre.shape
         if norm == "layer":
             y, stat = _ln_silu_fwd(pre, None, gamma, beta)
         else:
             if training:
-                slabs = lib.alignn_col_stats_slabs(rows)
-                partial = _empty(slabs, 2, F, like=pre)
-                check(lib.alignn_col_stats(ptr(pre), pre.stride(0), rows, F, ptr(partial), stream()), "col_stats")
+                if not fused_stats:
+                    slabs = lib.alignn_col_stats_slabs(rows)
+                    partial = _empty(slabs, 2, F, like=pre)
+                    check(lib.alignn_col_stats(ptr(pre), pre.stride(0), rows, F, ptr(partial), stream()), "col_stats")
                 stat = _bn_finalize(partial, slabs, rows, gamma, beta, running_mean, running_var, True)
             else:
                 stat = _bn_finalize(None, 0, rows, gamma, beta, running_mean, running_var, False)
@@ -954,15 +984,44 @@ class EdgeGatedConvFn(torch.autograd.Function):
         # convolutions of a real batch): M leaves the GEMM as m = A[u] + Bd[v] + C and the gate pass only reads it
         pre_added = GATHER_FUSED and w_eg.shape[0] == H and _f16x3_applies(y, ctx.y_amax, H, w_eg.shape[1])
 
+        # ... and with BatchNorm the same epilogue leaves the column sums of m, so the gate pass can normalise right away:
+        # it writes y' = y + silu(BN(m)) itself and the separate 3-row normalise / activate pass disappears
+        fuse_norm = pre_added and norm == "batch" and STATS_FUSED
+
         def edge_side():
+            if fuse_norm and training:
+                M, e_part, e_slabs = gemm_nt_f16x3_gather(y, ctx.y_amax, split_f16x2(w_eg), b_eg, P, graph.src, graph.dst,
+                                                          want_stats=True)
+                return M, (e_part, e_slabs)
             if pre_added:
                 M = gemm_nt_f16x3_gather(y, ctx.y_amax, split_f16x2(w_eg), b_eg, P, graph.src, graph.dst)
             else:
                 M = project(y, w_eg, b_eg, a_amax=ctx.y_amax)  # [m,H]  -> m_pre in place
-            e_part = _empty(slabs, 2, H, like=x) if bn_train else None
+            e_part = _empty(slabs, 2, H, like=x) if (bn_train and not fuse_norm) else None
             return M, e_part
 
+        fused_out = {}
+
         def gate(M, e_part):
+            if fuse_norm:
+                if training:
+                    e_stat = _bn_finalize(e_part[0], e_part[1], m, e_gamma, e_beta, e_rm, e_rv, True)
+                else:
+                    e_stat = _bn_finalize(None, 0, m, e_gamma, e_beta, e_rm, e_rv, False)
+                fused_out["e_stat"] = e_stat
+                if need_y:
+                    y_o = _empty(m, H, like=x)
+                    y_amax = new_amax(x) if _track(m) else None
+                    check(
+                        lib.alignn_egc_gate_fwd_pre_norm(ptr(P), ptr(M), ptr(graph.seg_ptr), ptr(graph.seg_node),
+                                                         ptr(graph.src), n, m, H, ptr(xpre), ptr(s0), ptr(hh), ptr(n_part),
+                                                         ptr(e_stat), ptr(y) if residual else None, ptr(y_o), ptr(y_amax),
+                                                         stream()),
+                        "egc_gate_fwd_pre_norm",
+                    )
+                    fused_out["y"] = set_amax(y_o, y_amax) if y_amax is not None else y_o
+                    return
+                e_part = None  # dead edge output: plain pre-added gate pass, the statistics are already in e_stat
             fn = lib.alignn_egc_gate_fwd_pre if pre_added else lib.alignn_egc_gate_fwd
             check(
                 fn(ptr(P), ptr(M), ptr(graph.seg_ptr), ptr(graph.seg_node), ptr(graph.src), n, m, H, ptr(xpre), ptr(s0),
@@ -971,6 +1030,10 @@ class EdgeGatedConvFn(torch.autograd.Function):
             )
 
         def edge_norm(M, e_part):
+            if fuse_norm:
+                y_o = fused_out.get("y")
+                _register_norm_src(y_o, M, fused_out["e_stat"])
+                return y_o, fused_out["e_stat"]
             if norm == "layer":  # LayerNorm flavour (alignn_atomwise.py:151,155): per-row statistics, no global barrier
                 if need_y:
                     return _ln_silu_fwd(M, y if residual else None, e_gamma, e_beta)

@@ -366,7 +366,7 @@ def main():
         # T-row launches of the f16x3 NT kernel family by epilogue variant; algorithmic rows moved per output row:
         # plain (read A, write C) 2; addend 3; gather (+ the A[u] row per edge, Bd[v] is constant per segment) 3;
         # bnred (+ the pre-activation read for the BatchNorm-backward sums) 3, with addend 4
-        rows_moved = {"plain": 2, "addend": 3, "gather": 3, "bnred": 3, "bnred_addend": 4}
+        rows_moved = {"plain": 2, "addend": 3, "gather": 3, "bnred": 3, "bnred_addend": 4, "stats": 2}
         by = {}
         for (label, n_, k_, e0, e1) in ev:
             if n_ == H and k_ == H:

@@ -123,7 +123,20 @@ int alignn_gemm_nt_f16x3(const float* A, int64_t lda, const float* a_amax, const
 int alignn_gemm_nt_f16x3_gather(const float* A, int64_t lda, const float* a_amax, const void* Wsplit,
                                 const float* w_amax, const float* bias, float* C, int64_t ldc, int64_t M, int N, int K,
                                 const float* P, int64_t ldp, const int32_t* src, const int32_t* dst,
-                                alignn_stream_t stream);
+                                float* stats_partial, alignn_stream_t stream);
+/* stats_partial (above: may be NULL) / alignn_gemm_nt_f16x3_stats: the projection also leaves, per row tile, the column
+ * sums of its output and of its square - [alignn_gemm_nt_x6_row_tiles][2][N], the slab layout alignn_bn_finalize takes -
+ * i.e. the BatchNorm statistics torch's BatchNorm1d would compute with another pass over the tensor
+ * (alignn/models/alignn.py:122-127 bn_edges, :175-179 MLPLayer).  alignn_egc_gate_fwd_pre_norm is the gate pass for an M
+ * that already holds m AND whose statistics are known: it writes Y' = Y + silu((m - mean) scale + beta) itself (e_stat as
+ * from alignn_bn_finalize; Y may be NULL), so the edge branch needs no separate normalise / activate pass. */
+int alignn_gemm_nt_f16x3_stats(const float* A, int64_t lda, const float* a_amax, const void* Wsplit,
+                               const float* w_amax, const float* bias, float* C, int64_t ldc, int64_t M, int N, int K,
+                               float* stats_partial, alignn_stream_t stream);
+int alignn_egc_gate_fwd_pre_norm(const float* P, const float* M, const int32_t* seg_ptr, const int32_t* seg_node,
+                                 const int32_t* src, int64_t n_seg, int64_t m_rows, int H, float* XPRE, float* S0,
+                                 float* HH, float* n_partial, const float* e_stat, const float* Y, float* YOUT,
+                                 float* y_amax, alignn_stream_t stream);
 int alignn_egc_gate_fwd_pre(const float* P, float* M, const int32_t* seg_ptr, const int32_t* seg_node,
                             const int32_t* src, int64_t n_seg, int64_t m_rows, int H, float* XPRE, float* S0, float* HH,
                             float* e_partial, float* n_partial, alignn_stream_t stream);

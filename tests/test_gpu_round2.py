@@ -487,6 +487,7 @@ def test_u_add_v_in_the_projection_epilogue_gives_the_same_bits():
     res = {}
     for fused in (True, False):
         ops.GATHER_FUSED = fused
+        ops.STATS_FUSED = False  # (the statistics-in-the-epilogue route rides on the gather variant and sums in another order)
         try:
             torch.manual_seed(0)
             model = ALIGNN(ALIGNNConfig(name="alignn")).to(DEV).train()
@@ -495,6 +496,7 @@ def test_u_add_v_in_the_projection_epilogue_gives_the_same_bits():
             torch.cuda.synchronize()
         finally:
             ops.GATHER_FUSED = True
+            ops.STATS_FUSED = True
         res[fused] = (pred.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None},
                       {k: v.clone() for k, v in model.state_dict().items() if "running" in k})
     assert torch.equal(res[True][0], res[False][0])
@@ -502,3 +504,31 @@ def test_u_add_v_in_the_projection_epilogue_gives_the_same_bits():
         assert torch.equal(res[True][1][k], res[False][1][k]), k
     for k in res[False][2]:
         assert torch.equal(res[True][2][k], res[False][2][k]), k
+
+
+def test_batchnorm_statistics_from_the_projection_epilogue():
+    """STATS in the projection's epilogue (alignn_gemm_nt_f16x3_stats / _gather with stats) + the gate pass that
+    normalises right away (alignn_egc_gate_fwd_pre_norm) against projection -> statistics pass -> normalise pass: same
+    training step to rounding (the statistics are summed per row tile instead of per slab)."""
+    raw = make_batch(16, 60, seed0=93)
+    batch = GraphBatch.from_raw(raw, device=DEV)
+    target = torch.randn(16, generator=torch.Generator().manual_seed(5)).to(DEV)
+    res = {}
+    for fused in (True, False):
+        ops.STATS_FUSED = fused
+        try:
+            torch.manual_seed(0)
+            model = ALIGNN(ALIGNNConfig(name="alignn")).to(DEV).train()
+            pred = model(batch)
+            torch.nn.functional.l1_loss(pred, target).backward()
+            torch.cuda.synchronize()
+        finally:
+            ops.STATS_FUSED = True
+        res[fused] = (pred.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None},
+                      {k: v.clone() for k, v in model.state_dict().items() if "running" in k})
+    assert rel_err(res[True][0], res[False][0]) < 1e-5
+    gmax = max(float(v.abs().max()) for v in res[False][1].values())
+    for k, g in res[False][1].items():
+        assert float((res[True][1][k] - g).abs().max()) < 1e-4 * max(float(g.abs().max()), 1e-3 * gmax), k
+    for k, v in res[False][2].items():
+        assert rel_err(res[True][2][k], v, floor=1e-3) < 1e-5, k
