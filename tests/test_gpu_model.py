@@ -768,7 +768,8 @@ def test_atomwise_g_lat_input_builds_line_graph_on_device():
 
 def test_default_config_depth_vs_oracle_on_x6_path():
     """Default ALIGNNConfig (4+4 layers, hidden 256) on 16 x 60-atom crystals: large enough that every wide
-    projection runs on the bf16x6 kernels and the line-graph kernels see real segment lengths.  Prediction,
+    projection runs on the split-product MFMA kernels (f16x3 wherever max|x| is tracked, i.e. everywhere on this path - the
+    bf16x6 fallback is covered at GEMM level, tests/test_gpu_kernels.py) and the line-graph kernels see real segment lengths.  Prediction,
     every parameter gradient and the BatchNorm running statistics vs the CPU oracle (north_star bar 1e-4)."""
     B = 16
     raw = make_batch(B, 60, seed0=2024)
