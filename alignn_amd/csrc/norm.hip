@@ -170,6 +170,23 @@ __global__ __launch_bounds__(kRedCols* kRedLanes) void slab_sum_kernel(const flo
     if (f < width && threadIdx.y == 0) out[f] = (float)s;
 }
 
+// Fold many slabs into kFold: out[g][f] = sum over slabs k = g, g + kFold, ... of partial[k][f] (double accumulation, fixed
+// order).  The projection epilogues emit one slab per ROW TILE (5 283 at T rows); the column-block finalisers above walk
+// slabs/64 steps per lane with 64-byte accesses - 60 us for that many -, this pre-pass reads whole 256-byte row
+// segments with kFold x width/64 workgroups (5 us) and leaves them 64 slabs.
+constexpr int kFold = 64;
+__global__ __launch_bounds__(256) void slab_fold_kernel(const float* __restrict__ partial, int slabs, int width,
+                                                        float* __restrict__ out) {
+    __shared__ double sh[4][64];
+    const int f = blockIdx.x * 64 + threadIdx.x, g = blockIdx.y, lane = threadIdx.y;
+    double s = 0.0;
+    if (f < width)
+        for (int k = g + lane * kFold; k < slabs; k += 4 * kFold) s += (double)partial[(size_t)k * width + f];
+    sh[lane][threadIdx.x] = s;
+    __syncthreads();
+    if (lane == 0 && f < width) out[(size_t)g * width + f] = (float)(((sh[0][threadIdx.x] + sh[1][threadIdx.x]) + sh[2][threadIdx.x]) + sh[3][threadIdx.x]);
+}
+
 // Y = R + silu((X-mean)*scale + beta)
 template <bool HAS_RES, bool STREAM>
 __global__ __launch_bounds__(kThreads) void bn_silu_fwd_kernel(const float* __restrict__ X, int64_t ldx,
@@ -536,6 +553,16 @@ int alignn_ln_silu_bwd(const float* GY, int64_t ldgy, const float* X, int64_t ld
         case 3: hipLaunchKernelGGL(ln_silu_bwd_kernel<3>, grid, block, 0, st, GY, ldgy, X, ldx, gamma, beta, stats, GX, ldgx, partial, rows, F, amax); break;
         default: hipLaunchKernelGGL(ln_silu_bwd_kernel<4>, grid, block, 0, st, GY, ldgy, X, ldx, gamma, beta, stats, GX, ldgx, partial, rows, F, amax); break;
     }
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_slab_fold_slabs(void) { return kFold; }
+
+int alignn_slab_fold(const float* partial, int slabs, int width, float* out, alignn_stream_t stream) {
+    if (width <= 0 || slabs <= 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(slab_fold_kernel, dim3(alignn_ceil_div(width, 64), kFold), dim3(64, 4), 0, (hipStream_t)stream,
+                       partial, slabs, width, out);
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }

@@ -457,6 +457,7 @@ def gemm_nt_f16x3_bnred(a, a_amax, ws, xn, nstat, bias=None, addend=None, out=No
         "gemm_nt_f16x3_bnred",
     ))
     red = _empty(2, N, like=a)
+    partial, tiles = _fold(partial, tiles, 2 * N)
     check(lib.alignn_bn_bwd_finalize(ptr(partial), tiles, N, ptr(red), stream()), "bn_bwd_finalize")
     return out, red
 
@@ -652,10 +653,26 @@ def col_sum(x):
     return out
 
 
+FOLD_ABOVE = 1024  # more slabs than this (one per row tile of a T-row projection): fold to 64 first
+
+
+def _fold(partial, slabs, width):
+    """(partial, slabs) with at most FOLD_ABOVE slabs: many-slab inputs are pre-summed to 64 slabs (alignn_slab_fold)."""
+    if slabs <= FOLD_ABOVE:
+        return partial, slabs
+    lib = _lib.load()
+    g = lib.alignn_slab_fold_slabs()
+    out = _empty(g, width, like=partial)
+    check(lib.alignn_slab_fold(ptr(partial), slabs, width, ptr(out), stream()), "slab_fold")
+    return out, g
+
+
 def _bn_finalize(partial, slabs, rows, gamma, beta, running_mean, running_var, update_running):
     """-> stat [4,F] = mean, rstd, scale, shift.  slabs == 0: evaluation mode (running statistics)."""
     lib = _lib.load()
     F = gamma.numel()
+    if slabs:
+        partial, slabs = _fold(partial, slabs, 2 * F)
     stat = _empty(4, F, like=gamma)
     rm = running_mean if (update_running or slabs == 0) else None
     rv = running_var if (update_running or slabs == 0) else None

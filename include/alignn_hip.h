@@ -197,6 +197,10 @@ int alignn_ln_silu_bwd(const float* GY, int64_t ldgy, const float* X, int64_t ld
                        int64_t rows, int F, float* amax, alignn_stream_t stream);
 /* out[f] = sum_s partial[s][f] over `slabs` slabs of `width` floats (fp64 accumulation, fixed order) */
 int alignn_slab_sum(const float* partial, int slabs, int width, float* out, alignn_stream_t stream);
+/* Pre-pass for very many slabs (one per row tile of a T-row projection): out[g][f] = sum of partial[k][f] over
+ * k = g, g + G, ... with G = alignn_slab_fold_slabs() (64); out is [G][width].  Same fixed order every time. */
+int alignn_slab_fold_slabs(void);
+int alignn_slab_fold(const float* partial, int slabs, int width, float* out, alignn_stream_t stream);
 /* phase 2: GX = gamma*rstd*(gz - red0/rows - xhat*red1/rows)   (training-mode BatchNorm backward)
  * eval_mode != 0: GX = gz*scale (running statistics are constants) */
 int alignn_bn_silu_bwd_apply(const float* GY, int64_t ldgy, const float* X, int64_t ldx,
