@@ -279,7 +279,7 @@ def gemm_nt(a, w, bias=None, addend=None, out=None):
     return out
 
 
-X6_MIN_TILES = 256  # 64x256 tiles below which the fp32-MFMA kernel's finer tiles win (100-512 measured the same)
+X6_MIN_TILES = int(_os.environ.get("ALIGNN_AMD_X6_MIN_TILES", "256"))  # 64x256 tiles below which the fp32-MFMA kernel's finer tiles win (100-512 measured the same)
 F16X3 = True  # use the three-product fp16 scheme wherever max|A| is known (False: always bf16x6)
 
 # max|x| of activations, tracked by the kernels that produce them (one device float per tensor).  Keyed by object
