@@ -26,11 +26,11 @@ if ROOT not in sys.path:
 H = 256
 # HBM bytes per launch of the dominant kernel at this exact shape (T=676 200 rows), from rocprofv3 PMC passes over
 # bench.py itself (separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs, profiles/r02_pmc_fetch_size.txt /
-# r02_pmc_write_size.txt: the 32 T-row launches of gemm_nt_x6_kernel<false,true,2>): FETCH_SIZE 335.0 MiB, doubled as
-# MI355X_MICROARCH.md prescribes for 16 B/lane streaming reads on gfx950, + WRITE_SIZE 660.6 MiB = 1.395 GB against
+# r02_pmc_write_size.txt: the T-row launches of gemm_nt_x6_kernel<false,true,2>): FETCH_SIZE 334.9 MiB, doubled as
+# MI355X_MICROARCH.md prescribes for 16 B/lane streaming reads on gfx950, + WRITE_SIZE 660.4 MiB = 1.395 GB against
 # 1.385 GB algorithmic.  (bf16x6 variant: round-1 measurement, profiles/r01_pmc_split_gemm.txt.)  PMC cannot be sampled
 # from inside this process, so the measured value is carried here and only reported when the workload matches.
-PMC_TRAFFIC_F16X3_T676200 = (2 * 335.0 + 660.6) * 1048576
+PMC_TRAFFIC_F16X3_T676200 = (2 * 334.9 + 660.4) * 1048576
 PMC_TRAFFIC_X6_T676200 = (2 * 360721.0 + 676200.0) * 1024
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F32_PEAK_TF = 157.3  # v_mfma_f32_32x32x2_f32 dense peak
