@@ -50,6 +50,9 @@
 #ifndef X6_PERSIST
 #define X6_PERSIST 0  // 1: long products on 512 persistent workgroups (bit-identical, measured no faster: see PERSIST below)
 #endif
+#ifndef TN_PIPE
+#define TN_PIPE 0  // 1: software-pipelined stage loop of the f16x3 weight-gradient kernel (see gemm_tn_x6_kernel)
+#endif
 #ifndef X6_EPI_NOSYNC
 #define X6_EPI_NOSYNC 0  // 1: no per-round __syncthreads() in the epilogue (see there)
 #endif
@@ -720,7 +723,6 @@ __global__ __launch_bounds__(TNT) void gemm_tn_x6_kernel(TnArgs g) {
         b_off[b] = NPL * TPLANE + k * (TSTEP * 2) + ((half ^ ((k >> 3) & 1)) << 4);
     }
 
-    float ra[TSTEP], rb[TSTEP];  // two stages of this thread's column in flight
 #define TN_LOAD(R, ST)                                                             \
     if ((ST) < nst && (!X6_ABL_NOALOAD || (ST) < 2)) {                                                              \
         _Pragma("unroll") for (int m = 0; m < TSTEP; ++m) {                        \
@@ -729,19 +731,14 @@ __global__ __launch_bounds__(TNT) void gemm_tn_x6_kernel(TnArgs g) {
             R[m] = __builtin_nontemporal_load(src + row * ld);                     \
         }                                                                          \
     }
-    // slice the landed stage into the LDS image `buf`, refill the registers with stage ST+2, hand over, multiply
-#define TN_STEP(R, ST, BUFI)                                                                                    \
-    if ((ST) < nst) {                                                                                           \
-        if ((ST) + 1 < nst)                                                                                     \
-            wait_vmcnt<TSTEP>();                                                                                \
-        else                                                                                                    \
-            wait_vmcnt<0>();                                                                                    \
-        unsigned char* buf = smem + (BUFI) * BUF;                                                               \
+    // slice the landed stage ST (registers R) into the LDS image `buf`
+#define TN_SLICE(R, ST, buf)                                                                                    \
+    {                                                                                                           \
         const int valid = (int)((rend - (rbeg + (int64_t)(ST) * TSTEP)) < TSTEP ? (rend - (rbeg + (int64_t)(ST) * TSTEP)) : TSTEP); \
         _Pragma("unroll") for (int c = 0; c < 2; ++c) {                                                         \
             float x[8];                                                                                         \
             _Pragma("unroll") for (int j = 0; j < 8; ++j) x[j] = (8 * c + j) < valid ? R[8 * c + j] : 0.0f;     \
-            unsigned char* dst = buf + w_off + ((c ^ w_swz) << 4);                                              \
+            unsigned char* dst = (buf) + w_off + ((c ^ w_swz) << 4);                                            \
             if constexpr (F16) {                                                                                \
                 f16x8 h, l;                                                                                     \
                 slice8_f16(make_float4(x[0], x[1], x[2], x[3]), make_float4(x[4], x[5], x[6], x[7]), scale, h, l); \
@@ -755,48 +752,106 @@ __global__ __launch_bounds__(TNT) void gemm_tn_x6_kernel(TnArgs g) {
                 *reinterpret_cast<bf16x8*>(dst + 2 * TPLANE) = l;                                               \
             }                                                                                                   \
         }                                                                                                       \
-        TN_LOAD(R, (ST) + 2)                                                                                    \
-        block_barrier(); /* slices of stage ST visible; every wave is past its reads of the other buffer */    \
-        if constexpr (F16) {                                                                                    \
-            f16x8 ah[TRM], al[TRM], bh[TRN], bl[TRN];                                                           \
-            _Pragma("unroll") for (int a = 0; a < TRM; ++a) {                                                   \
-                ah[a] = *reinterpret_cast<const f16x8*>(buf + a_off[a]);                                        \
-                al[a] = *reinterpret_cast<const f16x8*>(buf + a_off[a] + TPLANE);                               \
-            }                                                                                                   \
-            _Pragma("unroll") for (int b = 0; b < TRN; ++b) {                                                   \
-                bh[b] = *reinterpret_cast<const f16x8*>(buf + b_off[b]);                                        \
-                bl[b] = *reinterpret_cast<const f16x8*>(buf + b_off[b] + TPLANE);                               \
-            }                                                                                                   \
-            if (!X6_ABL_ONEMFMA) { TN_PASS(f16, al, bh) TN_PASS(f16, ah, bl) }                                  \
-            TN_PASS(f16, ah, bh)                                                                                \
-        } else {                                                                                                \
-            bf16x8 ah[TRM], am[TRM], al[TRM], bh[TRN], bm[TRN], bl[TRN];                                        \
-            _Pragma("unroll") for (int a = 0; a < TRM; ++a) {                                                   \
-                ah[a] = *reinterpret_cast<const bf16x8*>(buf + a_off[a]);                                       \
-                am[a] = *reinterpret_cast<const bf16x8*>(buf + a_off[a] + TPLANE);                              \
-                al[a] = *reinterpret_cast<const bf16x8*>(buf + a_off[a] + 2 * TPLANE);                          \
-            }                                                                                                   \
-            _Pragma("unroll") for (int b = 0; b < TRN; ++b) {                                                   \
-                bh[b] = *reinterpret_cast<const bf16x8*>(buf + b_off[b]);                                       \
-                bm[b] = *reinterpret_cast<const bf16x8*>(buf + b_off[b] + TPLANE);                              \
-                bl[b] = *reinterpret_cast<const bf16x8*>(buf + b_off[b] + 2 * TPLANE);                          \
-            }                                                                                                   \
-            TN_PASS(bf16, al, bh) TN_PASS(bf16, ah, bl) TN_PASS(bf16, am, bm)                                   \
-            TN_PASS(bf16, am, bh) TN_PASS(bf16, ah, bm) TN_PASS(bf16, ah, bh)                                   \
-        }                                                                                                       \
     }
 #define TN_PASS(TY, AA, BB)                                                                            \
     _Pragma("unroll") for (int a = 0; a < TRM; ++a) _Pragma("unroll") for (int b = 0; b < TRN; ++b)    \
         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_##TY(AA[a], BB[b], acc[a][b], 0, 0, 0);
-
-    TN_LOAD(ra, 0)
-    TN_LOAD(rb, 1)
-    for (int st = 0; st < nst; st += 2) {
-        TN_STEP(ra, st, 0)
-        TN_STEP(rb, st + 1, 1)
+    // operands of this wave's tiles out of the LDS image `buf` (f16x3), products deferred to TN_MMA_F16
+#define TN_READ_F16(buf)                                                                                        \
+    f16x8 ah[TRM], al[TRM], bh[TRN], bl[TRN];                                                                   \
+    _Pragma("unroll") for (int a = 0; a < TRM; ++a) {                                                           \
+        ah[a] = *reinterpret_cast<const f16x8*>((buf) + a_off[a]);                                              \
+        al[a] = *reinterpret_cast<const f16x8*>((buf) + a_off[a] + TPLANE);                                     \
+    }                                                                                                           \
+    _Pragma("unroll") for (int b = 0; b < TRN; ++b) {                                                           \
+        bh[b] = *reinterpret_cast<const f16x8*>((buf) + b_off[b]);                                              \
+        bl[b] = *reinterpret_cast<const f16x8*>((buf) + b_off[b] + TPLANE);                                     \
     }
-#undef TN_PASS
+#define TN_MMA_F16                                                                                              \
+    if (!X6_ABL_ONEMFMA) { TN_PASS(f16, al, bh) TN_PASS(f16, ah, bl) }                                          \
+    TN_PASS(f16, ah, bh)
+#define TN_MMA_BF16(buf)                                                                                        \
+    {                                                                                                           \
+        bf16x8 ah[TRM], am[TRM], al[TRM], bh[TRN], bm[TRN], bl[TRN];                                            \
+        _Pragma("unroll") for (int a = 0; a < TRM; ++a) {                                                       \
+            ah[a] = *reinterpret_cast<const bf16x8*>((buf) + a_off[a]);                                         \
+            am[a] = *reinterpret_cast<const bf16x8*>((buf) + a_off[a] + TPLANE);                                \
+            al[a] = *reinterpret_cast<const bf16x8*>((buf) + a_off[a] + 2 * TPLANE);                            \
+        }                                                                                                       \
+        _Pragma("unroll") for (int b = 0; b < TRN; ++b) {                                                       \
+            bh[b] = *reinterpret_cast<const bf16x8*>((buf) + b_off[b]);                                         \
+            bm[b] = *reinterpret_cast<const bf16x8*>((buf) + b_off[b] + TPLANE);                                \
+            bl[b] = *reinterpret_cast<const bf16x8*>((buf) + b_off[b] + 2 * TPLANE);                            \
+        }                                                                                                       \
+        TN_PASS(bf16, al, bh) TN_PASS(bf16, ah, bl) TN_PASS(bf16, am, bm)                                       \
+        TN_PASS(bf16, am, bh) TN_PASS(bf16, ah, bm) TN_PASS(bf16, ah, bh)                                       \
+    }
+
+    if constexpr (F16 && TN_PIPE) {
+        // Software-pipelined stage loop (f16x3): THREE stages of this thread's column in flight in registers; the slices
+        // of stage s+1 are computed and written to the other LDS buffer in the shadow of the products of stage s (VALU
+        // and LDS-write instructions issue while the matrix pipe works through the 24 products), one barrier per stage.
+        // Same arithmetic in the same order as the two-stage loop: bit-identical.
+        float r0[TSTEP], r1[TSTEP], r2[TSTEP];
+        TN_LOAD(r0, 0)
+        TN_LOAD(r1, 1)
+        TN_LOAD(r2, 2)
+        if (nst > 0) {
+            if (nst > 2) wait_vmcnt<2 * TSTEP>(); else if (nst > 1) wait_vmcnt<TSTEP>(); else wait_vmcnt<0>();
+            TN_SLICE(r0, 0, smem)
+        }
+#define TN_PIPE_STEP(RNEXT, RFREE, ST)                                                                          \
+    if ((ST) < nst) {                                                                                           \
+        if ((ST) + 2 < nst) wait_vmcnt<TSTEP>(); else wait_vmcnt<0>(); /* stage ST+1 has landed */              \
+        block_barrier(); /* slices of stage ST visible; every wave is past its reads of stage ST-1 */          \
+        unsigned char* cur = smem + ((ST) & 1) * BUF;                                                           \
+        unsigned char* nxt = smem + (((ST) + 1) & 1) * BUF;                                                     \
+        TN_READ_F16(cur)                                                                                        \
+        if (!X6_ABL_ONEMFMA) { TN_PASS(f16, al, bh) }                                                           \
+        if ((ST) + 1 < nst) TN_SLICE(RNEXT, (ST) + 1, nxt)                                                      \
+        if (!X6_ABL_ONEMFMA) { TN_PASS(f16, ah, bl) }                                                           \
+        TN_PASS(f16, ah, bh)                                                                                    \
+        TN_LOAD(RFREE, (ST) + 3)                                                                                \
+    }
+        for (int st = 0; st < nst; st += 3) {
+            TN_PIPE_STEP(r1, r0, st)
+            TN_PIPE_STEP(r2, r1, st + 1)
+            TN_PIPE_STEP(r0, r2, st + 2)
+        }
+#undef TN_PIPE_STEP
+    } else {
+        float ra[TSTEP], rb[TSTEP];  // two stages of this thread's column in flight
+        // slice the landed stage into the LDS image, refill the registers with stage ST+2, hand over, multiply
+#define TN_STEP(R, ST, BUFI)                                                                                    \
+    if ((ST) < nst) {                                                                                           \
+        if ((ST) + 1 < nst)                                                                                     \
+            wait_vmcnt<TSTEP>();                                                                                \
+        else                                                                                                    \
+            wait_vmcnt<0>();                                                                                    \
+        unsigned char* buf = smem + (BUFI) * BUF;                                                               \
+        TN_SLICE(R, ST, buf)                                                                                    \
+        TN_LOAD(R, (ST) + 2)                                                                                    \
+        block_barrier(); /* slices of stage ST visible; every wave is past its reads of the other buffer */    \
+        if constexpr (F16) {                                                                                    \
+            TN_READ_F16(buf)                                                                                    \
+            TN_MMA_F16                                                                                          \
+        } else {                                                                                                \
+            TN_MMA_BF16(buf)                                                                                    \
+        }                                                                                                       \
+    }
+        TN_LOAD(ra, 0)
+        TN_LOAD(rb, 1)
+        for (int st = 0; st < nst; st += 2) {
+            TN_STEP(ra, st, 0)
+            TN_STEP(rb, st + 1, 1)
+        }
 #undef TN_STEP
+    }
+#undef TN_MMA_BF16
+#undef TN_MMA_F16
+#undef TN_READ_F16
+#undef TN_PASS
+#undef TN_SLICE
 #undef TN_LOAD
 
     // epilogue: slab z of the workspace, rows n, cols k; per-wave LDS transpose -> float4 row segments

@@ -52,6 +52,14 @@ def run_tn():
         for _ in range(10): call()
         e.record(); torch.cuda.synchronize()
         print(f"TN f16x3 {k:18s} {s.elapsed_time(e)/10*1e3:8.1f} us", flush=True)
+        ws.zero_(); assert call() == 0; torch.cuda.synchronize()
+        if os.environ.get("ABL_CHECK") == "1":
+            if "_tn_ref" not in globals():
+                globals()["_tn_ref"] = (k, ws.clone())
+            else:
+                rk, rw = globals()["_tn_ref"]
+                same = torch.equal(ws, rw)
+                print(f"   check {k} vs {rk}: {'bit-identical' if same else 'DIFFERENT max|d| = %g' % (ws - rw).abs().max().item()}", flush=True)
 def run_f16():
     """f16x3 NT kernel, T x 256 x 256 (the roofline kernel of bench.py)."""
     M, N, K = 676200, 256, 256
@@ -102,7 +110,7 @@ F16V = {"warm": [], "base": [], "nosync": ["-DX6_EPI_NOSYNC=1"], "nolate": ["-DX
         "onemfma_noepi": ["-DX6_ABL_ONEMFMA=1", "-DX6_ABL_NOSTORE=2"],
         "noaload_nostore": ["-DX6_ABL_NOALOAD=1", "-DX6_ABL_NOSTORE=1"],
         "stage3_noepi": ["-DX6_NSTAGE=3", "-DX6_ABL_NOSTORE=2"], "rm1": ["-DX6_FORCE_RM=1"], "stage3": ["-DX6_NSTAGE=3"], "stage3_nostore": ["-DX6_NSTAGE=3", "-DX6_ABL_NOSTORE=1"]}
-TNV = {"warm": [], "base": [], "noload": ["-DX6_ABL_NOALOAD=1"], "onemfma": ["-DX6_ABL_ONEMFMA=1"], "noload_onemfma": ["-DX6_ABL_NOALOAD=1", "-DX6_ABL_ONEMFMA=1"]}
+TNV = {"warm": [], "base": [], "pipe": ["-DTN_PIPE=1"], "noload": ["-DX6_ABL_NOALOAD=1"], "onemfma": ["-DX6_ABL_ONEMFMA=1"], "noload_onemfma": ["-DX6_ABL_NOALOAD=1", "-DX6_ABL_ONEMFMA=1"]}
 if os.environ.get("ABL_TN") == "1":
     VARIANTS = TNV
     run = run_tn
