@@ -31,6 +31,8 @@
 // thread owns one column of a 16-row stage (16 coalesced nontemporal dword loads, two stages in flight in
 // registers), slices it ONCE and writes the 16-bit planes k-contiguous to LDS; the waves then fetch MFMA operands
 // with ds_read_b128.  Split-K over M into slabs; the slab partials are summed by gemm_f32.hip's slab_reduce4.
+#include <cstdlib>
+
 #include "common.h"
 #include "../../include/alignn_hip.h"
 
@@ -55,6 +57,30 @@
 #endif
 #ifndef X6_EPI_NOSYNC
 #define X6_EPI_NOSYNC 0  // 1: no per-round __syncthreads() in the epilogue (see there)
+#endif
+#ifndef X6_KPIPE
+#define X6_KPIPE 0  // 1: f16x3 k-loop with the stage hand-over in the middle of a step's MFMAs (see the k-loop)
+#endif
+#ifndef X6_STAGGER
+#define X6_STAGGER 0
+#endif
+#ifndef X6P_NT
+#define X6P_NT 1  // 0: plain (L2 write-back) stores in the persistent kernel's epilogue (experiment)
+#endif
+#ifndef X6_TRACE
+#define X6_TRACE 0  // 1: wave 0 of every workgroup stamps its phases with s_memtime (tools/x6_trace.py reads them)
+#endif
+#if X6_TRACE
+__device__ unsigned long long x6_trace_buf[8192 * 8];
+#define X6_STAMP(i)                                                                                   \
+    do {                                                                                              \
+        if (threadIdx.x == 0 && blockIdx.x < 8192 && blockIdx.y == 0)                                 \
+            x6_trace_buf[blockIdx.x * 8 + (i)] = __builtin_readcyclecounter();                        \
+    } while (0)
+#else
+#define X6_STAMP(i) \
+    do {            \
+    } while (0)
 #endif
 #ifndef X6_ABL_NOSTORE
 #define X6_ABL_NOSTORE 0  // 1: epilogue without its global stores, 2: no epilogue at all
@@ -136,6 +162,8 @@ struct X6Args {
     int64_t ldgp;
     const int32_t* gsrc;  // [M] source node of edge row e
     const int32_t* gdst;  // [M] destination node of edge row e
+    int stagger;          // persistent kernel: start delay (shader cycles) of the second workgroup of every CU
+    int strip_slabs;      // one-tile kernels: column-sum slabs per 64-row wave strip (see the end of gemm_nt_x6_body)
 };
 
 __device__ __forceinline__ unsigned hi_pair(float x1, float x0) {
@@ -210,14 +238,18 @@ __device__ __forceinline__ void slice8_f16(const float4& lo, const float4& hi4, 
     slice8_f16_lo(xs, h, l);
 }
 
-#ifndef X6_A_AUX
-#define X6_A_AUX 0  // default cache policy (nt on the read-once activation tile measured 10 % slower)
-#endif
-template <int AUX>
-__device__ __forceinline__ void dma16(const void* gsrc, unsigned char* lds_wave_base) {
-    // 64 lanes x 16 B -> 1 KiB of LDS at lds_wave_base (wave-uniform) + lane*16; source address is per lane
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, AUX);
+// 64 lanes x 16 B -> 1 KiB of LDS at lds_wave_base (wave-uniform) + lane*16, from sbase (wave-uniform, scalar
+// registers) + lane_off (+ OFF).  Written as the instruction itself: through __builtin_amdgcn_global_load_lds hipcc
+// builds a 64-bit vector address per piece and k-step (v_lshl_add_u64) and, in the pipelined loop, answered a ds_read
+// whose destination landed on such an address pair with s_waitcnt vmcnt(0) - a wait for the DMA issued just before.
+// The compiler neither sees these loads (every vmcnt wait on them is explicit, see wait_vmcnt) nor uses M0 for
+// anything else on gfx950.  (Default cache policy: nt on the read-once activation tile measured 10 % slower.)
+template <int OFF>
+__device__ __forceinline__ void dma16(const void* sbase, unsigned lane_off, unsigned char* lds_wave_base) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3"
+                 :
+                 : "s"((unsigned)(size_t)lds_wave_base), "v"(lane_off), "s"(sbase), "n"(OFF)
+                 : "memory");
 }
 
 // PERSIST: the launch has fewer workgroups than row tiles; a workgroup walks tiles blockIdx.x, +gridDim.x, ... and
@@ -266,18 +298,47 @@ __device__ __forceinline__ void gemm_nt_x6_body(const X6Args& g) {
 
     f32x16 acc[RM][RN];
 
+#if X6_TRACE
+    if (threadIdx.x == 0 && blockIdx.x < 8192 && blockIdx.y == 0) {
+        unsigned id, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        x6_trace_buf[blockIdx.x * 8 + 7] = ((unsigned long long)xcc << 32) | id;
+    }
+    X6_STAMP(0);
+#endif
+#if X6_STAGGER
+    // (experiment) the two workgroups of a CU start together and have the same work: they stay in phase - both in the
+    // k-loop (competing for the matrix pipe), then both in the epilogue (matrix pipe idle).  Delay the first-generation
+    // workgroup in the odd wave slot by about half a tile time; its successors inherit the offset.
+    if (blockIdx.x < 512 && blockIdx.y == 0) {
+        unsigned id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id));
+        if (id & 1) {
+            const unsigned long long t0 = __builtin_readcyclecounter();
+            while (__builtin_readcyclecounter() - t0 < (unsigned long long)X6_STAGGER) __builtin_amdgcn_s_sleep(16);
+        }
+    }
+#endif
+
     // ---- DMA addressing (LDS image is lane-linear; the XOR swizzle lives in the SOURCE address)
     // A: piece q = wave*A_DMA + i holds tile positions p = q*64 + lane -> row p/4, stored chunk p%4, which is
     //    global chunk (p%4) ^ ((row>>2)&3) of that row.
-    const float* a_src[A_DMA];
+    // Global addresses are a wave-uniform base (scalar registers, advanced per k-step) plus a loop-invariant 32-bit lane
+    // offset: no per-piece 64-bit vector arithmetic in the loop and no short-lived address registers (a ds_read whose
+    // destination the allocator had put on a just-used address pair drew an s_waitcnt vmcnt(0) from hipcc in the
+    // pipelined loop - i.e. a wait for the DMA issued two instructions earlier).
+    unsigned a_lane[A_DMA];
+    const float* a_base = g.A;
     auto set_rows = [&](int64_t row0) {
+        a_base = g.A + row0 * g.lda;
 #pragma unroll
         for (int i = 0; i < A_DMA; ++i) {
             const int p = (wave * A_DMA + i) * 64 + lane;
             const int row = p >> 2, c = (p & 3) ^ ((row >> 2) & 3);
             int64_t grow = row0 + row;
             if (grow >= g.M) grow = g.M - 1;  // clamp: rows past the end are computed but never stored
-            a_src[i] = g.A + grow * g.lda + c * 4;
+            a_lane[i] = (unsigned)(((grow - row0) * g.lda + c * 4) * 4);
         }
     };
     set_rows(m0);
@@ -285,24 +346,21 @@ __device__ __forceinline__ void gemm_nt_x6_body(const X6Args& g) {
     // exactly the LDS image order (pre-swizzled), so a stage is sequential 1 KiB pieces and consecutive
     // k-blocks walk the weight image linearly (no power-of-two plane strides in the L2).
     const int64_t kb_stride = (int64_t)(g.Npad / BN) * (NPL * B_PLANE);
-    const unsigned char* b_src[B_DMA];
-#pragma unroll
-    for (int i = 0; i < B_DMA; ++i) {
-        const int q = wave * B_DMA + i;  // 1 KiB piece q of the 24 KiB stage image
-        b_src[i] = g.Ws + (int64_t)blockIdx.y * (NPL * B_PLANE) + q * 1024 + lane * 16;
-    }
+    const unsigned char* b_base = g.Ws + (int64_t)blockIdx.y * (NPL * B_PLANE) + (wave * B_DMA) * 1024;
+    const unsigned b_lane = lane * 16;
     auto issue = [&](int kt, unsigned char* stage) {
 #if X6_ABL_NOALOAD
         if (kt == 0)
 #endif
 #pragma unroll
-        for (int i = 0; i < A_DMA; ++i) dma16<X6_A_AUX>(a_src[i] + kt * BK, stage + (wave * A_DMA + i) * 1024);
+        for (int i = 0; i < A_DMA; ++i)
+            dma16<0>(a_base + kt * BK, a_lane[i], stage + (wave * A_DMA + i) * 1024);
 #if X6_ABL_NOBLOAD
         if (kt == 0)
 #endif
 #pragma unroll
         for (int i = 0; i < B_DMA; ++i)
-            dma16<0>(b_src[i] + kt * kb_stride, stage + A_BYTES + (wave * B_DMA + i) * 1024);
+            dma16<0>(b_base + kt * kb_stride + i * 1024, b_lane, stage + A_BYTES + (wave * B_DMA + i) * 1024);
     };
 
     // reader addresses (bytes inside a stage)
@@ -360,6 +418,76 @@ __device__ __forceinline__ void gemm_nt_x6_body(const X6Args& g) {
         for (int b = 0; b < RN; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    if constexpr (F16 && X6_KPIPE && !PERSIST) {
+        // Software-pipelined form of the loop below.  A wave's step there is a serial chain - wait for the stage, barrier,
+        // issue the next DMA, LDS reads, high slices, 24 MFMAs - of which only the MFMAs are hidden by the co-resident
+        // workgroup.  Here the stage hand-over sits in the MIDDLE of a step's products: after the first two passes of step
+        // kt (16 MFMAs in the pipe) the wave waits for stage kt+1, passes the barrier, issues the DMA of stage kt+NSTAGE
+        // into the slot of stage kt (every wave's LDS reads of it have completed: block_barrier() drains lgkmcnt) and
+        // reads the operands of step kt+1 - into the registers the finished passes have released - while the third pass
+        // runs.  Same products in the same order per accumulator: bit-identical.
+        f16x8 ah[RM], al[RM], bh[RN], bl[RN];
+        float xs[RM][8];
+        auto read_hi = [&](const unsigned char* stage) {
+#pragma unroll
+            for (int b = 0; b < RN; ++b) bh[b] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(stage + b_off[b]));
+#pragma unroll
+            for (int a = 0; a < RM; ++a)
+                slice8_f16_hi(*reinterpret_cast<const float4*>(stage + a_off0[a]),
+                              *reinterpret_cast<const float4*>(stage + a_off1[a]), sa, xs[a], ah[a]);
+        };
+        auto read_lo = [&](const unsigned char* stage) {
+#pragma unroll
+            for (int b = 0; b < RN; ++b)
+                bl[b] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(stage + b_off[b] + B_PLANE));
+        };
+#define X6_PASS(AA, BB)                                                                              \
+    _Pragma("unroll") for (int a = 0; a < RM; ++a) _Pragma("unroll") for (int b = 0; b < RN; ++b)    \
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AA[a], BB[b], acc[a][b], 0, 0, 0);
+        // stage 0: landed -> barrier -> DMA of stage NSTAGE-1 -> operands of step 0
+        if (NSTAGE == 3 && 1 < nk)
+            wait_vmcnt<PIECES>();
+        else
+            wait_vmcnt<0>();
+        block_barrier();
+        if (NSTAGE - 1 < nk) issue(NSTAGE - 1, smem + ((NSTAGE - 1) % NSTAGE) * STAGE_BYTES);
+        read_hi(smem);
+        read_lo(smem);
+        for (int kt = 0; kt < nk; ++kt) {
+            X6_PASS(ah, bh)
+#pragma unroll
+            for (int a = 0; a < RM; ++a) slice8_f16_lo(xs[a], ah[a], al[a]);
+            X6_PASS(al, bh)
+            const bool more = kt + 1 < nk;
+            const unsigned char* nstage = smem + ((kt + 1) % NSTAGE) * STAGE_BYTES;
+            float4 raw0[RM], raw1[RM];
+            if (more) {
+                if (NSTAGE == 3 && kt + 2 < nk)
+                    wait_vmcnt<PIECES>();
+                else
+                    wait_vmcnt<0>();
+                block_barrier();
+                if (kt + NSTAGE < nk) issue(kt + NSTAGE, smem + ((kt + NSTAGE) % NSTAGE) * STAGE_BYTES);
+#pragma unroll
+                for (int b = 0; b < RN; ++b)
+                    bh[b] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(nstage + b_off[b]));
+#pragma unroll
+                for (int a = 0; a < RM; ++a) {
+                    raw0[a] = *reinterpret_cast<const float4*>(nstage + a_off0[a]);
+                    raw1[a] = *reinterpret_cast<const float4*>(nstage + a_off1[a]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            X6_PASS(ah, bl)
+            __builtin_amdgcn_sched_barrier(0);  // (the LDS latency of the reads above is spent under this pass)
+            if (more) {
+                read_lo(nstage);
+#pragma unroll
+                for (int a = 0; a < RM; ++a) slice8_f16_hi(raw0[a], raw1[a], sa, xs[a], ah[a]);
+            }
+        }
+#undef X6_PASS
+    } else
     for (int kt = 0; kt < nk; ++kt) {
         if (PERSIST && kt == 0 && !first)
             wait_vmcnt<EPI_STORES>();  // stage 0 was prefetched BEFORE the previous tile's stores: leave those in flight
@@ -368,6 +496,8 @@ __device__ __forceinline__ void gemm_nt_x6_body(const X6Args& g) {
         else
             wait_vmcnt<0>();
         block_barrier();
+        if (kt == 0) X6_STAMP(1);
+        if (kt == 8) X6_STAMP(2);
         // (issuing these DMA pieces between the product passes instead - they cost a wave fewer issue cycles among
         // MFMAs than in front of LDS reads - measured 3.5 % SLOWER at T x 256 x 256)
         if (kt + NSTAGE - 1 < nk) issue(kt + NSTAGE - 1, smem + ((kt + NSTAGE - 1) % NSTAGE) * STAGE_BYTES);
@@ -432,6 +562,7 @@ __device__ __forceinline__ void gemm_nt_x6_body(const X6Args& g) {
         }
     }
 
+    X6_STAMP(3);
     // epilogue: per-wave LDS transpose of two 32x32 tiles at a time -> float4 row segments.  Per round: all LDS
     // traffic first, then all addend loads (rows clamped, no per-element branches), then the stores.
     const int64_t next = tile + gridDim.x;
@@ -574,8 +705,11 @@ __device__ __forceinline__ void gemm_nt_x6_body(const X6Args& g) {
     }
     if constexpr (BNRED || STATS) {
         // column sums: the 4 row groups of a wave (lanes l, l+16, l+32, l+48), then the 2 wave rows - fixed order
+        // (strip_slabs: one slab per wave row strip instead of one per tile - the slab granularity of the persistent
+        // kernel, which takes most variants of the same shape; alignn_gemm_nt_x6_row_tiles counts strips then)
         __syncthreads();
-        if (wm == 0 && lane < 16) {
+        const bool strips = g.strip_slabs != 0;
+        if ((strips ? m0 + wm * TM < g.M : wm == 0) && lane < 16) {
 #pragma unroll
             for (int hb = 0; hb < RN / 2; ++hb) {
                 const int col = n0 + wn * TN + hb * 64 + lane * 4;
@@ -585,17 +719,24 @@ __device__ __forceinline__ void gemm_nt_x6_body(const X6Args& g) {
                         float4 sum = f4_zero();
 #pragma unroll
                         for (int w = 0; w < WM; ++w)
+                            if (!strips || w == wm)
 #pragma unroll
-                            for (int pr = 0; pr < 4; ++pr)
-                                sum = f4_add(sum, f4_ld(red_acc + (((w * WN + wn) * (RN / 2) + hb) * 2 + k) * 256 +
-                                                        (pr * 16 + lane) * 4));
+                                for (int pr = 0; pr < 4; ++pr)
+                                    sum = f4_add(sum, f4_ld(red_acc + (((w * WN + wn) * (RN / 2) + hb) * 2 + k) * 256 +
+                                                            (pr * 16 + lane) * 4));
                         if (BNRED && k == 1) sum = f4_mul(sum, f4_ld(g.nstat + g.N + col));  // sum gz*(x-mean) -> sum gz*xhat
-                        f4_st(g.red_partial + ((size_t)tile * 2 + k) * g.N + col, sum);
+                        const size_t slab = strips ? (size_t)tile * WM + wm : (size_t)tile;
+                        f4_st(g.red_partial + (slab * 2 + k) * g.N + col, sum);
                     }
                 }
             }
         }
     }
+    X6_STAMP(4);
+#if X6_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    X6_STAMP(5);
+#endif
     if (!has_next) break;
     tile = next;
     m0 = tile * BM;
@@ -621,6 +762,339 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void ge
 template <int RM_>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void gemm_nt_x6_stats_kernel(X6Args g) {
     gemm_nt_x6_body<false, true, RM_, false, 4>(g);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Persistent form of the f16x3 NT kernel for long products (>= 2 row tiles per resident workgroup; 128 x 256 tiles).
+// A one-tile workgroup spends its life in four serial phases - in-kernel s_memtime stamps at T x 256 x 256
+// (tools/x6_trace.py, profiles/r02_x6_phase_trace_onetile.txt): 11 % from entry until the first k-stage has landed, 62 % in the
+// 16 k-steps, 23 % in the epilogue, 3 % waiting for its stores before it may retire - and only the co-resident
+// workgroup fills the gaps.  Here 512 workgroups walk the row tiles.  The DMA ring has THREE slots: while step s
+// multiplies out of slot s % 3, stages s+1 and s+2 are in flight - across tile boundaries too, so the first two
+// stages of the next tile land under the epilogue of the current one, and the slot the last step has just released
+// (s % 3) serves as the transpose patches (per wave a private 32 x 32 patch: no barrier inside the epilogue).  The
+// stores are fire-and-forget: vmcnt retires in order and counts stores, so the only waits that could meet them are
+// the ones on stages issued AFTER them - the first of which is needed two k-steps later, when they are long gone; the
+// two prefetched stages are waited for (vmcnt(0), normally already there) BEFORE the first store is issued, so no
+// counted wait ever spans the data-dependent number of stores of an epilogue.
+// Per tile: nk step barriers + one barrier between the last step and the first patch write.
+// Column sums (EPI flags BNRED / STATS): per WAVE strip of 64 rows, reduced over the wave's eight row groups by
+// lane shuffles in a fixed order -> one [2][N] slab per 64 rows (alignn_gemm_nt_x6_row_tiles tells the caller).
+template <bool HAS_ADD, int EPI>
+__device__ __forceinline__ void gemm_nt_f16p_body(const X6Args& g) {
+    constexpr bool BNRED = (EPI & 1) != 0, GATHER = (EPI & 2) != 0, STATS = (EPI & 4) != 0;
+    static_assert(!(BNRED && STATS), "one set of column sums per launch");
+    static_assert(!GATHER || !HAS_ADD, "the gather variant has its own two addends");
+    constexpr int RM = 2, BM = Geo<2>::BM, TM = Geo<2>::TM, A_BYTES = Geo<2>::A_BYTES, A_DMA = Geo<2>::A_DMA;
+    constexpr int NPL = 2, STAGE_BYTES = A_BYTES + NPL * B_PLANE, B_DMA = NPL * B_PLANE / 1024 / (NT / 64);
+    constexpr int NS = 3, PIECES = A_DMA + B_DMA;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int il = lane & 31, half = lane >> 5;
+    const int n_nt = g.Npad / BN;
+    const int tiles = (int)((g.M + BM - 1) / BM) * n_nt;  // (< 2^31: the launcher checks)
+    const int J = (tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;  // tiles of this workgroup (>= 1)
+    const int nk = g.K / BK;
+    const int S = J * nk;  // k-steps of this workgroup, numbered across its tiles
+
+    // ---- DMA side: the stage to issue next is (it_tile, it_kt)
+    const int64_t kb_stride = (int64_t)n_nt * (NPL * B_PLANE);
+    const unsigned b_lane = lane * 16;
+    unsigned a_lane[A_DMA];
+    const float* a_base = g.A;
+    const unsigned char* b_base = g.Ws;
+    int it_tile = blockIdx.x;
+    int it_kt = 0, issued = 0;
+    auto set_issue_tile = [&](int tile) {
+        const int64_t row0 = (int64_t)(tile / n_nt) * BM;
+        a_base = g.A + row0 * g.lda;
+        b_base = g.Ws + (tile % n_nt) * (NPL * B_PLANE) + (wave * B_DMA) * 1024;
+#pragma unroll
+        for (int i = 0; i < A_DMA; ++i) {
+            const int p = (wave * A_DMA + i) * 64 + lane;
+            const int row = p >> 2, c = (p & 3) ^ ((row >> 2) & 3);
+            int64_t grow = row0 + row;
+            if (grow >= g.M) grow = g.M - 1;  // clamp: rows past the end are computed but never stored
+            a_lane[i] = (unsigned)(((grow - row0) * g.lda + c * 4) * 4);
+        }
+    };
+    auto issue_next = [&](int slot) {
+        unsigned char* stage = smem + slot * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < A_DMA; ++i) dma16<0>(a_base + it_kt * BK, a_lane[i], stage + (wave * A_DMA + i) * 1024);
+#pragma unroll
+        for (int i = 0; i < B_DMA; ++i)
+            dma16<0>(b_base + it_kt * kb_stride + i * 1024, b_lane, stage + A_BYTES + (wave * B_DMA + i) * 1024);
+        ++issued;
+        if (++it_kt == nk) {
+            it_kt = 0;
+            it_tile += gridDim.x;
+            if (it_tile < tiles) set_issue_tile(it_tile);
+        }
+    };
+    set_issue_tile(it_tile);
+
+    // reader addresses (bytes inside a stage)
+    int a_off0[RM], a_off1[RM];
+#pragma unroll
+    for (int a = 0; a < RM; ++a) {
+        const int arow = wm * TM + a * 32 + il;
+        const int a_f = (arow >> 2) & 3;
+        a_off0[a] = arow * (BK * 4) + (((2 * half) ^ a_f) << 4);
+        a_off1[a] = arow * (BK * 4) + (((2 * half + 1) ^ a_f) << 4);
+    }
+    int b_off[RN];
+#pragma unroll
+    for (int b = 0; b < RN; ++b) {
+        const int n = wn * TN + b * 32 + il;
+        b_off[b] = A_BYTES + n * (BK * 2) + ((half ^ ((n >> 3) & 1)) << 4);
+    }
+    const float sa = f16_scale(*g.a_amax), inv_sa = 1.0f / sa, inv_sw = 1.0f / f16_scale(*g.w_amax);
+
+    // Persistent workgroups that start together stay in step for the whole launch - all of them in the k-loop (reads, matrix
+    // pipe), then all of them in the epilogue (writes, matrix pipe idle).  The second resident workgroup of every CU
+    // (blocks 256..511: block b runs on XCD b % 8 and the first 256 fill one slot of every CU) starts half a tile later,
+    // so that one's epilogue runs beside the other's k-loop.
+    if (g.stagger > 0 && blockIdx.x >= 256) {
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        while (__builtin_readcyclecounter() - t0 < (unsigned long long)g.stagger) __builtin_amdgcn_s_sleep(8);
+    }
+    if (0 < S) issue_next(0);
+    if (1 < S) issue_next(1);
+
+    f32x16 acc[RM][RN];
+    int slot = 0;  // of the step about to run
+    int tile = blockIdx.x;
+    constexpr int PLD = 32 + 4;                // patch row stride (floats)
+    constexpr int PATCH_BYTES = STAGE_BYTES / (NT / 64);  // 6 KiB per wave >= 32 * PLD * 4
+    static_assert(32 * PLD * 4 <= PATCH_BYTES, "patch fits its share of a slot");
+    const int prow = lane >> 3, pc4 = (lane & 7) * 4;  // patch reader: 8 lanes per 32-float row, 8 rows per instruction
+    for (int j = 0; j < J; ++j, tile += gridDim.x) {
+        const int64_t m0 = (int64_t)(tile / n_nt) * BM;
+        const int n0 = (tile % n_nt) * BN;
+#pragma unroll
+        for (int a = 0; a < RM; ++a)
+#pragma unroll
+            for (int b = 0; b < RN; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+        // EPI GATHER: the node pair (src, dst) of the strip's row `lane`, requested now and used after the k-loop (one
+        // coalesced load per tile instead of a dependent index load in front of every gather)
+        int src_l = 0, dst_l = 0;
+        if constexpr (GATHER) {
+            int64_t row = m0 + wm * TM + lane;
+            row = row < g.M ? row : g.M - 1;
+            src_l = g.gsrc[row];
+            dst_l = g.gdst[row];
+        }
+        if (j == 1) X6_STAMP(0);
+#if X6_TRACE == 2
+        unsigned long long ph[5] = {0, 0, 0, 0, 0}, tp = __builtin_readcyclecounter();
+#define X6_PH(i)                                                    \
+    do {                                                            \
+        const unsigned long long tn_ = __builtin_readcyclecounter(); \
+        ph[i] += tn_ - tp;                                          \
+        tp = tn_;                                                   \
+    } while (0)
+#else
+#define X6_PH(i) \
+    do {         \
+    } while (0)
+#endif
+        for (int kt = 0; kt < nk; ++kt) {
+            const int s = j * nk + kt;
+            // stage s has landed?  Steps 0 and 1 of a later tile were waited for before the previous epilogue.
+            if (j == 0 || kt >= 2) {
+                if (s + 1 < S)
+                    wait_vmcnt<PIECES>();
+                else
+                    wait_vmcnt<0>();
+            }
+            X6_PH(0);
+            block_barrier();  // (also: every wave has left slot (s+2) % 3 - the reads of step s-1 or the patches)
+            X6_PH(1);
+            if (j == 2 && kt == 0) X6_STAMP(5);
+            if (j == 2 && kt == 2) X6_STAMP(6);
+            if (issued < S) issue_next(slot == 0 ? 2 : slot - 1);  // stage s+2 -> slot (s+2) % 3
+            X6_PH(2);
+            const unsigned char* stage = smem + slot * STAGE_BYTES;
+            slot = slot == NS - 1 ? 0 : slot + 1;
+            f16x8 ah[RM], al[RM], bh[RN], bl[RN];
+            float xs[RM][8];
+#pragma unroll
+            for (int a = 0; a < RM; ++a)
+                slice8_f16_hi(*reinterpret_cast<const float4*>(stage + a_off0[a]),
+                              *reinterpret_cast<const float4*>(stage + a_off1[a]), sa, xs[a], ah[a]);
+#pragma unroll
+            for (int b = 0; b < RN; ++b) {
+                const unsigned char* q = stage + b_off[b];
+                bh[b] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(q));
+                bl[b] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(q + B_PLANE));
+            }
+#define X6_PASS(AA, BB)                                                                              \
+    _Pragma("unroll") for (int a = 0; a < RM; ++a) _Pragma("unroll") for (int b = 0; b < RN; ++b)    \
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AA[a], BB[b], acc[a][b], 0, 0, 0);
+#if X6_TRACE == 2
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            X6_PH(3);
+#endif
+            X6_PASS(ah, bh)
+#pragma unroll
+            for (int a = 0; a < RM; ++a) slice8_f16_lo(xs[a], ah[a], al[a]);
+            X6_PASS(ah, bl)
+            X6_PASS(al, bh)
+#undef X6_PASS
+#if X6_TRACE == 2
+            __builtin_amdgcn_sched_barrier(0);
+            X6_PH(4);
+#endif
+        }
+#if X6_TRACE == 2
+        if (j == 1 && threadIdx.x == 0 && blockIdx.x < 512)
+            for (int i = 0; i < 5; ++i) x6_trace_buf[(4096 + blockIdx.x) * 8 + i] = ph[i];
+#endif
+        if (j == 1) X6_STAMP(1);
+        // the two stages in flight belong to the next tile: have them landed before the first store goes out (see above)
+        wait_vmcnt<0>();
+        if (j == 1) X6_STAMP(2);
+        block_barrier();  // every wave has finished reading the last stage: its slot becomes the patches
+        if (j == 1) X6_STAMP(3);
+        float* patch = reinterpret_cast<float*>(smem + (slot == 0 ? NS - 1 : slot - 1) * STAGE_BYTES + wave * PATCH_BYTES);
+        // The epilogue has NO control flow around its memory operations (N is a multiple of 256 here; rows past the end are
+        // clamped to the last row, whose values the clamped operand rows reproduce bit for bit, so the surplus stores
+        // rewrite that row with what it already holds): hipcc counts vmcnt exactly only through straight-line code -
+        // with predicated stores it fell back to s_waitcnt vmcnt(0) before every round's loads AND before the first LDS
+        // read of the next k-loop, i.e. it drained the stores and the DMA ring.
+        // Eight rounds (b = column group, a = row group) of one 32 x 32 accumulator tile per wave.  vmcnt retires in order
+        // and counts stores, so the operands of round r+1 (residual / pre-activation / gathered rows, BatchNorm constants)
+        // are requested BEFORE the stores of round r go out: their consumer then waits for vmcnt(4), not for those stores.
+        const int last_row = (int)(g.M - 1 - m0 < BM - 1 ? g.M - 1 - m0 : BM - 1);  // last valid row of the tile (relative)
+        // (the global offsets below are the same for every tile: left alone, hipcc computes all 32 of them once, in front
+        // of the tile loop, and carries them through the k-loop in registers the MFMA operands need)
+        int prow_e = prow, pc4_e = pc4;
+        asm volatile("" : "+v"(prow_e), "+v"(pc4_e));
+        float* c_t = g.C + m0 * g.ldc;
+        const float* add_t = HAS_ADD ? g.addend + m0 * g.ldadd : nullptr;
+        const float* xn_t = BNRED ? g.xn + m0 * g.ldxn : nullptr;
+        const int col0 = n0 + wn * TN + pc4_e;
+        // operands of one HALF round (16 x 32 of the 32 x 32 tile: two float4 per lane and array), requested D half rounds
+        // ahead of their use - the latency of these loads, not their volume, is what the fused epilogues cost
+        // (tools/x6p_trace.py: 9 k cycles for the plain epilogue, 54 k with a dependent index load + gather per half round)
+        constexpr int D = (BNRED && HAS_ADD) ? 1 : 2, NH = 2 * RN * RM;  // look-ahead, half rounds per tile
+        float4 av[(HAS_ADD || GATHER) ? D : 1][2], xv[BNRED ? D : 1][2], nst[BNRED ? 2 : 1][3], bias_b[2], s0, s1;
+        auto row_of = [&](int a, int i) {
+            const int rrel = wm * TM + a * 32 + prow_e + i * 8;
+            return rrel < last_row ? rrel : last_row;
+        };
+        auto load_half = [&](int q) {  // half round q = (b, a, h)
+            const int b = q / (2 * RM), a = (q / 2) % RM, h = q & 1, col = col0 + b * 32, sl = q % D;
+            if constexpr (GATHER) {
+                int ui[2], vi[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {  // (lane l holds the node pair of the strip's row l: no dependent index load here)
+                    const int holder = a * 32 + (2 * h + i) * 8 + prow_e;
+                    ui[i] = __shfl(src_l, holder);
+                    vi[i] = __shfl(dst_l, holder);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    av[sl][i] = f4_add(f4_ld(g.gp + (int64_t)ui[i] * g.ldgp + col), f4_ld(g.gp + (int64_t)vi[i] * g.ldgp + g.N + col));
+            }
+            if constexpr (HAS_ADD) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) av[sl][i] = f4_ld(add_t + (row_of(a, 2 * h + i) * (int)g.ldadd + col));
+            }
+            if constexpr (BNRED) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) xv[sl][i] = f4_lds<true>(xn_t + (row_of(a, 2 * h + i) * (int)g.ldxn + col));
+            }
+            if (a == 0 && h == 0) {  // (constants of a new column group)
+                bias_b[b & 1] = g.bias ? f4_ld(g.bias + col) : f4_zero();
+                if constexpr (BNRED)
+                    nst[b & 1][0] = f4_ld(g.nstat + col), nst[b & 1][1] = f4_ld(g.nstat + 2 * g.N + col),
+                              nst[b & 1][2] = f4_ld(g.nstat + 3 * g.N + col);
+            }
+        };
+#pragma unroll
+        for (int q = 0; q < D; ++q) load_half(q);
+#pragma unroll
+        for (int rd = 0; rd < RN * RM; ++rd) {
+            const int b = rd / RM, a = rd % RM;
+            const int col = col0 + b * 32;
+            if (a == 0 && (BNRED || STATS)) s0 = s1 = f4_zero();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * half) * PLD + il] = acc[a][b][r];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int q = 2 * rd + h, sl = q % D;
+                float4 v[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    v[i] = f4_ld(patch + ((2 * h + i) * 8 + prow) * PLD + pc4);
+                    v[i] = f4_scale(f4_scale(v[i], inv_sa), inv_sw);
+                    v[i] = f4_add(v[i], bias_b[b & 1]);
+                    if constexpr (HAS_ADD || GATHER) v[i] = f4_add(v[i], av[sl][i]);
+                    const bool valid = wm * TM + a * 32 + prow_e + (2 * h + i) * 8 <= last_row;
+                    if constexpr (STATS) {
+                        const float4 u = valid ? v[i] : f4_zero();
+                        s0 = f4_add(s0, u);
+                        s1 = f4_fma(u, u, s1);
+                    }
+                    if constexpr (BNRED) {
+                        const float4 xc = f4_sub(xv[sl][i], nst[b & 1][0]);
+                        const float4 z = f4_fma(xc, nst[b & 1][1], nst[b & 1][2]);
+                        float4 gz = make_float4(v[i].x * dsilu_f(z.x), v[i].y * dsilu_f(z.y), v[i].z * dsilu_f(z.z), v[i].w * dsilu_f(z.w));
+                        gz = valid ? gz : f4_zero();
+                        s0 = f4_add(s0, gz);
+                        s1 = f4_fma(gz, xc, s1);  // (x rstd once, at the end)
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);  // (the look-ahead loads go here, not above the arithmetic: registers)
+                if (q + D < NH) load_half(q + D);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) f4_sts<X6P_NT != 0>(c_t + (row_of(a, 2 * h + i) * (int)g.ldc + col), v[i]);  // (write-once hint)
+                if (a == RM - 1 && h == 1 && (BNRED || STATS)) {
+                    // the wave's eight row groups (lane >> 3) hold the same four columns: fixed-order butterfly
+#pragma unroll
+                    for (int d = 8; d < 64; d <<= 1) {
+                        s0 = f4_add(s0, make_float4(__shfl_xor(s0.x, d), __shfl_xor(s0.y, d), __shfl_xor(s0.z, d), __shfl_xor(s0.w, d)));
+                        s1 = f4_add(s1, make_float4(__shfl_xor(s1.x, d), __shfl_xor(s1.y, d), __shfl_xor(s1.z, d), __shfl_xor(s1.w, d)));
+                    }
+                    if constexpr (BNRED) s1 = f4_mul(s1, f4_ld(g.nstat + g.N + col));  // sum gz*(x-mean) -> sum gz*xhat
+                    // every lane stores (the eight row groups hold the same sums: same bits to the same place); a strip that
+                    // lies entirely past the end carries zeros and goes to the scratch slab behind the valid ones (red_partial
+                    // holds alignn_gemm_nt_x6_row_tiles() + 1 slabs) - again no branch around a store
+                    const int64_t n_strips = (g.M + TM - 1) / TM;
+                    int64_t strip = m0 / TM + wm;
+                    strip = strip < n_strips ? strip : n_strips;
+                    f4_st(g.red_partial + (strip * 2 + 0) * g.N + col, s0);
+                    f4_st(g.red_partial + (strip * 2 + 1) * g.N + col, s1);
+                }
+            }
+        }
+        if (j == 1) X6_STAMP(4);
+    }
+}
+
+template <bool HAS_ADD>
+__global__ __launch_bounds__(NT) void gemm_nt_f16p_kernel(X6Args g) {
+    gemm_nt_f16p_body<HAS_ADD, 0>(g);
+}
+template <bool HAS_ADD>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void gemm_nt_f16p_bnred_kernel(X6Args g) {
+    gemm_nt_f16p_body<HAS_ADD, 1>(g);
+}
+template <bool STATS>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void gemm_nt_f16p_gather_kernel(X6Args g) {
+    gemm_nt_f16p_body<false, 2 | (STATS ? 4 : 0)>(g);
+}
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void gemm_nt_f16p_stats_kernel(X6Args g) {
+    gemm_nt_f16p_body<false, 4>(g);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1059,11 +1533,71 @@ int launch_nt_rm(const X6Args& g, hipStream_t st) {
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }
-// rows per block tile the dispatcher below picks (the EPI == 1 variant writes one reduction slab per row tile)
+// ---- persistent f16x3 kernel (gemm_nt_f16p_body): long products only
+#ifndef X6_NO_PERSIST
+#define X6_NO_PERSIST 0  // 1: never dispatch the persistent kernel (A/B in tools/ablate_x6.py)
+#endif
+constexpr int kResidentP = 512;  // two workgroups per CU
+inline bool nt_persistent(int64_t M, int N, int K) {
+#if X6_NO_PERSIST || defined(X6_FORCE_RM)
+    return false;
+#endif
+    const char* e = getenv("ALIGNN_AMD_X6_PERSIST");  // =0: one-tile kernels everywhere (read per call: A/B runs, tests)
+    if (e != nullptr && e[0] == '0') return false;
+    const int64_t tiles = alignn_ceil_div(M, 128) * (int64_t)(npad(N) / BN);
+    return K > 64 && K / BK >= 3 && N % BN == 0 && tiles >= 2 * kResidentP && tiles < ((int64_t)1 << 30);
+}
+int launch_nt_p(const X6Args& g_in, hipStream_t st) {
+    constexpr int lds = 3 * (Geo<2>::A_BYTES + 2 * B_PLANE);  // 72 KiB: two workgroups per CU
+    static bool attr_set = false;
+    if (!attr_set) {
+        const void* fns[] = {(const void*)gemm_nt_f16p_kernel<false>,        (const void*)gemm_nt_f16p_kernel<true>,
+                             (const void*)gemm_nt_f16p_bnred_kernel<false>,  (const void*)gemm_nt_f16p_bnred_kernel<true>,
+                             (const void*)gemm_nt_f16p_gather_kernel<false>, (const void*)gemm_nt_f16p_gather_kernel<true>,
+                             (const void*)gemm_nt_f16p_stats_kernel};
+        for (const void* fn : fns) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (e != hipSuccess) return (int)e;
+        }
+        attr_set = true;
+    }
+    if (g_in.ldc >= (1 << 20) || g_in.ldadd >= (1 << 20) || g_in.ldxn >= (1 << 20)) return (int)hipErrorInvalidValue;
+    static const int stagger = [] {
+        const char* e = getenv("ALIGNN_AMD_X6_STAGGER");
+        return e ? atoi(e) : 0;
+    }();
+    X6Args g = g_in;
+    g.stagger = stagger;
+    const int64_t tiles = alignn_ceil_div(g.M, 128) * (int64_t)(g.Npad / BN);
+    const dim3 grid((unsigned)(tiles < kResidentP ? tiles : kResidentP)), block(NT);
+    if (g.gp != nullptr) {
+        if (g.red_partial)
+            hipLaunchKernelGGL(gemm_nt_f16p_gather_kernel<true>, grid, block, lds, st, g);
+        else
+            hipLaunchKernelGGL(gemm_nt_f16p_gather_kernel<false>, grid, block, lds, st, g);
+    } else if (g.red_partial != nullptr && g.xn == nullptr) {
+        if (g.addend) return (int)hipErrorInvalidValue;
+        hipLaunchKernelGGL(gemm_nt_f16p_stats_kernel, grid, block, lds, st, g);
+    } else if (g.red_partial != nullptr) {
+        if (g.addend)
+            hipLaunchKernelGGL(gemm_nt_f16p_bnred_kernel<true>, grid, block, lds, st, g);
+        else
+            hipLaunchKernelGGL(gemm_nt_f16p_bnred_kernel<false>, grid, block, lds, st, g);
+    } else if (g.addend) {
+        hipLaunchKernelGGL(gemm_nt_f16p_kernel<true>, grid, block, lds, st, g);
+    } else {
+        hipLaunchKernelGGL(gemm_nt_f16p_kernel<false>, grid, block, lds, st, g);
+    }
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+// rows per reduction slab of the f16x3 kernels' column sums (EPI flags BNRED / STATS): the block tile of the one-tile
+// kernels, the 64-row wave strip of the persistent one
 inline int nt_block_rows(int64_t M, int N, int K) {
 #ifdef X6_FORCE_RM
     return 64 * X6_FORCE_RM;
 #endif
+    if (nt_persistent(M, N, K)) return 64;
     const int64_t tiles128 = alignn_ceil_div(M, 128) * (int64_t)(npad(N) / BN);
     return (K <= 64 || tiles128 < 256) ? 64 : 128;
 }
@@ -1074,6 +1608,16 @@ int launch_nt(const X6Args& g, hipStream_t st) {
 #ifdef X6_FORCE_RM  // (tools/ablate_x6.py)
     return launch_nt_rm<F16, X6_FORCE_RM>(g, st);
 #endif
+    if constexpr (F16)
+        if (nt_persistent(g.M, g.N, g.K)) {
+            // measured per variant at T x 256 x 256, kernels interleaved (tools/x6_family_check.py): persistent -5 % plain,
+            // -4 % statistics, -7..-9 % gather (+ statistics), -2 % BatchNorm-backward sums; +3 % with an addend and +10 %
+            // for sums + addend (its operand look-ahead spills) - those two stay on the one-tile kernel, with strip slabs
+            if (g.addend == nullptr) return launch_nt_p(g, st);
+            X6Args gs = g;
+            gs.strip_slabs = 1;
+            return launch_nt_rm<F16, 2>(gs, st);
+        }
     if (g.K <= 64 || tiles128 < 256) return launch_nt_rm<F16, 1>(g, st);
     return launch_nt_rm<F16, 2>(g, st);
 }
@@ -1083,6 +1627,12 @@ inline bool nt_args_ok(const float* A, int64_t lda, const void* Wsplit, const fl
              (addend && ((ldadd & 3) || !a16(addend))));
 }
 }  // namespace
+
+#if X6_TRACE
+extern "C" int alignn_x6_trace_read(void* host, size_t bytes) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(x6_trace_buf), bytes < sizeof(x6_trace_buf) ? bytes : sizeof(x6_trace_buf));
+}
+#endif
 
 extern "C" {
 

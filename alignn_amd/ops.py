@@ -449,7 +449,7 @@ def gemm_nt_f16x3_bnred(a, a_amax, ws, xn, nstat, bias=None, addend=None, out=No
     if out is None:
         out = _empty(M, N, like=a)
     tiles = lib.alignn_gemm_nt_x6_row_tiles(M, N, K)
-    partial = _empty(tiles, 2, N, like=a)
+    partial = _empty(tiles + 1, 2, N, like=a)  # (+ the kernel's scratch slab)
     _timed("bnred_addend" if addend is not None else "bnred", M, N, K, lambda: check(
         lib.alignn_gemm_nt_f16x3_bnred(ptr(a), a.stride(0), ptr(a_amax), ptr(ws.buf), ptr(ws.amax), ptr(bias), ptr(addend),
                                        addend.stride(0) if addend is not None else 0, ptr(out), out.stride(0), M, N, K,
@@ -484,7 +484,7 @@ def gemm_nt_f16x3_gather(a, a_amax, ws, bias, P, src, dst, out=None, want_stats=
     if out is None:
         out = _empty(M, N, like=a)
     tiles = lib.alignn_gemm_nt_x6_row_tiles(M, N, K) if want_stats else 0
-    partial = _empty(tiles, 2, N, like=a) if want_stats else None
+    partial = _empty(tiles + 1, 2, N, like=a) if want_stats else None  # (+ the kernel's scratch slab)
     _timed("gather", M, N, K, lambda: check(
         lib.alignn_gemm_nt_f16x3_gather(ptr(a), a.stride(0), ptr(a_amax), ptr(ws.buf), ptr(ws.amax), ptr(bias), ptr(out),
                                         out.stride(0), M, N, K, ptr(P), P.stride(0), ptr(src), ptr(dst), ptr(partial),
@@ -504,7 +504,7 @@ def gemm_nt_f16x3_stats(a, a_amax, ws, bias=None, out=None):
     if out is None:
         out = _empty(M, N, like=a)
     tiles = lib.alignn_gemm_nt_x6_row_tiles(M, N, K)
-    partial = _empty(tiles, 2, N, like=a)
+    partial = _empty(tiles + 1, 2, N, like=a)  # (+ the kernel's scratch slab)
     _timed("stats", M, N, K, lambda: check(
         lib.alignn_gemm_nt_f16x3_stats(ptr(a), a.stride(0), ptr(a_amax), ptr(ws.buf), ptr(ws.amax), ptr(bias), ptr(out),
                                        out.stride(0), M, N, K, ptr(partial), stream()),

@@ -112,7 +112,9 @@ int alignn_gemm_nt_f16x3(const float* A, int64_t lda, const float* a_amax, const
  * with g_y is BatchNorm's backward: alignn/models/alignn.py:126 bn_edges / :178 MLPLayer's BatchNorm1d under
  * torch.autograd): additionally writes, per row tile of the product, the column sums over the tile's rows of
  *   gz = g_y * silu'((Xn - mean) * scale + beta)   and   gz * (Xn - mean) * rstd
- * into red_partial [row_tiles][2][N] (nstat = [4][N] as written by alignn_bn_finalize).  alignn_bn_bwd_finalize
+ * into red_partial [row_tiles + 1][2][N] (the last slab is scratch for the kernel, never summed; nstat = [4][N] as
+ * written by alignn_bn_finalize; a "row tile" is the 64 / 128-row unit alignn_gemm_nt_x6_row_tiles counts for the shape
+ * - the block tile of the one-tile kernels, the 64-row wave strip of the persistent one).  alignn_bn_bwd_finalize
  * over `alignn_gemm_nt_x6_row_tiles(M, N, K)` slabs then gives dbeta / dgamma - what alignn_bn_silu_bwd_reduce
  * computes with two more passes over g_y and Xn. */
 /* The edge-gate projection of EdgeGatedGraphConv with DGL's u_add_v folded in (alignn/models/alignn.py:98-101:
@@ -125,7 +127,8 @@ int alignn_gemm_nt_f16x3_gather(const float* A, int64_t lda, const float* a_amax
                                 const float* P, int64_t ldp, const int32_t* src, const int32_t* dst,
                                 float* stats_partial, alignn_stream_t stream);
 /* stats_partial (above: may be NULL) / alignn_gemm_nt_f16x3_stats: the projection also leaves, per row tile, the column
- * sums of its output and of its square - [alignn_gemm_nt_x6_row_tiles][2][N], the slab layout alignn_bn_finalize takes -
+ * sums of its output and of its square - [alignn_gemm_nt_x6_row_tiles + 1][2][N] (last slab: scratch), the slab layout
+ * alignn_bn_finalize takes -
  * i.e. the BatchNorm statistics torch's BatchNorm1d would compute with another pass over the tensor
  * (alignn/models/alignn.py:122-127 bn_edges, :175-179 MLPLayer).  alignn_egc_gate_fwd_pre_norm is the gate pass for an M
  * that already holds m AND whose statistics are known: it writes Y' = Y + silu((m - mean) scale + beta) itself (e_stat as
