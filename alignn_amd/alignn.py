@@ -201,6 +201,25 @@ class EdgeGatedGraphConv(nn.Module):
         self.__dict__["_fused_wb"] = (wcat, bcat)
         return wcat, bcat
 
+    def _fused_parameter_groups(self):
+        """(weights, biases) in the row-block order of the fused node projection - ``alignn_amd.optim.FlatAdamW`` keeps
+        each list contiguous when it re-homes the parameters and then calls ``_adopt_fused_buffers``."""
+        lins = (self.src_gate, self.dst_gate, self.dst_update, self.src_update)
+        return [m.weight for m in lins], [m.bias for m in lins]
+
+    def _adopt_fused_buffers(self):
+        """The four weights (biases) are already adjacent row blocks of one buffer somebody else owns: use THAT as the
+        fused buffer instead of re-fusing into a new one (which would take the parameters away from their owner)."""
+        ws, bs = self._fused_parameter_groups()
+        rows = ws[0].shape[0]
+        for group in (ws, bs):
+            step = group[0].numel() * group[0].element_size()
+            if any(group[i].data_ptr() != group[0].data_ptr() + i * step for i in range(4)):
+                raise ValueError("parameters are not adjacent")
+        wcat = torch.as_strided(ws[0].data, (4 * rows, ws[0].shape[1]), (ws[0].shape[1], 1))
+        bcat = torch.as_strided(bs[0].data, (4 * rows,), (1,))
+        self.__dict__["_fused_wb"] = (wcat, bcat)
+
     def _own_params_need_grad(self) -> bool:
         return any(p.requires_grad for p in self.parameters(recurse=True))
 

@@ -223,7 +223,14 @@ def main():
     broadcast_parameters(model)
     target = torch.randn(B, generator=torch.Generator().manual_seed(1 + rank)).to(dev)
     sync = FlatGradSync(model.parameters())
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, fused=True)
+    # AdamW: torch's fused kernel either way - over ONE flat parameter buffer (alignn_amd/optim.py: bit-identical updates,
+    # one launch instead of five) unless ALIGNN_BENCH_FLAT_ADAMW=0 asks for the per-tensor optimizer of the reference loop
+    if os.environ.get("ALIGNN_BENCH_FLAT_ADAMW", "1") != "0":
+        from alignn_amd.optim import FlatAdamW
+
+        opt = FlatAdamW(model, lr=1e-3)
+    else:
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, fused=True)
 
     if args.model == "alignn_ff":
         # SURVEY 8(d) cfg 4: loss = L1(energy) + L1(forces) + L1(stress), differentiating THROUGH the forces
