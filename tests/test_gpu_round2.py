@@ -532,3 +532,29 @@ def test_batchnorm_statistics_from_the_projection_epilogue():
         assert float((res[True][1][k] - g).abs().max()) < 1e-4 * max(float(g.abs().max()), 1e-3 * gmax), k
     for k, v in res[False][2].items():
         assert rel_err(res[True][2][k], v, floor=1e-3) < 1e-5, k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows", [131073, 140011, 262144 + 64])
+def test_long_projections_every_epilogue_variant_persistent_and_one_tile_kernels(rows):
+    """The f16x3 projection with each fused epilogue (plain, residual, statistics, u_add_v gather, gather + statistics,
+    BatchNorm-backward sums with / without residual) at row counts that take the PERSISTENT kernel (>= 1 024 row tiles),
+    including a last tile whose second 64-row strip lies entirely past the end (rows % 128 in (0, 64]: the scratch slab)
+    and ragged ends - against float64, and the one-tile kernels of the same shapes (ALIGNN_AMD_X6_PERSIST=0, read per
+    call) against the same bound.  Bound: 5e-6 of the largest reference element (tools/x6_family_check.py)."""
+    import ctypes
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location(
+        "x6_family_check", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "x6_family_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    libc = ctypes.CDLL(None)
+    try:
+        for mode in ("1", "0"):
+            mod.MODES = [mode]
+            mod.t = lambda fn, rounds=1: [1.0]  # (no timing in the test)
+            assert mod.main(rows) == 0, f"ALIGNN_AMD_X6_PERSIST={mode}"
+    finally:
+        libc.unsetenv(b"ALIGNN_AMD_X6_PERSIST")
