@@ -1416,6 +1416,49 @@ __global__ void split_f16x2_kernel(const float* __restrict__ W, int64_t ldw, int
     }
 }
 
+// One launch per weight and optimizer step: max|W| AND the fp16 two-slice images of W (forward products) and of W^T
+// (input-gradient products) - instead of a memset, an absmax and two slicing launches.  Every workgroup first takes the
+// maximum over the WHOLE weight itself (<= 1 MB, out of L2; order-independent, so every workgroup gets the same bits
+// as alignn_absmax would), then slices its share of the two index spaces.  Same images as split_f16x2_kernel.
+__global__ __launch_bounds__(1024) void split_f16x2_both_kernel(const float* __restrict__ W, int64_t ldw, int N, int K,
+                                                                float* __restrict__ amax_out, _Float16* __restrict__ out,
+                                                                _Float16* __restrict__ outT) {
+    __shared__ float wmax[16];
+    const int t = threadIdx.x;
+    float m = 0.0f;
+    for (int64_t i = t; i < (int64_t)N * K; i += 1024) m = fmaxf(m, fabsf(W[(i / K) * ldw + (i % K)]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((t & 63) == 0) wmax[t >> 6] = m;
+    __syncthreads();
+    m = wmax[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) m = fmaxf(m, wmax[w]);
+    if (blockIdx.x == 0 && t == 0) *amax_out = m;
+    const float sw = f16_scale(m);
+    constexpr int plane = BN * BK;
+#pragma unroll
+    for (int tr = 0; tr < 2; ++tr) {  // tr == 1: the image of W^T, a [K, N] matrix
+        _Float16* o = tr ? outT : out;
+        if (o == nullptr) continue;
+        const int n_ = tr ? K : N, k_ = tr ? N : K, np = ((n_ + BN - 1) / BN) * BN, ntiles = np / BN;
+        const int64_t total = (int64_t)np * k_;
+        for (int64_t i = (int64_t)blockIdx.x * 1024 + t; i < total; i += (int64_t)gridDim.x * 1024) {
+            const int n = (int)(i / k_), k = (int)(i % k_);
+            float x = 0.0f;
+            if (n < n_) x = tr ? W[(int64_t)k * ldw + n] : W[(int64_t)n * ldw + k];
+            x *= sw;
+            const _Float16 h = (_Float16)x;
+            const _Float16 l = (_Float16)(x - (float)h);
+            const int kb = k / BK, c = (k % BK) >> 3, e = k & 7;
+            const int nt = n / BN, nin = n % BN;
+            const int64_t q = ((int64_t)kb * ntiles + nt) * (2 * plane) + nin * BK + ((c ^ ((n >> 3) & 1)) << 3) + e;
+            o[q] = h;
+            o[q + plane] = l;
+        }
+    }
+}
+
 // max|X| of a row-major [rows, F] matrix (F % 4 == 0): one atomicMax per workgroup on the bit pattern
 // (non-negative floats order like unsigned ints; max is order independent, so this is deterministic)
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ X, int64_t ldx, int64_t rows, int F,
@@ -1659,6 +1702,20 @@ int alignn_split_f16x2(const float* W, int64_t ldw, int N, int K, int transpose,
     if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(split_f16x2_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, W, ldw, N, npad(N), K,
                        transpose, w_amax, (_Float16*)out);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_split_f16x2_both(const float* W, int64_t ldw, int N, int K, float* w_amax, void* out, void* out_t,
+                            alignn_stream_t stream) {
+    if (N <= 0 || K <= 0 || (K % BK) != 0 || out == nullptr || w_amax == nullptr || (int64_t)N * K > ((int64_t)1 << 22))
+        return (int)hipErrorInvalidValue;
+    if (out_t != nullptr && (N % BK) != 0) return (int)hipErrorInvalidValue;
+    const int64_t total = (int64_t)npad(N > K ? N : K) * (N > K ? K : N) ;
+    int grid = (int)((total + 65535) / 65536);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(split_f16x2_both_kernel, dim3(grid), dim3(1024), 0, (hipStream_t)stream, W, ldw, N, K, w_amax,
+                       (_Float16*)out, (_Float16*)out_t);
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }

@@ -368,6 +368,8 @@ def split_bf16x3(w, transpose=False):
 
 
 _W_AMAX = {}
+_W_IMG_T = {}  # id(w) -> (weakref, version, SplitWeight of w^T): made with the forward image, used by the way back
+SPLIT_BOTH = True  # one launch per weight and step for max|w| + both images (tests flip it: same bits)
 
 
 def split_f16x2(w, transpose=False):
@@ -375,6 +377,25 @@ def split_f16x2(w, transpose=False):
     lib = _lib.load()
     require_f32(w)
     n, k = (w.shape[1], w.shape[0]) if transpose else (w.shape[0], w.shape[1])
+    if transpose:
+        # the image of w^T was made together with the forward image of the same weight version (below)
+        img = _W_IMG_T.get(id(w))
+        if img is not None and img[0]() is w and img[1] == w._version:
+            return img[2]
+    elif (SPLIT_BOTH and torch.is_grad_enabled() and w.dim() == 2 and w.stride(1) == 1 and w.shape[0] % 16 == 0
+          and w.shape[1] % 16 == 0 and w.numel() <= (1 << 22)):
+        # forward product with a way back: max|w|, this image and the input-gradient image in ONE launch.  As with the
+        # cached maximum below, only the way BACK reuses anything - every forward measures and slices afresh.
+        amax = torch.empty(1, dtype=torch.float32, device=w.device)
+        buf = torch.empty(lib.alignn_split_f16x2_bytes(n, k), dtype=torch.uint8, device=w.device)
+        buf_t = torch.empty(lib.alignn_split_f16x2_bytes(k, n), dtype=torch.uint8, device=w.device)
+        check(lib.alignn_split_f16x2_both(ptr(w), w.stride(0), n, k, ptr(amax), ptr(buf), ptr(buf_t), stream()), "split_f16x2_both")
+        sw, sw_t = SplitWeight(buf, n, k), SplitWeight(buf_t, k, n)
+        sw.amax = sw_t.amax = amax
+        k_ = id(w)
+        _W_IMG_T[k_] = (weakref.ref(w, lambda _r, k_=k_: _W_IMG_T.pop(k_, None)), w._version, sw_t)
+        _W_AMAX[k_] = (weakref.ref(w, lambda _r, k_=k_: _W_AMAX.pop(k_, None)), w._version, amax)
+        return sw
     # max|w| is shared by the forward (W) and the input-gradient (W^T) images of one step: cache it per weight VERSION
     # (the optimizer's in-place update bumps the version)
     hit = _W_AMAX.get(id(w))

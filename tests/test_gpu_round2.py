@@ -558,3 +558,46 @@ def test_long_projections_every_epilogue_variant_persistent_and_one_tile_kernels
             assert mod.main(rows) == 0, f"ALIGNN_AMD_X6_PERSIST={mode}"
     finally:
         libc.unsetenv(b"ALIGNN_AMD_X6_PERSIST")
+
+
+@pytest.mark.gpu
+def test_weight_images_from_one_launch_equal_the_three_launch_route():
+    """alignn_split_f16x2_both (max|w| + the images of w and w^T in one launch) against alignn_absmax +
+    alignn_split_f16x2 x 2: same maximum, same bytes; and a training step of the model is bit-identical either way."""
+    from alignn_amd import ALIGNN, ALIGNNConfig, GraphBatch, ops
+    from alignn_amd.synthetic import make_batch
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(11)
+    for n, k in ((256, 256), (1024, 256), (256, 64), (64, 256)):
+        w = (torch.randn(n, k, generator=g) * 0.07).to(dev).requires_grad_(True)
+        ops.SPLIT_BOTH = True
+        try:
+            a = ops.split_f16x2(w)
+            at = ops.split_f16x2(w, transpose=True)
+            ops.SPLIT_BOTH = False
+            ops._W_IMG_T.clear()
+            b = ops.split_f16x2(w)
+            bt = ops.split_f16x2(w, transpose=True)
+        finally:
+            ops.SPLIT_BOTH = True
+        assert torch.equal(a.amax.reshape(()), b.amax.reshape(())) and torch.equal(a.buf, b.buf) and torch.equal(at.buf, bt.buf)
+        assert (at.n, at.k) == (k, n)
+
+    batch = GraphBatch.from_raw(make_batch(16, 40, seed0=21), device=dev)
+    target = torch.randn(16, generator=torch.Generator().manual_seed(2)).to(dev)
+    outs = []
+    for both in (True, False):
+        ops.SPLIT_BOTH = both
+        ops._W_IMG_T.clear()
+        try:
+            torch.manual_seed(0)
+            m = ALIGNN(ALIGNNConfig(name="alignn")).to(dev).train()
+            loss = torch.nn.functional.l1_loss(m(batch), target)
+            loss.backward()
+            torch.cuda.synchronize()
+            outs.append((loss.detach().clone(), [p.grad.clone() for p in m.parameters() if p.grad is not None]))
+        finally:
+            ops.SPLIT_BOTH = True
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert len(outs[0][1]) == len(outs[1][1]) and all(torch.equal(x, y) for x, y in zip(outs[0][1], outs[1][1]))
