@@ -1416,35 +1416,19 @@ __global__ void split_f16x2_kernel(const float* __restrict__ W, int64_t ldw, int
     }
 }
 
-// One launch per weight and optimizer step: max|W| AND the fp16 two-slice images of W (forward products) and of W^T
-// (input-gradient products) - instead of a memset, an absmax and two slicing launches.  Every workgroup first takes the
-// maximum over the WHOLE weight itself (<= 1 MB, out of L2; order-independent, so every workgroup gets the same bits
-// as alignn_absmax would), then slices its share of the two index spaces.  Same images as split_f16x2_kernel.
-__global__ __launch_bounds__(1024) void split_f16x2_both_kernel(const float* __restrict__ W, int64_t ldw, int N, int K,
-                                                                float* __restrict__ amax_out, _Float16* __restrict__ out,
-                                                                _Float16* __restrict__ outT) {
-    __shared__ float wmax[16];
-    const int t = threadIdx.x;
-    float m = 0.0f;
-    for (int64_t i = t; i < (int64_t)N * K; i += 1024) m = fmaxf(m, fabsf(W[(i / K) * ldw + (i % K)]));
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-    if ((t & 63) == 0) wmax[t >> 6] = m;
-    __syncthreads();
-    m = wmax[0];
-#pragma unroll
-    for (int w = 1; w < 16; ++w) m = fmaxf(m, wmax[w]);
-    if (blockIdx.x == 0 && t == 0) *amax_out = m;
-    const float sw = f16_scale(m);
+// fp16 two-slice images of W (forward products) and of W^T (input-gradient products) in one launch: the two index spaces
+// of split_f16x2_kernel walked by one grid (same images, bit for bit)
+__global__ void split_f16x2_both_kernel(const float* __restrict__ W, int64_t ldw, int N, int K, const float* __restrict__ w_amax,
+                                        _Float16* __restrict__ out, _Float16* __restrict__ outT) {
+    const float sw = f16_scale(*w_amax);
     constexpr int plane = BN * BK;
 #pragma unroll
     for (int tr = 0; tr < 2; ++tr) {  // tr == 1: the image of W^T, a [K, N] matrix
         _Float16* o = tr ? outT : out;
-        if (o == nullptr) continue;
         const int n_ = tr ? K : N, k_ = tr ? N : K, np = ((n_ + BN - 1) / BN) * BN, ntiles = np / BN;
-        const int64_t total = (int64_t)np * k_;
-        for (int64_t i = (int64_t)blockIdx.x * 1024 + t; i < total; i += (int64_t)gridDim.x * 1024) {
-            const int n = (int)(i / k_), k = (int)(i % k_);
+        const int total = np * k_;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+            const int n = i / k_, k = i % k_;
             float x = 0.0f;
             if (n < n_) x = tr ? W[(int64_t)k * ldw + n] : W[(int64_t)n * ldw + k];
             x *= sw;
@@ -1706,16 +1690,28 @@ int alignn_split_f16x2(const float* W, int64_t ldw, int N, int K, int transpose,
     return 0;
 }
 
-int alignn_split_f16x2_both(const float* W, int64_t ldw, int N, int K, float* w_amax, void* out, void* out_t,
+int alignn_split_f16x2_both(const float* W, int64_t ldw, int N, int K, const float* w_amax, void* out, void* out_t,
                             alignn_stream_t stream) {
-    if (N <= 0 || K <= 0 || (K % BK) != 0 || out == nullptr || w_amax == nullptr || (int64_t)N * K > ((int64_t)1 << 22))
+    if (N <= 0 || K <= 0 || (K % BK) != 0 || (N % BK) != 0 || out == nullptr || out_t == nullptr || w_amax == nullptr ||
+        (int64_t)npad(N) * K > ((int64_t)1 << 28) || (int64_t)npad(K) * N > ((int64_t)1 << 28))
         return (int)hipErrorInvalidValue;
-    if (out_t != nullptr && (N % BK) != 0) return (int)hipErrorInvalidValue;
-    const int64_t total = (int64_t)npad(N > K ? N : K) * (N > K ? K : N) ;
-    int grid = (int)((total + 65535) / 65536);
-    if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(split_f16x2_both_kernel, dim3(grid), dim3(1024), 0, (hipStream_t)stream, W, ldw, N, K, w_amax,
+    const int64_t total = (int64_t)npad(N) * K > (int64_t)npad(K) * N ? (int64_t)npad(N) * K : (int64_t)npad(K) * N;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(split_f16x2_both_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, W, ldw, N, K, w_amax,
                        (_Float16*)out, (_Float16*)out_t);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+/* *amax = max(*amax, max|X|): alignn_absmax without the reset - for a slot the caller knows to hold 0 (or a bound to keep) */
+int alignn_absmax_raise(const float* X, int64_t ldx, int64_t rows, int F, float* amax, alignn_stream_t stream) {
+    if (F <= 0 || (F & 3) || (ldx & 3) || rows < 0 || amax == nullptr || !a16(X)) return (int)hipErrorInvalidValue;
+    if (rows == 0) return 0;
+    int64_t blocks = (rows * (F >> 2) + 256 * 8 - 1) / (256 * 8);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(absmax_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, X, ldx, rows, F, amax);
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }

@@ -341,10 +341,15 @@ def _track(rows):
     return F16X3 and rows >= AMAX_MIN_ROWS
 
 
-def absmax(x):
-    """max|x| of a 2-D fp32 tensor as a device scalar (stand-alone pass; the fused producers avoid it)."""
+def absmax(x, arena=False):
+    """max|x| of a 2-D fp32 tensor as a device scalar (stand-alone pass; the fused producers avoid it).  ``arena``: into
+    a zeroed slot of the step's amax arena - no reset launch of its own."""
     lib = _lib.load()
     require_f32(x)
+    if arena:
+        out = new_amax(x)
+        check(lib.alignn_absmax_raise(ptr(x), x.stride(0), x.shape[0], x.shape[1], ptr(out), stream()), "absmax_raise")
+        return out
     out = torch.empty(1, dtype=torch.float32, device=x.device)
     check(lib.alignn_absmax(ptr(x), x.stride(0), x.shape[0], x.shape[1], ptr(out), stream()), "absmax")
     return out
@@ -369,7 +374,7 @@ def split_bf16x3(w, transpose=False):
 
 _W_AMAX = {}
 _W_IMG_T = {}  # id(w) -> (weakref, version, SplitWeight of w^T): made with the forward image, used by the way back
-SPLIT_BOTH = True  # one launch per weight and step for max|w| + both images (tests flip it: same bits)
+SPLIT_BOTH = _os.environ.get("ALIGNN_AMD_SPLIT_BOTH", "1") != "0"  # both slice images of a weight from one launch (tests flip it: same bits)
 
 
 def split_f16x2(w, transpose=False):
@@ -382,11 +387,14 @@ def split_f16x2(w, transpose=False):
         img = _W_IMG_T.get(id(w))
         if img is not None and img[0]() is w and img[1] == w._version:
             return img[2]
-    elif (SPLIT_BOTH and torch.is_grad_enabled() and w.dim() == 2 and w.stride(1) == 1 and w.shape[0] % 16 == 0
-          and w.shape[1] % 16 == 0 and w.numel() <= (1 << 22)):
-        # forward product with a way back: max|w|, this image and the input-gradient image in ONE launch.  As with the
-        # cached maximum below, only the way BACK reuses anything - every forward measures and slices afresh.
-        amax = torch.empty(1, dtype=torch.float32, device=w.device)
+    elif (SPLIT_BOTH and w.dim() == 2 and w.stride(1) == 1 and w.stride(0) % 4 == 0 and w.shape[0] % 16 == 0
+          and w.shape[1] % 16 == 0):
+        # forward product: max|w| into an arena slot (no reset launch), then this image and the input-gradient image in
+        # ONE launch - two launches per weight and step instead of four (autograd.Function.forward runs with grad mode
+        # off, so "will there be a way back" is not known here; without one the second image is a few microseconds
+        # inside the same launch).  As with the cached maximum below, only the way BACK reuses anything - every
+        # forward measures and slices afresh.
+        amax = absmax(w, arena=True)
         buf = torch.empty(lib.alignn_split_f16x2_bytes(n, k), dtype=torch.uint8, device=w.device)
         buf_t = torch.empty(lib.alignn_split_f16x2_bytes(k, n), dtype=torch.uint8, device=w.device)
         check(lib.alignn_split_f16x2_both(ptr(w), w.stride(0), n, k, ptr(amax), ptr(buf), ptr(buf_t), stream()), "split_f16x2_both")

@@ -33,8 +33,8 @@ H = 256
 PMC_TRAFFIC_F16X3_T676200 = (2 * 334.9 + 660.4) * 1048576
 PMC_TRAFFIC_X6_T676200 = (2 * 360721.0 + 676200.0) * 1024
 # in-step launches of the same kernel body with its fused epilogues (same PMC passes; MiB per launch: FETCH raw, WRITE)
-PMC_MIB_BY_VARIANT_T676200 = {"plain": (334.9, 660.4), "gather": (468.6, 717.1), "bnred": (667.0, 670.7),
-                              "bnred_addend": (1030.7, 712.0)}
+PMC_MIB_BY_VARIANT_T676200 = {"plain": (334.9, 660.4), "gather": (424.5, 681.0), "bnred": (691.9, 686.0),
+                              "bnred_addend": (1027.1, 717.1)}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F32_PEAK_TF = 157.3  # v_mfma_f32_32x32x2_f32 dense peak
 

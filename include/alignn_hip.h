@@ -104,12 +104,13 @@ int alignn_absmax(const float* X, int64_t ldx, int64_t rows, int F, float* amax,
 size_t alignn_split_f16x2_bytes(int N, int K);
 int alignn_split_f16x2(const float* W, int64_t ldw, int N, int K, int transpose, const float* w_amax, void* out,
                        alignn_stream_t stream);
-/* max|W| (written to *w_amax), the image of W and - out_t != NULL, N % 16 == 0 - the image of W^T in ONE launch: what
- * alignn_absmax + alignn_split_f16x2(transpose=0) + alignn_split_f16x2(transpose=1) produce, bit for bit (N*K <= 2^22).
- * The forward products (alignn/models/alignn.py:98-110 nn.Linear) and torch.autograd's input gradients of the same
- * Linear use the two images of one optimizer step. */
-int alignn_split_f16x2_both(const float* W, int64_t ldw, int N, int K, float* w_amax, void* out, void* out_t,
+/* The image of W and the image of W^T (N % 16 == 0 as well) in ONE launch: what alignn_split_f16x2(transpose=0) and
+ * alignn_split_f16x2(transpose=1) produce, bit for bit.  The forward products (alignn/models/alignn.py:98-110 nn.Linear)
+ * and torch.autograd's input gradients of the same Linear use the two images of one optimizer step. */
+int alignn_split_f16x2_both(const float* W, int64_t ldw, int N, int K, const float* w_amax, void* out, void* out_t,
                             alignn_stream_t stream);
+/* *amax = max(*amax, max|X|): alignn_absmax (below) without its reset, for a slot known to hold 0 */
+int alignn_absmax_raise(const float* X, int64_t ldx, int64_t rows, int F, float* amax, alignn_stream_t stream);
 int alignn_gemm_nt_f16x3(const float* A, int64_t lda, const float* a_amax, const void* Wsplit,
                          const float* w_amax, const float* bias, const float* addend, int64_t ldadd, float* C,
                          int64_t ldc, int64_t M, int N, int K, alignn_stream_t stream);
