@@ -39,16 +39,19 @@ __global__ __launch_bounds__(kThreads) void col_reduce_kernel(Fn fn, int64_t row
     const int64_t stride = (int64_t)slabs * RP;
     float4 a0 = f4_zero(), a1 = f4_zero();
     if (rl < RP) {
-        // two independent accumulator pairs: two row loads in flight per thread
-        float4 b0 = f4_zero(), b1 = f4_zero();
+        // four independent accumulator pairs: four row loads in flight per thread (narrow matrices - F = 64 at T rows -
+        // have few bytes per row group and were latency-bound with two: 115 us for 173 MB)
+        float4 b0 = f4_zero(), b1 = f4_zero(), c0 = f4_zero(), c1 = f4_zero(), d0 = f4_zero(), d1 = f4_zero();
         int64_t r = (int64_t)blockIdx.x * RP + rl;
-        for (; r + stride < rows; r += 2 * stride) {
+        for (; r + 3 * stride < rows; r += 4 * stride) {
             fn(r, q, a0, a1);
             fn(r + stride, q, b0, b1);
+            fn(r + 2 * stride, q, c0, c1);
+            fn(r + 3 * stride, q, d0, d1);
         }
-        if (r < rows) fn(r, q, a0, a1);
-        a0 = f4_add(a0, b0);
-        a1 = f4_add(a1, b1);
+        for (; r < rows; r += stride) fn(r, q, a0, a1);
+        a0 = f4_add(f4_add(a0, b0), f4_add(c0, d0));
+        a1 = f4_add(f4_add(a1, b1), f4_add(c1, d1));
     }
     __shared__ float4 sh[2][kThreads];
     sh[0][t] = a0;
@@ -448,9 +451,15 @@ int alignn_col_sum(const float* X, int64_t ldx, int64_t rows, int F, float* out,
     // wide matrices (the [n,4H] projection gradient) go in column panels of <= 1024
     for (int c = 0; c < F; c += 1024) {
         const int w = F - c < 1024 ? F - c : 1024;
-        StatsFn<false> fn{X + c, ldx};
-        hipLaunchKernelGGL(col_reduce_kernel<StatsFn<false>>, dim3(slabs), dim3(kThreads), 0, (hipStream_t)stream, fn,
-                           rows, w, slabs, workspace);
+        if (streaming(rows, w)) {  // (a T-row gradient read once: bias gradient of the angle embedding)
+            StatsFn<true> fn{X + c, ldx};
+            hipLaunchKernelGGL(col_reduce_kernel<StatsFn<true>>, dim3(slabs), dim3(kThreads), 0, (hipStream_t)stream, fn,
+                               rows, w, slabs, workspace);
+        } else {
+            StatsFn<false> fn{X + c, ldx};
+            hipLaunchKernelGGL(col_reduce_kernel<StatsFn<false>>, dim3(slabs), dim3(kThreads), 0, (hipStream_t)stream, fn,
+                               rows, w, slabs, workspace);
+        }
         hipLaunchKernelGGL(slab_sum_kernel, dim3(alignn_ceil_div(w, kRedCols)), dim3(kRedCols, kRedLanes), 0,
                            (hipStream_t)stream, workspace, slabs, w, 2 * w, out + c);
     }
