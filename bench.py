@@ -168,6 +168,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries ONE JSON line and nothing else: everything a library may print on file descriptor 1 (gloo announces
+    # its connections there) is sent to stderr for the rest of the run; emit() below writes to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(json_fd, (json.dumps(obj) + "\n").encode())
+
     import torch.distributed as dist
 
     # ALIGNN_BENCH_BACKEND=gloo + fewer GPUs than ranks is a SMOKE mode for the multi-process code path on a
@@ -179,7 +188,7 @@ def main():
         seen = torch.ones(1)
         dist.all_reduce(seen)
         if rank == 0:
-            print(json.dumps({"n_gpus": world, "ranks_seen": int(seen.item()), "rendezvous_only": True}), flush=True)
+            emit({"n_gpus": world, "ranks_seen": int(seen.item()), "rendezvous_only": True})
         dist.barrier()
         dist.destroy_process_group()
         return
@@ -547,7 +556,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
 
 
 if __name__ == "__main__":
