@@ -61,9 +61,6 @@
 #ifndef X6_KPIPE
 #define X6_KPIPE 0  // 1: f16x3 k-loop with the stage hand-over in the middle of a step's MFMAs (see the k-loop)
 #endif
-#ifndef X6_STAGGER
-#define X6_STAGGER 0
-#endif
 #ifndef X6P_NT
 #define X6P_NT 1  // 0: plain (L2 write-back) stores in the persistent kernel's epilogue (experiment)
 #endif
@@ -162,7 +159,6 @@ struct X6Args {
     int64_t ldgp;
     const int32_t* gsrc;  // [M] source node of edge row e
     const int32_t* gdst;  // [M] destination node of edge row e
-    int stagger;          // persistent kernel: start delay (shader cycles) of the second workgroup of every CU
     int strip_slabs;      // one-tile kernels: column-sum slabs per 64-row wave strip (see the end of gemm_nt_x6_body)
 };
 
@@ -306,19 +302,6 @@ __device__ __forceinline__ void gemm_nt_x6_body(const X6Args& g) {
         x6_trace_buf[blockIdx.x * 8 + 7] = ((unsigned long long)xcc << 32) | id;
     }
     X6_STAMP(0);
-#endif
-#if X6_STAGGER
-    // (experiment) the two workgroups of a CU start together and have the same work: they stay in phase - both in the
-    // k-loop (competing for the matrix pipe), then both in the epilogue (matrix pipe idle).  Delay the first-generation
-    // workgroup in the odd wave slot by about half a tile time; its successors inherit the offset.
-    if (blockIdx.x < 512 && blockIdx.y == 0) {
-        unsigned id;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id));
-        if (id & 1) {
-            const unsigned long long t0 = __builtin_readcyclecounter();
-            while (__builtin_readcyclecounter() - t0 < (unsigned long long)X6_STAGGER) __builtin_amdgcn_s_sleep(16);
-        }
-    }
 #endif
 
     // ---- DMA addressing (LDS image is lane-linear; the XOR swizzle lives in the SOURCE address)
@@ -854,14 +837,6 @@ __device__ __forceinline__ void gemm_nt_f16p_body(const X6Args& g) {
     }
     const float sa = f16_scale(*g.a_amax), inv_sa = 1.0f / sa, inv_sw = 1.0f / f16_scale(*g.w_amax);
 
-    // Persistent workgroups that start together stay in step for the whole launch - all of them in the k-loop (reads, matrix
-    // pipe), then all of them in the epilogue (writes, matrix pipe idle).  The second resident workgroup of every CU
-    // (blocks 256..511: block b runs on XCD b % 8 and the first 256 fill one slot of every CU) starts half a tile later,
-    // so that one's epilogue runs beside the other's k-loop.
-    if (g.stagger > 0 && blockIdx.x >= 256) {
-        const unsigned long long t0 = __builtin_readcyclecounter();
-        while (__builtin_readcyclecounter() - t0 < (unsigned long long)g.stagger) __builtin_amdgcn_s_sleep(8);
-    }
     if (0 < S) issue_next(0);
     if (1 < S) issue_next(1);
 
@@ -1589,12 +1564,7 @@ int launch_nt_p(const X6Args& g_in, hipStream_t st) {
         attr_set = true;
     }
     if (g_in.ldc >= (1 << 20) || g_in.ldadd >= (1 << 20) || g_in.ldxn >= (1 << 20)) return (int)hipErrorInvalidValue;
-    static const int stagger = [] {
-        const char* e = getenv("ALIGNN_AMD_X6_STAGGER");
-        return e ? atoi(e) : 0;
-    }();
     X6Args g = g_in;
-    g.stagger = stagger;
     const int64_t tiles = alignn_ceil_div(g.M, 128) * (int64_t)(g.Npad / BN);
     const dim3 grid((unsigned)(tiles < kResidentP ? tiles : kResidentP)), block(NT);
     if (g.gp != nullptr) {

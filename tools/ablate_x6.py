@@ -112,8 +112,6 @@ F16V = {"warm": [], "base": [], "nosync": ["-DX6_EPI_NOSYNC=1"], "nolate": ["-DX
         "noslp": ["-fno-slp-vectorize"], "noslp_noloads_noepi": ["-fno-slp-vectorize", "-DX6_ABL_NOBLOAD=1", "-DX6_ABL_NOALOAD=1", "-DX6_ABL_NOSTORE=2"],
         "noslice_noloads_noepi": ["-DX6_ABL_NOSLICE=1", "-DX6_ABL_NOBLOAD=1", "-DX6_ABL_NOALOAD=1", "-DX6_ABL_NOSTORE=2"],
         "kpipe_noslice_noloads_noepi": ["-DX6_KPIPE=1", "-DX6_ABL_NOSLICE=1", "-DX6_ABL_NOBLOAD=1", "-DX6_ABL_NOALOAD=1", "-DX6_ABL_NOSTORE=2"],
-        "stag8k": ["-DX6_STAGGER=8000"], "stag16k": ["-DX6_STAGGER=16000"], "stag24k": ["-DX6_STAGGER=24000"], "stag32k": ["-DX6_STAGGER=32000"], "stag48k": ["-DX6_STAGGER=48000"],
-        "kpipe_stag24k": ["-DX6_KPIPE=1", "-DX6_STAGGER=24000"], "kpipe_stag32k": ["-DX6_KPIPE=1", "-DX6_STAGGER=32000"],
         "nopersist": ["-DX6_NO_PERSIST=1"],
         "kpipe": ["-DX6_KPIPE=1"], "kpipe_stage3": ["-DX6_KPIPE=1", "-DX6_NSTAGE=3"], "kpipe_noepi": ["-DX6_KPIPE=1", "-DX6_ABL_NOSTORE=2"],
         "kpipe_noloads_noepi": ["-DX6_KPIPE=1", "-DX6_ABL_NOBLOAD=1", "-DX6_ABL_NOALOAD=1", "-DX6_ABL_NOSTORE=2"],
