@@ -113,3 +113,58 @@ def test_shards_are_balanced_by_triplet_count():
         rr = np.array([sum(costs[i] for i in range(r, len(sizes), world)) for r in range(world)], dtype=float)
         assert load.max() <= rr.max()  # never worse than the r::world split
         assert load.max() - load.min() <= max(costs)  # LPT bound
+
+
+def _worker_opt(rank, world, port, q):
+    """FlatGradSync + FlatAdamW as bench.py chains them at N > 1: sync() hands the parameters views of its flat bucket,
+    the optimizer gathers them into its own flat gradient and updates the re-homed parameters."""
+    from alignn_amd.optim import FlatAdamW
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)
+    net = Net()
+    broadcast_parameters(net)
+    gen = torch.Generator().manual_seed(7)
+    X, Y = torch.randn(8, 6, generator=gen), torch.randn(8, generator=gen)
+    shard = slice(rank, None, world)
+    sync = FlatGradSync(net.parameters())
+    opt = FlatAdamW(net, lr=1e-2)
+    for _ in range(3):
+        sync.zero_grad()
+        torch.nn.functional.mse_loss(net(X[shard]), Y[shard]).backward()
+        sync.sync()
+        opt.step()
+    q.put((rank, {k: p.detach().numpy().copy() for k, p in net.named_parameters()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_adamw_behind_the_flat_allreduce_equals_the_full_batch_optimizer():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_opt, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process reference: same initial parameters (rank 0's), full batch, mean of the two shard losses' gradients
+    torch.manual_seed(100)
+    ref = Net()
+    gen = torch.Generator().manual_seed(7)
+    X, Y = torch.randn(8, 6, generator=gen), torch.randn(8, generator=gen)
+    opt = torch.optim.AdamW([p for n, p in ref.named_parameters() if not n.startswith("unused")], lr=1e-2)
+    for _ in range(3):
+        opt.zero_grad()
+        loss = 0.5 * (torch.nn.functional.mse_loss(ref(X[0::2]), Y[0::2]) + torch.nn.functional.mse_loss(ref(X[1::2]), Y[1::2]))
+        loss.backward()
+        opt.step()
+    for k, p in ref.named_parameters():
+        a, b = torch.from_numpy(res[0][k]), torch.from_numpy(res[1][k])
+        assert torch.equal(a, b), k  # ranks stay in lock-step
+        assert torch.allclose(a, p.detach(), rtol=1e-5, atol=1e-7), k  # = the full-batch optimizer (all-reduce rounding apart)
