@@ -21,6 +21,8 @@ SIGNATURES = {
     "alignn_version": (C.c_char_p, []),
     "alignn_gemm_nt": (_i32, [_p, _i64, _p, _i64, _p, _p, _i64, _p, _i64, _i64, _i32, _i32, _p]),
     "alignn_gemm_nn": (_i32, [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i32, _i32, _p]),
+    "alignn_gemm_nn_split_workspace": (_sz, [_i64, _i32, _i32]),
+    "alignn_gemm_nn_split": (_i32, [_p, _i64, _p, _i64, _p, _i64, _p, _i64, _i64, _i32, _i32, _p, _sz, _p]),
     "alignn_gemm_tn_workspace": (_sz, [_i64, _i32, _i32]),
     "alignn_gemm_tn": (_i32, [_p, _i64, _p, _p, _i64, _p, _p, _i64, _i64, _i32, _i32, _p, _sz, _p]),
     "alignn_split_bf16x3_bytes": (_sz, [_i32, _i32]),

@@ -449,6 +449,61 @@ int alignn_gemm_nn(const float* G, int64_t ldg, const float* W, int64_t ldw, con
     return launch<128, 64, 4, 1, true, false>(g, 1, st);
 }
 
+// ---- split reduction for C[M,K] = G[M,N] W[N,K] (+ addend) with FEW output tiles and a LONG reduction: the input gradient
+// of the fused node projection of a bond-graph convolution is [3 840 x 1 024] x [1 024 x 256] - 30 tiles of 128 x 256
+// on 256 CUs, each walking 1 024 reduction steps (52 us); eight slabs of 128 make it 240 workgroups (~12 us) plus one
+// pass that adds the slabs in a fixed order (and the addend once).
+static int nn_splits(int64_t M, int N, int K) {
+    const int64_t tiles = (int64_t)alignn_ceil_div(M, 128) * alignn_ceil_div(K, 256);
+    if (K <= 128 || tiles >= 128 || N < 512 || (N % 128) != 0) return 1;
+    int s = N / 128;
+    while (s > 8) s >>= 1;
+    return (N % s == 0 && (N / s) % BK == 0) ? s : 1;
+}
+
+namespace {
+__global__ __launch_bounds__(256) void splitk_sum_kernel(const float* __restrict__ ws, int splits, int64_t slab, int cols,
+                                                         const float* __restrict__ addend, int64_t ldadd,
+                                                         float* __restrict__ out, int64_t ldo, int64_t rows) {
+    const int Q = cols >> 2;
+    const int64_t total = rows * Q;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / Q;
+        const int q = (int)(i - r * Q);
+        float4 s = addend ? f4_ld(addend + r * ldadd + q * 4) : f4_zero();
+        for (int z = 0; z < splits; ++z) s = f4_add(s, f4_ld(ws + (int64_t)z * slab + r * cols + q * 4));
+        f4_st(out + r * ldo + q * 4, s);
+    }
+}
+}  // namespace
+
+size_t alignn_gemm_nn_split_workspace(int64_t M, int N, int K) {
+    const int s = nn_splits(M, N, K);
+    return s > 1 ? (size_t)s * (size_t)M * (size_t)K * sizeof(float) : 0;
+}
+
+int alignn_gemm_nn_split(const float* G, int64_t ldg, const float* W, int64_t ldw, const float* addend, int64_t ldadd,
+                         float* C, int64_t ldc, int64_t M, int N, int K, void* workspace, size_t workspace_bytes,
+                         alignn_stream_t stream) {
+    const int splits = nn_splits(M, N, K);
+    const bool vec_ok = (N % 4 == 0) && (K % 4 == 0) && (ldg % 4 == 0) && (ldw % 4 == 0) && (ldc % 4 == 0) && aligned16(G) &&
+                        aligned16(W) && aligned16(C) && (addend == nullptr || ((ldadd % 4 == 0) && aligned16(addend)));
+    if (splits <= 1 || !vec_ok || workspace == nullptr || workspace_bytes < alignn_gemm_nn_split_workspace(M, N, K) ||
+        !aligned16(workspace))
+        return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    GemmArgs g{G, ldg, W, ldw, nullptr, nullptr, 0, (float*)workspace, K, M, K, N, N / splits, M * (int64_t)K, 0, 0, 0, 0};
+    int rc = launch<128, 256, 2, 4, true, false>(g, splits, st);
+    if (rc) return rc;
+    const int64_t quads = M * (int64_t)(K >> 2);
+    int grid = (int)((quads + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(splitk_sum_kernel, dim3(grid), dim3(256), 0, st, (const float*)workspace, splits, M * (int64_t)K, K,
+                       addend, ldadd, C, ldc, M);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
 // bf16x6 variant (csrc/gemm_x6.hip) for the large, aligned weight gradients
 int alignn_gemm_tn_x6_supported(int64_t M, int N, int K);
 size_t alignn_gemm_tn_x6_workspace(int64_t M, int N, int K);

@@ -560,6 +560,9 @@ def gemm_nt_x6(a, ws, bias=None, addend=None, out=None):
     return out
 
 
+NN_SPLIT = _os.environ.get("ALIGNN_AMD_NN_SPLIT", "1") != "0"  # split-reduction input gradients on atom rows (tests flip it)
+
+
 def project(a, w, bias=None, addend=None, transpose_w=False, a_amax=None):
     """a @ W^T (transpose_w: a @ W) choosing the kernel: the split-product kernels for the wide, deep products
     that dominate the step (three fp16 products when max|a| is known - ``a_amax`` or the producer registry -, six
@@ -576,6 +579,8 @@ def project(a, w, bias=None, addend=None, transpose_w=False, a_amax=None):
             return gemm_nt_f16x3(a, a_amax, split_f16x2(w, transpose_w), bias, addend)
         return gemm_nt_x6(a, split_bf16x3(w, transpose_w), bias, addend)
     if transpose_w:
+        if NN_SPLIT and bias is None and lib.alignn_gemm_nn_split_workspace(M, w.shape[0], w.shape[1]):
+            return gemm_nn(a, w, addend)  # few output tiles, long reduction: reduction slabs side by side
         if w.shape[0] % 4 == 0 and w.shape[1] >= 16:
             return gemm_nt(a, w.t().contiguous(), bias, addend)
         return gemm_nn(a, w, addend)
@@ -590,6 +595,14 @@ def gemm_nn(g, w, addend=None, out=None):
     K = w.shape[1]
     if out is None:
         out = _empty(M, K, like=g)
+    nbytes = lib.alignn_gemm_nn_split_workspace(M, N, K) if NN_SPLIT else 0
+    if nbytes and g.stride(0) % 4 == 0 and w.stride(0) % 4 == 0 and (addend is None or addend.stride(0) % 4 == 0):
+        # few output tiles, long reduction (atom rows x [4H, H]): reduction slabs side by side + one fixed-order sum
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=g.device)
+        check(lib.alignn_gemm_nn_split(ptr(g), g.stride(0), ptr(w), w.stride(0), ptr(addend),
+                                       addend.stride(0) if addend is not None else 0, ptr(out), out.stride(0), M, N, K,
+                                       ptr(ws), nbytes, stream()), "gemm_nn_split")
+        return out
     check(
         lib.alignn_gemm_nn(ptr(g), g.stride(0), ptr(w), w.stride(0), ptr(addend),
                            addend.stride(0) if addend is not None else 0, ptr(out), out.stride(0), M, N, K, stream()),

@@ -53,6 +53,13 @@ int alignn_gemm_nt(const float* A, int64_t lda, const float* W, int64_t ldw, con
 int alignn_gemm_nn(const float* G, int64_t ldg, const float* W, int64_t ldw,
                    const float* addend, int64_t ldadd, float* C, int64_t ldc,
                    int64_t M, int N, int K, alignn_stream_t stream);
+/* The same product with the reduction split into slabs when there are few output tiles and a long reduction (the input
+ * gradient of the fused node projection on atom rows: [n, 4H] x [4H, H]): `_workspace` returns the bytes of slab storage the
+ * shape wants, 0 when alignn_gemm_nn is the right call.  Slabs are added in a fixed order (bit-reproducible). */
+size_t alignn_gemm_nn_split_workspace(int64_t M, int N, int K);
+int alignn_gemm_nn_split(const float* G, int64_t ldg, const float* W, int64_t ldw, const float* addend, int64_t ldadd,
+                         float* C, int64_t ldc, int64_t M, int N, int K, void* workspace, size_t workspace_bytes,
+                         alignn_stream_t stream);
 
 /* dW[N,K] = G[M,N]^T * A[M,K]                                  -- nn.Linear weight gradient.
  * Split over M in `splits` deterministic slabs; `workspace` holds splits*N*K floats

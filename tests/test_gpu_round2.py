@@ -601,3 +601,32 @@ def test_weight_images_from_one_launch_equal_the_three_launch_route():
             ops.SPLIT_BOTH = True
     assert torch.equal(outs[0][0], outs[1][0])
     assert len(outs[0][1]) == len(outs[1][1]) and all(torch.equal(x, y) for x, y in zip(outs[0][1], outs[1][1]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K", [(3840, 1024, 256), (777, 512, 256), (5000, 1024, 512), (64, 2048, 256)])
+def test_split_reduction_input_gradient_vs_float64(M, N, K):
+    """alignn_gemm_nn_split (reduction slabs + fixed-order sum + addend) against float64 and against alignn_gemm_nn."""
+    from alignn_amd import _lib, ops
+
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn(M, N, generator=g).to(dev)
+    w = (torch.randn(N, K, generator=g) / N ** 0.5).to(dev)
+    add = torch.randn(M, K, generator=g).to(dev)
+    assert _lib.load().alignn_gemm_nn_split_workspace(M, N, K) > 0
+    ref = a.double() @ w.double() + add.double()
+    ops.NN_SPLIT = True
+    try:
+        out = ops.gemm_nn(a, w, add)
+        again = ops.gemm_nn(a, w, add)
+        ops.NN_SPLIT = False
+        plain = ops.gemm_nn(a, w, add)
+    finally:
+        ops.NN_SPLIT = True
+    scale = float(ref.abs().max())
+    assert torch.equal(out, again)  # fixed summation order
+    assert float((out.double() - ref).abs().max()) <= 2e-6 * scale
+    assert float((out - plain).abs().max()) <= 2e-6 * scale
+    no_add = ops.gemm_nn(a, w)
+    assert float((no_add.double() - (ref - add.double())).abs().max()) <= 2e-6 * scale
