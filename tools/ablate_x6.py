@@ -117,7 +117,7 @@ F16V = {"warm": [], "base": [], "nosync": ["-DX6_EPI_NOSYNC=1"], "nolate": ["-DX
         "kpipe_noloads_noepi": ["-DX6_KPIPE=1", "-DX6_ABL_NOBLOAD=1", "-DX6_ABL_NOALOAD=1", "-DX6_ABL_NOSTORE=2"],
         "kpipe_stage3_noepi": ["-DX6_KPIPE=1", "-DX6_NSTAGE=3", "-DX6_ABL_NOSTORE=2"],
         "stage3_noepi": ["-DX6_NSTAGE=3", "-DX6_ABL_NOSTORE=2"], "rm1": ["-DX6_FORCE_RM=1"], "stage3": ["-DX6_NSTAGE=3"], "stage3_nostore": ["-DX6_NSTAGE=3", "-DX6_ABL_NOSTORE=1"]}
-TNV = {"warm": [], "base": [], "pipe": ["-DTN_PIPE=1"], "noload": ["-DX6_ABL_NOALOAD=1"], "onemfma": ["-DX6_ABL_ONEMFMA=1"], "noload_onemfma": ["-DX6_ABL_NOALOAD=1", "-DX6_ABL_ONEMFMA=1"]}
+TNV = {"warm": [], "base": [], "head": [], "pipe": ["-DTN_PIPE=1"], "noload": ["-DX6_ABL_NOALOAD=1"], "onemfma": ["-DX6_ABL_ONEMFMA=1"], "noload_onemfma": ["-DX6_ABL_NOALOAD=1", "-DX6_ABL_ONEMFMA=1"]}
 if os.environ.get("ABL_TN") == "1":
     VARIANTS = TNV
     run = run_tn
