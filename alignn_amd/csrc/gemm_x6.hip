@@ -225,8 +225,19 @@ __device__ __forceinline__ void slice8_f16_lo(const float (&xs)[8], const f16x8&
     l = __builtin_bit_cast(f16x8, make_float4(xs[0], xs[1], xs[2], xs[3]));
     return;
 #endif
+    // l = RN_f16(xs - h) (the subtraction is exact in fp32).  As v_fma_mixlo/hi_f16 (fp32 fma of xs * 1.0 - h with the fp16
+    // operand read straight out of the packed high slice, result rounded into one half of the destination): one
+    // instruction per element where hipcc emits v_cvt_f32_f16 + v_pk_add_f32 + v_cvt_pk_f16_f32 (two per element) - and
+    // the packed fp32 operations are the expensive neighbours of MFMAs.  Same bits (tools/mix_check.hip: 16 M pairs).
+    const uint4 hp = __builtin_bit_cast(uint4, h);
+    const unsigned hw[4] = {hp.x, hp.y, hp.z, hp.w};
+    unsigned lw[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) l[j] = (_Float16)(xs[j] - (float)h[j]);  // the subtraction is exact
+    for (int p2 = 0; p2 < 4; ++p2) {
+        asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(lw[p2]) : "v"(xs[2 * p2]), "v"(hw[p2]));
+        asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lw[p2]) : "v"(xs[2 * p2 + 1]), "v"(hw[p2]));
+    }
+    l = __builtin_bit_cast(f16x8, make_uint4(lw[0], lw[1], lw[2], lw[3]));
 }
 __device__ __forceinline__ void slice8_f16(const float4& lo, const float4& hi4, float s, f16x8& h, f16x8& l) {
     float xs[8];
@@ -1200,9 +1211,12 @@ __global__ __launch_bounds__(TNT) void gemm_tn_x6_kernel(TnArgs g) {
 #define TN_SLICE(R, ST, buf)                                                                                    \
     {                                                                                                           \
         const int valid = (int)((rend - (rbeg + (int64_t)(ST) * TSTEP)) < TSTEP ? (rend - (rbeg + (int64_t)(ST) * TSTEP)) : TSTEP); \
+        if (valid < TSTEP) { /* (only the last stage of a slab can be short: mask it once, not per use) */      \
+            _Pragma("unroll") for (int m = 0; m < TSTEP; ++m) R[m] = m < valid ? R[m] : 0.0f;                   \
+        }                                                                                                       \
         _Pragma("unroll") for (int c = 0; c < 2; ++c) {                                                         \
             float x[8];                                                                                         \
-            _Pragma("unroll") for (int j = 0; j < 8; ++j) x[j] = (8 * c + j) < valid ? R[8 * c + j] : 0.0f;     \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) x[j] = R[8 * c + j];                                  \
             unsigned char* dst = (buf) + w_off + ((c ^ w_swz) << 4);                                            \
             if constexpr (F16) {                                                                                \
                 f16x8 h, l;                                                                                     \
