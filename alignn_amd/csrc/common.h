@@ -14,7 +14,11 @@
 
 static inline int alignn_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
-__device__ __forceinline__ float fast_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// sigmoid with the hardware reciprocal (v_rcp_f32, 1 ulp) instead of an IEEE division (v_div_scale x2, v_rcp, four fma,
+// v_div_fmas, v_div_fixup: ten instructions per element, 40 % of the line-graph backward kernel's VALU work); the exponential
+// is __expf (2 ulp) already.  Every kernel - forward, recomputation in backward, the oracle comparison - goes through this
+// one function.
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 __device__ __forceinline__ float4 f4_ld(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void f4_st(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }

@@ -30,7 +30,7 @@ __device__ __forceinline__ float wsum(float v) {
     return v;
 }
 __device__ __forceinline__ float hsum4(float4 a) { return (a.x + a.y) + (a.z + a.w); }
-__device__ __forceinline__ float sig_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float sig_f(float x) { return fast_sigmoid(x); }
 // silu'(z), silu''(z)
 __device__ __forceinline__ void dsilu2(float z, float& d1, float& d2) {
     const float s = sig_f(z), sp = s * (1.0f - s);
