@@ -20,6 +20,28 @@ static inline int alignn_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 
 // one function.
 __device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
+// flat element index i -> (row, quad) of a [rows, Q quads] matrix.  Q is a run-time value, so `i / Q` on a 64-bit index
+// is a ~100-instruction emulated division PER ELEMENT in kernels that otherwise do a handful of FMAs; feature counts are
+// powers of two almost everywhere (256, 64, 1024): shift and mask then, 32-bit division when the index fits, the general
+// case last.  (Wave-uniform branches.)
+struct RowQuad {
+    int Q, shift;  // shift = log2(Q) when Q is a power of two, else -1
+    __device__ __forceinline__ explicit RowQuad(int q) : Q(q), shift((q & (q - 1)) == 0 ? __ffs(q) - 1 : -1) {}
+    __device__ __forceinline__ void split(int64_t i, int64_t total, int64_t& r, int& q) const {
+        if (shift >= 0) {
+            r = i >> shift;
+            q = (int)(i & (Q - 1));
+        } else if (total < ((int64_t)1 << 31)) {
+            const unsigned ri = (unsigned)i / (unsigned)Q;
+            r = ri;
+            q = (int)((unsigned)i - ri * (unsigned)Q);
+        } else {
+            r = i / Q;
+            q = (int)(i - r * Q);
+        }
+    }
+};
+
 __device__ __forceinline__ float4 f4_ld(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void f4_st(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 // streaming (read-once / write-once) variants: nontemporal hint, measured +9 % on a 2-read 1-write pass over 2 GB

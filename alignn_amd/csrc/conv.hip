@@ -167,10 +167,12 @@ __global__ __launch_bounds__(256) void egc_node_bwd_kernel(const float* __restri
                                                            const float* __restrict__ HH, float* __restrict__ GS1,
                                                            float* __restrict__ GS0, int64_t n, int H) {
     const int Q = H >> 2;
+    const RowQuad rq(Q);
     const int64_t total = n * Q;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        int64_t r = i / Q;
-        int q = (int)(i - r * Q);
+        int64_t r;
+        int q;
+        rq.split(i, total, r, q);
         float4 g = f4_ld(GXPRE + r * ldg + q * 4);
         float4 s0 = f4_ld(S0 + r * H + q * 4);
         float4 h = f4_ld(HH + r * H + q * 4);

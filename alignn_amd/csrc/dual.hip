@@ -305,10 +305,12 @@ __global__ __launch_bounds__(256) void egc_node_dual_bwd_kernel(
     const float* __restrict__ HH, const float* __restrict__ S0t, const float* __restrict__ HHt,
     float* __restrict__ Q1, float* __restrict__ Q0, float* __restrict__ Q1t, float* __restrict__ Q0t, int64_t n, int H) {
     const int Q = H >> 2;
+    const RowQuad rq(Q);
     const int64_t total = n * Q;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t r = i / Q;
-        const int q = (int)(i - r * Q);
+        int64_t r;
+        int q;
+        rq.split(i, total, r, q);
         const float4 g = f4_ld(G + r * ldg + q * 4), gt = f4_ld(Gt + r * ldg + q * 4);
         const float4 s0 = f4_ld(S0 + r * H + q * 4), h = f4_ld(HH + r * H + q * 4);
         const float4 s0t = f4_ld(S0t + r * H + q * 4), ht = f4_ld(HHt + r * H + q * 4);

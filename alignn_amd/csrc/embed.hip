@@ -18,9 +18,11 @@ inline int grid_for(int64_t total, int threads = 256, int cap = 2048) {
 __global__ void rbf_fwd_kernel(const float* __restrict__ d, const float* __restrict__ centers, float gamma,
                                float* __restrict__ out, int64_t rows, int bins) {
     const int64_t total = rows * bins;
+    const RowQuad rq(bins);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int64_t r = i / bins;
-        int k = (int)(i - r * bins);
+        int64_t r;
+        int k;
+        rq.split(i, total, r, k);
         float t = d[r] - centers[k];
         out[i] = __expf(-gamma * t * t);
     }

@@ -466,10 +466,12 @@ __global__ __launch_bounds__(256) void splitk_sum_kernel(const float* __restrict
                                                          const float* __restrict__ addend, int64_t ldadd,
                                                          float* __restrict__ out, int64_t ldo, int64_t rows) {
     const int Q = cols >> 2;
+    const RowQuad rq(Q);
     const int64_t total = rows * Q;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t r = i / Q;
-        const int q = (int)(i - r * Q);
+        int64_t r;
+        int q;
+        rq.split(i, total, r, q);
         float4 s = addend ? f4_ld(addend + r * ldadd + q * 4) : f4_zero();
         for (int z = 0; z < splits; ++z) s = f4_add(s, f4_ld(ws + (int64_t)z * slab + r * cols + q * 4));
         f4_st(out + r * ldo + q * 4, s);

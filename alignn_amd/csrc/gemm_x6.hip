@@ -1453,11 +1453,13 @@ __global__ void split_f16x2_both_kernel(const float* __restrict__ W, int64_t ldw
 __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ X, int64_t ldx, int64_t rows, int F,
                                                       float* __restrict__ amax) {
     const int Q = F >> 2;
+    const RowQuad rq(Q);
     const int64_t total = rows * Q;
     float m = 0.0f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t r = i / Q;
-        const int q = (int)(i - r * Q);
+        int64_t r;
+        int q;
+        rq.split(i, total, r, q);
         const float4 v = f4_ld(X + r * ldx + q * 4);
         m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
     }

@@ -198,11 +198,13 @@ __global__ __launch_bounds__(kThreads) void bn_silu_fwd_kernel(const float* __re
                                                                float* __restrict__ Y, int64_t ldy,
                                                                int64_t rows, int F, float* __restrict__ amax) {
     const int Q = F >> 2;
+    const RowQuad rq(Q);
     const int64_t total = rows * Q;
     float am = 0.0f;
     for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
-        int64_t r = i / Q;
-        int q = (int)(i - r * Q);
+        int64_t r;
+        int q;
+        rq.split(i, total, r, q);
         float4 x = f4_lds<STREAM>(X + r * ldx + q * 4);
         float4 mean = f4_ld(stat + q * 4);
         float4 sc = f4_ld(stat + 2 * F + q * 4), be = f4_ld(stat + 3 * F + q * 4);
@@ -221,12 +223,14 @@ __global__ __launch_bounds__(kThreads) void bn_silu_bwd_apply_kernel(
     const float* __restrict__ stat, const float* __restrict__ gamma, const float* __restrict__ red, int eval_mode,
     float* __restrict__ GX, int64_t ldgx, int64_t rows, int F, float* __restrict__ amax) {
     const int Q = F >> 2;
+    const RowQuad rq(Q);
     const int64_t total = rows * Q;
     const float inv_n = 1.0f / (float)rows;
     float am = 0.0f;
     for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
-        int64_t r = i / Q;
-        int q = (int)(i - r * Q);
+        int64_t r;
+        int q;
+        rq.split(i, total, r, q);
         float4 gy = f4_lds<STREAM>(GY + r * ldgy + q * 4);
         float4 x = f4_lds<STREAM>(X + r * ldx + q * 4);
         float4 mean = f4_ld(stat + q * 4), rstd = f4_ld(stat + F + q * 4);
