@@ -256,6 +256,60 @@ __global__ __launch_bounds__(kThreads) void bn_silu_bwd_apply_kernel(
     block_amax_commit(am, amax);
 }
 
+// The same pass in the column-walking form of col_reduce_kernel: a thread owns ONE feature quad (its six constant rows are
+// loaded once, not per element) and walks the rows of its slab, so it can also sum what it writes - the column sums of GX
+// are the bias gradient of the Linear in front of the norm (MLPLayer: alignn/models/alignn.py:170-184), which otherwise
+// costs another full pass over GX (alignn_col_sum: 0.11 ms at T x 256).  partial: [gridDim.x][F].
+template <bool STREAM>
+__global__ __launch_bounds__(kThreads) void bn_silu_bwd_apply_sum_kernel(
+    const float* __restrict__ GY, int64_t ldgy, const float* __restrict__ X, int64_t ldx,
+    const float* __restrict__ stat, const float* __restrict__ red, int eval_mode, float* __restrict__ GX, int64_t ldgx,
+    int64_t rows, int F, int slabs, float* __restrict__ amax, float* __restrict__ partial) {
+    const int Q = F >> 2;
+    const int RP = kThreads / Q;
+    const int t = threadIdx.x;
+    const int q = t % Q;
+    const int rl = t / Q;
+    const float inv_n = 1.0f / (float)rows;
+    const int64_t stride = (int64_t)slabs * RP;
+    float4 acc = f4_zero();
+    float am = 0.0f;
+    if (rl < RP) {
+        const float4 mean = f4_ld(stat + q * 4), rstd = f4_ld(stat + F + q * 4);
+        const float4 sc = f4_ld(stat + 2 * F + q * 4), be = f4_ld(stat + 3 * F + q * 4);
+        float4 c0 = f4_zero(), c1 = f4_zero();
+        if (!eval_mode) c0 = f4_ld(red + q * 4), c1 = f4_ld(red + F + q * 4);
+        for (int64_t r = (int64_t)blockIdx.x * RP + rl; r < rows; r += stride) {
+            const float4 gy = f4_lds<STREAM>(GY + r * ldgy + q * 4);
+            const float4 x = f4_lds<STREAM>(X + r * ldx + q * 4);
+            const float4 xc = f4_sub(x, mean);
+            const float4 z = f4_fma(xc, sc, be);
+            const float4 gz = make_float4(gy.x * dsilu_f(z.x), gy.y * dsilu_f(z.y), gy.z * dsilu_f(z.z), gy.w * dsilu_f(z.w));
+            float4 o;
+            if (eval_mode) {
+                o = f4_mul(gz, sc);
+            } else {
+                const float4 xh = f4_mul(xc, rstd);
+                o.x = sc.x * (gz.x - inv_n * (c0.x + xh.x * c1.x));
+                o.y = sc.y * (gz.y - inv_n * (c0.y + xh.y * c1.y));
+                o.z = sc.z * (gz.z - inv_n * (c0.z + xh.z * c1.z));
+                o.w = sc.w * (gz.w - inv_n * (c0.w + xh.w * c1.w));
+            }
+            f4_sts<STREAM>(GX + r * ldgx + q * 4, o);
+            acc = f4_add(acc, o);
+            am = fmaxf(am, f4_absmax(o));
+        }
+    }
+    __shared__ float4 sh[kThreads];
+    sh[t] = acc;
+    __syncthreads();
+    if (rl == 0) {
+        for (int k = 1; k < RP; ++k) acc = f4_add(acc, sh[k * Q + q]);
+        f4_st(partial + (size_t)blockIdx.x * F + q * 4, acc);
+    }
+    block_amax_commit(am, amax);
+}
+
 // ---------------------------------------------------------------------------------------------
 // LayerNorm(+SiLU, +residual) - the ALIGNNAtomWise flavour (alignn/models/alignn_atomwise.py:151,155 and
 // alignn/models/utils.py:277-292): statistics per ROW over the F features, eps 1e-5, affine gamma/beta.
@@ -600,6 +654,24 @@ int alignn_bn_silu_bwd_apply(const float* GY, int64_t ldgy, const float* X, int6
     else
         hipLaunchKernelGGL(bn_silu_bwd_apply_kernel<false>, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, GY, ldgy,
                            X, ldx, stat, gamma, red, eval_mode, GX, ldgx, rows, F, amax);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+/* alignn_bn_silu_bwd_apply that also leaves the column sums of GX (the bias gradient of the Linear in front of the norm)
+ * as [alignn_col_stats_slabs(rows)][F] slabs for alignn_slab_sum; F <= 1024. */
+int alignn_bn_silu_bwd_apply_sum(const float* GY, int64_t ldgy, const float* X, int64_t ldx, const float* stat,
+                                 const float* red, int eval_mode, float* GX, int64_t ldgx, int64_t rows, int F,
+                                 float* amax, float* partial, alignn_stream_t stream) {
+    if (!feat_ok(F) || F > 4 * kThreads || partial == nullptr || (!eval_mode && red == nullptr)) return (int)hipErrorInvalidValue;
+    if (rows == 0) return 0;
+    const int slabs = slabs_for(rows);
+    if (streaming(rows, F))
+        hipLaunchKernelGGL(bn_silu_bwd_apply_sum_kernel<true>, dim3(slabs), dim3(kThreads), 0, (hipStream_t)stream, GY, ldgy, X,
+                           ldx, stat, red, eval_mode, GX, ldgx, rows, F, slabs, amax, partial);
+    else
+        hipLaunchKernelGGL(bn_silu_bwd_apply_sum_kernel<false>, dim3(slabs), dim3(kThreads), 0, (hipStream_t)stream, GY, ldgy,
+                           X, ldx, stat, red, eval_mode, GX, ldgx, rows, F, slabs, amax, partial);
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }

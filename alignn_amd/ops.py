@@ -897,6 +897,9 @@ def linear(x, w, b=None):
 # ---------------------------------------------------------------------------------------------
 # MLPLayer = Linear + BatchNorm1d + SiLU   (alignn/models/alignn.py:170-184)
 # ---------------------------------------------------------------------------------------------
+APPLY_SUM = _os.environ.get("ALIGNN_AMD_APPLY_SUM", "1") != "0"  # bias gradient from the norm-backward pass (tests flip it)
+
+
 class MLPLayerFn(torch.autograd.Function):
     """``norm`` = "batch" (alignn/models/alignn.py:170-184) or "layer" (alignn/models/utils.py:277-292).  T-row layers
     (the angle embedding) run on lane T inside ``lanes()``."""
@@ -952,6 +955,7 @@ class MLPLayerFn(torch.autograd.Function):
     @staticmethod
     def _bwd(ctx, gy, x, w, pre, stat, gamma, beta):
         gpre = torch.empty_like(pre)
+        gb_part = None
         g_amax = new_amax(pre) if _track(pre.shape[0]) else None
         if ctx.norm == "layer":
             red = _ln_silu_bwd(gy, pre, gamma, beta, stat, gpre, g_amax)
@@ -959,9 +963,20 @@ class MLPLayerFn(torch.autograd.Function):
             red = _take_pre_red(gy, pre)
             if red is None:
                 red = _bn_silu_bwd_reduce(gy, pre, stat)
-            _bn_silu_bwd_apply(gy, pre, stat, gamma, red, not ctx.training, gpre, g_amax)
+            if APPLY_SUM and getattr(ctx, "param_grads", False) and pre.shape[1] <= 1024:
+                # the pass that writes gpre also sums its columns (the Linear's bias gradient): no col_sum pass over gpre
+                lib = _lib.load()
+                rows, F = pre.shape
+                slabs = lib.alignn_col_stats_slabs(rows)
+                gb_part = _empty(slabs, F, like=pre)
+                check(lib.alignn_bn_silu_bwd_apply_sum(ptr(gy), gy.stride(0), ptr(pre), pre.stride(0), ptr(stat), ptr(red),
+                                                       int(not ctx.training), ptr(gpre), gpre.stride(0), rows, F, ptr(g_amax),
+                                                       ptr(gb_part), stream()), "bn_silu_bwd_apply_sum")
+                gb_part = (gb_part, slabs)
+            else:
+                _bn_silu_bwd_apply(gy, pre, stat, gamma, red, not ctx.training, gpre, g_amax)
         gx = _dgrad_bnred(gpre, w, None, g_amax, ctx.x_src) if ctx.needs_input_grad[0] else None
-        return gpre, g_amax, red, gx
+        return gpre, g_amax, red, gx, gb_part
 
     @staticmethod
     def backward(ctx, gy):
@@ -971,7 +986,7 @@ class MLPLayerFn(torch.autograd.Function):
         if ctx.lane:
             main, T = _lane_streams(gy.device)
             with _on_T(main, T, reads=(gy,)):
-                gpre, g_amax, red, gx = MLPLayerFn._bwd(ctx, gy, x, w, pre, stat, gamma, beta)
+                gpre, g_amax, red, gx, gb_part = MLPLayerFn._bwd(ctx, gy, x, w, pre, stat, gamma, beta)
             ev = _event_after(T)
             # dgamma / dbeta (``red``) come off lane T: same rule as the side-stream gradients; the input gradient stays
             # on lane T only for a producer that is lane-aware itself
@@ -985,13 +1000,20 @@ class MLPLayerFn(torch.autograd.Function):
                         t.record_stream(main)
         else:
             _main_reads(gy)
-            gpre, g_amax, red, gx = MLPLayerFn._bwd(ctx, gy, x, w, pre, stat, gamma, beta)
+            gpre, g_amax, red, gx, gb_part = MLPLayerFn._bwd(ctx, gy, x, w, pre, stat, gamma, beta)
         dbeta, dgamma = red[0], red[1]
         if not ctx.param_grads:
             return gx, None, None, None, None, None, None, None, None
         x_amax = ctx.x_amax
-        gw, gb = on_side_stream(lambda: (gemm_tn(gpre, x, g_amax, x_amax), col_sum(gpre)), [gpre, x, g_amax, x_amax],
-                                ctx.wb, wait=(ev,))
+        def bias_grad():
+            if gb_part is None:
+                return col_sum(gpre)
+            out = _empty(gpre.shape[1], like=gpre)
+            check(_lib.load().alignn_slab_sum(ptr(gb_part[0]), gb_part[1], gpre.shape[1], ptr(out), stream()), "slab_sum")
+            return out
+
+        gw, gb = on_side_stream(lambda: (gemm_tn(gpre, x, g_amax, x_amax), bias_grad()),
+                                [gpre, x, g_amax, x_amax, gb_part[0] if gb_part is not None else None], ctx.wb, wait=(ev,))
         return gx, gw, gb, dgamma, dbeta, None, None, None, None
 
 

@@ -224,6 +224,11 @@ int alignn_bn_silu_bwd_apply(const float* GY, int64_t ldgy, const float* X, int6
                              const float* stat, const float* gamma, const float* red, int eval_mode,
                              float* GX, int64_t ldgx, int64_t rows, int F, float* amax,
                              alignn_stream_t stream);
+/* ... and, in the same pass, the column sums of GX - the bias gradient of the nn.Linear in front of the BatchNorm
+ * (MLPLayer, alignn/models/alignn.py:170-184) - as [alignn_col_stats_slabs(rows)][F] slabs for alignn_slab_sum. */
+int alignn_bn_silu_bwd_apply_sum(const float* GY, int64_t ldgy, const float* X, int64_t ldx, const float* stat,
+                                 const float* red, int eval_mode, float* GX, int64_t ldgx, int64_t rows, int F,
+                                 float* amax, float* partial, alignn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Edge-gated graph convolution core (gather -> gate -> segment-sum), one wavefront per

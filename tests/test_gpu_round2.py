@@ -630,3 +630,37 @@ def test_split_reduction_input_gradient_vs_float64(M, N, K):
     assert float((out - plain).abs().max()) <= 2e-6 * scale
     no_add = ops.gemm_nn(a, w)
     assert float((no_add.double() - (ref - add.double())).abs().max()) <= 2e-6 * scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,F,eval_mode", [(676200, 64, False), (50712, 256, False), (1000, 256, True), (37, 1024, False)])
+def test_norm_backward_pass_that_also_sums_its_output_columns(rows, F, eval_mode):
+    """alignn_bn_silu_bwd_apply_sum against alignn_bn_silu_bwd_apply (same GX: the arithmetic per element is the same)
+    and its column sums against float64 sums of that GX."""
+    from alignn_amd import _lib, ops
+
+    dev = torch.device("cuda", 0)
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(rows + F)
+    gy = torch.randn(rows, F, generator=g).to(dev)
+    x = (torch.randn(rows, F, generator=g) * 1.3 + 0.2).to(dev)
+    gamma = (1 + 0.1 * torch.randn(F, generator=g)).to(dev)
+    beta = (0.1 * torch.randn(F, generator=g)).to(dev)
+    mean, rstd = x.mean(0), torch.rsqrt(x.var(0, unbiased=False) + 1e-5)
+    stat = torch.stack([mean, rstd, gamma * rstd, beta]).contiguous()
+    red = ops._bn_silu_bwd_reduce(gy, x, stat)
+    ref = ops._bn_silu_bwd_apply(gy, x, stat, gamma, red, eval_mode, torch.empty_like(x))
+    out = torch.empty_like(x)
+    slabs = lib.alignn_col_stats_slabs(rows)
+    part = torch.empty(slabs, F, device=dev)
+    amax = torch.zeros(1, device=dev)
+    ops.check(lib.alignn_bn_silu_bwd_apply_sum(ops.ptr(gy), gy.stride(0), ops.ptr(x), x.stride(0), ops.ptr(stat), ops.ptr(red),
+                                               int(eval_mode), ops.ptr(out), out.stride(0), rows, F, ops.ptr(amax), ops.ptr(part),
+                                               ops.stream()), "apply_sum")
+    assert torch.equal(out, ref)
+    assert float(amax) == float(ref.abs().max())
+    sums = torch.empty(F, device=dev)
+    ops.check(lib.alignn_slab_sum(ops.ptr(part), slabs, F, ops.ptr(sums), ops.stream()), "slab_sum")
+    want = ref.double().sum(0)
+    scale = float(ref.double().abs().sum(0).max())
+    assert float((sums.double() - want).abs().max()) <= 2e-6 * scale
