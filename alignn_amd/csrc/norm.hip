@@ -217,6 +217,33 @@ __global__ __launch_bounds__(kThreads) void bn_silu_fwd_kernel(const float* __re
     block_amax_commit(am, amax);
 }
 
+// column-walking form of bn_silu_fwd_kernel for tall matrices: a thread keeps its quad's three constant rows in registers
+// and walks the rows of its slab (the element-wise form reloads them for every element)
+template <bool HAS_RES, bool STREAM>
+__global__ __launch_bounds__(kThreads) void bn_silu_fwd_cols_kernel(const float* __restrict__ X, int64_t ldx,
+                                                                    const float* __restrict__ R, int64_t ldr,
+                                                                    const float* __restrict__ stat, float* __restrict__ Y,
+                                                                    int64_t ldy, int64_t rows, int F, int slabs,
+                                                                    float* __restrict__ amax) {
+    const int Q = F >> 2;
+    const int RP = kThreads / Q;
+    const int q = threadIdx.x % Q, rl = threadIdx.x / Q;
+    const int64_t stride = (int64_t)slabs * RP;
+    float am = 0.0f;
+    if (rl < RP) {
+        const float4 mean = f4_ld(stat + q * 4), sc = f4_ld(stat + 2 * F + q * 4), be = f4_ld(stat + 3 * F + q * 4);
+        for (int64_t r = (int64_t)blockIdx.x * RP + rl; r < rows; r += stride) {
+            const float4 x = f4_lds<STREAM>(X + r * ldx + q * 4);
+            const float4 z = f4_fma(f4_sub(x, mean), sc, be);
+            float4 o = make_float4(silu_f(z.x), silu_f(z.y), silu_f(z.z), silu_f(z.w));
+            if (HAS_RES) o = f4_add(o, f4_lds<STREAM>(R + r * ldr + q * 4));
+            f4_sts<STREAM>(Y + r * ldy + q * 4, o);
+            am = fmaxf(am, f4_absmax(o));
+        }
+    }
+    block_amax_commit(am, amax);
+}
+
 template <bool STREAM>
 __global__ __launch_bounds__(kThreads) void bn_silu_bwd_apply_kernel(
     const float* __restrict__ GY, int64_t ldgy, const float* __restrict__ X, int64_t ldx,
@@ -540,6 +567,20 @@ int alignn_bn_silu_fwd(const float* X, int64_t ldx, const float* R, int64_t ldr,
                        int64_t ldy, int64_t rows, int F, float* amax, alignn_stream_t stream) {
     if (!feat_ok(F)) return (int)hipErrorInvalidValue;
     if (rows == 0) return 0;
+    if (F <= 4 * kThreads && rows >= 16384) {  // tall: column-walking form
+        const int slabs = slabs_for(rows);
+#define ALIGNN_BNFC(RES_, ST_)                                                                                          \
+    hipLaunchKernelGGL((bn_silu_fwd_cols_kernel<RES_, ST_>), dim3(slabs), dim3(kThreads), 0, (hipStream_t)stream, X, ldx, R, \
+                       ldr, stat, Y, ldy, rows, F, slabs, amax)
+        if (streaming(rows, F)) {
+            if (R) ALIGNN_BNFC(true, true); else ALIGNN_BNFC(false, true);
+        } else {
+            if (R) ALIGNN_BNFC(true, false); else ALIGNN_BNFC(false, false);
+        }
+#undef ALIGNN_BNFC
+        ALIGNN_CHECK_LAUNCH();
+        return 0;
+    }
     int grid = stream_grid(rows * (F >> 2), streaming(rows, F));
 #define ALIGNN_BNF(RES_, ST_)                                                                                      \
     hipLaunchKernelGGL((bn_silu_fwd_kernel<RES_, ST_>), dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, X, ldx, R, \
