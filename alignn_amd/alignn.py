@@ -182,10 +182,16 @@ class EdgeGatedGraphConv(nn.Module):
         re-established lazily whenever something re-homed the parameters (``.to()``, ``load_state_dict(assign=True)``)."""
         lins = (self.src_gate, self.dst_gate, self.dst_update, self.src_update)
         ws, bs = [m.weight for m in lins], [m.bias for m in lins]
+        if self.__dict__.get("_fused_pinned"):
+            # somebody else owns the parameters' storage and could not keep the eight of them adjacent (FlatAdamW with a
+            # frozen / unused member): concatenate per forward, do NOT re-home
+            with torch.no_grad():
+                return torch.cat([w.detach() for w in ws], 0), torch.cat([b.detach() for b in bs], 0)
         fused = self.__dict__.get("_fused_wb")
         if fused is not None:
             wcat, bcat = fused
-            rows, wstep, bstep = ws[0].shape[0], ws[0].numel() * 4, bs[0].numel() * 4
+            rows = ws[0].shape[0]
+            wstep, bstep = ws[0].numel() * ws[0].element_size(), bs[0].numel() * bs[0].element_size()
             ok = wcat.device == ws[0].device and wcat.dtype == ws[0].dtype and wcat.shape[0] == 4 * rows
             for i in range(4):
                 ok = ok and ws[i].data_ptr() == wcat.data_ptr() + i * wstep and bs[i].data_ptr() == bcat.data_ptr() + i * bstep
@@ -219,6 +225,13 @@ class EdgeGatedGraphConv(nn.Module):
         wcat = torch.as_strided(ws[0].data, (4 * rows, ws[0].shape[1]), (ws[0].shape[1], 1))
         bcat = torch.as_strided(bs[0].data, (4 * rows,), (1,))
         self.__dict__["_fused_wb"] = (wcat, bcat)
+        self.__dict__.pop("_fused_pinned", None)
+
+    def _pin_unfused(self):
+        """The owner of the parameters' storage cannot offer them as adjacent row blocks: stop re-fusing (which would move
+        them into a private buffer) and concatenate per forward instead."""
+        self.__dict__["_fused_pinned"] = True
+        self.__dict__.pop("_fused_wb", None)
 
     def _own_params_need_grad(self) -> bool:
         return any(p.requires_grad for p in self.parameters(recurse=True))
@@ -231,7 +244,8 @@ class EdgeGatedGraphConv(nn.Module):
 
     def _forward(self, g, node_feats, edge_feats, need_edge_out):
         csr, canonical = _as_csr(g, node_feats.device)
-        y_in = edge_feats if canonical else edge_feats[csr.perm]
+        # (a permuting gather is a plain torch consumer: it must not read a lane-T tensor without the event)
+        y_in = edge_feats if canonical else ops.main_reads(edge_feats)[csr.perm]
         # fused node projection: P = x [W_sg; W_dg; W_du; W_su]^T -> A | Bd | Bh | Ux
         wcat, bcat = self._fused_node_projection()
         if (self._norm == "batch" and not self.training and ops.INFER_FUSED
@@ -247,7 +261,7 @@ class EdgeGatedGraphConv(nn.Module):
                     self.bn_edges.weight, self.bn_edges.bias, self.bn_edges.running_mean, self.bn_edges.running_var,
                     self.residual, need_edge_out)
             if not canonical and y is not None:
-                y = y[csr.inv]
+                y = ops.main_reads(y)[csr.inv]
             return x, y
         _bump(self.bn_nodes, self.training)
         _bump(self.bn_edges, self.training)
@@ -263,7 +277,7 @@ class EdgeGatedGraphConv(nn.Module):
             self.training, self.residual, need_edge_out, self._norm,
         )
         if not canonical and y is not None:
-            y = y[csr.inv]
+            y = ops.main_reads(y)[csr.inv]
         return x, y
 
 
@@ -349,6 +363,7 @@ class ALIGNN(nn.Module):
     def forward(self, g: Union[Sequence, GraphBatch]):
         """``g`` = ``(g, lg, lat)`` of DGL-like graphs as in the reference (alignn.py:291-295), a bare
         graph when ``alignn_layers == 0``, or a prebuilt ``GraphBatch``.  Returns ``squeeze(out)``."""
+        ops.new_weight_generation()  # weight images cached by an earlier forward are not this forward's (ops._WGEN)
         with _lib.device_guard(self.fc.weight), _deferred_bumps(), ops.lanes(self.fc.weight.device):
             return self._forward(self._batch(g))
 

@@ -338,6 +338,7 @@ class ALIGNNAtomWise(nn.Module):
 
     def forward(self, g: Union[Sequence, GraphBatch]):
         cfg = self.config
+        ops.new_weight_generation()  # (see ops._WGEN)
         b = self._batch(g)
         # Forces: in training the loss differentiates THROUGH them -> composed, twice-differentiable path.  In eval
         # mode (MD / calculators: alignn/ff/calculators.py) only the first derivative is needed -> the fused kernels
@@ -375,7 +376,9 @@ class ALIGNNAtomWise(nn.Module):
         if cfg.use_cutoff_function:
             if cfg.multiply_cutoff:
                 c_off = cutoff_function_based_edges(bondlength, cfg.inner_cutoff, cfg.exponent).unsqueeze(1)
-                y = self.edge_embedding(bondlength) * c_off
+                # the multiply is a plain torch consumer: join lane T first (inside lanes() the last embedding layer
+                # may have run there)
+                y = ops.main_reads(self.edge_embedding(bondlength)) * c_off
             else:  # ``bondlength`` becomes the envelope from here on (:446-451), also for the penalty
                 bondlength = cutoff_function_based_edges(bondlength, cfg.inner_cutoff, cfg.exponent)
                 y = self.edge_embedding(bondlength)

@@ -251,6 +251,16 @@ def _main_reads(*tensors):
                 t.record_stream(cur)  # (allocated in lane T's pool)
 
 
+def main_reads(*tensors):
+    """Public form of ``_main_reads`` for model code: call it on any tensor a lane-aware layer (MLPLayer,
+    EdgeGatedGraphConv) returned BEFORE handing it to a consumer that is not lane-aware (a plain torch operation such as
+    ``y * c_off`` or ``y[perm]``) - inside ``lanes()`` that tensor may have been produced on lane T, and a consumer enqueued
+    on the caller's stream without this event races with its producer (and is missing from a captured hipGraph as a
+    dependency).  A no-op when nothing is marked."""
+    _main_reads(*tensors)
+    return tensors[0] if len(tensors) == 1 else tensors
+
+
 def _arm_backward_join():
     if not _SIDE["armed"]:
         _SIDE["armed"] = True
@@ -288,6 +298,30 @@ F16X3 = True  # use the three-product fp16 scheme wherever max|A| is known (Fals
 # projection then takes the range-free bf16x6 scheme).
 _AMAX = {}
 
+# Hits and misses of the identity-keyed side-band registries (``_AMAX``, ``_W_IMG_T`` / ``_W_AMAX``, ``_NORM_SRC``,
+# ``_PRE_RED``).  A miss is always SAFE (the consumer measures / reduces / slices for itself, or takes the range-free
+# bf16x6 scheme) but it is a slower step, and anything that clones a tensor between two autograd nodes (a hook,
+# ``torch.utils.checkpoint``, DistributedDataParallel's bucket views) causes one silently - so they are counted
+# (tests/test_gpu_round3.py pins the counts of a default-config step, plain and DDP-wrapped) and the two expensive
+# fall-backs warn once per process.
+REGISTRY_STATS = {"amax_hit": 0, "amax_miss": 0, "wimg_hit": 0, "wimg_miss": 0, "norm_src_hit": 0, "norm_src_miss": 0,
+                  "pre_red_hit": 0, "pre_red_miss": 0, "bf16x6_fallback": 0, "separate_bn_reduce": 0}
+_WARNED = set()
+
+
+def reset_registry_stats():
+    for k in REGISTRY_STATS:
+        REGISTRY_STATS[k] = 0
+    BNRED_STATS["fused"] = BNRED_STATS["used"] = 0
+
+
+def _warn_once(key, msg):
+    if key not in _WARNED:
+        _WARNED.add(key)
+        import warnings
+
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
+
 
 def set_amax(t, amax):
     k = id(t)
@@ -297,7 +331,10 @@ def set_amax(t, amax):
 
 def get_amax(t):
     e = _AMAX.get(id(t))
-    return e[1] if e is not None and e[0]() is t and e[2] == t._version else None
+    hit = e is not None and e[0]() is t and e[2] == t._version
+    if t.dim() == 2 and _track(t.shape[0]):  # (only tensors a producer WOULD have tracked count as misses)
+        REGISTRY_STATS["amax_hit" if hit else "amax_miss"] += 1
+    return e[1] if hit else None
 
 
 _AMAX_ARENA = {"buf": None, "next": 0}
@@ -373,7 +410,28 @@ def split_bf16x3(w, transpose=False):
 
 
 _W_AMAX = {}
-_W_IMG_T = {}  # id(w) -> (weakref, version, SplitWeight of w^T): made with the forward image, used by the way back
+_W_IMG_T = {}  # id(w) -> (weakref, stamp, SplitWeight of w^T): made with the forward image, used by the way back
+# Validity stamp of those two caches.  ``w._version`` alone is not enough: the fused node projection ``wcat`` is a plain
+# tensor whose storage is updated THROUGH the four Parameters that alias it (``.data`` views), and under FlatAdamW the
+# update goes through the flat buffer - neither bumps ``wcat._version`` (or the Parameters').  So an entry also carries
+# the weight GENERATION: bumped after every optimizer step (torch's global step hook - any torch.optim.Optimizer,
+# FlatAdamW included) and at the start of every whole-model forward (``new_weight_generation``).  A backward whose own
+# forward did not slice the weight (e.g. it took the bf16x6 path because max|x| was unknown) can then never meet the
+# image or max|w| of an earlier step.
+_WGEN = [0]
+
+
+def new_weight_generation(*_a, **_k):
+    _WGEN[0] += 1
+
+
+def _wstamp(w):
+    return (w._version, _WGEN[0])
+
+
+from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_step_hook  # noqa: E402
+
+_reg_step_hook(new_weight_generation)
 SPLIT_BOTH = _os.environ.get("ALIGNN_AMD_SPLIT_BOTH", "1") != "0"  # both slice images of a weight from one launch (tests flip it: same bits)
 
 
@@ -385,8 +443,10 @@ def split_f16x2(w, transpose=False):
     if transpose:
         # the image of w^T was made together with the forward image of the same weight version (below)
         img = _W_IMG_T.get(id(w))
-        if img is not None and img[0]() is w and img[1] == w._version:
+        if img is not None and img[0]() is w and img[1] == _wstamp(w):
+            REGISTRY_STATS["wimg_hit"] += 1
             return img[2]
+        REGISTRY_STATS["wimg_miss"] += 1
     elif (SPLIT_BOTH and w.dim() == 2 and w.stride(1) == 1 and w.stride(0) % 4 == 0 and w.shape[0] % 16 == 0
           and w.shape[1] % 16 == 0):
         # forward product: max|w| into an arena slot (no reset launch), then this image and the input-gradient image in
@@ -401,21 +461,21 @@ def split_f16x2(w, transpose=False):
         sw, sw_t = SplitWeight(buf, n, k), SplitWeight(buf_t, k, n)
         sw.amax = sw_t.amax = amax
         k_ = id(w)
-        _W_IMG_T[k_] = (weakref.ref(w, lambda _r, k_=k_: _W_IMG_T.pop(k_, None)), w._version, sw_t)
-        _W_AMAX[k_] = (weakref.ref(w, lambda _r, k_=k_: _W_AMAX.pop(k_, None)), w._version, amax)
+        _W_IMG_T[k_] = (weakref.ref(w, lambda _r, k_=k_: _W_IMG_T.pop(k_, None)), _wstamp(w), sw_t)
+        _W_AMAX[k_] = (weakref.ref(w, lambda _r, k_=k_: _W_AMAX.pop(k_, None)), _wstamp(w), amax)
         return sw
-    # max|w| is shared by the forward (W) and the input-gradient (W^T) images of one step: cache it per weight VERSION
-    # (the optimizer's in-place update bumps the version)
+    # max|w| is shared by the forward (W) and the input-gradient (W^T) images of one step: cache it per weight stamp
+    # (version + generation, see _WGEN)
     hit = _W_AMAX.get(id(w))
     # reuse only on the way BACK (transpose=True: the input-gradient image of the weight the forward just sliced) -
     # every forward measures afresh, so an in-place edit that bypasses the version counter (w.data.mul_) between
     # steps can never meet a stale maximum
-    if transpose and hit is not None and hit[0]() is w and hit[1] == w._version:
+    if transpose and hit is not None and hit[0]() is w and hit[1] == _wstamp(w):
         amax = hit[2]
     else:
         amax = absmax(w if w.stride(0) % 4 == 0 and w.shape[1] % 4 == 0 else w.contiguous().view(1, -1))
         k_ = id(w)
-        _W_AMAX[k_] = (weakref.ref(w, lambda _r, k_=k_: _W_AMAX.pop(k_, None)), w._version, amax)
+        _W_AMAX[k_] = (weakref.ref(w, lambda _r, k_=k_: _W_AMAX.pop(k_, None)), _wstamp(w), amax)
     buf = torch.empty(lib.alignn_split_f16x2_bytes(n, k), dtype=torch.uint8, device=w.device)
     check(lib.alignn_split_f16x2(ptr(w), w.stride(0), n, k, int(transpose), ptr(amax), ptr(buf), stream()), "split_f16x2")
     sw = SplitWeight(buf, n, k)
@@ -577,6 +637,11 @@ def project(a, w, bias=None, addend=None, transpose_w=False, a_amax=None):
             a_amax = get_amax(a)
         if F16X3 and a_amax is not None:
             return gemm_nt_f16x3(a, a_amax, split_f16x2(w, transpose_w), bias, addend)
+        if F16X3:
+            REGISTRY_STATS["bf16x6_fallback"] += 1
+            _warn_once("bf16x6", f"alignn_amd: a [{M},{K}] x [{K},{N}] projection runs the six-product bf16 scheme because max|a| "
+                                 "of its input is unknown (the tensor did not come from a kernel that tracks it, or was cloned / "
+                                 "edited in between): correct, but ~1.6x slower than the three-product fp16 scheme")
         return gemm_nt_x6(a, split_bf16x3(w, transpose_w), bias, addend)
     if transpose_w:
         if NN_SPLIT and bias is None and lib.alignn_gemm_nn_split_workspace(M, w.shape[0], w.shape[1]):
@@ -636,7 +701,10 @@ def _register_norm_src(y, xn, stat):
 
 def _norm_src_of(y):
     e = _NORM_SRC.get(id(y))
-    return (e[1], e[2]) if e is not None and e[0]() is y else None
+    hit = e is not None and e[0]() is y
+    if BNRED_FUSED:
+        REGISTRY_STATS["norm_src_hit" if hit else "norm_src_miss"] += 1
+    return (e[1], e[2]) if hit else None
 
 
 def _take_pre_red(gy, xn):
@@ -645,7 +713,18 @@ def _take_pre_red(gy, xn):
     e = _PRE_RED.pop(id(gy), None)
     if e is not None and e[0]() is gy and e[1] is xn:
         BNRED_STATS["used"] += 1
+        REGISTRY_STATS["pre_red_hit"] += 1
         return e[2]
+    REGISTRY_STATS["pre_red_miss"] += 1
+    # a record for THIS pre-activation filed under another gradient tensor: the gradient was cloned / re-wrapped between
+    # the two autograd nodes (a hook, checkpointing, a bucket view) - the fused reduction was paid for and is now lost
+    for k, rec in list(_PRE_RED.items()):
+        if rec[1] is xn:
+            _PRE_RED.pop(k, None)
+            REGISTRY_STATS["separate_bn_reduce"] += 1
+            _warn_once("pre_red", "alignn_amd: BatchNorm-backward sums taken in a projection's epilogue were not picked up by the "
+                                  "layer they belong to (its incoming gradient is a different tensor object than the one the "
+                                  "projection wrote: hook / clone / checkpoint in between?) - reducing again in a separate pass")
     return None
 
 

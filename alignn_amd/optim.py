@@ -1,25 +1,46 @@
-"""AdamW over ONE flat parameter buffer.
+"""AdamW over flat parameter buffers - a ``torch.optim.Optimizer`` the reference's training loop can use as it is.
 
-``torch.optim.AdamW(model.parameters(), fused=True)`` - what the reference's training loop builds
-(alignn/train.py:175-186 through ``setup_optimizer``) - walks ~100 parameter tensors in five ``multi_tensor_apply``
-launches of ~44 us each at the benchmark model (16 MB of parameters): 0.22 ms of a 17.5 ms step for 112 MB of traffic
-that a single elementwise pass moves in ~25 us.  ``FlatAdamW`` re-homes the parameters as views of one contiguous
-fp32 buffer (names, shapes and ``state_dict`` are untouched; the four gate / update weights of every
-``EdgeGatedGraphConv`` stay adjacent, in the order its fused node projection wants them, and the module adopts the
-flat slice as that fused buffer), gathers the gradients with one batched copy and runs torch's own fused AdamW kernel
-on ONE tensor.  Same arithmetic per element, same step count: the parameters after a step are bit-identical to the
-per-tensor optimizer's (tests/test_gpu_round2.py).
+``torch.optim.AdamW(group_decay(model), ...)`` - what the reference builds (alignn/train.py:209-210 through
+``alignn/utils.py:77-108``: two parameter groups, no weight decay on names containing "bias" / "bn" / "norm") - walks
+~100 parameter tensors in five ``multi_tensor_apply`` launches of ~44 us each at the benchmark model (16 MB of
+parameters): 0.22 ms of a 17.5 ms step for 112 MB of traffic that a single elementwise pass moves in ~25 us.
+``FlatAdamW`` re-homes the parameters of every group as views of ONE contiguous fp32 buffer per group (names, shapes
+and ``state_dict`` are untouched; the four gate / update weights - and biases - of every ``EdgeGatedGraphConv`` stay
+adjacent, in the order its fused node projection wants them, and the module adopts the flat slice as that fused buffer),
+gathers the gradients with one batched copy per group and runs torch's own fused AdamW kernel on one tensor per group.
+Same arithmetic per element, same step count: the parameters after a step are bit-identical to the per-tensor
+optimizer's (tests/test_optim.py, tests/test_gpu_round2.py).
+
+It IS a ``torch.optim.Optimizer``: ``param_groups`` are real and persistent from construction (learning-rate schedulers
+- the reference's default ``OneCycleLR``, alignn/train.py:217-226 - read and write ``lr`` / ``betas`` there, and every
+``step()`` copies those hyper-parameters onto the flat groups), ``state_dict`` / ``load_state_dict`` round-trip the
+moments and the layout, ``zero_grad`` is the base class's.
 
 Parameters that never receive a gradient (``grad is None`` after backward: e.g. the edge norm of the last convolution,
-whose output is dead) are left out of the buffer - torch's AdamW skips them, so they must not see weight decay either.
-The layout is therefore fixed at the first ``step()``.  Learning-rate schedules: assign ``opt.lr`` (or use
-``opt.param_groups`` once the first step has run).
+whose output is dead) are left out of the buffers - torch's AdamW skips them, so they must not see weight decay either.
+The layout is therefore fixed at the first ``step()`` (or by ``load_state_dict``).  Every ``step()`` checks that each
+parameter still IS its slice of the flat buffer; something that re-homed one in between (``.to()``,
+``load_state_dict(assign=True)``, a module re-fusing its weights) is undone - value kept, storage moved back - instead
+of silently training a buffer nobody reads.
 """
 from __future__ import annotations
 
-from typing import List
+import warnings
+from typing import Dict, List, Optional
 
 import torch
+
+_HYPER = ("lr", "betas", "eps", "weight_decay")
+
+
+def group_decay(model: torch.nn.Module):
+    """The reference's parameter groups (alignn/utils.py:77-92): no weight decay on parameters whose NAME contains
+    "bias", "bn" or "norm" (note: the BatchNorm of an ``MLPLayer`` is called ``layer.1`` and is therefore decayed -
+    reproduced as it is)."""
+    decay, no_decay = [], []
+    for name, p in model.named_parameters():
+        (no_decay if ("bias" in name or "bn" in name or "norm" in name) else decay).append(p)
+    return [{"params": decay}, {"params": no_decay, "weight_decay": 0}]
 
 
 def _fused_groups(module: torch.nn.Module):
@@ -32,81 +53,176 @@ def _fused_groups(module: torch.nn.Module):
     return out
 
 
-class FlatAdamW:
-    def __init__(self, module: torch.nn.Module, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 1e-2):
+class FlatAdamW(torch.optim.Optimizer):
+    """``FlatAdamW(model)`` (one group, decay everywhere), ``FlatAdamW(group_decay(model), module=model)`` (the
+    reference's two groups) or any iterable of parameters / group dicts.  ``module``: where to look for layers that keep
+    fused weight buffers (``EdgeGatedGraphConv``); defaults to the module passed as ``params``."""
+
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
+                 module: Optional[torch.nn.Module] = None):
+        if isinstance(params, torch.nn.Module):
+            module = params if module is None else module
+            params = [p for p in params.parameters() if p.requires_grad]
         self.module = module
-        self.defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
-        self.flat = None  # nn.Parameter over the flat buffer (its .grad is the flat gradient)
-        self.live: List[torch.nn.Parameter] = []
-        self.inner = None
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._flat: List[Optional[torch.nn.Parameter]] = []  # per group (None: no live parameter in it)
+        self._live: List[List[torch.nn.Parameter]] = []
+        self._live_idx: List[List[int]] = []
+        self._offsets: List[List[int]] = []
+        self._inner: Optional[torch.optim.AdamW] = None
+        self._adopted = []
+        self._warned = False
 
-    # ---- the pieces of torch.optim.Optimizer the training loops use
-    @property
-    def param_groups(self):
-        return self.inner.param_groups if self.inner is not None else [dict(self.defaults, params=[])]
-
+    # ---- conveniences kept from the round-2 class
     @property
     def lr(self):
         return self.param_groups[0]["lr"]
 
     @lr.setter
     def lr(self, value):
-        self.defaults["lr"] = value
-        if self.inner is not None:
-            self.inner.param_groups[0]["lr"] = value
+        for g in self.param_groups:
+            g["lr"] = value
 
-    def zero_grad(self, set_to_none: bool = True):
-        for p in self.module.parameters():
-            if set_to_none:
-                p.grad = None
-            elif p.grad is not None:
-                p.grad.zero_()
+    @property
+    def flat(self):
+        """The flat parameter buffer (single-group use); with several groups see ``flat_buffers``."""
+        live = [f for f in self._flat if f is not None]
+        return live[0] if len(live) == 1 else None
 
-    def _build(self):
-        params = [p for p in self.module.parameters() if p.requires_grad]
-        live_ids = {id(p) for p in params if p.grad is not None}
-        if not live_ids:
-            raise RuntimeError("FlatAdamW.step() before any backward(): no parameter has a gradient")
-        order, seen, adopt = [], set(), []
-        for owner, ws, bs in _fused_groups(self.module):  # fused groups first, each contiguous and in its own order
-            if all(id(p) in live_ids for p in list(ws) + list(bs)):
-                adopt.append((owner, ws, bs))
-                for p in list(ws) + list(bs):
-                    order.append(p)
-                    seen.add(id(p))
-        order += [p for p in params if id(p) in live_ids and id(p) not in seen]
-        p0 = order[0]
-        if any(p.dtype != p0.dtype or p.device != p0.device for p in order):
-            raise ValueError("FlatAdamW needs all parameters on one device in one dtype")
-        total = sum(p.numel() for p in order)
-        flat = torch.empty(total, dtype=p0.dtype, device=p0.device)
-        off = 0
-        with torch.no_grad():
-            for p in order:
-                view = flat[off:off + p.numel()].view(p.shape)
-                view.copy_(p.data)
-                p.data = view
-                off += p.numel()
-        for owner, ws, bs in adopt:
-            owner._adopt_fused_buffers()
-        self.live = order
-        self.flat = torch.nn.Parameter(flat, requires_grad=True)
-        self.flat.grad = torch.zeros_like(flat)
-        self.inner = torch.optim.AdamW([self.flat], fused=flat.is_cuda, **self.defaults)
+    @property
+    def flat_buffers(self):
+        return [f for f in self._flat if f is not None]
+
+    # ---- layout
+    def _build(self, live_idx: Optional[List[List[int]]] = None):
+        """Fix the layout: ``live_idx`` (from a checkpoint) or, by default, the parameters that hold a gradient now."""
+        if live_idx is None:
+            live_idx = [[i for i, p in enumerate(g["params"]) if p.requires_grad and p.grad is not None]
+                        for g in self.param_groups]
+            if not any(live_idx):
+                raise RuntimeError("FlatAdamW.step() before any backward(): no parameter has a gradient")
+        fused = _fused_groups(self.module) if self.module is not None else []
+        self._flat, self._live, self._live_idx, self._offsets, self._adopted = [], [], [], [], []
+        flats = []
+        for g, idx in zip(self.param_groups, live_idx):
+            members = [g["params"][i] for i in idx]
+            if not members:
+                self._flat.append(None)
+                self._live.append([])
+                self._live_idx.append([])
+                self._offsets.append([])
+                continue
+            ids = {id(p) for p in members}
+            order, seen = [], set()
+            # fused runs first (each contiguous and in its owner's order) - a run is the part of an owner's weight (or
+            # bias) list that lives in THIS group; the owner adopts the flat slices only if BOTH its lists are complete
+            for owner, ws, bs in fused:
+                for run in (ws, bs):
+                    if all(id(p) in ids for p in run) and not any(id(p) in seen for p in run):
+                        for p in run:
+                            order.append(p)
+                            seen.add(id(p))
+            order += [p for p in members if id(p) not in seen]
+            p0 = order[0]
+            if any(p.dtype != p0.dtype or p.device != p0.device for p in order):
+                raise ValueError("FlatAdamW needs the parameters of a group on one device in one dtype")
+            flat = torch.empty(sum(p.numel() for p in order), dtype=p0.dtype, device=p0.device)
+            offs, off = [], 0
+            with torch.no_grad():
+                for p in order:
+                    view = flat[off:off + p.numel()].view(p.shape)
+                    view.copy_(p.data)
+                    p.data = view
+                    offs.append(off)
+                    off += p.numel()
+            fp = torch.nn.Parameter(flat, requires_grad=True)
+            fp.grad = torch.zeros_like(flat)
+            pos = {id(p): i for i, p in enumerate(g["params"])}
+            self._flat.append(fp)
+            self._live.append(order)
+            self._live_idx.append([pos[id(p)] for p in order])
+            self._offsets.append(offs)
+            flats.append((fp, g))
+        everything = {id(p) for lst in self._live for p in lst}
+        for owner, ws, bs in fused:
+            if all(id(p) in everything for p in list(ws) + list(bs)):
+                try:
+                    owner._adopt_fused_buffers()
+                    self._adopted.append(owner)
+                    continue
+                except ValueError:
+                    pass
+            # a member is frozen / unused / in another dtype: this layer must not re-fuse (that would take its live
+            # parameters out of our buffers) - it concatenates per forward instead
+            pin = getattr(owner, "_pin_unfused", None)
+            if pin is not None:
+                pin()
+        self._inner = torch.optim.AdamW([dict(params=[fp], **{k: g[k] for k in _HYPER}) for fp, g in flats],
+                                        fused=flats[0][0].is_cuda)
+
+    def _check_aliasing(self):
+        """Every live parameter must still be its slice of the flat buffer; put back the ones that are not."""
+        moved = 0
+        for fp, members, offs in zip(self._flat, self._live, self._offsets):
+            if fp is None:
+                continue
+            base, es = fp.data_ptr(), fp.element_size()
+            for p, off in zip(members, offs):
+                if p.data_ptr() != base + off * es or p.device != fp.device or p.dtype != fp.dtype:
+                    view = fp.data[off:off + p.numel()].view(p.shape)
+                    view.copy_(p.data)
+                    p.data = view
+                    moved += 1
+        if moved:
+            for owner in self._adopted:
+                owner._adopt_fused_buffers()
+            if not self._warned:
+                self._warned = True
+                warnings.warn(f"FlatAdamW: {moved} parameter(s) had been moved out of the flat buffer since the last step "
+                              "(.to(), load_state_dict(assign=True), a re-fused layer?); moved back, values kept")
 
     @torch.no_grad()
-    def step(self):
-        if self.inner is None:
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        if self._inner is None:
             self._build()
-        grads = []
-        for p in self.live:
-            if p.grad is None:
-                raise RuntimeError("a parameter that had a gradient at the first step() has none now: FlatAdamW's layout is "
-                                   "fixed at the first step")
-            grads.append(p.grad.reshape(-1))
-        torch.cat(grads, out=self.flat.grad)  # one batched copy
-        self.inner.step()
+        self._check_aliasing()
+        k = 0
+        for g, fp, members in zip(self.param_groups, self._flat, self._live):
+            if fp is None:
+                continue
+            grads = []
+            for p in members:
+                if p.grad is None:
+                    raise RuntimeError("a parameter that had a gradient at the first step() has none now: FlatAdamW's "
+                                       "layout is fixed at the first step")
+                grads.append(p.grad.reshape(-1))
+            torch.cat(grads, out=fp.grad)  # one batched copy
+            ig = self._inner.param_groups[k]
+            for h in _HYPER:  # what a scheduler wrote into OUR groups since the last step
+                ig[h] = g[h]
+            k += 1
+        self._inner.step()
+        return loss
 
+    # ---- checkpoints
     def state_dict(self):
-        return {"inner": self.inner.state_dict() if self.inner is not None else None, "defaults": dict(self.defaults)}
+        return {
+            "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups],
+            "live_idx": [list(ix) for ix in self._live_idx] if self._inner is not None else None,
+            "inner": self._inner.state_dict() if self._inner is not None else None,
+        }
+
+    def load_state_dict(self, state):
+        if len(state["param_groups"]) != len(self.param_groups):
+            raise ValueError("loaded state dict has a different number of parameter groups")
+        for g, sg in zip(self.param_groups, state["param_groups"]):
+            g.update(sg)
+        if state.get("inner") is None:
+            return
+        if [len(ix) for ix in state["live_idx"]] != [len(ix) for ix in self._live_idx] or self._inner is None:
+            self._build(state["live_idx"])
+        self._inner.load_state_dict(state["inner"])

@@ -2,13 +2,14 @@
 
 Run in the authoring container only (needs /root/reference, ~50 GB of RAM, ~10 minutes):
 
-    python oracle/make_golden_full.py [cfg2] [cfg5] [cfg4] [cfg1]
+    python oracle/make_golden_full.py [cfg2] [cfg5] [cfg4] [cfg1] [cfg2q]
 
 Test infrastructure: imported by nothing in the product path.  Same method as oracle/make_golden.py (the
 reference's ``alignn/models/*.py`` unmodified on ``oracle/shims``), at the EXACT sizes BASELINE.json quotes:
 
 * cfg2  ``ALIGNN`` default config, ``make_batch(64, 60)``              (N=3 840, E=50 712, T=676 200)
-* cfg1  the same model on ``make_batch(8, 60)``                        (the reference's CPU plumbing case)
+* cfg1  the same model on ``make_batch(8, 60)``                        (the reference's CPU plumbing case; + float64 fwd+bwd)
+* cfg2q the same model on ``make_batch(16, 60)`` = the first 16 crystals of cfg2, with a float64 forward AND backward
 * cfg5  ``ALIGNN`` default config, ``make_batch(256, (9, 27), kind="molecule")``
 * cfg4  ``ALIGNNAtomWise`` 4+4 / H=256 / forces + stresses on ``make_batch(16, 200)``.  The force head keeps the
   double-backward graph of a 200-atom crystal alive (~4 GB per crystal), so the batch is evaluated in four chunks
@@ -57,7 +58,7 @@ def _hook(model, conv_cls, store):
             mod.register_forward_hook(hook)
 
 
-def case_alignn(tag, raw, seed):
+def case_alignn(tag, raw, seed, grad64=False):
     """One training step (forward, L1 loss, backward) of the reference's ALIGNN, default config, BatchNorm train mode."""
     t0 = time.time()
     model = ALIGNN(ALIGNNConfig(name="alignn"))
@@ -90,8 +91,19 @@ def case_alignn(tag, raw, seed):
         for k in list(d.keys()):
             if d[k].is_floating_point():
                 d[k] = d[k].double()
-    with torch.no_grad():
-        out["pred64"] = m64((g64, lg64, lat64.double())).numpy()
+    if grad64:
+        # ... and, where the RAM allows it (cfg 1, and cfg 2's first 16 crystals), the float64 BACKWARD as well: parameter
+        # gradients free of the float32 reference's own T-row summation error
+        pred64 = m64((g64, lg64, lat64.double()))
+        loss64 = torch.nn.functional.l1_loss(pred64, target.double())
+        loss64.backward()
+        out["pred64"], out["loss64"] = pred64.detach().numpy(), loss64.item()
+        for k, p in m64.named_parameters():
+            if p.grad is not None:
+                out["grad64." + k] = full_size_sample(p.grad)
+    else:
+        with torch.no_grad():
+            out["pred64"] = m64((g64, lg64, lat64.double())).numpy()
     for k, v in m64.state_dict().items():
         if "running" in k:
             out["sd_after64." + k] = v.numpy().copy()
@@ -154,9 +166,11 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["cfg1", "cfg2", "cfg5", "cfg4"]
     torch.set_num_threads(os.cpu_count() or 8)
     if "cfg1" in which:
-        case_alignn("cfg1", make_batch(8, 60), seed=10)
-    if "cfg2" in which:
-        case_alignn("cfg2", make_batch(64, 60), seed=20)
+        case_alignn("cfg1", make_batch(8, 60), seed=10, grad64=True)
+    if "cfg2q" in which:  # the first 16 crystals of the cfg-2 batch, with the float64 backward (the full 64 need > 62 GB)
+        case_alignn("cfg2q", make_batch(16, 60), seed=20, grad64=True)
+    if "cfg2" in which or "cfg2g64" in which:  # cfg2g64: + the float64 backward (peak RSS ~ see DESIGN section 2)
+        case_alignn("cfg2", make_batch(64, 60), seed=20, grad64="cfg2g64" in which)
     if "cfg5" in which:
         case_alignn("cfg5", make_batch(256, (9, 27), kind="molecule"), seed=50)
     if "cfg4" in which:

@@ -80,3 +80,114 @@ def test_flat_adamw_on_the_model_is_bit_identical_and_keeps_the_fused_projection
     m3 = ALIGNN(cfg).to(dev)
     m3.load_state_dict(sd)  # a checkpoint of the re-homed model loads like any other
     assert torch.equal(m3.eval()(batch), m2.eval()(batch))
+
+
+# ---------------------------------------------------------------------------------------------
+# round 3: a real torch.optim.Optimizer: schedulers, the reference's parameter groups, checkpoints, aliasing
+# ---------------------------------------------------------------------------------------------
+class _NamedNet(torch.nn.Module):
+    """Names as in the reference model: ``bn_nodes`` / ``*.bias`` go to the no-decay group of ``group_decay``."""
+
+    def __init__(self):
+        super().__init__()
+        self.lin = torch.nn.Linear(6, 12)
+        self.bn_nodes = torch.nn.BatchNorm1d(12)
+        self.out = torch.nn.Linear(12, 3)
+
+    def forward(self, x):
+        return self.out(torch.nn.functional.silu(self.bn_nodes(self.lin(x))))
+
+
+def test_group_decay_is_the_reference_rule():
+    from alignn_amd.optim import group_decay
+
+    m = _NamedNet()
+    groups = group_decay(m)
+    names = {id(p): n for n, p in m.named_parameters()}
+    assert sorted(names[id(p)] for p in groups[0]["params"]) == ["lin.weight", "out.weight"]
+    assert sorted(names[id(p)] for p in groups[1]["params"]) == ["bn_nodes.bias", "bn_nodes.weight", "lin.bias", "out.bias"]
+    assert groups[1]["weight_decay"] == 0 and "weight_decay" not in groups[0]
+
+
+def test_flat_adamw_is_an_optimizer_onecycle_and_two_groups_match_torch():
+    """The reference's loop: ``AdamW(group_decay(net))`` + ``OneCycleLR`` (alignn/train.py:209-226).  The scheduler
+    writes lr AND betas into param_groups every step; both optimizers must end bit-identical."""
+    from alignn_amd.optim import group_decay
+
+    torch.manual_seed(1)
+    m1 = _NamedNet()
+    m2 = copy.deepcopy(m1)
+    o1 = torch.optim.AdamW(group_decay(m1), lr=1e-2, weight_decay=0.1)
+    o2 = FlatAdamW(group_decay(m2), lr=1e-2, weight_decay=0.1, module=m2)
+    assert isinstance(o2, torch.optim.Optimizer)
+    s1 = torch.optim.lr_scheduler.OneCycleLR(o1, max_lr=1e-2, epochs=2, steps_per_epoch=4)
+    s2 = torch.optim.lr_scheduler.OneCycleLR(o2, max_lr=1e-2, epochs=2, steps_per_epoch=4)
+    for _ in range(8):
+        x = torch.randn(7, 6)
+        for m, o, s in ((m1, o1, s1), (m2, o2, s2)):
+            o.zero_grad()
+            m(x).square().mean().backward()
+            o.step()
+            s.step()
+    assert o1.param_groups[0]["lr"] == o2.param_groups[0]["lr"]
+    for (n, p), q in zip(m1.named_parameters(), m2.parameters()):
+        assert torch.equal(p, q), n
+    assert len(o2.flat_buffers) == 2 and o2.param_groups[1]["weight_decay"] == 0
+
+
+def test_flat_adamw_checkpoint_round_trip():
+    torch.manual_seed(2)
+    m1 = _NamedNet()
+    o1 = FlatAdamW(m1, lr=5e-3)
+    xs = [torch.randn(5, 6) for _ in range(6)]
+
+    def run(m, o, batch):
+        o.zero_grad()
+        m(batch).square().mean().backward()
+        o.step()
+
+    for x in xs[:3]:
+        run(m1, o1, x)
+    ck_model, ck_opt = copy.deepcopy(m1.state_dict()), copy.deepcopy(o1.state_dict())
+    for x in xs[3:]:
+        run(m1, o1, x)
+    # resume in a fresh process: new model + new optimizer, NO backward before load_state_dict
+    m2 = _NamedNet()
+    m2.load_state_dict(ck_model)
+    o2 = FlatAdamW(m2, lr=1.0)  # (the checkpoint's hyper-parameters win)
+    o2.load_state_dict(ck_opt)
+    assert o2.param_groups[0]["lr"] == 5e-3
+    for x in xs[3:]:
+        run(m2, o2, x)
+    for (n, p), q in zip(m1.named_parameters(), m2.parameters()):
+        assert torch.equal(p, q), n
+
+
+def test_flat_adamw_puts_rehomed_parameters_back():
+    """Something moves a parameter out of the flat buffer between steps (``load_state_dict(assign=True)``, ``.to()``): the
+    next step must train THAT value, not a stale slice."""
+    torch.manual_seed(3)
+    m1 = _NamedNet()
+    m2 = copy.deepcopy(m1)
+    o1 = torch.optim.AdamW(m1.parameters(), lr=1e-2)
+    o2 = FlatAdamW(m2, lr=1e-2)
+    xs = [torch.randn(5, 6) for _ in range(4)]
+    for i, x in enumerate(xs):
+        if i == 2:
+            with torch.no_grad():
+                new = torch.randn_like(m1.lin.weight)
+                m1.lin.weight.copy_(new)
+                m2.lin.weight.data = new.clone()  # re-homed: no longer a view of the flat buffer
+            assert m2.lin.weight.data_ptr() != o2.flat.data_ptr()
+        for m, o in ((m1, o1), (m2, o2)):
+            o.zero_grad()
+            m(x).square().mean().backward()
+            if i == 2 and o is o2:
+                with pytest.warns(UserWarning, match="moved out of the flat buffer"):
+                    o.step()
+            else:
+                o.step()
+    for (n, p), q in zip(m1.named_parameters(), m2.parameters()):
+        assert torch.equal(p, q), n
+    lo = o2.flat.data_ptr()
+    assert lo <= m2.lin.weight.data_ptr() < lo + o2.flat.numel() * 4
