@@ -28,7 +28,7 @@ except Exception:  # pragma: no cover - depends on the image
 
     _CONFIG = {"extra": "forbid", "protected_namespaces": ()}
 
-from . import _lib, ops
+from . import _lib, ops, torch_path
 from .graph import CSRGraph, GraphBatch, build_csr, cached_dgl_batch
 
 
@@ -71,6 +71,8 @@ class RBFExpansion(nn.Module):
             self.gamma = 1.0 / (lengthscale**2)
 
     def forward(self, distance: torch.Tensor) -> torch.Tensor:
+        if torch_path.wanted(distance):  # float64 / 16-bit: plain torch (the HIP kernels are float32)
+            return torch_path.rbf(distance, self.centers, self.gamma)
         return ops.rbf_expand(distance, self.centers, self.gamma)
 
 
@@ -125,6 +127,8 @@ class MLPLayer(nn.Module):
 
     def forward(self, x):
         lin, bn = self.layer[0], self.layer[1]
+        if torch_path.wanted(x, lin.weight):
+            return torch_path.mlp_layer(self, x)
         _bump(bn, self.training)
         with _lib.device_guard(x):
             return ops.MLPLayerFn.apply(
@@ -243,6 +247,12 @@ class EdgeGatedGraphConv(nn.Module):
             return self._forward(g, node_feats, edge_feats, need_edge_out)
 
     def _forward(self, g, node_feats, edge_feats, need_edge_out):
+        if torch_path.wanted(node_feats, edge_feats, self.edge_gate.weight):
+            if isinstance(g, CSRGraph):
+                return torch_path.edge_gated_conv(self, g.src, g.dst, g.n_nodes, node_feats, edge_feats, need_edge_out)
+            u, v = g.edges()  # the caller's edge order, as in the reference: no permutation needed
+            dev = node_feats.device
+            return torch_path.edge_gated_conv(self, u.to(dev), v.to(dev), g.num_nodes(), node_feats, edge_feats, need_edge_out)
         csr, canonical = _as_csr(g, node_feats.device)
         # (a permuting gather is a plain torch consumer: it must not read a lane-T tensor without the event)
         y_in = edge_feats if canonical else ops.main_reads(edge_feats)[csr.perm]
@@ -363,6 +373,8 @@ class ALIGNN(nn.Module):
     def forward(self, g: Union[Sequence, GraphBatch]):
         """``g`` = ``(g, lg, lat)`` of DGL-like graphs as in the reference (alignn.py:291-295), a bare
         graph when ``alignn_layers == 0``, or a prebuilt ``GraphBatch``.  Returns ``squeeze(out)``."""
+        if torch_path.wanted(self.fc.weight):  # model.double() / .bfloat16(): see alignn_amd/torch_path.py
+            return torch_path.alignn_forward(self, self._batch(g))
         ops.new_weight_generation()  # weight images cached by an earlier forward are not this forward's (ops._WGEN)
         with _lib.device_guard(self.fc.weight), _deferred_bumps(), ops.lanes(self.fc.weight.device):
             return self._forward(self._batch(g))

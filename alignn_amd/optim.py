@@ -7,7 +7,9 @@ parameters): 0.22 ms of a 17.5 ms step for 112 MB of traffic that a single eleme
 ``FlatAdamW`` re-homes the parameters of every group as views of ONE contiguous fp32 buffer per group (names, shapes
 and ``state_dict`` are untouched; the four gate / update weights - and biases - of every ``EdgeGatedGraphConv`` stay
 adjacent, in the order its fused node projection wants them, and the module adopts the flat slice as that fused buffer),
-gathers the gradients with one batched copy per group and runs torch's own fused AdamW kernel on one tensor per group.
+gathers the gradients with one batched copy per group and runs torch's own fused AdamW kernel on one tensor per group
+(the groups are ranges of ONE buffer, so a data-parallel run all-reduces everything with one collective:
+``average_gradients=True``).
 Same arithmetic per element, same step count: the parameters after a step are bit-identical to the per-tensor
 optimizer's (tests/test_optim.py, tests/test_gpu_round2.py).
 
@@ -59,12 +61,26 @@ class FlatAdamW(torch.optim.Optimizer):
     fused weight buffers (``EdgeGatedGraphConv``); defaults to the module passed as ``params``."""
 
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
-                 module: Optional[torch.nn.Module] = None):
+                 module: Optional[torch.nn.Module] = None, average_gradients: bool = False, process_group=None):
+        """``average_gradients``: data-parallel training without a DDP wrapper - ``step()`` all-reduces the ONE flat
+        gradient buffer over ``process_group`` (default group if None) and divides by the world size before the update:
+        the packed buffer the optimizer needs anyway IS the collective's buffer (one batched copy per step instead of
+        the two of FlatGradSync + optimizer).  The parameters are then marked as "gradient read after backward()"
+        (``ops.GRAD_READ_AFTER_BACKWARD``), like FlatGradSync's."""
         if isinstance(params, torch.nn.Module):
             module = params if module is None else module
             params = [p for p in params.parameters() if p.requires_grad]
         self.module = module
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.average_gradients, self.process_group = average_gradients, process_group
+        self.last_allreduce_events = None  # (start, end) HIP events around the last all-reduce (bench.py reads them)
+        if average_gradients:
+            from .ops import GRAD_READ_AFTER_BACKWARD
+
+            for g in self.param_groups:
+                for p in g["params"]:
+                    setattr(p, GRAD_READ_AFTER_BACKWARD, True)
+        self._flat_all = self._grad_all = None
         self._flat: List[Optional[torch.nn.Parameter]] = []  # per group (None: no live parameter in it)
         self._live: List[List[torch.nn.Parameter]] = []
         self._live_idx: List[List[int]] = []
@@ -85,9 +101,13 @@ class FlatAdamW(torch.optim.Optimizer):
 
     @property
     def flat(self):
-        """The flat parameter buffer (single-group use); with several groups see ``flat_buffers``."""
-        live = [f for f in self._flat if f is not None]
-        return live[0] if len(live) == 1 else None
+        """The flat parameter buffer (all groups, each a contiguous 64-element-aligned range of it)."""
+        return self._flat_all
+
+    @property
+    def flat_grad(self):
+        """The flat gradient buffer ``step()`` packs (and, with ``average_gradients``, all-reduces)."""
+        return self._grad_all
 
     @property
     def flat_buffers(self):
@@ -104,7 +124,17 @@ class FlatAdamW(torch.optim.Optimizer):
         fused = _fused_groups(self.module) if self.module is not None else []
         self._flat, self._live, self._live_idx, self._offsets, self._adopted = [], [], [], [], []
         flats = []
-        for g, idx in zip(self.param_groups, live_idx):
+        # ONE buffer for all groups (each group a contiguous range of it: one all-reduce covers everything), ranges
+        # rounded up to 64 elements so that every group's slice starts 256-byte aligned
+        sizes = [sum(g["params"][i].numel() for i in idx) for g, idx in zip(self.param_groups, live_idx)]
+        starts, total = [], 0
+        for n in sizes:
+            starts.append(total)
+            total += (n + 63) // 64 * 64
+        first = next(g["params"][idx[0]] for g, idx in zip(self.param_groups, live_idx) if idx)
+        self._flat_all = torch.zeros(total, dtype=first.dtype, device=first.device)
+        self._grad_all = torch.zeros_like(self._flat_all)
+        for gi, (g, idx) in enumerate(zip(self.param_groups, live_idx)):
             members = [g["params"][i] for i in idx]
             if not members:
                 self._flat.append(None)
@@ -123,10 +153,9 @@ class FlatAdamW(torch.optim.Optimizer):
                             order.append(p)
                             seen.add(id(p))
             order += [p for p in members if id(p) not in seen]
-            p0 = order[0]
-            if any(p.dtype != p0.dtype or p.device != p0.device for p in order):
-                raise ValueError("FlatAdamW needs the parameters of a group on one device in one dtype")
-            flat = torch.empty(sum(p.numel() for p in order), dtype=p0.dtype, device=p0.device)
+            if any(p.dtype != first.dtype or p.device != first.device for p in order):
+                raise ValueError("FlatAdamW needs all parameters on one device in one dtype")
+            flat = self._flat_all[starts[gi]:starts[gi] + sizes[gi]]
             offs, off = [], 0
             with torch.no_grad():
                 for p in order:
@@ -136,7 +165,7 @@ class FlatAdamW(torch.optim.Optimizer):
                     offs.append(off)
                     off += p.numel()
             fp = torch.nn.Parameter(flat, requires_grad=True)
-            fp.grad = torch.zeros_like(flat)
+            fp.grad = self._grad_all[starts[gi]:starts[gi] + sizes[gi]]
             pos = {id(p): i for i, p in enumerate(g["params"])}
             self._flat.append(fp)
             self._live.append(order)
@@ -205,8 +234,29 @@ class FlatAdamW(torch.optim.Optimizer):
             for h in _HYPER:  # what a scheduler wrote into OUR groups since the last step
                 ig[h] = g[h]
             k += 1
+        if self.average_gradients:
+            self._all_reduce()
         self._inner.step()
         return loss
+
+    def _all_reduce(self):
+        import torch.distributed as dist
+
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        world = dist.get_world_size(self.process_group)
+        if world == 1:
+            return
+        buf = self._grad_all
+        timed = buf.is_cuda and not torch.cuda.is_current_stream_capturing()
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.process_group)
+        buf.div_(world)
+        if timed:
+            e1.record()
+            self.last_allreduce_events = (e0, e1)
 
     # ---- checkpoints
     def state_dict(self):

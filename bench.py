@@ -24,17 +24,22 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 H = 256
-# HBM bytes per launch of the dominant kernel at this exact shape (T=676 200 rows), from rocprofv3 PMC passes over
-# bench.py itself (separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs, profiles/r02_pmc_fetch_size.txt /
-# r02_pmc_write_size.txt: the T-row launches of gemm_nt_x6_kernel<false,true,2>): FETCH_SIZE 334.9 MiB, doubled as
-# MI355X_MICROARCH.md prescribes for 16 B/lane streaming reads on gfx950, + WRITE_SIZE 660.4 MiB = 1.395 GB against
-# 1.385 GB algorithmic.  (bf16x6 variant: round-1 measurement, profiles/r01_pmc_split_gemm.txt.)  PMC cannot be sampled
-# from inside this process, so the measured value is carried here and only reported when the workload matches.
-PMC_TRAFFIC_F16X3_T676200 = (2 * 334.9 + 660.4) * 1048576
+# HBM bytes per launch of the dominant kernel and per training step, from rocprofv3 PMC passes over bench.py itself
+# (separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs; FETCH doubled as MI355X_MICROARCH.md prescribes for 16 B/lane
+# streaming reads on gfx950).  PMC cannot be sampled from inside this process, so the measured values are carried in
+# profiles/pmc_traffic.json - written ONLY by tools/pmc_constants.py from the committed rNN_pmc_*.txt summaries (a CPU test
+# re-derives it and fails if it is stale) - and are reported only when the workload matches the profiled one.
+def load_pmc_traffic():
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
+PMC = load_pmc_traffic()
+# (bf16x6 variant of the bare projection: round-1 measurement, profiles/r01_pmc_split_gemm.txt)
 PMC_TRAFFIC_X6_T676200 = (2 * 360721.0 + 676200.0) * 1024
-# in-step launches of the same kernel body with its fused epilogues (same PMC passes; MiB per launch: FETCH raw, WRITE)
-PMC_MIB_BY_VARIANT_T676200 = {"plain": (334.9, 660.4), "gather": (424.5, 681.0), "bnred": (691.9, 686.0),
-                              "bnred_addend": (1027.1, 717.1)}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F32_PEAK_TF = 157.3  # v_mfma_f32_32x32x2_f32 dense peak
 
@@ -110,6 +115,50 @@ def time_kernel(fn, iters=10):
     e.record()
     torch.cuda.synchronize()
     return s.elapsed_time(e) / iters
+
+
+def cpu_baseline_ff(n_atoms, sample=4):
+    """BASELINE configs[3] (ALIGNN-FF: energy + forces + stress, loss differentiated THROUGH the forces): the oracle's
+    ``alignn_atomwise_forward`` (reference arithmetic of alignn_atomwise.py:364-660 on torch-CPU, autograd.grad with
+    create_graph + a second backward) timed on a BOUNDED sample: ``sample`` crystals of the same generator (the double
+    backward keeps ~4 GB per 200-atom crystal alive - BASELINE.md section 2 prescribes B = 4 and scaling; the model has
+    no batch statistic, so the cost per crystal does not depend on the batch)."""
+    import numpy as np
+
+    from alignn_amd.synthetic import make_batch
+    from oracle import alignn_oracle as O
+
+    cores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    log(f"cpu baseline (force field) on {cores} threads (host has {os.cpu_count()})")
+    p = O.as_params(O.init_state_dict(seed=0))  # (same key names for the LayerNorm model; running statistics unused)
+    leaves = [t for t in p.values() if t.requires_grad]
+    opt = torch.optim.AdamW(leaves, lr=1e-3)
+    l1 = torch.nn.functional.l1_loss
+
+    def step(raw):
+        g = O.TorchGraph(raw)
+        vol = torch.from_numpy(np.abs(np.linalg.det(raw.lattice.astype(np.float64))).astype(np.float32))
+        opt.zero_grad(set_to_none=True)
+        out, forces, stresses = O.alignn_atomwise_forward(p, g, 4, 4, True, calculate_gradient=True, volume=vol,
+                                                          batch_num_edges=torch.from_numpy(raw.batch_num_edges), stress=True)
+        gen = torch.Generator().manual_seed(1)
+        loss = (l1(out, torch.randn(out.shape, generator=gen)) + l1(forces, torch.randn(forces.shape, generator=gen))
+                + 0.05 * l1(stresses, torch.randn(stresses.shape, generator=gen)))
+        loss.backward()
+        opt.step()
+
+    step(make_batch(1, 40, seed0=999))  # warm-up (thread pool, allocator)
+    raw = make_batch(sample, n_atoms)
+    t0 = time.perf_counter()
+    step(raw)
+    dt = time.perf_counter() - t0
+    return {"value": round(sample / dt, 3), "unit": "graphs/s", "cores": cores, "host_cpus": os.cpu_count(), "kind": "port",
+            "seconds_per_step": round(dt, 2),
+            "sample": f"1 timed training step (energy + forces + stress, fwd + force autograd + double backward + AdamW) of "
+                      f"{sample} of the GPU run's {n_atoms}-atom crystals (N={raw.num_nodes} E={raw.num_edges} "
+                      f"T={raw.num_triplets}), ALIGNNAtomWise 4+4 / H=256, torch-CPU oracle; cost per crystal is batch-independent "
+                      "(LayerNorm model)"}
 
 
 def cpu_baseline(n_graphs, n_atoms, kind="crystal"):
@@ -231,15 +280,31 @@ def main():
         predict = lambda b: model(b)["out"]  # noqa: E731
     broadcast_parameters(model)
     target = torch.randn(B, generator=torch.Generator().manual_seed(1 + rank)).to(dev)
-    sync = FlatGradSync(model.parameters())
-    # AdamW: torch's fused kernel either way - over ONE flat parameter buffer (alignn_amd/optim.py: bit-identical updates,
-    # one launch instead of five) unless ALIGNN_BENCH_FLAT_ADAMW=0 asks for the per-tensor optimizer of the reference loop
-    if os.environ.get("ALIGNN_BENCH_FLAT_ADAMW", "1") != "0":
-        from alignn_amd.optim import FlatAdamW
+    # AdamW on the reference's parameter groups (alignn/train.py:209-210 -> alignn/utils.py:77-108 ``group_decay``: no
+    # weight decay on names containing bias / bn / norm), torch's fused kernel either way - over ONE flat parameter buffer
+    # (alignn_amd/optim.py: bit-identical updates, two launches instead of ten; its packed gradient buffer is also the
+    # buffer of the ONE gradient all-reduce per step) unless ALIGNN_BENCH_FLAT_ADAMW=0 asks for the per-tensor optimizer
+    # behind FlatGradSync's separate flat bucket
+    from alignn_amd.optim import FlatAdamW, group_decay
 
-        opt = FlatAdamW(model, lr=1e-3)
+    LR, WD = 1e-3, 1e-2
+    if os.environ.get("ALIGNN_BENCH_FLAT_ADAMW", "1") != "0":
+        opt = FlatAdamW(group_decay(model), lr=LR, weight_decay=WD, module=model, average_gradients=True)
+        sync = None
+        opt_desc = "FlatAdamW (torch fused AdamW on one flat buffer) over group_decay(model): lr 1e-3, weight_decay 1e-2 / 0 on bias|bn|norm"
     else:
-        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, fused=True)
+        opt = torch.optim.AdamW(group_decay(model), lr=LR, weight_decay=WD, fused=True)
+        sync = FlatGradSync(model.parameters())
+        opt_desc = "torch.optim.AdamW(fused) over group_decay(model) behind FlatGradSync: lr 1e-3, weight_decay 1e-2 / 0 on bias|bn|norm"
+
+    def zero_grad():
+        for p_ in model.parameters():
+            p_.grad = None
+
+    def reduce_and_update():
+        if sync is not None:
+            sync.sync()
+        opt.step()  # (FlatAdamW: packs the gradients, all-reduces the packed buffer, updates)
 
     if args.model == "alignn_ff":
         # SURVEY 8(d) cfg 4: loss = L1(energy) + L1(forces) + L1(stress), differentiating THROUGH the forces
@@ -247,21 +312,19 @@ def main():
         s_tgt = torch.randn(B, 3, 3, generator=torch.Generator().manual_seed(8 + rank)).to(dev)
 
         def step():
-            sync.zero_grad()
+            zero_grad()
             o = model(batch)
             l1 = torch.nn.functional.l1_loss
             loss = l1(o["out"], target) + l1(o["grad"], f_tgt) + l1(o["stresses"], s_tgt)
             loss.backward()
-            sync.sync()
-            opt.step()
+            reduce_and_update()
             return loss
     else:
         def step():
-            sync.zero_grad()
+            zero_grad()
             loss = torch.nn.functional.l1_loss(predict(batch), target)
             loss.backward()
-            sync.sync()
-            opt.step()
+            reduce_and_update()
             return loss
 
     main_prio = os.environ.get("ALIGNN_BENCH_MAIN_PRIORITY")
@@ -311,8 +374,7 @@ def main():
                 graph.replay()
                 for p_, g_ in zip(params, g_grads):
                     p_.grad = g_
-                sync.sync()
-                opt.step()
+                reduce_and_update()
                 return g_loss
 
             step()
@@ -340,10 +402,39 @@ def main():
     t_enq = time.perf_counter() - t0  # host time to ENQUEUE the steps (no device sync inside)
     fence()
     dt = time.perf_counter() - t0
+    multi = None
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dt_rank = dt
+        t = torch.tensor([dt, -dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, dt_min = float(t[0].item()), -float(t[1].item())
+        # every rank is counted over the SAME backend the gradients travel on (RCCL for real runs)
+        seen = torch.ones(1, device=dev)
+        dist.all_reduce(seen)
+        # the gradient all-reduce on its own: HIP events around the collective of the last timed step (FlatAdamW) and a
+        # stand-alone loop over the same buffer
+        ar_in_step = None
+        evs = getattr(opt, "last_allreduce_events", None)
+        if evs is not None:
+            torch.cuda.synchronize()
+            ar_in_step = evs[0].elapsed_time(evs[1])
+        buf = opt.flat_grad.clone() if getattr(opt, "flat_grad", None) is not None else torch.zeros(4026753, device=dev)
+        for _ in range(3):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            dist.all_reduce(buf)
+        e1.record()
+        torch.cuda.synchronize()
+        multi = {"ranks_seen": int(seen.item()), "backend": backend, "rank_ms_per_step_max": round(dt / args.steps * 1e3, 3),
+                 "rank_ms_per_step_min": round(dt_min / args.steps * 1e3, 3), "rank0_ms_per_step": round(dt_rank / args.steps * 1e3, 3),
+                 "allreduce_bytes": buf.numel() * buf.element_size(),
+                 "allreduce_ms_in_step_incl_divide": None if ar_in_step is None else round(ar_in_step, 4),
+                 "allreduce_ms_standalone": round(e0.elapsed_time(e1) / 10, 4),
+                 "collectives_per_step": 1}
+        assert multi["ranks_seen"] == world, multi
     ms = dt / args.steps * 1e3
     gps = world * B * args.steps / dt
     log(f"{ms:.2f} ms/step, {gps:.1f} graphs/s (host enqueue {t_enq / args.steps * 1e3:.2f} ms/step)")
@@ -406,9 +497,9 @@ def main():
             t_all = sum(sum(ts) for ts in by.values())
             b_all = sum(rows_moved[label] * row_bytes * len(ts) for label, ts in by.items())
             pmc = None
-            if raw.num_triplets == 676200 and all(label in PMC_MIB_BY_VARIANT_T676200 for label in by):
-                pmc = sum((2 * PMC_MIB_BY_VARIANT_T676200[label][0] + PMC_MIB_BY_VARIANT_T676200[label][1]) * 1048576 * len(ts)
-                          for label, ts in by.items()) / n_l
+            pv = PMC["variants"] if (PMC is not None and raw.num_triplets == PMC["triplets"]) else {}
+            if pv and all(label in pv for label in by):
+                pmc = sum(pv[label]["bytes_per_launch"] * len(ts) for label, ts in by.items()) / n_l
             in_step["family"] = {"launches_per_step": n_l, "ms_per_launch": t_all / n_l, "algorithmic_bytes_per_launch": b_all / n_l,
                                  "GBps": b_all / (t_all * 1e-3) / 1e9, "traffic": pmc}
 
@@ -428,11 +519,10 @@ def main():
 
         def sstep():
             b, t = next(it)
-            sync.zero_grad()
+            zero_grad()
             loss_ = torch.nn.functional.l1_loss(predict(b), t)
             loss_.backward()
-            sync.sync()
-            opt.step()
+            reduce_and_update()
 
         for _ in range(2):
             sstep()
@@ -470,6 +560,9 @@ def main():
         flops = 2.0 * T * H * H
         gemm_bytes = 2.0 * T * H * 4
         gbs = gemm_bytes / (t_h3 * 1e-3) / 1e9
+        plain_traffic = (PMC["variants"]["plain"]["bytes_per_launch"]
+                         if (PMC is not None and T == PMC["triplets"] and "plain" in PMC["variants"]) else None)
+        pmc_step = PMC["pmc_bytes_per_step"] if (PMC is not None and T == PMC["triplets"] and args.model == "alignn") else None
         step_bytes = algorithmic_bytes_per_step(N, E, T)
         step_flops = algorithmic_flops_per_step(N, E, T)
         out = {
@@ -508,7 +601,8 @@ def main():
                            "step: edge projection + u_add_v + BN statistics / input gradient + residual + BN-backward sums",
                  "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "in_step": in_step,
                  "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + --pmc WRITE_SIZE over bench.py, "
-                                   "profiles/r02_pmc_fetch_size.txt + r02_pmc_write_size.txt (per variant, averaged over the launches)"},
+                                   + (" + ".join(PMC["source"]) if PMC is not None else "profiles/") +
+                                   " via tools/pmc_constants.py -> profiles/pmc_traffic.json (per variant, averaged over the launches)"},
                 **({"achieved": round(in_step["family"]["GBps"], 1),
                     "frac": round(in_step["family"]["GBps"] / HBM_PEAK_GBS, 4),
                     "traffic": in_step["family"]["traffic"],
@@ -517,11 +611,11 @@ def main():
                     "algorithmic_bytes_per_launch": in_step["family"]["algorithmic_bytes_per_launch"]}
                    if in_step is not None and "family" in in_step else
                    {"achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4),
-                    "traffic": PMC_TRAFFIC_F16X3_T676200 if T == 676200 else None, "ms_per_launch": round(t_h3, 4),
+                    "traffic": plain_traffic, "ms_per_launch": round(t_h3, 4),
                     "algorithmic_bytes_per_launch": gemm_bytes}),
                 standalone_plain_projection={
                     "ms_per_launch": round(t_h3, 4), "algorithmic_bytes_per_launch": gemm_bytes, "GBps": round(gbs, 1),
-                    "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": PMC_TRAFFIC_F16X3_T676200 if T == 676200 else None,
+                    "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": plain_traffic,
                     "equivalent_fp32_TFLOPs": round(flops / (t_h3 * 1e-3) / 1e12, 1),
                     "f16_mfma_frac_of_2500TF": round(3 * flops / (t_h3 * 1e-3) / 1e12 / 2500.0, 4)},
                 bf16x6_kernel_same_shape={
@@ -540,16 +634,29 @@ def main():
                 "algorithmic_GB_per_step": round(step_bytes / 1e9, 2),
                 "algorithmic_GFLOP_per_step": round(step_flops / 1e9, 1),
                 "hbm_frac_of_8TBs": round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                # what the schedule really moves (it needs fewer passes than SURVEY's accounting: 5 forward passes per
+                # line-graph convolution, dead last-layer outputs, fused reductions): rocprofv3 FETCH_SIZE x2 + WRITE_SIZE
+                # summed over the launches of one step (profiles/pmc_traffic.json), and the bandwidth THAT corresponds to
+                "pmc_GB_per_step": None if pmc_step is None else round(pmc_step / 1e9, 2),
+                "pmc_hbm_frac_of_8TBs": None if pmc_step is None else round(pmc_step / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "pmc_source": None if pmc_step is None else PMC["source"],
                 "mfma_frac_of_157TF": round(step_flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4),
             },
             "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3),
+            "optimizer": opt_desc,
+            "multi_gpu": multi,
             "step_launch": "hipGraph replay of forward+loss+backward, eager all-reduce + fused AdamW" if use_graph else "eager",
             "peak_hbm_GB": round(torch.cuda.max_memory_allocated(dev) / 1e9, 2),
             "streamed_batches": streamed,
             "loss": round(float(loss.item()), 6),
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_graphs or B, n_atoms, args.kind)
+            if args.model == "alignn_ff":
+                out["cpu_baseline"] = cpu_baseline_ff(n_atoms, sample=min(B, args.cpu_graphs or 4))
+            elif args.model == "alignn":
+                out["cpu_baseline"] = cpu_baseline(args.cpu_graphs or B, n_atoms, args.kind)
+            else:
+                out["cpu_baseline"] = None
         else:
             out["cpu_baseline"] = None
     if world > 1:

@@ -31,3 +31,32 @@ def test_gpus_flag_must_match_the_launcher():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env, capture_output=True,
                        text=True, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+def test_gpus_8_rendezvous_counts_every_rank():
+    """The driver's 8-GPU launch shape (one process per GPU): all eight ranks join the group on the loopback address and
+    are counted (no GPU: they stop after the rendezvous)."""
+    r = _run(["--gpus", "8", "--steps", "1", "--warmup", "0"], {})
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 8 and out["ranks_seen"] == 8
+
+
+def test_pmc_traffic_json_is_derived_from_the_committed_profiles():
+    """bench.py reports HBM traffic from profiles/pmc_traffic.json; that file must equal what tools/pmc_constants.py derives
+    from the newest committed rNN_pmc_fetch_size.txt / rNN_pmc_write_size.txt, and bench.py must carry no byte constants of
+    its own for it."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_constants
+
+    committed = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    assert committed == pmc_constants.build()
+    for src in committed["source"]:
+        assert os.path.exists(os.path.join(ROOT, src))
+    text = open(os.path.join(ROOT, "bench.py")).read()
+    assert "PMC_MIB_BY_VARIANT" not in text and "PMC_TRAFFIC_F16X3" not in text
+    v = committed["variants"]
+    assert {"plain", "gather", "bnred", "bnred_addend"} <= set(v)
+    for name, e in v.items():  # no wasted traffic: within 1.15x of the algorithmic rows of each variant
+        rows = {"plain": 2, "gather": 2.15, "stats": 2, "bnred": 3, "bnred_addend": 4}[name]
+        assert 0.95 < e["bytes_per_launch"] / (rows * committed["triplets"] * 1024) < 1.15, (name, e)

@@ -168,3 +168,63 @@ def test_flat_adamw_behind_the_flat_allreduce_equals_the_full_batch_optimizer():
         a, b = torch.from_numpy(res[0][k]), torch.from_numpy(res[1][k])
         assert torch.equal(a, b), k  # ranks stay in lock-step
         assert torch.allclose(a, p.detach(), rtol=1e-5, atol=1e-7), k  # = the full-batch optimizer (all-reduce rounding apart)
+
+
+def _worker_opt_avg(rank, world, port, q):
+    """Round 3: FlatAdamW(average_gradients=True) - the optimizer's own packed gradient buffer IS the all-reduce buffer
+    (one batched copy per step instead of FlatGradSync's + the optimizer's), two parameter groups in one buffer."""
+    from alignn_amd.optim import FlatAdamW, group_decay
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)
+    net = Net()
+    broadcast_parameters(net)
+    gen = torch.Generator().manual_seed(7)
+    X, Y = torch.randn(8, 6, generator=gen), torch.randn(8, generator=gen)
+    shard = slice(rank, None, world)
+    opt = FlatAdamW(group_decay(net), lr=1e-2, weight_decay=0.1, module=net, average_gradients=True)
+    for _ in range(3):
+        opt.zero_grad()
+        torch.nn.functional.mse_loss(net(X[shard]), Y[shard]).backward()
+        opt.step()
+    out = {k: p.detach().numpy().copy() for k, p in net.named_parameters()}
+    out["__flat_numel"] = opt.flat_grad.numel()
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_adamw_averaging_its_own_gradient_buffer_equals_the_full_batch_optimizer():
+    from alignn_amd.optim import group_decay
+
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_opt_avg, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    torch.manual_seed(100)
+    ref = Net()
+    gen = torch.Generator().manual_seed(7)
+    X, Y = torch.randn(8, 6, generator=gen), torch.randn(8, generator=gen)
+    groups = group_decay(ref)
+    for g in groups:  # torch's AdamW would decay the never-used parameters too; FlatAdamW leaves them out like grad=None
+        g["params"] = [p for p in g["params"] if all(p is not q_ for q_ in ref.unused.parameters())]
+    opt = torch.optim.AdamW(groups, lr=1e-2, weight_decay=0.1)
+    for _ in range(3):
+        opt.zero_grad()
+        loss = 0.5 * (torch.nn.functional.mse_loss(ref(X[0::2]), Y[0::2]) + torch.nn.functional.mse_loss(ref(X[1::2]), Y[1::2]))
+        loss.backward()
+        opt.step()
+    assert res[0]["__flat_numel"] % 64 == 0
+    for k, p in ref.named_parameters():
+        a, b = torch.from_numpy(res[0][k]), torch.from_numpy(res[1][k])
+        assert torch.equal(a, b), k
+        assert torch.allclose(a, p.detach(), rtol=1e-5, atol=1e-7), k

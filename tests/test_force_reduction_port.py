@@ -1,0 +1,119 @@
+"""The reference's own numerical test (alignn/tests/test_force_reduction.py:131-268), ported 1:1 onto
+``alignn_amd.alignn.EdgeGatedGraphConv``: float64 default dtype, the 32-atom JVASP-98225 cluster, ``dgl.radius_graph`` +
+``fn.v_sub_u`` + ``SumPooling`` (here: the torch-only DGL stand-in of oracle/shims - test infrastructure), two
+EdgeGatedGraphConv layers in train mode with constant node features.
+
+float64 modules run on ``alignn_amd/torch_path.py`` (the HIP kernels are float32), so this file needs
+no GPU and belongs to the CPU suite.  The float32-kernel form of the same two checks is
+tests/test_gpu_round2.py::test_forces_against_finite_differences_of_the_float64_oracle.
+"""
+import os
+import sys
+
+import pytest
+import torch
+from torch import nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle", "shims"))
+
+import dgl  # noqa: E402  (oracle/shims/dgl)
+import dgl.function as fn  # noqa: E402
+from dgl.nn import SumPooling  # noqa: E402
+
+from alignn_amd.alignn import EdgeGatedGraphConv  # noqa: E402  (where the reference imports alignn.models.alignn)
+from tests.helpers import load_golden  # noqa: E402
+
+
+def _cart_coords():
+    z = load_golden("graphs_sample_data.npz")  # the reference's examples/sample_data structures (fractional + lattice)
+    i = z["names"].tolist().index("POSCAR-JVASP-98225.vasp")
+    return torch.from_numpy(z[f"{i}.frac"] @ z[f"{i}.lat"])  # [32, 3] float64 = Atoms.cart_coords
+
+
+class SimpleModel(nn.Module):
+    """test_force_reduction.py:131-217, line for line in behaviour."""
+
+    def __init__(self, cutoff=8, width=16):
+        super().__init__()
+        self.cutoff, self.width = cutoff, width
+        self.edge_embedding = nn.Linear(1, width)
+        self.hidden1 = EdgeGatedGraphConv(width, width)
+        self.hidden2 = EdgeGatedGraphConv(width, width)
+        self.fc = nn.Linear(width, 1)
+        self.readout = SumPooling()
+
+    def forward(self, positions, autograd_forces=False):
+        if autograd_forces:
+            positions.requires_grad_(True)
+        g = dgl.radius_graph(positions, self.cutoff)
+        g.ndata["r"] = positions
+        g.apply_edges(fn.v_sub_u("r", "r", "bondvec"))
+        bondvec = g.edata.pop("bondvec")
+        bondlength = torch.norm(bondvec, dim=1).squeeze()
+        y = self.edge_embedding(bondlength.unsqueeze(-1))
+        g.edata["y"] = y
+        x = torch.ones(g.num_nodes(), self.width)
+        x, y = self.hidden1(g, x, y)
+        x, y = self.hidden2(g, x, y)
+        energy = self.fc(x)
+        total_energy = torch.squeeze(self.readout(g, energy))
+        if not autograd_forces:
+            return total_energy
+        forces_x = -torch.autograd.grad(total_energy, positions, retain_graph=True)[0]
+        pairwise_forces = -torch.autograd.grad(total_energy, bondvec)[0]
+        g.edata["pairwise_forces"] = pairwise_forces
+        g.update_all(fn.copy_e("pairwise_forces", "m"), fn.sum("m", "forces_ji"))
+        rg = dgl.reverse(g, copy_edata=True)
+        rg.update_all(fn.copy_e("pairwise_forces", "m"), fn.sum("m", "forces_ij"))
+        forces_vec = torch.squeeze(g.ndata["forces_ji"] - rg.ndata["forces_ij"])
+        return total_energy, forces_x, forces_vec
+
+
+@pytest.fixture
+def float64_default():
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    yield
+    torch.set_default_dtype(prev)
+
+
+@pytest.mark.filterwarnings("ignore:alignn_amd. torch.float64 tensors run on plain torch")
+def test_compare_position_and_displacement_autograd_forces(float64_default):
+    torch.manual_seed(0)
+    model = SimpleModel(cutoff=5)
+    assert model.hidden1.src_gate.weight.dtype == torch.float64
+    e, f_x, f_vec = model(_cart_coords(), autograd_forces=True)
+    assert torch.isclose(f_x, f_vec).all().item()
+
+
+@pytest.mark.filterwarnings("ignore:alignn_amd. torch.float64 tensors run on plain torch")
+def test_compare_forces_finite_difference(float64_default):
+    torch.manual_seed(0)
+    model = SimpleModel(cutoff=5)
+    x = _cart_coords()
+    n = x.shape[0]
+
+    def finite_difference_force(x, i, j, delta=1e-6):
+        xa, xb = x.detach().clone(), x.detach().clone()
+        xa[i, j] -= delta
+        xb[i, j] += delta
+        with torch.no_grad():
+            return -(model(xb) - model(xa)) / (2 * delta)
+
+    e, f_x, f_vec = model(x, autograd_forces=True)
+    f_dx = torch.tensor([[finite_difference_force(x, i, j) for j in range(3)] for i in range(n)])
+    # the reference's numerical parameters (those of torch.autograd.gradcheck)
+    assert torch.isclose(f_vec, f_dx, atol=1e-05, rtol=0.001).all().item()
+    assert torch.isclose(f_x, f_dx, atol=1e-05, rtol=0.001).all().item()
+    # (with constant node features the forces themselves are ~1e-5, i.e. of the size of ``atol``: the reference's check
+    # is a weak one by construction; the well-conditioned variant with a relative bound is the GPU test named above)
+    assert float((f_vec - f_x).abs().max()) < 1e-12
+
+
+def test_float32_cpu_tensors_still_refused():
+    """The torch path is for non-float32 dtypes only: a float32 module on the CPU must raise, not fall back."""
+    conv = EdgeGatedGraphConv(16, 16)
+    g = dgl.radius_graph(_cart_coords().float(), 5.0)
+    with pytest.raises((TypeError, RuntimeError)):
+        conv(g, torch.ones(g.num_nodes(), 16), torch.ones(g.num_edges(), 16))

@@ -90,3 +90,104 @@ def test_flat_allreduce_of_the_real_model_averages_the_rank_gradients():
         assert np.array_equal(got[0][k], got[1][k]), k  # both ranks hold the same averaged gradient
         n += 1
     assert n > 40
+
+
+# ---------------------------------------------------------------------------------------------
+# round 3: the collective path the driver's 8-GPU run takes, as far as one box can exercise it
+# ---------------------------------------------------------------------------------------------
+def _bench(args, env_extra, timeout=900):
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **env_extra)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0]), r.stderr
+
+
+SMALL = ["--steps", "3", "--warmup", "1", "--batch", "8", "--atoms", "20", "--no-cpu-baseline", "--eager-steps", "2",
+         "--streamed-steps", "0"]
+
+
+def test_bench_two_ranks_on_one_gpu_with_hipgraph_capture_beside_the_collective():
+    """``bench.py --gpus 2`` self-spawned, both ranks on this box's one GPU, gloo collectives, hipGraph capture ON (the
+    default): forward + backward replayed from the graph, the packed-gradient all-reduce and the optimizer eager beside
+    it - the step structure of the 8-GPU run.  Every rank must be counted and the line must say it replayed a graph."""
+    out, err = _bench(["--gpus", "2"] + SMALL, {"ALIGNN_BENCH_BACKEND": "gloo"})
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 16
+    mg = out["multi_gpu"]
+    assert mg["ranks_seen"] == 2 and mg["collectives_per_step"] == 1
+    assert mg["rank_ms_per_step_min"] <= mg["rank_ms_per_step_max"]
+    assert out["step_launch"].startswith("hipGraph replay"), (out["step_launch"], err[-1500:])
+    assert out["eager_launches"] is not None and out["loss"] == out["loss"]  # (not NaN)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: exercised by the driver's multi-GPU box")
+def test_bench_two_ranks_over_rccl():
+    """The real thing wherever >= 2 GPUs are visible: one rank per GPU, RCCL all-reduce of the packed gradient buffer
+    beside the replayed hipGraph; ranks_seen counted over RCCL itself."""
+    out, err = _bench(["--gpus", "2"] + SMALL, {})
+    mg = out["multi_gpu"]
+    assert out["n_gpus"] == 2 and mg["ranks_seen"] == 2 and mg["backend"] == "nccl"
+    assert mg["allreduce_ms_standalone"] > 0
+    assert out["step_launch"].startswith("hipGraph replay"), (out["step_launch"], err[-1500:])
+    one, _ = _bench(["--gpus", "1"] + SMALL, {})
+    assert out["value"] > 1.2 * one["value"], (out["value"], one["value"])  # two GPUs do more than one
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: exercised by the driver's multi-GPU box")
+def test_rccl_average_equals_the_mean_of_the_rank_gradients():
+    """FlatAdamW(average_gradients=True) over nccl on two distinct GPUs: after one step both ranks hold bit-identical
+    parameters (the all-reduced gradient is the same tensor on both)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_nccl, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    import numpy as np
+
+    for k in got[0]:
+        assert np.array_equal(got[0][k], got[1][k]), k
+
+
+def _worker_nccl(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    from alignn_amd import ALIGNN, ALIGNNConfig, GraphBatch
+    from alignn_amd.ddp import broadcast_parameters
+    from alignn_amd.optim import FlatAdamW, group_decay
+    from alignn_amd.synthetic import make_batch
+
+    torch.manual_seed(0)
+    dev = torch.device("cuda", rank)
+    model = ALIGNN(ALIGNNConfig(**CFG)).to(dev).train()
+    broadcast_parameters(model)
+    opt = FlatAdamW(group_decay(model), lr=1e-3, module=model, average_gradients=True)
+    batch = GraphBatch.from_raw(make_batch(4, 12, seed0=500 + 10 * rank), device=dev)
+    target = torch.linspace(-1, 1, 4, device=dev)
+    for _ in range(2):
+        opt.zero_grad()
+        torch.nn.functional.l1_loss(model(batch), target).backward()
+        opt.step()
+    torch.cuda.synchronize()
+    q.put((rank, {k: p.detach().cpu().numpy().copy() for k, p in model.named_parameters()}))
+    dist.barrier()
+    dist.destroy_process_group()

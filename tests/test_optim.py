@@ -36,7 +36,9 @@ def test_flat_adamw_equals_per_tensor_adamw_on_cpu():
     for p, q in zip(m1.parameters(), m2.parameters()):
         assert torch.equal(p, q)
     assert m2.a.weight.data_ptr() == o2.flat.data_ptr()  # parameters are views of the flat buffer
-    assert o2.flat.numel() == sum(p.numel() for p in list(m2.a.parameters()) + list(m2.b.parameters()))  # `dead` left out
+    # `dead` left out (the buffer itself is padded to a multiple of 64 elements per group)
+    assert sum(f.numel() for f in o2.flat_buffers) == sum(p.numel() for p in list(m2.a.parameters()) + list(m2.b.parameters()))
+    assert o2.flat.numel() % 64 == 0
     assert set(m2.state_dict()) == set(m1.state_dict())
 
 
