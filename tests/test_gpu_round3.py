@@ -141,3 +141,112 @@ def test_non_canonical_graph_conv_on_a_lane():
         got = run("1")
         for a, b in zip(ref, got):
             assert torch.equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------------
+# the identity-keyed side-band registries: hits and misses are counted, expensive misses warn
+# ---------------------------------------------------------------------------------------------
+def _default_step_stats(wrap_ddp):
+    import socket
+    import warnings
+
+    import torch.distributed as dist
+
+    torch.manual_seed(0)
+    model = ALIGNN(ALIGNNConfig(name="alignn")).to(DEV).train()
+    raw = make_batch(16, 60, seed0=77)  # E = 12.6 k, T = 169 k rows: every split-product path of the benchmark is taken
+    batch = GraphBatch.from_raw(raw, device=DEV)
+    target = torch.randn(16, generator=torch.Generator().manual_seed(2)).to(DEV)
+    net = model
+    if wrap_ddp:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+        net = torch.nn.parallel.DistributedDataParallel(model, find_unused_parameters=True)  # alignn/train.py:207
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("error", RuntimeWarning)  # a fall-back to bf16x6 / separate reductions would raise here
+            torch.nn.functional.l1_loss(net(batch), target).backward()  # first step: lazy initialisations
+            ops.reset_registry_stats()
+            torch.nn.functional.l1_loss(net(batch), target).backward()
+        torch.cuda.synchronize()
+        return dict(ops.REGISTRY_STATS), dict(ops.BNRED_STATS)
+    finally:
+        if wrap_ddp:
+            dist.destroy_process_group()
+
+
+def test_registry_hits_of_a_default_config_step_plain_and_under_ddp():
+    plain, bn_plain = _default_step_stats(False)
+    print("registry stats, plain:", plain, bn_plain)
+    # nothing silently dropped to a slow path
+    assert plain["bf16x6_fallback"] == 0 and plain["separate_bn_reduce"] == 0 and plain["wimg_miss"] == 0
+    # (amax_miss counts tall tensors that arrive without a tracked max|.| - the raw inputs and the RBF expansions, whose
+    # projections are not split-product shapes; a miss that COSTS something shows up as bf16x6_fallback above)
+    assert plain["amax_hit"] >= 20, plain
+    assert plain["wimg_hit"] >= 12  # the input-gradient images of the 4+4+4 edge-gate weights (at least)
+    assert bn_plain["fused"] == bn_plain["used"] == plain["pre_red_hit"] and bn_plain["fused"] >= 4
+    ddp, bn_ddp = _default_step_stats(True)
+    print("registry stats, DDP-wrapped:", ddp, bn_ddp)
+    assert ddp == plain and bn_ddp == bn_plain  # the reducer's hooks and bucket views cost no registry hit
+
+
+def test_a_cloned_gradient_is_counted_and_warned_about():
+    """A hook that clones the gradient between two layers breaks the identity the pre-reduced BatchNorm-backward sums
+    travel under: the step stays correct (same gradients up to summation order), the miss is counted and warns once."""
+    import warnings
+
+    from alignn_amd.alignn import MLPLayer
+
+    torch.manual_seed(0)
+    a, b = MLPLayer(64, 256).to(DEV).train(), MLPLayer(256, 256).to(DEV).train()
+    x = torch.randn(40000, 64, device=DEV)
+
+    def run(clone):
+        for m in (a, b):
+            m.zero_grad(set_to_none=True)
+        h = a(x)
+        if clone:
+            h.register_hook(lambda g: g.clone())
+        b(h).square().mean().backward()
+        torch.cuda.synchronize()
+        return [p.grad.clone() for p in list(a.parameters()) + list(b.parameters())]
+
+    ops._WARNED.discard("pre_red")
+    ref = run(False)
+    ops.reset_registry_stats()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        got = run(True)
+    if ops.BNRED_STATS["fused"]:  # (the product took the f16x3 kernel with the fused sums: then the clone must be noticed)
+        assert ops.REGISTRY_STATS["separate_bn_reduce"] == 1
+        assert any("BatchNorm-backward sums" in str(m.message) for m in w)
+    for p, q in zip(ref, got):
+        assert float((p - q).abs().max()) <= 1e-5 * float(p.abs().max() + 1e-30)
+
+
+# ---------------------------------------------------------------------------------------------
+# non-float32 modules: plain torch on the device (alignn_amd/torch_path.py)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.filterwarnings("ignore:alignn_amd. torch.float64 tensors run on plain torch")
+def test_float64_model_on_the_gpu_reproduces_the_float64_reference():
+    from oracle import alignn_oracle as O
+    from tests.helpers import load_golden
+
+    z = load_golden("full_cfg1.npz")
+    raw = make_batch(8, 60)
+    seed = int(z["seed"])
+    model = ALIGNN(ALIGNNConfig(name="alignn"))
+    model.load_state_dict(O.perturbed_norm_state_dict(O.init_state_dict(seed=seed), seed=seed + 1))
+    model = model.double().to(DEV).train()
+    batch = GraphBatch.from_raw(raw, device=DEV, dtype=torch.float64)
+    pred = model(batch)
+    loss = torch.nn.functional.l1_loss(pred, torch.from_numpy(z["target"]).double().to(DEV))
+    loss.backward()
+    assert float((pred.detach().cpu() - torch.from_numpy(z["pred64"])).abs().max()) < 1e-10
+    assert abs(loss.item() - float(z["loss64"])) < 1e-12
+    g = O.full_size_sample(dict(model.named_parameters())["alignn_layers.0.edge_update.edge_gate.weight"].grad, 512)
+    ref = z["grad64.alignn_layers.0.edge_update.edge_gate.weight"]
+    assert np.abs(g[:-4] - ref[:-4]).max() < 1e-9 * np.abs(ref[:-4]).max()
