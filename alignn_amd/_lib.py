@@ -86,6 +86,10 @@ SIGNATURES = {
     "alignn_segment_mean_bwd": (_i32, [_p, _p, _p, _i32, _i32, _p]),
     "alignn_gather_rows": (_i32, [_p, _p, _p, _i64, _i32, _p]),
     "alignn_segment_sum": (_i32, [_p, _i64, _p, _p, _p, _p, _i64, _i64, _i32, _p]),
+    "alignn_knn_levels": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i64, _p, _p]),
+    "alignn_knn_kth": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i64, _p, _p, _p]),
+    "alignn_knn_count": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i64, _p, _p, _p, _p]),
+    "alignn_knn_emit": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i64, _p, _p, _p, _p, _p, _p, _p, _p]),
 }
 
 _lib = None

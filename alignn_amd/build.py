@@ -1,35 +1,63 @@
-"""Build libalignn_hip.so (gfx950) in-tree with hipcc.  ``python -m alignn_amd.build``."""
+"""Build libalignn_hip.so (gfx950) in-tree with hipcc.  ``python -m alignn_amd.build``.
+
+Every source is compiled to its own object (in parallel, only when it or a header changed) and the objects are linked
+into ONE shared library - the same command line per file as a single hipcc invocation, but an edit of one kernel file
+rebuilds in seconds."""
 
 from __future__ import annotations
 
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libalignn_hip.so")
-SOURCES = ["norm.hip", "conv.hip", "gemm_f32.hip", "gemm_x6.hip", "embed.hip", "dual.hip"]
+SOURCES = ["norm.hip", "conv.hip", "gemm_f32.hip", "gemm_x6.hip", "embed.hip", "dual.hip", "knn.hip", "composite.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
 
-def _stale() -> bool:
-    if not os.path.exists(LIB):
+def _headers():
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [
+        os.path.join(os.path.dirname(HERE), "include", "alignn_hip.h")]
+
+
+def _stale(target, deps) -> bool:
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(os.path.dirname(HERE), "include", "alignn_hip.h")]
+    t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile every HIP source for gfx950 into one shared library; returns its path."""
-    if not force and not _stale():
-        return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    hdrs = _headers()
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    if not force and not _stale(LIB, [os.path.join(CSRC, s) for s in srcs] + hdrs):
+        return LIB  # (e.g. on the GPU box: the prebuilt library travelled with the snapshot, the objects did not)
+    os.makedirs(OBJ, exist_ok=True)
+    objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in srcs]
+
+    def compile_one(pair):
+        src, obj = pair
+        if force or _stale(obj, [os.path.join(CSRC, src)] + hdrs):
+            cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+            return True
+        return False
+
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as pool:
+        rebuilt = list(pool.map(compile_one, zip(srcs, objs)))
+    if force or any(rebuilt) or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
     return LIB
 
 

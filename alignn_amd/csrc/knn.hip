@@ -1,0 +1,309 @@
+// Periodic k-nearest-neighbour bond lists on the device, one wavefront per site.
+//
+// Reference: alignn/graphs.py:155-264 (nearest_neighbor_edges + build_undirected_edgedata + canonize_edge, :128-153) on
+// jarvis' get_all_neighbors - rebuilt at EVERY molecular-dynamics step by the ASE calculators
+// (alignn/ff/calculators.py:280-291).  Semantics restated (and pinned bit-exactly to the reference's own functions over
+// its 70 example structures, tests/test_graph_builder_golden.py):
+//   * candidates of site i: all (j, image I) with |I_k| <= reach_k = ceil(cutoff / plane spacing_k) and
+//     1e-8 < dist <= cutoff;
+//   * some site of the crystal has fewer than k candidates -> the WHOLE crystal is redone with a larger cutoff
+//     (longest lattice vector if the cutoff was below it, else twice the cutoff; :170-188) - a larger box can add
+//     near neighbours the smaller box did not scan, so the level is a property of the crystal, not of the site;
+//   * per site keep everything out to the distance of its k-th nearest candidate, ties included (:206-216);
+//   * undirected multigraph keyed (smaller id, larger id, image seen from the smaller id): the union of what either end
+//     kept; both directions of a bond are emitted as a consecutive pair, r = Cartesian displacement src -> dst (:230-264).
+//
+// Index work: the bar is bit-exact.  Tie decisions compare float64 distances, so every distance is evaluated as the SAME
+// fixed sequence of IEEE operations as the numpy / torch restatements (alignn_amd/synthetic.py, neighbors.py):
+// shift = (i0*a + i1*b) + i2*c ; d = (cart_j + shift) - cart_i ; dist = sqrt((dx*dx + dy*dy) + dz*dz), no fused
+// multiply-add (contraction is switched off for this file's arithmetic).
+//
+// Shape of the work: a crystal of n atoms with an image box of I cells has n*I candidates per site (60 atoms, 27 images:
+// 1 620) - the "cell list" of a cell that is about as large as the cutoff IS the image loop.  One wave per site scans
+// its candidates 64 at a time; the k-th distance comes from at most k rounds of "smallest distance above the last one +
+// its multiplicity" (exact, no sort, no memory); the edge list is compacted in candidate order by ballot / popcount, so a
+// site's bonds leave sorted by (neighbour, image) - the order torch.unique gives the torch builder.  No atomics on the
+// output, no host synchronisation inside (the host reads ONE number - the total bond count - to size the output).
+#include "common.h"
+#include "../../include/alignn_hip.h"
+
+namespace {
+
+constexpr int kSitesPerBlock = 4;
+constexpr int kThreads = kSitesPerBlock * ALIGNN_WAVE;
+
+struct Cell {
+    double lat[9];
+    int r0, r1, r2;      // image box half-widths
+    int n1, n2, nimg;    // 2*r1+1, 2*r2+1, images in the box
+    double cutoff;
+};
+
+__device__ __forceinline__ Cell load_cell(const double* __restrict__ lat, const double* __restrict__ cut,
+                                          const int32_t* __restrict__ reach, int b, int L, int level) {
+    Cell c;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) c.lat[i] = lat[(size_t)b * 9 + i];
+    const int32_t* r = reach + ((size_t)b * L + level) * 3;
+    c.r0 = r[0], c.r1 = r[1], c.r2 = r[2];
+    c.n1 = 2 * c.r1 + 1;
+    c.n2 = 2 * c.r2 + 1;
+    c.nimg = (2 * c.r0 + 1) * c.n1 * c.n2;
+    c.cutoff = cut[(size_t)b * L + level];
+    return c;
+}
+
+// distance of (cart_j + shift(image)) from cart_i, in the reference's operation order
+__device__ __forceinline__ double image_distance(const Cell& c, const double ci[3], const double cj[3], int i0, int i1,
+                                                 int i2) {
+#pragma clang fp contract(off)
+    double d[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double s = ((double)i0 * c.lat[k] + (double)i1 * c.lat[3 + k]) + (double)i2 * c.lat[6 + k];
+        d[k] = (cj[k] + s) - ci[k];
+    }
+    return __dsqrt_rn((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+}
+
+// candidate index -> (j, image): candidates are ordered by (j, i0, i1, i2), images ascending from -r
+__device__ __forceinline__ void split_candidate(const Cell& c, int cand, int& j, int& i0, int& i1, int& i2) {
+    j = cand / c.nimg;
+    int im = cand - j * c.nimg;
+    const int q = c.n1 * c.n2;
+    i0 = im / q;
+    im -= i0 * q;
+    i1 = im / c.n2;
+    i2 = im - i1 * c.n2;
+    i0 -= c.r0;
+    i1 -= c.r1;
+    i2 -= c.r2;
+}
+
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_min_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// number of candidates of site i (global id) at the given level
+__device__ __forceinline__ int count_candidates(const Cell& c, const double* __restrict__ cart, int base, int n, int i,
+                                                int lane) {
+    const double ci[3] = {cart[3 * (size_t)i], cart[3 * (size_t)i + 1], cart[3 * (size_t)i + 2]};
+    const int total = n * c.nimg;
+    int cnt = 0;
+    for (int cand = lane; cand < total; cand += ALIGNN_WAVE) {
+        int j, i0, i1, i2;
+        split_candidate(c, cand, j, i0, i1, i2);
+        const double cj[3] = {cart[3 * (size_t)(base + j)], cart[3 * (size_t)(base + j) + 1], cart[3 * (size_t)(base + j) + 2]};
+        const double d = image_distance(c, ci, cj, i0, i1, i2);
+        cnt += (d <= c.cutoff && d > 1e-8) ? 1 : 0;
+    }
+    return wave_sum_i(cnt);
+}
+
+// ---- pass 1: the crystal's level = the first cutoff of its sequence at which EVERY site has >= k candidates
+__global__ __launch_bounds__(kThreads) void knn_level_kernel(const double* __restrict__ lat, const double* __restrict__ cart,
+                                                             const int32_t* __restrict__ graph_ptr,
+                                                             const int32_t* __restrict__ site_graph,
+                                                             const double* __restrict__ cut,
+                                                             const int32_t* __restrict__ reach, int L, int k, int N,
+                                                             int32_t* __restrict__ crystal_level) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * kSitesPerBlock + (threadIdx.x >> 6);
+    if (i >= N) return;
+    const int b = site_graph[i], base = graph_ptr[b], n = graph_ptr[b + 1] - base;
+    int level = 0;
+    for (; level < L; ++level) {
+        const Cell c = load_cell(lat, cut, reach, b, L, level);
+        if (count_candidates(c, cart, base, n, i, lane) >= k) break;
+    }
+    // (level == L: not even the widest cutoff reaches k candidates - reported to the host through the level array)
+    if (lane == 0 && level > 0) atomicMax(crystal_level + b, level);  // integer max: order independent
+}
+
+// ---- pass 2: distance of the k-th nearest candidate of every site, at the crystal's level
+__global__ __launch_bounds__(kThreads) void knn_kth_kernel(const double* __restrict__ lat, const double* __restrict__ cart,
+                                                           const int32_t* __restrict__ graph_ptr,
+                                                           const int32_t* __restrict__ site_graph,
+                                                           const double* __restrict__ cut, const int32_t* __restrict__ reach,
+                                                           int L, int k, int N, const int32_t* __restrict__ crystal_level,
+                                                           double* __restrict__ kth) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * kSitesPerBlock + (threadIdx.x >> 6);
+    if (i >= N) return;
+    const int b = site_graph[i], base = graph_ptr[b], n = graph_ptr[b + 1] - base;
+    const int level = crystal_level[b];
+    if (level >= L) {
+        if (lane == 0) kth[i] = -1.0;
+        return;
+    }
+    const Cell c = load_cell(lat, cut, reach, b, L, level);
+    const double ci[3] = {cart[3 * (size_t)i], cart[3 * (size_t)i + 1], cart[3 * (size_t)i + 2]};
+    const int total = n * c.nimg;
+    // ascending over the DISTINCT distances: `last` = the largest distance accounted for, `seen` = candidates <= last
+    double last = 1e-8;  // candidates must exceed 1e-8 anyway
+    int seen = 0;
+    const double inf = __longlong_as_double(0x7ff0000000000000LL);
+    while (seen < k) {
+        double mn = inf;
+        for (int cand = lane; cand < total; cand += ALIGNN_WAVE) {
+            int j, i0, i1, i2;
+            split_candidate(c, cand, j, i0, i1, i2);
+            const double cj[3] = {cart[3 * (size_t)(base + j)], cart[3 * (size_t)(base + j) + 1], cart[3 * (size_t)(base + j) + 2]};
+            const double d = image_distance(c, ci, cj, i0, i1, i2);
+            if (d > last && d <= c.cutoff) mn = fmin(mn, d);
+        }
+        mn = wave_min_d(mn);
+        if (!(mn < inf)) break;  // (cannot happen: the level guarantees k candidates)
+        int mult = 0;
+        for (int cand = lane; cand < total; cand += ALIGNN_WAVE) {
+            int j, i0, i1, i2;
+            split_candidate(c, cand, j, i0, i1, i2);
+            const double cj[3] = {cart[3 * (size_t)(base + j)], cart[3 * (size_t)(base + j) + 1], cart[3 * (size_t)(base + j) + 2]};
+            mult += image_distance(c, ci, cj, i0, i1, i2) == mn ? 1 : 0;
+        }
+        seen += wave_sum_i(mult);
+        last = mn;
+    }
+    if (lane == 0) kth[i] = last;
+}
+
+// Is the canonical bond (a, b, image of b seen from a), a <= b, in the graph?  Kept by a: a's own distance to (b, +im)
+// within a's shell; kept by b: b's distance to (a, -im) - evaluated the way b's wave evaluates it - within b's shell.
+__device__ __forceinline__ bool bond_exists(const Cell& c, const double ca[3], const double cb[3], bool same, int i0, int i1,
+                                            int i2, double kth_a, double kth_b) {
+    const double da = image_distance(c, ca, cb, i0, i1, i2);
+    if (da > 1e-8 && da <= c.cutoff && da <= kth_a) return true;
+    if (same) return false;  // a == b: (a, a, im) and (a, a, -im) are separate keys, each kept on its own
+    const double db = image_distance(c, cb, ca, -i0, -i1, -i2);
+    return db > 1e-8 && db <= c.cutoff && db <= kth_b;
+}
+
+// ---- pass 3 (COUNT) / pass 4 (EMIT): canonical bonds owned by site a = those to sites b >= a
+template <bool EMIT>
+__global__ __launch_bounds__(kThreads) void knn_bonds_kernel(const double* __restrict__ lat, const double* __restrict__ cart,
+                                                             const int32_t* __restrict__ graph_ptr,
+                                                             const int32_t* __restrict__ site_graph,
+                                                             const double* __restrict__ cut, const int32_t* __restrict__ reach,
+                                                             int L, int N, const int32_t* __restrict__ crystal_level,
+                                                             const double* __restrict__ kth, int64_t* __restrict__ count,
+                                                             const int64_t* __restrict__ offset, int64_t* __restrict__ U,
+                                                             int64_t* __restrict__ V, float* __restrict__ R,
+                                                             int32_t* __restrict__ IMG) {
+    const int lane = threadIdx.x & 63;
+    const int a = blockIdx.x * kSitesPerBlock + (threadIdx.x >> 6);
+    if (a >= N) return;
+    const int b_ = site_graph[a], base = graph_ptr[b_], n = graph_ptr[b_ + 1] - base;
+    const int level = crystal_level[b_];
+    if (level >= L) {
+        if (!EMIT && lane == 0) count[a] = 0;
+        return;
+    }
+    const Cell c = load_cell(lat, cut, reach, b_, L, level);
+    const double ca[3] = {cart[3 * (size_t)a], cart[3 * (size_t)a + 1], cart[3 * (size_t)a + 2]};
+    const double kth_a = kth[a];
+    const int la = a - base;
+    const int total = (n - la) * c.nimg;  // candidates (b, im) with local id of b >= la, in (b, image) order
+    int64_t pos = EMIT ? offset[a] : 0;  // bonds (not directed edges) before this site's
+    int cnt = 0;
+    for (int c0 = 0; c0 < total; c0 += ALIGNN_WAVE) {
+        const int cand = c0 + lane;
+        bool keep = false;
+        int j = 0, i0 = 0, i1 = 0, i2 = 0;
+        if (cand < total) {
+            split_candidate(c, cand, j, i0, i1, i2);
+            j += la;
+            const size_t gb = (size_t)(base + j);
+            const double cb[3] = {cart[3 * gb], cart[3 * gb + 1], cart[3 * gb + 2]};
+            keep = bond_exists(c, ca, cb, j == la, i0, i1, i2, kth_a, kth[gb]);
+        }
+        const unsigned long long mask = __ballot(keep);
+        if (EMIT && keep) {
+            const int64_t e = pos + __popcll(mask & ((1ull << lane) - 1ull));
+            const size_t gb = (size_t)(base + j);
+            // r = cart(b) + shift(im) - cart(a) as one float64 expression of the FRACTIONAL difference, like
+            // build_undirected_edgedata (:245-250): d = lattice.cart_coords(frac_b + im - frac_a); here from the
+            // Cartesian positions (equal to rounding, the bar the golden test sets for the float32 bond vectors)
+            double d[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double s = ((double)i0 * c.lat[k] + (double)i1 * c.lat[3 + k]) + (double)i2 * c.lat[6 + k];
+                d[k] = (cart[3 * gb + k] + s) - ca[k];
+            }
+            U[2 * e] = a, V[2 * e] = (int64_t)gb;
+            U[2 * e + 1] = (int64_t)gb, V[2 * e + 1] = a;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                R[3 * (2 * e) + k] = (float)d[k];
+                R[3 * (2 * e + 1) + k] = (float)(-d[k]);
+            }
+            if (IMG) {
+                IMG[3 * (2 * e)] = i0, IMG[3 * (2 * e) + 1] = i1, IMG[3 * (2 * e) + 2] = i2;
+                IMG[3 * (2 * e + 1)] = i0, IMG[3 * (2 * e + 1) + 1] = i1, IMG[3 * (2 * e + 1) + 2] = i2;  // (forward image for both, like the reference)
+            }
+        }
+        const int got = __popcll(mask);
+        pos += got;
+        cnt += got;
+    }
+    if (!EMIT && lane == 0) count[a] = cnt;
+}
+
+}  // namespace
+
+extern "C" {
+
+int alignn_knn_levels(const double* lat, const double* cart, const int32_t* graph_ptr, const int32_t* site_graph,
+                      const double* cut, const int32_t* reach, int levels, int k, int64_t n_sites, int32_t* crystal_level,
+                      alignn_stream_t stream) {
+    if (levels <= 0 || k <= 0 || n_sites < 0 || n_sites > INT32_MAX) return (int)hipErrorInvalidValue;
+    if (n_sites == 0) return 0;
+    hipLaunchKernelGGL(knn_level_kernel, dim3(alignn_ceil_div(n_sites, kSitesPerBlock)), dim3(kThreads), 0, (hipStream_t)stream,
+                       lat, cart, graph_ptr, site_graph, cut, reach, levels, k, (int)n_sites, crystal_level);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_knn_kth(const double* lat, const double* cart, const int32_t* graph_ptr, const int32_t* site_graph,
+                   const double* cut, const int32_t* reach, int levels, int k, int64_t n_sites, const int32_t* crystal_level,
+                   double* kth, alignn_stream_t stream) {
+    if (levels <= 0 || k <= 0 || n_sites < 0 || n_sites > INT32_MAX) return (int)hipErrorInvalidValue;
+    if (n_sites == 0) return 0;
+    hipLaunchKernelGGL(knn_kth_kernel, dim3(alignn_ceil_div(n_sites, kSitesPerBlock)), dim3(kThreads), 0, (hipStream_t)stream, lat,
+                       cart, graph_ptr, site_graph, cut, reach, levels, k, (int)n_sites, crystal_level, kth);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_knn_count(const double* lat, const double* cart, const int32_t* graph_ptr, const int32_t* site_graph,
+                     const double* cut, const int32_t* reach, int levels, int64_t n_sites, const int32_t* crystal_level,
+                     const double* kth, int64_t* count, alignn_stream_t stream) {
+    if (levels <= 0 || n_sites < 0 || n_sites > INT32_MAX) return (int)hipErrorInvalidValue;
+    if (n_sites == 0) return 0;
+    hipLaunchKernelGGL(knn_bonds_kernel<false>, dim3(alignn_ceil_div(n_sites, kSitesPerBlock)), dim3(kThreads), 0,
+                       (hipStream_t)stream, lat, cart, graph_ptr, site_graph, cut, reach, levels, (int)n_sites, crystal_level, kth,
+                       count, nullptr, nullptr, nullptr, nullptr, nullptr);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_knn_emit(const double* lat, const double* cart, const int32_t* graph_ptr, const int32_t* site_graph,
+                    const double* cut, const int32_t* reach, int levels, int64_t n_sites, const int32_t* crystal_level,
+                    const double* kth, const int64_t* offset, int64_t* u, int64_t* v, float* r, int32_t* image,
+                    alignn_stream_t stream) {
+    if (levels <= 0 || n_sites < 0 || n_sites > INT32_MAX || !u || !v || !r) return (int)hipErrorInvalidValue;
+    if (n_sites == 0) return 0;
+    hipLaunchKernelGGL(knn_bonds_kernel<true>, dim3(alignn_ceil_div(n_sites, kSitesPerBlock)), dim3(kThreads), 0,
+                       (hipStream_t)stream, lat, cart, graph_ptr, site_graph, cut, reach, levels, (int)n_sites, crystal_level, kth,
+                       nullptr, offset, u, v, r, image);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

@@ -14,8 +14,10 @@ construction as device tensor operations, so positions never leave the GPU:
 
 It is the same algorithm (and gives the same edge list, in the same order) as ``alignn_amd.synthetic.knn_multigraph``,
 the numpy restatement every test input of this repository comes from; distances are evaluated in float64 so that the
-shell / tie decisions are identical.  This is index-heavy O(n^2 x images) set-up work on a few hundred atoms - plain
-torch device ops (broadcast distance, sort, unique), not a hand-written kernel: it is not on the training hot path.
+shell / tie decisions are identical.  ``knn_multigraph`` / ``knn_multigraph_batch`` are plain torch tensor operations
+(broadcast distance, sort, unique: any device, the CPU twin and the checker); ``knn_multigraph_batch_hip`` is the same
+construction on the hand-written kernels of ``csrc/knn.hip`` (one wavefront per site, no padded [B,n,n,I] tensors, one
+host read per batch) and is what ``crystal_batch`` uses on the GPU.
 
 ``crystal_batch`` chains it with ``graph.build_csr`` / ``graph.line_graph_of``: positions -> canonical ``GraphBatch``
 without a host round trip of any per-bond array.
@@ -29,7 +31,7 @@ import torch
 
 from .graph import GraphBatch, _ptr_from_counts, build_csr, line_graph_of
 
-__all__ = ["knn_multigraph", "knn_multigraph_batch", "crystal_batch"]
+__all__ = ["knn_multigraph", "knn_multigraph_batch", "knn_multigraph_batch_hip", "crystal_batch"]
 
 
 def _all_neighbors(lat: torch.Tensor, frac: torch.Tensor, cutoff: float):
@@ -149,12 +151,80 @@ def knn_multigraph_batch(lattices: Sequence, fracs: Sequence, cutoff: float = 8.
     return u, v, r, ns
 
 
+KNN_LEVELS = 5  # cutoffs tried per crystal: the given one, then longest lattice vector / doubling (graphs.py:170-188)
+
+
+def knn_multigraph_batch_hip(lattices: Sequence, fracs: Sequence, cutoff: float = 8.0, max_neighbors: int = 12, device=None,
+                             return_images: bool = False):
+    """``knn_multigraph_batch`` on the hand-written kernels of csrc/knn.hip (one wavefront per site): the same bond
+    list in the same order - bit-identical index arrays, bond vectors equal to rounding - with no padded [B,n,n,I]
+    tensors and ONE host read per batch (the total bond count, to size the output).  CUDA(HIP) device only."""
+    from . import _lib
+    from ._lib import check, ptr, stream
+
+    lib = _lib.load()
+    dev = torch.device(device) if device is not None else torch.as_tensor(fracs[0]).device
+    if dev.type != "cuda":
+        raise TypeError("knn_multigraph_batch_hip runs on the GPU; use knn_multigraph_batch elsewhere")
+    B = len(fracs)
+    ns = [int(torch.as_tensor(f).shape[0]) for f in fracs]
+    N = sum(ns)
+    with _lib.device_guard(torch.empty(0, device=dev)):
+        lat = torch.stack([torch.as_tensor(x).to(dev, torch.float64) for x in lattices]).contiguous()  # [B,3,3]
+        frac = torch.cat([torch.as_tensor(f).to(dev, torch.float64) for f in fracs]).contiguous()  # [N,3]
+        n_t = torch.tensor(ns, device=dev, dtype=torch.int64)
+        gptr = _ptr_from_counts(n_t).to(torch.int32)
+        site_graph = torch.repeat_interleave(torch.arange(B, device=dev, dtype=torch.int32), n_t, output_size=N)
+        lg = lat[site_graph.long()]  # [N,3,3]
+        # the fixed-order float64 product of knn_multigraph / synthetic._all_neighbors (separate multiplies and adds)
+        cart = (frac[:, 0:1] * lg[:, 0, :] + frac[:, 1:2] * lg[:, 1, :] + frac[:, 2:3] * lg[:, 2, :]).contiguous()
+        longest = torch.linalg.norm(lat, dim=2).max(dim=1).values
+        spacing = 1.0 / torch.linalg.norm(torch.linalg.inv(lat), dim=1)  # [B,3]
+        cuts = [torch.full((B,), float(cutoff), dtype=torch.float64, device=dev)]
+        for _ in range(KNN_LEVELS - 1):
+            c = cuts[-1]
+            cuts.append(torch.where(c < longest, longest, 2.0 * c))
+        cut = torch.stack(cuts, 1).contiguous()  # [B,L]
+        reach = torch.ceil(cut[:, :, None] / spacing[:, None, :]).to(torch.int32).contiguous()  # [B,L,3]
+        level = torch.zeros(B, dtype=torch.int32, device=dev)
+        kth = torch.empty(N, dtype=torch.float64, device=dev)
+        count = torch.empty(N, dtype=torch.int64, device=dev)
+        st = stream()
+        L, k = KNN_LEVELS, int(max_neighbors)
+        check(lib.alignn_knn_levels(ptr(lat), ptr(cart), ptr(gptr), ptr(site_graph), ptr(cut), ptr(reach), L, k, N, ptr(level),
+                                    st), "knn_levels")
+        check(lib.alignn_knn_kth(ptr(lat), ptr(cart), ptr(gptr), ptr(site_graph), ptr(cut), ptr(reach), L, k, N, ptr(level),
+                                 ptr(kth), st), "knn_kth")
+        check(lib.alignn_knn_count(ptr(lat), ptr(cart), ptr(gptr), ptr(site_graph), ptr(cut), ptr(reach), L, N, ptr(level),
+                                   ptr(kth), ptr(count), st), "knn_count")
+        csum = torch.cumsum(count, 0)
+        offset = (csum - count).contiguous()
+        # the one host read: total bonds (sizes the output) and "did every crystal find its k neighbours"
+        tail = torch.stack([csum[-1], level.max().to(torch.int64)]).tolist() if N else [0, 0]
+        if tail[1] >= L:
+            raise RuntimeError(f"a site has fewer than {k} neighbours even at the widest of {L} cutoffs")
+        E = 2 * int(tail[0])
+        u = torch.empty(E, dtype=torch.int64, device=dev)
+        v = torch.empty(E, dtype=torch.int64, device=dev)
+        r = torch.empty(E, 3, dtype=torch.float32, device=dev)
+        img = torch.empty(E, 3, dtype=torch.int32, device=dev) if return_images else None
+        if E:
+            check(lib.alignn_knn_emit(ptr(lat), ptr(cart), ptr(gptr), ptr(site_graph), ptr(cut), ptr(reach), L, N, ptr(level),
+                                      ptr(kth), ptr(offset), ptr(u), ptr(v), ptr(r), ptr(img), st), "knn_emit")
+    if return_images:
+        return u, v, r, ns, img
+    return u, v, r, ns
+
+
 def crystal_batch(lattices: Sequence, fracs: Sequence, atom_features: Optional[Sequence] = None, device=None,
                   cutoff: float = 8.0, max_neighbors: int = 12, line_graph: bool = True) -> GraphBatch:
     """Positions -> canonical (g, L(g)) batch, all on the device: one crystal per (lattice, frac) pair; the bond cosines
     are left to the model (``lg_on_fly``) or to ``ops.bond_cosines(batch.r, batch.lg)``."""
     dev = torch.device(device) if device is not None else torch.as_tensor(fracs[0]).device
-    u, v, r, nn = knn_multigraph_batch(lattices, fracs, cutoff, max_neighbors, device=dev)
+    if dev.type == "cuda":  # one wave per site (csrc/knn.hip); the torch builder below is its CPU twin and its checker
+        u, v, r, nn = knn_multigraph_batch_hip(lattices, fracs, cutoff, max_neighbors, device=dev)
+    else:
+        u, v, r, nn = knn_multigraph_batch(lattices, fracs, cutoff, max_neighbors, device=dev)
     off = sum(nn)
     g = build_csr(u, v, off)
     lg = line_graph_of(g) if line_graph else None

@@ -716,16 +716,31 @@ def _take_pre_red(gy, xn):
         REGISTRY_STATS["pre_red_hit"] += 1
         return e[2]
     REGISTRY_STATS["pre_red_miss"] += 1
-    # a record for THIS pre-activation filed under another gradient tensor: the gradient was cloned / re-wrapped between
-    # the two autograd nodes (a hook, checkpointing, a bucket view) - the fused reduction was paid for and is now lost
+    # a record for THIS pre-activation whose gradient tensor is gone, or filed under another gradient tensor: the gradient
+    # was cloned / re-wrapped between the two autograd nodes (a hook, checkpointing, a bucket view) - the fused reduction
+    # was paid for and is lost (NOT reused: the hook may have changed the values)
+    lost = _PRE_RED_ORPHANS.pop(id(xn), None) is not None
     for k, rec in list(_PRE_RED.items()):
         if rec[1] is xn:
             _PRE_RED.pop(k, None)
-            REGISTRY_STATS["separate_bn_reduce"] += 1
-            _warn_once("pre_red", "alignn_amd: BatchNorm-backward sums taken in a projection's epilogue were not picked up by the "
-                                  "layer they belong to (its incoming gradient is a different tensor object than the one the "
-                                  "projection wrote: hook / clone / checkpoint in between?) - reducing again in a separate pass")
+            lost = True
+    if lost:
+        REGISTRY_STATS["separate_bn_reduce"] += 1
+        _warn_once("pre_red", "alignn_amd: BatchNorm-backward sums taken in a projection's epilogue were not picked up by the "
+                              "layer they belong to (its incoming gradient is a different tensor object than the one the "
+                              "projection wrote: hook / clone / checkpoint in between?) - reducing again in a separate pass")
     return None
+
+
+_PRE_RED_ORPHANS = {}  # id(xn) -> weakref(xn): records whose gradient tensor died before its producer's backward asked
+
+
+def _orphan_pre_red(k):
+    rec = _PRE_RED.pop(k, None)
+    if rec is not None:
+        xn = rec[1]
+        kx = id(xn)
+        _PRE_RED_ORPHANS[kx] = weakref.ref(xn, lambda _r, kx=kx: _PRE_RED_ORPHANS.pop(kx, None))
 
 
 def _dgrad_bnred(g, w, addend, g_amax, src):
@@ -741,7 +756,7 @@ def _dgrad_bnred(g, w, addend, g_amax, src):
     out, red = gemm_nt_f16x3_bnred(g, g_amax, split_f16x2(w, True), src[0], src[1], None, addend)
     BNRED_STATS["fused"] += 1
     k = id(out)
-    _PRE_RED[k] = (weakref.ref(out, lambda _r, k=k: _PRE_RED.pop(k, None)), src[0], red)
+    _PRE_RED[k] = (weakref.ref(out, lambda _r, k=k: _orphan_pre_red(k)), src[0], red)
     return out
 
 

@@ -398,6 +398,37 @@ int alignn_egc_dual_bwd_src(const float* GM, const float* GMt, const float* M, c
                             const float* q1t, const int32_t* out_ptr, const int32_t* out_slot, const int32_t* dst,
                             int64_t n, int H, float* GP, float* GPt, float* gp_amax2, alignn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Periodic k-nearest-neighbour bond lists on the device (csrc/knn.hip).
+ * Replace alignn/graphs.py:155-264 (nearest_neighbor_edges on jarvis' get_all_neighbors, canonize_edge :128-153,
+ * build_undirected_edgedata :230-264), which alignn/ff/calculators.py:280-291 re-runs at every MD step.
+ * One wavefront per site; float64 distances evaluated in the reference's operation order (bit-exact tie decisions);
+ * no atomics on the output, no host synchronisation.  Inputs shared by the four passes:
+ *   lat[B][9] float64 (rows a, b, c), cart[N][3] float64 Cartesian positions (frac . lat, the caller's fixed-order
+ *   product), graph_ptr[B+1] site offsets, site_graph[N] crystal of each site, cut[B][levels] the crystal's cutoff
+ *   sequence (cutoff, then "longest lattice vector if below it, else twice", graphs.py:170-188), reach[B][levels][3]
+ *   image-box half-widths ceil(cut / plane spacing).
+ *   knn_levels: crystal_level[B] (zeroed by the caller) = first level at which EVERY site of the crystal has >= k
+ *               candidates (== levels: not reachable - the caller raises)
+ *   knn_kth:    kth[N] = distance of the k-th nearest candidate (ties share it)
+ *   knn_count:  count[N] = canonical bonds (a, b >= a, image) owned by site a: kept by a OR by b
+ *   knn_emit:   offset[N] = exclusive prefix sum of count; writes both directions of bond e at rows 2e, 2e+1 of
+ *               u, v (int64), r[.][3] float32 = src -> dst displacement, image[.][3] int32 (optional; forward image for
+ *               both directions, like the reference's `images`); a site's bonds leave sorted by (b, image). */
+int alignn_knn_levels(const double* lat, const double* cart, const int32_t* graph_ptr, const int32_t* site_graph,
+                      const double* cut, const int32_t* reach, int levels, int k, int64_t n_sites, int32_t* crystal_level,
+                      alignn_stream_t stream);
+int alignn_knn_kth(const double* lat, const double* cart, const int32_t* graph_ptr, const int32_t* site_graph,
+                   const double* cut, const int32_t* reach, int levels, int k, int64_t n_sites, const int32_t* crystal_level,
+                   double* kth, alignn_stream_t stream);
+int alignn_knn_count(const double* lat, const double* cart, const int32_t* graph_ptr, const int32_t* site_graph,
+                     const double* cut, const int32_t* reach, int levels, int64_t n_sites, const int32_t* crystal_level,
+                     const double* kth, int64_t* count, alignn_stream_t stream);
+int alignn_knn_emit(const double* lat, const double* cart, const int32_t* graph_ptr, const int32_t* site_graph,
+                    const double* cut, const int32_t* reach, int levels, int64_t n_sites, const int32_t* crystal_level,
+                    const double* kth, const int64_t* offset, int64_t* u, int64_t* v, float* r, int32_t* image,
+                    alignn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

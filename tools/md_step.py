@@ -21,6 +21,9 @@ def timeit(fn, k=10):
     for _ in range(k): out = fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / k, out
 
+t_knn_hip, _ = timeit(lambda: neighbors.knn_multigraph_batch_hip([lat_d], [frac_d]))
+t_knn_torch, _ = timeit(lambda: neighbors.knn_multigraph_batch([lat_d], [frac_d]))
+print(f"neighbour list alone: csrc/knn.hip {t_knn_hip*1e3:.2f} ms, torch tensor ops {t_knn_torch*1e3:.2f} ms")
 t_build, batch = timeit(lambda: neighbors.crystal_batch([lat_d], [frac_d], atom_features=[feats]))
 t_model, res = timeit(lambda: model(batch))
 t_step, _ = timeit(lambda: model(neighbors.crystal_batch([lat_d], [frac_d + 1e-4 * torch.randn_like(frac_d)], atom_features=[feats])))
