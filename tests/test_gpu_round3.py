@@ -225,8 +225,9 @@ def test_a_cloned_gradient_is_counted_and_warned_about():
     if ops.BNRED_STATS["fused"]:  # (the product took the f16x3 kernel with the fused sums: then the clone must be noticed)
         assert ops.REGISTRY_STATS["separate_bn_reduce"] == 1
         assert any("BatchNorm-backward sums" in str(m.message) for m in w)
+    scale = max(float(p.abs().max()) for p in ref)  # (the Linear biases in front of BatchNorm hold only rounding noise)
     for p, q in zip(ref, got):
-        assert float((p - q).abs().max()) <= 1e-5 * float(p.abs().max() + 1e-30)
+        assert float((p - q).abs().max()) <= 1e-5 * scale
 
 
 # ---------------------------------------------------------------------------------------------
