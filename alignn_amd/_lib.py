@@ -86,11 +86,26 @@ SIGNATURES = {
     "alignn_segment_mean_bwd": (_i32, [_p, _p, _p, _i32, _i32, _p]),
     "alignn_gather_rows": (_i32, [_p, _p, _p, _i64, _i32, _p]),
     "alignn_segment_sum": (_i32, [_p, _i64, _p, _p, _p, _p, _i64, _i64, _i32, _p]),
+    "alignn_egc_conv_fwd_scratch": (_sz, [_i64, _i64, _i32, _i32, _i32]),
+    "alignn_egc_conv_fwd": (_i32, [_p, _p]),
+    "alignn_egc_conv_bwd_scratch": (_sz, [_i64, _i64, _i32, _i32, _i32, _i32]),
+    "alignn_egc_conv_bwd": (_i32, [_p, _p]),
+    "alignn_egc_conv_wgrad_scratch": (_sz, [_i64, _i64, _i32, _i32]),
+    "alignn_egc_conv_wgrad": (_i32, [_p, _p]),
+    "alignn_egc_args_sizeof": (_sz, [_i32]),
     "alignn_knn_levels": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i64, _p, _p]),
     "alignn_knn_kth": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i64, _p, _p, _p]),
     "alignn_knn_count": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i64, _p, _p, _p, _p]),
     "alignn_knn_emit": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i64, _p, _p, _p, _p, _p, _p, _p, _p]),
 }
+
+# argument blocks of the composite entry points (include/alignn_hip.h: alignn_egc_fwd_args / _bwd_args / _wgrad_args), packed
+# with the platform's C layout rules ("@": native sizes and alignment); load() checks the sizes against the library's
+import struct as _struct
+
+EGC_FWD_ARGS = _struct.Struct("@4P2q6i2f32PN")
+EGC_BWD_ARGS = _struct.Struct("@8P3q8i22Pq13PN")
+EGC_WGRAD_ARGS = _struct.Struct("@2q4i14PN")
 
 _lib = None
 
@@ -109,6 +124,10 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
+        for which, st in enumerate((EGC_FWD_ARGS, EGC_BWD_ARGS, EGC_WGRAD_ARGS)):
+            if lib.alignn_egc_args_sizeof(which) != st.size:
+                raise RuntimeError(f"argument block {which} of the composite entry points: library says "
+                                   f"{lib.alignn_egc_args_sizeof(which)} bytes, the binding packs {st.size}")
         _lib = lib
     return _lib
 

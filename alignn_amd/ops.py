@@ -1114,6 +1114,49 @@ class MLPLayerFn(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------
 # EdgeGatedGraphConv   (alignn/models/alignn.py:78-129)
 # ---------------------------------------------------------------------------------------------
+# Composite entry points (csrc/composite.hip): the launches of a convolution's forward / backward issued by ONE C call each
+# instead of ~11 / ~20 (same kernels, same arguments, same order: bit-identical - tests flip this flag).  Used for the
+# BatchNorm flavour in training mode on one stream; lanes (hipGraph capture: host cost is irrelevant there), LayerNorm,
+# eval mode and the rare kernel choices the composites do not carry take the per-kernel path below.
+COMPOSITE = _os.environ.get("ALIGNN_AMD_COMPOSITE", "1") != "0"
+COMPOSITE_STATS = {"fwd": 0, "bwd": 0, "wgrad": 0}
+
+
+def _x6_shape_ok(a, N, K):
+    """``project``'s test for the split-product kernels (shape part)."""
+    M = a.shape[0]
+    return (((M + 63) // 64) * ((N + 255) // 256) >= X6_MIN_TILES and a.stride(0) % 4 == 0
+            and bool(_lib.load().alignn_gemm_nt_x6_supported(M, N, K)))
+
+
+def _dgrad_kind(g, w, g_amax):
+    """Which kernel ``_dgrad(g, w)`` (= ``project(g, w, transpose_w=True)``) runs: 1 f16x3 on the W^T image, 2 split-
+    reduction NN, 3 plain NN, 4 NT on a transposed copy; None: one the composites do not carry (bf16x6)."""
+    lib = _lib.load()
+    M, N, K = g.shape[0], w.shape[1], w.shape[0]
+    if _x6_shape_ok(g, N, K):
+        return 1 if (F16X3 and g_amax is not None) else None
+    if NN_SPLIT and lib.alignn_gemm_nn_split_workspace(M, w.shape[0], w.shape[1]):
+        return 2 if (g.stride(0) % 4 == 0 and w.stride(0) % 4 == 0) else 3
+    if w.shape[0] % 4 == 0 and w.shape[1] >= 16:
+        return 4
+    return 3
+
+
+def _P(t):
+    return 0 if t is None else t.data_ptr()
+
+
+class _Shape:
+    """What the kernel-choice helpers need of a not-yet-allocated contiguous [rows, cols] fp32 matrix."""
+
+    def __init__(self, r, c):
+        self.shape = (r, c)
+
+    def stride(self, d):
+        return self.shape[1] if d == 0 else 1
+
+
 class EdgeGatedConvFn(torch.autograd.Function):
     """Whole convolution as one autograd node with a hand-written backward.
 
@@ -1146,6 +1189,12 @@ class EdgeGatedConvFn(torch.autograd.Function):
         ctx.y_src = _norm_src_of(y)  # y = r + silu(BatchNorm(.)) of the previous layer: see _dgrad_bnred
         ctx.x_amax, ctx.y_amax = get_amax(x), get_amax(y)  # tracked by the kernels that produced x and y
         bn_train = training and norm == "batch"
+        if COMPOSITE and bn_train and lane is None and KERNEL_TIMER is None:
+            done = EdgeGatedConvFn._forward_composite(ctx, graph, x, y, wcat, bcat, w_eg, b_eg, n_gamma, n_beta, n_rm, n_rv,
+                                                      e_gamma, e_beta, e_rm, e_rv, residual, need_y)
+            if done is not None:
+                ctx.leaves = (w_sg, w_dg, w_du, w_su, b_sg, b_dg, b_du, b_su, w_eg, b_eg)
+                return done
         slabs = lib.alignn_egc_slabs(n)
         _main_reads(x, None if lane is not None else y)
         # ---- node side, part 1 (caller's stream): P = [A | Bd | Bh | Ux]
@@ -1258,8 +1307,187 @@ class EdgeGatedConvFn(torch.autograd.Function):
         return x_out, y_out
 
     @staticmethod
+    def _forward_composite(ctx, graph, x, y, wcat, bcat, w_eg, b_eg, n_gamma, n_beta, n_rm, n_rv, e_gamma, e_beta, e_rm, e_rv,
+                           residual, need_y):
+        """The BatchNorm / training forward through alignn_egc_conv_fwd; None if a kernel choice is not covered."""
+        lib = _lib.load()
+        n, Kin = x.shape
+        m = y.shape[0]
+        H = w_eg.shape[0]
+        if wcat.shape != (4 * H, Kin) or y.shape[1] != Kin or (residual and Kin != H):
+            return None
+        require_f32(x, y, wcat, bcat, w_eg, b_eg, n_gamma, n_beta, e_gamma, e_beta)
+        x_amax, y_amax = ctx.x_amax, ctx.y_amax
+        # node projection: the kernel ``project(x, wcat, bcat)`` would take
+        wcat_img = None
+        if _x6_shape_ok(x, 4 * H, Kin):
+            if not (F16X3 and x_amax is not None):
+                return None
+            node_kind = 1
+        else:
+            node_kind = 0
+        # edge projection
+        weg_img = None
+        if GATHER_FUSED and STATS_FUSED and _f16x3_applies(y, y_amax, H, Kin):
+            edge_kind = 1
+        elif _x6_shape_ok(y, H, Kin):
+            return None  # a split-product projection without the fused epilogues: per-kernel path
+        else:
+            edge_kind = 0
+        _main_reads(x, y)
+        if node_kind == 1:
+            wcat_img = split_f16x2(wcat)
+        if edge_kind == 1:
+            weg_img = split_f16x2(w_eg)
+        P = _empty(n, 4 * H, like=x)
+        M = _empty(m, H, like=x)
+        xpre, s0, hh = _empty(n, H, like=x), _empty(n, H, like=x), _empty(n, H, like=x)
+        stats = _empty(2, 4, H, like=x)
+        n_stat, e_stat = stats[0], stats[1]
+        x_out = _empty(n, H, like=x)
+        y_out = _empty(m, H, like=x) if need_y else None
+        xo_amax = new_amax(x) if _track(n) else None
+        yo_amax = new_amax(x) if (need_y and _track(m)) else None
+        nbytes = lib.alignn_egc_conv_fwd_scratch(n, m, H, Kin, edge_kind)
+        scratch = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+        args = _lib.EGC_FWD_ARGS.pack(
+            _P(graph.seg_ptr), _P(graph.seg_node), _P(graph.src), _P(graph.dst), n, m,
+            H, Kin, node_kind, edge_kind, int(residual), 0, BN_EPS, BN_MOMENTUM,
+            _P(x), _P(y), _P(x_amax), _P(y_amax),
+            _P(wcat), _P(bcat), _P(wcat_img.amax if wcat_img is not None else None), _P(wcat_img.buf if wcat_img is not None else None),
+            _P(w_eg), _P(b_eg), _P(weg_img.amax if weg_img is not None else None), _P(weg_img.buf if weg_img is not None else None),
+            _P(n_gamma), _P(n_beta), _P(e_gamma), _P(e_beta), _P(n_rm), _P(n_rv), _P(e_rm), _P(e_rv),
+            _P(P), _P(M), _P(xpre), _P(s0), _P(hh), _P(n_stat), _P(e_stat), _P(x_out), _P(y_out), _P(xo_amax), _P(yo_amax),
+            _P(scratch), nbytes)
+        check(lib.alignn_egc_conv_fwd(args, stream()), "egc_conv_fwd")
+        COMPOSITE_STATS["fwd"] += 1
+        if xo_amax is not None:
+            set_amax(x_out, xo_amax)
+        if yo_amax is not None:
+            set_amax(y_out, yo_amax)
+        _register_norm_src(y_out, M, e_stat)
+        ctx.graph = graph
+        ctx.training = True
+        ctx.residual = residual
+        ctx.norm = "batch"
+        ctx.param_grads = _PARAM_GRADS["on"]
+        ctx.save_for_backward(x, y, wcat, w_eg, P, M, xpre, s0, hh, n_stat, e_stat, n_gamma, e_gamma, n_beta, e_beta)
+        return x_out, y_out
+
+    @staticmethod
+    def _backward_composite(ctx, gx_out, gy_out):
+        """The BatchNorm / training backward through alignn_egc_conv_bwd (+ alignn_egc_conv_wgrad on the side stream);
+        None if a kernel choice is not covered (the per-kernel path then runs)."""
+        lib = _lib.load()
+        graph: CSRGraph = ctx.graph
+        x, y, wcat, w_eg, P, M, xpre, s0, hh, n_stat, e_stat, n_gamma, e_gamma, n_beta, e_beta = ctx.saved_tensors
+        n, Kin = x.shape
+        m = y.shape[0]
+        H = w_eg.shape[0]
+        if wcat.shape != (4 * H, Kin) or w_eg.shape[1] != Kin:
+            return None
+        # kernel choices of the two input-gradient products, decided on shapes and on which maxima will exist (the arena
+        # slots themselves are drawn only once the composite is certain to run)
+        has_gp, has_gm = (True if _track(n) else None), (True if _track(m) else None)
+        dx_kind = _dgrad_kind(_Shape(n, 4 * H), wcat, has_gp)
+        if dx_kind is None:
+            return None
+        y_src = ctx.y_src
+        bnred = (y_src is not None and BNRED_FUSED and F16X3 and has_gm is not None and _x6_shape_ok(_Shape(m, H), Kin, H)
+                 and tuple(y_src[0].shape) == (m, Kin) and y_src[0].stride(0) % 4 == 0)
+        if bnred:
+            dy_kind = 1
+        else:
+            dy_kind = _dgrad_kind(_Shape(m, H), w_eg, has_gm)
+            if dy_kind == 1:
+                dy_kind = 5
+            elif dy_kind == 2 or dy_kind is None:
+                return None
+        gp_amax = new_amax(x) if has_gp else None
+        gm_amax = new_amax(x) if has_gm else None
+        if gx_out is None:
+            gx_out = torch.zeros_like(x)
+        _main_reads(gx_out, gy_out)
+        gx_out = gx_out.contiguous()
+        if gy_out is not None:
+            gy_out = gy_out.contiguous()
+        lg_blocks = graph.grp_seg_ptr is not None and FUSED_LG_BACKWARD
+        dense = lg_blocks and DENSE_LG_BACKWARD and lib.alignn_egc_bwd_lg_dense_supported(graph.dense_max_src)
+        gate_mode = 2 if dense else (1 if lg_blocks else 0)
+        gslabs = (graph.grp_seg_ptr.numel() - 1) if lg_blocks else lib.alignn_egc_slabs(n)
+        e_red_in = _take_pre_red(gy_out, M) if gy_out is not None else None
+        wcat_t_img = split_f16x2(wcat, True) if dx_kind == 1 else None
+        weg_t_img = split_f16x2(w_eg, True) if dy_kind in (1, 5) else None
+        wcat_t = wcat.t().contiguous() if dx_kind == 4 else None
+        weg_t = w_eg.t().contiguous() if dy_kind == 4 else None
+        GP = _empty(n, 4 * H, like=x)
+        GM = _empty(m, H, like=x)
+        gs = _empty(2, n, H, like=x)
+        gb_part = _empty(gslabs, H, like=x)
+        n_red = _empty(2, H, like=x)
+        e_red = e_red_in if e_red_in is not None else (_empty(2, H, like=x) if gy_out is not None else None)
+        src_red = _empty(2, Kin, like=x) if dy_kind == 1 else None
+        g_x = _empty(n, Kin, like=x)
+        g_y = _empty(m, Kin, like=x)
+        nbytes = lib.alignn_egc_conv_bwd_scratch(n, m, H, Kin, dx_kind, dy_kind)
+        scratch = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+        args = _lib.EGC_BWD_ARGS.pack(
+            _P(graph.seg_ptr), _P(graph.seg_node), _P(graph.src), _P(graph.dst), _P(graph.out_ptr), _P(graph.out_slot),
+            _P(graph.grp_seg_ptr), _P(graph.grp_src_ptr), n, m, gslabs if lg_blocks else 0,
+            H, Kin, gate_mode, int(graph.dense_max_src) if dense else 0, dx_kind, dy_kind, int(ctx.residual), 0,
+            _P(gx_out), _P(gy_out),
+            _P(P), _P(M), _P(xpre), _P(s0), _P(hh), _P(n_stat), _P(e_stat), _P(n_gamma), _P(e_gamma),
+            _P(e_red_in),
+            _P(wcat), _P(wcat_t), _P(wcat_t_img.amax if wcat_t_img is not None else None),
+            _P(wcat_t_img.buf if wcat_t_img is not None else None),
+            _P(w_eg), _P(weg_t), _P(weg_t_img.amax if weg_t_img is not None else None),
+            _P(weg_t_img.buf if weg_t_img is not None else None),
+            _P(y_src[0] if dy_kind == 1 else None), _P(y_src[1] if dy_kind == 1 else None),
+            y_src[0].stride(0) if dy_kind == 1 else 0,
+            _P(GP), _P(GM), _P(gs[0]), _P(gs[1]), _P(n_red), _P(e_red if e_red_in is None else None), _P(gb_part), _P(g_x),
+            _P(g_y), _P(src_red), _P(gp_amax), _P(gm_amax),
+            _P(scratch), nbytes)
+        check(lib.alignn_egc_conv_bwd(args, stream()), "egc_conv_bwd")
+        COMPOSITE_STATS["bwd"] += 1
+        if dy_kind == 1:
+            BNRED_STATS["fused"] += 1
+            k = id(g_y)
+            _PRE_RED[k] = (weakref.ref(g_y, lambda _r, k=k: _orphan_pre_red(k)), y_src[0], src_red)
+        if not ctx.param_grads:
+            return (None, g_x, g_y) + (None,) * 24
+        x_amax, y_amax = ctx.x_amax, ctx.y_amax
+        tn_gm = (gm_amax, y_amax) if (F16X3 and gm_amax is not None and y_amax is not None) else (None, None)
+        tn_gp = (gp_amax, x_amax) if (F16X3 and gp_amax is not None and x_amax is not None) else (None, None)
+
+        def _wgrads():
+            g_weg, g_beg = _empty(H, Kin, like=x), _empty(H, like=x)
+            g_wcat, g_bcat = _empty(4 * H, Kin, like=x), _empty(4 * H, like=x)
+            wb = lib.alignn_egc_conv_wgrad_scratch(n, m, H, Kin)
+            ws = torch.empty(wb // 4, dtype=torch.float32, device=x.device)
+            wargs = _lib.EGC_WGRAD_ARGS.pack(n, m, H, Kin, gslabs, 0, _P(GM), _P(GP), _P(x), _P(y), _P(gb_part), _P(tn_gm[0]),
+                                             _P(tn_gp[0]), _P(tn_gp[1]), _P(tn_gm[1]), _P(g_weg), _P(g_beg), _P(g_wcat), _P(g_bcat),
+                                             _P(ws), wb)
+            check(lib.alignn_egc_conv_wgrad(wargs, stream()), "egc_conv_wgrad")
+            COMPOSITE_STATS["wgrad"] += 1
+            return g_weg, g_beg, g_wcat, g_bcat
+
+        g_weg, g_beg, g_wcat, g_bcat = on_side_stream(_wgrads, [GM, y, GP, x, gb_part, gm_amax, gp_amax, x_amax, y_amax],
+                                                      ctx.leaves)
+        dn_gamma, dn_beta = n_red[1], n_red[0]
+        de_gamma = e_red[1] if e_red is not None else None
+        de_beta = e_red[0] if e_red is not None else None
+        gw4 = tuple(g_wcat[i * H:(i + 1) * H] for i in range(4))
+        gb4 = tuple(g_bcat[i * H:(i + 1) * H] for i in range(4))
+        return (None, g_x, g_y, None, None) + gw4 + gb4 + (g_weg, g_beg, dn_gamma, dn_beta, None, None, de_gamma,
+                                                            de_beta, None, None, None, None, None, None)
+
+    @staticmethod
     def backward(ctx, gx_out, gy_out):
         lib = _lib.load()
+        if (COMPOSITE and ctx.norm == "batch" and ctx.training and not ctx.lane and KERNEL_TIMER is None):
+            done = EdgeGatedConvFn._backward_composite(ctx, gx_out, gy_out)
+            if done is not None:
+                return done
         graph: CSRGraph = ctx.graph
         x, y, wcat, w_eg, P, M, xpre, s0, hh, n_stat, e_stat, n_gamma, e_gamma, n_beta, e_beta = ctx.saved_tensors
         n, H = x.shape

@@ -429,6 +429,77 @@ int alignn_knn_emit(const double* lat, const double* cart, const int32_t* graph_
                     const double* kth, const int64_t* offset, int64_t* u, int64_t* v, float* r, int32_t* image,
                     alignn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Composite entry points (csrc/composite.hip): ONE call = one EdgeGatedGraphConv forward / backward, BatchNorm
+ * flavour in training mode (alignn/models/alignn.py:78-129 and torch.autograd's backward of it).  They issue exactly
+ * the launches the per-kernel entry points above would, in the same order with the same arguments (bit-identical
+ * results), so that an eagerly launched training step costs ~3 host calls per convolution instead of ~30.
+ * Every pointer is a device pointer owned by the caller; `scratch` is one block of alignn_egc_conv_*_scratch() bytes.
+ * Shapes: x [n,Kin], y [m,Kin], P [n,4H], M [m,H], everything else [n,H] / [m,H] / [4,H] / [2,H] as named.
+ *   node_kind  0: P by alignn_gemm_nt(wcat)            1: alignn_gemm_nt_f16x3(wcat_img, x_amax)
+ *   edge_kind  0: alignn_gemm_nt(w_eg) + alignn_egc_gate_fwd + alignn_bn_silu_fwd
+ *              1: alignn_gemm_nt_f16x3_gather(+statistics) + alignn_egc_gate_fwd_pre_norm
+ *   y_out == NULL: dead edge output (statistics / running buffers still updated)
+ *   gate_mode  0: alignn_egc_bwd_dst + _src   1: alignn_egc_bwd_lg_fused   2: alignn_egc_bwd_lg_dense
+ *   dx_kind / dy_kind (input gradients g_x = GP wcat, g_y = GM w_eg):
+ *              1: f16x3 on the W^T image (dy: + BatchNorm-backward sums of (src_xn, src_nstat) -> src_red)
+ *              2: alignn_gemm_nn_split (dx only)   3: alignn_gemm_nn   4: alignn_gemm_nt on a transposed copy (wcat_t / weg_t)
+ *              5: f16x3 on the W^T image, no sums (dy only)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct alignn_egc_fwd_args {
+    const int32_t *seg_ptr, *seg_node, *src, *dst;
+    int64_t n, m;
+    int32_t H, Kin, node_kind, edge_kind, residual, pad_;
+    float eps, momentum;
+    const float *x, *y, *x_amax, *y_amax;
+    const float *wcat, *bcat, *wcat_amax;
+    const void* wcat_img;
+    const float *w_eg, *b_eg, *weg_amax;
+    const void* weg_img;
+    const float *n_gamma, *n_beta, *e_gamma, *e_beta;
+    float *n_rm, *n_rv, *e_rm, *e_rv;
+    float *P, *M, *xpre, *s0, *hh, *n_stat, *e_stat, *x_out, *y_out, *x_out_amax, *y_out_amax;
+    float* scratch;
+    size_t scratch_bytes;
+} alignn_egc_fwd_args;
+size_t alignn_egc_conv_fwd_scratch(int64_t n, int64_t m, int H, int Kin, int edge_kind);
+int alignn_egc_conv_fwd(const alignn_egc_fwd_args* args, alignn_stream_t stream);
+
+typedef struct alignn_egc_bwd_args {
+    const int32_t *seg_ptr, *seg_node, *src, *dst, *out_ptr, *out_slot, *grp_seg_ptr, *grp_src_ptr;
+    int64_t n, m, n_groups;
+    int32_t H, Kin, gate_mode, dense_max_src, dx_kind, dy_kind, residual, pad_;
+    const float *gx_out, *gy_out;                                       /* incoming gradients (gy_out may be NULL) */
+    const float *P, *M, *xpre, *s0, *hh, *n_stat, *e_stat, *n_gamma, *e_gamma; /* saved by the forward */
+    const float* e_red_in;                                              /* pre-reduced sums of the edge norm, or NULL */
+    const float *wcat, *wcat_t, *wcat_amax;
+    const void* wcat_t_img;
+    const float *w_eg, *weg_t, *weg_amax;
+    const void* weg_t_img;
+    const float *src_xn, *src_nstat;                                    /* dy_kind 1: the norm y came out of */
+    int64_t src_ldxn;
+    float *GP, *GM, *gs1, *gs0, *n_red, *e_red, *gb_part, *g_x, *g_y, *src_red, *gp_amax, *gm_amax;
+    float* scratch;
+    size_t scratch_bytes;
+} alignn_egc_bwd_args;
+size_t alignn_egc_conv_bwd_scratch(int64_t n, int64_t m, int H, int Kin, int dx_kind, int dy_kind);
+int alignn_egc_conv_bwd(const alignn_egc_bwd_args* args, alignn_stream_t stream);
+
+/* the weight / bias gradients of the same convolution (the host code runs this one on its side stream):
+ * g_beg = column sums of GM (from gb_part), g_weg = GM^T y, g_wcat = GP^T x, g_bcat = column sums of GP */
+typedef struct alignn_egc_wgrad_args {
+    int64_t n, m;
+    int32_t H, Kin, gb_slabs, pad_;
+    const float *GM, *GP, *x, *y, *gb_part, *gm_amax, *gp_amax, *x_amax, *y_amax;
+    float *g_weg, *g_beg, *g_wcat, *g_bcat;
+    float* scratch;
+    size_t scratch_bytes;
+} alignn_egc_wgrad_args;
+size_t alignn_egc_conv_wgrad_scratch(int64_t n, int64_t m, int H, int Kin);
+int alignn_egc_conv_wgrad(const alignn_egc_wgrad_args* args, alignn_stream_t stream);
+/* sizeof the three argument structs (0: fwd, 1: bwd, 2: wgrad) - a binding checks its own packing against these */
+size_t alignn_egc_args_sizeof(int which);
+
 #ifdef __cplusplus
 }
 #endif

@@ -253,3 +253,63 @@ def test_float64_model_on_the_gpu_reproduces_the_float64_reference():
     g = O.full_size_sample(dict(model.named_parameters())["alignn_layers.0.edge_update.edge_gate.weight"].grad, 512)
     ref = z["grad64.alignn_layers.0.edge_update.edge_gate.weight"]
     assert np.abs(g[:-4] - ref[:-4]).max() < 1e-9 * np.abs(ref[:-4]).max()
+
+
+# ---------------------------------------------------------------------------------------------
+# composite entry points: one C call per convolution forward / backward - same launches, same bits
+# ---------------------------------------------------------------------------------------------
+def _train_state(mk_model, batch, target, composite, steps=2):
+    prev = ops.COMPOSITE
+    ops.COMPOSITE = composite
+    for k in ops.COMPOSITE_STATS:
+        ops.COMPOSITE_STATS[k] = 0
+    try:
+        model = mk_model()
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, fused=True)
+        for _ in range(steps):
+            opt.zero_grad(set_to_none=True)
+            pred = model(batch)
+            torch.nn.functional.l1_loss(pred, target).backward()
+            opt.step()
+        torch.cuda.synchronize()
+        out = {"pred": pred.detach().clone()}
+        out.update({"g." + k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+        out.update({"s." + k: v.clone() for k, v in model.state_dict().items()})
+        return out, dict(ops.COMPOSITE_STATS)
+    finally:
+        ops.COMPOSITE = prev
+
+
+@pytest.mark.parametrize("case", ["small_fp32_kernels", "default_16x60_mixed", "default_48x60_split_products", "no_residual_dims"])
+def test_composite_entry_points_are_bit_identical_to_the_per_kernel_path(case):
+    if case == "small_fp32_kernels":  # H = 64, 5 x 16 atoms: exact-fp32 projections, generic + line-graph reverse kernels
+        raw = make_batch(5, 16, seed0=78)
+
+        def mk():
+            torch.manual_seed(21)
+            return ALIGNN(ALIGNNConfig(name="alignn", alignn_layers=2, gcn_layers=1, hidden_features=64,
+                                       embedding_features=32)).to(DEV).train()
+    elif case == "no_residual_dims":  # hidden 96: not a multiple of 64 lanes x 4, odd tile counts
+        raw = make_batch(3, 14, seed0=5)
+
+        def mk():
+            torch.manual_seed(3)
+            return ALIGNN(ALIGNNConfig(name="alignn", alignn_layers=1, gcn_layers=2, hidden_features=96,
+                                       embedding_features=48)).to(DEV).train()
+    else:
+        raw = make_batch(16 if "16x60" in case else 48, 60, seed0=77)
+
+        def mk():
+            torch.manual_seed(0)
+            return ALIGNN(ALIGNNConfig(name="alignn")).to(DEV).train()
+    batch = GraphBatch.from_raw(raw, device=DEV)
+    target = torch.randn(raw.batch_size, generator=torch.Generator().manual_seed(2)).to(DEV)
+    a, stats = _train_state(mk, batch, target, True)
+    b, stats_off = _train_state(mk, batch, target, False)
+    print(case, "composite calls:", stats)
+    n_conv = 2 * (len(mk().alignn_layers) * 2 + len(mk().gcn_layers))  # convolutions x steps
+    assert stats["fwd"] == n_conv and stats["bwd"] == n_conv and stats["wgrad"] == n_conv, stats
+    assert stats_off == {"fwd": 0, "bwd": 0, "wgrad": 0}
+    assert a.keys() == b.keys()
+    for k in a:
+        assert torch.equal(a[k], b[k]), (case, k)
