@@ -37,6 +37,7 @@ SIGNATURES = {
     "alignn_split_f16x2_bytes": (_sz, [_i32, _i32]),
     "alignn_split_f16x2": (_i32, [_p, _i64, _i32, _i32, _i32, _p, _p, _p]),
     "alignn_split_f16x2_both": (_i32, [_p, _i64, _i32, _i32, _p, _p, _p, _p]),
+    "alignn_prepare_weights": (_i32, [_p, _i32, _p, _p]),
     "alignn_absmax_raise": (_i32, [_p, _i64, _i64, _i32, _p, _p]),
     "alignn_gemm_nt_f16x3": (_i32, [_p, _i64, _p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _i32, _i32, _p]),
     "alignn_gemm_nt_f16x3_gather": (_i32, [_p, _i64, _p, _p, _p, _p, _p, _i64, _i64, _i32, _i32, _p, _i64, _p, _p, _p, _p]),

@@ -291,6 +291,28 @@ class EdgeGatedGraphConv(nn.Module):
         return x, y
 
 
+def _prepare_split_weights(model: nn.Module):
+    """max|W| + slice images of every weight a split-product projection of this forward / backward may use (the fused node
+    projection and the edge gate of every convolution, the wide MLP layers) in one batched call - ``ops.WeightPrep``."""
+    if not model.training and not torch.is_grad_enabled():
+        return  # (inference: the per-weight path slices what it needs, nothing is reused by a backward)
+    prep = model.__dict__.get("_weight_prep")
+    if prep is None:
+        prep = model.__dict__["_weight_prep"] = ops.WeightPrep()
+    ws = []
+    for m in model.modules():
+        if isinstance(m, EdgeGatedGraphConv):
+            if m.edge_gate.weight.dtype != torch.float32:
+                return
+            ws.append(m._fused_node_projection()[0])
+            ws.append(m.edge_gate.weight)
+        elif isinstance(m, MLPLayer):
+            w = m.layer[0].weight
+            if w.shape[0] >= 128:
+                ws.append(w)
+    prep.run(ws)
+
+
 class ALIGNNConv(nn.Module):
     """Line graph update (alignn/models/alignn.py:132-167): bond-graph conv, then line-graph conv
     whose node inputs are the bond messages ``m``."""
@@ -376,8 +398,10 @@ class ALIGNN(nn.Module):
         if torch_path.wanted(self.fc.weight):  # model.double() / .bfloat16(): see alignn_amd/torch_path.py
             return torch_path.alignn_forward(self, self._batch(g))
         ops.new_weight_generation()  # weight images cached by an earlier forward are not this forward's (ops._WGEN)
-        with _lib.device_guard(self.fc.weight), _deferred_bumps(), ops.lanes(self.fc.weight.device):
-            return self._forward(self._batch(g))
+        with _lib.device_guard(self.fc.weight), _deferred_bumps():
+            _prepare_split_weights(self)  # (on the caller's stream, BEFORE the lanes fork: lane T waits for it)
+            with ops.lanes(self.fc.weight.device):
+                return self._forward(self._batch(g))
 
     def _forward(self, b: GraphBatch):
         if b.atom_features is None or b.r is None:

@@ -1466,6 +1466,57 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ X
     block_amax_commit(m, amax);
 }
 
+// ---- all split-product weights of a model in two launches (alignn_prepare_weights): one descriptor per weight
+struct WeightDesc {
+    const float* W;      // [N, K], leading dimension ldw
+    int64_t ldw;
+    int32_t N, K;
+    float* amax;         // max|W| slot: slot i of the `amax` array alignn_prepare_weights zeroes first
+    _Float16* out;       // image of W    (alignn_split_f16x2_bytes(N, K))
+    _Float16* outT;      // image of W^T  (alignn_split_f16x2_bytes(K, N))
+};
+static_assert(sizeof(WeightDesc) == 48, "descriptor layout is part of the C ABI (alignn_prepare_weights)");
+
+__global__ __launch_bounds__(256) void absmax_batched_kernel(const WeightDesc* __restrict__ descs) {
+    const WeightDesc d = descs[blockIdx.y];
+    const int Q = d.K >> 2;
+    const int64_t total = (int64_t)d.N * Q;
+    float m = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / Q;
+        const int q = (int)(i - r * Q);
+        const float4 v = f4_ld(d.W + r * d.ldw + q * 4);
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    block_amax_commit(m, d.amax);
+}
+
+__global__ __launch_bounds__(256) void split_f16x2_both_batched_kernel(const WeightDesc* __restrict__ descs) {
+    const WeightDesc d = descs[blockIdx.y];
+    const float sw = f16_scale(*d.amax);
+    constexpr int plane = BN * BK;
+    const int N = d.N, K = d.K;
+#pragma unroll
+    for (int tr = 0; tr < 2; ++tr) {  // same element map as split_f16x2_both_kernel: bit-identical images
+        _Float16* o = tr ? d.outT : d.out;
+        const int n_ = tr ? K : N, k_ = tr ? N : K, np = ((n_ + BN - 1) / BN) * BN, ntiles = np / BN;
+        const int total = np * k_;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+            const int n = i / k_, k = i % k_;
+            float x = 0.0f;
+            if (n < n_) x = tr ? d.W[(int64_t)k * d.ldw + n] : d.W[(int64_t)n * d.ldw + k];
+            x *= sw;
+            const _Float16 h = (_Float16)x;
+            const _Float16 l = (_Float16)(x - (float)h);
+            const int kb = k / BK, c = (k % BK) >> 3, e = k & 7;
+            const int nt = n / BN, nin = n % BN;
+            const int64_t q = ((int64_t)kb * ntiles + nt) * (2 * plane) + nin * BK + ((c ^ ((n >> 3) & 1)) << 3) + e;
+            o[q] = h;
+            o[q + plane] = l;
+        }
+    }
+}
+
 inline bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 inline int npad(int N) { return ((N + BN - 1) / BN) * BN; }
 
@@ -1702,6 +1753,23 @@ int alignn_split_f16x2_both(const float* W, int64_t ldw, int N, int K, const flo
     if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(split_f16x2_both_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, W, ldw, N, K, w_amax,
                        (_Float16*)out, (_Float16*)out_t);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+/* max|W| and both slice images (W for the forward products, W^T for the input gradients) of EVERY split-product weight of a
+ * model in three stream operations (a memset of the max|W| slots + two launches) instead of two launches per weight:
+ * `descs` = n_weights device records {const float* W; int64 ldw; int32 N, K; float* amax; void* out; void* out_t}
+ * (48 bytes each), `amax_slots` = the n_weights floats the records' `amax` point into.  Images are bit-identical to
+ * alignn_split_f16x2_both's. */
+int alignn_prepare_weights(const void* descs, int n_weights, float* amax_slots, alignn_stream_t stream) {
+    if (n_weights == 0) return 0;
+    if (descs == nullptr || n_weights < 0 || amax_slots == nullptr) return (int)hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(amax_slots, 0, sizeof(float) * (size_t)n_weights, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(absmax_batched_kernel, dim3(32, n_weights), dim3(256), 0, (hipStream_t)stream, (const WeightDesc*)descs);
+    hipLaunchKernelGGL(split_f16x2_both_batched_kernel, dim3(256, n_weights), dim3(256), 0, (hipStream_t)stream,
+                       (const WeightDesc*)descs);
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }

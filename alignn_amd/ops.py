@@ -435,11 +435,68 @@ _reg_step_hook(new_weight_generation)
 SPLIT_BOTH = _os.environ.get("ALIGNN_AMD_SPLIT_BOTH", "1") != "0"  # both slice images of a weight from one launch (tests flip it: same bits)
 
 
+_W_IMG = {}  # id(w) -> (weakref, stamp, SplitWeight of w): images made ahead of the step by WeightPrep (below)
+BATCHED_WEIGHT_PREP = _os.environ.get("ALIGNN_AMD_WEIGHT_PREP", "1") != "0"  # tests flip it: same bits
+
+
+class WeightPrep:
+    """max|W| and both slice images of all split-product weights of a model in ONE call per step
+    (alignn_prepare_weights: a memset + two launches instead of two launches per weight, 26 weights at the default
+    model).  The image buffers and the descriptor table are persistent (rebuilt when a weight moved); every run files the
+    images in the registries ``split_f16x2`` consults, stamped with the current weight generation - a later lookup by
+    another forward (another generation) misses and slices for itself."""
+
+    def __init__(self):
+        self.sig = None
+
+    def _rebuild(self, weights, sig):
+        import numpy as np
+
+        lib = _lib.load()
+        dev = weights[0].device
+        nw = len(weights)
+        self.amax = torch.zeros(nw, dtype=torch.float32, device=dev)
+        self.images, self.keep = [], list(weights)
+        rec = np.zeros(nw, dtype=np.dtype([("W", "<u8"), ("ldw", "<i8"), ("N", "<i4"), ("K", "<i4"), ("amax", "<u8"),
+                                           ("out", "<u8"), ("outT", "<u8")]))
+        assert rec.dtype.itemsize == 48
+        for i, w in enumerate(weights):
+            n, k = w.shape
+            buf = torch.empty(lib.alignn_split_f16x2_bytes(n, k), dtype=torch.uint8, device=dev)
+            buf_t = torch.empty(lib.alignn_split_f16x2_bytes(k, n), dtype=torch.uint8, device=dev)
+            sw, sw_t = SplitWeight(buf, n, k), SplitWeight(buf_t, k, n)
+            sw.amax = sw_t.amax = self.amax[i:i + 1]
+            self.images.append((sw, sw_t))
+            rec[i] = (w.data_ptr(), w.stride(0), n, k, sw.amax.data_ptr(), buf.data_ptr(), buf_t.data_ptr())
+        self.desc = torch.from_numpy(rec.view(np.uint8)).to(dev)
+        self.sig = sig
+
+    def run(self, weights):
+        weights = [w for w in weights if (w.dim() == 2 and w.is_cuda and w.dtype == torch.float32 and w.stride(1) == 1
+                                          and w.stride(0) % 4 == 0 and w.shape[0] % 16 == 0 and w.shape[1] % 16 == 0)]
+        if not weights or not (BATCHED_WEIGHT_PREP and F16X3 and SPLIT_BOTH):
+            return
+        sig = tuple((w.data_ptr(), w.shape[0], w.shape[1], w.stride(0)) for w in weights)
+        if sig != self.sig:
+            self._rebuild(weights, sig)
+        check(_lib.load().alignn_prepare_weights(ptr(self.desc), len(weights), ptr(self.amax), stream()), "prepare_weights")
+        for w, (sw, sw_t) in zip(weights, self.images):
+            k_ = id(w)
+            st = _wstamp(w)
+            _W_IMG[k_] = (weakref.ref(w, lambda _r, k_=k_: _W_IMG.pop(k_, None)), st, sw)
+            _W_IMG_T[k_] = (weakref.ref(w, lambda _r, k_=k_: _W_IMG_T.pop(k_, None)), st, sw_t)
+            _W_AMAX[k_] = (weakref.ref(w, lambda _r, k_=k_: _W_AMAX.pop(k_, None)), st, sw.amax)
+
+
 def split_f16x2(w, transpose=False):
     """Slice ``w * 2^s`` into two fp16 planes (``s`` from max|w|, kept with the image)."""
     lib = _lib.load()
     require_f32(w)
     n, k = (w.shape[1], w.shape[0]) if transpose else (w.shape[0], w.shape[1])
+    if not transpose:
+        img = _W_IMG.get(id(w))  # made ahead of this step by WeightPrep
+        if img is not None and img[0]() is w and img[1] == _wstamp(w):
+            return img[2]
     if transpose:
         # the image of w^T was made together with the forward image of the same weight version (below)
         img = _W_IMG_T.get(id(w))

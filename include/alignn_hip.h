@@ -116,6 +116,11 @@ int alignn_split_f16x2(const float* W, int64_t ldw, int N, int K, int transpose,
  * and torch.autograd's input gradients of the same Linear use the two images of one optimizer step. */
 int alignn_split_f16x2_both(const float* W, int64_t ldw, int N, int K, const float* w_amax, void* out, void* out_t,
                             alignn_stream_t stream);
+/* max|W| + both images of EVERY split-product weight of a model in three stream operations (once per optimizer step; the
+ * per-weight calls above cost two launches each, ~28 weights): `descs` = n_weights device records {const float* W;
+ * int64_t ldw; int32_t N, K; float* amax; void* out; void* out_t} (48 bytes), `amax_slots` = the n_weights floats the
+ * records' `amax` fields point into (zeroed here first); N, K multiples of 16, ldw of 4. */
+int alignn_prepare_weights(const void* descs, int n_weights, float* amax_slots, alignn_stream_t stream);
 /* *amax = max(*amax, max|X|): alignn_absmax (below) without its reset, for a slot known to hold 0 */
 int alignn_absmax_raise(const float* X, int64_t ldx, int64_t rows, int F, float* amax, alignn_stream_t stream);
 int alignn_gemm_nt_f16x3(const float* A, int64_t lda, const float* a_amax, const void* Wsplit,

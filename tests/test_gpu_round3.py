@@ -313,3 +313,27 @@ def test_composite_entry_points_are_bit_identical_to_the_per_kernel_path(case):
     assert a.keys() == b.keys()
     for k in a:
         assert torch.equal(a[k], b[k]), (case, k)
+
+
+def test_batched_weight_preparation_gives_the_same_bits():
+    """ops.WeightPrep (all slice images of the model in one call per step) vs two launches per weight: identical training
+    state, and the per-weight slicing launches are gone from the step."""
+    raw = make_batch(48, 60, seed0=77)
+    batch = GraphBatch.from_raw(raw, device=DEV)
+    target = torch.randn(48, generator=torch.Generator().manual_seed(2)).to(DEV)
+
+    def mk():
+        torch.manual_seed(0)
+        return ALIGNN(ALIGNNConfig(name="alignn")).to(DEV).train()
+
+    def run(flag):
+        prev = ops.BATCHED_WEIGHT_PREP
+        ops.BATCHED_WEIGHT_PREP = flag
+        try:
+            return _train_state(mk, batch, target, True, steps=3)[0]
+        finally:
+            ops.BATCHED_WEIGHT_PREP = prev
+
+    a, b = run(True), run(False)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
