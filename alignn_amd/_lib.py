@@ -57,6 +57,8 @@ SIGNATURES = {
     "alignn_slab_fold": (_i32, [_p, _i32, _i32, _p, _p]),
     "alignn_col_stats_slabs": (_i32, [_i64]),
     "alignn_col_stats": (_i32, [_p, _i64, _i64, _i32, _p, _p]),
+    "alignn_col_stats_welford": (_i32, [_p, _i64, _i64, _i32, _p, _p]),
+    "alignn_bn_finalize_welford": (_i32, [_p, _i32, _i64, _i32, _p, _p, _f32, _f32, _p, _p, _p, _p]),
     "alignn_col_sum": (_i32, [_p, _i64, _i64, _i32, _p, _p, _p]),
     "alignn_bn_finalize": (_i32, [_p, _i32, _i64, _i32, _p, _p, _f32, _f32, _p, _p, _p, _p]),
     "alignn_bn_silu_fwd": (_i32, [_p, _i64, _p, _i64, _p, _p, _i64, _i64, _i32, _p, _p]),

@@ -299,18 +299,18 @@ def _prepare_split_weights(model: nn.Module):
     prep = model.__dict__.get("_weight_prep")
     if prep is None:
         prep = model.__dict__["_weight_prep"] = ops.WeightPrep()
+    if prep.modules is None:  # (the module tree is walked once; the weights are looked up afresh every step)
+        prep.modules = ([m for m in model.modules() if isinstance(m, EdgeGatedGraphConv)],
+                        [m for m in model.modules() if isinstance(m, MLPLayer) and m.layer[0].weight.shape[0] >= 128])
+    convs, mlps = prep.modules
     ws = []
-    for m in model.modules():
-        if isinstance(m, EdgeGatedGraphConv):
-            if m.edge_gate.weight.dtype != torch.float32:
-                return
-            ws.append(m._fused_node_projection()[0])
-            ws.append(m.edge_gate.weight)
-        elif isinstance(m, MLPLayer):
-            w = m.layer[0].weight
-            if w.shape[0] >= 128:
-                ws.append(w)
-    prep.run(ws)
+    for m in convs:
+        ws.append(m._fused_node_projection()[0])
+        ws.append(m.edge_gate.weight)
+    for m in mlps:
+        ws.append(m.layer[0].weight)
+    if ws and ws[0].dtype == torch.float32:
+        prep.run(ws)
 
 
 class ALIGNNConv(nn.Module):

@@ -35,9 +35,9 @@ FwdScratch fwd_scratch(int64_t n, int64_t m, int H, int Kin, int edge_kind) {
     s.n_slabs = alignn_egc_slabs(n);
     s.e_slabs = edge_kind == 1 ? alignn_gemm_nt_x6_row_tiles(m, H, Kin) : s.n_slabs;
     size_t off = 0;
-    s.e_part = off, off += al((size_t)(s.e_slabs + 1) * 2 * H);
+    s.e_part = off, off += al((size_t)(s.e_slabs + 1) * (2 * H + 1));  // (+ counts: the gate pass writes Welford slabs)
     s.e_fold = off, off += al((size_t)alignn_slab_fold_slabs() * 2 * H);
-    s.n_part = off, off += al((size_t)s.n_slabs * 2 * H);
+    s.n_part = off, off += al((size_t)s.n_slabs * (2 * H + 1));
     s.total = off;
     return s;
 }
@@ -125,15 +125,15 @@ int alignn_egc_conv_fwd(const alignn_egc_fwd_args* a, alignn_stream_t st) {
         ALIGNN_TRY(alignn_gemm_nt(a->y, Kin, a->w_eg, Kin, a->b_eg, nullptr, 0, a->M, H, m, H, Kin, st));
         ALIGNN_TRY(alignn_egc_gate_fwd(a->P, a->M, a->seg_ptr, a->seg_node, a->src, n, m, H, a->xpre, a->s0, a->hh, e_part,
                                        n_part, st));
-        ALIGNN_TRY(alignn_bn_finalize(e_part, s.e_slabs, m, H, a->e_gamma, a->e_beta, a->eps, a->momentum, a->e_rm, a->e_rv,
-                                      a->e_stat, st));
+        ALIGNN_TRY(alignn_bn_finalize_welford(e_part, s.e_slabs, m, H, a->e_gamma, a->e_beta, a->eps, a->momentum, a->e_rm,
+                                              a->e_rv, a->e_stat, st));
         if (a->y_out != nullptr)
             ALIGNN_TRY(alignn_bn_silu_fwd(a->M, H, a->residual ? a->y : nullptr, a->residual ? Kin : 0, a->e_stat, a->y_out, H,
                                           m, H, a->y_out_amax, st));
     }
     // ---- node norm
-    ALIGNN_TRY(alignn_bn_finalize(n_part, s.n_slabs, n, H, a->n_gamma, a->n_beta, a->eps, a->momentum, a->n_rm, a->n_rv,
-                                  a->n_stat, st));
+    ALIGNN_TRY(alignn_bn_finalize_welford(n_part, s.n_slabs, n, H, a->n_gamma, a->n_beta, a->eps, a->momentum, a->n_rm,
+                                          a->n_rv, a->n_stat, st));
     ALIGNN_TRY(alignn_bn_silu_fwd(a->xpre, H, a->residual ? a->x : nullptr, a->residual ? Kin : 0, a->n_stat, a->x_out, H, n, H,
                                   a->x_out_amax, st));
     return 0;

@@ -25,21 +25,59 @@ __host__ __device__ inline int egc_blocks(int64_t n_seg) {
     return (int)b;
 }
 
-// Sum the four waves' partial accumulators in wave order and let wave 0 write the slab entry.
-__device__ __forceinline__ void block_slab_store(float4 s, float4 ss, float* slab, int H, int f, bool active,
-                                                 float4 (*sh)[kWavesPerBlock][ALIGNN_WAVE], int wave, int lane) {
-    sh[0][wave][lane] = s;
-    sh[1][wave][lane] = ss;
+// BatchNorm statistics as "Welford slabs" (csrc/norm.hip: col_stats_welford_kernel): every lane sums (v - p) and
+// (v - p)^2 about a pivot p = the first value it sees, a wave's sums become (sum v, M2 about the wave's mean), the four
+// waves are merged with Chan's formula in wave order, and the slab [2][H] = (sum, M2) goes out with its row count
+// (counts[] follows the slabs: partial[gridDim.x][2][H] | counts[gridDim.x]).  No E[x^2] - mean^2 anywhere.
+struct ShiftAcc {
+    float4 p, S, SS;
+    __device__ __forceinline__ void reset() { p = S = SS = f4_zero(); }
+    __device__ __forceinline__ void add(float4 v, bool first) {
+        if (first) p = v;  // (wave-uniform condition)
+        const float4 d = f4_sub(v, p);
+        S = f4_add(S, d);
+        SS = f4_fma(d, d, SS);
+    }
+};
+__device__ __forceinline__ void chan_merge4(float& na, float4& sa, float4& ma, float nb, float4 sb, float4 mb) {
+    if (nb == 0.0f) return;
+    if (na == 0.0f) {
+        na = nb, sa = sb, ma = mb;
+        return;
+    }
+    const float n = na + nb, ia = 1.0f / na, ib = 1.0f / nb, w = na * nb / n;
+    const float4 d = make_float4(sb.x * ib - sa.x * ia, sb.y * ib - sa.y * ia, sb.z * ib - sa.z * ia, sb.w * ib - sa.w * ia);
+    ma = make_float4(ma.x + mb.x + d.x * d.x * w, ma.y + mb.y + d.y * d.y * w, ma.z + mb.z + d.z * d.z * w,
+                     ma.w + mb.w + d.w * d.w * w);
+    sa = f4_add(sa, sb);
+    na = n;
+}
+// `cnt`: values this wave accumulated (wave-uniform).  Writes slab [2][H] at `slab` and, for the first feature panel, the
+// block's row count at `count_out`.
+__device__ __forceinline__ void block_moments_store(const ShiftAcc& a, float cnt, float* slab, float* count_out, int H, int f,
+                                                    bool active, bool first_panel,
+                                                    float4 (*sh)[kWavesPerBlock][ALIGNN_WAVE], float* shn, int wave, int lane) {
+    float4 sum = f4_zero(), m2 = f4_zero();
+    if (cnt > 0.0f) {
+        const float in = 1.0f / cnt;
+        sum = make_float4(fmaf(cnt, a.p.x, a.S.x), fmaf(cnt, a.p.y, a.S.y), fmaf(cnt, a.p.z, a.S.z), fmaf(cnt, a.p.w, a.S.w));
+        m2 = make_float4(fmaxf(a.SS.x - a.S.x * a.S.x * in, 0.f), fmaxf(a.SS.y - a.S.y * a.S.y * in, 0.f),
+                         fmaxf(a.SS.z - a.S.z * a.S.z * in, 0.f), fmaxf(a.SS.w - a.S.w * a.S.w * in, 0.f));
+    }
+    sh[0][wave][lane] = sum;
+    sh[1][wave][lane] = m2;
+    if (lane == 0) shn[wave] = cnt;
     __syncthreads();
-    if (wave == 0 && active) {
-        float4 a = sh[0][0][lane], b = sh[1][0][lane];
+    if (wave == 0) {
+        float n = shn[0];
+        float4 s = sh[0][0][lane], m = sh[1][0][lane];
 #pragma unroll
-        for (int w = 1; w < kWavesPerBlock; ++w) {
-            a = f4_add(a, sh[0][w][lane]);
-            b = f4_add(b, sh[1][w][lane]);
+        for (int w = 1; w < kWavesPerBlock; ++w) chan_merge4(n, s, m, shn[w], sh[0][w][lane], sh[1][w][lane]);
+        if (active) {
+            f4_st(slab + f, s);
+            f4_st(slab + H + f, m);
         }
-        f4_st(slab + f, a);
-        f4_st(slab + H + f, b);
+        if (first_panel && lane == 0) *count_out = n;
     }
     __syncthreads();
 }
@@ -61,6 +99,7 @@ __global__ __launch_bounds__(kThreads) void egc_gate_fwd_kernel(
     float* __restrict__ n_partial, const float* __restrict__ e_stat, const float* __restrict__ Y,
     float* __restrict__ YOUT, float* __restrict__ y_amax) {
     __shared__ float4 sh[2][kWavesPerBlock][ALIGNN_WAVE];
+    __shared__ float shn[kWavesPerBlock];
     float y_am = 0.0f;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -71,7 +110,10 @@ __global__ __launch_bounds__(kThreads) void egc_gate_fwd_kernel(
     for (int c0 = 0; c0 < H; c0 += 4 * ALIGNN_WAVE) {
         const int f = c0 + 4 * lane;
         const bool active = f < H;
-        float4 e_s = f4_zero(), e_ss = f4_zero(), n_s = f4_zero(), n_ss = f4_zero();
+        ShiftAcc e_acc, n_acc;
+        e_acc.reset();
+        n_acc.reset();
+        float e_cnt = 0.0f, n_cnt = 0.0f;  // wave-uniform: edges / segments this wave has accumulated
         float4 e_mean = f4_zero(), e_sc = f4_zero(), e_sh = f4_zero();
         if (INFER && active && YOUT) {
             e_mean = f4_ld(e_stat + f);
@@ -116,8 +158,8 @@ __global__ __launch_bounds__(kThreads) void egc_gate_fwd_kernel(
                         float4 sg = f4_sigmoid(m);
                         s1 = f4_fma(sg, bh[k], s1);
                         s0 = f4_add(s0, sg);
-                        e_s = f4_add(e_s, m);
-                        e_ss = f4_fma(m, m, e_ss);
+                        e_acc.add(m, e_cnt == 0.0f);
+                        e_cnt += 1.0f;
                     }
                 }
                 for (; e < end; ++e) {
@@ -138,8 +180,8 @@ __global__ __launch_bounds__(kThreads) void egc_gate_fwd_kernel(
                     float4 sg = f4_sigmoid(m);
                     s1 = f4_fma(sg, f4_ld(Pu + 2 * H + f), s1);
                     s0 = f4_add(s0, sg);
-                    e_s = f4_add(e_s, m);
-                    e_ss = f4_fma(m, m, e_ss);
+                    e_acc.add(m, e_cnt == 0.0f);
+                    e_cnt += 1.0f;
                 }
                 float4 h;
                 h.x = s1.x / (s0.x + ALIGNN_EPS_GATE);
@@ -150,14 +192,18 @@ __global__ __launch_bounds__(kThreads) void egc_gate_fwd_kernel(
                 f4_st(XPRE + (int64_t)i * H + f, xp);
                 if (S0) f4_st(S0 + (int64_t)i * H + f, s0);
                 if (HH) f4_st(HH + (int64_t)i * H + f, h);
-                n_s = f4_add(n_s, xp);
-                n_ss = f4_fma(xp, xp, n_ss);
+                n_acc.add(xp, n_cnt == 0.0f);
+                n_cnt += 1.0f;
             }
         }
+        // (lane 0 is active in every panel and carries the wave's counts; an inactive lane of a partial last panel
+        // accumulated nothing and stores nothing)
         if (e_partial)
-            block_slab_store(e_s, e_ss, e_partial + (size_t)blockIdx.x * 2 * H, H, f, active, sh, wave, lane);
+            block_moments_store(e_acc, e_cnt, e_partial + (size_t)blockIdx.x * 2 * H, e_partial + (size_t)gridDim.x * 2 * H + blockIdx.x,
+                                H, f, active, c0 == 0, sh, shn, wave, lane);
         if (n_partial)
-            block_slab_store(n_s, n_ss, n_partial + (size_t)blockIdx.x * 2 * H, H, f, active, sh, wave, lane);
+            block_moments_store(n_acc, n_cnt, n_partial + (size_t)blockIdx.x * 2 * H, n_partial + (size_t)gridDim.x * 2 * H + blockIdx.x,
+                                H, f, active, c0 == 0, sh, shn, wave, lane);
     }
     if (INFER) block_amax_commit(y_am, y_amax);
 }

@@ -190,6 +190,128 @@ __global__ __launch_bounds__(256) void slab_fold_kernel(const float* __restrict_
     if (lane == 0 && f < width) out[(size_t)g * width + f] = (float)(((sh[0][threadIdx.x] + sh[1][threadIdx.x]) + sh[2][threadIdx.x]) + sh[3][threadIdx.x]);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Well-conditioned BatchNorm statistics ("Welford slabs").  sum x / sum x^2 slabs lose (mean / std)^2 digits when the
+// variance is taken as E[x^2] - mean^2 (the reference's own force test - constant node features, every atom's
+// pre-activation equal up to the gate's 1e-6 - shows it: alignn/tests/test_force_reduction.py:131-268).  Here every
+// thread sums (x - p) and (x - p)^2 about a pivot p = the first value it sees, a slab is (sum x, M2 = sum (x - slab mean)^2)
+// together with its row count, and slabs are merged with Chan's formula in float64 - the cancellation is gone and the
+// result depends on mean / std only through float32's representation of the mean itself.  Fixed order everywhere.
+// Slab layout: partial[slabs][2][F] (sum, M2) followed by counts[slabs] (float: exact below 2^24 rows per slab).
+// ---------------------------------------------------------------------------------------------
+struct Moments {
+    float n;
+    float4 sum, m2;
+};
+// (count, sum, M2) of the union of two disjoint sets (Chan et al.); empty sets pass through
+__device__ __forceinline__ void chan_merge(float& na, float4& sa, float4& ma, float nb, float4 sb, float4 mb) {
+    if (nb == 0.0f) return;
+    if (na == 0.0f) {
+        na = nb, sa = sb, ma = mb;
+        return;
+    }
+    const float n = na + nb, ia = 1.0f / na, ib = 1.0f / nb, w = na * nb / n;
+    const float4 d = make_float4(sb.x * ib - sa.x * ia, sb.y * ib - sa.y * ia, sb.z * ib - sa.z * ia, sb.w * ib - sa.w * ia);
+    ma = make_float4(ma.x + mb.x + d.x * d.x * w, ma.y + mb.y + d.y * d.y * w, ma.z + mb.z + d.z * d.z * w,
+                     ma.w + mb.w + d.w * d.w * w);
+    sa = f4_add(sa, sb);
+    na = n;
+}
+// shifted sums about pivot p over n values -> (sum, M2)
+__device__ __forceinline__ void shifted_to_moments(float n, float4 p, float4 S, float4 SS, float4& sum, float4& m2) {
+    if (n == 0.0f) {
+        sum = m2 = f4_zero();
+        return;
+    }
+    const float in = 1.0f / n;
+    sum = make_float4(fmaf(n, p.x, S.x), fmaf(n, p.y, S.y), fmaf(n, p.z, S.z), fmaf(n, p.w, S.w));
+    m2 = make_float4(fmaxf(SS.x - S.x * S.x * in, 0.f), fmaxf(SS.y - S.y * S.y * in, 0.f), fmaxf(SS.z - S.z * S.z * in, 0.f),
+                     fmaxf(SS.w - S.w * S.w * in, 0.f));
+}
+
+template <bool STREAM>
+__global__ __launch_bounds__(kThreads) void col_stats_welford_kernel(const float* __restrict__ X, int64_t ldx, int64_t rows,
+                                                                     int F, int slabs, float* __restrict__ partial) {
+    const int Q = F >> 2;
+    const int RP = kThreads / Q;
+    const int t = threadIdx.x;
+    const int q = t % Q;
+    const int rl = t / Q;
+    const int64_t stride = (int64_t)slabs * RP;  // same row -> slab map as col_reduce_kernel
+    float n = 0.0f;
+    float4 p = f4_zero(), S = f4_zero(), SS = f4_zero();
+    if (rl < RP) {
+        int64_t r = (int64_t)blockIdx.x * RP + rl;
+        if (r < rows) p = f4_lds<STREAM>(X + r * ldx + q * 4);
+        for (; r < rows; r += stride) {
+            const float4 d = f4_sub(f4_lds<STREAM>(X + r * ldx + q * 4), p);
+            S = f4_add(S, d);
+            SS = f4_fma(d, d, SS);
+            n += 1.0f;
+        }
+    }
+    float4 sum, m2;
+    shifted_to_moments(n, p, S, SS, sum, m2);
+    __shared__ float4 sh[2][kThreads];
+    __shared__ float shn[kThreads];
+    sh[0][t] = sum;
+    sh[1][t] = m2;
+    shn[t] = n;
+    __syncthreads();
+    if (rl == 0) {
+        for (int k = 1; k < RP; ++k) chan_merge(n, sum, m2, shn[k * Q + q], sh[0][k * Q + q], sh[1][k * Q + q]);
+        float* out = partial + (size_t)blockIdx.x * 2 * F;
+        f4_st(out + q * 4, sum);
+        f4_st(out + F + q * 4, m2);
+        if (q == 0) partial[(size_t)slabs * 2 * F + blockIdx.x] = n;  // every column of the slab saw the same rows
+    }
+}
+
+// finalise Welford slabs: mean = sum_k sum_k / n, M2 = sum_k [M2_k + n_k (mean_k - mean)^2] in float64, fixed order
+__global__ __launch_bounds__(kRedCols* kRedLanes) void bn_finalize_welford_kernel(
+    const float* __restrict__ partial, const float* __restrict__ counts, int slabs, int64_t rows, int F,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+    float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ stat) {
+    __shared__ double sh[kRedLanes][kRedCols];
+    const int f = blockIdx.x * kRedCols + threadIdx.x;
+    const bool ok = f < F;
+    double s = 0.0;
+    if (ok)
+        for (int k = threadIdx.y; k < slabs; k += kRedLanes) s += (double)partial[(size_t)k * 2 * F + f];
+    s = lane_tree_sum(s, sh);
+    // (only row 0 holds the total: hand it to every slab-lane through the scratch array)
+    if (threadIdx.y == 0) sh[0][threadIdx.x] = s;
+    __syncthreads();
+    const double n = (double)rows;
+    const double m = sh[0][threadIdx.x] / n;
+    __syncthreads();
+    double m2 = 0.0;
+    if (ok)
+        for (int k = threadIdx.y; k < slabs; k += kRedLanes) {
+            const double nk = (double)counts[k];
+            if (nk > 0.0) {
+                const double d = (double)partial[(size_t)k * 2 * F + f] / nk - m;
+                m2 += (double)partial[(size_t)k * 2 * F + F + f] + nk * d * d;
+            }
+        }
+    m2 = lane_tree_sum(m2, sh);
+    if (!ok || threadIdx.y != 0) return;
+    double v = m2 / n;
+    if (v < 0.0) v = 0.0;
+    const float mean = (float)m, var = (float)v;
+    if (running_mean != nullptr) {
+        const double unbiased = rows > 1 ? v * n / (n - 1.0) : v;
+        running_mean[f] = (1.0f - momentum) * running_mean[f] + momentum * mean;
+        running_var[f] = (1.0f - momentum) * running_var[f] + momentum * (float)unbiased;
+    }
+    const float rstd = 1.0f / sqrtf(var + eps);
+    const float g = gamma ? gamma[f] : 1.0f, b = beta ? beta[f] : 0.0f;
+    stat[f] = mean;
+    stat[F + f] = rstd;
+    stat[2 * F + f] = g * rstd;
+    stat[3 * F + f] = b;
+}
+
 // Y = R + silu((X-mean)*scale + beta)
 template <bool HAS_RES, bool STREAM>
 __global__ __launch_bounds__(kThreads) void bn_silu_fwd_kernel(const float* __restrict__ X, int64_t ldx,
@@ -525,6 +647,30 @@ int alignn_col_stats(const float* X, int64_t ldx, int64_t rows, int F, float* pa
         hipLaunchKernelGGL(col_reduce_kernel<StatsFn<false>>, dim3(slabs), dim3(kThreads), 0, (hipStream_t)stream, fn,
                            rows, F, slabs, partial);
     }
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_col_stats_welford(const float* X, int64_t ldx, int64_t rows, int F, float* partial, alignn_stream_t stream) {
+    if (!feat_ok(F) || rows < 0) return (int)hipErrorInvalidValue;
+    int slabs = slabs_for(rows);
+    if (streaming(rows, F))
+        hipLaunchKernelGGL(col_stats_welford_kernel<true>, dim3(slabs), dim3(kThreads), 0, (hipStream_t)stream, X, ldx, rows, F,
+                           slabs, partial);
+    else
+        hipLaunchKernelGGL(col_stats_welford_kernel<false>, dim3(slabs), dim3(kThreads), 0, (hipStream_t)stream, X, ldx, rows,
+                           F, slabs, partial);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_bn_finalize_welford(const float* partial, int slabs, int64_t rows, int F, const float* gamma, const float* beta,
+                               float eps, float momentum, float* running_mean, float* running_var, float* stat,
+                               alignn_stream_t stream) {
+    if (F <= 0 || slabs <= 0 || partial == nullptr) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(bn_finalize_welford_kernel, dim3(alignn_ceil_div(F, kRedCols)), dim3(kRedCols, kRedLanes), 0,
+                       (hipStream_t)stream, partial, partial + (size_t)slabs * 2 * F, slabs, rows, F, gamma, beta, eps, momentum,
+                       running_mean, running_var, stat);
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }

@@ -447,7 +447,7 @@ class WeightPrep:
     another forward (another generation) misses and slices for itself."""
 
     def __init__(self):
-        self.sig = None
+        self.sig, self.keep, self.refs, self.modules = None, [], [], None
 
     def _rebuild(self, weights, sig):
         import numpy as np
@@ -472,20 +472,26 @@ class WeightPrep:
         self.sig = sig
 
     def run(self, weights):
-        weights = [w for w in weights if (w.dim() == 2 and w.is_cuda and w.dtype == torch.float32 and w.stride(1) == 1
-                                          and w.stride(0) % 4 == 0 and w.shape[0] % 16 == 0 and w.shape[1] % 16 == 0)]
-        if not weights or not (BATCHED_WEIGHT_PREP and F16X3 and SPLIT_BOTH):
+        """``weights``: the same list (same tensor objects, same order) every step while nothing moved - the cheap path."""
+        if not (BATCHED_WEIGHT_PREP and F16X3 and SPLIT_BOTH):
             return
-        sig = tuple((w.data_ptr(), w.shape[0], w.shape[1], w.stride(0)) for w in weights)
-        if sig != self.sig:
+        sig = tuple([w.data_ptr() for w in weights])
+        if sig != self.sig or len(weights) != len(self.keep) or any(a is not b for a, b in zip(weights, self.keep)):
+            ok = [w for w in weights if (w.dim() == 2 and w.is_cuda and w.dtype == torch.float32 and w.stride(1) == 1
+                                         and w.stride(0) % 4 == 0 and w.shape[0] % 16 == 0 and w.shape[1] % 16 == 0)]
+            if len(ok) != len(weights) or not ok:
+                self.sig = None
+                return
             self._rebuild(weights, sig)
+            self.refs = [(id(w), weakref.ref(w, lambda _r, k_=id(w): (_W_IMG.pop(k_, None), _W_IMG_T.pop(k_, None),
+                                                                      _W_AMAX.pop(k_, None)))) for w in weights]
         check(_lib.load().alignn_prepare_weights(ptr(self.desc), len(weights), ptr(self.amax), stream()), "prepare_weights")
-        for w, (sw, sw_t) in zip(weights, self.images):
-            k_ = id(w)
-            st = _wstamp(w)
-            _W_IMG[k_] = (weakref.ref(w, lambda _r, k_=k_: _W_IMG.pop(k_, None)), st, sw)
-            _W_IMG_T[k_] = (weakref.ref(w, lambda _r, k_=k_: _W_IMG_T.pop(k_, None)), st, sw_t)
-            _W_AMAX[k_] = (weakref.ref(w, lambda _r, k_=k_: _W_AMAX.pop(k_, None)), st, sw.amax)
+        gen = _WGEN[0]
+        for w, (k_, ref), (sw, sw_t) in zip(weights, self.refs, self.images):
+            st = (w._version, gen)
+            _W_IMG[k_] = (ref, st, sw)
+            _W_IMG_T[k_] = (ref, st, sw_t)
+            _W_AMAX[k_] = (ref, st, sw.amax)
 
 
 def split_f16x2(w, transpose=False):
@@ -860,15 +866,25 @@ def _fold(partial, slabs, width):
     return out, g
 
 
-def _bn_finalize(partial, slabs, rows, gamma, beta, running_mean, running_var, update_running):
-    """-> stat [4,F] = mean, rstd, scale, shift.  slabs == 0: evaluation mode (running statistics)."""
+def _welford_slabs(slabs, F, like):
+    """Storage for ``slabs`` Welford slabs [2][F] + their counts (alignn_col_stats_welford, the gate passes)."""
+    return _empty(slabs * (2 * F + 1), like=like)
+
+
+def _bn_finalize(partial, slabs, rows, gamma, beta, running_mean, running_var, update_running, welford=False):
+    """-> stat [4,F] = mean, rstd, scale, shift.  slabs == 0: evaluation mode (running statistics).  ``welford``: the slabs
+    are (sum, M2) + counts (well-conditioned: column statistics pass, gate passes) instead of plain sums."""
     lib = _lib.load()
     F = gamma.numel()
-    if slabs:
-        partial, slabs = _fold(partial, slabs, 2 * F)
     stat = _empty(4, F, like=gamma)
     rm = running_mean if (update_running or slabs == 0) else None
     rv = running_var if (update_running or slabs == 0) else None
+    if welford and slabs:
+        check(lib.alignn_bn_finalize_welford(ptr(partial), slabs, rows, F, ptr(gamma), ptr(beta), BN_EPS, BN_MOMENTUM, ptr(rm),
+                                             ptr(rv), ptr(stat), stream()), "bn_finalize_welford")
+        return stat
+    if slabs:
+        partial, slabs = _fold(partial, slabs, 2 * F)
     check(
         lib.alignn_bn_finalize(ptr(partial), slabs, rows, F, ptr(gamma), ptr(beta), BN_EPS, BN_MOMENTUM, ptr(rm),
                                ptr(rv), ptr(stat), stream()),
@@ -1072,9 +1088,9 @@ class MLPLayerFn(torch.autograd.Function):
             if training:
                 if not fused_stats:
                     slabs = lib.alignn_col_stats_slabs(rows)
-                    partial = _empty(slabs, 2, F, like=pre)
-                    check(lib.alignn_col_stats(ptr(pre), pre.stride(0), rows, F, ptr(partial), stream()), "col_stats")
-                stat = _bn_finalize(partial, slabs, rows, gamma, beta, running_mean, running_var, True)
+                    partial = _welford_slabs(slabs, F, pre)
+                    check(lib.alignn_col_stats_welford(ptr(pre), pre.stride(0), rows, F, ptr(partial), stream()), "col_stats")
+                stat = _bn_finalize(partial, slabs, rows, gamma, beta, running_mean, running_var, True, welford=not fused_stats)
             else:
                 stat = _bn_finalize(None, 0, rows, gamma, beta, running_mean, running_var, False)
             y = _bn_silu_fwd(pre, None, stat)
@@ -1259,7 +1275,7 @@ class EdgeGatedConvFn(torch.autograd.Function):
         xpre = _empty(n, H, like=x)
         s0 = _empty(n, H, like=x)
         hh = _empty(n, H, like=x)
-        n_part = _empty(slabs, 2, H, like=x) if bn_train else None
+        n_part = _welford_slabs(slabs, H, x) if bn_train else None  # (written by the gate pass: Welford slabs)
 
         # u_add_v inside the edge projection's epilogue when that projection runs on the f16x3 kernel (the T- and E-row
         # convolutions of a real batch): M leaves the GEMM as m = A[u] + Bd[v] + C and the gate pass only reads it
@@ -1278,7 +1294,7 @@ class EdgeGatedConvFn(torch.autograd.Function):
                 M = gemm_nt_f16x3_gather(y, ctx.y_amax, split_f16x2(w_eg), b_eg, P, graph.src, graph.dst)
             else:
                 M = project(y, w_eg, b_eg, a_amax=ctx.y_amax)  # [m,H]  -> m_pre in place
-            e_part = _empty(slabs, 2, H, like=x) if (bn_train and not fuse_norm) else None
+            e_part = _welford_slabs(slabs, H, x) if (bn_train and not fuse_norm) else None
             return M, e_part
 
         fused_out = {}
@@ -1319,7 +1335,7 @@ class EdgeGatedConvFn(torch.autograd.Function):
                 if need_y:
                     return _ln_silu_fwd(M, y if residual else None, e_gamma, e_beta)
                 return None, _empty(1, 2, like=x)
-            e_stat = (_bn_finalize(e_part, slabs, m, e_gamma, e_beta, e_rm, e_rv, True) if training
+            e_stat = (_bn_finalize(e_part, slabs, m, e_gamma, e_beta, e_rm, e_rv, True, welford=True) if training
                       else _bn_finalize(None, 0, m, e_gamma, e_beta, e_rm, e_rv, False))
             # need_y == False: the caller discards the edge output (last layer) - skip the pass, keep the
             # statistics side effect (running_mean/var of bn_edges are updated exactly as in the reference)
@@ -1351,7 +1367,7 @@ class EdgeGatedConvFn(torch.autograd.Function):
         if norm == "layer":
             x_out, n_stat = _ln_silu_fwd(xpre, x if residual else None, n_gamma, n_beta)
         else:
-            n_stat = (_bn_finalize(n_part, slabs, n, n_gamma, n_beta, n_rm, n_rv, True) if training
+            n_stat = (_bn_finalize(n_part, slabs, n, n_gamma, n_beta, n_rm, n_rv, True, welford=True) if training
                       else _bn_finalize(None, 0, n, n_gamma, n_beta, n_rm, n_rv, False))
             x_out = _bn_silu_fwd(xpre, x if residual else None, n_stat)
         ctx.graph = graph

@@ -337,3 +337,62 @@ def test_batched_weight_preparation_gives_the_same_bits():
     a, b = run(True), run(False)
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+# ---------------------------------------------------------------------------------------------
+# BatchNorm statistics as Welford slabs: well-conditioned when |mean| >> std
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,F", [(37, 64), (3840, 256), (50712, 256), (200003, 64)])
+@pytest.mark.parametrize("offset", [0.0, 300.0])
+def test_welford_column_statistics_are_well_conditioned(rows, F, offset):
+    """column mean / rstd of X = offset + small noise.  With offset = 300 and std = 1e-2, E[x^2] - mean^2 in float32 has no
+    correct digit (mean^2 / var = 9e8); the Welford slabs give rstd to 1e-4 of the float64 value."""
+    from alignn_amd import _lib
+    from alignn_amd._lib import check, ptr, stream
+
+    lib = _lib.load()
+    g = torch.Generator(device="cpu").manual_seed(rows + F)
+    noise = torch.randn(rows, F, generator=g, dtype=torch.float64) * (1e-2 if offset else 1.0)
+    X64 = offset * (1.0 + 0.01 * torch.arange(F, dtype=torch.float64)) + noise  # a different mean per column
+    X = X64.float().to(DEV)
+    X64 = X.double().cpu()  # (statistics of what the kernel really sees)
+    gamma, beta = torch.ones(F, device=DEV), torch.zeros(F, device=DEV)
+    rm, rv = torch.zeros(F, device=DEV), torch.ones(F, device=DEV)
+    slabs = lib.alignn_col_stats_slabs(rows)
+    partial = torch.empty(slabs * (2 * F + 1), device=DEV)
+    stat = torch.empty(4, F, device=DEV)
+    check(lib.alignn_col_stats_welford(ptr(X), F, rows, F, ptr(partial), stream()), "col_stats_welford")
+    check(lib.alignn_bn_finalize_welford(ptr(partial), slabs, rows, F, ptr(gamma), ptr(beta), 1e-5, 0.1, ptr(rm), ptr(rv),
+                                         ptr(stat), stream()), "bn_finalize_welford")
+    torch.cuda.synchronize()
+    assert float(partial[slabs * 2 * F:].sum()) == rows  # the slabs' counts
+    mean64, var64 = X64.mean(0), X64.var(0, unbiased=False)
+    rstd64 = 1.0 / torch.sqrt(var64 + 1e-5)
+    assert float((stat[0].double().cpu() - mean64).abs().max()) <= 2e-7 * float(mean64.abs().max() + 1.0)
+    assert float(((stat[1].double().cpu() - rstd64) / rstd64).abs().max()) < 1e-4
+    unb = X64.var(0, unbiased=True) if rows > 1 else var64
+    assert float(((rv.double().cpu() - (0.9 + 0.1 * unb)) / (0.9 + 0.1 * unb)).abs().max()) < 1e-5
+
+
+def test_conv_with_constant_node_features_matches_float64():
+    """The regime of the reference's force test (alignn/tests/test_force_reduction.py: x = ones): every atom's
+    pre-activation differs only through the gate's 1e-6 / the bond sums, |mean| >> std on the node norm.  Output of the
+    float32 kernels against the float64 torch path of the SAME module."""
+    import copy
+
+    from alignn_amd.alignn import EdgeGatedGraphConv
+    from alignn_amd.graph import build_csr
+
+    torch.manual_seed(0)
+    raw = make_batch(2, 30, seed0=3)
+    u, v = torch.from_numpy(raw.u).to(DEV), torch.from_numpy(raw.v).to(DEV)
+    csr = build_csr(u, v, raw.num_nodes)
+    conv = EdgeGatedGraphConv(64, 64).to(DEV).train()
+    conv64 = copy.deepcopy(conv).double()
+    x = torch.ones(raw.num_nodes, 64, device=DEV)
+    y = torch.randn(raw.num_edges, 64, device=DEV)
+    xo, yo = conv(csr, x, y)
+    with pytest.warns(RuntimeWarning):
+        xo64, yo64 = conv64(csr, x.double(), y.double())
+    for a, b in ((xo, xo64), (yo, yo64)):
+        assert float((a.double() - b).abs().max()) < 2e-4 * float(b.abs().max())
