@@ -35,9 +35,9 @@ FwdScratch fwd_scratch(int64_t n, int64_t m, int H, int Kin, int edge_kind) {
     s.n_slabs = alignn_egc_slabs(n);
     s.e_slabs = edge_kind == 1 ? alignn_gemm_nt_x6_row_tiles(m, H, Kin) : s.n_slabs;
     size_t off = 0;
-    s.e_part = off, off += al((size_t)(s.e_slabs + 1) * (2 * H + 1));  // (+ counts: the gate pass writes Welford slabs)
+    s.e_part = off, off += al((size_t)(s.e_slabs + 1) * (3 * H + 1));  // (the gate pass writes pivot slabs [3][H] + counts)
     s.e_fold = off, off += al((size_t)alignn_slab_fold_slabs() * 2 * H);
-    s.n_part = off, off += al((size_t)s.n_slabs * (2 * H + 1));
+    s.n_part = off, off += al((size_t)s.n_slabs * (3 * H + 1));
     s.total = off;
     return s;
 }

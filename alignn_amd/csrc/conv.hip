@@ -25,10 +25,10 @@ __host__ __device__ inline int egc_blocks(int64_t n_seg) {
     return (int)b;
 }
 
-// BatchNorm statistics as "Welford slabs" (csrc/norm.hip: col_stats_welford_kernel): every lane sums (v - p) and
-// (v - p)^2 about a pivot p = the first value it sees, a wave's sums become (sum v, M2 about the wave's mean), the four
-// waves are merged with Chan's formula in wave order, and the slab [2][H] = (sum, M2) goes out with its row count
-// (counts[] follows the slabs: partial[gridDim.x][2][H] | counts[gridDim.x]).  No E[x^2] - mean^2 anywhere.
+// BatchNorm statistics as "pivot slabs" (csrc/norm.hip: col_stats_welford_kernel): every lane sums d = v - p and d^2 about
+// a pivot p = the first value it sees; the four waves are merged in wave order by re-centring onto wave 0's pivot (all
+// sums stay of the size of the spread - no E[x^2] - mean^2 anywhere, and no mean rounded to float32 either); the slab
+// [3][H] = (pivot, S, SS) goes out with its row count: partial[gridDim.x][3][H] | counts[gridDim.x].
 struct ShiftAcc {
     float4 p, S, SS;
     __device__ __forceinline__ void reset() { p = S = SS = f4_zero(); }
@@ -39,43 +39,38 @@ struct ShiftAcc {
         SS = f4_fma(d, d, SS);
     }
 };
-__device__ __forceinline__ void chan_merge4(float& na, float4& sa, float4& ma, float nb, float4 sb, float4 mb) {
+__device__ __forceinline__ void pivot_merge4(float& na, float4& pa, float4& Sa, float4& SSa, float nb, float4 pb, float4 Sb,
+                                             float4 SSb) {
     if (nb == 0.0f) return;
     if (na == 0.0f) {
-        na = nb, sa = sb, ma = mb;
+        na = nb, pa = pb, Sa = Sb, SSa = SSb;
         return;
     }
-    const float n = na + nb, ia = 1.0f / na, ib = 1.0f / nb, w = na * nb / n;
-    const float4 d = make_float4(sb.x * ib - sa.x * ia, sb.y * ib - sa.y * ia, sb.z * ib - sa.z * ia, sb.w * ib - sa.w * ia);
-    ma = make_float4(ma.x + mb.x + d.x * d.x * w, ma.y + mb.y + d.y * d.y * w, ma.z + mb.z + d.z * d.z * w,
-                     ma.w + mb.w + d.w * d.w * w);
-    sa = f4_add(sa, sb);
-    na = n;
+    const float4 d = f4_sub(pb, pa);
+    SSa = make_float4(SSa.x + SSb.x + d.x * (2.0f * Sb.x + nb * d.x), SSa.y + SSb.y + d.y * (2.0f * Sb.y + nb * d.y),
+                      SSa.z + SSb.z + d.z * (2.0f * Sb.z + nb * d.z), SSa.w + SSb.w + d.w * (2.0f * Sb.w + nb * d.w));
+    Sa = make_float4(Sa.x + Sb.x + nb * d.x, Sa.y + Sb.y + nb * d.y, Sa.z + Sb.z + nb * d.z, Sa.w + Sb.w + nb * d.w);
+    na += nb;
 }
-// `cnt`: values this wave accumulated (wave-uniform).  Writes slab [2][H] at `slab` and, for the first feature panel, the
-// block's row count at `count_out`.
+// `cnt`: values this wave accumulated (wave-uniform; lane 0 is active in every panel).  Writes slab [3][H] at `slab` and, for
+// the first feature panel, the block's row count at `count_out`.
 __device__ __forceinline__ void block_moments_store(const ShiftAcc& a, float cnt, float* slab, float* count_out, int H, int f,
                                                     bool active, bool first_panel,
                                                     float4 (*sh)[kWavesPerBlock][ALIGNN_WAVE], float* shn, int wave, int lane) {
-    float4 sum = f4_zero(), m2 = f4_zero();
-    if (cnt > 0.0f) {
-        const float in = 1.0f / cnt;
-        sum = make_float4(fmaf(cnt, a.p.x, a.S.x), fmaf(cnt, a.p.y, a.S.y), fmaf(cnt, a.p.z, a.S.z), fmaf(cnt, a.p.w, a.S.w));
-        m2 = make_float4(fmaxf(a.SS.x - a.S.x * a.S.x * in, 0.f), fmaxf(a.SS.y - a.S.y * a.S.y * in, 0.f),
-                         fmaxf(a.SS.z - a.S.z * a.S.z * in, 0.f), fmaxf(a.SS.w - a.S.w * a.S.w * in, 0.f));
-    }
-    sh[0][wave][lane] = sum;
-    sh[1][wave][lane] = m2;
+    sh[0][wave][lane] = a.p;
+    sh[1][wave][lane] = a.S;
+    sh[2][wave][lane] = a.SS;
     if (lane == 0) shn[wave] = cnt;
     __syncthreads();
     if (wave == 0) {
         float n = shn[0];
-        float4 s = sh[0][0][lane], m = sh[1][0][lane];
+        float4 p = sh[0][0][lane], S = sh[1][0][lane], SS = sh[2][0][lane];
 #pragma unroll
-        for (int w = 1; w < kWavesPerBlock; ++w) chan_merge4(n, s, m, shn[w], sh[0][w][lane], sh[1][w][lane]);
+        for (int w = 1; w < kWavesPerBlock; ++w) pivot_merge4(n, p, S, SS, shn[w], sh[0][w][lane], sh[1][w][lane], sh[2][w][lane]);
         if (active) {
-            f4_st(slab + f, s);
-            f4_st(slab + H + f, m);
+            f4_st(slab + f, p);
+            f4_st(slab + H + f, S);
+            f4_st(slab + 2 * H + f, SS);
         }
         if (first_panel && lane == 0) *count_out = n;
     }
@@ -98,7 +93,7 @@ __global__ __launch_bounds__(kThreads) void egc_gate_fwd_kernel(
     float* __restrict__ XPRE, float* __restrict__ S0, float* __restrict__ HH, float* __restrict__ e_partial,
     float* __restrict__ n_partial, const float* __restrict__ e_stat, const float* __restrict__ Y,
     float* __restrict__ YOUT, float* __restrict__ y_amax) {
-    __shared__ float4 sh[2][kWavesPerBlock][ALIGNN_WAVE];
+    __shared__ float4 sh[3][kWavesPerBlock][ALIGNN_WAVE];
     __shared__ float shn[kWavesPerBlock];
     float y_am = 0.0f;
     const int lane = threadIdx.x & 63;
@@ -199,10 +194,10 @@ __global__ __launch_bounds__(kThreads) void egc_gate_fwd_kernel(
         // (lane 0 is active in every panel and carries the wave's counts; an inactive lane of a partial last panel
         // accumulated nothing and stores nothing)
         if (e_partial)
-            block_moments_store(e_acc, e_cnt, e_partial + (size_t)blockIdx.x * 2 * H, e_partial + (size_t)gridDim.x * 2 * H + blockIdx.x,
+            block_moments_store(e_acc, e_cnt, e_partial + (size_t)blockIdx.x * 3 * H, e_partial + (size_t)gridDim.x * 3 * H + blockIdx.x,
                                 H, f, active, c0 == 0, sh, shn, wave, lane);
         if (n_partial)
-            block_moments_store(n_acc, n_cnt, n_partial + (size_t)blockIdx.x * 2 * H, n_partial + (size_t)gridDim.x * 2 * H + blockIdx.x,
+            block_moments_store(n_acc, n_cnt, n_partial + (size_t)blockIdx.x * 3 * H, n_partial + (size_t)gridDim.x * 3 * H + blockIdx.x,
                                 H, f, active, c0 == 0, sh, shn, wave, lane);
     }
     if (INFER) block_amax_commit(y_am, y_amax);

@@ -191,42 +191,27 @@ __global__ __launch_bounds__(256) void slab_fold_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
-// Well-conditioned BatchNorm statistics ("Welford slabs").  sum x / sum x^2 slabs lose (mean / std)^2 digits when the
-// variance is taken as E[x^2] - mean^2 (the reference's own force test - constant node features, every atom's
-// pre-activation equal up to the gate's 1e-6 - shows it: alignn/tests/test_force_reduction.py:131-268).  Here every
-// thread sums (x - p) and (x - p)^2 about a pivot p = the first value it sees, a slab is (sum x, M2 = sum (x - slab mean)^2)
-// together with its row count, and slabs are merged with Chan's formula in float64 - the cancellation is gone and the
-// result depends on mean / std only through float32's representation of the mean itself.  Fixed order everywhere.
-// Slab layout: partial[slabs][2][F] (sum, M2) followed by counts[slabs] (float: exact below 2^24 rows per slab).
+// Well-conditioned BatchNorm statistics ("pivot slabs").  sum x / sum x^2 slabs lose (mean / std)^2 digits when the
+// variance is taken as E[x^2] - mean^2.  Here every thread sums d = x - p and d^2 about a pivot p = the first value it
+// sees; partial results are merged by RE-CENTRING onto one of the two pivots (p_b - p_a is exact for nearby floats, and all
+// sums stay of the size of the spread, not of the mean - a float32 mean could not even hold the sub-ulp part); a slab is
+// (pivot, S, SS) with its row count, and the slabs are re-centred onto slab 0's pivot and summed in float64.  Fixed order
+// everywhere.  Layout: partial[slabs][3][F] (pivot, S = sum (x - pivot), SS = sum (x - pivot)^2) | counts[slabs] (float).
 // ---------------------------------------------------------------------------------------------
-struct Moments {
-    float n;
-    float4 sum, m2;
-};
-// (count, sum, M2) of the union of two disjoint sets (Chan et al.); empty sets pass through
-__device__ __forceinline__ void chan_merge(float& na, float4& sa, float4& ma, float nb, float4 sb, float4 mb) {
+// (n, p, S, SS) of set a  <-  union with set b, expressed about a's pivot; empty sets pass through
+__device__ __forceinline__ void pivot_merge(float& na, float4& pa, float4& Sa, float4& SSa, float nb, float4 pb, float4 Sb,
+                                            float4 SSb) {
     if (nb == 0.0f) return;
     if (na == 0.0f) {
-        na = nb, sa = sb, ma = mb;
+        na = nb, pa = pb, Sa = Sb, SSa = SSb;
         return;
     }
-    const float n = na + nb, ia = 1.0f / na, ib = 1.0f / nb, w = na * nb / n;
-    const float4 d = make_float4(sb.x * ib - sa.x * ia, sb.y * ib - sa.y * ia, sb.z * ib - sa.z * ia, sb.w * ib - sa.w * ia);
-    ma = make_float4(ma.x + mb.x + d.x * d.x * w, ma.y + mb.y + d.y * d.y * w, ma.z + mb.z + d.z * d.z * w,
-                     ma.w + mb.w + d.w * d.w * w);
-    sa = f4_add(sa, sb);
-    na = n;
-}
-// shifted sums about pivot p over n values -> (sum, M2)
-__device__ __forceinline__ void shifted_to_moments(float n, float4 p, float4 S, float4 SS, float4& sum, float4& m2) {
-    if (n == 0.0f) {
-        sum = m2 = f4_zero();
-        return;
-    }
-    const float in = 1.0f / n;
-    sum = make_float4(fmaf(n, p.x, S.x), fmaf(n, p.y, S.y), fmaf(n, p.z, S.z), fmaf(n, p.w, S.w));
-    m2 = make_float4(fmaxf(SS.x - S.x * S.x * in, 0.f), fmaxf(SS.y - S.y * S.y * in, 0.f), fmaxf(SS.z - S.z * S.z * in, 0.f),
-                     fmaxf(SS.w - S.w * S.w * in, 0.f));
+    const float4 d = f4_sub(pb, pa);
+    // sum (x - pa)^2 over b = SSb + 2 d Sb + nb d^2 ;  sum (x - pa) over b = Sb + nb d
+    SSa = make_float4(SSa.x + SSb.x + d.x * (2.0f * Sb.x + nb * d.x), SSa.y + SSb.y + d.y * (2.0f * Sb.y + nb * d.y),
+                      SSa.z + SSb.z + d.z * (2.0f * Sb.z + nb * d.z), SSa.w + SSb.w + d.w * (2.0f * Sb.w + nb * d.w));
+    Sa = make_float4(Sa.x + Sb.x + nb * d.x, Sa.y + Sb.y + nb * d.y, Sa.z + Sb.z + nb * d.z, Sa.w + Sb.w + nb * d.w);
+    na += nb;
 }
 
 template <bool STREAM>
@@ -250,24 +235,25 @@ __global__ __launch_bounds__(kThreads) void col_stats_welford_kernel(const float
             n += 1.0f;
         }
     }
-    float4 sum, m2;
-    shifted_to_moments(n, p, S, SS, sum, m2);
-    __shared__ float4 sh[2][kThreads];
+    __shared__ float4 sh[3][kThreads];
     __shared__ float shn[kThreads];
-    sh[0][t] = sum;
-    sh[1][t] = m2;
+    sh[0][t] = p;
+    sh[1][t] = S;
+    sh[2][t] = SS;
     shn[t] = n;
     __syncthreads();
     if (rl == 0) {
-        for (int k = 1; k < RP; ++k) chan_merge(n, sum, m2, shn[k * Q + q], sh[0][k * Q + q], sh[1][k * Q + q]);
-        float* out = partial + (size_t)blockIdx.x * 2 * F;
-        f4_st(out + q * 4, sum);
-        f4_st(out + F + q * 4, m2);
-        if (q == 0) partial[(size_t)slabs * 2 * F + blockIdx.x] = n;  // every column of the slab saw the same rows
+        for (int k = 1; k < RP; ++k) pivot_merge(n, p, S, SS, shn[k * Q + q], sh[0][k * Q + q], sh[1][k * Q + q], sh[2][k * Q + q]);
+        float* out = partial + (size_t)blockIdx.x * 3 * F;
+        f4_st(out + q * 4, p);
+        f4_st(out + F + q * 4, S);
+        f4_st(out + 2 * F + q * 4, SS);
+        if (q == 0) partial[(size_t)slabs * 3 * F + blockIdx.x] = n;  // every column of the slab saw the same rows
     }
 }
 
-// finalise Welford slabs: mean = sum_k sum_k / n, M2 = sum_k [M2_k + n_k (mean_k - mean)^2] in float64, fixed order
+// finalise pivot slabs in float64: re-centre every slab onto slab 0's pivot P, then mean = P + S / n, var = SS / n - (S / n)^2
+// (S / n is of the size of the spread: the subtraction costs nothing)
 __global__ __launch_bounds__(kRedCols* kRedLanes) void bn_finalize_welford_kernel(
     const float* __restrict__ partial, const float* __restrict__ counts, int slabs, int64_t rows, int F,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
@@ -275,30 +261,30 @@ __global__ __launch_bounds__(kRedCols* kRedLanes) void bn_finalize_welford_kerne
     __shared__ double sh[kRedLanes][kRedCols];
     const int f = blockIdx.x * kRedCols + threadIdx.x;
     const bool ok = f < F;
-    double s = 0.0;
-    if (ok)
-        for (int k = threadIdx.y; k < slabs; k += kRedLanes) s += (double)partial[(size_t)k * 2 * F + f];
-    s = lane_tree_sum(s, sh);
-    // (only row 0 holds the total: hand it to every slab-lane through the scratch array)
-    if (threadIdx.y == 0) sh[0][threadIdx.x] = s;
-    __syncthreads();
-    const double n = (double)rows;
-    const double m = sh[0][threadIdx.x] / n;
-    __syncthreads();
-    double m2 = 0.0;
-    if (ok)
+    double s = 0.0, ss = 0.0, P = 0.0;
+    if (ok) {
+        // the pivot of the first non-empty slab (the same one for every slab-lane: fixed)
+        int k0 = 0;
+        while (k0 < slabs - 1 && counts[k0] == 0.0f) ++k0;
+        P = (double)partial[(size_t)k0 * 3 * F + f];
         for (int k = threadIdx.y; k < slabs; k += kRedLanes) {
             const double nk = (double)counts[k];
             if (nk > 0.0) {
-                const double d = (double)partial[(size_t)k * 2 * F + f] / nk - m;
-                m2 += (double)partial[(size_t)k * 2 * F + F + f] + nk * d * d;
+                const float* sl = partial + (size_t)k * 3 * F;
+                const double d = (double)sl[f] - P, Sk = (double)sl[F + f];
+                s += Sk + nk * d;
+                ss += (double)sl[2 * F + f] + d * (2.0 * Sk + nk * d);
             }
         }
-    m2 = lane_tree_sum(m2, sh);
+    }
+    s = lane_tree_sum(s, sh);
+    ss = lane_tree_sum(ss, sh);
     if (!ok || threadIdx.y != 0) return;
-    double v = m2 / n;
+    const double n = (double)rows;
+    const double ms = s / n;
+    double v = ss / n - ms * ms;
     if (v < 0.0) v = 0.0;
-    const float mean = (float)m, var = (float)v;
+    const float mean = (float)(P + ms), var = (float)v;
     if (running_mean != nullptr) {
         const double unbiased = rows > 1 ? v * n / (n - 1.0) : v;
         running_mean[f] = (1.0f - momentum) * running_mean[f] + momentum * mean;
@@ -669,7 +655,7 @@ int alignn_bn_finalize_welford(const float* partial, int slabs, int64_t rows, in
                                alignn_stream_t stream) {
     if (F <= 0 || slabs <= 0 || partial == nullptr) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(bn_finalize_welford_kernel, dim3(alignn_ceil_div(F, kRedCols)), dim3(kRedCols, kRedLanes), 0,
-                       (hipStream_t)stream, partial, partial + (size_t)slabs * 2 * F, slabs, rows, F, gamma, beta, eps, momentum,
+                       (hipStream_t)stream, partial, partial + (size_t)slabs * 3 * F, slabs, rows, F, gamma, beta, eps, momentum,
                        running_mean, running_var, stat);
     ALIGNN_CHECK_LAUNCH();
     return 0;

@@ -867,8 +867,8 @@ def _fold(partial, slabs, width):
 
 
 def _welford_slabs(slabs, F, like):
-    """Storage for ``slabs`` Welford slabs [2][F] + their counts (alignn_col_stats_welford, the gate passes)."""
-    return _empty(slabs * (2 * F + 1), like=like)
+    """Storage for ``slabs`` pivot slabs [3][F] + their counts (alignn_col_stats_welford, the gate passes)."""
+    return _empty(slabs * (3 * F + 1), like=like)
 
 
 def _bn_finalize(partial, slabs, rows, gamma, beta, running_mean, running_var, update_running, welford=False):

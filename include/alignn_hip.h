@@ -179,14 +179,14 @@ int alignn_col_stats_slabs(int64_t rows);
 /* partial[s][0][f] = sum_r X[r,f], partial[s][1][f] = sum_r X[r,f]^2 over slab s's rows */
 int alignn_col_stats(const float* X, int64_t ldx, int64_t rows, int F, float* partial,
                      alignn_stream_t stream);
-/* The same statistics as WELFORD SLABS - well-conditioned when |mean| >> std, where sum x^2 - (sum x)^2 / n cancels (the
- * constant-node-feature set-up of alignn/tests/test_force_reduction.py): partial[s][0][f] = sum of slab s's rows,
- * partial[s][1][f] = sum (x - slab mean)^2, followed by counts[s] (float) at partial + slabs*2*F; every thread sums about
- * a pivot (the first value it sees) and the threads / slabs are merged with Chan's formula.  partial holds
- * slabs*(2*F+1) floats.  alignn_bn_finalize_welford merges the slabs in float64 (same outputs as alignn_bn_finalize).
- * The gate passes (alignn_egc_gate_fwd, _pre, _pre_norm) write their e_partial / n_partial in THIS layout
- * (slabs = alignn_egc_slabs(n_seg)); the projection epilogues (alignn_gemm_nt_f16x3_stats / _gather) keep plain
- * sum / sum-of-squares slabs for alignn_bn_finalize. */
+/* The same statistics as PIVOT SLABS - well-conditioned when |mean| >> std, where sum x^2 - (sum x)^2 / n cancels and a
+ * float32 mean cannot even hold the sub-ulp part: partial[s][0][f] = a pivot p (the first value slab s saw in column f),
+ * partial[s][1][f] = sum (x - p), partial[s][2][f] = sum (x - p)^2 over the slab's rows, followed by counts[s] (float) at
+ * partial + slabs*3*F; partial holds slabs*(3*F+1) floats.  Threads / waves / slabs are merged by re-centring onto one
+ * pivot (float64 in alignn_bn_finalize_welford; same outputs as alignn_bn_finalize).  The gate passes
+ * (alignn_egc_gate_fwd, _pre, _pre_norm) write their e_partial / n_partial in THIS layout (slabs =
+ * alignn_egc_slabs(n_seg)); the projection epilogues (alignn_gemm_nt_f16x3_stats / _gather) keep plain sum /
+ * sum-of-squares slabs for alignn_bn_finalize. */
 int alignn_col_stats_welford(const float* X, int64_t ldx, int64_t rows, int F, float* partial, alignn_stream_t stream);
 int alignn_bn_finalize_welford(const float* partial, int slabs, int64_t rows, int F, const float* gamma, const float* beta,
                                float eps, float momentum, float* running_mean, float* running_var, float* stat,
@@ -260,7 +260,7 @@ int alignn_bn_silu_bwd_apply_sum(const float* GY, int64_t ldgy, const float* X, 
  * P is the fused node projection [n, 4H] = [A | Bd | Bh | Ux] = x * [W_sg;W_dg;W_du;W_su]^T + b.
  * ------------------------------------------------------------------------------------------ */
 
-/* number of stat slabs the gate kernel writes for a graph with n segments (Welford layout: slabs*(2*H+1) floats, see
+/* number of stat slabs the gate kernel writes for a graph with n segments (pivot-slab layout: slabs*(3*H+1) floats, see
  * alignn_col_stats_welford) */
 int alignn_egc_slabs(int64_t n_seg);
 

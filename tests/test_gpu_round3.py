@@ -359,13 +359,13 @@ def test_welford_column_statistics_are_well_conditioned(rows, F, offset):
     gamma, beta = torch.ones(F, device=DEV), torch.zeros(F, device=DEV)
     rm, rv = torch.zeros(F, device=DEV), torch.ones(F, device=DEV)
     slabs = lib.alignn_col_stats_slabs(rows)
-    partial = torch.empty(slabs * (2 * F + 1), device=DEV)
+    partial = torch.empty(slabs * (3 * F + 1), device=DEV)
     stat = torch.empty(4, F, device=DEV)
     check(lib.alignn_col_stats_welford(ptr(X), F, rows, F, ptr(partial), stream()), "col_stats_welford")
     check(lib.alignn_bn_finalize_welford(ptr(partial), slabs, rows, F, ptr(gamma), ptr(beta), 1e-5, 0.1, ptr(rm), ptr(rv),
                                          ptr(stat), stream()), "bn_finalize_welford")
     torch.cuda.synchronize()
-    assert float(partial[slabs * 2 * F:].sum()) == rows  # the slabs' counts
+    assert float(partial[slabs * 3 * F:].sum()) == rows  # the slabs' counts
     mean64, var64 = X64.mean(0), X64.var(0, unbiased=False)
     rstd64 = 1.0 / torch.sqrt(var64 + 1e-5)
     assert float((stat[0].double().cpu() - mean64).abs().max()) <= 2e-7 * float(mean64.abs().max() + 1.0)
@@ -374,11 +374,13 @@ def test_welford_column_statistics_are_well_conditioned(rows, F, offset):
     assert float(((rv.double().cpu() - (0.9 + 0.1 * unb)) / (0.9 + 0.1 * unb)).abs().max()) < 1e-5
 
 
-def test_conv_with_constant_node_features_matches_float64():
-    """The regime of the reference's force test (alignn/tests/test_force_reduction.py: x = ones): every atom's
-    pre-activation differs only through the gate's 1e-6 / the bond sums, |mean| >> std on the node norm.  Output of the
-    float32 kernels against the float64 torch path of the SAME module."""
+def test_conv_with_nearly_constant_node_features_matches_float64():
+    """Node features 1 + 1e-2 * noise: |mean| / std = 100 on every norm input, i.e. sum x^2 - (sum x)^2 / n would lose four
+    of float32's seven digits.  Output of the float32 kernels against the float64 torch path of the SAME module.  (The
+    reference's own set-up, x = ones exactly, is not resolvable in float32 at all: there the atoms' pre-activations differ
+    in the 7th digit - the DATA is below float32's resolution before any statistic is taken.)"""
     import copy
+    import warnings
 
     from alignn_amd.alignn import EdgeGatedGraphConv
     from alignn_amd.graph import build_csr
@@ -389,10 +391,11 @@ def test_conv_with_constant_node_features_matches_float64():
     csr = build_csr(u, v, raw.num_nodes)
     conv = EdgeGatedGraphConv(64, 64).to(DEV).train()
     conv64 = copy.deepcopy(conv).double()
-    x = torch.ones(raw.num_nodes, 64, device=DEV)
-    y = torch.randn(raw.num_edges, 64, device=DEV)
+    x = 1.0 + 1e-2 * torch.randn(raw.num_nodes, 64, device=DEV)
+    y = 2.0 + 1e-2 * torch.randn(raw.num_edges, 64, device=DEV)
     xo, yo = conv(csr, x, y)
-    with pytest.warns(RuntimeWarning):
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
         xo64, yo64 = conv64(csr, x.double(), y.double())
     for a, b in ((xo, xo64), (yo, yo64)):
         assert float((a.double() - b).abs().max()) < 2e-4 * float(b.abs().max())
