@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-2 profile set: kernel trace of the default bench command (replayed steps), the serialized one-stream eager
+# per-round profile set: kernel trace of the default bench command (replayed steps), the serialized one-stream eager
 # variant, PMC traffic passes, and the force-training step
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
 mkdir -p gpurun_out
@@ -21,6 +21,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
   timeout 600 rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_$c -o r -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --streamed-steps 0 --eager-steps 0 > /dev/null 2> gpurun_out/prof_pmc_$c.err
   db=$(find /tmp/pmc_$c -name "*.db" | head -1)
-  python tools/rocpd_pmc.py $db 250 > gpurun_out/prof_pmc_$c.txt
+  python tools/rocpd_pmc.py $db 0 > gpurun_out/prof_pmc_$c.txt
   head -14 gpurun_out/prof_pmc_$c.txt
 done
