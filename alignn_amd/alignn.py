@@ -301,7 +301,8 @@ def _prepare_split_weights(model: nn.Module):
         prep = model.__dict__["_weight_prep"] = ops.WeightPrep()
     if prep.modules is None:  # (the module tree is walked once; the weights are looked up afresh every step)
         prep.modules = ([m for m in model.modules() if isinstance(m, EdgeGatedGraphConv)],
-                        [m for m in model.modules() if isinstance(m, MLPLayer) and m.layer[0].weight.shape[0] >= 128])
+                        [m for m in model.modules() if isinstance(m, MLPLayer) and m.layer[0].weight.shape[0] >= 128
+                         and m.layer[0].weight.shape[0] % 16 == 0 and m.layer[0].weight.shape[1] % 16 == 0])
     convs, mlps = prep.modules
     ws = []
     for m in convs:

@@ -439,6 +439,9 @@ _W_IMG = {}  # id(w) -> (weakref, stamp, SplitWeight of w): images made ahead of
 BATCHED_WEIGHT_PREP = _os.environ.get("ALIGNN_AMD_WEIGHT_PREP", "1") != "0"  # tests flip it: same bits
 
 
+WEIGHT_PREP_STATS = {"runs": 0, "weights": 0}
+
+
 class WeightPrep:
     """max|W| and both slice images of all split-product weights of a model in ONE call per step
     (alignn_prepare_weights: a memset + two launches instead of two launches per weight, 26 weights at the default
@@ -486,6 +489,8 @@ class WeightPrep:
             self.refs = [(id(w), weakref.ref(w, lambda _r, k_=id(w): (_W_IMG.pop(k_, None), _W_IMG_T.pop(k_, None),
                                                                       _W_AMAX.pop(k_, None)))) for w in weights]
         check(_lib.load().alignn_prepare_weights(ptr(self.desc), len(weights), ptr(self.amax), stream()), "prepare_weights")
+        WEIGHT_PREP_STATS["runs"] += 1
+        WEIGHT_PREP_STATS["weights"] += len(weights)
         gen = _WGEN[0]
         for w, (k_, ref), (sw, sw_t) in zip(weights, self.refs, self.images):
             st = (w._version, gen)

@@ -63,6 +63,9 @@ def parse():
                     help="extra informational run with a fresh batch per step through alignn_amd.loader (0: skip)")
     ap.add_argument("--cpu-graphs", type=int, default=None,
                     help="graphs in the CPU-baseline sample (default: the same batch as the GPU run)")
+    ap.add_argument("--no-micro", action="store_true",
+                    help="skip the stand-alone micro-timings of the projection kernels (PMC passes: everything left in the "
+                         "profile is then step work)")
     ap.add_argument("--eager-steps", type=int, default=5,
                     help="extra informational run of this many eagerly launched steps on the resident batch (0: skip)")
     return ap.parse_args()
@@ -548,15 +551,19 @@ def main():
         # read z + write C = 2*T*H*4 (the 256 KiB of sliced weights stay in L2).  Timed live with HIP events on
         # the launch stream.  The six-product bf16 variant (used when max|z| is unknown) and the exact-fp32 MFMA
         # kernel are timed beside it for reference.
-        zt = torch.randn(T, H, device=dev)
-        w = torch.randn(H, H, device=dev) / 16
-        bz = torch.randn(H, device=dev)
-        buf = torch.empty(T, H, device=dev)
-        ws = ops.split_bf16x3(w)
-        wh, z_amax = ops.split_f16x2(w), ops.absmax(zt)
-        t_h3 = time_kernel(lambda: ops.gemm_nt_f16x3(zt, z_amax, wh, bz, out=buf))
-        t_x6 = time_kernel(lambda: ops.gemm_nt_x6(zt, ws, bz, out=buf))
-        t_f32 = time_kernel(lambda: ops.gemm_nt(zt, w, bz, out=buf))
+        if not args.no_micro:
+            zt = torch.randn(T, H, device=dev)
+            w = torch.randn(H, H, device=dev) / 16
+            bz = torch.randn(H, device=dev)
+            buf = torch.empty(T, H, device=dev)
+            ws = ops.split_bf16x3(w)
+            wh, z_amax = ops.split_f16x2(w), ops.absmax(zt)
+        if args.no_micro:
+            t_h3 = t_x6 = t_f32 = float("nan")
+        else:
+            t_h3 = time_kernel(lambda: ops.gemm_nt_f16x3(zt, z_amax, wh, bz, out=buf))
+            t_x6 = time_kernel(lambda: ops.gemm_nt_x6(zt, ws, bz, out=buf))
+            t_f32 = time_kernel(lambda: ops.gemm_nt(zt, w, bz, out=buf))
         flops = 2.0 * T * H * H
         gemm_bytes = 2.0 * T * H * 4
         gbs = gemm_bytes / (t_h3 * 1e-3) / 1e9
@@ -663,6 +670,15 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        if args.no_micro:  # (the skipped micro-timings are NaN placeholders: not valid JSON)
+            def scrub(o):
+                if isinstance(o, dict):
+                    return {k: scrub(v) for k, v in o.items()}
+                if isinstance(o, float) and o != o:
+                    return None
+                return o
+
+            out = scrub(out)
         emit(out)
 
 

@@ -334,7 +334,11 @@ def test_batched_weight_preparation_gives_the_same_bits():
         finally:
             ops.BATCHED_WEIGHT_PREP = prev
 
-    a, b = run(True), run(False)
+    ops.WEIGHT_PREP_STATS["runs"] = ops.WEIGHT_PREP_STATS["weights"] = 0
+    a = run(True)
+    assert ops.WEIGHT_PREP_STATS["runs"] == 3 and ops.WEIGHT_PREP_STATS["weights"] == 3 * 26, ops.WEIGHT_PREP_STATS
+    b = run(False)
+    assert ops.WEIGHT_PREP_STATS["runs"] == 3
     for k in a:
         assert torch.equal(a[k], b[k]), k
 

@@ -19,7 +19,7 @@ BARGS="" prof serialized ALIGNN_BENCH_EAGER=1 ALIGNN_AMD_SIDE_STREAM=0 ALIGNN_AM
 BARGS="--model alignn_ff --batch 16 --atoms 200" prof cfg4_ff ALIGNN_AMD_SIDE_STREAM=0
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
-  timeout 600 rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_$c -o r -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --streamed-steps 0 --eager-steps 0 > /dev/null 2> gpurun_out/prof_pmc_$c.err
+  timeout 600 rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_$c -o r -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --streamed-steps 0 --eager-steps 0 --no-micro > /dev/null 2> gpurun_out/prof_pmc_$c.err
   db=$(find /tmp/pmc_$c -name "*.db" | head -1)
   python tools/rocpd_pmc.py $db 0 > gpurun_out/prof_pmc_$c.txt
   head -14 gpurun_out/prof_pmc_$c.txt
