@@ -1190,6 +1190,131 @@ class MLPLayerFn(torch.autograd.Function):
 
 
 # ---------------------------------------------------------------------------------------------
+# RBFExpansion + MLPLayer fused (the head of the edge / angle embeddings, alignn/models/alignn.py:201-222)
+# ---------------------------------------------------------------------------------------------
+RBF_MLP_FUSED = _os.environ.get("ALIGNN_AMD_RBF_MLP", "1") != "0"  # tests flip it to compare with RBF -> MLPLayer
+
+
+def rbf_mlp_applies(d, w, norm):
+    """Can ``RbfMLPLayerFn`` take this embedding head?  BatchNorm flavour, no gradient w.r.t. the distances / cosines
+    (the force paths differentiate them: those keep the materialised RBF expansion), supported widths."""
+    return (RBF_MLP_FUSED and norm == "batch" and d.is_cuda and d.dtype == torch.float32 and not d.requires_grad
+            and w.dtype == torch.float32 and bool(_lib.load().alignn_rbf_mlp_supported(w.shape[0], w.shape[1])))
+
+
+class RbfMLPLayerFn(torch.autograd.Function):
+    """y = silu(BatchNorm(rbf(d) W^T + b)) without materialising the RBF matrix or the pre-activation
+    (csrc/rbf_mlp.hip).  T-row inputs (the bond-angle cosines) run on lane T inside ``lanes()``."""
+
+    @staticmethod
+    def _fwd(ctx, d, centers, gamma_rbf, Wt, b, gamma, beta, rm, rv, training):
+        lib = _lib.load()
+        rows, (bins, F) = d.numel(), Wt.shape
+        if training:
+            slabs = lib.alignn_rbf_mlp_slabs(rows)
+            partial = _welford_slabs(slabs, F, d)
+            check(lib.alignn_rbf_mlp_stats(ptr(d), ptr(centers), gamma_rbf, ptr(Wt), ptr(b), rows, bins, F, ptr(partial),
+                                           stream()), "rbf_mlp_stats")
+            stat = _bn_finalize(partial, slabs, rows, gamma, beta, rm, rv, True, welford=True)
+        else:
+            stat = _bn_finalize(None, 0, rows, gamma, beta, rm, rv, False)
+        y = _empty(rows, F, like=d)
+        amax = new_amax(d) if _track(rows) else None
+        check(lib.alignn_rbf_mlp_fwd(ptr(d), ptr(centers), gamma_rbf, ptr(Wt), ptr(b), rows, bins, F, ptr(stat), ptr(y),
+                                     ptr(amax), stream()), "rbf_mlp_fwd")
+        if amax is not None:
+            set_amax(y, amax)
+        return y, stat
+
+    @staticmethod
+    def forward(ctx, d, centers, gamma_rbf, w, b, gamma, beta, running_mean, running_var, training):
+        require_f32(d, centers, w, b, gamma, beta)
+        d = d.contiguous().reshape(-1)
+        lane = _lane_for(d.numel())
+        ctx.lane = lane is not None
+        if lane is not None:
+            with _on_T(*lane, reads=(d,)):
+                Wt = w.t().contiguous()
+                y, stat = RbfMLPLayerFn._fwd(ctx, d, centers, float(gamma_rbf), Wt, b, gamma, beta, running_mean, running_var,
+                                             training)
+            _mark_on_T(y)
+        else:
+            _main_reads(d)
+            Wt = w.t().contiguous()
+            y, stat = RbfMLPLayerFn._fwd(ctx, d, centers, float(gamma_rbf), Wt, b, gamma, beta, running_mean, running_var,
+                                         training)
+        ctx.save_for_backward(d, centers, Wt, b, stat, gamma, beta)
+        ctx.gamma_rbf = float(gamma_rbf)
+        ctx.training = training
+        ctx.param_grads = _PARAM_GRADS["on"]
+        ctx.wb = (w, b)
+        return y
+
+    @staticmethod
+    def _bwd(ctx, gy, d, centers, Wt, b, stat):
+        lib = _lib.load()
+        rows, (bins, F) = d.numel(), Wt.shape
+        slabs = lib.alignn_rbf_mlp_slabs(rows)
+        red = None
+        if ctx.training:
+            part = _empty(slabs, 2, F, like=d)
+            check(lib.alignn_rbf_mlp_bwd_reduce(ptr(d), ptr(centers), ctx.gamma_rbf, ptr(Wt), ptr(b), rows, bins, F, ptr(stat),
+                                                ptr(gy), ptr(part), stream()), "rbf_mlp_bwd_reduce")
+            red = _empty(2, F, like=d)
+            check(lib.alignn_bn_bwd_finalize(ptr(part), slabs, F, ptr(red), stream()), "bn_bwd_finalize")
+        gpre = _empty(rows, F, like=d)
+        gb_part = _empty(slabs, F, like=d)
+        check(lib.alignn_rbf_mlp_bwd_apply(ptr(d), ptr(centers), ctx.gamma_rbf, ptr(Wt), ptr(b), rows, bins, F, ptr(stat),
+                                           ptr(gy), ptr(red), int(not ctx.training), ptr(gpre), ptr(gb_part), None, stream()),
+              "rbf_mlp_bwd_apply")
+        return gpre, gb_part, red, slabs
+
+    @staticmethod
+    def backward(ctx, gy):
+        lib = _lib.load()
+        d, centers, Wt, b, stat, gamma, beta = ctx.saved_tensors
+        gy = gy.contiguous()
+        bins, F = Wt.shape
+        rows = d.numel()
+        ev = None
+        if ctx.lane:
+            main, T = _lane_streams(gy.device)
+            with _on_T(main, T, reads=(gy,)):
+                gpre, gb_part, red, slabs = RbfMLPLayerFn._bwd(ctx, gy, d, centers, Wt, b, stat)
+            ev = _event_after(T)
+            if not ctx.param_grads or _deferred_join_is_safe((gamma, beta)):
+                _arm_backward_join()
+            else:
+                main.wait_event(ev)
+                if red is not None:
+                    red.record_stream(main)
+        else:
+            _main_reads(gy)
+            gpre, gb_part, red, slabs = RbfMLPLayerFn._bwd(ctx, gy, d, centers, Wt, b, stat)
+        if not ctx.param_grads:
+            return (None,) * 10
+        if red is None:  # eval mode: the norm's affine parameters still receive gradients through z = (x - mean) scale + beta
+            raise NotImplementedError("RbfMLPLayerFn: parameter gradients in eval mode are not implemented (use the unfused layers)")
+
+        def _wgrads():
+            wpart = _empty(slabs, F * bins, like=d)
+            check(lib.alignn_rbf_mlp_wgrad(ptr(d), ptr(centers), ctx.gamma_rbf, ptr(gpre), rows, bins, F, ptr(wpart), stream()),
+                  "rbf_mlp_wgrad")
+            gw = _empty(F, bins, like=d)
+            check(lib.alignn_slab_sum(ptr(wpart), slabs, F * bins, ptr(gw), stream()), "slab_sum")
+            gb = _empty(F, like=d)
+            check(lib.alignn_slab_sum(ptr(gb_part), slabs, F, ptr(gb), stream()), "slab_sum")
+            return gw, gb
+
+        gw, gb = on_side_stream(_wgrads, [gpre, d, gb_part], ctx.wb, wait=(ev,))
+        return None, None, None, gw, gb, red[1], red[0], None, None, None
+
+
+def rbf_mlp_layer(d, centers, gamma_rbf, w, b, gamma, beta, running_mean, running_var, training):
+    return RbfMLPLayerFn.apply(d, centers, gamma_rbf, w, b, gamma, beta, running_mean, running_var, training)
+
+
+# ---------------------------------------------------------------------------------------------
 # EdgeGatedGraphConv   (alignn/models/alignn.py:78-129)
 # ---------------------------------------------------------------------------------------------
 # Composite entry points (csrc/composite.hip): the launches of a convolution's forward / backward issued by ONE C call each

@@ -403,3 +403,81 @@ def test_conv_with_nearly_constant_node_features_matches_float64():
         xo64, yo64 = conv64(csr, x.double(), y.double())
     for a, b in ((xo, xo64), (yo, yo64)):
         assert float((a.double() - b).abs().max()) < 2e-4 * float(b.abs().max())
+
+
+# ---------------------------------------------------------------------------------------------
+# RBF expansion + first embedding layer fused (csrc/rbf_mlp.hip)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,bins,F", [(1, 40, 64), (1000, 40, 64), (50712, 80, 64), (200001, 40, 64), (333, 20, 16), (4097, 128, 48)])
+def test_fused_rbf_mlp_layer_against_float64(rows, bins, F):
+    """forward, BatchNorm running statistics, and all five gradients (W, b, gamma, beta of the fused layer; via a loss that
+    weights every output) against the same layer in float64 torch."""
+    from alignn_amd.alignn import MLPLayer, RBFExpansion
+
+    torch.manual_seed(rows + bins)
+    rbf = RBFExpansion(vmin=-1, vmax=1.0, bins=bins).to(DEV)
+    layer = MLPLayer(bins, F).to(DEV).train()
+    with torch.no_grad():
+        layer.layer[1].weight.uniform_(0.5, 1.5)
+        layer.layer[1].bias.uniform_(-0.5, 0.5)
+    d = (torch.rand(rows, device=DEV) * 2 - 1)
+    coef = torch.randn(rows, F, device=DEV)
+    lin, bn = layer.layer[0], layer.layer[1]
+    y = ops.rbf_mlp_layer(d, rbf.centers, rbf.gamma, lin.weight, lin.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, True)
+    (y * coef).sum().backward()
+    torch.cuda.synchronize()
+    # float64 reference
+    W, b, g, be = (t.detach().double().cpu().requires_grad_(True) for t in (lin.weight, lin.bias, bn.weight, bn.bias))
+    d64 = d.double().cpu()
+    r = torch.exp(-rbf.gamma * (d64[:, None] - rbf.centers.double().cpu()) ** 2)
+    pre = r @ W.t() + b
+    mean, var = pre.mean(0), pre.var(0, unbiased=False)
+    y64 = torch.nn.functional.silu((pre - mean) / torch.sqrt(var + 1e-5) * g + be)
+    (y64 * coef.double().cpu()).sum().backward()
+    assert float((y.double().cpu() - y64).abs().max()) < 2e-5 * float(y64.abs().max() + 1e-30) if rows > 1 else True
+    for name, mine, ref in (("W", lin.weight.grad, W.grad), ("gamma", bn.weight.grad, g.grad), ("beta", bn.bias.grad, be.grad)):
+        if rows > 1:
+            assert float((mine.double().cpu() - ref).abs().max()) < 2e-4 * float(ref.abs().max() + 1e-30), name
+    if rows > 1:
+        assert float(lin.bias.grad.abs().max()) < 1e-3 * float(coef.abs().sum(0).max())  # analytically zero (bias before BatchNorm)
+        unb = pre.var(0, unbiased=True).detach()
+        assert float((bn.running_mean.double().cpu() - 0.1 * mean.detach()).abs().max()) < 1e-6 * float(mean.abs().max() + 1)
+        assert float(((bn.running_var.double().cpu() - (0.9 + 0.1 * unb)) / (0.9 + 0.1 * unb)).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("case", ["small", "default_16x60"])
+def test_fused_embedding_head_equals_the_unfused_layers(case):
+    """A training step with the fused RBF + first embedding layer against RBFExpansion -> MLPLayer (GEMM path): same
+    model state to rounding."""
+    if case == "small":
+        raw = make_batch(5, 16, seed0=78)
+
+        def mk():
+            torch.manual_seed(21)
+            return ALIGNN(ALIGNNConfig(name="alignn", alignn_layers=2, gcn_layers=1, hidden_features=64,
+                                       embedding_features=32)).to(DEV).train()
+    else:
+        raw = make_batch(16, 60, seed0=77)
+
+        def mk():
+            torch.manual_seed(0)
+            return ALIGNN(ALIGNNConfig(name="alignn")).to(DEV).train()
+    batch = GraphBatch.from_raw(raw, device=DEV)
+    target = torch.randn(raw.batch_size, generator=torch.Generator().manual_seed(2)).to(DEV)
+
+    def run(flag):
+        prev = ops.RBF_MLP_FUSED
+        ops.RBF_MLP_FUSED = flag
+        try:
+            return _train_state(mk, batch, target, True, steps=1)[0]
+        finally:
+            ops.RBF_MLP_FUSED = prev
+
+    a, b = run(True), run(False)
+    gmax = max(float(v.abs().max()) for k, v in b.items() if k.startswith("g."))
+    for k in b:
+        if not b[k].is_floating_point():
+            assert torch.equal(a[k], b[k]), k
+            continue
+        scale = max(float(b[k].abs().max()), 1e-3 * gmax if k.startswith("g.") else 1e-12)
+        assert float((a[k] - b[k]).abs().max()) <= 2e-4 * scale, (k, float((a[k] - b[k]).abs().max()), scale)
