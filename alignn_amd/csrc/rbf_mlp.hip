@@ -64,6 +64,55 @@ __device__ __forceinline__ void pivot_merge1(float& na, float& pa, float& Sa, fl
     na += nb;
 }
 
+// A wave's tile = 64 consecutive rows of a [rows][F] matrix = ONE contiguous run of 64 F floats: moved as F / 4 float4 per
+// lane (whole 1 KiB segments per instruction, all loads in flight at once) to / from the LDS tile [64][F + 1].
+template <int F>
+__device__ __forceinline__ void tile_load(const float* __restrict__ G, int64_t r0, int valid, float* tl, int lane) {
+    constexpr int LD = F + 1;
+    float4 v[F / 4];
+#pragma unroll
+    for (int q = 0; q < F / 4; ++q) {
+        const int e = (q * 64 + lane) * 4;  // flat element of the tile
+        v[q] = (e / F) < valid ? f4_ld(G + r0 * F + e) : f4_zero();
+    }
+#pragma unroll
+    for (int q = 0; q < F / 4; ++q) {
+        const int e = (q * 64 + lane) * 4;
+        float* o = tl + (e / F) * LD + (e % F);
+        o[0] = v[q].x, o[1] = v[q].y, o[2] = v[q].z, o[3] = v[q].w;
+    }
+}
+template <int F>
+__device__ __forceinline__ float tile_store(float* __restrict__ Y, int64_t r0, int valid, const float* tl, int lane) {
+    constexpr int LD = F + 1;
+    float am = 0.0f;
+#pragma unroll
+    for (int q = 0; q < F / 4; ++q) {
+        const int e = (q * 64 + lane) * 4;
+        const float* o = tl + (e / F) * LD + (e % F);
+        const float4 v = make_float4(o[0], o[1], o[2], o[3]);
+        if ((e / F) < valid) {
+            f4_st(Y + r0 * F + e, v);
+            am = fmaxf(am, f4_absmax(v));
+        }
+    }
+    return am;
+}
+// column sum over the tile's 64 rows for column `lane` (rows past `valid` hold zeros)
+template <int F>
+__device__ __forceinline__ float tile_colsum(const float* tl, int lane) {
+    constexpr int LD = F + 1;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 64; i += 4) {
+        s0 += tl[i * LD + lane];
+        s1 += tl[(i + 1) * LD + lane];
+        s2 += tl[(i + 2) * LD + lane];
+        s3 += tl[(i + 3) * LD + lane];
+    }
+    return (s0 + s1) + (s2 + s3);
+}
+
 enum Mode { STATS = 0, APPLY = 1, BWD_REDUCE = 2, BWD_APPLY = 3 };
 
 // One wave = 64 consecutive rows per step; LDS tile [64][F + 1] per wave turns "lane = row" into "lane = column" for the
@@ -101,14 +150,14 @@ __global__ __launch_bounds__(kThreads) void rbf_mlp_kernel(
 #pragma unroll
             for (int j = 0; j < F; ++j) tl[lane * LD + j] = acc[j];
             if (lane < F) {
-                for (int i = 0; i < valid; ++i) {
-                    const float v = tl[i * LD + lane];
-                    if (cn == 0.0f) cp = v;
-                    const float dv = v - cp;
+                if (cn == 0.0f) cp = tl[lane];  // (row r0 is always valid)
+#pragma unroll 16
+                for (int i = 0; i < 64; ++i) {
+                    const float dv = i < valid ? tl[i * LD + lane] - cp : 0.0f;
                     cS += dv;
                     cSS = fmaf(dv, dv, cSS);
-                    cn += 1.0f;
                 }
+                cn += (float)valid;
             }
         } else if (MODE == APPLY) {
 #pragma unroll
@@ -116,18 +165,10 @@ __global__ __launch_bounds__(kThreads) void rbf_mlp_kernel(
                 const float z = fmaf(acc[j] - stat[j], stat[2 * F + j], stat[3 * F + j]);
                 tl[lane * LD + j] = silu_f(z);
             }
-            // rows of the tile as 256-byte-or-so segments: lane l writes column l of row i
-            for (int i = 0; i < valid; ++i) {
-                if (lane < F) {
-                    const float v = tl[i * LD + lane];
-                    Y[(r0 + i) * F + lane] = v;
-                    am = fmaxf(am, fabsf(v));
-                }
-            }
+            am = fmaxf(am, tile_store<F>(Y, r0, valid, tl, lane));
         } else {
-            // gy tile in (coalesced), then lane = row again
-            for (int i = 0; i < valid; ++i)
-                if (lane < F) tl[i * LD + lane] = GY[(r0 + i) * F + lane];
+            // gy tile in (coalesced float4, all in flight), then lane = row again
+            tile_load<F>(GY, r0, valid, tl, lane);
             float gz[F], xh[F];
 #pragma unroll
             for (int j = 0; j < F; ++j) {
@@ -139,12 +180,10 @@ __global__ __launch_bounds__(kThreads) void rbf_mlp_kernel(
             if (MODE == BWD_REDUCE) {
 #pragma unroll
                 for (int j = 0; j < F; ++j) tl[lane * LD + j] = gz[j];
-                if (lane < F)
-                    for (int i = 0; i < valid; ++i) cS += tl[i * LD + lane];
+                if (lane < F) cS += tile_colsum<F>(tl, lane);
 #pragma unroll
                 for (int j = 0; j < F; ++j) tl[lane * LD + j] = gz[j] * xh[j];
-                if (lane < F)
-                    for (int i = 0; i < valid; ++i) cSS += tl[i * LD + lane];
+                if (lane < F) cSS += tile_colsum<F>(tl, lane);
             } else {  // BWD_APPLY
 #pragma unroll
                 for (int j = 0; j < F; ++j) {
@@ -153,16 +192,10 @@ __global__ __launch_bounds__(kThreads) void rbf_mlp_kernel(
                         o = gz[j] * stat[2 * F + j];
                     else
                         o = stat[2 * F + j] * (gz[j] - inv_n * (red[j] + xh[j] * red[F + j]));
-                    tl[lane * LD + j] = o;
+                    tl[lane * LD + j] = row_ok ? o : 0.0f;
                 }
-                for (int i = 0; i < valid; ++i) {
-                    if (lane < F) {
-                        const float v = tl[i * LD + lane];
-                        Y[(r0 + i) * F + lane] = v;
-                        cS += v;
-                        am = fmaxf(am, fabsf(v));
-                    }
-                }
+                if (lane < F) cS += tile_colsum<F>(tl, lane);
+                am = fmaxf(am, tile_store<F>(Y, r0, valid, tl, lane));
             }
         }
     }
@@ -202,52 +235,81 @@ __global__ __launch_bounds__(kThreads) void rbf_mlp_kernel(
     if (MODE == APPLY || MODE == BWD_APPLY) block_amax_commit(am, amax);
 }
 
-// Weight gradient dW[j][k] = sum_t G[t][j] rbf_k(d_t): lane j owns row j of dW (bins accumulators); the rbf values of a
-// row are computed by lanes k < bins (one exponential each) and broadcast lane by lane.  Slabs [grid][F][bins].
+// Weight gradient dW[j][k] = sum_t G[t][j] rbf_k(d_t).  Per 64-row tile: G goes to LDS by float4 (coalesced, all in
+// flight), every lane (= row) writes its `bins` rbf values to LDS as R[k][row]; then lane j walks the 64 rows:
+// acc[k] += G[i][j] R[k][i] with R read as wave-uniform (broadcast) float4 over four rows.  Slabs [grid][F][bins].
 template <int F, int BINS_MAX>
 __global__ __launch_bounds__(kThreads) void rbf_wgrad_kernel(const float* __restrict__ d, const float* __restrict__ centers,
                                                              float gamma, const float* __restrict__ G, int bins, int64_t rows,
                                                              float* __restrict__ partial) {
-    __shared__ float mrg[kWaves][BINS_MAX][F];
+    constexpr int LD = F + 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* tl = smem + (threadIdx.x >> 6) * (64 * LD + BINS_MAX * 64);  // per wave: G tile [64][F+1] | R [BINS_MAX][64]
+    float* R = tl + 64 * LD;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float acc[BINS_MAX];
 #pragma unroll
     for (int k = 0; k < BINS_MAX; ++k) acc[k] = 0.0f;
-    const float ck0 = lane < bins ? centers[lane] : 0.0f;
-    const float ck1 = (lane + 64) < bins ? centers[lane + 64] : 0.0f;  // bins <= 128: a second value per lane
     const int64_t n_batches = (rows + 63) / 64;
     for (int64_t b = (int64_t)blockIdx.x * kWaves + wave; b < n_batches; b += (int64_t)gridDim.x * kWaves) {
         const int64_t r0 = b * 64;
         const int valid = rows - r0 < 64 ? (int)(rows - r0) : 64;
-        const float dl = lane < valid ? d[r0 + lane] : 0.0f;  // this wave's 64 distances, one per lane
-        for (int i = 0; i < valid; ++i) {
-            const float x = __shfl(dl, i, 64);
-            const float t0 = x - ck0, t1 = x - ck1;
-            const float r_lo = __expf(-gamma * t0 * t0), r_hi = __expf(-gamma * t1 * t1);
-            const float g = lane < F ? G[(r0 + i) * F + lane] : 0.0f;
+        tile_load<F>(G, r0, valid, tl, lane);  // (rows past the end: zeros, so their rbf values do not matter)
+        const float x = lane < valid ? d[r0 + lane] : 0.0f;
+        for (int k = 0; k < bins; ++k) {
+            const float t = x - centers[k];
+            R[k * 64 + lane] = __expf(-gamma * t * t);
+        }
+        if (lane < F) {
+#pragma unroll 2
+            for (int i = 0; i < 64; i += 4) {
+                const float g0 = tl[i * LD + lane], g1 = tl[(i + 1) * LD + lane], g2 = tl[(i + 2) * LD + lane],
+                            g3 = tl[(i + 3) * LD + lane];
 #pragma unroll
-            for (int k = 0; k < BINS_MAX; ++k) {
-                if (k < bins) {
-                    const float rk = k < 64 ? __shfl(r_lo, k, 64) : __shfl(r_hi, k - 64, 64);
-                    acc[k] = fmaf(g, rk, acc[k]);
+                for (int k = 0; k < BINS_MAX; ++k) {
+                    if (k < bins) {
+                        const float4 r = *reinterpret_cast<const float4*>(R + k * 64 + i);  // same address in every lane
+                        acc[k] = fmaf(g3, r.w, fmaf(g2, r.z, fmaf(g1, r.y, fmaf(g0, r.x, acc[k]))));
+                    }
                 }
             }
         }
     }
+    // the waves' partial dW through LDS (reusing the tile space), summed in wave order
+    __syncthreads();
+    float* mrg = smem;  // [kWaves][BINS_MAX][F] <= the tiles' space (checked on the host side)
     if (lane < F) {
 #pragma unroll
-        for (int k = 0; k < BINS_MAX; ++k) mrg[wave][k][lane] = acc[k];
+        for (int k = 0; k < BINS_MAX; ++k) mrg[(wave * BINS_MAX + k) * F + lane] = acc[k];
     }
     __syncthreads();
-    // slab [F][bins]: fixed-order sum of the four waves
     for (int e = threadIdx.x; e < F * bins; e += kThreads) {
         const int j = e / bins, k = e - j * bins;
-        float s = mrg[0][k][j];
+        float sum = mrg[k * F + j];
 #pragma unroll
-        for (int w = 1; w < kWaves; ++w) s += mrg[w][k][j];
-        partial[(size_t)blockIdx.x * F * bins + e] = s;
+        for (int w = 1; w < kWaves; ++w) sum += mrg[(w * BINS_MAX + k) * F + j];
+        partial[(size_t)blockIdx.x * F * bins + e] = sum;
     }
+}
+
+template <int F, int BINS_MAX>
+constexpr size_t wgrad_lds() { return (size_t)kWaves * (64 * (F + 1) + BINS_MAX * 64) * sizeof(float); }
+
+template <int F, int BINS_MAX>
+int launch_wgrad(const float* d, const float* centers, float gamma, const float* G, int bins, int64_t rows, float* partial,
+                 int grid, hipStream_t stream) {
+    constexpr size_t lds = wgrad_lds<F, BINS_MAX>();
+    static_assert(lds <= 160 * 1024, "LDS of the weight-gradient kernel");
+    static_assert((size_t)kWaves * BINS_MAX * F * sizeof(float) <= lds, "the merge buffer reuses the tiles");
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)rbf_wgrad_kernel<F, BINS_MAX>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL((rbf_wgrad_kernel<F, BINS_MAX>), dim3(grid), dim3(kThreads), lds, stream, d, centers, gamma, G, bins, rows,
+                       partial);
+    return 0;
 }
 
 inline bool shape_ok(int F, int bins) { return (F == 16 || F == 32 || F == 48 || F == 64) && bins > 0 && bins <= 128; }
@@ -317,16 +379,15 @@ int alignn_rbf_mlp_wgrad(const float* d, const float* centers, float gamma, cons
                          float* partial, alignn_stream_t stream) {
     if (!shape_ok(F, bins) || rows < 0 || GPRE == nullptr || partial == nullptr) return (int)hipErrorInvalidValue;
     const int grid = blocks_for(rows);
+    int rc = 0;
     if (bins <= 40) {
-        RBF_DISPATCH_F(F, hipLaunchKernelGGL((rbf_wgrad_kernel<FF, 40>), dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, d, centers,
-                                             gamma, GPRE, bins, rows, partial));
+        RBF_DISPATCH_F(F, rc = (launch_wgrad<FF, 40>(d, centers, gamma, GPRE, bins, rows, partial, grid, (hipStream_t)stream)));
     } else if (bins <= 80) {
-        RBF_DISPATCH_F(F, hipLaunchKernelGGL((rbf_wgrad_kernel<FF, 80>), dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, d, centers,
-                                             gamma, GPRE, bins, rows, partial));
+        RBF_DISPATCH_F(F, rc = (launch_wgrad<FF, 80>(d, centers, gamma, GPRE, bins, rows, partial, grid, (hipStream_t)stream)));
     } else {
-        RBF_DISPATCH_F(F, hipLaunchKernelGGL((rbf_wgrad_kernel<FF, 128>), dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, d,
-                                             centers, gamma, GPRE, bins, rows, partial));
+        RBF_DISPATCH_F(F, rc = (launch_wgrad<FF, 128>(d, centers, gamma, GPRE, bins, rows, partial, grid, (hipStream_t)stream)));
     }
+    if (rc != 0) return rc;
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }

@@ -1192,7 +1192,13 @@ class MLPLayerFn(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------
 # RBFExpansion + MLPLayer fused (the head of the edge / angle embeddings, alignn/models/alignn.py:201-222)
 # ---------------------------------------------------------------------------------------------
-RBF_MLP_FUSED = _os.environ.get("ALIGNN_AMD_RBF_MLP", "1") != "0"  # tests flip it to compare with RBF -> MLPLayer
+# OFF by default: measured on MI355X at T = 676 200 rows (tools/rbf_mlp_time.py, profiles/README.md round 3) the two forward
+# passes win (66 + 81 us against rbf 30 + GEMM 86..170 + statistics 32 + normalise 45), the three backward passes lose
+# (210 + 167 + 374 us against ~250): the F x bins products of a row run on the vector ALU with wave-uniform weights from
+# scalar loads, whose latency the compiler does not hide - the step gets 1.0 ms SLOWER (16.7 vs 15.7 ms).  An MFMA
+# formulation (weights resident in registers as the B operand) would make every pass HBM-bound (~250 us in total); until
+# then the materialised RBF expansion + GEMM stays the default.  ALIGNN_AMD_RBF_MLP=1 / tests switch it on.
+RBF_MLP_FUSED = _os.environ.get("ALIGNN_AMD_RBF_MLP", "0") == "1"
 
 
 def rbf_mlp_applies(d, w, norm):

@@ -479,5 +479,7 @@ def test_fused_embedding_head_equals_the_unfused_layers(case):
         if not b[k].is_floating_point():
             assert torch.equal(a[k], b[k]), k
             continue
-        scale = max(float(b[k].abs().max()), 1e-3 * gmax if k.startswith("g.") else 1e-12)
+        # gradients: against max(own scale, 1e-3 of the largest gradient) - the Linear biases in front of BatchNorm hold
+        # rounding noise only; everything else: against the tensor's own scale
+        scale = max(float(b[k].abs().max()), 1e-3 * gmax) if k.startswith("g.") else max(float(b[k].abs().max()), 1e-6)
         assert float((a[k] - b[k]).abs().max()) <= 2e-4 * scale, (k, float((a[k] - b[k]).abs().max()), scale)
