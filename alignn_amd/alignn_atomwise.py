@@ -339,6 +339,8 @@ class ALIGNNAtomWise(nn.Module):
     def forward(self, g: Union[Sequence, GraphBatch]):
         cfg = self.config
         ops.new_weight_generation()  # (see ops._WGEN)
+        with _lib.device_guard(self.fc.weight):
+            _bn._prepare_split_weights(self)  # all weight images of the step in one call (ops.WeightPrep)
         b = self._batch(g)
         # Forces: in training the loss differentiates THROUGH them -> composed, twice-differentiable path.  In eval
         # mode (MD / calculators: alignn/ff/calculators.py) only the first derivative is needed -> the fused kernels

@@ -83,9 +83,20 @@ __global__ void rbf_bwd_kernel(const float* __restrict__ d, const float* __restr
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
         const float x = d[r];
         float acc = 0.0f;
-        for (int k = 0; k < bins; ++k) {
-            const float t = x - centers[k];
-            acc += G[r * bins + k] * __expf(-gamma * t * t) * (-2.0f * gamma * t);
+        if ((bins & 3) == 0) {  // rows are 16-byte aligned: four bins per load (the scalar form reads 4 of every 16 bytes it fetches)
+            for (int k = 0; k < bins; k += 4) {
+                const float4 g = f4_ld(G + r * bins + k);
+                const float t0 = x - centers[k], t1 = x - centers[k + 1], t2 = x - centers[k + 2], t3 = x - centers[k + 3];
+                acc += g.x * __expf(-gamma * t0 * t0) * (-2.0f * gamma * t0);
+                acc += g.y * __expf(-gamma * t1 * t1) * (-2.0f * gamma * t1);
+                acc += g.z * __expf(-gamma * t2 * t2) * (-2.0f * gamma * t2);
+                acc += g.w * __expf(-gamma * t3 * t3) * (-2.0f * gamma * t3);
+            }
+        } else {
+            for (int k = 0; k < bins; ++k) {
+                const float t = x - centers[k];
+                acc += G[r * bins + k] * __expf(-gamma * t * t) * (-2.0f * gamma * t);
+            }
         }
         gd[r] = acc;
     }
@@ -132,6 +143,41 @@ __global__ void segment_sum_kernel(const float* __restrict__ vals, int64_t ldv, 
         const int f = (int)(i - s * F);
         float acc = 0.0f;
         for (int k = ptr[s]; k < ptr[s + 1]; ++k) acc += vals[(int64_t)(slot ? slot[k] : k) * ldv + f];
+        out[(int64_t)(node ? node[s] : s) * ldo + f] = acc;
+    }
+}
+
+// The same sum for FEW, LONG segments (per-crystal reductions: 16 crystals x 9 stress components over thousands of
+// bonds each - the one-thread-per-output kernel above walks such a segment serially: 745 us at 16 x 200-atom crystals).
+// One workgroup per segment: thread t owns feature t % F and walks the rows t / F, t / F + G, ... (G = 256 / F row
+// groups); the G partial sums are added in group order through LDS - fixed order, bit-reproducible.
+__global__ __launch_bounds__(256) void segment_sum_long_kernel(const float* __restrict__ vals, int64_t ldv,
+                                                               const int32_t* __restrict__ ptr,
+                                                               const int32_t* __restrict__ slot,
+                                                               const int32_t* __restrict__ node, float* __restrict__ out,
+                                                               int64_t ldo, int F) {
+    __shared__ float sh[256];
+    const int s = blockIdx.x;
+    const int G = 256 / F;
+    const int f = threadIdx.x % F, g = threadIdx.x / F;
+    float acc = 0.0f;
+    if (g < G) {
+        const int beg = ptr[s], end = ptr[s + 1];
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int k = beg + g;
+        for (; k + 3 * G < end; k += 4 * G) {
+            a0 += vals[(int64_t)(slot ? slot[k] : k) * ldv + f];
+            a1 += vals[(int64_t)(slot ? slot[k + G] : k + G) * ldv + f];
+            a2 += vals[(int64_t)(slot ? slot[k + 2 * G] : k + 2 * G) * ldv + f];
+            a3 += vals[(int64_t)(slot ? slot[k + 3 * G] : k + 3 * G) * ldv + f];
+        }
+        for (; k < end; k += G) a0 += vals[(int64_t)(slot ? slot[k] : k) * ldv + f];
+        acc = (a0 + a1) + (a2 + a3);
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    if (g == 0) {
+        for (int q = 1; q < G; ++q) acc += sh[q * F + f];
         out[(int64_t)(node ? node[s] : s) * ldo + f] = acc;
     }
 }
@@ -223,6 +269,13 @@ int alignn_segment_sum(const float* vals, int64_t ldv, const int32_t* ptr, const
                        float* out, int64_t ldo, int64_t n_seg, int F, alignn_stream_t stream) {
     if (F <= 0 || n_seg < 0) return (int)hipErrorInvalidValue;
     if (n_seg == 0) return 0;
+    if (n_seg * F <= 4096 && F <= 64 && n_seg <= 4096) {
+        // few outputs: whatever the segments' lengths, a workgroup per segment is never slower than a thread per output
+        hipLaunchKernelGGL(segment_sum_long_kernel, dim3((int)n_seg), dim3(256), 0, (hipStream_t)stream, vals, ldv, ptr, slot, node,
+                           out, ldo, F);
+        ALIGNN_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(segment_sum_kernel, dim3(grid_for(n_seg * F)), dim3(256), 0, (hipStream_t)stream, vals, ldv, ptr,
                        slot, node, out, ldo, n_seg, F);
     ALIGNN_CHECK_LAUNCH();
