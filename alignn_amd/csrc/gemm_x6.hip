@@ -1477,6 +1477,11 @@ struct WeightDesc {
 };
 static_assert(sizeof(WeightDesc) == 48, "descriptor layout is part of the C ABI (alignn_prepare_weights)");
 
+__global__ void zero_floats_kernel(float* __restrict__ p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.0f;
+}
+
 __global__ __launch_bounds__(256) void absmax_batched_kernel(const WeightDesc* __restrict__ descs) {
     const WeightDesc d = descs[blockIdx.y];
     const int Q = d.K >> 2;
@@ -1765,8 +1770,10 @@ int alignn_split_f16x2_both(const float* W, int64_t ldw, int N, int K, const flo
 int alignn_prepare_weights(const void* descs, int n_weights, float* amax_slots, alignn_stream_t stream) {
     if (n_weights == 0) return 0;
     if (descs == nullptr || n_weights < 0 || amax_slots == nullptr) return (int)hipErrorInvalidValue;
-    hipError_t e = hipMemsetAsync(amax_slots, 0, sizeof(float) * (size_t)n_weights, (hipStream_t)stream);
-    if (e != hipSuccess) return (int)e;
+    // (a kernel, not hipMemsetAsync: inside a hipGraph capture the memset node was observed to race with the launch behind
+    // it - force training replayed with stale maxima, profiles/README.md round 3)
+    hipLaunchKernelGGL(zero_floats_kernel, dim3(alignn_ceil_div(n_weights, 256)), dim3(256), 0, (hipStream_t)stream, amax_slots,
+                       n_weights);
     hipLaunchKernelGGL(absmax_batched_kernel, dim3(32, n_weights), dim3(256), 0, (hipStream_t)stream, (const WeightDesc*)descs);
     hipLaunchKernelGGL(split_f16x2_both_batched_kernel, dim3(256, n_weights), dim3(256), 0, (hipStream_t)stream,
                        (const WeightDesc*)descs);
@@ -1788,8 +1795,8 @@ int alignn_absmax_raise(const float* X, int64_t ldx, int64_t rows, int F, float*
 
 int alignn_absmax(const float* X, int64_t ldx, int64_t rows, int F, float* amax, alignn_stream_t stream) {
     if (F <= 0 || (F & 3) || (ldx & 3) || rows < 0 || amax == nullptr || !a16(X)) return (int)hipErrorInvalidValue;
-    hipError_t e = hipMemsetAsync(amax, 0, sizeof(float), (hipStream_t)stream);
-    if (e != hipSuccess) return (int)e;
+    // (zeroed by a kernel, not hipMemsetAsync: see alignn_prepare_weights)
+    hipLaunchKernelGGL(zero_floats_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, amax, 1);
     if (rows == 0) return 0;
     int64_t blocks = (rows * (F >> 2) + 256 * 8 - 1) / (256 * 8);
     if (blocks > 4096) blocks = 4096;

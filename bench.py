@@ -290,7 +290,7 @@ def main():
     # behind FlatGradSync's separate flat bucket
     from alignn_amd.optim import FlatAdamW, group_decay
 
-    LR, WD = 1e-3, 1e-2
+    LR, WD = float(os.environ.get("ALIGNN_BENCH_LR", "1e-3")), 1e-2
     if os.environ.get("ALIGNN_BENCH_FLAT_ADAMW", "1") != "0":
         opt = FlatAdamW(group_decay(model), lr=LR, weight_decay=WD, module=model, average_gradients=True)
         sync = None
