@@ -253,13 +253,17 @@ __global__ __launch_bounds__(kThreads) void col_stats_welford_kernel(const float
 }
 
 // finalise pivot slabs in float64: re-centre every slab onto slab 0's pivot P, then mean = P + S / n, var = SS / n - (S / n)^2
-// (S / n is of the size of the spread: the subtraction costs nothing)
-__global__ __launch_bounds__(kRedCols* kRedLanes) void bn_finalize_welford_kernel(
+// (S / n is of the size of the spread: the subtraction costs nothing).  kWfCols columns x kWfLanes slab-lanes per
+// workgroup: F / 4 workgroups (the 16-column form of bn_finalize_kernel needs 16 steps of three loads per slab-lane at
+// 1 024 slabs and took 14.7 us; this one 4), two-stage fixed-order tree (256 -> 16 -> 1).
+constexpr int kWfCols = 4, kWfLanes = 256;
+__global__ __launch_bounds__(kWfCols* kWfLanes) void bn_finalize_welford_kernel(
     const float* __restrict__ partial, const float* __restrict__ counts, int slabs, int64_t rows, int F,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
     float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ stat) {
-    __shared__ double sh[kRedLanes][kRedCols];
-    const int f = blockIdx.x * kRedCols + threadIdx.x;
+    __shared__ double sh[2][kWfLanes][kWfCols];
+    __shared__ double sh2[2][16][kWfCols];
+    const int f = blockIdx.x * kWfCols + threadIdx.x;
     const bool ok = f < F;
     double s = 0.0, ss = 0.0, P = 0.0;
     if (ok) {
@@ -267,7 +271,7 @@ __global__ __launch_bounds__(kRedCols* kRedLanes) void bn_finalize_welford_kerne
         int k0 = 0;
         while (k0 < slabs - 1 && counts[k0] == 0.0f) ++k0;
         P = (double)partial[(size_t)k0 * 3 * F + f];
-        for (int k = threadIdx.y; k < slabs; k += kRedLanes) {
+        for (int k = threadIdx.y; k < slabs; k += kWfLanes) {
             const double nk = (double)counts[k];
             if (nk > 0.0) {
                 const float* sl = partial + (size_t)k * 3 * F;
@@ -277,9 +281,27 @@ __global__ __launch_bounds__(kRedCols* kRedLanes) void bn_finalize_welford_kerne
             }
         }
     }
-    s = lane_tree_sum(s, sh);
-    ss = lane_tree_sum(ss, sh);
+    sh[0][threadIdx.y][threadIdx.x] = s;
+    sh[1][threadIdx.y][threadIdx.x] = ss;
+    __syncthreads();
+    if (threadIdx.y < 16) {
+        double a = 0.0, b2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            a += sh[0][threadIdx.y * 16 + k][threadIdx.x];
+            b2 += sh[1][threadIdx.y * 16 + k][threadIdx.x];
+        }
+        sh2[0][threadIdx.y][threadIdx.x] = a;
+        sh2[1][threadIdx.y][threadIdx.x] = b2;
+    }
+    __syncthreads();
     if (!ok || threadIdx.y != 0) return;
+    s = ss = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        s += sh2[0][k][threadIdx.x];
+        ss += sh2[1][k][threadIdx.x];
+    }
     const double n = (double)rows;
     const double ms = s / n;
     double v = ss / n - ms * ms;
@@ -654,7 +676,7 @@ int alignn_bn_finalize_welford(const float* partial, int slabs, int64_t rows, in
                                float eps, float momentum, float* running_mean, float* running_var, float* stat,
                                alignn_stream_t stream) {
     if (F <= 0 || slabs <= 0 || partial == nullptr) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(bn_finalize_welford_kernel, dim3(alignn_ceil_div(F, kRedCols)), dim3(kRedCols, kRedLanes), 0,
+    hipLaunchKernelGGL(bn_finalize_welford_kernel, dim3(alignn_ceil_div(F, kWfCols)), dim3(kWfCols, kWfLanes), 0,
                        (hipStream_t)stream, partial, partial + (size_t)slabs * 3 * F, slabs, rows, F, gamma, beta, eps, momentum,
                        running_mean, running_var, stat);
     ALIGNN_CHECK_LAUNCH();
