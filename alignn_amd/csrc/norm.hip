@@ -105,7 +105,10 @@ struct BwdReduceFn {
 // Slab reductions: blocks of 16 columns x 64 slab-lanes.  Lane y sums slabs y, y+64, ... in double,
 // then the 64 lanes are combined through LDS in a fixed order (bit-reproducible, ~slabs/64 steps).
 // ---------------------------------------------------------------------------------------------
-constexpr int kRedCols = 16, kRedLanes = 64;  // 16 columns x 64 slab-lanes: F/16 workgroups, <= 16 steps per lane
+// 4 columns x 64 slab-lanes = 256 threads: F/4 workgroups.  (Round 2 ran 16 x 64 = 1 024 threads per workgroup: inside a
+// replayed step such a block needs sixteen free wave slots on ONE CU at once, and beside a T-row kernel's resident
+// workgroups it waited for them - rocprofv3 showed 5 us slab sums taking 290 us, profiles/r03_default_timeline.txt.)
+constexpr int kRedCols = 4, kRedLanes = 64;
 
 __device__ __forceinline__ double lane_tree_sum(double v, double (*sh)[kRedCols]) {
     sh[threadIdx.y][threadIdx.x] = v;
@@ -254,15 +257,14 @@ __global__ __launch_bounds__(kThreads) void col_stats_welford_kernel(const float
 
 // finalise pivot slabs in float64: re-centre every slab onto slab 0's pivot P, then mean = P + S / n, var = SS / n - (S / n)^2
 // (S / n is of the size of the spread: the subtraction costs nothing).  kWfCols columns x kWfLanes slab-lanes per
-// workgroup: F / 4 workgroups (the 16-column form of bn_finalize_kernel needs 16 steps of three loads per slab-lane at
-// 1 024 slabs and took 14.7 us; this one 4), two-stage fixed-order tree (256 -> 16 -> 1).
-constexpr int kWfCols = 4, kWfLanes = 256;
+// workgroup, two-stage fixed-order tree (64 -> 8 -> 1).
+constexpr int kWfCols = 4, kWfLanes = 64;  // (256 threads: see kRedCols)
 __global__ __launch_bounds__(kWfCols* kWfLanes) void bn_finalize_welford_kernel(
     const float* __restrict__ partial, const float* __restrict__ counts, int slabs, int64_t rows, int F,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
     float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ stat) {
     __shared__ double sh[2][kWfLanes][kWfCols];
-    __shared__ double sh2[2][16][kWfCols];
+    __shared__ double sh2[2][8][kWfCols];
     const int f = blockIdx.x * kWfCols + threadIdx.x;
     const bool ok = f < F;
     double s = 0.0, ss = 0.0, P = 0.0;
@@ -284,12 +286,12 @@ __global__ __launch_bounds__(kWfCols* kWfLanes) void bn_finalize_welford_kernel(
     sh[0][threadIdx.y][threadIdx.x] = s;
     sh[1][threadIdx.y][threadIdx.x] = ss;
     __syncthreads();
-    if (threadIdx.y < 16) {
+    if (threadIdx.y < 8) {
         double a = 0.0, b2 = 0.0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            a += sh[0][threadIdx.y * 16 + k][threadIdx.x];
-            b2 += sh[1][threadIdx.y * 16 + k][threadIdx.x];
+        for (int k = 0; k < 8; ++k) {
+            a += sh[0][threadIdx.y * 8 + k][threadIdx.x];
+            b2 += sh[1][threadIdx.y * 8 + k][threadIdx.x];
         }
         sh2[0][threadIdx.y][threadIdx.x] = a;
         sh2[1][threadIdx.y][threadIdx.x] = b2;
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(kWfCols* kWfLanes) void bn_finalize_welford_kernel(
     if (!ok || threadIdx.y != 0) return;
     s = ss = 0.0;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
+    for (int k = 0; k < 8; ++k) {
         s += sh2[0][k][threadIdx.x];
         ss += sh2[1][k][threadIdx.x];
     }

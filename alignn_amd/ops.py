@@ -371,7 +371,7 @@ def new_amax(like):
     return a["buf"][i:i + 1]
 
 
-AMAX_MIN_ROWS = 4096  # below this no projection of the tensor can reach X6_MIN_TILES 64-row tiles (N <= 1024): skip tracking
+AMAX_MIN_ROWS = int(_os.environ.get("ALIGNN_AMD_AMAX_MIN_ROWS", "4096"))  # below this no projection of the tensor can reach X6_MIN_TILES 64-row tiles (N <= 1024): skip tracking
 
 
 def _track(rows):
