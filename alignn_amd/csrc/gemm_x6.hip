@@ -1654,7 +1654,10 @@ int launch_nt_p(const X6Args& g_in, hipStream_t st) {
     if (g_in.ldc >= (1 << 20) || g_in.ldadd >= (1 << 20) || g_in.ldxn >= (1 << 20)) return (int)hipErrorInvalidValue;
     X6Args g = g_in;
     const int64_t tiles = alignn_ceil_div(g.M, 128) * (int64_t)(g.Npad / BN);
-    const dim3 grid((unsigned)(tiles < kResidentP ? tiles : kResidentP)), block(NT);
+    // ALIGNN_AMD_X6P_WGS (experiment): fewer resident workgroups than two per CU leave some CUs half free for the small
+    // kernels of the other lane, which otherwise queue behind this kernel for its whole duration
+    static const int resident = [] { const char* e = getenv("ALIGNN_AMD_X6P_WGS"); int v = e ? atoi(e) : 0; return v > 0 ? v : kResidentP; }();
+    const dim3 grid((unsigned)(tiles < resident ? tiles : resident)), block(NT);
     if (g.gp != nullptr) {
         if (g.red_partial)
             hipLaunchKernelGGL(gemm_nt_f16p_gather_kernel<true>, grid, block, lds, st, g);
@@ -1698,7 +1701,8 @@ int launch_nt(const X6Args& g, hipStream_t st) {
             // measured per variant at T x 256 x 256, kernels interleaved (tools/x6_family_check.py): persistent -5 % plain,
             // -4 % statistics, -7..-9 % gather (+ statistics), -2 % BatchNorm-backward sums; +3 % with an addend and +10 %
             // for sums + addend (its operand look-ahead spills) - those two stay on the one-tile kernel, with strip slabs
-            if (g.addend == nullptr) return launch_nt_p(g, st);
+            static const bool addend_too = [] { const char* e = getenv("ALIGNN_AMD_X6P_ADDEND"); return e && e[0] == '1'; }();
+            if (g.addend == nullptr || addend_too) return launch_nt_p(g, st);
             X6Args gs = g;
             gs.strip_slabs = 1;
             return launch_nt_rm<F16, 2>(gs, st);
