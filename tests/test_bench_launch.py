@@ -56,7 +56,9 @@ def test_pmc_traffic_json_is_derived_from_the_committed_profiles():
     text = open(os.path.join(ROOT, "bench.py")).read()
     assert "PMC_MIB_BY_VARIANT" not in text and "PMC_TRAFFIC_F16X3" not in text
     v = committed["variants"]
-    assert {"plain", "gather", "bnred", "bnred_addend"} <= set(v)
+    # (the variants a training STEP launches at T rows; the bare projection only exists in bench.py's stand-alone
+    # micro-timing, which the PMC passes skip with --no-micro)
+    assert {"gather", "bnred", "bnred_addend"} <= set(v)
     for name, e in v.items():  # no wasted traffic: within 1.15x of the algorithmic rows of each variant
         rows = {"plain": 2, "gather": 2.15, "stats": 2, "bnred": 3, "bnred_addend": 4}[name]
         assert 0.95 < e["bytes_per_launch"] / (rows * committed["triplets"] * 1024) < 1.15, (name, e)
