@@ -58,7 +58,12 @@ def set_priorities(raw_graph, high):
             v.priority = high
             rc = hip.hipGraphKernelNodeSetAttribute(C.c_void_p(node), 8, C.byref(v))
             if rc != 0:
-                raise RuntimeError(f"hipGraphKernelNodeSetAttribute rc={rc}")
+                g = AttrValue()
+                rcs = {a: hip.hipGraphKernelNodeGetAttribute(C.c_void_p(node), a, C.byref(g)) for a in (1, 2, 8)}
+                v0 = AttrValue()
+                v0.priority = 0
+                rc0 = hip.hipGraphKernelNodeSetAttribute(C.c_void_p(node), 8, C.byref(v0))
+                raise RuntimeError(f"hipGraphKernelNodeSetAttribute(priority={high}) rc={rc}; get-attribute rcs {rcs}; set priority 0 rc={rc0}")
             n_high += 1
     return n_kernel, n_high
 
