@@ -33,6 +33,8 @@ from .graph import GraphBatch, _ptr_from_counts, build_csr, line_graph_of
 
 __all__ = ["knn_multigraph", "knn_multigraph_batch", "knn_multigraph_batch_hip", "crystal_batch"]
 
+PAD_BUDGET = 2 << 30  # bytes of padded distance tensor above which knn_multigraph_batch goes crystal by crystal
+
 
 def _all_neighbors(lat: torch.Tensor, frac: torch.Tensor, cutoff: float):
     inv = torch.linalg.inv(lat)
@@ -101,6 +103,26 @@ def knn_multigraph_batch(lattices: Sequence, fracs: Sequence, cutoff: float = 8.
     ns = [int(torch.as_tensor(f).shape[0]) for f in fracs]
     nmax = max(ns)
     lat = torch.stack([torch.as_tensor(x).to(dev, torch.float64) for x in lattices])  # [B,3,3]
+    # The padded form materialises float64 [B, nmax, nmax, I, 3] for the LARGEST image grid of the batch: a 2-atom cell that
+    # needs 729 images next to a 100-atom cell makes that tens of GB where each crystal alone needs MBs.  Estimate both
+    # volumes from the lattices (no host read of device data beyond the 9 x B lattice entries the caller passed in) and
+    # take the per-crystal loop when padding would cost more than PAD_BUDGET bytes or 8x the ragged volume.
+    if B > 1:
+        lat_h = lat.detach().cpu()
+        sp = 1.0 / torch.linalg.norm(torch.linalg.inv(lat_h), dim=1)
+        reach_h = torch.ceil(float(cutoff) / sp).to(torch.int64)
+        imgs = (2 * reach_h + 1).prod(dim=1)
+        padded = B * nmax * nmax * int((2 * reach_h.max(dim=0).values + 1).prod()) * 3 * 8
+        ragged = int(sum(n * n * int(i) for n, i in zip(ns, imgs.tolist()))) * 3 * 8
+        if padded > PAD_BUDGET or padded > 8 * max(ragged, 1):
+            us, vs, rs, off = [], [], [], 0
+            for b in range(B):
+                u, v, r = knn_multigraph(lat[b], torch.as_tensor(fracs[b]), cutoff, max_neighbors, device=dev)
+                us.append(u + off)
+                vs.append(v + off)
+                rs.append(r)
+                off += ns[b]
+            return torch.cat(us), torch.cat(vs), torch.cat(rs), ns
     frac = torch.zeros(B, nmax, 3, dtype=torch.float64, device=dev)
     for b, f in enumerate(fracs):
         frac[b, :ns[b]] = torch.as_tensor(f).to(dev, torch.float64)
