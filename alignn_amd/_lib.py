@@ -41,6 +41,8 @@ SIGNATURES = {
     "alignn_absmax_raise": (_i32, [_p, _i64, _i64, _i32, _p, _p]),
     "alignn_gemm_nt_f16x3": (_i32, [_p, _i64, _p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _i32, _i32, _p]),
     "alignn_gemm_nt_f16x3_gather": (_i32, [_p, _i64, _p, _p, _p, _p, _p, _i64, _i64, _i32, _i32, _p, _i64, _p, _p, _p, _p]),
+    "alignn_gemm_nt_f16x3_gather2": (_i32, [_p, _i64, _p, _p, _p, _p, _p, _i64, _i64, _i32, _i32, _p, _i64, _p, _p, _i64, _p, _p, _p]),
+    "alignn_gather_rows_ld": (_i32, [_p, _i64, _p, _p, _i64, _i64, _i32, _p]),
     "alignn_gemm_nt_f16x3_stats": (_i32, [_p, _i64, _p, _p, _p, _p, _p, _i64, _i64, _i32, _i32, _p, _p]),
     "alignn_egc_gate_fwd_pre_norm": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "alignn_egc_gate_fwd_pre": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p]),
@@ -113,7 +115,7 @@ SIGNATURES = {
 # with the platform's C layout rules ("@": native sizes and alignment); load() checks the sizes against the library's
 import struct as _struct
 
-EGC_FWD_ARGS = _struct.Struct("@4P2q6i2f32PN")
+EGC_FWD_ARGS = _struct.Struct("@5P2q6i2f32PN")
 EGC_BWD_ARGS = _struct.Struct("@8P3q8i22Pq13PN")
 EGC_WGRAD_ARGS = _struct.Struct("@2q4i14PN")
 

@@ -25,19 +25,20 @@ inline size_t al(size_t floats) { return (floats + 63) / 64 * 64; }  // 256-byte
 
 constexpr int kFoldAbove = 1024;  // ops.FOLD_ABOVE: more slabs than this are pre-summed to alignn_slab_fold_slabs() first
 
-// forward scratch: [e_part | e_fold | n_part]
+// forward scratch: [e_part | e_fold | n_part | bd2 (edge_kind 2)]
 struct FwdScratch {
-    size_t e_part, e_fold, n_part, total;
+    size_t e_part, e_fold, n_part, bd2, total;
     int e_slabs, n_slabs;
 };
 FwdScratch fwd_scratch(int64_t n, int64_t m, int H, int Kin, int edge_kind) {
     FwdScratch s{};
     s.n_slabs = alignn_egc_slabs(n);
-    s.e_slabs = edge_kind == 1 ? alignn_gemm_nt_x6_row_tiles(m, H, Kin) : s.n_slabs;
+    s.e_slabs = edge_kind >= 1 ? alignn_gemm_nt_x6_row_tiles(m, H, Kin) : s.n_slabs;
     size_t off = 0;
     s.e_part = off, off += al((size_t)(s.e_slabs + 1) * (3 * H + 1));  // (the gate pass writes pivot slabs [3][H] + counts)
     s.e_fold = off, off += al((size_t)alignn_slab_fold_slabs() * 2 * H);
     s.n_part = off, off += al((size_t)s.n_slabs * (3 * H + 1));
+    s.bd2 = off, off += edge_kind == 2 ? al((size_t)n * H) : 0;
     s.total = off;
     return s;
 }
@@ -109,10 +110,17 @@ int alignn_egc_conv_fwd(const alignn_egc_fwd_args* a, alignn_stream_t st) {
     else
         ALIGNN_TRY(alignn_gemm_nt(a->x, Kin, a->wcat, Kin, a->bcat, nullptr, 0, a->P, 4 * H, n, 4 * H, Kin, st));
     // ---- edge branch + gate pass
-    if (a->edge_kind == 1) {
+    if (a->edge_kind >= 1) {
         // u_add_v and the BatchNorm statistics in the projection's epilogue; the gate pass normalises itself
-        ALIGNN_TRY(alignn_gemm_nt_f16x3_gather(a->y, Kin, a->y_amax, a->weg_img, a->weg_amax, a->b_eg, a->M, H, m, H, Kin, a->P,
-                                               4 * H, a->src, a->dst, e_part, st));
+        if (a->edge_kind == 2) {  // line graphs: the destination term from a segment-ordered copy of Bd (same values)
+            if (a->seg_rank == nullptr || a->seg_node == nullptr) return (int)hipErrorInvalidValue;
+            float* bd2 = a->scratch + s.bd2;
+            ALIGNN_TRY(alignn_gather_rows_ld(a->P + H, 4 * H, a->seg_node, bd2, H, n, H, st));
+            ALIGNN_TRY(alignn_gemm_nt_f16x3_gather2(a->y, Kin, a->y_amax, a->weg_img, a->weg_amax, a->b_eg, a->M, H, m, H, Kin,
+                                                    a->P, 4 * H, a->src, bd2, H, a->seg_rank, e_part, st));
+        } else
+            ALIGNN_TRY(alignn_gemm_nt_f16x3_gather(a->y, Kin, a->y_amax, a->weg_img, a->weg_amax, a->b_eg, a->M, H, m, H, Kin,
+                                                   a->P, 4 * H, a->src, a->dst, e_part, st));
         ALIGNN_TRY(bn_finalize_folded(e_part, s.e_slabs, e_fold, m, H, a->e_gamma, a->e_beta, a->eps, a->momentum, a->e_rm,
                                       a->e_rv, a->e_stat, st));
         if (a->y_out != nullptr)

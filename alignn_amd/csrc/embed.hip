@@ -192,6 +192,20 @@ __global__ void gather_rows_kernel(const float* __restrict__ in, const int32_t* 
     }
 }
 
+// out[r, 0:F] = in[perm[r], 0:F] with leading dimensions (a column block of a wider matrix); float4 per thread
+__global__ void gather_rows_ld_kernel(const float* __restrict__ in, int64_t ld_in, const int32_t* __restrict__ perm,
+                                      float* __restrict__ out, int64_t ld_out, int64_t rows, int F) {
+    const int Q = F >> 2;
+    const RowQuad rq(Q);
+    const int64_t total = rows * Q;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r;
+        int q;
+        rq.split(i, total, r, q);
+        f4_st(out + r * ld_out + q * 4, f4_ld(in + (int64_t)perm[r] * ld_in + q * 4));
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -278,6 +292,16 @@ int alignn_segment_sum(const float* vals, int64_t ldv, const int32_t* ptr, const
     }
     hipLaunchKernelGGL(segment_sum_kernel, dim3(grid_for(n_seg * F)), dim3(256), 0, (hipStream_t)stream, vals, ldv, ptr,
                        slot, node, out, ldo, n_seg, F);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_gather_rows_ld(const float* in, int64_t ld_in, const int32_t* perm, float* out, int64_t ld_out, int64_t rows, int F,
+                          alignn_stream_t stream) {
+    if (F <= 0 || (F & 3) || (ld_in & 3) || (ld_out & 3)) return (int)hipErrorInvalidValue;
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(gather_rows_ld_kernel, dim3(grid_for(rows * (F >> 2), 256, 4096)), dim3(256), 0, (hipStream_t)stream, in,
+                       ld_in, perm, out, ld_out, rows, F);
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }

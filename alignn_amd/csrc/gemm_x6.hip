@@ -160,6 +160,12 @@ struct X6Args {
     const int32_t* gsrc;  // [M] source node of edge row e
     const int32_t* gdst;  // [M] destination node of edge row e
     int strip_slabs;      // one-tile kernels: column-sum slabs per 64-row wave strip (see the end of gemm_nt_x6_body)
+    int xcd_map;          // persistent kernel: 1 = each XCD walks its own contiguous range of row tiles (see gemm_nt_f16p_body)
+    // EPI == 2, optional: the SECOND gathered row comes from its own table instead of P's Bd block - row gdst[e] of gp2
+    // (leading dimension ldgp2).  The host passes the Bd rows permuted into SEGMENT order and gdst = the segment rank of
+    // row e, so consecutive output rows read consecutive table rows (alignn_gemm_nt_f16x3_gather2).
+    const float* gp2;
+    int64_t ldgp2;
 };
 
 __device__ __forceinline__ unsigned hi_pair(float x1, float x0) {
@@ -638,7 +644,8 @@ __device__ __forceinline__ void gemm_nt_x6_body(const X6Args& g) {
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i)
-                av[i] = f4_add(f4_ld(g.gp + (int64_t)ui[i] * g.ldgp + colc), f4_ld(g.gp + (int64_t)vi[i] * g.ldgp + g.N + colc));
+                av[i] = f4_add(f4_ld(g.gp + (int64_t)ui[i] * g.ldgp + colc),
+                               f4_ld((g.gp2 ? g.gp2 : g.gp + g.N) + (int64_t)vi[i] * (g.gp2 ? g.ldgp2 : g.ldgp) + colc));
         }
         if (HAS_ADD) {
 #pragma unroll
@@ -790,7 +797,22 @@ __device__ __forceinline__ void gemm_nt_f16p_body(const X6Args& g) {
     const int il = lane & 31, half = lane >> 5;
     const int n_nt = g.Npad / BN;
     const int tiles = (int)((g.M + BM - 1) / BM) * n_nt;  // (< 2^31: the launcher checks)
-    const int J = (tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;  // tiles of this workgroup (>= 1)
+    // Which tiles this workgroup walks: tile_first, tile_first + tile_step, ... (J of them).  Default: blockIdx.x, + grid.
+    // XCD-aware map (g.xcd_map; one column tile per row, grid a multiple of 8): workgroup w runs on XCD w % 8 and every XCD
+    // has its own L2, so XCD x takes the CONTIGUOUS range of row tiles [x chunk, (x+1) chunk) and its grid / 8 workgroups
+    // walk it side by side.  Adjacent tiles of a line graph gather the same node rows (the in-edges of one atom, the Bd
+    // row of one bond): with the round-robin map the 8 L2s each fetch all of them (gather with real indices = gather with
+    // random rows: 453 vs 448 us, all rows -> row 0: 388 us, tools/gather_probe.py), with this map one L2 does.
+    int tile_first = blockIdx.x, tile_step = gridDim.x, tile_end = tiles;
+    if (g.xcd_map && n_nt == 1 && (gridDim.x & 7) == 0) {
+        const int per = gridDim.x >> 3, xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+        const int chunk = (tiles + 7) >> 3;
+        tile_first = xcd * chunk + q;
+        tile_step = per;
+        tile_end = (xcd + 1) * chunk < tiles ? (xcd + 1) * chunk : tiles;
+    }
+    const int J = tile_first < tile_end ? (tile_end - tile_first + tile_step - 1) / tile_step : 0;  // tiles of this workgroup
+    if (J == 0) return;  // (uniform per workgroup; cannot happen for the shapes the launcher sends here)
     const int nk = g.K / BK;
     const int S = J * nk;  // k-steps of this workgroup, numbered across its tiles
 
@@ -800,7 +822,7 @@ __device__ __forceinline__ void gemm_nt_f16p_body(const X6Args& g) {
     unsigned a_lane[A_DMA];
     const float* a_base = g.A;
     const unsigned char* b_base = g.Ws;
-    int it_tile = blockIdx.x;
+    int it_tile = tile_first;
     int it_kt = 0, issued = 0;
     auto set_issue_tile = [&](int tile) {
         const int64_t row0 = (int64_t)(tile / n_nt) * BM;
@@ -825,8 +847,8 @@ __device__ __forceinline__ void gemm_nt_f16p_body(const X6Args& g) {
         ++issued;
         if (++it_kt == nk) {
             it_kt = 0;
-            it_tile += gridDim.x;
-            if (it_tile < tiles) set_issue_tile(it_tile);
+            it_tile += tile_step;
+            if (it_tile < tile_end) set_issue_tile(it_tile);
         }
     };
     set_issue_tile(it_tile);
@@ -853,12 +875,12 @@ __device__ __forceinline__ void gemm_nt_f16p_body(const X6Args& g) {
 
     f32x16 acc[RM][RN];
     int slot = 0;  // of the step about to run
-    int tile = blockIdx.x;
+    int tile = tile_first;
     constexpr int PLD = 32 + 4;                // patch row stride (floats)
     constexpr int PATCH_BYTES = STAGE_BYTES / (NT / 64);  // 6 KiB per wave >= 32 * PLD * 4
     static_assert(32 * PLD * 4 <= PATCH_BYTES, "patch fits its share of a slot");
     const int prow = lane >> 3, pc4 = (lane & 7) * 4;  // patch reader: 8 lanes per 32-float row, 8 rows per instruction
-    for (int j = 0; j < J; ++j, tile += gridDim.x) {
+    for (int j = 0; j < J; ++j, tile += tile_step) {
         const int64_t m0 = (int64_t)(tile / n_nt) * BM;
         const int n0 = (tile % n_nt) * BN;
 #pragma unroll
@@ -964,6 +986,8 @@ __device__ __forceinline__ void gemm_nt_f16p_body(const X6Args& g) {
         int prow_e = prow, pc4_e = pc4;
         asm volatile("" : "+v"(prow_e), "+v"(pc4_e));
         float* c_t = g.C + m0 * g.ldc;
+        const float* bd_tab = GATHER ? (g.gp2 ? g.gp2 : g.gp + g.N) : nullptr;  // (scalar selects: no branch in the epilogue)
+        const int64_t bd_ld = GATHER ? (g.gp2 ? g.ldgp2 : g.ldgp) : 0;
         const float* add_t = HAS_ADD ? g.addend + m0 * g.ldadd : nullptr;
         const float* xn_t = BNRED ? g.xn + m0 * g.ldxn : nullptr;
         const int col0 = n0 + wn * TN + pc4_e;
@@ -988,7 +1012,7 @@ __device__ __forceinline__ void gemm_nt_f16p_body(const X6Args& g) {
                 }
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
-                    av[sl][i] = f4_add(f4_ld(g.gp + (int64_t)ui[i] * g.ldgp + col), f4_ld(g.gp + (int64_t)vi[i] * g.ldgp + g.N + col));
+                    av[sl][i] = f4_add(f4_ld(g.gp + (int64_t)ui[i] * g.ldgp + col), f4_ld(bd_tab + (int64_t)vi[i] * bd_ld + col));
             }
             if constexpr (HAS_ADD) {
 #pragma unroll
@@ -1653,6 +1677,8 @@ int launch_nt_p(const X6Args& g_in, hipStream_t st) {
     }
     if (g_in.ldc >= (1 << 20) || g_in.ldadd >= (1 << 20) || g_in.ldxn >= (1 << 20)) return (int)hipErrorInvalidValue;
     X6Args g = g_in;
+    static const bool xcd_map = [] { const char* e = getenv("ALIGNN_AMD_X6P_XCD"); return !(e && e[0] == '0'); }();
+    g.xcd_map = xcd_map ? 1 : 0;
     const int64_t tiles = alignn_ceil_div(g.M, 128) * (int64_t)(g.Npad / BN);
     // ALIGNN_AMD_X6P_WGS (experiment): fewer resident workgroups than two per CU leave some CUs half free for the small
     // kernels of the other lane, which otherwise queue behind this kernel for its whole duration
@@ -1882,6 +1908,26 @@ int alignn_gemm_nt_f16x3_gather(const float* A, int64_t lda, const float* a_amax
         return (int)hipErrorInvalidValue;
     X6Args g{A, lda, (const unsigned char*)Wsplit, a_amax, w_amax, bias, nullptr, 0, C, ldc, M, N, npad(N), K,
              M * (int64_t)N * 4 >= ((int64_t)128 << 20), nullptr, 0, nullptr, stats_partial, P, ldp, src, dst};
+    return launch_nt<true>(g, (hipStream_t)stream);
+}
+
+/* alignn_gemm_nt_f16x3_gather with the second gathered row taken from its own table: C[e] = A[e] W^T + bias +
+ * P[src[e]][0:N] + Bd2[rank[e]][0:N].  For a line graph the host passes Bd2 = the Bd rows in SEGMENT order and rank[e] = the
+ * segment of row e: rows of one segment share one table row and consecutive segments read consecutive rows, where
+ * P[dst[e]][N:2N] jumps through the table once per segment (measured: 65 of the kernel's 450 us at T rows). */
+int alignn_gemm_nt_f16x3_gather2(const float* A, int64_t lda, const float* a_amax, const void* Wsplit, const float* w_amax,
+                                 const float* bias, float* C, int64_t ldc, int64_t M, int N, int K, const float* P, int64_t ldp,
+                                 const int32_t* src, const float* Bd2, int64_t ldbd2, const int32_t* rank,
+                                 float* stats_partial, alignn_stream_t stream) {
+    if (!alignn_gemm_nt_x6_supported(M, N, K) || a_amax == nullptr || w_amax == nullptr) return (int)hipErrorInvalidValue;
+    if (!nt_args_ok(A, lda, Wsplit, bias, nullptr, 0, C, ldc)) return (int)hipErrorInvalidValue;
+    if (P == nullptr || src == nullptr || Bd2 == nullptr || rank == nullptr || (ldp & 3) || (ldbd2 & 3) || !a16(P) || !a16(Bd2) ||
+        (N & 3) || (stats_partial && !a16(stats_partial)))
+        return (int)hipErrorInvalidValue;
+    X6Args g{A, lda, (const unsigned char*)Wsplit, a_amax, w_amax, bias, nullptr, 0, C, ldc, M, N, npad(N), K,
+             M * (int64_t)N * 4 >= ((int64_t)128 << 20), nullptr, 0, nullptr, stats_partial, P, ldp, src, rank};
+    g.gp2 = Bd2;
+    g.ldgp2 = ldbd2;
     return launch_nt<true>(g, (hipStream_t)stream);
 }
 

@@ -46,6 +46,17 @@ class CSRGraph:
     # minus s itself when the bond is a self-image - so the row of (source q, segment s) is pure index arithmetic
     # (see alignn_egc_bwd_lg_dense); the value is the largest number of sources of any atom.  0: not established.
     dense_max_src: int = 0
+    # [m] int32, line graphs: the segment (rank in seg_ptr order) of every edge row - what the edge-gate projection's
+    # epilogue gathers the destination term with (ops.gemm_nt_f16x3_gather with a segment-ordered table); built by
+    # ``segment_rank()`` when the batch is staged
+    seg_rank: Optional[torch.Tensor] = None
+
+    def segment_rank(self) -> torch.Tensor:
+        if self.seg_rank is None:
+            sp = self.seg_ptr.long()
+            self.seg_rank = torch.repeat_interleave(torch.arange(self.n_nodes, device=sp.device, dtype=torch.int32),
+                                                    sp[1:] - sp[:-1], output_size=self.n_edges)
+        return self.seg_rank
 
 
 def _ptr_from_counts(counts: torch.Tensor) -> torch.Tensor:
@@ -141,6 +152,7 @@ def line_graph_of(g: CSRGraph) -> CSRGraph:
         grp_seg_ptr=g.out_ptr,
         grp_src_ptr=g.seg_ptr,
         dense_max_src=int(din.max()) if m > 0 else 0,  # dense and source-sorted by construction (= _dense_blocks)
+        seg_rank=seg_of.to(torch.int32),
     )
 
 
@@ -229,6 +241,7 @@ class GraphBatch:
             if bool((g.dst[lg.src.long()] == g.src[lg.dst.long()]).all()):
                 lg.grp_seg_ptr, lg.grp_src_ptr = g.out_ptr, g.seg_ptr
                 lg.dense_max_src = _dense_blocks(g, lg)
+            lg.segment_rank()
         elif build_line_graph:
             lg = line_graph_of(g)
         bnn = torch.as_tensor(batch_num_nodes).to(dev).to(torch.int64)

@@ -145,7 +145,7 @@ def _batch_tensors(b: GraphBatch):
         if csr is None:
             continue
         for t in (csr.seg_ptr, csr.seg_node, csr.src, csr.dst, csr.out_ptr, csr.out_slot, csr.perm, csr.inv,
-                  csr.grp_seg_ptr, csr.grp_src_ptr):
+                  csr.grp_seg_ptr, csr.grp_src_ptr, csr.seg_rank):
             if t is not None:
                 yield t
     for t in (b.graph_ptr, b.atom_features, b.r, b.h, b.volume):

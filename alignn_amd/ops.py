@@ -631,17 +631,45 @@ def _f16x3_applies(a, a_amax, N, K):
             and bool(lib.alignn_gemm_nt_x6_supported(M, N, K)))
 
 
-def gemm_nt_f16x3_gather(a, a_amax, ws, bias, P, src, dst, out=None, want_stats=False):
+BD_SEGMENT_TABLE = _os.environ.get("ALIGNN_AMD_BD_TABLE", "1") != "0"  # line graphs: destination term from a segment-ordered copy (tests flip it: same bits)
+BD_TABLE_STATS = {"used": 0}  # edge-gate projections that read the table (tests)
+
+
+def segment_ordered_bd(P, graph, H):
+    """The Bd block of the node projection P [n, 4H] with its rows in SEGMENT order (row s = Bd[seg_node[s]]) - the table
+    ``gemm_nt_f16x3_gather(..., bd2=, rank=)`` reads: consecutive edge rows then gather consecutive table rows.  None when the
+    graph's segments are in node order already (bond graphs) or the switch is off."""
+    if not BD_SEGMENT_TABLE or graph.seg_node is None or graph.seg_rank is None:
+        return None
+    lib = _lib.load()
+    n = P.shape[0]
+    bd2 = _empty(n, H, like=P)
+    BD_TABLE_STATS["used"] += 1
+    check(lib.alignn_gather_rows_ld(P.data_ptr() + 4 * H, P.stride(0), ptr(graph.seg_node), ptr(bd2), H, n, H, stream()),
+          "gather_rows_ld")
+    return bd2
+
+
+def gemm_nt_f16x3_gather(a, a_amax, ws, bias, P, src, dst, out=None, want_stats=False, bd2=None, rank=None):
     """out[e] = a[e] @ W^T + bias + P[src[e], 0:N] + P[dst[e], N:2N]  (edge-gate projection + DGL u_add_v in one pass).
+    ``bd2`` / ``rank``: the second term as bd2[rank[e]] instead (``segment_ordered_bd``: same values, cache-friendly order).
     ``want_stats``: -> (out, partial [tiles,2,N], tiles): per-tile column sums of out and out^2 (alignn_bn_finalize's slabs)."""
     lib = _lib.load()
-    require_f32(a, bias, P)
+    require_f32(a, bias, P, bd2)
     M, K = a.shape
     N = ws.n
     if out is None:
         out = _empty(M, N, like=a)
     tiles = lib.alignn_gemm_nt_x6_row_tiles(M, N, K) if want_stats else 0
     partial = _empty(tiles + 1, 2, N, like=a) if want_stats else None  # (+ the kernel's scratch slab)
+    if bd2 is not None:
+        _timed("gather", M, N, K, lambda: check(
+            lib.alignn_gemm_nt_f16x3_gather2(ptr(a), a.stride(0), ptr(a_amax), ptr(ws.buf), ptr(ws.amax), ptr(bias), ptr(out),
+                                             out.stride(0), M, N, K, ptr(P), P.stride(0), ptr(src), ptr(bd2), bd2.stride(0),
+                                             ptr(rank), ptr(partial), stream()),
+            "gemm_nt_f16x3_gather2",
+        ))
+        return (out, partial, tiles) if want_stats else out
     _timed("gather", M, N, K, lambda: check(
         lib.alignn_gemm_nt_f16x3_gather(ptr(a), a.stride(0), ptr(a_amax), ptr(ws.buf), ptr(ws.amax), ptr(bias), ptr(out),
                                         out.stride(0), M, N, K, ptr(P), P.stride(0), ptr(src), ptr(dst), ptr(partial),
@@ -1422,12 +1450,14 @@ class EdgeGatedConvFn(torch.autograd.Function):
         fuse_norm = pre_added and norm == "batch" and STATS_FUSED
 
         def edge_side():
+            bd2 = segment_ordered_bd(P, graph, H) if pre_added else None
             if fuse_norm and training:
                 M, e_part, e_slabs = gemm_nt_f16x3_gather(y, ctx.y_amax, split_f16x2(w_eg), b_eg, P, graph.src, graph.dst,
-                                                          want_stats=True)
+                                                          want_stats=True, bd2=bd2, rank=graph.seg_rank)
                 return M, (e_part, e_slabs)
             if pre_added:
-                M = gemm_nt_f16x3_gather(y, ctx.y_amax, split_f16x2(w_eg), b_eg, P, graph.src, graph.dst)
+                M = gemm_nt_f16x3_gather(y, ctx.y_amax, split_f16x2(w_eg), b_eg, P, graph.src, graph.dst, bd2=bd2,
+                                         rank=graph.seg_rank)
             else:
                 M = project(y, w_eg, b_eg, a_amax=ctx.y_amax)  # [m,H]  -> m_pre in place
             e_part = _welford_slabs(slabs, H, x) if (bn_train and not fuse_norm) else None
@@ -1548,6 +1578,9 @@ class EdgeGatedConvFn(torch.autograd.Function):
             wcat_img = split_f16x2(wcat)
         if edge_kind == 1:
             weg_img = split_f16x2(w_eg)
+            if BD_SEGMENT_TABLE and graph.seg_node is not None and graph.seg_rank is not None:
+                edge_kind = 2  # (segment_ordered_bd's table, built and read inside the C call)
+                BD_TABLE_STATS["used"] += 1
         P = _empty(n, 4 * H, like=x)
         M = _empty(m, H, like=x)
         xpre, s0, hh = _empty(n, H, like=x), _empty(n, H, like=x), _empty(n, H, like=x)
@@ -1560,7 +1593,7 @@ class EdgeGatedConvFn(torch.autograd.Function):
         nbytes = lib.alignn_egc_conv_fwd_scratch(n, m, H, Kin, edge_kind)
         scratch = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
         args = _lib.EGC_FWD_ARGS.pack(
-            _P(graph.seg_ptr), _P(graph.seg_node), _P(graph.src), _P(graph.dst), n, m,
+            _P(graph.seg_ptr), _P(graph.seg_node), _P(graph.src), _P(graph.dst), _P(graph.seg_rank), n, m,
             H, Kin, node_kind, edge_kind, int(residual), 0, BN_EPS, BN_MOMENTUM,
             _P(x), _P(y), _P(x_amax), _P(y_amax),
             _P(wcat), _P(bcat), _P(wcat_img.amax if wcat_img is not None else None), _P(wcat_img.buf if wcat_img is not None else None),

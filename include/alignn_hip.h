@@ -145,6 +145,16 @@ int alignn_gemm_nt_f16x3_gather(const float* A, int64_t lda, const float* a_amax
                                 const float* w_amax, const float* bias, float* C, int64_t ldc, int64_t M, int N, int K,
                                 const float* P, int64_t ldp, const int32_t* src, const int32_t* dst,
                                 float* stats_partial, alignn_stream_t stream);
+/* The same with the second gathered row from its own table: C[e] = A[e] W^T + bias + P[src[e]][0:N] + Bd2[rank[e]][0:N].
+ * For a line graph: Bd2 = the Bd block of P with its rows in SEGMENT order (alignn_gather_rows_ld by seg_node), rank[e] =
+ * the segment of edge row e - consecutive rows then read consecutive table rows instead of one random row per segment. */
+int alignn_gemm_nt_f16x3_gather2(const float* A, int64_t lda, const float* a_amax, const void* Wsplit, const float* w_amax,
+                                 const float* bias, float* C, int64_t ldc, int64_t M, int N, int K, const float* P, int64_t ldp,
+                                 const int32_t* src, const float* Bd2, int64_t ldbd2, const int32_t* rank,
+                                 float* stats_partial, alignn_stream_t stream);
+/* out[r][0:F] = in[perm[r]][0:F] for matrices with leading dimensions (F, ld_in, ld_out multiples of 4) */
+int alignn_gather_rows_ld(const float* in, int64_t ld_in, const int32_t* perm, float* out, int64_t ld_out, int64_t rows, int F,
+                          alignn_stream_t stream);
 /* stats_partial (above: may be NULL) / alignn_gemm_nt_f16x3_stats: the projection also leaves, per row tile, the column
  * sums of its output and of its square - [alignn_gemm_nt_x6_row_tiles + 1][2][N] (last slab: scratch), the slab layout
  * alignn_bn_finalize takes -
@@ -496,6 +506,8 @@ int alignn_knn_emit(const double* lat, const double* cart, const int32_t* graph_
  * ------------------------------------------------------------------------------------------ */
 typedef struct alignn_egc_fwd_args {
     const int32_t *seg_ptr, *seg_node, *src, *dst;
+    const int32_t* seg_rank; /* edge_kind 2: [m] segment of every edge row (the destination term is then read from a
+                                segment-ordered copy of P's Bd block, alignn_gather_rows_ld + alignn_gemm_nt_f16x3_gather2) */
     int64_t n, m;
     int32_t H, Kin, node_kind, edge_kind, residual, pad_;
     float eps, momentum;

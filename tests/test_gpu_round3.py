@@ -343,6 +343,46 @@ def test_batched_weight_preparation_gives_the_same_bits():
         assert torch.equal(a[k], b[k]), k
 
 
+@pytest.mark.parametrize("composite", [True, False])
+@pytest.mark.parametrize("loader", [False, True])
+def test_segment_ordered_destination_table_gives_the_same_bits(composite, loader):
+    """Line-graph edge-gate projection: the destination term read from a segment-ordered copy of P's Bd block
+    (alignn_gather_rows_ld + alignn_gemm_nt_f16x3_gather2, ops.segment_ordered_bd) instead of P[dst[e]] - the same addends
+    in the same order, so every bit of the training state agrees.  Both ways a batch gets its line graph are covered."""
+    raw = make_batch(48, 60, seed0=77)
+    if loader:
+        from alignn_amd.loader import pack_raw, stage
+        batch, _ = stage(pack_raw(raw), DEV)
+    else:
+        batch = GraphBatch.from_raw(raw, device=DEV)
+    lg = batch.lg
+    sp = lg.seg_ptr.long()
+    assert lg.seg_rank is not None and lg.seg_rank.dtype == torch.int32
+    assert torch.equal(lg.seg_rank.long(), torch.repeat_interleave(torch.arange(lg.n_nodes, device=DEV), sp[1:] - sp[:-1]))
+    assert torch.equal(lg.seg_node[lg.seg_rank.long()], lg.dst)  # (what makes the two readings the same values)
+    target = torch.randn(48, generator=torch.Generator().manual_seed(2)).to(DEV)
+
+    def mk():
+        torch.manual_seed(0)
+        return ALIGNN(ALIGNNConfig(name="alignn")).to(DEV).train()
+
+    def run(flag):
+        prev = ops.BD_SEGMENT_TABLE
+        ops.BD_SEGMENT_TABLE = flag
+        try:
+            return _train_state(mk, batch, target, composite)[0]
+        finally:
+            ops.BD_SEGMENT_TABLE = prev
+
+    ops.BD_TABLE_STATS["used"] = 0
+    a = run(True)
+    assert ops.BD_TABLE_STATS["used"] == 2 * 4, ops.BD_TABLE_STATS  # steps x line-graph convolutions
+    b = run(False)
+    assert ops.BD_TABLE_STATS["used"] == 2 * 4
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
 # ---------------------------------------------------------------------------------------------
 # BatchNorm statistics as Welford slabs (VERDICT r02 item 2): well-conditioned when |mean| >> std
 # ---------------------------------------------------------------------------------------------
