@@ -1707,13 +1707,22 @@ int launch_nt_p(const X6Args& g_in, hipStream_t st) {
 }
 // rows per reduction slab of the f16x3 kernels' column sums (EPI flags BNRED / STATS): the block tile of the one-tile
 // kernels, the 64-row wave strip of the persistent one
+// a product with fewer 128-row tiles than this runs on 64-row tiles (default: fewer than one per CU; ALIGNN_AMD_X6_RM1_BELOW
+// moves the line for A/B runs - e.g. 512 puts the bond-row products, 397 tiles = one thin generation, on 793 half tiles)
+inline int64_t rm1_below() {
+    static const int64_t v = [] {
+        const char* e = getenv("ALIGNN_AMD_X6_RM1_BELOW");
+        return e ? (int64_t)atoll(e) : (int64_t)256;
+    }();
+    return v;
+}
 inline int nt_block_rows(int64_t M, int N, int K) {
 #ifdef X6_FORCE_RM
     return 64 * X6_FORCE_RM;
 #endif
     if (nt_persistent(M, N, K)) return 64;
     const int64_t tiles128 = alignn_ceil_div(M, 128) * (int64_t)(npad(N) / BN);
-    return (K <= 64 || tiles128 < 256) ? 64 : 128;
+    return (K <= 64 || tiles128 < rm1_below()) ? 64 : 128;
 }
 template <bool F16>
 int launch_nt(const X6Args& g, hipStream_t st) {
@@ -1733,7 +1742,7 @@ int launch_nt(const X6Args& g, hipStream_t st) {
             gs.strip_slabs = 1;
             return launch_nt_rm<F16, 2>(gs, st);
         }
-    if (g.K <= 64 || tiles128 < 256) return launch_nt_rm<F16, 1>(g, st);
+    if (g.K <= 64 || tiles128 < rm1_below()) return launch_nt_rm<F16, 1>(g, st);
     return launch_nt_rm<F16, 2>(g, st);
 }
 inline bool nt_args_ok(const float* A, int64_t lda, const void* Wsplit, const float* bias, const float* addend,

@@ -284,3 +284,111 @@ def test_alignn_ff_training_step_at_cfg4_size_vs_reference_class():
             assert e_n < 2e-4, (key, e_n)
     finally:
         _emit("cfg4", report)
+
+
+# ---------------------------------------------------------------------------------------------
+# EVERY element at the benchmarked size (the goldens hold 512 strided samples + 4 moments per tensor,
+# which a fault confined to one ragged tile of 676 200 rows would not move).  The float64 reference here is the PRODUCT's
+# plain-torch path (alignn_amd/torch_path.py: the modules' own nn.Linear / norm children + index_select / index_add),
+# run on the GPU on the same canonical batch - itself pinned to the reference class's float64 run at 1e-10
+# (tests/test_gpu_round3.py::test_float64_model_on_the_gpu_reproduces_the_float64_reference).  Nothing under oracle/
+# computes anything here except the seeded initial state.
+# ---------------------------------------------------------------------------------------------
+def _cmp_all(a, b):
+    """(normwise, elementwise with the 1 % floor, row of the worst element) over ALL elements, on the device"""
+    a, b = a.double(), b.double()
+    d = (a - b).abs()
+    scale = float(b.abs().max())
+    floor = 0.01 * float(b.abs().mean())
+    flat = int(d.argmax())
+    row = flat // (d.shape[-1] if d.dim() > 1 else 1)
+    return float(d.max()) / max(scale, 1e-300), float((d / (b.abs() + floor)).max()), row
+
+
+@pytest.mark.filterwarnings("ignore:alignn_amd. torch.float64 tensors run on plain torch")
+@pytest.mark.parametrize("tag,mk", [
+    ("cfg2", lambda: make_batch(64, 60)),
+    ("cfg5", lambda: make_batch(256, (9, 27), kind="molecule")),
+])
+def test_every_element_at_baseline_size_against_the_float64_torch_path(tag, mk):
+    import copy
+
+    raw = mk()
+    seed = 11
+    model = ALIGNN(ALIGNNConfig(name="alignn"))
+    model.load_state_dict(O.perturbed_norm_state_dict(O.init_state_dict(seed=seed), seed=seed + 1))
+    target = torch.randn(raw.batch_size, generator=torch.Generator().manual_seed(5))
+
+    m64 = copy.deepcopy(model).double().to(DEV).train()
+    acts64 = _hook(m64)
+    b64 = GraphBatch.from_raw(raw, device=DEV, dtype=torch.float64)
+    pred64 = m64(b64)
+    torch.nn.functional.l1_loss(pred64, target.double().to(DEV)).backward()
+    pred64 = pred64.detach()
+    grads64 = {k: p.grad for k, p in m64.named_parameters() if p.grad is not None}
+    stats64 = {k: v for k, v in m64.state_dict().items() if "running_" in k}
+    del b64
+    torch.cuda.empty_cache()
+
+    m32 = model.to(DEV).train()
+    acts = _hook(m32)
+    batch = GraphBatch.from_raw(raw, device=DEV)
+    pred = m32(batch)
+    torch.nn.functional.l1_loss(pred, target.to(DEV)).backward()
+    torch.cuda.synchronize()
+
+    report = [f"{tag}: every element vs the float64 torch path; N={raw.num_nodes} E={raw.num_edges} T={raw.num_triplets}"]
+    fails = []
+    try:
+        en, ee, _ = _cmp_all(pred.detach(), pred64)
+        report.append(f"pred: normwise {en:.2e} elementwise {ee:.2e}")
+        if not (en < 1e-5 and ee < 1e-3):  # (measured 1.1e-6 / 9.4e-5: the elementwise figure sits on a prediction near zero)
+            fails.append(("pred", en, ee))
+        worst_n, worst_e, n_act, n_elem = (0.0, None), (0.0, None), 0, 0
+        for name, (x, y) in acts.items():
+            x64, y64 = acts64[name]
+            for what, t, r in (("x_out", x, x64), ("y_out", y, y64)):
+                if t is None:  # dead output of the last layer: never materialised on the kernel path
+                    continue
+                assert t.shape == r.shape, (name, what, t.shape, r.shape)
+                assert bool(torch.isfinite(t).all()), (name, what)
+                en, ee, row = _cmp_all(t, r)
+                n_act, n_elem = n_act + 1, n_elem + t.numel()
+                worst_n, worst_e = max(worst_n, (en, f"{name}.{what} row {row}")), max(worst_e, (ee, f"{name}.{what} row {row}"))
+                if not (en < 1e-4 and ee < 2e-2):
+                    fails.append((name, what, en, ee, row))
+        report.append(f"activations: {n_act} tensors, {n_elem} elements, worst normwise {worst_n[0]:.2e} ({worst_n[1]}), worst "
+                      f"elementwise {worst_e[0]:.2e} ({worst_e[1]})")
+        gmax = max(float(g.abs().max()) for g in grads64.values())
+        worst_g, n_g, n_zero = (0.0, None), 0, 0
+        for k, p in m32.named_parameters():
+            if k not in grads64:
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+                continue
+            r = grads64[k]
+            own = float(r.abs().max())
+            if own < 1e-5 * gmax:  # analytically zero (a bias in front of a batch statistic): noise on both sides
+                n_zero += 1
+                if not float(p.grad.abs().max()) < 1e-5 * gmax:  # (measured 1.3e-6 on 256 molecules)
+                    fails.append((k, "zero-gradient noise", float(p.grad.abs().max()) / gmax))
+                continue
+            e = float((p.grad.double() - r).abs().max()) / own
+            worst_g = max(worst_g, (e, k))
+            n_g += 1
+            if not e < 1e-4:
+                fails.append((k, "grad", e))
+        report.append(f"gradients: {n_g} parameters (all elements), worst error vs the parameter's own scale {worst_g[0]:.2e} "
+                      f"({worst_g[1]}); {n_zero} analytically-zero gradients")
+        worst_s = (0.0, None)
+        sd = m32.state_dict()
+        for k, r in stats64.items():
+            e = float((sd[k].double() - r).abs().max()) / max(float(r.abs().max()), 1e-30)
+            worst_s = max(worst_s, (e, k))
+            if not e < 1e-5:
+                fails.append((k, "running statistic", e))
+        report.append(f"running statistics: {len(stats64)} buffers, worst {worst_s[0]:.2e} ({worst_s[1]})")
+        if fails:
+            report.append(f"FAILURES: {fails[:12]}")
+    finally:
+        _emit(f"{tag}_every_element", report)
+    assert not fails, fails[:12]
