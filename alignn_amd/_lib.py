@@ -67,6 +67,7 @@ SIGNATURES = {
     "alignn_bn_silu_bwd_reduce": (_i32, [_p, _i64, _p, _i64, _p, _i64, _i32, _p, _p]),
     "alignn_bn_bwd_finalize": (_i32, [_p, _i32, _i32, _p, _p]),
     "alignn_bn_silu_bwd_apply": (_i32, [_p, _i64, _p, _i64, _p, _p, _p, _i32, _p, _i64, _i64, _i32, _p, _p]),
+    "alignn_bn_silu_bwd_apply_node": (_i32, [_p, _i64, _p, _i64, _p, _p, _p, _i32, _p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p]),
     "alignn_bn_silu_bwd_apply_sum": (_i32, [_p, _i64, _p, _i64, _p, _p, _i32, _p, _i64, _i64, _i32, _p, _p, _p]),
     "alignn_egc_slabs": (_i32, [_i64]),
     "alignn_egc_gate_fwd": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p]),

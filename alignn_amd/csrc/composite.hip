@@ -163,9 +163,8 @@ int alignn_egc_conv_bwd(const alignn_egc_bwd_args* a, alignn_stream_t st) {
     // ---- node branch: BatchNorm / SiLU backward -> g_xpre, then the quotient's adjoints
     ALIGNN_TRY(alignn_bn_silu_bwd_reduce(a->gx_out, H, a->xpre, H, a->n_stat, n, H, n_red_part, st));
     ALIGNN_TRY(alignn_bn_bwd_finalize(n_red_part, s.n_slabs, H, a->n_red, st));
-    ALIGNN_TRY(alignn_bn_silu_bwd_apply(a->gx_out, H, a->xpre, H, a->n_stat, a->n_gamma, a->n_red, 0, g_xpre, 4 * H, n, H,
-                                        a->gp_amax, st));
-    ALIGNN_TRY(alignn_egc_node_bwd(g_xpre, 4 * H, a->s0, a->hh, a->gs1, a->gs0, n, H, st));
+    ALIGNN_TRY(alignn_bn_silu_bwd_apply_node(a->gx_out, H, a->xpre, H, a->n_stat, a->n_gamma, a->n_red, 0, g_xpre, 4 * H, n, H,
+                                             a->gp_amax, a->s0, a->hh, a->gs1, a->gs0, st));
     // ---- edge branch: the BatchNorm-backward sums of the edge output (unless the consumer's projection left them)
     const float* e_red = a->e_red_in;
     if (a->gy_out != nullptr && e_red == nullptr) {

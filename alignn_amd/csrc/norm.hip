@@ -131,7 +131,20 @@ __global__ __launch_bounds__(kRedCols* kRedLanes) void bn_finalize_kernel(
     const bool ok = f < F;
     double s = 0.0, ss = 0.0;
     if (ok) {
-        for (int k = threadIdx.y; k < slabs; k += kRedLanes) {
+        // (eight slabs' loads in flight before the first add: the slabs were just written by other XCDs, every load is a
+        // last-level-cache round trip and the compiler otherwise chains them behind the float64 adds; same order of adds)
+        int k = threadIdx.y;
+        for (; k + 7 * kRedLanes < slabs; k += 8 * kRedLanes) {
+            float a[8], b[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                a[u] = partial[(size_t)(k + u * kRedLanes) * 2 * F + f];
+                b[u] = partial[(size_t)(k + u * kRedLanes) * 2 * F + F + f];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += (double)a[u], ss += (double)b[u];
+        }
+        for (; k < slabs; k += kRedLanes) {
             s += (double)partial[(size_t)k * 2 * F + f];
             ss += (double)partial[(size_t)k * 2 * F + F + f];
         }
@@ -170,8 +183,17 @@ __global__ __launch_bounds__(kRedCols* kRedLanes) void slab_sum_kernel(const flo
     __shared__ double sh[kRedLanes][kRedCols];
     const int f = blockIdx.x * kRedCols + threadIdx.x;
     double s = 0.0;
-    if (f < width)
-        for (int k = threadIdx.y; k < slabs; k += kRedLanes) s += (double)partial[(size_t)k * stride + f];
+    if (f < width) {
+        int k = threadIdx.y;
+        for (; k + 7 * kRedLanes < slabs; k += 8 * kRedLanes) {  // (batched loads, same order of adds: see bn_finalize_kernel)
+            float a[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] = partial[(size_t)(k + u * kRedLanes) * stride + f];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += (double)a[u];
+        }
+        for (; k < slabs; k += kRedLanes) s += (double)partial[(size_t)k * stride + f];
+    }
     s = lane_tree_sum(s, sh);
     if (f < width && threadIdx.y == 0) out[f] = (float)s;
 }
@@ -273,14 +295,28 @@ __global__ __launch_bounds__(kWfCols* kWfLanes) void bn_finalize_welford_kernel(
         int k0 = 0;
         while (k0 < slabs - 1 && counts[k0] == 0.0f) ++k0;
         P = (double)partial[(size_t)k0 * 3 * F + f];
-        for (int k = threadIdx.y; k < slabs; k += kWfLanes) {
-            const double nk = (double)counts[k];
+        auto merge = [&](float nkf, float pk, float Skf, float SSk) {
+            const double nk = (double)nkf;
             if (nk > 0.0) {
-                const float* sl = partial + (size_t)k * 3 * F;
-                const double d = (double)sl[f] - P, Sk = (double)sl[F + f];
+                const double d = (double)pk - P, Sk = (double)Skf;
                 s += Sk + nk * d;
-                ss += (double)sl[2 * F + f] + d * (2.0 * Sk + nk * d);
+                ss += (double)SSk + d * (2.0 * Sk + nk * d);
             }
+        };
+        int k = threadIdx.y;
+        for (; k + 3 * kWfLanes < slabs; k += 4 * kWfLanes) {  // (four slabs' loads in flight; same order of merges)
+            float nk[4], pk[4], Sk[4], SSk[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float* sl = partial + (size_t)(k + u * kWfLanes) * 3 * F;
+                nk[u] = counts[k + u * kWfLanes], pk[u] = sl[f], Sk[u] = sl[F + f], SSk[u] = sl[2 * F + f];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) merge(nk[u], pk[u], Sk[u], SSk[u]);
+        }
+        for (; k < slabs; k += kWfLanes) {
+            const float* sl = partial + (size_t)k * 3 * F;
+            merge(counts[k], sl[f], sl[F + f], sl[2 * F + f]);
         }
     }
     sh[0][threadIdx.y][threadIdx.x] = s;
@@ -376,11 +412,15 @@ __global__ __launch_bounds__(kThreads) void bn_silu_fwd_cols_kernel(const float*
     block_amax_commit(am, amax);
 }
 
-template <bool STREAM>
+// NODE: GX is the gradient of a convolution's x_pre = Ux + S1 / (S0 + eps) - the quotient's adjoints
+// gS1 = GX / (S0 + eps), gS0 = -gS1 * h (h = S1 / (S0 + eps), saved by the forward) go out in the same pass
+// (alignn_egc_node_bwd's arithmetic on the values this pass has in registers: same bits, one launch and one read of GX less)
+template <bool STREAM, bool NODE = false>
 __global__ __launch_bounds__(kThreads) void bn_silu_bwd_apply_kernel(
     const float* __restrict__ GY, int64_t ldgy, const float* __restrict__ X, int64_t ldx,
     const float* __restrict__ stat, const float* __restrict__ gamma, const float* __restrict__ red, int eval_mode,
-    float* __restrict__ GX, int64_t ldgx, int64_t rows, int F, float* __restrict__ amax) {
+    float* __restrict__ GX, int64_t ldgx, int64_t rows, int F, float* __restrict__ amax,
+    const float* __restrict__ S0, const float* __restrict__ HH, float* __restrict__ GS1, float* __restrict__ GS0) {
     const int Q = F >> 2;
     const RowQuad rq(Q);
     const int64_t total = rows * Q;
@@ -411,6 +451,16 @@ __global__ __launch_bounds__(kThreads) void bn_silu_bwd_apply_kernel(
         }
         f4_sts<STREAM>(GX + r * ldgx + q * 4, o);
         am = fmaxf(am, f4_absmax(o));
+        if constexpr (NODE) {
+            const float4 s0 = f4_ld(S0 + r * F + q * 4), h = f4_ld(HH + r * F + q * 4);
+            float4 g1;
+            g1.x = o.x / (s0.x + ALIGNN_EPS_GATE);
+            g1.y = o.y / (s0.y + ALIGNN_EPS_GATE);
+            g1.z = o.z / (s0.z + ALIGNN_EPS_GATE);
+            g1.w = o.w / (s0.w + ALIGNN_EPS_GATE);
+            f4_st(GS1 + r * F + q * 4, g1);
+            f4_st(GS0 + r * F + q * 4, make_float4(-g1.x * h.x, -g1.y * h.y, -g1.z * h.z, -g1.w * h.w));
+        }
     }
     block_amax_commit(am, amax);
 }
@@ -846,11 +896,28 @@ int alignn_bn_silu_bwd_apply(const float* GY, int64_t ldgy, const float* X, int6
     if (rows == 0) return 0;
     int grid = stream_grid(rows * (F >> 2), streaming(rows, F));
     if (streaming(rows, F))
-        hipLaunchKernelGGL(bn_silu_bwd_apply_kernel<true>, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, GY, ldgy, X,
-                           ldx, stat, gamma, red, eval_mode, GX, ldgx, rows, F, amax);
+        hipLaunchKernelGGL((bn_silu_bwd_apply_kernel<true, false>), dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, GY, ldgy,
+                           X, ldx, stat, gamma, red, eval_mode, GX, ldgx, rows, F, amax, nullptr, nullptr, nullptr, nullptr);
     else
-        hipLaunchKernelGGL(bn_silu_bwd_apply_kernel<false>, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, GY, ldgy,
-                           X, ldx, stat, gamma, red, eval_mode, GX, ldgx, rows, F, amax);
+        hipLaunchKernelGGL((bn_silu_bwd_apply_kernel<false, false>), dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, GY,
+                           ldgy, X, ldx, stat, gamma, red, eval_mode, GX, ldgx, rows, F, amax, nullptr, nullptr, nullptr, nullptr);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_bn_silu_bwd_apply_node(const float* GY, int64_t ldgy, const float* X, int64_t ldx, const float* stat,
+                                  const float* gamma, const float* red, int eval_mode, float* GX, int64_t ldgx, int64_t rows,
+                                  int F, float* amax, const float* S0, const float* HH, float* GS1, float* GS0,
+                                  alignn_stream_t stream) {
+    if (!feat_ok(F) || S0 == nullptr || HH == nullptr || GS1 == nullptr || GS0 == nullptr) return (int)hipErrorInvalidValue;
+    if (rows == 0) return 0;
+    int grid = stream_grid(rows * (F >> 2), streaming(rows, F));
+    if (streaming(rows, F))
+        hipLaunchKernelGGL((bn_silu_bwd_apply_kernel<true, true>), dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, GY, ldgy,
+                           X, ldx, stat, gamma, red, eval_mode, GX, ldgx, rows, F, amax, S0, HH, GS1, GS0);
+    else
+        hipLaunchKernelGGL((bn_silu_bwd_apply_kernel<false, true>), dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, GY,
+                           ldgy, X, ldx, stat, gamma, red, eval_mode, GX, ldgx, rows, F, amax, S0, HH, GS1, GS0);
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }

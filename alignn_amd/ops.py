@@ -1751,11 +1751,16 @@ class EdgeGatedConvFn(torch.autograd.Function):
             n_red = _ln_silu_bwd(gx_out, xpre, n_gamma, n_beta, n_stat, g_xpre, gp_amax)
         else:
             n_red = _bn_silu_bwd_reduce(gx_out, xpre, n_stat)
-            _bn_silu_bwd_apply(gx_out, xpre, n_stat, n_gamma, n_red, ev, g_xpre, gp_amax)
         gs1 = _empty(n, H, like=x)
         gs0 = _empty(n, H, like=x)
-        check(lib.alignn_egc_node_bwd(ptr(g_xpre), 4 * H, ptr(s0), ptr(hh), ptr(gs1), ptr(gs0), n, H, stream()),
-              "egc_node_bwd")
+        if layer:
+            check(lib.alignn_egc_node_bwd(ptr(g_xpre), 4 * H, ptr(s0), ptr(hh), ptr(gs1), ptr(gs0), n, H, stream()),
+                  "egc_node_bwd")
+        else:  # (norm backward and the quotient's adjoints in one pass)
+            check(lib.alignn_bn_silu_bwd_apply_node(ptr(gx_out), gx_out.stride(0), ptr(xpre), xpre.stride(0), ptr(n_stat),
+                                                    ptr(n_gamma), ptr(n_red), int(ev), ptr(g_xpre), g_xpre.stride(0), n, H,
+                                                    ptr(gp_amax), ptr(s0), ptr(hh), ptr(gs1), ptr(gs0), stream()),
+                  "bn_silu_bwd_apply_node")
         if gy_out is not None:
             gy_out = gy_out.contiguous()
         lg_blocks = graph.grp_seg_ptr is not None and FUSED_LG_BACKWARD

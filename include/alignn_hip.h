@@ -251,6 +251,13 @@ int alignn_bn_silu_bwd_apply(const float* GY, int64_t ldgy, const float* X, int6
                              const float* stat, const float* gamma, const float* red, int eval_mode,
                              float* GX, int64_t ldgx, int64_t rows, int F, float* amax,
                              alignn_stream_t stream);
+/* ... for the NODE norm of a convolution (GX = gradient of x_pre = Ux + S1 / (S0 + 1e-6), alignn/models/alignn.py:110-111,
+ * 122-123): the quotient's adjoints GS1 = GX / (S0 + 1e-6), GS0 = -GS1 * HH in the same pass - alignn_bn_silu_bwd_apply
+ * followed by alignn_egc_node_bwd, same bits, one launch.  S0, HH, GS1, GS0: [rows, F] contiguous. */
+int alignn_bn_silu_bwd_apply_node(const float* GY, int64_t ldgy, const float* X, int64_t ldx, const float* stat,
+                                  const float* gamma, const float* red, int eval_mode, float* GX, int64_t ldgx,
+                                  int64_t rows, int F, float* amax, const float* S0, const float* HH, float* GS1, float* GS0,
+                                  alignn_stream_t stream);
 /* ... and, in the same pass, the column sums of GX - the bias gradient of the nn.Linear in front of the BatchNorm
  * (MLPLayer, alignn/models/alignn.py:170-184) - as [alignn_col_stats_slabs(rows)][F] slabs for alignn_slab_sum. */
 int alignn_bn_silu_bwd_apply_sum(const float* GY, int64_t ldgy, const float* X, int64_t ldx, const float* stat,

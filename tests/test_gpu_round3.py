@@ -525,3 +525,47 @@ def test_fused_embedding_head_equals_the_unfused_layers(case):
         # rounding noise only; everything else: against the tensor's own scale
         scale = max(float(b[k].abs().max()), 1e-3 * gmax) if k.startswith("g.") else max(float(b[k].abs().max()), 1e-6)
         assert float((a[k] - b[k]).abs().max()) <= 2e-4 * scale, (k, float((a[k] - b[k]).abs().max()), scale)
+
+
+# ---------------------------------------------------------------------------------------------
+# BatchNorm backward of the node norm with the quotient's adjoints in the same pass
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,F", [(1, 64), (3840, 256), (50712, 256), (140001, 256)])
+def test_norm_backward_with_node_adjoints_is_the_two_pass_result_bit_for_bit(rows, F):
+    from alignn_amd import _lib
+    from alignn_amd._lib import check, ptr
+
+    lib = _lib.load()
+    g = torch.Generator(device=DEV).manual_seed(rows)
+    gy = torch.randn(rows, F, device=DEV, generator=g)
+    x = torch.randn(rows, F, device=DEV, generator=g) * 2 + 0.5
+    s0 = torch.rand(rows, F, device=DEV, generator=g) * 8
+    s0[::7] = 0.0  # (isolated nodes: S0 = 0, the epsilon alone in the denominator)
+    hh = torch.randn(rows, F, device=DEV, generator=g)
+    gamma = torch.rand(F, device=DEV, generator=g) + 0.5
+    stat = torch.stack([x.mean(0), 1 / (x.var(0, unbiased=False) + 1e-5).sqrt(), gamma / (x.var(0, unbiased=False) + 1e-5).sqrt(),
+                        torch.randn(F, device=DEV, generator=g)]).contiguous()
+    red = torch.randn(2, F, device=DEV, generator=g)
+    st = torch.cuda.current_stream().cuda_stream
+
+    GP_a, GP_b = torch.zeros(rows, 4 * F, device=DEV), torch.zeros(rows, 4 * F, device=DEV)
+    am_a, am_b = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+    gxa, gxb = GP_a[:, 3 * F:], GP_b[:, 3 * F:]
+    gs1a, gs0a, gs1b, gs0b = (torch.empty(rows, F, device=DEV) for _ in range(4))
+    check(lib.alignn_bn_silu_bwd_apply(ptr(gy), F, ptr(x), F, ptr(stat), ptr(gamma), ptr(red), 0, ptr(gxa), 4 * F, rows, F,
+                                       ptr(am_a), st), "apply")
+    check(lib.alignn_egc_node_bwd(ptr(gxa), 4 * F, ptr(s0), ptr(hh), ptr(gs1a), ptr(gs0a), rows, F, st), "node_bwd")
+    check(lib.alignn_bn_silu_bwd_apply_node(ptr(gy), F, ptr(x), F, ptr(stat), ptr(gamma), ptr(red), 0, ptr(gxb), 4 * F, rows, F,
+                                            ptr(am_b), ptr(s0), ptr(hh), ptr(gs1b), ptr(gs0b), st), "apply_node")
+    torch.cuda.synchronize()
+    assert torch.equal(GP_a, GP_b) and torch.equal(am_a, am_b)
+    assert torch.equal(gs1a, gs1b) and torch.equal(gs0a, gs0b)
+    # and against float64
+    xc = x.double() - stat[0].double()
+    z = xc * stat[2].double() + stat[3].double()
+    sg = torch.sigmoid(z)
+    gz = gy.double() * (sg * (1 + z * (1 - sg)))
+    ref = stat[2].double() * (gz - (red[0].double() + xc * stat[1].double() * red[1].double()) / rows)
+    assert float((gxb.double() - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+    ref1 = ref / (s0.double() + 1e-6)
+    assert float((gs1b.double() - ref1).abs().max()) < 2e-5 * float(ref1.abs().max())
