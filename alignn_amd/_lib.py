@@ -99,6 +99,7 @@ SIGNATURES = {
     "alignn_egc_conv_wgrad_scratch": (_sz, [_i64, _i64, _i32, _i32]),
     "alignn_egc_conv_wgrad": (_i32, [_p, _p]),
     "alignn_egc_args_sizeof": (_sz, [_i32]),
+    "alignn_fork_events_init": (_i32, []),
     "alignn_rbf_mlp_supported": (_i32, [_i32, _i32]),
     "alignn_rbf_mlp_slabs": (_i32, [_i64]),
     "alignn_rbf_mlp_stats": (_i32, [_p, _p, _f32, _p, _p, _i64, _i32, _i32, _p, _p]),
@@ -117,7 +118,7 @@ SIGNATURES = {
 import struct as _struct
 
 EGC_FWD_ARGS = _struct.Struct("@5P2q6i2f32PN")
-EGC_BWD_ARGS = _struct.Struct("@8P3q8i22Pq13PN")
+EGC_BWD_ARGS = _struct.Struct("@8P3q8i22Pq14PN")
 EGC_WGRAD_ARGS = _struct.Struct("@2q4i14PN")
 
 _lib = None

@@ -77,9 +77,36 @@ int bn_finalize_folded(const float* partial, int slabs, float* fold, int64_t row
     return alignn_bn_finalize(partial, slabs, rows, F, gamma, beta, eps, momentum, rm, rv, stat, st);
 }
 
+// fork / join events of the composite entry points, one pair per device (alignn_fork_events_init)
+constexpr int kMaxDevices = 32;
+hipEvent_t g_fork_ev[kMaxDevices][2];
+bool g_fork_ok[kMaxDevices];
+
+inline bool fork_events(hipEvent_t* fork, hipEvent_t* join) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices || !g_fork_ok[dev]) return false;
+    *fork = g_fork_ev[dev][0];
+    *join = g_fork_ev[dev][1];
+    return true;
+}
+
 }  // namespace
 
 extern "C" {
+
+int alignn_fork_events_init(void) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= kMaxDevices) return (int)hipErrorInvalidDevice;
+    if (g_fork_ok[dev]) return 0;
+    for (int i = 0; i < 2; ++i) {
+        e = hipEventCreateWithFlags(&g_fork_ev[dev][i], hipEventDisableTiming);
+        if (e != hipSuccess) return (int)e;
+    }
+    g_fork_ok[dev] = true;
+    return 0;
+}
 
 size_t alignn_egc_args_sizeof(int which) {
     switch (which) {
@@ -186,7 +213,16 @@ int alignn_egc_conv_bwd(const alignn_egc_bwd_args* a, alignn_stream_t st) {
                                       a->seg_node, a->src, n, H, a->GM, a->GP, a->gb_part, a->gm_amax, a->gp_amax, st));
         ALIGNN_TRY(alignn_egc_bwd_src(a->GM, a->M, a->gs1, a->out_ptr, a->out_slot, a->dst, n, H, a->GP, a->gp_amax, st));
     }
-    // ---- input gradients (critical path): g_x = GP wcat (+ gx_out), g_y = GM w_eg (+ gy_out)
+    // ---- input gradients (critical path): g_x = GP wcat (+ gx_out), g_y = GM w_eg (+ gy_out) - independent of each other:
+    // with a second stream the (shorter) node product runs beside the edge product
+    hipEvent_t ev_fork, ev_join;
+    const bool forked = a->aux_stream != nullptr && fork_events(&ev_fork, &ev_join);
+    alignn_stream_t st_main = st;
+    if (forked) {
+        ALIGNN_TRY((int)hipEventRecord(ev_fork, (hipStream_t)st_main));
+        ALIGNN_TRY((int)hipStreamWaitEvent((hipStream_t)a->aux_stream, ev_fork, 0));
+        st = a->aux_stream;
+    }
     const float* addx = a->residual ? a->gx_out : nullptr;
     switch (a->dx_kind) {
         case 1:
@@ -202,6 +238,10 @@ int alignn_egc_conv_bwd(const alignn_egc_bwd_args* a, alignn_stream_t st) {
             break;
         default:
             ALIGNN_TRY(alignn_gemm_nn(a->GP, 4 * H, a->wcat, Kin, addx, addx ? H : 0, a->g_x, Kin, n, 4 * H, Kin, st));
+    }
+    if (forked) {
+        ALIGNN_TRY((int)hipEventRecord(ev_join, (hipStream_t)a->aux_stream));
+        st = st_main;
     }
     const float* addy = (a->residual && a->gy_out != nullptr) ? a->gy_out : nullptr;
     switch (a->dy_kind) {
@@ -234,6 +274,7 @@ int alignn_egc_conv_bwd(const alignn_egc_bwd_args* a, alignn_stream_t st) {
         default:
             ALIGNN_TRY(alignn_gemm_nn(a->GM, H, a->w_eg, Kin, addy, addy ? H : 0, a->g_y, Kin, m, H, Kin, st));
     }
+    if (forked) ALIGNN_TRY((int)hipStreamWaitEvent((hipStream_t)st_main, ev_join, 0));
     return 0;
 }
 

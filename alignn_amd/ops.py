@@ -1356,6 +1356,29 @@ def rbf_mlp_layer(d, centers, gamma_rbf, w, b, gamma, beta, running_mean, runnin
 # BatchNorm flavour in training mode on one stream; lanes (hipGraph capture: host cost is irrelevant there), LayerNorm,
 # eval mode and the rare kernel choices the composites do not carry take the per-kernel path below.
 COMPOSITE = _os.environ.get("ALIGNN_AMD_COMPOSITE", "1") != "0"
+# composite backward: node input gradient on a second stream beside the edge one.  "auto": inside a stream capture only (like the
+# lanes: -0.15 ms per replayed step at 64 crystals, -0.24 ms at 8; eagerly launched the four event calls per convolution cost
+# the host more than the overlap returns: 16.96 vs 16.81 ms); "1": always; "0": never.
+FORK_DGRAD = _os.environ.get("ALIGNN_AMD_FORK", "auto")
+_AUX = {}  # device -> torch.cuda.Stream of the fork (None: the library's events could not be made yet)
+
+
+def _aux_stream(dev):
+    """Raw handle of the stream the composite backward forks its node input gradient onto, or None (switch off, or the
+    first call on this device happens inside a stream capture - the library's event pair has to be created outside one)."""
+    if FORK_DGRAD == "0":
+        return None
+    capturing = torch.cuda.is_current_stream_capturing()
+    s = _AUX.get(dev)
+    if s is None:
+        if capturing:
+            return None
+        with torch.cuda.device(dev):
+            check(_lib.load().alignn_fork_events_init(), "fork_events_init")
+            s = _AUX[dev] = torch.cuda.Stream(device=dev)
+    if FORK_DGRAD == "auto" and not capturing:
+        return None
+    return s.cuda_stream
 COMPOSITE_STATS = {"fwd": 0, "bwd": 0, "wgrad": 0}
 
 
@@ -1687,7 +1710,7 @@ class EdgeGatedConvFn(torch.autograd.Function):
             _P(y_src[0] if dy_kind == 1 else None), _P(y_src[1] if dy_kind == 1 else None),
             y_src[0].stride(0) if dy_kind == 1 else 0,
             _P(GP), _P(GM), _P(gs[0]), _P(gs[1]), _P(n_red), _P(e_red if e_red_in is None else None), _P(gb_part), _P(g_x),
-            _P(g_y), _P(src_red), _P(gp_amax), _P(gm_amax),
+            _P(g_y), _P(src_red), _P(gp_amax), _P(gm_amax), _aux_stream(x.device) or 0,
             _P(scratch), nbytes)
         check(lib.alignn_egc_conv_bwd(args, stream()), "egc_conv_bwd")
         COMPOSITE_STATS["bwd"] += 1

@@ -546,9 +546,16 @@ typedef struct alignn_egc_bwd_args {
     const float *src_xn, *src_nstat;                                    /* dy_kind 1: the norm y came out of */
     int64_t src_ldxn;
     float *GP, *GM, *gs1, *gs0, *n_red, *e_red, *gb_part, *g_x, *g_y, *src_red, *gp_amax, *gm_amax;
+    alignn_stream_t aux_stream; /* optional second stream: the node input gradient g_x = GP wcat runs there, beside
+                                   g_y = GM w_eg on the caller's stream (fork after the gate backward, join before the call
+                                   returns; needs alignn_fork_events_init() to have run on this device - otherwise, or with
+                                   NULL, everything stays on the one stream).  Same kernels, same results. */
     float* scratch;
     size_t scratch_bytes;
 } alignn_egc_bwd_args;
+/* creates (once per device, for the CURRENT device) the two events the composite entry points fork / join with; call it
+ * outside stream capture.  Returns 0, or the HIP error. */
+int alignn_fork_events_init(void);
 size_t alignn_egc_conv_bwd_scratch(int64_t n, int64_t m, int H, int Kin, int dx_kind, int dy_kind);
 int alignn_egc_conv_bwd(const alignn_egc_bwd_args* args, alignn_stream_t stream);
 
