@@ -4,11 +4,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from alignn_amd import ALIGNN, ALIGNNConfig, GraphBatch
 from alignn_amd.synthetic import make_batch
 dev = "cuda"
-batch = GraphBatch.from_raw(make_batch(64, 60), device=dev)
+B = int(os.environ.get("B", "64"))
+batch = GraphBatch.from_raw(make_batch(B, 60), device=dev)
 torch.manual_seed(0)
 model = ALIGNN(ALIGNNConfig(name="alignn")).to(dev).train()
 opt = torch.optim.AdamW(model.parameters(), lr=1e-3, fused=True)
-target = torch.randn(64, device=dev)
+target = torch.randn(B, device=dev)
 def step():
     opt.zero_grad(set_to_none=True)
     torch.nn.functional.l1_loss(model(batch), target).backward()
@@ -18,4 +19,4 @@ torch.cuda.synchronize()
 pr = cProfile.Profile(); pr.enable()
 for _ in range(5): step()
 pr.disable(); torch.cuda.synchronize()
-st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(28)
+st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(32); st.sort_stats("cumulative").print_stats(45)
