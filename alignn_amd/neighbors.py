@@ -176,6 +176,44 @@ def knn_multigraph_batch(lattices: Sequence, fracs: Sequence, cutoff: float = 8.
 KNN_LEVELS = 5  # cutoffs tried per crystal: the given one, then longest lattice vector / doubling (graphs.py:170-188)
 
 
+# What knn_multigraph_batch_hip derives from the LATTICES alone (cell matrices, per-site crystal index, the ladder of cutoffs
+# and image-box reaches: ~20 small torch operations incl. a batched 3 x 3 inverse).  MD at constant cell (alignn/ff/
+# calculators.py rebuilds the graph of the same atoms every step) passes the same lattice tensors again and again: the last
+# result is kept, keyed on the tensors' identity and version counters.
+_LATTICE_TABLES = {"key": None, "refs": None, "val": None}
+
+
+def _lattice_tables(lattices, ns, dev, cutoff):
+    tens = [x for x in lattices if isinstance(x, torch.Tensor)]
+    key = None
+    if len(tens) == len(lattices):
+        key = (tuple((id(x), x._version, x.device, x.dtype) for x in tens), tuple(ns), str(dev), cutoff)
+        c = _LATTICE_TABLES
+        if c["key"] == key and all(r() is x for r, x in zip(c["refs"], tens)):
+            return c["val"]
+    B, N = len(ns), sum(ns)
+    lat = torch.stack([torch.as_tensor(x).to(dev, torch.float64) for x in lattices]).contiguous()  # [B,3,3]
+    n_t = torch.tensor(ns, device=dev, dtype=torch.int64)
+    gptr = _ptr_from_counts(n_t).to(torch.int32)
+    site_graph = torch.repeat_interleave(torch.arange(B, device=dev, dtype=torch.int32), n_t, output_size=N)
+    lg = lat[site_graph.long()].contiguous()  # [N,3,3]
+    longest = torch.linalg.norm(lat, dim=2).max(dim=1).values
+    spacing = 1.0 / torch.linalg.norm(torch.linalg.inv(lat), dim=1)  # [B,3]
+    cuts = [torch.full((B,), float(cutoff), dtype=torch.float64, device=dev)]
+    for _ in range(KNN_LEVELS - 1):
+        c = cuts[-1]
+        cuts.append(torch.where(c < longest, longest, 2.0 * c))
+    cut = torch.stack(cuts, 1).contiguous()  # [B,L]
+    reach = torch.ceil(cut[:, :, None] / spacing[:, None, :]).to(torch.int32).contiguous()  # [B,L,3]
+    val = (lat, gptr, site_graph, lg, cut, reach)
+    _LATTICE_TABLES["volume"] = torch.linalg.det(lat).abs().float()  # (crystal_batch's GraphBatch.volume, same lifetime)
+    if key is not None:
+        import weakref
+
+        _LATTICE_TABLES.update(key=key, refs=[weakref.ref(x) for x in tens], val=val)
+    return val
+
+
 def knn_multigraph_batch_hip(lattices: Sequence, fracs: Sequence, cutoff: float = 8.0, max_neighbors: int = 12, device=None,
                              return_images: bool = False):
     """``knn_multigraph_batch`` on the hand-written kernels of csrc/knn.hip (one wavefront per site): the same bond
@@ -192,22 +230,10 @@ def knn_multigraph_batch_hip(lattices: Sequence, fracs: Sequence, cutoff: float 
     ns = [int(torch.as_tensor(f).shape[0]) for f in fracs]
     N = sum(ns)
     with _lib.device_guard(torch.empty(0, device=dev)):
-        lat = torch.stack([torch.as_tensor(x).to(dev, torch.float64) for x in lattices]).contiguous()  # [B,3,3]
         frac = torch.cat([torch.as_tensor(f).to(dev, torch.float64) for f in fracs]).contiguous()  # [N,3]
-        n_t = torch.tensor(ns, device=dev, dtype=torch.int64)
-        gptr = _ptr_from_counts(n_t).to(torch.int32)
-        site_graph = torch.repeat_interleave(torch.arange(B, device=dev, dtype=torch.int32), n_t, output_size=N)
-        lg = lat[site_graph.long()]  # [N,3,3]
+        lat, gptr, site_graph, lg, cut, reach = _lattice_tables(lattices, ns, dev, float(cutoff))
         # the fixed-order float64 product of knn_multigraph / synthetic._all_neighbors (separate multiplies and adds)
         cart = (frac[:, 0:1] * lg[:, 0, :] + frac[:, 1:2] * lg[:, 1, :] + frac[:, 2:3] * lg[:, 2, :]).contiguous()
-        longest = torch.linalg.norm(lat, dim=2).max(dim=1).values
-        spacing = 1.0 / torch.linalg.norm(torch.linalg.inv(lat), dim=1)  # [B,3]
-        cuts = [torch.full((B,), float(cutoff), dtype=torch.float64, device=dev)]
-        for _ in range(KNN_LEVELS - 1):
-            c = cuts[-1]
-            cuts.append(torch.where(c < longest, longest, 2.0 * c))
-        cut = torch.stack(cuts, 1).contiguous()  # [B,L]
-        reach = torch.ceil(cut[:, :, None] / spacing[:, None, :]).to(torch.int32).contiguous()  # [B,L,3]
         level = torch.zeros(B, dtype=torch.int32, device=dev)
         kth = torch.empty(N, dtype=torch.float64, device=dev)
         count = torch.empty(N, dtype=torch.int64, device=dev)
@@ -255,6 +281,9 @@ def crystal_batch(lattices: Sequence, fracs: Sequence, atom_features: Optional[S
     batch.r = r[g.perm].contiguous()
     if atom_features is not None:
         batch.atom_features = torch.cat([torch.as_tensor(a) for a in atom_features]).to(dev, torch.float32).contiguous()
-    lat_t = torch.stack([torch.as_tensor(x).to(dev, torch.float64) for x in lattices])
-    batch.volume = torch.linalg.det(lat_t).abs().float()
+    if dev.type == "cuda":  # (derived with the other lattice tables a moment ago, or kept from the last call with these tensors)
+        batch.volume = _LATTICE_TABLES["volume"]
+    else:
+        lat_t = torch.stack([torch.as_tensor(x).to(dev, torch.float64) for x in lattices])
+        batch.volume = torch.linalg.det(lat_t).abs().float()
     return batch

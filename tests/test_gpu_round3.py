@@ -569,3 +569,39 @@ def test_norm_backward_with_node_adjoints_is_the_two_pass_result_bit_for_bit(row
     assert float((gxb.double() - ref).abs().max()) < 2e-5 * float(ref.abs().max())
     ref1 = ref / (s0.double() + 1e-6)
     assert float((gs1b.double() - ref1).abs().max()) < 2e-5 * float(ref1.abs().max())
+
+
+# ---------------------------------------------------------------------------------------------
+# MD: the force-field evaluation replayed from a hipGraph per batch shape (alignn_amd/md.py)
+# ---------------------------------------------------------------------------------------------
+def test_graphed_force_field_replays_equal_the_eager_evaluation():
+    from alignn_amd import ALIGNNAtomWise, ALIGNNAtomWiseConfig, neighbors
+    from alignn_amd.md import GraphedForceField, signature
+    from alignn_amd.synthetic import make_crystal
+
+    n = 64
+    lat, frac, _ = make_crystal(n, 4321)
+    lat_d, frac_d = torch.from_numpy(lat).to(DEV), torch.from_numpy(frac).to(DEV)
+    feats = torch.randn(n, 92, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+    torch.manual_seed(0)
+    model = ALIGNNAtomWise(ALIGNNAtomWiseConfig(name="alignn_atomwise", alignn_layers=2, gcn_layers=2, hidden_features=64,
+                                                 embedding_features=32, atom_input_features=92, calculate_gradient=True,
+                                                 stresswise_weight=0.05)).to(DEV).eval()
+    ff = GraphedForceField(model, clone=True)
+    gen = torch.Generator(device=DEV).manual_seed(7)
+    sigs = set()
+    for step in range(8):
+        # small displacements: the neighbour lists mostly keep their sizes, the bond vectors change every step
+        f = frac_d + (1e-5 * step) * torch.randn(frac_d.shape, device=DEV, dtype=frac_d.dtype, generator=gen)
+        batch = neighbors.crystal_batch([lat_d], [f], atom_features=[feats])
+        sigs.add(signature(batch))
+        ref = model(batch)
+        got = ff(batch)
+        for k in ("out", "grad", "stresses"):
+            assert got[k].shape == ref[k].shape, k
+            scale = float(ref[k].abs().max())
+            assert float((got[k] - ref[k]).abs().max()) <= 1e-6 * scale, (step, k, float((got[k] - ref[k]).abs().max()), scale)
+    assert ff.stats["captured"] == len(sigs) <= 4, (ff.stats, len(sigs))
+    assert ff.stats["replayed"] == 8 - len(sigs) and ff.stats["replayed"] >= 4, ff.stats
+    with pytest.raises(ValueError):
+        GraphedForceField(model.train())

@@ -27,6 +27,14 @@ print(f"neighbour list alone: csrc/knn.hip {t_knn_hip*1e3:.2f} ms, torch tensor 
 t_build, batch = timeit(lambda: neighbors.crystal_batch([lat_d], [frac_d], atom_features=[feats]))
 t_model, res = timeit(lambda: model(batch))
 t_step, _ = timeit(lambda: model(neighbors.crystal_batch([lat_d], [frac_d + 1e-4 * torch.randn_like(frac_d)], atom_features=[feats])))
+from alignn_amd.md import GraphedForceField
+ff = GraphedForceField(model)
+def md_step_graphed():
+    return ff(neighbors.crystal_batch([lat_d], [frac_d + 1e-6 * torch.randn_like(frac_d)], atom_features=[feats]))
+t_gstep, _ = timeit(md_step_graphed, 20)
+t_replay, _ = timeit(lambda: ff(batch), 20)
+print(f"hipGraph per batch shape (alignn_amd/md.py): model replay {t_replay*1e3:.2f} ms, full MD step {t_gstep*1e3:.2f} ms "
+      f"({ff.stats['replayed']} replays, {ff.stats['captured']} captures)")
 t0 = time.perf_counter()
 for _ in range(3):
     raw = batch_raw([_one(n, 1234, "crystal", 92)])
