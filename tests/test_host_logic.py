@@ -280,3 +280,34 @@ def test_canonical_layout_on_arbitrary_multigraphs():
                 assert fb.lg.dense_max_src == 0
 
     check()
+
+
+def test_md_batch_signature_and_static_copy():
+    """alignn_amd/md.py host logic (no GPU): batches of the same crystal at displaced positions share a signature while the
+    neighbour lists keep their sizes; the static copy is deep, keeps the tensors L(g) shares with g shared, and the copy
+    loop of a replay reproduces the new batch exactly."""
+    from alignn_amd import neighbors
+    from alignn_amd.md import _tensors, clone_batch, signature
+    from alignn_amd.synthetic import make_crystal
+
+    lat, frac, _ = make_crystal(24, 99)
+    lat_t, frac_t = torch.from_numpy(lat), torch.from_numpy(frac)
+    feats = torch.randn(24, 92)
+    a = neighbors.crystal_batch([lat_t], [frac_t], atom_features=[feats])
+    b = neighbors.crystal_batch([lat_t], [frac_t + 1e-7], atom_features=[feats])
+    assert signature(a) == signature(b)
+    big = neighbors.crystal_batch([lat_t * 1.5], [frac_t], atom_features=[feats])
+    if (big.g.n_edges, big.lg.n_edges) != (a.g.n_edges, a.lg.n_edges):
+        assert signature(big) != signature(a)
+    st = clone_batch(a)
+    assert st.lg.grp_seg_ptr is st.g.out_ptr and st.lg.grp_src_ptr is st.g.seg_ptr  # shared in the copy as in the original
+    assert a.lg.grp_seg_ptr is a.g.out_ptr
+    names_a = [k for k, _ in _tensors(a)]
+    assert names_a == [k for k, _ in _tensors(st)] and "lg.seg_rank" in names_a and "r" in names_a
+    for (k, x), (_, y) in zip(_tensors(a), _tensors(st)):
+        assert x.data_ptr() != y.data_ptr() and torch.equal(x, y), k
+    for (k, dst), (_, src) in zip(_tensors(st), _tensors(b)):  # what _Captured.run does before a replay
+        dst.copy_(src)
+    for (k, x), (_, y) in zip(_tensors(st), _tensors(b)):
+        assert torch.equal(x, y), k
+    assert (st.g.n_nodes, st.g.n_edges, st.lg.n_edges) == (b.g.n_nodes, b.g.n_edges, b.lg.n_edges)
