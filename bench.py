@@ -216,6 +216,11 @@ def main():
     if "WORLD_SIZE" not in os.environ and (args.gpus or 1) > 1:
         sys.exit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # (the warm-up step before the capture runs on a side stream on purpose - torch's capture recipe - and the gradient
+    # accumulators made by the eager steps before it live on the default stream: torch warns about exactly that, per rank)
+    quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+    if quiet is not None:
+        quiet(False)
     if args.gpus is not None and args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     rank = int(os.environ.get("RANK", "0"))
