@@ -53,7 +53,8 @@ def _empty(*shape, like):
 # ---------------------------------------------------------------------------------------------
 import os as _os
 
-_SIDE = {"enabled": _os.environ.get("ALIGNN_AMD_SIDE_STREAM", "1") != "0", "streams": {}, "armed": False}
+_SIDE = {"enabled": _os.environ.get("ALIGNN_AMD_SIDE_STREAM", "1") != "0", "streams": {}, "armed": False,
+         "min_rows": int(_os.environ.get("ALIGNN_AMD_SIDE_MIN_ROWS", "32768"))}
 
 # Parameters whose owner promises to read ``.grad`` only after backward() has returned (alignn_amd.ddp.FlatGradSync
 # marks its parameters): under an initialised process group everything else is assumed to sit under
@@ -100,6 +101,15 @@ def on_side_stream(fn, inputs, params=(), wait=()):
         return fn()
     dev = inputs[0].device
     main = torch.cuda.current_stream(dev)
+    # Eagerly launched, the fork costs the HOST ~80 us per call (stream switch, an event, a record_stream per input) - more
+    # than the GPU gets back when the product is small and the step is launch-bound anyway (8 crystals: 7.9-8.7 ms with every
+    # weight gradient forked, 6.3-6.7 ms with none).  So outside a stream capture only products over many rows go to the side
+    # stream; inside a capture (host time irrelevant) all of them do.
+    if inputs[0].dim() > 0 and inputs[0].shape[0] < _SIDE["min_rows"] and not torch.cuda.is_current_stream_capturing():
+        for ev in wait:
+            if ev is not None:
+                main.wait_event(ev)
+        return fn()
     side = _SIDE["streams"].get(dev)
     if side is None:
         side = _SIDE["streams"][dev] = torch.cuda.Stream(device=dev, priority=int(_os.environ.get("ALIGNN_AMD_SIDE_PRIORITY", "0")))

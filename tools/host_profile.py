@@ -8,10 +8,12 @@ B = int(os.environ.get("B", "64"))
 batch = GraphBatch.from_raw(make_batch(B, 60), device=dev)
 torch.manual_seed(0)
 model = ALIGNN(ALIGNNConfig(name="alignn")).to(dev).train()
-opt = torch.optim.AdamW(model.parameters(), lr=1e-3, fused=True)
+from alignn_amd.optim import FlatAdamW, group_decay
+opt = FlatAdamW(group_decay(model), lr=1e-3, weight_decay=1e-2, module=model)
+torch.autograd.set_multithreading_enabled(False)  # backward nodes in this thread: cProfile sees them
 target = torch.randn(B, device=dev)
 def step():
-    opt.zero_grad(set_to_none=True)
+    opt.zero_grad()
     torch.nn.functional.l1_loss(model(batch), target).backward()
     opt.step()
 for _ in range(3): step()
