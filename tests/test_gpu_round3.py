@@ -605,3 +605,45 @@ def test_graphed_force_field_replays_equal_the_eager_evaluation():
     assert ff.stats["replayed"] == 8 - len(sigs) and ff.stats["replayed"] >= 4, ff.stats
     with pytest.raises(ValueError):
         GraphedForceField(model.train())
+
+
+def test_pipelined_gather_projection_is_bit_identical_to_the_shipped_one():
+    """csrc/gemm_x6.hip gemm_nt_f16pp_gather_kernel (ALIGNN_AMD_X6PP=1, off by default: one workgroup per CU, the previous
+    tile's epilogue issued under the k-loop) against the two-workgroup persistent kernel: output and column-sum slabs."""
+    import os
+
+    raw = make_batch(48, 60, seed0=3)
+    lg = GraphBatch.from_raw(raw, device=DEV).lg
+    T, E, H = lg.n_edges, lg.n_nodes, 256
+    assert T // 128 >= 1024  # (long enough for the persistent kernels)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    y = torch.randn(T, H, device=DEV, generator=g)
+    P = torch.randn(E, 4 * H, device=DEV, generator=g)
+    w = torch.randn(H, H, device=DEV, generator=g) / 16
+    bias = torch.randn(H, device=DEV, generator=g)
+    wh, am = ops.split_f16x2(w), ops.absmax(y)
+    bd2 = ops.segment_ordered_bd(P, lg, H)
+
+    def run(flag, stats, table):
+        prev = os.environ.get("ALIGNN_AMD_X6PP")
+        os.environ["ALIGNN_AMD_X6PP"] = flag
+        try:
+            r = ops.gemm_nt_f16x3_gather(y, am, wh, bias, P, lg.src, lg.dst, want_stats=stats, bd2=bd2 if table else None,
+                                         rank=lg.seg_rank if table else None)
+            torch.cuda.synchronize()
+            return (r[0], r[1][:r[2]]) if stats else (r, None)
+        finally:
+            if prev is None:
+                os.environ.pop("ALIGNN_AMD_X6PP", None)
+            else:
+                os.environ["ALIGNN_AMD_X6PP"] = prev
+
+    for stats in (True, False):
+        for table in (True, False):
+            a, pa = run("0", stats, table)
+            b, pb = run("1", stats, table)
+            assert torch.equal(a, b), (stats, table)
+            if stats:
+                assert torch.equal(pa, pb), (stats, table)
+    ref = y.double() @ w.double().t() + bias.double() + P[lg.src.long(), :H].double() + P[lg.dst.long(), H:2 * H].double()
+    assert float((b.double() - ref).abs().max()) < 2e-6 * float(ref.abs().max())
