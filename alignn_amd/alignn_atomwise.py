@@ -25,7 +25,7 @@ import torch
 from torch import nn
 
 from . import alignn as _bn
-from . import _lib, ops
+from . import _lib, ops, torch_path
 from .alignn import _Base, _CONFIG, RBFExpansion  # noqa: F401  (RBFExpansion re-exported like the reference)
 from .graph import GraphBatch, cached_dgl_batch
 
@@ -140,7 +140,7 @@ def _single_virial(b: GraphBatch, pair_forces):
     if r_pos is None:
         raise ValueError("batch_stress=False takes the bond vectors from the positions: pass (g, lg, lat) with "
                          "g.ndata['frac_coords'] and g.edata['images']")
-    return -160.21766208 * (r_pos.t() @ pair_forces) / (2 * b.volume[0])
+    return -160.21766208 * (r_pos.to(pair_forces.dtype).t() @ pair_forces) / (2 * b.volume[0].to(pair_forces.dtype))
 
 
 class _TorchLNMLPLayer(nn.Module):
@@ -233,7 +233,7 @@ class ALIGNNAtomWise(nn.Module):
                 batch.r_from_positions = r_pos
         return batch
 
-    def _forward_ff(self, b: GraphBatch):
+    def _forward_ff(self, b: GraphBatch, with_forces: bool = True):
         """Energy + forces (+ stress): alignn_atomwise.py:364-660 with calculate_gradient=True.  Composed from the
         twice-differentiable primitives of ``alignn_amd.ff`` so that ``autograd.grad(create_graph=True)`` and the
         training loss's backward through it both work."""
@@ -241,11 +241,12 @@ class ALIGNNAtomWise(nn.Module):
 
         cfg = self.config
         n_a = len(self.alignn_layers)
-        x = ff.mlp_layer(b.atom_features, self.atom_embedding)
-        r = b.r.detach().clone().requires_grad_(True)  # canonical bond order; :420
+        dt = self.fc.weight.dtype
+        x = ff.mlp_layer(b.atom_features.to(dt), self.atom_embedding)
+        r = b.r.detach().to(dt).clone().requires_grad_(with_forces)  # canonical bond order; :420
         bondlength = torch.norm(r, dim=1)
         if n_a > 0:
-            h = ff.bond_cosines(r, b.lg) if cfg.lg_on_fly else b.h
+            h = ff.bond_cosines(r, b.lg) if cfg.lg_on_fly else b.h.to(dt)
             z = ff.mlp_layer(ff.mlp_layer(ff.rbf(h, self.angle_embedding[0]), self.angle_embedding[1]), self.angle_embedding[2])
         d_in = bondlength
         c_off = None
@@ -265,7 +266,7 @@ class ALIGNNAtomWise(nn.Module):
             y, z = ff.edge_gated_conv(b.lg, m, z, layer.edge_update)
         for layer in self.gcn_layers:
             x, y = ff.edge_gated_conv(b.g, x, y, layer)
-        counts = (b.graph_ptr[1:] - b.graph_ptr[:-1]).to(torch.float32)
+        counts = (b.graph_ptr[1:] - b.graph_ptr[:-1]).to(dt)
         if "atoms_by_graph" not in b.cache:  # (repeat_interleave sizes its output on the host: once per batch)
             b.cache["atoms_by_graph"] = ff.by_graph(b.graph_ptr)
         hpool = ff.segment_sum(x, b.cache["atoms_by_graph"]) / counts.unsqueeze(1)
@@ -274,7 +275,7 @@ class ALIGNNAtomWise(nn.Module):
             # [B,1] output is NOT squeezed upstream, so ``out * natoms`` below broadcasts to [B,B] exactly as it does there
             if b.extra_features is None:
                 raise ValueError("extra_features != 0 needs g.ndata['extra_features'] (GraphBatch.extra_features)")
-            feats = self.extra_feature_embedding(b.extra_features)
+            feats = self.extra_feature_embedding(b.extra_features.to(dt))
             h_feat = ff.segment_sum(feats, b.cache["atoms_by_graph"]) / counts.unsqueeze(1)
             hpool = self.fc2(self.fc1(torch.cat((hpool, h_feat), 1)))
             out = self.fc3(hpool)
@@ -287,6 +288,8 @@ class ALIGNNAtomWise(nn.Module):
         if cfg.atomwise_output_features > 0 and cfg.atomwise_weight != 0:
             atomwise_pred = ff.linear(x, self.fc_atomwise)
         en_out, out = self._total_energy(out, counts, bondlength)  # :494-510
+        if not with_forces:
+            return self._finish(out, additional_out, torch.empty(1), torch.empty(1), atomwise_pred)
         pair_forces = cfg.grad_multiplier * torch.autograd.grad(
             en_out, r, grad_outputs=torch.ones_like(en_out), create_graph=True, retain_graph=True)[0]  # :530-539
         stress = torch.empty(1)
@@ -311,7 +314,7 @@ class ALIGNNAtomWise(nn.Module):
             if "bonds_by_graph" not in b.cache:
                 b.cache["bonds_by_graph"] = ff.by_graph(b.edge_graph_ptr)
             st = ff.segment_sum(outer, b.cache["bonds_by_graph"]).reshape(-1, 3, 3)
-            stress = cfg.stress_multiplier * (-160.21766208) * st / b.volume.reshape(-1, 1, 1)
+            stress = cfg.stress_multiplier * (-160.21766208) * st / b.volume.to(dt).reshape(-1, 1, 1)
         return self._finish(out, additional_out, forces, stress, atomwise_pred)
 
     def _total_energy(self, out, counts, bondlength):
@@ -338,6 +341,10 @@ class ALIGNNAtomWise(nn.Module):
 
     def forward(self, g: Union[Sequence, GraphBatch]):
         cfg = self.config
+        if torch_path.wanted(self.fc.weight):
+            # float64 / 16-bit module (alignn/train.py:89-95): the composed path on plain torch operations (alignn_amd/ff.py
+            # switches per dtype), energies with or without forces - twice differentiable by autograd like the reference
+            return self._forward_ff(self._batch(g), with_forces=bool(cfg.calculate_gradient))
         ops.new_weight_generation()  # (see ops._WGEN)
         with _lib.device_guard(self.fc.weight):
             _bn._prepare_split_weights(self)  # all weight images of the step in one call (ops.WeightPrep)

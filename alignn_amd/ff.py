@@ -106,11 +106,22 @@ class SegSumFn(torch.autograd.Function):
         return GatherFn.apply(g, ctx.rel), None
 
 
+# float64 / 16-bit tensors (alignn/train.py:89-95 sets torch's default dtype from the config) take plain torch operations
+# with the same meaning - index_select / index_add / matmul, twice differentiable as they are - instead of the float32
+# kernels; like alignn_amd/torch_path.py this is NOT a fallback for float32.
+def _f32(t):
+    return t.dtype == torch.float32
+
+
 def gather(x, rel):
+    if not _f32(x):
+        return x.index_select(0, rel.idx.long())
     return GatherFn.apply(x, rel)
 
 
 def segment_sum(v, rel):
+    if not _f32(v):
+        return v.new_zeros((rel.n,) + tuple(v.shape[1:])).index_add(0, rel.idx.long(), v)
     return SegSumFn.apply(v, rel)
 
 
@@ -157,6 +168,8 @@ class MatmulTN(torch.autograd.Function):
 
 
 def linear(x, lin):
+    if not _f32(x):
+        return x @ lin.weight.t() + lin.bias
     return MatmulNT.apply(x, lin.weight) + lin.bias
 
 
@@ -168,7 +181,7 @@ def mlp_layer(x, layer):
 
 def rbf(d, mod):
     """RBFExpansion.forward (alignn/models/utils.py:40-44) with gradient w.r.t. the distances."""
-    return torch.exp(-mod.gamma * (d.unsqueeze(1) - mod.centers) ** 2)
+    return torch.exp(-mod.gamma * (d.unsqueeze(1) - mod.centers.to(d.dtype)) ** 2)
 
 
 def bond_cosines(r, lg: CSRGraph):

@@ -117,3 +117,65 @@ def test_float32_cpu_tensors_still_refused():
     g = dgl.radius_graph(_cart_coords().float(), 5.0)
     with pytest.raises((TypeError, RuntimeError)):
         conv(g, torch.ones(g.num_nodes(), 16), torch.ones(g.num_edges(), 16))
+
+
+def test_float64_force_field_model_on_the_torch_path_matches_the_float64_oracle():
+    """``ALIGNNAtomWise(...).double()`` (alignn/train.py:89-95 sets the dtype globally): energies, forces through
+    ``autograd.grad(create_graph=True)``, stresses and the SECOND-order parameter gradients of an energy + force + stress loss on
+    plain torch operations (alignn_amd/ff.py per dtype) - against the oracle run in float64 on the same inputs (1e-7: the two
+    hold the RBF length scale as a float32-rounded and as a float64 number) and
+    against the reference class's own float32 golden (its tolerance).  No GPU, no HIP library."""
+    import numpy as np
+
+    from alignn_amd import ALIGNNAtomWise, ALIGNNAtomWiseConfig, GraphBatch
+    from oracle import alignn_oracle as O
+    from tests.helpers import load_golden, raw_from_golden, rel_err, state_dict_from_golden
+
+    z = load_golden("atomwise_ff_tiny.npz")
+    raw = raw_from_golden(z)
+    cfg = ALIGNNAtomWiseConfig(name="alignn_atomwise", alignn_layers=2, gcn_layers=2, hidden_features=32,
+                               embedding_features=16, atom_input_features=92, calculate_gradient=True,
+                               stresswise_weight=0.05)
+    model = ALIGNNAtomWise(cfg)
+    model.load_state_dict(state_dict_from_golden(z))
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        model = model.double().train()
+        batch = GraphBatch.from_raw(raw)
+        batch.volume = torch.from_numpy(z["volume"])
+        res = model(batch)
+        L = torch.nn.functional.l1_loss
+        t = lambda k: torch.from_numpy(z[k]).double()  # noqa: E731
+        loss = L(res["out"], t("t_energy")) + L(res["grad"], t("t_forces")) + 0.05 * L(res["stresses"], t("t_stress"))
+        loss.backward()
+        # energies only (calculate_gradient=False) on the same path
+        e_only = ALIGNNAtomWise(cfg.model_copy(update={"calculate_gradient": False})).double()
+        e_only.load_state_dict(model.state_dict())
+        assert rel_err(e_only(batch)["out"].detach(), res["out"].detach()) < 1e-12
+    assert res["out"].dtype == torch.float64 and res["grad"].dtype == torch.float64
+    # the reference class's float32 run
+    assert rel_err(res["out"].detach(), z["pred"]) < 1e-4
+    assert rel_err(res["grad"].detach(), z["forces"]) < 2e-4 and rel_err(res["stresses"].detach(), z["stresses"]) < 2e-4
+    # the oracle in float64 on the same inputs
+    p = {k: (v.detach().double().requires_grad_(v.requires_grad) if v.is_floating_point() else v)
+         for k, v in O.as_params(state_dict_from_golden(z)).items()}
+    out, forces, stresses = O.alignn_atomwise_forward(
+        p, O.TorchGraph(raw), 2, 2, True, calculate_gradient=True, stress=True,
+        volume=torch.from_numpy(z["volume"]).double(), batch_num_edges=torch.from_numpy(raw.batch_num_edges))
+    inv = batch.g.inv  # our forces are per atom (no permutation); stresses per crystal
+    assert rel_err(res["out"].detach(), out.detach()) < 1e-8
+    assert rel_err(res["grad"].detach(), forces.detach()) < 1e-7 and rel_err(res["stresses"].detach(), stresses.detach()) < 1e-7
+    oloss = L(out, t("t_energy")) + L(forces, t("t_forces")) + 0.05 * L(stresses, t("t_stress"))
+    oloss.backward()
+    assert abs(loss.item() - oloss.item()) < 1e-8
+    nograd = set(z["nograd"].tolist())
+    gmax = max(float(v.grad.abs().max()) for k, v in p.items() if v.grad is not None)
+    n = 0
+    for k, q in model.named_parameters():
+        if k in nograd or p[k].grad is None:
+            continue
+        assert float((q.grad - p[k].grad).abs().max()) < 1e-6 * gmax, k
+        n += 1
+    assert n > 40 and inv is not None

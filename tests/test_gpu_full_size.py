@@ -392,3 +392,73 @@ def test_every_element_at_baseline_size_against_the_float64_torch_path(tag, mk):
     finally:
         _emit(f"{tag}_every_element", report)
     assert not fails, fails[:12]
+
+
+@pytest.mark.filterwarnings("ignore:alignn_amd. torch.float64 tensors run on plain torch")
+def test_force_training_at_cfg4_size_every_element_against_the_float64_torch_path():
+    """BASELINE configs[3] (16 x 200 atoms, energy + forces + stresses, loss gradient THROUGH the forces) on the fused
+    forward-over-reverse kernels against the SAME model in float64 on plain torch operations (alignn_amd/ff.py per dtype;
+    pinned on the CPU to the float64 oracle and the reference class's golden: tests/test_force_reduction_port.py): every
+    force component, every stress, every element of every second-order parameter gradient."""
+    import copy
+
+    from alignn_amd import ALIGNNAtomWise, ALIGNNAtomWiseConfig
+
+    B, atoms = 16, 200
+    raw = batch_raw([_one(atoms, 1234 + i, "crystal", 92) for i in range(B)])
+    cfg = ALIGNNAtomWiseConfig(name="alignn_atomwise", alignn_layers=4, gcn_layers=4, hidden_features=256,
+                               atom_input_features=92, calculate_gradient=True, stresswise_weight=0.05)
+    model = ALIGNNAtomWise(cfg)
+    sd = O.perturbed_norm_state_dict(O.init_state_dict(seed=7), seed=8)
+    model.load_state_dict({k: v for k, v in sd.items() if "running" not in k and "tracked" not in k})
+    gen = torch.Generator().manual_seed(3)
+    t_e, t_f, t_s = torch.randn(B, generator=gen), torch.randn(raw.num_nodes, 3, generator=gen), torch.randn(B, 3, 3, generator=gen)
+    L = torch.nn.functional.l1_loss
+
+    def run(m, dt):
+        batch = GraphBatch.from_raw(raw, device=DEV)
+        res = m(batch)
+        loss = L(res["out"], t_e.to(DEV, dt)) + L(res["grad"], t_f.to(DEV, dt)) + L(res["stresses"], t_s.to(DEV, dt))
+        loss.backward()
+        torch.cuda.synchronize()
+        out = {k: res[k].detach().double() for k in ("out", "grad", "stresses")}
+        out["loss"] = float(loss.detach())
+        out["grads"] = {k: p.grad.detach().double() for k, p in m.named_parameters() if p.grad is not None}
+        return out
+
+    ref = run(copy.deepcopy(model).double().to(DEV).train(), torch.float64)
+    torch.cuda.empty_cache()
+    got = run(model.to(DEV).train(), torch.float32)
+    report = [f"cfg4, every element vs the float64 torch path: N={raw.num_nodes} E={raw.num_edges} T={raw.num_triplets}"]
+    fails = []
+    try:
+        for key, tol in (("out", 1e-5), ("grad", 1e-4), ("stresses", 1e-4)):
+            en, ee, _ = _cmp_all(got[key], ref[key])
+            report.append(f"{key}: normwise {en:.2e} elementwise {ee:.2e} ({got[key].numel()} elements)")
+            if not en < tol:
+                fails.append((key, en))
+        report.append(f"loss {got['loss']:.6f} vs {ref['loss']:.6f}")
+        if not abs(got["loss"] - ref["loss"]) < 1e-5 * abs(ref["loss"]):
+            fails.append(("loss", got["loss"], ref["loss"]))
+        gmax = max(float(g.abs().max()) for g in ref["grads"].values())
+        worst, n, n_zero = (0.0, None), 0, 0
+        assert got["grads"].keys() == ref["grads"].keys()
+        for k, r in ref["grads"].items():
+            own = float(r.abs().max())
+            if own < 1e-5 * gmax:
+                n_zero += 1
+                if not float(got["grads"][k].abs().max()) < 1e-4 * gmax:
+                    fails.append((k, "zero-gradient noise", float(got["grads"][k].abs().max()) / gmax))
+                continue
+            e = float((got["grads"][k] - r).abs().max()) / own
+            worst = max(worst, (e, k))
+            n += 1
+            if not e < 1e-4:  # (measured 4.5e-6)
+                fails.append((k, e))
+        report.append(f"second-order gradients: {n} parameters (all elements), worst error vs the parameter's own scale "
+                      f"{worst[0]:.2e} ({worst[1]}); {n_zero} analytically-zero")
+        if fails:
+            report.append(f"FAILURES: {fails[:12]}")
+    finally:
+        _emit("cfg4_every_element", report)
+    assert not fails, fails[:12]
