@@ -179,3 +179,40 @@ def test_float64_force_field_model_on_the_torch_path_matches_the_float64_oracle(
         assert float((q.grad - p[k].grad).abs().max()) < 1e-6 * gmax, k
         n += 1
     assert n > 40 and inv is not None
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_sixteen_bit_modules_run_on_the_torch_path(dtype):
+    """``model.to(torch.bfloat16)`` / ``.half()``: forward and backward of both model classes on plain torch operations,
+    close to the float64 run at the precision of the type (no HIP library, no GPU)."""
+    import copy
+    import warnings
+
+    from alignn_amd import ALIGNN, ALIGNNAtomWise, ALIGNNAtomWiseConfig, ALIGNNConfig, GraphBatch
+    from alignn_amd.synthetic import make_batch
+
+    raw = make_batch(3, 10, seed0=4)
+    batch = GraphBatch.from_raw(raw)
+    batch.volume = torch.ones(3)
+    tol = 4e-2 if dtype == torch.bfloat16 else 1e-2
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        torch.manual_seed(0)
+        m = ALIGNN(ALIGNNConfig(name="alignn", alignn_layers=1, gcn_layers=1, hidden_features=32, embedding_features=16)).train()
+        ref = copy.deepcopy(m).double()(batch).detach()
+        out = m.to(dtype)(batch)
+        assert out.dtype == dtype
+        out.float().sum().backward()
+        grads = [p.grad for p in m.parameters() if p.grad is not None]  # (the last edge output is dead: its norm has none)
+        assert len(grads) > 30 and all(bool(torch.isfinite(g).all()) for g in grads)
+        assert float((out.double() - ref).abs().max()) < tol * float(ref.abs().max())
+        cfg = ALIGNNAtomWiseConfig(name="alignn_atomwise", alignn_layers=1, gcn_layers=1, hidden_features=32,
+                                   embedding_features=16, atom_input_features=92, calculate_gradient=True,
+                                   stresswise_weight=0.05)
+        a = ALIGNNAtomWise(cfg).train()
+        r64 = copy.deepcopy(a).double()(batch)
+        res = a.to(dtype)(batch)
+        assert res["grad"].dtype == dtype and res["grad"].shape == (raw.num_nodes, 3)
+        (res["out"].float().sum() + res["grad"].float().abs().sum()).backward()
+        assert float((res["out"].double() - r64["out"]).abs().max()) < tol * float(r64["out"].abs().max())
+        assert float((res["grad"].double() - r64["grad"]).abs().max()) < 0.15 * float(r64["grad"].abs().max())
