@@ -110,6 +110,11 @@ SIGNATURES = {
     "alignn_knn_levels": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i64, _p, _p]),
     "alignn_knn_kth": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i64, _p, _p, _p]),
     "alignn_knn_count": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i64, _p, _p, _p, _p]),
+    "alignn_model_init": (_i32, []),
+    "alignn_model_sizeof": (_sz, [_i32]),
+    "alignn_model_plan": (_i32, [_p, _p, _p, _p]),
+    "alignn_model_fwd": (_i32, [_p, _p, _p, _sz, _p, _p]),
+    "alignn_model_bwd": (_i32, [_p, _p, _p, _sz, _p, _p]),
     "alignn_knn_emit": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i64, _p, _p, _p, _p, _p, _p, _p, _p]),
 }
 

@@ -28,7 +28,7 @@ except Exception:  # pragma: no cover - depends on the image
 
     _CONFIG = {"extra": "forbid", "protected_namespaces": ()}
 
-from . import _lib, ops, torch_path
+from . import _lib, cmodel, ops, torch_path
 from .graph import CSRGraph, GraphBatch, build_csr, cached_dgl_batch
 
 
@@ -417,11 +417,24 @@ class ALIGNN(nn.Module):
         graph when ``alignn_layers == 0``, or a prebuilt ``GraphBatch``.  Returns ``squeeze(out)``."""
         if torch_path.wanted(self.fc.weight):  # model.double() / .bfloat16(): see alignn_amd/torch_path.py
             return torch_path.alignn_forward(self, self._batch(g))
+        b = self._batch(g)
+        if cmodel.applicable(self, b):  # training step: the whole forward (and its backward) as ONE C call each
+            out = cmodel.forward(self, b)
+            if out is not None:
+                return self._head(out)
         ops.new_weight_generation()  # weight images cached by an earlier forward are not this forward's (ops._WGEN)
         with _lib.device_guard(self.fc.weight), _deferred_bumps():
             _prepare_split_weights(self)  # (on the caller's stream, BEFORE the lanes fork: lane T waits for it)
             with ops.lanes(self.fc.weight.device):
-                return self._forward(self._batch(g))
+                return self._forward(b)
+
+    def _head(self, out):
+        """link / classification head / squeeze (alignn.py:343-349) on the [B, out_features] readout."""
+        if self.link:
+            out = self.link(out)
+        if self.classification:
+            out = self.softmax(out)
+        return torch.squeeze(out)
 
     def _forward(self, b: GraphBatch):
         if b.atom_features is None or b.r is None:

@@ -1,0 +1,429 @@
+"""Whole-model launch path: ``ALIGNN.forward`` / its backward as ONE C call each (``csrc/model.hip``).
+
+The reference's loop hands the model a new ``(g, lg)`` every iteration (``alignn/train.py:258-270``); a step on a batch
+nobody has seen before cannot be replayed from a hipGraph, so its ~350 kernels are enqueued again - and when
+``alignn_amd.ops`` sequences them from Python (95 autograd nodes, ~100 torch glue calls, an allocation per tensor) the host
+needs 9-23 ms for what the GPU finishes in 15.8 ms.  ``alignn_model_fwd`` / ``alignn_model_bwd`` issue the SAME launches
+(same kernels, same arguments: bit-identical parameters gradients, tests/test_gpu_cmodel.py) from C over one workspace
+block planned from (N, E, T); Python keeps the module tree (``state_dict`` keys are the reference's), ONE
+``torch.autograd.Function`` whose inputs are the parameters, and the loss.
+
+Used by ``ALIGNN.forward`` whenever it applies (``applicable``): BatchNorm flavour in training mode on float32 HIP tensors,
+every parameter trainable, every kernel-choice switch of ``ops`` at its default (a test that flips one gets the
+per-operator path it wants to compare).  Anything else - eval mode, frozen parameters, the LayerNorm models, extra
+features, kernel choices the C side does not carry (``hipErrorNotSupported``) - takes the per-operator path as before.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+from . import _lib, ops
+
+ENABLED = os.environ.get("ALIGNN_AMD_CMODEL", "1") != "0"
+STATS = {"fwd": 0, "bwd": 0, "plans": 0, "rebuilds": 0, "arena_bytes": 0}
+_NOT_SUPPORTED = 801  # hipErrorNotSupported
+
+_p, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+class MlpParams(C.Structure):
+    _fields_ = [(n, _p) for n in ("W", "b", "gamma", "beta", "rm", "rv", "gW", "gb", "red", "img", "img_t", "w_amax")] + [
+        ("in_", _i32), ("out", _i32)]
+
+
+class ConvParams(C.Structure):
+    _fields_ = [(n, _p) for n in (
+        "wcat", "bcat", "w_eg", "b_eg", "n_gamma", "n_beta", "e_gamma", "e_beta", "n_rm", "n_rv", "e_rm", "e_rv",
+        "g_wcat", "g_bcat", "g_weg", "g_beg", "n_red", "e_red", "wcat_img", "wcat_img_t", "weg_img", "weg_img_t",
+        "wcat_amax", "weg_amax")]
+
+
+class GraphCSR(C.Structure):
+    _fields_ = [(n, _p) for n in ("seg_ptr", "seg_node", "src", "dst", "out_ptr", "out_slot", "grp_seg_ptr", "grp_src_ptr",
+                                  "seg_rank")] + [("n", _i64), ("m", _i64), ("n_groups", _i64), ("dense_max_src", _i32),
+                                                  ("pad_", _i32)]
+
+
+class ModelBatch(C.Structure):
+    _fields_ = [("g", GraphCSR), ("lg", GraphCSR), ("graph_ptr", _p), ("atom_features", _p), ("r", _p), ("h", _p),
+                ("B", _i32), ("pad_", _i32)]
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [(n, _i32) for n in ("alignn_layers", "gcn_layers", "H", "out_features", "atom_in", "edge_bins", "angle_bins",
+                                    "embed")] + [
+        ("edge_gamma", _f32), ("angle_gamma", _f32), ("eps", _f32), ("momentum", _f32),
+        ("edge_centers", _p), ("angle_centers", _p),
+        ("atom", MlpParams), ("edge1", MlpParams), ("edge2", MlpParams), ("angle1", MlpParams), ("angle2", MlpParams),
+        ("convs", C.POINTER(ConvParams)),
+        ("fc_W", _p), ("fc_b", _p), ("g_fc_W", _p), ("g_fc_b", _p),
+        ("weight_descs", _p), ("weight_amax", _p), ("bump_ptrs", _p),
+        ("n_weights", _i32), ("n_bump", _i32), ("x6_min_tiles", _i32), ("bd_segment_table", _i32),
+        ("amax_min_rows", _i64), ("lane_min_rows", _i64), ("side_min_rows", _i64),
+        ("lane_T", _p), ("side", _p), ("aux", _p)]
+
+
+_SIGS_DONE = False
+
+
+def _lib_model():
+    global _SIGS_DONE
+    lib = _lib.load()
+    if not _SIGS_DONE:
+        for which, st in enumerate((MlpParams, ConvParams, GraphCSR, ModelBatch, ModelDesc)):
+            if lib.alignn_model_sizeof(which) != C.sizeof(st):
+                raise RuntimeError(f"alignn_model struct {which}: library says {lib.alignn_model_sizeof(which)} bytes, "
+                                   f"the binding lays out {C.sizeof(st)}")
+        _SIGS_DONE = True
+    return lib
+
+
+def _flags_default() -> bool:
+    """Every kernel-choice switch of the per-operator path at the value the C side hard-wires."""
+    o = ops
+    return (o.F16X3 and o.GATHER_FUSED and o.STATS_FUSED and o.BNRED_FUSED and o.SPLIT_BOTH and o.BATCHED_WEIGHT_PREP
+            and o.NN_SPLIT and o.APPLY_SUM and o.FUSED_LG_BACKWARD and o.DENSE_LG_BACKWARD and o.COMPOSITE
+            and not o.RBF_MLP_FUSED and o.KERNEL_TIMER is None and o.FOLD_ABOVE == 1024 and o._PARAM_GRADS["on"])
+
+
+class disabled:
+    """``with cmodel.disabled():`` - the per-operator path (tests that count its registries, tools that time it)."""
+
+    def __enter__(self):
+        global ENABLED
+        self.prev, ENABLED = ENABLED, False
+
+    def __exit__(self, *exc):
+        global ENABLED
+        ENABLED = self.prev
+        return False
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+class Binding:
+    """Everything about one model on one device that does not change from batch to batch: the parameter blocks of the C
+    description, the gradient layout, the helper streams, the workspace."""
+
+    def __init__(self, model):
+        from .alignn import EdgeGatedGraphConv, MLPLayer
+
+        self.model = model
+        cfg = model.config
+        dev = model.fc.weight.device
+        self.device = dev
+        self.convs = []
+        for layer in model.alignn_layers:
+            self.convs += [layer.node_update, layer.edge_update]
+        self.convs += list(model.gcn_layers)
+        self.mlps = [model.atom_embedding, model.edge_embedding[1], model.edge_embedding[2], model.angle_embedding[1],
+                     model.angle_embedding[2]]
+        self.dead_edge = {2 * cfg.alignn_layers - 1, len(self.convs) - 1}  # convs whose edge output nobody reads
+        assert all(isinstance(m, EdgeGatedGraphConv) for m in self.convs) and all(isinstance(m, MLPLayer) for m in self.mlps)
+        self.desc = ModelDesc()
+        self.conv_arr = (ConvParams * len(self.convs))()
+        self.desc.convs = C.cast(self.conv_arr, C.POINTER(ConvParams))
+        with torch.cuda.device(dev):
+            _lib.check(_lib_model().alignn_model_init(), "model_init")
+            self.streams = [torch.cuda.Stream(device=dev) for _ in range(3)]  # lane T, side, aux
+        self.sig = self.psig = self.prep_sig = None
+        self.desc_addr = C.addressof(self.desc)
+        self.arena = None
+        self.arena_busy = False
+        self.plans = {}
+        self.bump = None
+        self._layout()
+
+    # ---- gradient layout: one flat buffer per backward, every parameter's gradient a view of it
+    def _layout(self):
+        m = self.model
+        entries = []  # (parameter or None (padding), floats)
+        self.grad_fields = []  # (struct, field name, float offset)
+        off = 0
+
+        def place(owner, field, params):
+            nonlocal off
+            pad = -off % 64
+            if pad:
+                entries.append((None, pad))
+                off += pad
+            self.grad_fields.append((owner, field, off))
+            for p in params:
+                entries.append((p, p.numel()))
+                off += p.numel()
+
+        d = self.desc
+        for blk, mod in zip((d.atom, d.edge1, d.edge2, d.angle1, d.angle2), self.mlps):
+            lin, bn = mod.layer[0], mod.layer[1]
+            place(blk, "gW", [lin.weight])
+            place(blk, "gb", [lin.bias])
+            place(blk, "red", [bn.bias, bn.weight])
+        for i, cv in enumerate(self.convs):
+            blk = self.conv_arr[i]
+            ws, bs = cv._fused_parameter_groups()
+            place(blk, "g_wcat", ws)
+            place(blk, "g_bcat", bs)
+            place(blk, "g_weg", [cv.edge_gate.weight])
+            place(blk, "g_beg", [cv.edge_gate.bias])
+            place(blk, "n_red", [cv.bn_nodes.bias, cv.bn_nodes.weight])
+            place(blk, "e_red", [cv.bn_edges.bias, cv.bn_edges.weight])
+        place(d, "g_fc_W", [m.fc.weight])
+        place(d, "g_fc_b", [m.fc.bias])
+        self.grad_floats = off
+        self.params = [p for p, _ in entries if p is not None]
+        self.sizes = [n for _, n in entries]
+        self.keep = [i for i, (p, _) in enumerate(entries) if p is not None]
+        self.shapes = [tuple(p.shape) for p in self.params]
+        dead = set()
+        for i in self.dead_edge:
+            dead.update((id(self.convs[i].bn_edges.bias), id(self.convs[i].bn_edges.weight)))
+        self.no_grad = [id(p) in dead for p in self.params]
+
+    def param_sig(self):
+        return tuple([p.data_ptr() for p in self.params])
+
+    # ---- parameter blocks (rebuilt when a parameter moved: .to(), FlatAdamW re-homing, load_state_dict(assign=True))
+    def refresh(self):
+        m, d = self.model, self.desc
+        prep = m.__dict__.get("_weight_prep")
+        if prep is None:
+            prep = m.__dict__["_weight_prep"] = ops.WeightPrep()
+        psig = self.param_sig()
+        if psig == self.psig and prep.sig is not None and prep.sig == self.prep_sig:
+            return  # nothing moved since the blocks were filled (the fused buffers alias the parameters)
+        # fused node projections first: asking for them may re-home the four Linear parameters of a convolution
+        fused = [cv._fused_node_projection() for cv in self.convs]
+        weights = []
+        for (wcat, _b), cv in zip(fused, self.convs):
+            weights += [wcat, cv.edge_gate.weight]
+        mlp_w = [mod.layer[0].weight for mod in self.mlps if (mod.layer[0].weight.shape[0] >= 128
+                                                              and mod.layer[0].weight.shape[0] % 16 == 0
+                                                              and mod.layer[0].weight.shape[1] % 16 == 0)]
+        weights += mlp_w
+        have_images = prep.ensure(weights)
+        self.psig = self.param_sig()  # (after any re-homing above)
+        self.prep_sig = prep.sig if have_images else None
+        sig = (self.psig, tuple(w.data_ptr() for w in weights), have_images and prep.desc.data_ptr())
+        if sig == self.sig:
+            return
+        STATS["rebuilds"] += 1
+        self.sig = sig
+        self.weights = weights
+        img = {}
+        if have_images:
+            for w, (sw, sw_t) in zip(weights, prep.images):
+                img[id(w)] = (sw.buf.data_ptr(), sw_t.buf.data_ptr(), sw.amax.data_ptr())
+        cfg = m.config
+        d.alignn_layers, d.gcn_layers, d.H, d.out_features = cfg.alignn_layers, cfg.gcn_layers, cfg.hidden_features, m.fc.weight.shape[0]
+        d.atom_in, d.edge_bins, d.angle_bins, d.embed = (cfg.atom_input_features, cfg.edge_input_features,
+                                                         cfg.triplet_input_features, cfg.embedding_features)
+        rbf_e, rbf_a = m.edge_embedding[0], m.angle_embedding[0]
+        d.edge_gamma, d.angle_gamma, d.eps, d.momentum = rbf_e.gamma, rbf_a.gamma, ops.BN_EPS, ops.BN_MOMENTUM
+        d.edge_centers, d.angle_centers = rbf_e.centers.data_ptr(), rbf_a.centers.data_ptr()
+        bumps = []
+        for blk, mod in zip((d.atom, d.edge1, d.edge2, d.angle1, d.angle2), self.mlps):
+            lin, bn = mod.layer[0], mod.layer[1]
+            blk.W, blk.b, blk.gamma, blk.beta = lin.weight.data_ptr(), lin.bias.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr()
+            blk.rm, blk.rv = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+            i3 = img.get(id(lin.weight), (None, None, None))
+            blk.img, blk.img_t, blk.w_amax = i3
+            blk.in_, blk.out = lin.weight.shape[1], lin.weight.shape[0]
+            bumps.append(bn.num_batches_tracked)
+        for i, (cv, (wcat, bcat)) in enumerate(zip(self.convs, fused)):
+            blk = self.conv_arr[i]
+            blk.wcat, blk.bcat = wcat.data_ptr(), bcat.data_ptr()
+            blk.w_eg, blk.b_eg = cv.edge_gate.weight.data_ptr(), cv.edge_gate.bias.data_ptr()
+            blk.n_gamma, blk.n_beta = cv.bn_nodes.weight.data_ptr(), cv.bn_nodes.bias.data_ptr()
+            blk.e_gamma, blk.e_beta = cv.bn_edges.weight.data_ptr(), cv.bn_edges.bias.data_ptr()
+            blk.n_rm, blk.n_rv = cv.bn_nodes.running_mean.data_ptr(), cv.bn_nodes.running_var.data_ptr()
+            blk.e_rm, blk.e_rv = cv.bn_edges.running_mean.data_ptr(), cv.bn_edges.running_var.data_ptr()
+            blk.wcat_img, blk.wcat_img_t, blk.wcat_amax = img.get(id(wcat), (None, None, None))
+            blk.weg_img, blk.weg_img_t, blk.weg_amax = img.get(id(cv.edge_gate.weight), (None, None, None))
+            bumps += [cv.bn_nodes.num_batches_tracked, cv.bn_edges.num_batches_tracked]
+        d.fc_W, d.fc_b = m.fc.weight.data_ptr(), m.fc.bias.data_ptr()
+        if have_images:
+            d.weight_descs, d.weight_amax, d.n_weights = prep.desc.data_ptr(), prep.amax.data_ptr(), len(weights)
+        else:
+            d.weight_descs, d.weight_amax, d.n_weights = None, None, 0
+        self.bump_keep = bumps
+        self.bump = torch.tensor([t.data_ptr() for t in bumps], dtype=torch.int64).to(self.device)
+        d.bump_ptrs, d.n_bump = self.bump.data_ptr(), len(bumps)
+        d.x6_min_tiles, d.bd_segment_table = ops.X6_MIN_TILES, int(ops.BD_SEGMENT_TABLE)
+        d.amax_min_rows = ops.AMAX_MIN_ROWS if ops.F16X3 else (1 << 62)
+        self.plans = {}
+
+    def set_mode(self):
+        """Per-call stream choices (mirror ops.lanes / on_side_stream / FORK_DGRAD: the helper streams cost the host a few
+        microseconds per event here, not ~80, so outside a capture they stay ON unless switched off)."""
+        d = self.desc
+        capturing = torch.cuda.is_current_stream_capturing()
+        lanes = ops._LANE["enabled"] not in ("0", False)
+        d.lane_T = self.streams[0].cuda_stream if lanes else None
+        d.lane_min_rows = ops._LANE["min_rows"]
+        d.side = self.streams[1].cuda_stream if ops._SIDE["enabled"] else None
+        d.side_min_rows = 0 if capturing else ops._SIDE["min_rows"]
+        d.aux = self.streams[2].cuda_stream if ops.FORK_DGRAD != "0" else None
+        return capturing
+
+    def batch_struct(self, b):
+        mb = ModelBatch()
+        for dst, g in ((mb.g, b.g), (mb.lg, b.lg)):
+            dst.seg_ptr, dst.seg_node, dst.src, dst.dst = _ptr(g.seg_ptr), _ptr(g.seg_node), _ptr(g.src), _ptr(g.dst)
+            dst.out_ptr, dst.out_slot = _ptr(g.out_ptr), _ptr(g.out_slot)
+            dst.grp_seg_ptr, dst.grp_src_ptr, dst.seg_rank = _ptr(g.grp_seg_ptr), _ptr(g.grp_src_ptr), _ptr(g.seg_rank)
+            dst.n, dst.m = g.n_nodes, g.n_edges
+            dst.n_groups = (g.grp_seg_ptr.numel() - 1) if g.grp_seg_ptr is not None else 0
+            dst.dense_max_src = int(g.dense_max_src)
+        mb.graph_ptr, mb.B = b.graph_ptr.data_ptr(), b.batch_size
+        return mb
+
+    def plan(self, mb):
+        key = (mb.g.n, mb.g.m, mb.lg.m, mb.B, mb.lg.dense_max_src, bool(mb.lg.grp_seg_ptr), bool(mb.lg.seg_rank),
+               bool(mb.g.seg_node), bool(self.desc.lane_T), bool(self.desc.side), bool(self.desc.aux),
+               self.desc.side_min_rows, self.desc.lane_min_rows)
+        hit = self.plans.get(key)
+        if hit is None:
+            fwd, tot = C.c_size_t(0), C.c_size_t(0)
+            rc = _lib_model().alignn_model_plan(self.desc_addr, C.addressof(mb), C.addressof(fwd), C.addressof(tot))
+            STATS["plans"] += 1
+            if rc == _NOT_SUPPORTED:
+                hit = (None, None)
+            else:
+                _lib.check(rc, "model_plan")
+                hit = (fwd.value, tot.value)
+            self.plans[key] = hit
+        return hit
+
+    def take_arena(self, nbytes, capturing, need_backward):
+        """The workspace of one forward (+ backward).  Eagerly launched steps share ONE grow-only block (a fresh 15 GB
+        allocation per step would fragment the caching allocator when no two batches are alike); a forward that finds it
+        still held by an earlier one whose backward has not run, and every forward inside a stream capture (the block
+        then has to belong to the graph's own memory pool), allocates its own."""
+        if capturing or self.arena_busy:
+            return torch.empty(nbytes, dtype=torch.uint8, device=self.device), False
+        if self.arena is None or self.arena.numel() < nbytes:
+            self.arena = None
+            self.arena = torch.empty(int(nbytes * 1.05) + 4096, dtype=torch.uint8, device=self.device)
+            STATS["arena_bytes"] = self.arena.numel()
+        self.arena_busy = need_backward
+        return self.arena, need_backward
+
+
+class _Lease:
+    """Holds the shared workspace for one forward until its backward ran - or until the autograd graph that owned it was
+    dropped without one (validation in training mode, an exception)."""
+
+    def __init__(self, bind, owns):
+        self.bind, self.owns = bind, owns
+
+    def release(self):
+        if self.owns:
+            self.owns = False
+            self.bind.arena_busy = False
+
+    __del__ = release
+
+
+def binding_of(model) -> Binding:
+    b = model.__dict__.get("_cmodel")
+    if b is None or b.device != model.fc.weight.device:
+        b = model.__dict__["_cmodel"] = Binding(model)
+    return b
+
+
+class _ModelFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, bind, mb, keep, arena, arena_bytes, owns, *params):
+        lib = _lib_model()
+        out = torch.empty(mb.B, bind.desc.out_features, dtype=torch.float32, device=bind.device)
+        _lib.check(lib.alignn_model_fwd(bind.desc_addr, C.addressof(mb), arena.data_ptr(), arena_bytes, out.data_ptr(),
+                                        _lib.stream()), "model_fwd")
+        STATS["fwd"] += 1
+        ctx.bind, ctx.mb, ctx.keep, ctx.arena, ctx.arena_bytes, ctx.lease = bind, mb, keep, arena, arena_bytes, _Lease(bind, owns)
+        ctx.sig = bind.sig
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        bind = ctx.bind
+        lib = _lib_model()
+        if ctx.arena is None:
+            raise RuntimeError("alignn_amd.cmodel: backward called twice on the same forward (its workspace is gone)")
+        if bind.sig != ctx.sig:
+            raise RuntimeError("alignn_amd.cmodel: the model's parameters moved between forward and backward")
+        g_out = g_out.contiguous()
+        gflat = torch.empty(bind.grad_floats, dtype=torch.float32, device=bind.device)
+        base = gflat.data_ptr()
+        for owner, field, off in bind.grad_fields:
+            setattr(owner, field, base + 4 * off)
+        bind.set_mode()
+        try:
+            _lib.check(lib.alignn_model_bwd(bind.desc_addr, C.addressof(ctx.mb), ctx.arena.data_ptr(), ctx.arena_bytes,
+                                            g_out.data_ptr(), _lib.stream()), "model_bwd")
+        finally:
+            ctx.lease.release()
+            ctx.arena = None
+        STATS["bwd"] += 1
+        pieces = gflat.split_with_sizes(bind.sizes)
+        grads = []
+        for i, shape, dead in zip(bind.keep, bind.shapes, bind.no_grad):
+            grads.append(None if dead else (pieces[i] if len(shape) == 1 else pieces[i].view(shape)))
+        return (None,) * 6 + tuple(grads)
+
+
+def applicable(model, b) -> bool:
+    if not (ENABLED and model.training and _flags_default()):
+        return False
+    cfg = model.config
+    if cfg.extra_features != 0 or cfg.alignn_layers < 1 or cfg.gcn_layers < 1 or cfg.hidden_features % 4:
+        return False
+    w = model.fc.weight
+    if not w.is_cuda or w.dtype != torch.float32 or b.lg is None or b.h is None or b.atom_features is None or b.r is None:
+        return False
+    for t in (b.atom_features, b.r, b.h):
+        if t.dtype != torch.float32 or t.requires_grad or not t.is_cuda:
+            return False
+    if type(model).__name__ != "ALIGNN":
+        return False
+    ok = model.__dict__.get("_cmodel_static_ok")
+    if ok is None:
+        from .alignn import EdgeGatedGraphConv, MLPLayer
+
+        ok = all(getattr(m, "_norm", "batch") == "batch" and (not isinstance(m, EdgeGatedGraphConv) or m.residual)
+                 for m in model.modules() if isinstance(m, (EdgeGatedGraphConv, MLPLayer)))
+        model.__dict__["_cmodel_static_ok"] = ok
+    if not ok:
+        return False
+    if torch.is_grad_enabled() and not all(p.requires_grad for p in model.parameters()):
+        return False
+    if any(p.dtype != torch.float32 for p in (model.atom_embedding.layer[0].weight, model.fc.bias)):
+        return False
+    return True
+
+
+def forward(model, b):
+    """-> ``fc(AvgPooling(...))`` [B, out_features] of a training-mode forward, or None when the C side does not carry a
+    kernel choice this (model, batch) needs (the caller then takes the per-operator path)."""
+    bind = binding_of(model)
+    with _lib.device_guard(model.fc.weight):
+        bind.refresh()
+        capturing = bind.set_mode()
+        mb = bind.batch_struct(b)
+        af, r, h = b.atom_features.contiguous(), b.r.contiguous(), b.h.contiguous()
+        if af.shape != (b.g.n_nodes, bind.desc.atom_in) or r.shape != (b.g.n_edges, 3) or h.numel() != b.lg.n_edges:
+            raise ValueError("feature rows do not match the graphs")
+        mb.atom_features, mb.r, mb.h = af.data_ptr(), r.data_ptr(), h.data_ptr()
+        fwd_bytes, total = bind.plan(mb)
+        if total is None:
+            return None
+        need_bwd = torch.is_grad_enabled()
+        nbytes = total if need_bwd else fwd_bytes
+        arena, owns = bind.take_arena(nbytes, capturing, need_bwd)
+        ops.new_weight_generation()
+        return _ModelFn.apply(bind, mb, (b, af, r, h), arena, nbytes, owns, *bind.params)

@@ -1,0 +1,796 @@
+// Whole-model entry points: ONE C call = the forward (or the backward) of alignn.models.alignn.ALIGNN in training mode.
+//
+// The reference's training loop feeds a NEW (g, lg) batch every iteration (alignn/train.py:258-270), so nothing can be
+// replayed from a captured hipGraph there: the ~350 kernels of a step have to be enqueued again, and when Python sequences
+// them (alignn_amd/ops.py: ~95 autograd nodes, ~100 torch glue operations, one allocation per tensor) the host needs
+// 9-23 ms per step against 15.8 ms of GPU work.  Here the same launches - same kernels, same arguments, therefore the same
+// bits as the per-operator path - are issued from C over ONE workspace block whose layout is a pure function of the model
+// dimensions and (N, E, T): no allocation, no interpreter, ~3 us per launch.  What ALIGNN.forward does
+// (alignn/models/alignn.py:282-349): RBF + MLPLayer embeddings (:201-222, models/utils.py:11-44), alignn_layers x
+// ALIGNNConv (:132-167: EdgeGatedGraphConv :48-129 on g, then on L(g)), gcn_layers x EdgeGatedGraphConv on g,
+// AvgPooling + fc (:325,341); and torch.autograd's backward of all of it.
+//
+// Streams: the caller's stream plus up to three helpers (all optional; NULL = stay on the caller's stream):
+//   lane_T  - the kernels over T = |edges of L(g)| rows (edge projection, gate pass, their backward, the angle embedding);
+//   side    - weight / bias gradients (nothing on the critical path reads them);
+//   aux     - the node input gradient of a bond-graph convolution beside the edge one.
+// Dependencies are HIP events from a per-device pool (alignn_model_init); every helper stream is joined back into the
+// caller's stream before a call returns, so the caller sees ordinary stream semantics and the calls are capture-safe.
+//
+// Workspace = [forward tape | backward temporaries]; the forward's tape (pre-activations, projections, statistics ...) is
+// found again by the backward by re-running the same deterministic plan without launching.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../include/alignn_hip.h"
+#include "common.h"
+
+namespace {
+
+constexpr int kFoldAbove = 1024;  // ops.FOLD_ABOVE
+constexpr int kEvents = 512;
+constexpr int kMaxDevices = 32;
+constexpr int kAmaxSlots = 1024;
+
+struct EventPool {
+    hipEvent_t ev[kEvents];
+    int next = 0;
+    bool ok = false;
+};
+EventPool g_pool[kMaxDevices];
+
+__global__ void fill_kernel(float* __restrict__ p, int64_t n, float v) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+__global__ void bump_kernel(int64_t* const* __restrict__ ptrs, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) ptrs[i][0] += 1;
+}
+// out[c][r] = in[r][c]  (weights of at most a few hundred rows: one 32 x 32 tile per workgroup through LDS)
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, int64_t ld, int rows, int cols,
+                                                        float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    for (int j = ty; j < 32; j += 8)
+        if (r0 + j < rows && c0 + tx < cols) tile[j][tx] = in[(int64_t)(r0 + j) * ld + c0 + tx];
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+        if (c0 + j < cols && r0 + tx < rows) out[(int64_t)(c0 + j) * rows + r0 + tx] = tile[tx][j];
+}
+
+struct Act {  // an activation [rows, F] and what its producer knows about it
+    float* p = nullptr;
+    float* amax = nullptr;  // device scalar max|p|, tracked by the producing kernel (NULL: not tracked)
+    float* xn = nullptr;    // p = r + silu(BatchNorm(xn)): the pre-activation,
+    float* stat = nullptr;  // its [4, F] statistics,
+    float* red = nullptr;   // and where the producer's backward expects (sum gz, sum gz * xhat) [2, F]
+    bool on_T = false;      // last written on lane T
+};
+struct Grad {
+    float* p = nullptr;
+    bool on_T = false;
+    bool pre_red = false;  // the projection that wrote p also left the BatchNorm-backward sums in the producer's `red`
+};
+
+struct MlpTape {
+    const alignn_mlp_params* p = nullptr;
+    Act x, y;
+    float *pre = nullptr, *stat = nullptr;
+    int64_t rows = 0;
+    bool lane = false;
+};
+struct ConvTape {
+    const alignn_conv_params* p = nullptr;
+    const alignn_graph_csr* g = nullptr;
+    Act x, y, x_out, y_out;
+    float *P = nullptr, *M = nullptr, *xpre = nullptr, *s0 = nullptr, *hh = nullptr, *n_stat = nullptr, *e_stat = nullptr;
+    bool lane = false, need_y = true;
+};
+struct Tape {
+    float *bl = nullptr, *rbf_e = nullptr, *rbf_a = nullptr, *pool = nullptr;
+    MlpTape atom, e1, e2, a1, a2;
+    std::vector<ConvTape> convs;
+};
+
+struct Ctx {
+    const alignn_model_desc* d;
+    const alignn_model_batch* b;
+    char* base;
+    size_t off = 0, cap = 0;
+    bool launch = false;
+    bool unsupported = false;
+    int unsupported_line = 0;
+    int rc = 0;
+    hipStream_t main = nullptr, T = nullptr, side = nullptr, aux = nullptr;
+    float* amax_arena = nullptr;
+    int amax_next = 0;
+    EventPool* pool = nullptr;
+
+    float* alloc(size_t floats) {
+        const size_t bytes = (floats * sizeof(float) + 255) / 256 * 256;
+        float* p = reinterpret_cast<float*>(base + off);
+        off += bytes;
+        if (launch && off > cap && rc == 0) rc = (int)hipErrorInvalidValue;
+        return p;
+    }
+    // stream-local scratch: transient buffers (split-reduction slabs, transposed weights) that only kernels of ONE stream
+    // touch, one after the other - the region is rewound (tmp_reset) before the next group of launches on that stream
+    // reuses it; stream order is the only synchronisation it needs (a captured graph keeps those edges)
+    size_t sbase[4] = {0, 0, 0, 0}, scur[4] = {0, 0, 0, 0}, speak[4] = {0, 0, 0, 0};
+    int which(hipStream_t st) const { return st == main ? 0 : st == T ? 1 : st == side ? 2 : 3; }
+    void tmp_reset(hipStream_t st) { scur[which(st)] = 0; }
+    float* tmp(hipStream_t st, size_t floats) {
+        const int i = which(st);
+        const size_t bytes = (floats * sizeof(float) + 255) / 256 * 256;
+        float* p = reinterpret_cast<float*>(base + sbase[i] + scur[i]);
+        scur[i] += bytes;
+        if (scur[i] > speak[i]) speak[i] = scur[i];
+        if (launch && sbase[i] + scur[i] > cap && rc == 0) rc = (int)hipErrorInvalidValue;
+        return p;
+    }
+    float* new_amax() {
+        if (amax_next >= kAmaxSlots) {
+            if (rc == 0) rc = (int)hipErrorInvalidValue;
+            return amax_arena;
+        }
+        return amax_arena + amax_next++;
+    }
+    bool track(int64_t rows) const { return rows >= d->amax_min_rows; }
+    // `waiter` continues only after everything enqueued on `src` so far
+    void sync(hipStream_t waiter, hipStream_t src) {
+        if (!launch || rc != 0 || waiter == src) return;
+        hipEvent_t e = pool->ev[pool->next];
+        pool->next = (pool->next + 1) % kEvents;
+        rc = (int)hipEventRecord(e, src);
+        if (rc == 0) rc = (int)hipStreamWaitEvent(waiter, e, 0);
+    }
+};
+
+#define UNSUP()                         \
+    do {                                \
+        c.unsupported = true;           \
+        if (!c.unsupported_line) c.unsupported_line = __LINE__; \
+    } while (0)
+
+#define L(call)                                       \
+    do {                                              \
+        if (c.launch && c.rc == 0) c.rc = (call);     \
+    } while (0)
+
+inline bool x6_shape_ok(const Ctx& c, int64_t M, int64_t lda, int N, int K) {
+    const int64_t tiles = ((M + 63) / 64) * ((N + 255) / 256);
+    return tiles >= c.d->x6_min_tiles && (lda % 4) == 0 && alignn_gemm_nt_x6_supported(M, N, K) != 0;
+}
+
+void fill(Ctx& c, float* p, int64_t n, float v, hipStream_t st) {
+    if (!c.launch || c.rc != 0 || n <= 0) return;
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n, v);
+    c.rc = (int)hipGetLastError();
+}
+
+// ops.project (forward products): split-product kernel for the wide, deep shapes, exact-fp32 MFMA otherwise
+void project(Ctx& c, const float* a, int64_t lda, const float* a_amax, const float* w, int64_t ldw, const void* img,
+             const float* w_amax, const float* bias, float* out, int64_t ldo, int64_t M, int N, int K, hipStream_t st) {
+    if (x6_shape_ok(c, M, lda, N, K)) {
+        if (a_amax == nullptr || img == nullptr) {  // (the per-operator path would take bf16x6 / slice for itself)
+            if (getenv("ALIGNN_AMD_DEBUG")) fprintf(stderr, "project M=%lld N=%d K=%d amax=%p img=%p\n", (long long)M, N, K, (void*)a_amax, img);
+            UNSUP();
+            return;
+        }
+        L(alignn_gemm_nt_f16x3(a, lda, a_amax, img, w_amax, bias, nullptr, 0, out, ldo, M, N, K, st));
+    } else
+        L(alignn_gemm_nt(a, lda, w, ldw, bias, nullptr, 0, out, ldo, M, N, K, st));
+}
+
+void bn_finalize_folded(Ctx& c, float* partial, int slabs, int64_t rows, int F, const float* gamma, const float* beta,
+                        float* rm, float* rv, float* stat, hipStream_t st) {
+    if (slabs > kFoldAbove) {
+        float* fold = c.alloc((size_t)alignn_slab_fold_slabs() * 2 * F);
+        L(alignn_slab_fold(partial, slabs, 2 * F, fold, st));
+        partial = fold;
+        slabs = alignn_slab_fold_slabs();
+    }
+    L(alignn_bn_finalize(partial, slabs, rows, F, gamma, beta, c.d->eps, c.d->momentum, rm, rv, stat, st));
+}
+
+void bn_bwd_finalize_folded(Ctx& c, float* partial, int slabs, int F, float* red, hipStream_t st) {
+    if (slabs > kFoldAbove) {
+        float* fold = c.alloc((size_t)alignn_slab_fold_slabs() * 2 * F);
+        L(alignn_slab_fold(partial, slabs, 2 * F, fold, st));
+        partial = fold;
+        slabs = alignn_slab_fold_slabs();
+    }
+    L(alignn_bn_bwd_finalize(partial, slabs, F, red, st));
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward pieces
+// ---------------------------------------------------------------------------------------------------------------------
+
+// MLPLayer = Linear + BatchNorm1d (batch statistics) + SiLU, alignn/models/alignn.py:170-184  (ops.MLPLayerFn._fwd)
+Act mlp_fwd(Ctx& c, MlpTape& t, const alignn_mlp_params& p, const Act& x, int64_t rows) {
+    const int F = p.out, K = p.in;
+    t.p = &p;
+    t.x = x;
+    t.rows = rows;
+    t.lane = c.T != c.main && rows >= c.d->lane_min_rows;
+    hipStream_t st = t.lane ? c.T : c.main;
+    if (t.lane != x.on_T) c.sync(st, x.on_T ? c.T : c.main);
+    t.pre = c.alloc((size_t)rows * F);
+    t.stat = c.alloc((size_t)4 * F);
+    const bool fused_stats = x.amax != nullptr && x6_shape_ok(c, rows, K, F, K);
+    if (fused_stats) {  // the projection's epilogue leaves the column sums BatchNorm needs
+        if (p.img == nullptr) {
+            UNSUP();
+            return Act{};
+        }
+        const int tiles = alignn_gemm_nt_x6_row_tiles(rows, F, K);
+        float* partial = c.alloc((size_t)(tiles + 1) * 2 * F);
+        L(alignn_gemm_nt_f16x3_stats(x.p, K, x.amax, p.img, p.w_amax, p.b, t.pre, F, rows, F, K, partial, st));
+        bn_finalize_folded(c, partial, tiles, rows, F, p.gamma, p.beta, p.rm, p.rv, t.stat, st);
+    } else {
+        project(c, x.p, K, x.amax, p.W, K, p.img, p.w_amax, p.b, t.pre, F, rows, F, K, st);
+        const int slabs = alignn_col_stats_slabs(rows);
+        float* partial = c.alloc((size_t)slabs * (3 * F + 1));
+        L(alignn_col_stats_welford(t.pre, F, rows, F, partial, st));
+        L(alignn_bn_finalize_welford(partial, slabs, rows, F, p.gamma, p.beta, c.d->eps, c.d->momentum, p.rm, p.rv, t.stat, st));
+    }
+    Act y;
+    y.p = c.alloc((size_t)rows * F);
+    y.amax = c.track(rows) ? c.new_amax() : nullptr;
+    L(alignn_bn_silu_fwd(t.pre, F, nullptr, 0, t.stat, y.p, F, rows, F, y.amax, st));
+    y.xn = t.pre;
+    y.stat = t.stat;
+    y.red = p.red;
+    y.on_T = t.lane;
+    t.y = y;
+    return y;
+}
+
+// EdgeGatedGraphConv.forward, alignn/models/alignn.py:78-129  (ops.EdgeGatedConvFn.forward, BatchNorm / training)
+void conv_fwd(Ctx& c, ConvTape& t, const alignn_conv_params& p, const alignn_graph_csr& g, const Act& x, const Act& y,
+              bool need_y) {
+    const int H = c.d->H, Kin = H;
+    const int64_t n = g.n, m = g.m;
+    t.p = &p;
+    t.g = &g;
+    t.x = x;
+    t.y = y;
+    t.need_y = need_y;
+    t.lane = c.T != c.main && m >= c.d->lane_min_rows;
+    hipStream_t main = c.main, T = t.lane ? c.T : c.main;
+    if (x.on_T) c.sync(main, c.T);
+    if (!t.lane && y.on_T) c.sync(main, c.T);
+    // ---- node side, part 1: P = x [W_sg; W_dg; W_du; W_su]^T + b = A | Bd | Bh | Ux
+    t.P = c.alloc((size_t)n * 4 * H);
+    project(c, x.p, Kin, x.amax, p.wcat, Kin, p.wcat_img, p.wcat_amax, p.bcat, t.P, 4 * H, n, 4 * H, Kin, main);
+    t.xpre = c.alloc((size_t)n * H);
+    t.s0 = c.alloc((size_t)n * H);
+    t.hh = c.alloc((size_t)n * H);
+    const int n_slabs = alignn_egc_slabs(n);
+    float* n_part = c.alloc((size_t)n_slabs * (3 * H + 1));
+    t.M = c.alloc((size_t)m * H);
+    t.n_stat = c.alloc((size_t)8 * H);
+    t.e_stat = t.n_stat + 4 * H;
+    // u_add_v (and the BatchNorm statistics) in the edge projection's epilogue when it runs on the split-product kernel
+    const bool pre_added = y.amax != nullptr && x6_shape_ok(c, m, Kin, H, Kin);
+    if (!pre_added && x6_shape_ok(c, m, Kin, H, Kin)) UNSUP();  // (bf16x6 scheme: per-operator path)
+    if (t.lane) c.sync(T, main);  // lane T reads P (and y, if the caller's stream produced it)
+    Act yo;
+    if (need_y) {
+        yo.p = c.alloc((size_t)m * H);
+        yo.amax = c.track(m) ? c.new_amax() : nullptr;
+    }
+    if (pre_added) {
+        if (p.weg_img == nullptr) {
+            UNSUP();
+            return;
+        }
+        const int tiles = alignn_gemm_nt_x6_row_tiles(m, H, Kin);
+        float* e_part = c.alloc((size_t)(tiles + 1) * 2 * H);
+        if (c.d->bd_segment_table && g.seg_node != nullptr && g.seg_rank != nullptr) {
+            // line graphs: the destination term from a segment-ordered copy of Bd (consecutive rows, same values)
+            float* bd2 = c.alloc((size_t)n * H);
+            L(alignn_gather_rows_ld(t.P + H, 4 * H, g.seg_node, bd2, H, n, H, T));
+            L(alignn_gemm_nt_f16x3_gather2(y.p, Kin, y.amax, p.weg_img, p.weg_amax, p.b_eg, t.M, H, m, H, Kin, t.P, 4 * H, g.src,
+                                           bd2, H, g.seg_rank, e_part, T));
+        } else
+            L(alignn_gemm_nt_f16x3_gather(y.p, Kin, y.amax, p.weg_img, p.weg_amax, p.b_eg, t.M, H, m, H, Kin, t.P, 4 * H, g.src,
+                                          g.dst, e_part, T));
+        bn_finalize_folded(c, e_part, tiles, m, H, p.e_gamma, p.e_beta, p.e_rm, p.e_rv, t.e_stat, T);
+        if (need_y)
+            L(alignn_egc_gate_fwd_pre_norm(t.P, t.M, g.seg_ptr, g.seg_node, g.src, n, m, H, t.xpre, t.s0, t.hh, n_part, t.e_stat,
+                                           y.p, yo.p, yo.amax, T));
+        else
+            L(alignn_egc_gate_fwd_pre(t.P, t.M, g.seg_ptr, g.seg_node, g.src, n, m, H, t.xpre, t.s0, t.hh, nullptr, n_part, T));
+        if (t.lane) c.sync(main, T);
+    } else {
+        L(alignn_gemm_nt(y.p, Kin, p.w_eg, Kin, p.b_eg, nullptr, 0, t.M, H, m, H, Kin, T));
+        float* e_part = c.alloc((size_t)n_slabs * (3 * H + 1));
+        L(alignn_egc_gate_fwd(t.P, t.M, g.seg_ptr, g.seg_node, g.src, n, m, H, t.xpre, t.s0, t.hh, e_part, n_part, T));
+        if (t.lane) c.sync(main, T);
+        L(alignn_bn_finalize_welford(e_part, n_slabs, m, H, p.e_gamma, p.e_beta, c.d->eps, c.d->momentum, p.e_rm, p.e_rv,
+                                     t.e_stat, T));
+        if (need_y) L(alignn_bn_silu_fwd(t.M, H, y.p, Kin, t.e_stat, yo.p, H, m, H, yo.amax, T));
+    }
+    // ---- node side, part 2: node norm
+    L(alignn_bn_finalize_welford(n_part, n_slabs, n, H, p.n_gamma, p.n_beta, c.d->eps, c.d->momentum, p.n_rm, p.n_rv, t.n_stat,
+                                 main));
+    Act xo;
+    xo.p = c.alloc((size_t)n * H);
+    xo.amax = c.track(n) ? c.new_amax() : nullptr;
+    L(alignn_bn_silu_fwd(t.xpre, H, x.p, Kin, t.n_stat, xo.p, H, n, H, xo.amax, main));
+    if (need_y) {
+        yo.xn = t.M;
+        yo.stat = t.e_stat;
+        yo.red = p.e_red;
+        yo.on_T = t.lane;
+    }
+    t.x_out = xo;
+    t.y_out = yo;
+}
+
+int conv_count(const alignn_model_desc& d) { return 2 * d.alignn_layers + d.gcn_layers; }
+
+// the whole forward; with c.launch == false only the workspace plan (the tape's pointers) is produced
+void run_forward(Ctx& c, Tape& tp, float* out) {
+    const alignn_model_desc& d = *c.d;
+    const alignn_model_batch& b = *c.b;
+    const int64_t N = b.g.n, E = b.g.m, Tn = b.lg.m;
+    const int H = d.H;
+    c.amax_arena = c.alloc(kAmaxSlots);
+    c.amax_next = 0;
+    fill(c, c.amax_arena, kAmaxSlots, 0.0f, c.main);
+    if (d.n_weights > 0) L(alignn_prepare_weights(d.weight_descs, d.n_weights, d.weight_amax, c.main));
+    if (d.n_bump > 0 && c.launch && c.rc == 0) {
+        hipLaunchKernelGGL(bump_kernel, dim3((d.n_bump + 63) / 64), dim3(64), 0, c.main, (int64_t* const*)d.bump_ptrs, d.n_bump);
+        c.rc = (int)hipGetLastError();
+    }
+    c.sync(c.T, c.main);  // parameters, weight images, the zeroed arena
+    // ---- angle embedding (T rows: lane T), alignn.py:215-222
+    tp.rbf_a = c.alloc((size_t)Tn * d.angle_bins);
+    L(alignn_rbf_fwd(b.h, d.angle_centers, d.angle_gamma, tp.rbf_a, Tn, d.angle_bins, c.main));
+    Act za;
+    za.p = tp.rbf_a;
+    Act z = mlp_fwd(c, tp.a2, d.angle2, mlp_fwd(c, tp.a1, d.angle1, za, Tn), Tn);
+    // ---- atom embedding, alignn.py:197-199
+    Act xa;
+    xa.p = const_cast<float*>(b.atom_features);
+    Act x = mlp_fwd(c, tp.atom, d.atom, xa, N);
+    // ---- edge embedding, alignn.py:201-214,313
+    tp.bl = c.alloc((size_t)E);
+    L(alignn_norm3_fwd(b.r, tp.bl, E, c.main));
+    tp.rbf_e = c.alloc((size_t)E * d.edge_bins);
+    L(alignn_rbf_fwd(tp.bl, d.edge_centers, d.edge_gamma, tp.rbf_e, E, d.edge_bins, c.main));
+    Act ye;
+    ye.p = tp.rbf_e;
+    Act y = mlp_fwd(c, tp.e2, d.edge2, mlp_fwd(c, tp.e1, d.edge1, ye, E), E);
+    if (c.unsupported) return;
+    // ---- ALIGNN layers (alignn.py:317-319), then GCN layers (:322-323); dead last-layer outputs are not materialised
+    tp.convs.assign(conv_count(d), ConvTape{});
+    int k = 0;
+    for (int i = 0; i < d.alignn_layers; ++i) {
+        ConvTape& tg = tp.convs[k];
+        conv_fwd(c, tg, d.convs[k], b.g, x, y, true);
+        ++k;
+        ConvTape& tl = tp.convs[k];
+        conv_fwd(c, tl, d.convs[k], b.lg, tg.y_out, z, i + 1 < d.alignn_layers);
+        ++k;
+        x = tg.x_out;
+        y = tl.x_out;
+        z = tl.y_out;
+        if (c.unsupported) return;
+    }
+    for (int i = 0; i < d.gcn_layers; ++i) {
+        ConvTape& tg = tp.convs[k];
+        conv_fwd(c, tg, d.convs[k], b.g, x, y, i + 1 < d.gcn_layers);
+        ++k;
+        x = tg.x_out;
+        y = tg.y_out;
+        if (c.unsupported) return;
+    }
+    // ---- readout: AvgPooling + fc, alignn.py:325,341
+    if (x.on_T) c.sync(c.main, c.T);
+    tp.pool = c.alloc((size_t)b.B * H);
+    L(alignn_segment_mean_fwd(x.p, b.graph_ptr, tp.pool, b.B, H, c.main));
+    L(alignn_gemm_nt(tp.pool, H, d.fc_W, H, d.fc_b, nullptr, 0, out, d.out_features, b.B, d.out_features, H, c.main));
+    c.sync(c.main, c.T);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// backward pieces
+// ---------------------------------------------------------------------------------------------------------------------
+
+void transpose(Ctx& c, const float* w, int64_t ld, int rows, int cols, float* out, hipStream_t st) {
+    if (!c.launch || c.rc != 0) return;
+    hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, st, w, ld, rows, cols, out);
+    c.rc = (int)hipGetLastError();
+}
+
+// ops._dgrad / ops._dgrad_bnred: out[M, Kout] = g[M, Nred] w[Nred, Kout] (+ addend); with `src` (the norm the tensor this
+// gradient belongs to came out of) and the split-product kernel, the BatchNorm-backward sums are taken in the epilogue
+void dgrad(Ctx& c, const float* g, int64_t ldg, const float* g_amax, const float* w, int Nred, int Kout, const void* img_t,
+           const float* w_amax, const float* addend, int64_t ldadd, float* out, int64_t M, hipStream_t st, const Act* src,
+           bool* pre_red) {
+    if (pre_red) *pre_red = false;
+    const bool x6 = x6_shape_ok(c, M, ldg, Kout, Nred);
+    if (x6) {
+        if (g_amax == nullptr || img_t == nullptr) {
+            UNSUP();
+            return;
+        }
+        if (src != nullptr && src->xn != nullptr && src->red != nullptr) {
+            const int tiles = alignn_gemm_nt_x6_row_tiles(M, Kout, Nred);
+            float* part = c.alloc((size_t)(tiles + 1) * 2 * Kout);
+            L(alignn_gemm_nt_f16x3_bnred(g, ldg, g_amax, img_t, w_amax, nullptr, addend, ldadd, out, Kout, M, Kout, Nred, src->xn,
+                                         Kout, src->stat, part, st));
+            bn_bwd_finalize_folded(c, part, tiles, Kout, src->red, st);
+            if (pre_red) *pre_red = true;
+            return;
+        }
+        L(alignn_gemm_nt_f16x3(g, ldg, g_amax, img_t, w_amax, nullptr, addend, ldadd, out, Kout, M, Kout, Nred, st));
+        return;
+    }
+    const size_t sb = alignn_gemm_nn_split_workspace(M, Nred, Kout);
+    if (sb) {
+        if ((ldg % 4) == 0 && (Kout % 4) == 0 && (addend == nullptr || (ldadd % 4) == 0)) {
+            c.tmp_reset(st);
+            float* ws = c.tmp(st, sb / 4);
+            L(alignn_gemm_nn_split(g, ldg, w, Kout, addend, ldadd, out, Kout, M, Nred, Kout, ws, sb, st));
+        } else
+            L(alignn_gemm_nn(g, ldg, w, Kout, addend, ldadd, out, Kout, M, Nred, Kout, st));
+        return;
+    }
+    if ((Nred % 4) == 0 && Kout >= 16) {  // reduction-contiguous (NT) kernel on a transposed copy of the weight
+        c.tmp_reset(st);
+        float* wt = c.tmp(st, (size_t)Kout * Nred);
+        transpose(c, w, Kout, Nred, Kout, wt, st);
+        L(alignn_gemm_nt(g, ldg, wt, Nred, nullptr, addend, ldadd, out, Kout, M, Kout, Nred, st));
+        return;
+    }
+    L(alignn_gemm_nn(g, ldg, w, Kout, addend, ldadd, out, Kout, M, Nred, Kout, st));
+}
+
+void gemm_tn(Ctx& c, const float* g, int64_t ldg, const float* g_amax, const float* a, int64_t lda, const float* a_amax,
+             float* dW, int64_t M, int N, int K, hipStream_t st) {
+    if (g_amax == nullptr || a_amax == nullptr) g_amax = a_amax = nullptr;
+    const size_t nb = alignn_gemm_tn_workspace(M, N, K);
+    float* ws = c.tmp(st, nb / 4 + 1);
+    L(alignn_gemm_tn(g, ldg, g_amax, a, lda, a_amax, dW, K, M, N, K, ws, nb, st));
+}
+
+void col_sum(Ctx& c, const float* x, int64_t ldx, int64_t rows, int F, float* out, hipStream_t st) {
+    float* ws = c.tmp(st, (size_t)alignn_col_stats_slabs(rows) * 2 * F);
+    L(alignn_col_sum(x, ldx, rows, F, out, ws, st));
+}
+
+// where a weight-gradient product over `rows` rows goes: the side stream, or (few rows, eagerly launched) the caller's
+hipStream_t side_for(Ctx& c, int64_t rows) { return (c.side != c.main && rows >= c.d->side_min_rows) ? c.side : c.main; }
+
+// ops.MLPLayerFn.backward
+Grad mlp_bwd(Ctx& c, const MlpTape& t, const Grad& gy, bool need_gx) {
+    const alignn_mlp_params& p = *t.p;
+    const int F = p.out, K = p.in;
+    const int64_t rows = t.rows;
+    hipStream_t st = t.lane ? c.T : c.main;
+    if (t.lane != gy.on_T) c.sync(st, gy.on_T ? c.T : c.main);
+    float* gpre = c.alloc((size_t)rows * F);
+    float* g_amax = c.track(rows) ? c.new_amax() : nullptr;
+    const int slabs = alignn_col_stats_slabs(rows);
+    if (!gy.pre_red) {
+        float* part = c.alloc((size_t)slabs * 2 * F);
+        L(alignn_bn_silu_bwd_reduce(gy.p, F, t.pre, F, t.stat, rows, F, part, st));
+        L(alignn_bn_bwd_finalize(part, slabs, F, p.red, st));
+    }
+    float* gb_part = nullptr;
+    if (F <= 1024) {  // the pass that writes gpre also sums its columns (the Linear's bias gradient)
+        gb_part = c.alloc((size_t)slabs * F);
+        L(alignn_bn_silu_bwd_apply_sum(gy.p, F, t.pre, F, t.stat, p.red, 0, gpre, F, rows, F, g_amax, gb_part, st));
+    } else
+        L(alignn_bn_silu_bwd_apply(gy.p, F, t.pre, F, t.stat, p.gamma, p.red, 0, gpre, F, rows, F, g_amax, st));
+    Grad gx;
+    if (need_gx) {
+        gx.p = c.alloc((size_t)rows * K);
+        gx.on_T = t.lane;
+        const Act* src = (t.x.xn != nullptr && g_amax != nullptr) ? &t.x : nullptr;
+        dgrad(c, gpre, F, g_amax, p.W, F, K, p.img_t, p.w_amax, nullptr, 0, gx.p, rows, st, src, &gx.pre_red);
+    }
+    hipStream_t sd = side_for(c, rows);
+    if (sd != st) {
+        c.sync(sd, c.main);
+        if (t.lane) c.sync(sd, c.T);
+    }
+    c.tmp_reset(sd);
+    gemm_tn(c, gpre, F, g_amax, t.x.p, K, t.x.amax, p.gW, rows, F, K, sd);
+    if (gb_part != nullptr)
+        L(alignn_slab_sum(gb_part, slabs, F, p.gb, sd));
+    else
+        col_sum(c, gpre, F, rows, F, p.gb, sd);
+    return gx;
+}
+
+// ops.EdgeGatedConvFn.backward: -> gradients w.r.t. the node and edge inputs
+void conv_bwd(Ctx& c, const ConvTape& t, const Grad& gx_out, const Grad* gy_out, Grad& g_x, Grad& g_y) {
+    const alignn_conv_params& p = *t.p;
+    const alignn_graph_csr& g = *t.g;
+    const int H = c.d->H, Kin = H;
+    const int64_t n = g.n, m = g.m;
+    hipStream_t main = c.main, T = t.lane ? c.T : c.main;
+    if (gx_out.on_T) c.sync(main, c.T);
+    if (!t.lane && gy_out != nullptr && gy_out->on_T) c.sync(main, c.T);
+    float* GP = c.alloc((size_t)n * 4 * H);
+    float* gp_amax = c.track(n) ? c.new_amax() : nullptr;
+    float* gm_amax = c.track(m) ? c.new_amax() : nullptr;
+    float* g_xpre = GP + 3 * (size_t)H;
+    // ---- node branch: BatchNorm / SiLU backward -> g_xpre (the Ux block of GP), the quotient's adjoints
+    const int n_slabs = alignn_col_stats_slabs(n);
+    float* n_part = c.alloc((size_t)n_slabs * 2 * H);
+    L(alignn_bn_silu_bwd_reduce(gx_out.p, H, t.xpre, H, t.n_stat, n, H, n_part, main));
+    L(alignn_bn_bwd_finalize(n_part, n_slabs, H, p.n_red, main));
+    float* gs1 = c.alloc((size_t)n * H);
+    float* gs0 = c.alloc((size_t)n * H);
+    L(alignn_bn_silu_bwd_apply_node(gx_out.p, H, t.xpre, H, t.n_stat, p.n_gamma, p.n_red, 0, g_xpre, 4 * H, n, H, gp_amax, t.s0,
+                                    t.hh, gs1, gs0, main));
+    // ---- edge branch (lane T for the line graph)
+    const float* gy = gy_out != nullptr ? gy_out->p : nullptr;
+    if (t.lane && gy_out != nullptr && !gy_out->on_T) c.sync(T, main);
+    const float* e_red = nullptr;
+    if (gy != nullptr) {
+        if (!gy_out->pre_red) {
+            const int e_slabs = alignn_col_stats_slabs(m);
+            float* e_part = c.alloc((size_t)e_slabs * 2 * H);
+            L(alignn_bn_silu_bwd_reduce(gy, H, t.M, H, t.e_stat, m, H, e_part, T));
+            L(alignn_bn_bwd_finalize(e_part, e_slabs, H, p.e_red, T));
+        }
+        e_red = p.e_red;
+    }
+    if (t.lane) c.sync(T, main);  // gs1, gs0, the Ux block of GP and its maximum are ready
+    float* GM = c.alloc((size_t)m * H);
+    const bool lg_blocks = g.grp_seg_ptr != nullptr;
+    const bool dense = lg_blocks && g.dense_max_src > 0 && alignn_egc_bwd_lg_dense_supported(g.dense_max_src);
+    const int gslabs = lg_blocks ? (int)g.n_groups : alignn_egc_slabs(n);
+    float* gb_part = c.alloc((size_t)gslabs * H);
+    if (dense)
+        L(alignn_egc_bwd_lg_dense(gy, t.M, t.P, gs1, gs0, t.e_stat, e_red, 0, m, g.grp_seg_ptr, g.grp_src_ptr, g.n_groups,
+                                  g.dense_max_src, g.seg_ptr, g.seg_node, H, GM, GP, gb_part, gm_amax, gp_amax, T));
+    else if (lg_blocks)
+        L(alignn_egc_bwd_lg_fused(gy, t.M, t.P, gs1, gs0, t.e_stat, e_red, 0, m, g.grp_seg_ptr, g.grp_src_ptr, g.n_groups,
+                                  g.seg_ptr, g.seg_node, g.dst, g.out_ptr, g.out_slot, H, GM, GP, gb_part, gm_amax, gp_amax, T));
+    else {
+        L(alignn_egc_bwd_dst(gy, t.M, t.P, gs1, gs0, t.e_stat, p.e_gamma, e_red, 0, m, g.seg_ptr, g.seg_node, g.src, n, H, GM, GP,
+                             gb_part, gm_amax, gp_amax, T));
+        L(alignn_egc_bwd_src(GM, t.M, gs1, g.out_ptr, g.out_slot, g.dst, n, H, GP, gp_amax, T));
+    }
+    if (t.lane) c.sync(main, T);  // GP complete
+    // ---- input gradients (critical path): g_x = GP wcat (+ gx_out) beside g_y = GM w_eg (+ gy_out)
+    g_x.p = c.alloc((size_t)n * Kin);
+    g_y.p = c.alloc((size_t)m * Kin);
+    hipStream_t sx = main;
+    if (!t.lane && c.aux != main) {  // bond graph: the (shorter) node product on the aux stream beside the edge product
+        c.sync(c.aux, main);
+        sx = c.aux;
+    }
+    dgrad(c, GP, 4 * H, gp_amax, p.wcat, 4 * H, Kin, p.wcat_img_t, p.wcat_amax, gx_out.p, H, g_x.p, n, sx, nullptr, nullptr);
+    const Act* src = (t.y.xn != nullptr && gm_amax != nullptr) ? &t.y : nullptr;
+    dgrad(c, GM, H, gm_amax, p.w_eg, H, Kin, p.weg_img_t, p.weg_amax, gy, H, g_y.p, m, T, src, &g_y.pre_red);
+    g_y.on_T = t.lane;
+    g_x.on_T = false;
+    if (sx != main) c.sync(main, sx);
+    // ---- weight / bias gradients
+    hipStream_t sd = side_for(c, m);
+    if (sd != main) {
+        c.sync(sd, main);
+        if (t.lane) c.sync(sd, c.T);
+    } else if (t.lane)
+        c.sync(main, c.T);
+    c.tmp_reset(sd);
+    L(alignn_slab_sum(gb_part, gslabs, H, p.g_beg, sd));
+    gemm_tn(c, GM, H, gm_amax, t.y.p, Kin, t.y.amax, p.g_weg, m, H, Kin, sd);
+    gemm_tn(c, GP, 4 * H, gp_amax, t.x.p, Kin, t.x.amax, p.g_wcat, n, 4 * H, Kin, sd);
+    col_sum(c, GP, 4 * H, n, 4 * H, p.g_bcat, sd);
+}
+
+void run_backward(Ctx& c, const Tape& tp, const float* g_out) {
+    const alignn_model_desc& d = *c.d;
+    const alignn_model_batch& b = *c.b;
+    const int64_t N = b.g.n;
+    const int H = d.H, OF = d.out_features, B = b.B;
+    c.amax_arena = c.alloc(kAmaxSlots);
+    c.amax_next = 0;
+    fill(c, c.amax_arena, kAmaxSlots, 0.0f, c.main);
+    c.sync(c.T, c.main);
+    c.sync(c.side, c.main);
+    // ---- fc (ops.LinearFn.backward) and the pooling
+    float* g_pool = c.alloc((size_t)B * H);
+    dgrad(c, g_out, OF, nullptr, d.fc_W, OF, H, nullptr, nullptr, nullptr, 0, g_pool, B, c.main, nullptr, nullptr);
+    c.tmp_reset(c.main);
+    gemm_tn(c, g_out, OF, nullptr, tp.pool, H, nullptr, d.g_fc_W, B, OF, H, c.main);
+    if ((OF % 4) == 0)
+        col_sum(c, g_out, OF, B, OF, d.g_fc_b, c.main);
+    else {  // e.g. the 1-wide readout: gb[n] = (gy^T ones)[n]
+        float* ones = c.alloc((size_t)B);
+        fill(c, ones, B, 1.0f, c.main);
+        gemm_tn(c, g_out, OF, nullptr, ones, 1, nullptr, d.g_fc_b, B, OF, 1, c.main);
+    }
+    Grad gx;
+    gx.p = c.alloc((size_t)N * H);
+    L(alignn_segment_mean_bwd(g_pool, b.graph_ptr, gx.p, B, H, c.main));
+    // ---- GCN layers, then ALIGNN layers, in reverse
+    int k = conv_count(d) - 1;
+    Grad gy, gz;
+    bool have_gy = false, have_gz = false;
+    for (int i = d.gcn_layers - 1; i >= 0; --i, --k) {
+        Grad nx, ny;
+        conv_bwd(c, tp.convs[k], gx, have_gy ? &gy : nullptr, nx, ny);
+        gx = nx;
+        gy = ny;
+        have_gy = true;
+        if (c.unsupported) return;
+    }
+    for (int i = d.alignn_layers - 1; i >= 0; --i) {
+        // line-graph convolution: node output = the bond features (gradient gy), edge output = the triplet features (gz)
+        Grad gm, nz;
+        conv_bwd(c, tp.convs[k], gy, have_gz ? &gz : nullptr, gm, nz);
+        --k;
+        gz = nz;
+        have_gz = true;
+        if (i == 0) {  // the angle embedding's backward (lane T) can start now, under the last bond-graph backward
+            Grad ga = mlp_bwd(c, tp.a2, gz, true);
+            mlp_bwd(c, tp.a1, ga, false);
+        }
+        Grad nx, ny;
+        conv_bwd(c, tp.convs[k], gx, &gm, nx, ny);
+        --k;
+        gx = nx;
+        gy = ny;
+        if (c.unsupported) return;
+    }
+    // ---- embeddings
+    mlp_bwd(c, tp.atom, gx, false);
+    Grad ge = mlp_bwd(c, tp.e2, gy, true);
+    mlp_bwd(c, tp.e1, ge, false);
+    c.sync(c.main, c.T);
+    c.sync(c.main, c.side);
+}
+
+bool desc_ok(const alignn_model_desc* d, const alignn_model_batch* b) {
+    if (d == nullptr || b == nullptr || d->convs == nullptr) return false;
+    if (d->alignn_layers < 1 || d->gcn_layers < 1 || d->H <= 0 || (d->H & 3) || d->out_features <= 0) return false;
+    if (b->g.n <= 0 || b->g.m <= 0 || b->lg.m <= 0 || b->B <= 0 || b->lg.n != b->g.m) return false;
+    return true;
+}
+
+void set_streams(Ctx& c, alignn_stream_t st) {
+    c.main = (hipStream_t)st;
+    c.T = c.d->lane_T ? (hipStream_t)c.d->lane_T : c.main;
+    c.side = c.d->side ? (hipStream_t)c.d->side : c.main;
+    c.aux = c.d->aux ? (hipStream_t)c.d->aux : c.main;
+}
+
+bool take_pool(Ctx& c) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices || !g_pool[dev].ok) return false;
+    c.pool = &g_pool[dev];
+    return true;
+}
+
+// The workspace layout of one (model, batch, stream configuration): [forward tape | backward buffers | scratch per stream].
+struct Plan {
+    size_t fwd_persist = 0, all_persist = 0, peak_fwd[4] = {0, 0, 0, 0}, peak_all[4] = {0, 0, 0, 0};
+    bool unsupported = false;
+    int line = 0, rc = 0;
+    size_t fwd_total() const { return fwd_persist + peak_fwd[0] + peak_fwd[1] + peak_fwd[2] + peak_fwd[3]; }
+    size_t total() const { return all_persist + peak_all[0] + peak_all[1] + peak_all[2] + peak_all[3]; }
+    void place_scratch(Ctx& c, bool full) const {
+        size_t off = full ? all_persist : fwd_persist;
+        for (int i = 0; i < 4; ++i) {
+            c.sbase[i] = off;
+            off += full ? peak_all[i] : peak_fwd[i];
+        }
+    }
+};
+
+Plan make_plan(const alignn_model_desc* d, const alignn_model_batch* b, alignn_stream_t stream) {
+    Plan pl;
+    Ctx c{d, b, reinterpret_cast<char*>(4096)};  // (any non-null base: pointers are compared with NULL, never used)
+    set_streams(c, stream);
+    Tape tp;
+    run_forward(c, tp, nullptr);
+    pl.fwd_persist = c.off;
+    for (int i = 0; i < 4; ++i) pl.peak_fwd[i] = c.speak[i];
+    if (!c.unsupported) run_backward(c, tp, nullptr);
+    pl.all_persist = c.off;
+    for (int i = 0; i < 4; ++i) pl.peak_all[i] = c.speak[i];
+    pl.unsupported = c.unsupported;
+    pl.line = c.unsupported_line;
+    pl.rc = c.rc;
+    return pl;
+}
+
+}  // namespace
+
+extern "C" {
+
+int alignn_model_init(void) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= kMaxDevices) return (int)hipErrorInvalidDevice;
+    if (g_pool[dev].ok) return 0;
+    for (int i = 0; i < kEvents; ++i) {
+        e = hipEventCreateWithFlags(&g_pool[dev].ev[i], hipEventDisableTiming);
+        if (e != hipSuccess) return (int)e;
+    }
+    g_pool[dev].ok = true;
+    return 0;
+}
+
+size_t alignn_model_sizeof(int which) {
+    switch (which) {
+        case 0: return sizeof(alignn_mlp_params);
+        case 1: return sizeof(alignn_conv_params);
+        case 2: return sizeof(alignn_graph_csr);
+        case 3: return sizeof(alignn_model_batch);
+        case 4: return sizeof(alignn_model_desc);
+        default: return 0;
+    }
+}
+
+int alignn_model_plan(const alignn_model_desc* d, const alignn_model_batch* b, size_t* fwd_bytes, size_t* total_bytes) {
+    if (!desc_ok(d, b) || fwd_bytes == nullptr || total_bytes == nullptr) return (int)hipErrorInvalidValue;
+    Plan pl = make_plan(d, b, nullptr);
+    if (pl.unsupported) {
+        if (getenv("ALIGNN_AMD_DEBUG")) fprintf(stderr, "alignn_model_plan: kernel choice not carried (model.hip:%d)\n", pl.line);
+        return (int)hipErrorNotSupported;
+    }
+    *fwd_bytes = pl.fwd_total();
+    *total_bytes = pl.total();
+    return pl.rc;
+}
+
+int alignn_model_fwd(const alignn_model_desc* d, const alignn_model_batch* b, void* workspace, size_t workspace_bytes,
+                     float* out, alignn_stream_t stream) {
+    if (!desc_ok(d, b) || workspace == nullptr || out == nullptr) return (int)hipErrorInvalidValue;
+    const Plan pl = make_plan(d, b, stream);
+    if (pl.unsupported) return (int)hipErrorNotSupported;
+    Ctx c{d, b, static_cast<char*>(workspace)};
+    c.cap = workspace_bytes;
+    c.launch = true;
+    set_streams(c, stream);
+    if (workspace_bytes >= pl.total())
+        pl.place_scratch(c, true);
+    else if (workspace_bytes >= pl.fwd_total())
+        pl.place_scratch(c, false);  // (a forward nobody will differentiate: the tape and the forward's scratch only)
+    else
+        return (int)hipErrorInvalidValue;
+    if ((c.T != c.main || c.side != c.main || c.aux != c.main) && !take_pool(c)) return (int)hipErrorNotInitialized;
+    Tape tp;
+    run_forward(c, tp, out);
+    if (c.unsupported) return (int)hipErrorNotSupported;
+    return c.rc;
+}
+
+int alignn_model_bwd(const alignn_model_desc* d, const alignn_model_batch* b, void* workspace, size_t workspace_bytes,
+                     const float* g_out, alignn_stream_t stream) {
+    if (!desc_ok(d, b) || workspace == nullptr || g_out == nullptr) return (int)hipErrorInvalidValue;
+    const Plan pl = make_plan(d, b, stream);
+    if (pl.unsupported) return (int)hipErrorNotSupported;
+    if (workspace_bytes < pl.total()) return (int)hipErrorInvalidValue;
+    Ctx c{d, b, static_cast<char*>(workspace)};
+    c.cap = workspace_bytes;
+    set_streams(c, stream);
+    pl.place_scratch(c, true);
+    if ((c.T != c.main || c.side != c.main || c.aux != c.main) && !take_pool(c)) return (int)hipErrorNotInitialized;
+    Tape tp;
+    run_forward(c, tp, nullptr);  // (plan only: where the forward left its tape)
+    if (c.unsupported) return (int)hipErrorNotSupported;
+    c.launch = true;
+    run_backward(c, tp, g_out);
+    if (c.unsupported) return (int)hipErrorNotSupported;
+    return c.rc;
+}
+
+}  // extern "C"

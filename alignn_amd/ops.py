@@ -484,20 +484,27 @@ class WeightPrep:
         self.desc = torch.from_numpy(rec.view(np.uint8)).to(dev)
         self.sig = sig
 
-    def run(self, weights):
-        """``weights``: the same list (same tensor objects, same order) every step while nothing moved - the cheap path."""
+    def ensure(self, weights) -> bool:
+        """Image buffers and the descriptor table for ``weights`` (rebuilt when one of them moved); False when the batched
+        preparation does not apply to this list.  Launches nothing."""
         if not (BATCHED_WEIGHT_PREP and F16X3 and SPLIT_BOTH):
-            return
+            return False
         sig = tuple([w.data_ptr() for w in weights])
         if sig != self.sig or len(weights) != len(self.keep) or any(a is not b for a, b in zip(weights, self.keep)):
             ok = [w for w in weights if (w.dim() == 2 and w.is_cuda and w.dtype == torch.float32 and w.stride(1) == 1
                                          and w.stride(0) % 4 == 0 and w.shape[0] % 16 == 0 and w.shape[1] % 16 == 0)]
             if len(ok) != len(weights) or not ok:
                 self.sig = None
-                return
+                return False
             self._rebuild(weights, sig)
             self.refs = [(id(w), weakref.ref(w, lambda _r, k_=id(w): (_W_IMG.pop(k_, None), _W_IMG_T.pop(k_, None),
                                                                       _W_AMAX.pop(k_, None)))) for w in weights]
+        return True
+
+    def run(self, weights):
+        """``weights``: the same list (same tensor objects, same order) every step while nothing moved - the cheap path."""
+        if not self.ensure(weights):
+            return
         check(_lib.load().alignn_prepare_weights(ptr(self.desc), len(weights), ptr(self.amax), stream()), "prepare_weights")
         WEIGHT_PREP_STATS["runs"] += 1
         WEIGHT_PREP_STATS["weights"] += len(weights)

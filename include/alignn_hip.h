@@ -574,6 +574,81 @@ int alignn_egc_conv_wgrad(const alignn_egc_wgrad_args* args, alignn_stream_t str
 /* sizeof the three argument structs (0: fwd, 1: bwd, 2: wgrad) - a binding checks its own packing against these */
 size_t alignn_egc_args_sizeof(int which);
 
+/* ------------------------------------------------------------------------------------------
+ * Whole-model entry points (csrc/model.hip): ONE call = ALIGNN.forward in training mode
+ * (alignn/models/alignn.py:282-349: RBF + MLPLayer embeddings :201-222, ALIGNNConv x alignn_layers :132-167,
+ * EdgeGatedGraphConv x gcn_layers :48-129, AvgPooling + fc :325,341) or torch.autograd's backward of it - what the
+ * reference's per-batch loop (alignn/train.py:258-270: a NEW (g, lg) every iteration, so nothing can be replayed) pays
+ * per step.  The same kernels with the same arguments as the per-operator entry points above (bit-identical results),
+ * issued from C over ONE caller-owned workspace whose layout is a pure function of the model dimensions and (N, E, T).
+ *   alignn_model_init:  once per device, outside stream capture - the event pool the helper streams are ordered with
+ *   alignn_model_plan:  bytes of workspace the forward / forward + backward of this batch need; hipErrorNotSupported
+ *                       (801) when a kernel choice is not carried here (the caller then sequences the operators itself)
+ *   alignn_model_fwd:   out[B, out_features] = fc(pool(...)); running statistics and num_batches_tracked updated
+ *   alignn_model_bwd:   parameter gradients into the g_* / *red pointers of the parameter blocks; the workspace must be
+ *                       the one the forward of the same (desc, batch) filled
+ * Gradient layout: `red` / `n_red` / `e_red` = [2, F] = (dbeta | dgamma) of the norm; g_wcat [4H, H] = the four node
+ * projections' weight gradients as row blocks (src_gate, dst_gate, dst_update, src_update), g_bcat [4H] likewise.
+ * Streams (desc): lane_T / side / aux optional helper streams (NULL: the caller's); every one is joined back into
+ * `stream` before a call returns.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct alignn_mlp_params {
+    const float *W, *b, *gamma, *beta;         /* Linear [out, in] / [out], BatchNorm1d affine */
+    float *rm, *rv;                            /* running_mean / running_var (updated) */
+    float *gW, *gb, *red;                      /* gradients: [out, in], [out], [2, out] = dbeta | dgamma */
+    const void *img, *img_t;                   /* f16x2 slice images of W / W^T (alignn_prepare_weights) or NULL */
+    const float* w_amax;
+    int32_t in, out;
+} alignn_mlp_params;
+
+typedef struct alignn_conv_params {
+    const float *wcat, *bcat, *w_eg, *b_eg;    /* fused node projection [4H, H] / [4H]; edge_gate [H, H] / [H] */
+    const float *n_gamma, *n_beta, *e_gamma, *e_beta;
+    float *n_rm, *n_rv, *e_rm, *e_rv;
+    float *g_wcat, *g_bcat, *g_weg, *g_beg, *n_red, *e_red;
+    const void *wcat_img, *wcat_img_t, *weg_img, *weg_img_t;
+    const float *wcat_amax, *weg_amax;
+} alignn_conv_params;
+
+typedef struct alignn_graph_csr {              /* canonical CSR (see the conventions at the top of this file) */
+    const int32_t *seg_ptr, *seg_node, *src, *dst, *out_ptr, *out_slot;
+    const int32_t *grp_seg_ptr, *grp_src_ptr, *seg_rank; /* line graphs: dense blocks per centre atom; segment of every row */
+    int64_t n, m, n_groups;
+    int32_t dense_max_src, pad_;
+} alignn_graph_csr;
+
+typedef struct alignn_model_batch {
+    alignn_graph_csr g, lg;
+    const int32_t* graph_ptr;                  /* [B + 1] atom offsets per crystal */
+    const float *atom_features, *r, *h;        /* [N, atom_in], [E, 3] bond vectors, [T] bond-angle cosines (canonical order) */
+    int32_t B, pad_;
+} alignn_model_batch;
+
+typedef struct alignn_model_desc {
+    int32_t alignn_layers, gcn_layers, H, out_features, atom_in, edge_bins, angle_bins, embed;
+    float edge_gamma, angle_gamma, eps, momentum;
+    const float *edge_centers, *angle_centers;
+    alignn_mlp_params atom, edge1, edge2, angle1, angle2;
+    const alignn_conv_params* convs;           /* HOST array: (node_update, edge_update) x alignn_layers, then gcn_layers */
+    const float *fc_W, *fc_b;
+    float *g_fc_W, *g_fc_b;
+    const void* weight_descs;                  /* alignn_prepare_weights' device table (n_weights records) or NULL */
+    float* weight_amax;
+    const void* bump_ptrs;                     /* device array of n_bump int64_t* (num_batches_tracked), each += 1 per forward */
+    int32_t n_weights, n_bump;
+    int32_t x6_min_tiles, bd_segment_table;    /* kernel-choice constants of the per-operator path (256, 1) */
+    int64_t amax_min_rows, lane_min_rows, side_min_rows; /* 4096; rows from which a kernel goes to lane_T / side */
+    alignn_stream_t lane_T, side, aux;
+} alignn_model_desc;
+
+int alignn_model_init(void);
+size_t alignn_model_sizeof(int which); /* 0 mlp_params, 1 conv_params, 2 graph_csr, 3 model_batch, 4 model_desc */
+int alignn_model_plan(const alignn_model_desc* desc, const alignn_model_batch* batch, size_t* fwd_bytes, size_t* total_bytes);
+int alignn_model_fwd(const alignn_model_desc* desc, const alignn_model_batch* batch, void* workspace, size_t workspace_bytes,
+                     float* out, alignn_stream_t stream);
+int alignn_model_bwd(const alignn_model_desc* desc, const alignn_model_batch* batch, void* workspace, size_t workspace_bytes,
+                     const float* g_out, alignn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,202 @@
+"""Whole-model C entry points (csrc/model.hip, alignn_amd/cmodel.py): one C call per forward / backward of ALIGNN.
+
+They issue the launches of the per-operator path (alignn_amd/ops.py) with the same arguments, so the bar is BIT equality
+of predictions, every parameter gradient, the running statistics and the parameters after optimizer steps - on one stream
+and on four, eagerly launched and replayed from a hipGraph, on batches that change from step to step (the reference's loop,
+alignn/train.py:258-270).  tests/test_gpu_round3.py::test_composite_entry_points_... holds the model-size matrix (H = 64 /
+96 / 256, fp32 and split-product projections); the parity tests against the reference's goldens (tests/test_gpu_model.py,
+tests/test_gpu_full_size.py) run through this path by default."""
+
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from alignn_amd import ALIGNN, ALIGNNConfig, GraphBatch, cmodel, ops  # noqa: E402
+from alignn_amd.synthetic import make_batch  # noqa: E402
+
+DEV = "cuda"
+
+
+def _mk(seed=0, **cfg):
+    torch.manual_seed(seed)
+    return ALIGNN(ALIGNNConfig(name="alignn", **cfg)).to(DEV).train()
+
+
+def _state(model, pred=None):
+    out = {} if pred is None else {"pred": pred.detach().clone()}
+    out.update({"g." + k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+    out.update({"s." + k: v.clone() for k, v in model.state_dict().items()})
+    return out
+
+
+def _same(a, b, what=""):
+    assert a.keys() == b.keys(), set(a) ^ set(b)
+    for k in a:
+        assert torch.equal(a[k], b[k]), (what, k, float((a[k].double() - b[k].double()).abs().max()))
+
+
+def _steps(model, batches, targets, use_c, opt_cls=None):
+    prev = cmodel.ENABLED
+    cmodel.ENABLED = use_c
+    try:
+        opt = (opt_cls or (lambda ps: torch.optim.AdamW(ps, lr=1e-3, fused=True)))(model.parameters())
+        for b, t in zip(batches, targets):
+            opt.zero_grad(set_to_none=True)
+            pred = model(b)
+            torch.nn.functional.l1_loss(pred, t).backward()
+            opt.step()
+        torch.cuda.synchronize()
+        return _state(model, pred)
+    finally:
+        cmodel.ENABLED = prev
+
+
+def test_a_new_batch_every_step_equals_the_per_operator_path_bit_for_bit():
+    """Four optimizer steps on four different batches (the shared workspace grows, shrinks in use, plans are cached per
+    shape): same parameters, gradients, running statistics as the per-operator path."""
+    raws = [make_batch(n, a, seed0=s) for n, a, s in ((12, 40, 5), (20, 60, 6), (7, 25, 7), (20, 60, 8))]
+    batches = [GraphBatch.from_raw(r, device=DEV) for r in raws]
+    targets = [torch.randn(r.batch_size, generator=torch.Generator().manual_seed(i)).to(DEV) for i, r in enumerate(raws)]
+    for k in cmodel.STATS:
+        cmodel.STATS[k] = 0
+    a = _steps(_mk(), batches, targets, True)
+    assert cmodel.STATS["fwd"] == 4 and cmodel.STATS["bwd"] == 4 and cmodel.STATS["plans"] == 3, cmodel.STATS
+    b = _steps(_mk(), batches, targets, False)
+    _same(a, b)
+
+
+def test_one_stream_and_four_streams_give_the_same_bits():
+    raw = make_batch(24, 60, seed0=31)  # T = 254 k rows: lane T, the side stream and the aux fork are all in use
+    batch = GraphBatch.from_raw(raw, device=DEV)
+    target = torch.randn(24, generator=torch.Generator().manual_seed(4)).to(DEV)
+    ref = _steps(_mk(), [batch] * 2, [target] * 2, True)
+    saved = (ops._LANE["enabled"], ops._SIDE["enabled"], ops.FORK_DGRAD)
+    ops._LANE["enabled"], ops._SIDE["enabled"], ops.FORK_DGRAD = "0", False, "0"
+    try:
+        one = _steps(_mk(), [batch] * 2, [target] * 2, True)
+    finally:
+        ops._LANE["enabled"], ops._SIDE["enabled"], ops.FORK_DGRAD = saved
+    _same(ref, one, "streams")
+    for _ in range(3):  # and again: a missing dependency shows up as run-to-run differences
+        _same(ref, _steps(_mk(), [batch] * 2, [target] * 2, True), "repeat")
+
+
+def test_headline_batch_is_bit_identical_and_needs_few_host_calls():
+    raw = make_batch(64, 60)
+    batch = GraphBatch.from_raw(raw, device=DEV)
+    target = torch.randn(64, generator=torch.Generator().manual_seed(1)).to(DEV)
+    a = _steps(_mk(), [batch] * 2, [target] * 2, True)
+    b = _steps(_mk(), [batch] * 2, [target] * 2, False)
+    _same(a, b, "B=64")
+
+
+def test_replayed_from_a_hipgraph_equals_eager():
+    raw = make_batch(16, 60, seed0=9)
+    batch = GraphBatch.from_raw(raw, device=DEV)
+    target = torch.randn(16, generator=torch.Generator().manual_seed(2)).to(DEV)
+    eager = _mk()
+    losses = []
+    for _ in range(3):
+        for p in eager.parameters():
+            p.grad = None
+        loss = torch.nn.functional.l1_loss(eager(batch), target)
+        loss.backward()
+        losses.append(loss.detach().clone())
+    ref = _state(eager)
+    model = _mk()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):  # warm-up on a side stream (torch's capture recipe)
+        torch.nn.functional.l1_loss(model(batch), target).backward()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    for p in model.parameters():
+        p.grad = None
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        g_loss = torch.nn.functional.l1_loss(model(batch), target)
+        g_loss.backward()
+    grads = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+    for i in (1, 2):  # (the warm-up step was step 0 of the running statistics)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(g_loss, losses[i]), (i, g_loss.item(), losses[i].item())
+    got = {"g." + k: v for k, v in grads.items()}
+    got.update({"s." + k: v for k, v in model.state_dict().items()})
+    _same(ref, got, "replay")
+
+
+def test_autograd_semantics_accumulation_two_forwards_no_grad():
+    raw1, raw2 = make_batch(10, 30, seed0=3), make_batch(6, 50, seed0=4)
+    b1, b2 = GraphBatch.from_raw(raw1, device=DEV), GraphBatch.from_raw(raw2, device=DEV)
+    t1 = torch.randn(10, generator=torch.Generator().manual_seed(5)).to(DEV)
+    t2 = torch.randn(6, generator=torch.Generator().manual_seed(6)).to(DEV)
+
+    def run(use_c):
+        prev = cmodel.ENABLED
+        cmodel.ENABLED = use_c
+        try:
+            m = _mk(3)
+            with torch.no_grad():  # a forward nobody differentiates (training mode: statistics are still updated)
+                m(b1)
+            l1 = torch.nn.functional.l1_loss(m(b1), t1)  # two forwards alive at once ...
+            l2 = torch.nn.functional.l1_loss(m(b2), t2)
+            l2.backward()  # ... differentiated in the other order, gradients accumulate
+            l1.backward()
+            torch.cuda.synchronize()
+            return _state(m)
+        finally:
+            cmodel.ENABLED = prev
+
+    a, b = run(True), run(False)
+    assert a.keys() == b.keys()
+    gmax = max(float(v.abs().max()) for k, v in b.items() if k.startswith("g."))
+    for k in a:
+        if k.startswith("g."):  # (sum of two gradients: AccumulateGrad adds in the order the backward passes ran - same here)
+            assert torch.equal(a[k], b[k]) or float((a[k] - b[k]).abs().max()) < 1e-6 * gmax, k
+        else:
+            assert torch.equal(a[k], b[k]), k
+
+
+def test_cases_the_c_side_does_not_take_fall_back_to_the_operators():
+    raw = make_batch(6, 30, seed0=3)
+    batch = GraphBatch.from_raw(raw, device=DEV)
+    target = torch.randn(6, generator=torch.Generator().manual_seed(5)).to(DEV)
+    for k in cmodel.STATS:
+        cmodel.STATS[k] = 0
+    m = _mk(1)
+    m.fc.bias.requires_grad_(False)  # a frozen parameter: per-operator path
+    torch.nn.functional.l1_loss(m(batch), target).backward()
+    assert cmodel.STATS["fwd"] == 0 and m.fc.bias.grad is None and m.fc.weight.grad is not None
+    m = _mk(1).eval()
+    with torch.no_grad():
+        m(batch)
+    assert cmodel.STATS["fwd"] == 0
+    m = _mk(1)
+    torch.nn.functional.l1_loss(m(batch), target).backward()
+    assert cmodel.STATS["fwd"] == 1 and cmodel.STATS["bwd"] == 1
+
+
+def test_flat_adamw_rehoming_is_followed():
+    """FlatAdamW re-homes every parameter into one flat buffer at its first step(): the parameter blocks of the C
+    description are rebuilt, training continues bit-identically to the per-operator path."""
+    from alignn_amd.optim import FlatAdamW, group_decay
+
+    raw = make_batch(12, 40, seed0=5)
+    batch = GraphBatch.from_raw(raw, device=DEV)
+    target = torch.randn(12, generator=torch.Generator().manual_seed(1)).to(DEV)
+
+    def run(use_c):
+        m = _mk(2)
+        holder = {}
+
+        def mkopt(_ps):
+            holder["opt"] = FlatAdamW(group_decay(m), lr=1e-3, weight_decay=1e-2, module=m)
+            return holder["opt"]
+
+        return _steps(m, [batch] * 3, [target] * 3, use_c, opt_cls=mkopt)
+
+    _same(run(True), run(False), "flat adamw")

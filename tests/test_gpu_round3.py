@@ -165,8 +165,10 @@ def _default_step_stats(wrap_ddp):
         s.close()
         dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
         net = torch.nn.parallel.DistributedDataParallel(model, find_unused_parameters=True)  # alignn/train.py:207
+    from alignn_amd import cmodel
+
     try:
-        with warnings.catch_warnings():
+        with warnings.catch_warnings(), cmodel.disabled():  # (the registries belong to the per-operator path)
             warnings.simplefilter("error", RuntimeWarning)  # a fall-back to bf16x6 / separate reductions would raise here
             torch.nn.functional.l1_loss(net(batch), target).backward()  # first step: lazy initialisations
             ops.reset_registry_stats()
@@ -258,11 +260,18 @@ def test_float64_model_on_the_gpu_reproduces_the_float64_reference():
 # ---------------------------------------------------------------------------------------------
 # composite entry points: one C call per convolution forward / backward - same launches, same bits
 # ---------------------------------------------------------------------------------------------
-def _train_state(mk_model, batch, target, composite, steps=2):
-    prev = ops.COMPOSITE
+def _train_state(mk_model, batch, target, composite, steps=2, use_cmodel=False):
+    """``use_cmodel``: the whole-model C entry points (alignn_amd/cmodel.py - the default training path since round 4);
+    False = the per-operator path these A/B tests are about."""
+    from alignn_amd import cmodel
+
+    prev, prev_c = ops.COMPOSITE, cmodel.ENABLED
     ops.COMPOSITE = composite
+    cmodel.ENABLED = use_cmodel
     for k in ops.COMPOSITE_STATS:
         ops.COMPOSITE_STATS[k] = 0
+    for k in cmodel.STATS:
+        cmodel.STATS[k] = 0
     try:
         model = mk_model()
         opt = torch.optim.AdamW(model.parameters(), lr=1e-3, fused=True)
@@ -278,6 +287,7 @@ def _train_state(mk_model, batch, target, composite, steps=2):
         return out, dict(ops.COMPOSITE_STATS)
     finally:
         ops.COMPOSITE = prev
+        cmodel.ENABLED = prev_c
 
 
 @pytest.mark.parametrize("case", ["small_fp32_kernels", "default_16x60_mixed", "default_48x60_split_products", "no_residual_dims"])
@@ -313,6 +323,14 @@ def test_composite_entry_points_are_bit_identical_to_the_per_kernel_path(case):
     assert a.keys() == b.keys()
     for k in a:
         assert torch.equal(a[k], b[k]), (case, k)
+    # ... and the whole-model entry points (one C call per forward / backward: csrc/model.hip) issue the same launches again
+    from alignn_amd import cmodel
+
+    c, stats_c = _train_state(mk, batch, target, True, use_cmodel=True)
+    assert stats_c == {"fwd": 0, "bwd": 0, "wgrad": 0} and cmodel.STATS["fwd"] == 2 and cmodel.STATS["bwd"] == 2, cmodel.STATS
+    assert a.keys() == c.keys(), set(a) ^ set(c)
+    for k in a:
+        assert torch.equal(a[k], c[k]), (case, "cmodel", k)
 
 
 def test_batched_weight_preparation_gives_the_same_bits():
