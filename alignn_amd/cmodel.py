@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import time
 
 import torch
 
@@ -26,6 +27,7 @@ from . import _lib, ops
 ENABLED = os.environ.get("ALIGNN_AMD_CMODEL", "1") != "0"
 STATS = {"fwd": 0, "bwd": 0, "plans": 0, "rebuilds": 0, "arena_bytes": 0}
 _NOT_SUPPORTED = 801  # hipErrorNotSupported
+TIMING = None  # tools/host_profile_c.py: {"cfwd": s, "cbwd": s, "bwd_py": s} accumulated host seconds
 
 _p, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -136,6 +138,7 @@ class Binding:
         self.desc_addr = C.addressof(self.desc)
         self.arena = None
         self.arena_busy = False
+        self.pinned = []
         self.plans = {}
         self.bump = None
         self._layout()
@@ -305,12 +308,18 @@ class Binding:
         allocation per step would fragment the caching allocator when no two batches are alike); a forward that finds it
         still held by an earlier one whose backward has not run, and every forward inside a stream capture (the block
         then has to belong to the graph's own memory pool), allocates its own."""
-        if capturing or self.arena_busy:
+        if self.arena_busy:
             return torch.empty(nbytes, dtype=torch.uint8, device=self.device), False
         if self.arena is None or self.arena.numel() < nbytes:
+            if capturing:  # (the shared block would have to be allocated outside the capture: let the graph's pool own one)
+                return torch.empty(nbytes, dtype=torch.uint8, device=self.device), False
             self.arena = None
             self.arena = torch.empty(int(nbytes * 1.05) + 4096, dtype=torch.uint8, device=self.device)
             STATS["arena_bytes"] = self.arena.numel()
+        if capturing and not any(a is self.arena for a in self.pinned):
+            # a captured graph replays into THIS block for as long as it lives: never free it (a later, larger batch
+            # allocates a new shared block; eager steps in between only overwrite what every replay recomputes)
+            self.pinned.append(self.arena)
         self.arena_busy = need_backward
         return self.arena, need_backward
 
@@ -342,8 +351,11 @@ class _ModelFn(torch.autograd.Function):
     def forward(ctx, bind, mb, keep, arena, arena_bytes, owns, *params):
         lib = _lib_model()
         out = torch.empty(mb.B, bind.desc.out_features, dtype=torch.float32, device=bind.device)
+        t0 = time.perf_counter() if TIMING is not None else 0.0
         _lib.check(lib.alignn_model_fwd(bind.desc_addr, C.addressof(mb), arena.data_ptr(), arena_bytes, out.data_ptr(),
                                         _lib.stream()), "model_fwd")
+        if TIMING is not None:
+            TIMING["cfwd"] = TIMING.get("cfwd", 0.0) + time.perf_counter() - t0
         STATS["fwd"] += 1
         ctx.bind, ctx.mb, ctx.keep, ctx.arena, ctx.arena_bytes, ctx.lease = bind, mb, keep, arena, arena_bytes, _Lease(bind, owns)
         ctx.sig = bind.sig
@@ -357,16 +369,20 @@ class _ModelFn(torch.autograd.Function):
             raise RuntimeError("alignn_amd.cmodel: backward called twice on the same forward (its workspace is gone)")
         if bind.sig != ctx.sig:
             raise RuntimeError("alignn_amd.cmodel: the model's parameters moved between forward and backward")
+        t_in = time.perf_counter() if TIMING is not None else 0.0
         g_out = g_out.contiguous()
         gflat = torch.empty(bind.grad_floats, dtype=torch.float32, device=bind.device)
         base = gflat.data_ptr()
         for owner, field, off in bind.grad_fields:
             setattr(owner, field, base + 4 * off)
         bind.set_mode()
+        t0 = time.perf_counter() if TIMING is not None else 0.0
         try:
             _lib.check(lib.alignn_model_bwd(bind.desc_addr, C.addressof(ctx.mb), ctx.arena.data_ptr(), ctx.arena_bytes,
                                             g_out.data_ptr(), _lib.stream()), "model_bwd")
         finally:
+            if TIMING is not None:
+                TIMING["cbwd"] = TIMING.get("cbwd", 0.0) + time.perf_counter() - t0
             ctx.lease.release()
             ctx.arena = None
         STATS["bwd"] += 1
@@ -374,6 +390,8 @@ class _ModelFn(torch.autograd.Function):
         grads = []
         for i, shape, dead in zip(bind.keep, bind.shapes, bind.no_grad):
             grads.append(None if dead else (pieces[i] if len(shape) == 1 else pieces[i].view(shape)))
+        if TIMING is not None:
+            TIMING["bwd_py"] = TIMING.get("bwd_py", 0.0) + time.perf_counter() - t_in
         return (None,) * 6 + tuple(grads)
 
 
@@ -400,8 +418,18 @@ def applicable(model, b) -> bool:
         model.__dict__["_cmodel_static_ok"] = ok
     if not ok:
         return False
-    if torch.is_grad_enabled() and not all(p.requires_grad for p in model.parameters()):
-        return False
+    slots = model.__dict__.get("_cmodel_slots")
+    if slots is None:  # [(module._parameters, name, parameter)]: a replaced Parameter object is noticed without walking the tree
+        slots = model.__dict__["_cmodel_slots"] = [(mod._parameters, name, p) for mod in model.modules()
+                                                   for name, p in mod._parameters.items() if p is not None]
+    need_grad = torch.is_grad_enabled()
+    for d, name, p in slots:
+        if d.get(name) is not p:
+            model.__dict__.pop("_cmodel_slots", None)
+            model.__dict__.pop("_cmodel", None)
+            return applicable(model, b)
+        if need_grad and not p.requires_grad:
+            return False
     if any(p.dtype != torch.float32 for p in (model.atom_embedding.layer[0].weight, model.fc.bias)):
         return False
     return True

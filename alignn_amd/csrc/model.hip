@@ -19,6 +19,7 @@
 //
 // Workspace = [forward tape | backward temporaries]; the forward's tape (pre-activations, projections, statistics ...) is
 // found again by the backward by re-running the same deterministic plan without launching.
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -140,12 +141,18 @@ struct Ctx {
     }
     bool track(int64_t rows) const { return rows >= d->amax_min_rows; }
     // `waiter` continues only after everything enqueued on `src` so far
+    int n_sync = 0, n_launch = 0;
+    double t_sync = 0.0;
+    bool timing = false;
     void sync(hipStream_t waiter, hipStream_t src) {
         if (!launch || rc != 0 || waiter == src) return;
+        const auto t0 = timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
         hipEvent_t e = pool->ev[pool->next];
         pool->next = (pool->next + 1) % kEvents;
         rc = (int)hipEventRecord(e, src);
         if (rc == 0) rc = (int)hipStreamWaitEvent(waiter, e, 0);
+        ++n_sync;
+        if (timing) t_sync += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
 };
 
@@ -155,9 +162,13 @@ struct Ctx {
         if (!c.unsupported_line) c.unsupported_line = __LINE__; \
     } while (0)
 
-#define L(call)                                       \
-    do {                                              \
-        if (c.launch && c.rc == 0) c.rc = (call);     \
+#define L(call)                                                                                        \
+    do {                                                                                               \
+        if (c.launch && c.rc == 0) {                                                                   \
+            c.rc = (call);                                                                             \
+            ++c.n_launch;                                                                              \
+            if (c.rc != 0 && getenv("ALIGNN_AMD_DEBUG")) fprintf(stderr, "model.hip:%d rc %d: %s\n", __LINE__, c.rc, #call); \
+        }                                                                                              \
     } while (0)
 
 inline bool x6_shape_ok(const Ctx& c, int64_t M, int64_t lda, int N, int K) {
@@ -422,7 +433,7 @@ void dgrad(Ctx& c, const float* g, int64_t ldg, const float* g_amax, const float
             UNSUP();
             return;
         }
-        if (src != nullptr && src->xn != nullptr && src->red != nullptr) {
+        if (src != nullptr && src->xn != nullptr) {  // (never on `red`: a gradient pointer is not set yet when the plan is made)
             const int tiles = alignn_gemm_nt_x6_row_tiles(M, Kout, Nred);
             float* part = c.alloc((size_t)(tiles + 1) * 2 * Kout);
             L(alignn_gemm_nt_f16x3_bnred(g, ldg, g_amax, img_t, w_amax, nullptr, addend, ldadd, out, Kout, M, Kout, Nred, src->xn,
@@ -754,11 +765,15 @@ int alignn_model_plan(const alignn_model_desc* d, const alignn_model_batch* b, s
 int alignn_model_fwd(const alignn_model_desc* d, const alignn_model_batch* b, void* workspace, size_t workspace_bytes,
                      float* out, alignn_stream_t stream) {
     if (!desc_ok(d, b) || workspace == nullptr || out == nullptr) return (int)hipErrorInvalidValue;
+    const bool timing = getenv("ALIGNN_AMD_DEBUG_TIME") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     const Plan pl = make_plan(d, b, stream);
+    const auto t1 = std::chrono::steady_clock::now();
     if (pl.unsupported) return (int)hipErrorNotSupported;
     Ctx c{d, b, static_cast<char*>(workspace)};
     c.cap = workspace_bytes;
     c.launch = true;
+    c.timing = timing;
     set_streams(c, stream);
     if (workspace_bytes >= pl.total())
         pl.place_scratch(c, true);
@@ -769,6 +784,11 @@ int alignn_model_fwd(const alignn_model_desc* d, const alignn_model_batch* b, vo
     if ((c.T != c.main || c.side != c.main || c.aux != c.main) && !take_pool(c)) return (int)hipErrorNotInitialized;
     Tape tp;
     run_forward(c, tp, out);
+    if (timing) {
+        const double tot = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        fprintf(stderr, "alignn_model_fwd: %.3f ms host (plan %.3f ms, %d stream syncs %.3f ms, %d launch calls)\n", tot * 1e3,
+                std::chrono::duration<double>(t1 - t0).count() * 1e3, c.n_sync, c.t_sync * 1e3, c.n_launch);
+    }
     if (c.unsupported) return (int)hipErrorNotSupported;
     return c.rc;
 }
@@ -776,19 +796,28 @@ int alignn_model_fwd(const alignn_model_desc* d, const alignn_model_batch* b, vo
 int alignn_model_bwd(const alignn_model_desc* d, const alignn_model_batch* b, void* workspace, size_t workspace_bytes,
                      const float* g_out, alignn_stream_t stream) {
     if (!desc_ok(d, b) || workspace == nullptr || g_out == nullptr) return (int)hipErrorInvalidValue;
+    const bool timing = getenv("ALIGNN_AMD_DEBUG_TIME") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     const Plan pl = make_plan(d, b, stream);
     if (pl.unsupported) return (int)hipErrorNotSupported;
     if (workspace_bytes < pl.total()) return (int)hipErrorInvalidValue;
     Ctx c{d, b, static_cast<char*>(workspace)};
     c.cap = workspace_bytes;
+    c.timing = timing;
     set_streams(c, stream);
     pl.place_scratch(c, true);
     if ((c.T != c.main || c.side != c.main || c.aux != c.main) && !take_pool(c)) return (int)hipErrorNotInitialized;
     Tape tp;
     run_forward(c, tp, nullptr);  // (plan only: where the forward left its tape)
     if (c.unsupported) return (int)hipErrorNotSupported;
+    const auto t1 = std::chrono::steady_clock::now();
     c.launch = true;
     run_backward(c, tp, g_out);
+    if (timing) {
+        const double tot = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        fprintf(stderr, "alignn_model_bwd: %.3f ms host (plans %.3f ms, %d stream syncs %.3f ms, %d launch calls)\n", tot * 1e3,
+                std::chrono::duration<double>(t1 - t0).count() * 1e3, c.n_sync, c.t_sync * 1e3, c.n_launch);
+    }
     if (c.unsupported) return (int)hipErrorNotSupported;
     return c.rc;
 }

@@ -54,6 +54,8 @@ class PackedBatch:
     num_nodes: int
     num_edges: int
     batch_size: int
+    num_triplets: int = -1  # rows of L(g), derived from the bond list when the batch is packed (-1: unknown)
+    max_in_degree: int = 0  # largest number of bonds arriving at one atom (CSRGraph.dense_max_src of the line graph)
 
     @property
     def nbytes(self) -> int:
@@ -86,6 +88,17 @@ def pack(u, v, batch_num_nodes, r, lattice, atom_features=None, species=None, ta
     N = int(parts[2][1].sum())
     if int(parts[0][1].max(initial=-1)) >= N or int(parts[1][1].max(initial=-1)) >= N:
         raise ValueError("bond endpoint out of range")
+    # what the device-side staging needs to know BEFORE it runs (sizes of its outputs, the dense-block bound of the
+    # line-graph backward) and what is cheaper here than as device operations: functions of the bond list alone
+    uu, vv, bnn = parts[0][1].astype(np.int64), parts[1][1].astype(np.int64), parts[2][1].astype(np.int64)
+    din = np.bincount(vv, minlength=N)
+    n_triplets = int(din[uu].sum() - np.count_nonzero(uu == vv))  # rows of L(g): (in-edges of src(e2)) - (e2 itself if self image)
+    max_in = int(din[uu].max(initial=0))  # largest in-degree among atoms that have a bond leaving them (= line_graph_of's bound)
+    gp = np.zeros(bnn.shape[0] + 1, dtype=np.int32)
+    np.cumsum(bnn, out=gp[1:])
+    parts.append(("graph_ptr", gp))
+    lat64 = np.asarray(lattice, dtype=np.float64).reshape(-1, 3, 3)
+    parts.append(("volume", np.abs(np.linalg.det(lat64)).astype(np.float32)))
     sections, off = {}, 0
     tdt = {np.dtype(np.int32): torch.int32, np.dtype(np.float32): torch.float32}
     for name, arr in parts:
@@ -98,7 +111,7 @@ def pack(u, v, batch_num_nodes, r, lattice, atom_features=None, species=None, ta
     for name, arr in parts:
         o = sections[name][0]
         nb[o:o + arr.nbytes] = arr.reshape(-1).view(np.uint8)
-    return PackedBatch(buf, sections, N, E, int(parts[2][1].shape[0]))
+    return PackedBatch(buf, sections, N, E, int(parts[2][1].shape[0]), n_triplets, max_in)
 
 
 def pack_raw(raw, target=None, pin: Optional[bool] = None) -> PackedBatch:
@@ -119,6 +132,8 @@ def stage(packed: PackedBatch, device, feature_table: Optional[torch.Tensor] = N
         n = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
         return d[off:off + n].view(dtype).view(shape)
 
+    if STAGE_HIP and dev.type == "cuda" and packed.num_triplets >= 0 and packed.num_edges > 0:
+        return _stage_hip(packed, dev, d, view, feature_table, cosines)
     g = build_csr(view("u"), view("v"), packed.num_nodes)
     lg = line_graph_of(g)
     bnn = view("batch_num_nodes").to(torch.int64)
@@ -140,7 +155,67 @@ def stage(packed: PackedBatch, device, feature_table: Optional[torch.Tensor] = N
     return batch, target
 
 
+STAGE_HIP = True  # one C call (csrc/stage.hip) instead of ~60 torch index operations; tests flip it to compare (same arrays)
+_I32, _I64, _F32 = torch.int32, torch.int64, torch.float32
+
+
+def _stage_hip(packed: PackedBatch, dev, d, view, feature_table, cosines):
+    """``stage`` through ``alignn_stage_batch``: ONE device allocation carved into every index array of (g, L(g)), the
+    canonical bond vectors and the cosines, ONE C call (two stable radix sorts of E keys, two prefix sums, index
+    arithmetic for the T rows) - the consumer's thread spends microseconds, not the ~5 ms of host time the chain of torch
+    operations in ``graph.build_csr`` / ``graph.line_graph_of`` costs.  Same arrays, bit for bit (tests)."""
+    from . import _lib
+
+    lib = _lib.load()
+    N, E, T = packed.num_nodes, packed.num_edges, packed.num_triplets
+    want = [("seg_ptr", _I32, N + 1), ("src", _I32, E), ("dst", _I32, E), ("out_ptr", _I32, N + 1), ("out_slot", _I32, E),
+            ("perm", _I64, E), ("inv", _I64, E), ("r", _F32, 3 * E), ("lg_seg_ptr", _I32, E + 1), ("lg_src", _I32, T),
+            ("lg_dst", _I32, T), ("lg_out_ptr", _I32, E + 1), ("lg_out_slot", _I32, T), ("seg_rank", _I32, T),
+            ("ident", _I64, T), ("h", _F32, T if cosines else 0)]
+    offs, off = {}, 0
+    for name, dt, n in want:
+        offs[name] = off
+        off = _up(off + n * (8 if dt is _I64 else 4))
+    ws_bytes = lib.alignn_stage_batch_workspace(N, E)
+    out = torch.empty(off + ws_bytes, dtype=torch.uint8, device=dev)
+    base = out.data_ptr()
+    a = {name: (out[offs[name]:offs[name] + n * (8 if dt is _I64 else 4)].view(dt) if n else None) for name, dt, n in want}
+    _lib.check(lib.alignn_stage_batch(
+        view("u").data_ptr(), view("v").data_ptr(), view("r").data_ptr(), N, E, T,
+        base + offs["seg_ptr"], base + offs["src"], base + offs["dst"], base + offs["out_ptr"], base + offs["out_slot"],
+        base + offs["perm"], base + offs["inv"], base + offs["r"], base + offs["lg_seg_ptr"], base + offs["lg_src"],
+        base + offs["lg_dst"], base + offs["lg_out_ptr"], base + offs["lg_out_slot"], base + offs["seg_rank"],
+        base + offs["ident"], (base + offs["h"]) if cosines else None, base + off, ws_bytes, _lib.stream()), "stage_batch")
+    from .graph import CSRGraph
+
+    g = CSRGraph(n_nodes=N, n_edges=E, seg_ptr=a["seg_ptr"], seg_node=None, src=a["src"], dst=a["dst"], out_ptr=a["out_ptr"],
+                 out_slot=a["out_slot"], perm=a["perm"], inv=a["inv"])
+    lg = CSRGraph(n_nodes=E, n_edges=T, seg_ptr=a["lg_seg_ptr"], seg_node=a["out_slot"], src=a["lg_src"], dst=a["lg_dst"],
+                  out_ptr=a["lg_out_ptr"], out_slot=a["lg_out_slot"], perm=a["ident"], inv=a["ident"],
+                  grp_seg_ptr=a["out_ptr"], grp_src_ptr=a["seg_ptr"], dense_max_src=packed.max_in_degree, seg_rank=a["seg_rank"])
+    batch = GraphBatch(g=g, lg=lg, graph_ptr=view("graph_ptr"), batch_size=packed.batch_size)
+    batch.cache["staged_block"] = (out, d)  # the two device blocks every view above lives in
+    if "species" in packed.sections:
+        if feature_table is None:
+            raise ValueError("a species batch needs the device feature table")
+        batch.atom_features = feature_table.to(dev)[view("species").long()].contiguous()
+    else:
+        batch.atom_features = view("atom_features")
+    batch.r = a["r"].view(E, 3)
+    batch.volume = view("volume")
+    if cosines:
+        batch.h = a["h"]
+    target = view("target") if "target" in packed.sections else None
+    return batch, target
+
+
 def _batch_tensors(b: GraphBatch):
+    blk = b.cache.get("staged_block")
+    if blk is not None:  # (every array is a view of these two allocations)
+        yield from blk
+        if b.atom_features is not None and b.atom_features.data_ptr() not in range(blk[1].data_ptr(), blk[1].data_ptr() + blk[1].numel()):
+            yield b.atom_features
+        return
     for csr in (b.g, b.lg):
         if csr is None:
             continue

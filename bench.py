@@ -66,6 +66,10 @@ def parse():
     ap.add_argument("--no-micro", action="store_true",
                     help="skip the stand-alone micro-timings of the projection kernels (PMC passes: everything left in the "
                          "profile is then step work)")
+    ap.add_argument("--other-configs", type=int, default=None,
+                    help="1: after the headline run also the force-field (BASELINE configs[3]) and molecule (configs[4]) "
+                         "workloads, 5 replayed steps each in a child process, and put their lines under `other_configs` "
+                         "(default: on for the plain `python bench.py` headline run at N=1, off otherwise)")
     ap.add_argument("--eager-steps", type=int, default=5,
                     help="extra informational run of this many eagerly launched steps on the resident batch (0: skip)")
     return ap.parse_args()
@@ -205,6 +209,103 @@ def cpu_baseline(n_graphs, n_atoms, kind="crystal"):
                   f"E={raw.num_edges} T={raw.num_triplets}), default ALIGNN, torch-CPU oracle (reference model arithmetic on a "
                   "torch-only stand-in for the DGL primitives - not DGL's own CPU kernels), after a warm-up step on 8 graphs",
     }
+
+
+def workload_of(args, B):
+    """(metric, workload) strings that name what THIS invocation trains (BASELINE.json `metric` / `configs`)."""
+    tail = f"batch {B}/GPU, fwd+bwd+allreduce+AdamW"
+    if args.model == "alignn_ff":
+        return (f"graphs/sec (train fwd+bwd through forces), batch={B} ALIGNN-FF {args.atoms}-atom supercells, 4+4 ALIGNN layers",
+                f"BASELINE configs[3]: ALIGNN-FF (alignn_atomwise, LayerNorm) energy + force + stress head, loss differentiated "
+                f"through the forces, {args.atoms}-atom periodic supercells kNN-12/8A, hidden 256, {tail}")
+    if args.model == "alignn_atomwise":
+        return (f"graphs/sec (train fwd+bwd), batch={B} crystals, ALIGNNAtomWise energy head, 4+4 layers",
+                f"ALIGNNAtomWise (LayerNorm flavour) energy path only, {args.atoms}-atom periodic crystals kNN-12/8A, hidden 256, "
+                f"{tail} [informational: not a BASELINE config]")
+    if args.kind == "molecule":
+        return (f"graphs/sec (train fwd+bwd), batch={B} QM9-shaped molecules, 4+4 ALIGNN layers",
+                f"BASELINE configs[4]: QM9-shaped molecular graphs (9-27 atoms, no periodicity, irregular small segments), "
+                f"default ALIGNNConfig 4+4 layers hidden 256, {tail}")
+    cfg = "configs[1]" if B == 64 else ("configs[0] shape on the GPU" if B == 8 else "configs[1] shape at another batch size")
+    return (f"graphs/sec (train fwd+bwd), batch={B} JARVIS-DFT crystals, 4+4 ALIGNN layers",
+            f"BASELINE {cfg}: default ALIGNNConfig 4+4 layers hidden 256, {args.atoms}-atom periodic crystals kNN-12/8A, {tail}")
+
+
+def host_calibration(dev):
+    """What this HOST charges per call (microseconds): the numbers that turn 'eager_launches' / 'streamed_batches' of one
+    box into those of another (the GPU side is the same silicon; hosts of this pool differ by 2-3x)."""
+    import ctypes
+
+    from alignn_amd import _lib
+
+    lib = _lib.load()
+
+    def per_call(fn, n):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        return (time.perf_counter() - t0) / n * 1e6
+
+    out = {"c_call_us": round(per_call(lambda: lib.alignn_col_stats_slabs(1), 20000), 3),
+           "torch_empty_us": round(per_call(lambda: torch.empty(16, device=dev), 5000), 3)}
+
+    class _Id(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.view_as(x)
+
+        @staticmethod
+        def backward(ctx, g):
+            return g
+
+    x = torch.zeros(4, device=dev, requires_grad=True)
+    out["function_apply_us"] = round(per_call(lambda: _Id.apply(x), 5000), 3)
+    buf, slot = torch.zeros(64, 4, device=dev), torch.zeros(1, device=dev)
+    st = _lib.stream()
+    torch.cuda.synchronize()
+    out["kernel_launch_us"] = round(per_call(lambda: lib.alignn_absmax_raise(buf.data_ptr(), 4, 64, 4, slot.data_ptr(), st), 2000), 3)
+    torch.cuda.synchronize()
+    y = torch.zeros(4, device=dev)
+    out["torch_elementwise_us"] = round(per_call(lambda: y.add_(1.0), 2000), 3)
+    torch.cuda.synchronize()
+    e, s2 = torch.cuda.Event(), torch.cuda.Stream(device=dev)
+    cur = torch.cuda.current_stream(dev)
+
+    def pair():
+        e.record(cur)
+        s2.wait_event(e)
+
+    out["event_record_wait_us"] = round(per_call(pair, 2000), 3)
+    torch.cuda.synchronize()
+    out["host_cpus"] = os.cpu_count()
+    del ctypes
+    return out
+
+
+def other_config_lines():
+    """BASELINE configs[3] (force-field training) and configs[4] (molecules) in child processes of this same script: 5
+    replayed steps each, their own roofline object and a bounded CPU baseline (2 of the 16 supercells; 32 of the 256
+    molecules).  Returns {name: parsed JSON line or {"error": ...}}."""
+    import subprocess
+
+    runs = {"cfg3_ff": ["--model", "alignn_ff", "--batch", "16", "--atoms", "200", "--cpu-graphs", "2"],
+            "cfg4_mol": ["--kind", "molecule", "--batch", "256", "--cpu-graphs", "32"]}
+    out = {}
+    for name, extra in runs.items():
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "5", "--warmup", "2", "--streamed-steps", "0",
+               "--eager-steps", "3", "--other-configs", "0"] + extra
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=600,
+                               env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            out[name] = json.loads(line[-1]) if line else {"error": f"rc {r.returncode}", "stderr_tail": r.stderr[-800:]}
+        except Exception as e:  # never lose the headline to a side run
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+        out[name]["wall_s_incl_start_up"] = round(time.perf_counter() - t0, 1)
+        log(f"other config {name}: {out[name].get('ms_per_step')} ms/step, {out[name].get('value')} graphs/s")
+    return out
 
 
 def log(*a):
@@ -348,6 +449,70 @@ def main():
         step()  # capture needs the lazy one-time initialisations (kernel attributes, allocator pools) done eagerly first
     torch.cuda.synchronize()
 
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- the same steps launched EAGERLY (informational; BEFORE any hipGraph exists in the process, as in a real training
+    # loop): what a loop pays when every batch has its own (N, E, T) and nothing can be replayed - the launches of a step
+    # enqueued by two C calls (alignn_amd/cmodel.py), or from Python (ALIGNN_AMD_CMODEL=0)
+    eager_step = step
+    eager = None
+    if args.eager_steps > 0 and os.environ.get("ALIGNN_BENCH_EAGER", "0") != "1":
+        for _ in range(2):
+            eager_step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.eager_steps):
+            eager_step()
+        e_enq = time.perf_counter() - t0
+        fence()
+        edt = (time.perf_counter() - t0) / args.eager_steps
+        if world > 1:
+            t = torch.tensor([edt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            edt = float(t.item())
+        eager = {"ms_per_step": round(edt * 1e3, 3), "graphs_per_s": round(world * B / edt, 1), "steps": args.eager_steps,
+                 "host_enqueue_ms_per_step": round(e_enq / args.eager_steps * 1e3, 3)}
+        log(f"eager launches: {edt * 1e3:.2f} ms/step")
+
+    # ---- streamed batches (informational, N=1): a FRESH batch every step through alignn_amd.loader - one pinned
+    # 2.4 MB buffer per batch over PCIe, CSR + L(g) + cosines rebuilt on a staging stream under the previous step.
+    # `value` above stays the resident-input number the contract asks for; this is the PCIe-inclusive rate.
+    streamed = None
+    if world == 1 and args.streamed_steps > 0 and args.model == "alignn":
+        from alignn_amd import loader
+
+        n_b = args.streamed_steps + 2
+        log(f"packing {n_b} fresh batches on the host for the streamed run")
+        packed = [loader.pack_raw(make_batch(B, n_atoms, seed0=50_000 + 1000 * i, kind=args.kind),
+                                  target=torch.randn(B, generator=torch.Generator().manual_seed(100 + i)).numpy())
+                  for i in range(n_b)]
+        it = iter(loader.PrefetchLoader(packed, dev, depth=2))
+
+        def sstep():
+            b, t = next(it)
+            zero_grad()
+            loss_ = torch.nn.functional.l1_loss(predict(b), t)
+            loss_.backward()
+            reduce_and_update()
+
+        for _ in range(2):
+            sstep()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.streamed_steps):
+            sstep()
+        fence()
+        sdt = (time.perf_counter() - t0) / args.streamed_steps
+        streamed = {"ms_per_step": round(sdt * 1e3, 3), "graphs_per_s": round(B / sdt, 1), "steps": args.streamed_steps,
+                    "host_to_device_bytes_per_batch": packed[0].nbytes,
+                    "what": "fresh 64-crystal batch every step: one pinned buffer H2D, canonical CSR + line graph + "
+                            "bond cosines rebuilt on a staging stream (alignn_amd/loader.py)"}
+        log(f"streamed batches: {sdt * 1e3:.2f} ms/step, {B / sdt:.1f} graphs/s")
+
     # ---- forward + loss + backward of the timed steps as ONE hipGraph (the library never allocates or synchronises and
     # launches only on the current stream; the side-stream weight gradients are joined inside the capture).  Same ~520
     # kernels per step, replayed by the GPU front end instead of enqueued from Python: on a box with a slow or busy
@@ -404,12 +569,6 @@ def main():
             torch.cuda.synchronize()
     log(f"warmup done ({'hipGraph replay' if use_graph else 'eager'} steps); timing")
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -454,26 +613,17 @@ def main():
     gps = world * B * args.steps / dt
     log(f"{ms:.2f} ms/step, {gps:.1f} graphs/s (host enqueue {t_enq / args.steps * 1e3:.2f} ms/step)")
 
-    # ---- the same steps launched EAGERLY (informational): what a training loop pays when every batch has its own
-    # (N, E, T) and nothing can be replayed - ~520 launches per step enqueued from Python
-    eager = None
-    if args.eager_steps > 0 and use_graph:
+    if eager is not None and use_graph and os.environ.get("ALIGNN_BENCH_EAGER_AFTER", "0") == "1":
+        # diagnostic: the same eager steps once a captured graph has run in this process
         for _ in range(2):
             eager_step()
         fence()
         t0 = time.perf_counter()
         for _ in range(args.eager_steps):
             eager_step()
-        e_enq = time.perf_counter() - t0
         fence()
-        edt = (time.perf_counter() - t0) / args.eager_steps
-        if world > 1:
-            t = torch.tensor([edt], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            edt = float(t.item())
-        eager = {"ms_per_step": round(edt * 1e3, 3), "graphs_per_s": round(world * B / edt, 1), "steps": args.eager_steps,
-                 "host_enqueue_ms_per_step": round(e_enq / args.eager_steps * 1e3, 3)}
-        log(f"eager launches: {edt * 1e3:.2f} ms/step")
+        eager["ms_per_step_after_a_graph_replay"] = round((time.perf_counter() - t0) / args.eager_steps * 1e3, 3)
+        log(f"eager launches after the capture: {eager['ms_per_step_after_a_graph_replay']} ms/step")
 
     # ---- the dominant kernel INSIDE a training step: HIP events around every T-row launch of the f16x3 NT kernel during
     # one eagerly launched step (the weight-gradient GEMMs of the previous layer run beside it on the side stream, as
@@ -518,41 +668,6 @@ def main():
             in_step["family"] = {"launches_per_step": n_l, "ms_per_launch": t_all / n_l, "algorithmic_bytes_per_launch": b_all / n_l,
                                  "GBps": b_all / (t_all * 1e-3) / 1e9, "traffic": pmc}
 
-    # ---- streamed batches (informational, N=1): a FRESH batch every step through alignn_amd.loader - one pinned
-    # 2.4 MB buffer per batch over PCIe, CSR + L(g) + cosines rebuilt on a staging stream under the previous step.
-    # `value` above stays the resident-input number the contract asks for; this is the PCIe-inclusive rate.
-    streamed = None
-    if world == 1 and args.streamed_steps > 0 and args.model == "alignn":
-        from alignn_amd import loader
-
-        n_b = args.streamed_steps + 2
-        log(f"packing {n_b} fresh batches on the host for the streamed run")
-        packed = [loader.pack_raw(make_batch(B, n_atoms, seed0=50_000 + 1000 * i, kind=args.kind),
-                                  target=torch.randn(B, generator=torch.Generator().manual_seed(100 + i)).numpy())
-                  for i in range(n_b)]
-        it = iter(loader.PrefetchLoader(packed, dev, depth=2))
-
-        def sstep():
-            b, t = next(it)
-            zero_grad()
-            loss_ = torch.nn.functional.l1_loss(predict(b), t)
-            loss_.backward()
-            reduce_and_update()
-
-        for _ in range(2):
-            sstep()
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(args.streamed_steps):
-            sstep()
-        fence()
-        sdt = (time.perf_counter() - t0) / args.streamed_steps
-        streamed = {"ms_per_step": round(sdt * 1e3, 3), "graphs_per_s": round(B / sdt, 1), "steps": args.streamed_steps,
-                    "host_to_device_bytes_per_batch": packed[0].nbytes,
-                    "what": "fresh 64-crystal batch every step: one pinned buffer H2D, canonical CSR + line graph + "
-                            "bond cosines rebuilt on a staging stream (alignn_amd/loader.py)"}
-        log(f"streamed batches: {sdt * 1e3:.2f} ms/step, {B / sdt:.1f} graphs/s")
-
     out = None
     if rank == 0:
         N, E, T = raw.num_nodes, raw.num_edges, raw.num_triplets
@@ -584,8 +699,9 @@ def main():
         pmc_step = PMC["pmc_bytes_per_step"] if (PMC is not None and T == PMC["triplets"] and args.model == "alignn") else None
         step_bytes = algorithmic_bytes_per_step(N, E, T)
         step_flops = algorithmic_flops_per_step(N, E, T)
+        metric_name, workload_name = workload_of(args, B)
         out = {
-            "metric": "graphs/sec (train fwd+bwd), batch=64 JARVIS-DFT crystals, 4+4 ALIGNN layers",
+            "metric": metric_name,
             "value": round(gps, 2),
             "unit": "graphs/s",
             "n_gpus": world,
@@ -598,9 +714,7 @@ def main():
             "dtype": "f32 (projections: split-product MFMA - 3 fp16-slice or 6 bf16-slice products, fp32 accumulate, fp32-grade error)",
             "data": "synthetic",
             "config": {
-                "workload": f"BASELINE configs[1]: default ALIGNNConfig 4+4 layers hidden 256, batch {B}/GPU, "
-                f"{args.atoms}-atom periodic crystals kNN-12/8A, fwd+bwd+allreduce+AdamW"
-                + ("" if (args.model == "alignn" and args.kind == "crystal") else f" [NON-HEADLINE: {args.model}, {args.kind}]"),
+                "workload": workload_name,
                 "global_batch": world * B,
                 "nodes": N,
                 "edges": E,
@@ -650,17 +764,20 @@ def main():
                 },
             ),
             "step_roofline": {
-                "algorithmic_GB_per_step": round(step_bytes / 1e9, 2),
-                "algorithmic_GFLOP_per_step": round(step_flops / 1e9, 1),
-                "hbm_frac_of_8TBs": round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                # what the schedule really moves (it needs fewer passes than SURVEY's accounting: 5 forward passes per
-                # line-graph convolution, dead last-layer outputs, fused reductions): rocprofv3 FETCH_SIZE x2 + WRITE_SIZE
-                # summed over the launches of one step (profiles/pmc_traffic.json), and the bandwidth THAT corresponds to
+                # ACHIEVED bandwidth first: what the schedule really moves - rocprofv3 FETCH_SIZE x2 + WRITE_SIZE summed over
+                # the launches of one step (profiles/pmc_traffic.json) - divided by the step time
                 "pmc_GB_per_step": None if pmc_step is None else round(pmc_step / 1e9, 2),
                 "pmc_hbm_frac_of_8TBs": None if pmc_step is None else round(pmc_step / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "pmc_source": None if pmc_step is None else PMC["source"],
+                # SURVEY 8(d)'s algorithmic bytes of a maximally fused schedule over the same time: NOT a bandwidth the chip
+                # sustained (the schedule needs fewer passes than that accounting: 5 forward passes per line-graph
+                # convolution, dead last-layer outputs, fused reductions) - a distance to the 10.2 ms ceiling
+                "algorithmic_GB_per_step": round(step_bytes / 1e9, 2),
+                "algorithmic_GFLOP_per_step": round(step_flops / 1e9, 1),
+                "algorithmic_bytes_over_step_time_frac_of_8TBs": round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "mfma_frac_of_157TF": round(step_flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4),
             },
+            "host_calibration": host_calibration(dev),
             "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3),
             "optimizer": opt_desc,
             "multi_gpu": multi,
@@ -678,6 +795,13 @@ def main():
                 out["cpu_baseline"] = None
         else:
             out["cpu_baseline"] = None
+        want_other = args.other_configs
+        if want_other is None:  # the driver's plain command: headline workload on one GPU with its CPU baseline
+            want_other = int(world == 1 and args.model == "alignn" and args.kind == "crystal" and B == 64
+                             and not args.no_cpu_baseline and os.environ.get("ALIGNN_BENCH_OTHER_CONFIGS", "1") != "0")
+        if want_other and world == 1:
+            torch.cuda.empty_cache()
+            out["other_configs"] = other_config_lines()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -649,6 +649,27 @@ int alignn_model_fwd(const alignn_model_desc* desc, const alignn_model_batch* ba
 int alignn_model_bwd(const alignn_model_desc* desc, const alignn_model_batch* batch, void* workspace, size_t workspace_bytes,
                      const float* g_out, alignn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Batch staging in one call (csrc/stage.hip): canonical CSR of g (slots = bonds stably sorted by
+ * destination atom), its by-source view, the canonical line graph L(g) with its by-source view and segment ranks, the
+ * bond vectors in slot order and the bond-angle cosines - from the COO bond list (u -> v, caller's order, int32) a loader
+ * ships.  Replaces dgl.batch + g.to(device) + lg.to(device) of alignn/train.py:264-270 (alignn/lmdb_dataset.py:87-108
+ * builds and ships L(g)'s T-sized COO list and compute_bond_cosines' output, alignn/graphs.py:847-864, per batch).
+ * T = rows of L(g) = sum over bonds e2 of (in-degree of src(e2)) - [e2 is a self image] is a function of the bond list:
+ * the caller computes it (and the largest in-degree, for alignn_egc_bwd_lg_dense) on the host when it packs the batch,
+ * so nothing is read back.  Outputs (all caller-owned): seg_ptr / out_ptr [N+1], src / dst / out_slot [E] (out_slot is
+ * also L(g)'s seg_node), perm / inv [E] int64 (slot k holds caller edge perm[k]), r_canon [E,3]; lg_seg_ptr / lg_out_ptr
+ * [E+1], lg_src / lg_dst / lg_out_slot / lg_seg_rank [T], lg_ident [T] int64 = 0..T-1 (optional), h [T] (optional; needs
+ * r).  workspace: alignn_stage_batch_workspace(N, E) bytes.  ~15 launches, no atomics, bit-identical to alignn_amd.graph's
+ * build_csr + line_graph_of (tests).
+ * ------------------------------------------------------------------------------------------ */
+size_t alignn_stage_batch_workspace(int64_t n_nodes, int64_t n_edges);
+int alignn_stage_batch(const int32_t* u, const int32_t* v, const float* r, int64_t n_nodes, int64_t n_edges, int64_t n_triplets,
+                       int32_t* seg_ptr, int32_t* src, int32_t* dst, int32_t* out_ptr, int32_t* out_slot, int64_t* perm,
+                       int64_t* inv, float* r_canon, int32_t* lg_seg_ptr, int32_t* lg_src, int32_t* lg_dst,
+                       int32_t* lg_out_ptr, int32_t* lg_out_slot, int32_t* lg_seg_rank, int64_t* lg_ident, float* h,
+                       void* workspace, size_t workspace_bytes, alignn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,76 @@
+"""alignn_stage_batch (csrc/stage.hip): one C call builds what alignn_amd.graph.build_csr + line_graph_of + the cosine kernel
+build with ~60 torch operations - every array must be IDENTICAL (the kernels index rows by these arrays), and a training
+step on a staged batch must reproduce the step on the torch-staged one bit for bit."""
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from alignn_amd import ALIGNN, ALIGNNConfig, loader  # noqa: E402
+from alignn_amd.synthetic import make_batch  # noqa: E402
+
+DEV = "cuda"
+FIELDS = "seg_ptr seg_node src dst out_ptr out_slot perm inv grp_seg_ptr grp_src_ptr seg_rank".split()
+
+
+def _both(raw, **kw):
+    p = loader.pack_raw(raw, target=np.arange(raw.batch_size, dtype=np.float32), **kw)
+    a, ta = loader.stage(p, DEV)
+    loader.STAGE_HIP = False
+    try:
+        b, tb = loader.stage(p, DEV)
+    finally:
+        loader.STAGE_HIP = True
+    torch.cuda.synchronize()
+    return p, a, ta, b, tb
+
+
+@pytest.mark.parametrize("n,atoms,kind", [(1, 5, "crystal"), (3, 11, "crystal"), (8, 60, "crystal"), (64, 60, "crystal"),
+                                          (40, (9, 27), "molecule")])
+def test_every_array_equals_the_torch_builders(n, atoms, kind):
+    raw = make_batch(n, atoms, seed0=11 + n, kind=kind)
+    p, a, ta, b, tb = _both(raw)
+    assert p.num_triplets == raw.num_triplets == a.lg.n_edges == b.lg.n_edges
+    assert "staged_block" in a.cache and "staged_block" not in b.cache
+    for name, ga, gb in (("g", a.g, b.g), ("lg", a.lg, b.lg)):
+        assert (ga.n_nodes, ga.n_edges, ga.dense_max_src) == (gb.n_nodes, gb.n_edges, gb.dense_max_src), name
+        for f in FIELDS:
+            x, y = getattr(ga, f), getattr(gb, f)
+            assert (x is None) == (y is None), (name, f)
+            if x is not None:
+                assert x.dtype == y.dtype and torch.equal(x, y), (name, f)
+    for f in ("graph_ptr", "atom_features", "r", "h", "volume"):
+        x, y = getattr(a, f), getattr(b, f)
+        assert x.dtype == y.dtype and x.shape == y.shape, f
+        if f == "volume":
+            assert torch.allclose(x, y, rtol=1e-6)  # (float64 determinant on the host vs on the device)
+        else:
+            assert torch.equal(x, y), f
+    assert torch.equal(ta, tb)
+
+
+def test_a_training_step_on_a_staged_batch_is_bit_identical():
+    raw = make_batch(12, 40, seed0=4)
+    _p, a, ta, b, tb = _both(raw)
+    outs = []
+    for batch, t in ((a, ta), (b, tb)):
+        torch.manual_seed(0)
+        m = ALIGNN(ALIGNNConfig(name="alignn")).to(DEV).train()
+        loss = torch.nn.functional.l1_loss(m(batch), t)
+        loss.backward()
+        torch.cuda.synchronize()
+        outs.append([loss.detach().clone()] + [p.grad.clone() for p in m.parameters() if p.grad is not None])
+    assert len(outs[0]) == len(outs[1]) and all(torch.equal(x, y) for x, y in zip(*outs))
+
+
+def test_prefetch_loader_hands_over_staged_batches():
+    raws = [make_batch(6, 30, seed0=50 + i) for i in range(4)]
+    packed = [loader.pack_raw(r, target=np.zeros(r.batch_size, dtype=np.float32)) for r in raws]
+    seen = 0
+    for (b, t), r in zip(loader.PrefetchLoader(packed, DEV, depth=2), raws):
+        assert b.lg.n_edges == r.num_triplets and b.h.numel() == r.num_triplets and t.numel() == r.batch_size
+        assert float(b.h.abs().max()) <= 1.0
+        seen += 1
+    assert seen == 4
