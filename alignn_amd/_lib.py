@@ -110,6 +110,9 @@ SIGNATURES = {
     "alignn_knn_levels": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i64, _p, _p]),
     "alignn_knn_kth": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i64, _p, _p, _p]),
     "alignn_knn_count": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i64, _p, _p, _p, _p]),
+    "alignn_radius_levels": (_i32, [_p, _p, _p, _p, _p, _f32, _i32, _i32, _p, _p]),
+    "alignn_radius_count": (_i32, [_p, _p, _p, _p, _p, _p, _f32, _i32, _i64, _p, _p, _p]),
+    "alignn_radius_emit": (_i32, [_p, _p, _p, _p, _p, _p, _f32, _i32, _i64, _p, _p, _p, _p, _p, _p, _p]),
     "alignn_stage_batch_workspace": (_sz, [_i64, _i64]),
     "alignn_stage_batch": (_i32, [_p, _p, _p, _i64, _i64, _i64] + [_p] * 16 + [_p, _sz, _p]),
     "alignn_model_init": (_i32, []),

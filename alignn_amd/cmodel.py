@@ -418,6 +418,18 @@ def applicable(model, b) -> bool:
         model.__dict__["_cmodel_static_ok"] = ok
     if not ok:
         return False
+    # hooks on a layer (feature extraction, the activation checks of tests/test_gpu_full_size.py, DDP-style wrappers of a
+    # submodule) fire from the layers' own forward: the per-operator path calls those, one C call for the whole model does not
+    subs = model.__dict__.get("_cmodel_submodules")
+    if subs is None:
+        subs = model.__dict__["_cmodel_submodules"] = [m for m in model.modules() if m is not model]
+    import torch.nn.modules.module as _tm
+
+    if _tm._global_forward_hooks or _tm._global_forward_pre_hooks or _tm._global_backward_hooks:
+        return False
+    for m in subs:
+        if m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks:
+            return False
     slots = model.__dict__.get("_cmodel_slots")
     if slots is None:  # [(module._parameters, name, parameter)]: a replaced Parameter object is noticed without walking the tree
         slots = model.__dict__["_cmodel_slots"] = [(mod._parameters, name, p) for mod in model.modules()
@@ -426,6 +438,7 @@ def applicable(model, b) -> bool:
     for d, name, p in slots:
         if d.get(name) is not p:
             model.__dict__.pop("_cmodel_slots", None)
+            model.__dict__.pop("_cmodel_submodules", None)
             model.__dict__.pop("_cmodel", None)
             return applicable(model, b)
         if need_grad and not p.requires_grad:

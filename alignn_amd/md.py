@@ -115,6 +115,8 @@ class GraphedForceField:
     def __init__(self, model, max_graphs: int = 4, warmup: int = 2, clone: bool = False):
         if model.training:
             raise ValueError("GraphedForceField replays an evaluation with frozen weights: call model.eval() first")
+        if warmup < 1:  # (the first evaluation makes one-time host-to-device copies - weight descriptor tables - that must
+            raise ValueError("GraphedForceField needs warmup >= 1")  # not land inside the capture)
         self.model, self.max_graphs, self.warmup, self.clone = model, max_graphs, warmup, clone
         self.graphs: "collections.OrderedDict[tuple, _Captured]" = collections.OrderedDict()
         self.stats = {"replayed": 0, "captured": 0}
@@ -122,7 +124,9 @@ class GraphedForceField:
     def __call__(self, batch: GraphBatch):
         if batch.device.type != "cuda":
             return self.model(batch)
-        key = signature(batch)
+        # whether forces / stresses are part of the evaluation depends on the grad mode at CAPTURE time (ALIGNNAtomWise
+        # takes them by differentiating the energy): a graph captured under no_grad must not serve a grad-enabled call
+        key = signature(batch) + (torch.is_grad_enabled(),)
         cap = self.graphs.get(key)
         if cap is None:
             cap = _Captured(self.model, batch, self.warmup)  # (its capture evaluated this very batch)

@@ -31,7 +31,8 @@ import torch
 
 from .graph import GraphBatch, _ptr_from_counts, build_csr, line_graph_of
 
-__all__ = ["knn_multigraph", "knn_multigraph_batch", "knn_multigraph_batch_hip", "crystal_batch"]
+__all__ = ["knn_multigraph", "knn_multigraph_batch", "knn_multigraph_batch_hip", "radius_graph", "radius_graph_batch",
+           "radius_graph_batch_hip", "crystal_batch", "clear_lattice_cache"]
 
 PAD_BUDGET = 2 << 30  # bytes of padded distance tensor above which knn_multigraph_batch goes crystal by crystal
 
@@ -173,6 +174,143 @@ def knn_multigraph_batch(lattices: Sequence, fracs: Sequence, cutoff: float = 8.
     return u, v, r, ns
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# radius graphs (alignn/graphs.py:267-364) - what the reference's force-field configs select (neighbor_strategy
+# "radius_graph", alignn/examples/sample_data_ff/config_example_atomwise.json:6,37: cutoff 4.0)
+# ---------------------------------------------------------------------------------------------------------------------
+RADIUS_LEVELS = 24  # cutoff, cutoff + 0.5, ... tried per crystal (the reference loops without a bound)
+
+
+def _radius_box(lat64: torch.Tensor, frac32: torch.Tensor, cutoff: float, bond_tol: float):
+    """Image box [nmin, nmax) per axis as the reference lays it out (graphs.py:296-309): floor / ceil of the fractional
+    extent, widened by maxr = ceil((cutoff + bond_tol) / plane spacing) - evaluated in float64 with a hair of slack: a box
+    larger than needed changes neither the edge set (every image within the cutoff is inside either way) nor the edge
+    order (lexicographic in the image index)."""
+    spacing = 1.0 / torch.linalg.norm(torch.linalg.inv(lat64), dim=0)
+    maxr = torch.ceil((cutoff + bond_tol) / spacing + 1e-9)
+    nmin = torch.floor(frac32.min(dim=0).values.double()) - maxr
+    nmax = torch.ceil(frac32.max(dim=0).values.double()) + maxr
+    return nmin.to(torch.int64), nmax.to(torch.int64)
+
+
+def _radius_pass(lat32, cart32, nmin, nmax, cutoff: float, atol: float):
+    """One ``temp_graph`` of the reference (graphs.py:278-346) in float32, every operation spelled out (separate multiplies
+    and adds in a fixed order - the HIP kernel csrc/radius.hip evaluates the same sequence)."""
+    dev = lat32.device
+    rng = [torch.arange(int(a), int(b), device=dev) for a, b in zip(nmin.tolist(), nmax.tolist())]
+    images = torch.stack(torch.meshgrid(*rng, indexing="ij"), -1).reshape(-1, 3)  # cartesian_prod order: i0 major
+    imf = images.to(torch.float32)
+    shift = (imf[:, 0:1] * lat32[0] + imf[:, 1:2] * lat32[1]) + imf[:, 2:3] * lat32[2]  # [I,3]
+    x_dst = shift[:, None, :] + cart32[None, :, :]  # [I,n,3]; flat index = image * n + atom (graphs.py:314-318)
+    d = cart32[:, None, None, :] - x_dst[None]  # [n,I,n,3]
+    dx, dy, dz = d[..., 0], d[..., 1], d[..., 2]
+    dist = torch.sqrt((dx * dx + dy * dy) + dz * dz)
+    keep = (dist <= cutoff) & ~(dist <= atol)  # isclose(dist, 0, atol) with rtol * 0 = 0
+    u, img, v = torch.nonzero(keep, as_tuple=True)  # torch.where order: by source, then image, then destination atom
+    r = x_dst[img, v] - cart32[u]
+    return u, v, r, images[img]
+
+
+def radius_graph(lat, frac, cutoff: float = 5.0, bond_tol: float = 0.5, atol: float = 1e-5, cutoff_extra: float = 0.5,
+                 device=None, return_cutoff: bool = False):
+    """The reference's ``radius_graph`` (alignn/graphs.py:267-364) as tensor operations on any device: all pairs (site,
+    periodic image of a site) with ``atol < distance <= cutoff`` in ``torch.where`` order (by source atom, then image, then
+    destination atom - the two directions of a bond are NOT adjacent), the cutoff widened by ``cutoff_extra`` until the
+    last site appears in the graph (``dgl.graph((u, v)).num_nodes() == n``: the reference's stopping rule).
+    ``lat`` [3,3] (rows a, b, c), ``frac`` [n,3] -> ``(u, v, r, images)``: int64 [E] x 2, float32 [E,3], int64 [E,3].
+    float32 distances, as in the reference (``torch.get_default_dtype()``); this is the CPU twin and the checker of
+    ``radius_graph_batch_hip`` (bit-identical arrays)."""
+    frac = torch.as_tensor(frac)
+    dev = torch.device(device) if device is not None else frac.device
+    lat64 = torch.as_tensor(lat).to(dev, torch.float64)
+    frac64 = frac.to(dev, torch.float64)
+    n = frac64.shape[0]
+    cart64 = frac64[:, 0:1] * lat64[0] + frac64[:, 1:2] * lat64[1] + frac64[:, 2:3] * lat64[2]  # (jarvis: float64 product)
+    lat32, cart32, frac32 = lat64.float(), cart64.float(), frac64.float()
+    c = float(cutoff)
+    for _ in range(RADIUS_LEVELS):
+        nmin, nmax = _radius_box(lat64, frac32, c, bond_tol)
+        u, v, r, images = _radius_pass(lat32, cart32, nmin, nmax, c, atol)
+        if u.numel() and int(torch.maximum(u.max(), v.max())) + 1 == n:
+            return (u, v, r, images, c) if return_cutoff else (u, v, r, images)
+        c += cutoff_extra
+    raise RuntimeError(f"radius_graph: the last site has no neighbour within {c} A")
+
+
+def radius_graph_batch(lattices: Sequence, fracs: Sequence, cutoff: float = 5.0, device=None, return_images: bool = False):
+    """Crystal by crystal through ``radius_graph`` with atom ids offset per crystal -> ``(u, v, r, num_atoms)`` like
+    ``knn_multigraph_batch`` (any device: the CPU path of ``crystal_batch(neighbor_strategy="radius_graph")``)."""
+    us, vs, rs, ims, ns, off = [], [], [], [], [], 0
+    for lat, frac in zip(lattices, fracs):
+        u, v, r, im = radius_graph(lat, frac, cutoff, device=device)
+        us.append(u + off), vs.append(v + off), rs.append(r), ims.append(im)
+        ns.append(int(torch.as_tensor(frac).shape[0]))
+        off += ns[-1]
+    out = (torch.cat(us), torch.cat(vs), torch.cat(rs), ns)
+    return out + ((torch.cat(ims).to(torch.int32),) if return_images else ())
+
+
+def radius_graph_batch_hip(lattices: Sequence, fracs: Sequence, cutoff: float = 5.0, bond_tol: float = 0.5, atol: float = 1e-5,
+                           cutoff_extra: float = 0.5, device=None, return_images: bool = False, return_volume: bool = False):
+    """``radius_graph_batch`` on the kernels of csrc/radius.hip (one wavefront per site): the same bonds in the same order
+    with the same float32 bond vectors (bit-identical to the torch twin and to the reference's edge lists, tests), every
+    crystal on its own cutoff level, ONE host read per batch (total bond count + "did every crystal close its graph").
+    CUDA(HIP) device only."""
+    from . import _lib
+    from ._lib import check, ptr, stream
+
+    lib = _lib.load()
+    dev = torch.device(device) if device is not None else torch.as_tensor(fracs[0]).device
+    if dev.type != "cuda":
+        raise TypeError("radius_graph_batch_hip runs on the GPU; use radius_graph_batch elsewhere")
+    B = len(fracs)
+    ns = [int(torch.as_tensor(f).shape[0]) for f in fracs]
+    N, L = sum(ns), RADIUS_LEVELS
+    with _lib.device_guard(torch.empty(0, device=dev)):
+        lat64 = torch.stack([torch.as_tensor(x).to(dev, torch.float64) for x in lattices]).contiguous()  # [B,3,3]
+        frac64 = torch.cat([torch.as_tensor(f).to(dev, torch.float64) for f in fracs]).contiguous()  # [N,3]
+        n_t = torch.tensor(ns, device=dev, dtype=torch.int64)
+        gptr = _ptr_from_counts(n_t).to(torch.int32)
+        site_graph = torch.repeat_interleave(torch.arange(B, device=dev, dtype=torch.int32), n_t, output_size=N)
+        sg = site_graph.long()
+        lg = lat64[sg]  # [N,3,3]
+        cart32 = (frac64[:, 0:1] * lg[:, 0, :] + frac64[:, 1:2] * lg[:, 1, :] + frac64[:, 2:3] * lg[:, 2, :]).float().contiguous()
+        frac32 = frac64.float()
+        idx = sg[:, None].expand(-1, 3)
+        fmin = torch.full((B, 3), float("inf"), device=dev).scatter_reduce(0, idx, frac32, "amin")
+        fmax = torch.full((B, 3), float("-inf"), device=dev).scatter_reduce(0, idx, frac32, "amax")
+        spacing = 1.0 / torch.linalg.norm(torch.linalg.inv(lat64), dim=1)  # [B,3] plane spacings
+        cuts = float(cutoff) + float(cutoff_extra) * torch.arange(L, device=dev, dtype=torch.float64)  # [L]
+        maxr = torch.ceil((cuts[None, :, None] + bond_tol) / spacing[:, None, :] + 1e-9)  # [B,L,3] (see _radius_box)
+        nmin = torch.floor(fmin.double())[:, None, :] - maxr
+        nmax = torch.ceil(fmax.double())[:, None, :] + maxr
+        box = torch.cat([nmin, nmax], 2).to(torch.int32).contiguous()  # [B,L,6]
+        cut32 = cuts.float().contiguous()
+        lat32 = lat64.float().contiguous()
+        level = torch.empty(B, dtype=torch.int32, device=dev)
+        count = torch.empty(N, dtype=torch.int64, device=dev)
+        st = stream()
+        check(lib.alignn_radius_levels(ptr(lat32), ptr(cart32), ptr(gptr), ptr(box), ptr(cut32), float(atol), L, B, ptr(level), st),
+              "radius_levels")
+        check(lib.alignn_radius_count(ptr(lat32), ptr(cart32), ptr(gptr), ptr(site_graph), ptr(box), ptr(cut32), float(atol), L, N,
+                                      ptr(level), ptr(count), st), "radius_count")
+        csum = torch.cumsum(count, 0)
+        offset = (csum - count).contiguous()
+        tail = torch.stack([csum[-1], level.max().to(torch.int64)]).tolist() if N else [0, 0]  # the one host read
+        if tail[1] >= L:
+            raise RuntimeError(f"radius_graph: a crystal's last site has no neighbour within {cutoff + cutoff_extra * (L - 1)} A")
+        E = int(tail[0])
+        u = torch.empty(E, dtype=torch.int64, device=dev)
+        v = torch.empty(E, dtype=torch.int64, device=dev)
+        r = torch.empty(E, 3, dtype=torch.float32, device=dev)
+        img = torch.empty(E, 3, dtype=torch.int32, device=dev) if return_images else None
+        if E:
+            check(lib.alignn_radius_emit(ptr(lat32), ptr(cart32), ptr(gptr), ptr(site_graph), ptr(box), ptr(cut32), float(atol), L, N,
+                                         ptr(level), ptr(offset), ptr(u), ptr(v), ptr(r), ptr(img), st), "radius_emit")
+        volume = torch.linalg.det(lat64).abs().float() if return_volume else None
+    return (u, v, r, ns) + ((img,) if return_images else ()) + ((volume,) if return_volume else ())
+
+
 KNN_LEVELS = 5  # cutoffs tried per crystal: the given one, then longest lattice vector / doubling (graphs.py:170-188)
 
 
@@ -180,14 +318,24 @@ KNN_LEVELS = 5  # cutoffs tried per crystal: the given one, then longest lattice
 # and image-box reaches: ~20 small torch operations incl. a batched 3 x 3 inverse).  MD at constant cell (alignn/ff/
 # calculators.py rebuilds the graph of the same atoms every step) passes the same lattice tensors again and again: the last
 # result is kept, keyed on the tensors' identity and version counters.
+# The key covers identity, version counter, storage address, device and dtype of every lattice tensor: an edit through a
+# versioned in-place operation (``lat.mul_``, ``lat[0, 0] = ...``) is seen; one that bypasses the version counter
+# (``lat.data.copy_``, memory shared with a numpy array that is written to) is NOT - a changing-cell (NPT) run must pass
+# fresh tensors, edit through versioned operations, or call ``clear_lattice_cache()`` after such an edit.  Not
+# thread-safe (one MD loop per process is the use).
 _LATTICE_TABLES = {"key": None, "refs": None, "val": None}
+
+
+def clear_lattice_cache():
+    """Forget the lattice-derived tables kept between calls of ``knn_multigraph_batch_hip`` / ``crystal_batch``."""
+    _LATTICE_TABLES.update(key=None, refs=None, val=None)
 
 
 def _lattice_tables(lattices, ns, dev, cutoff):
     tens = [x for x in lattices if isinstance(x, torch.Tensor)]
     key = None
     if len(tens) == len(lattices):
-        key = (tuple((id(x), x._version, x.device, x.dtype) for x in tens), tuple(ns), str(dev), cutoff)
+        key = (tuple((id(x), x._version, x.data_ptr(), x.device, x.dtype) for x in tens), tuple(ns), str(dev), cutoff)
         c = _LATTICE_TABLES
         if c["key"] == key and all(r() is x for r, x in zip(c["refs"], tens)):
             return c["val"]
@@ -205,8 +353,8 @@ def _lattice_tables(lattices, ns, dev, cutoff):
         cuts.append(torch.where(c < longest, longest, 2.0 * c))
     cut = torch.stack(cuts, 1).contiguous()  # [B,L]
     reach = torch.ceil(cut[:, :, None] / spacing[:, None, :]).to(torch.int32).contiguous()  # [B,L,3]
-    val = (lat, gptr, site_graph, lg, cut, reach)
-    _LATTICE_TABLES["volume"] = torch.linalg.det(lat).abs().float()  # (crystal_batch's GraphBatch.volume, same lifetime)
+    # (the cell volumes - crystal_batch's GraphBatch.volume - travel WITH the tables: same key, same lifetime)
+    val = (lat, gptr, site_graph, lg, cut, reach, torch.linalg.det(lat).abs().float())
     if key is not None:
         import weakref
 
@@ -215,7 +363,7 @@ def _lattice_tables(lattices, ns, dev, cutoff):
 
 
 def knn_multigraph_batch_hip(lattices: Sequence, fracs: Sequence, cutoff: float = 8.0, max_neighbors: int = 12, device=None,
-                             return_images: bool = False):
+                             return_images: bool = False, return_volume: bool = False):
     """``knn_multigraph_batch`` on the hand-written kernels of csrc/knn.hip (one wavefront per site): the same bond
     list in the same order - bit-identical index arrays, bond vectors equal to rounding - with no padded [B,n,n,I]
     tensors and ONE host read per batch (the total bond count, to size the output).  CUDA(HIP) device only."""
@@ -231,7 +379,7 @@ def knn_multigraph_batch_hip(lattices: Sequence, fracs: Sequence, cutoff: float 
     N = sum(ns)
     with _lib.device_guard(torch.empty(0, device=dev)):
         frac = torch.cat([torch.as_tensor(f).to(dev, torch.float64) for f in fracs]).contiguous()  # [N,3]
-        lat, gptr, site_graph, lg, cut, reach = _lattice_tables(lattices, ns, dev, float(cutoff))
+        lat, gptr, site_graph, lg, cut, reach, volume = _lattice_tables(lattices, ns, dev, float(cutoff))
         # the fixed-order float64 product of knn_multigraph / synthetic._all_neighbors (separate multiplies and adds)
         cart = (frac[:, 0:1] * lg[:, 0, :] + frac[:, 1:2] * lg[:, 1, :] + frac[:, 2:3] * lg[:, 2, :]).contiguous()
         level = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -259,18 +407,29 @@ def knn_multigraph_batch_hip(lattices: Sequence, fracs: Sequence, cutoff: float 
         if E:
             check(lib.alignn_knn_emit(ptr(lat), ptr(cart), ptr(gptr), ptr(site_graph), ptr(cut), ptr(reach), L, N, ptr(level),
                                       ptr(kth), ptr(offset), ptr(u), ptr(v), ptr(r), ptr(img), st), "knn_emit")
-    if return_images:
-        return u, v, r, ns, img
-    return u, v, r, ns
+    out = (u, v, r, ns) + ((img,) if return_images else ()) + ((volume,) if return_volume else ())
+    return out
 
 
 def crystal_batch(lattices: Sequence, fracs: Sequence, atom_features: Optional[Sequence] = None, device=None,
-                  cutoff: float = 8.0, max_neighbors: int = 12, line_graph: bool = True) -> GraphBatch:
+                  cutoff: float = 8.0, max_neighbors: int = 12, line_graph: bool = True,
+                  neighbor_strategy: str = "k-nearest") -> GraphBatch:
     """Positions -> canonical (g, L(g)) batch, all on the device: one crystal per (lattice, frac) pair; the bond cosines
-    are left to the model (``lg_on_fly``) or to ``ops.bond_cosines(batch.r, batch.lg)``."""
+    are left to the model (``lg_on_fly``) or to ``ops.bond_cosines(batch.r, batch.lg)``.  ``neighbor_strategy``: the
+    reference's ``Graph.atom_dgl_multigraph`` switch (alignn/graphs.py:486-505) - "k-nearest" (kNN-``max_neighbors`` within
+    ``cutoff``, canonised to an undirected multigraph) or "radius_graph" (every pair within ``cutoff``; what the force-field
+    configs use)."""
     dev = torch.device(device) if device is not None else torch.as_tensor(fracs[0]).device
-    if dev.type == "cuda":  # one wave per site (csrc/knn.hip); the torch builder below is its CPU twin and its checker
-        u, v, r, nn = knn_multigraph_batch_hip(lattices, fracs, cutoff, max_neighbors, device=dev)
+    if neighbor_strategy == "radius_graph":
+        volume = None
+        if dev.type == "cuda":
+            u, v, r, nn, volume = radius_graph_batch_hip(lattices, fracs, cutoff, device=dev, return_volume=True)
+        else:
+            u, v, r, nn = radius_graph_batch(lattices, fracs, cutoff, device=dev)
+    elif neighbor_strategy != "k-nearest":
+        raise ValueError(f"neighbor_strategy {neighbor_strategy!r}: 'k-nearest' or 'radius_graph'")
+    elif dev.type == "cuda":  # one wave per site (csrc/knn.hip); the torch builder below is its CPU twin and its checker
+        u, v, r, nn, volume = knn_multigraph_batch_hip(lattices, fracs, cutoff, max_neighbors, device=dev, return_volume=True)
     else:
         u, v, r, nn = knn_multigraph_batch(lattices, fracs, cutoff, max_neighbors, device=dev)
     off = sum(nn)
@@ -281,8 +440,8 @@ def crystal_batch(lattices: Sequence, fracs: Sequence, atom_features: Optional[S
     batch.r = r[g.perm].contiguous()
     if atom_features is not None:
         batch.atom_features = torch.cat([torch.as_tensor(a) for a in atom_features]).to(dev, torch.float32).contiguous()
-    if dev.type == "cuda":  # (derived with the other lattice tables a moment ago, or kept from the last call with these tensors)
-        batch.volume = _LATTICE_TABLES["volume"]
+    if dev.type == "cuda" and volume is not None:  # (derived with - and cached under the same key as - the lattice tables)
+        batch.volume = volume
     else:
         lat_t = torch.stack([torch.as_tensor(x).to(dev, torch.float64) for x in lattices])
         batch.volume = torch.linalg.det(lat_t).abs().float()

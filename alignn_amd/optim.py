@@ -267,12 +267,17 @@ class FlatAdamW(torch.optim.Optimizer):
         }
 
     def load_state_dict(self, state):
+        if "state" in state and "inner" not in state:
+            raise ValueError("this is a plain torch optimizer state dict ({'state', 'param_groups'}); FlatAdamW keeps its "
+                             "moments per FLAT buffer: load a FlatAdamW.state_dict(), or load into torch.optim.AdamW")
+        if "inner" not in state or "live_idx" not in state:
+            raise ValueError("not a FlatAdamW state dict (needs 'param_groups', 'live_idx', 'inner')")
         if len(state["param_groups"]) != len(self.param_groups):
             raise ValueError("loaded state dict has a different number of parameter groups")
         for g, sg in zip(self.param_groups, state["param_groups"]):
-            g.update(sg)
+            g.update({k: v for k, v in sg.items() if k != "params"})  # (never the saved index lists: 'params' stay the tensors)
         if state.get("inner") is None:
             return
-        if [len(ix) for ix in state["live_idx"]] != [len(ix) for ix in self._live_idx] or self._inner is None:
-            self._build(state["live_idx"])
+        if [list(ix) for ix in state["live_idx"]] != [list(ix) for ix in self._live_idx] or self._inner is None:
+            self._build(state["live_idx"])  # (compared by CONTENT: an equal-length but different live set is another layout)
         self._inner.load_state_dict(state["inner"])

@@ -670,6 +670,29 @@ int alignn_stage_batch(const int32_t* u, const int32_t* v, const float* r, int64
                        int32_t* lg_out_ptr, int32_t* lg_out_slot, int32_t* lg_seg_rank, int64_t* lg_ident, float* h,
                        void* workspace, size_t workspace_bytes, alignn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Radius bond graphs on the device (csrc/radius.hip): alignn/graphs.py:267-364 (radius_graph),
+ * the neighbour strategy of the reference's force-field configs, re-run by alignn/ff/calculators.py:280-291 at every MD
+ * step.  One wavefront per site, float32 distances in the reference's dtype evaluated as one fixed operation sequence,
+ * bonds emitted in torch.where order (source, then periodic image, then destination) - the reference's edge ORDER, no
+ * sort, no atomics, no host synchronisation.  Inputs: lat[B][9] float32 (rows a, b, c), cart[N][3] float32, graph_ptr
+ * [B+1], site_graph[N], box[B][levels][6] = nmin[3], nmax[3] of the image box per cutoff level (graphs.py:296-309),
+ * cut[levels] = cutoff, cutoff + 0.5, ... (:349-358), atol (isclose-zero exclusion, 1e-5).
+ *   radius_levels: crystal_level[B] = first level at which the crystal's last site has a neighbour (== levels: none)
+ *   radius_count:  count[N] = bonds leaving each site at its crystal's level
+ *   radius_emit:   offset[N] = exclusive prefix sum of count; u, v int64, r[.][3] float32 = x_dst - x_src, image[.][3]
+ *                  int32 (optional)
+ * ------------------------------------------------------------------------------------------ */
+int alignn_radius_levels(const float* lat, const float* cart, const int32_t* graph_ptr, const int32_t* box, const float* cut,
+                         float atol, int levels, int n_crystals, int32_t* crystal_level, alignn_stream_t stream);
+int alignn_radius_count(const float* lat, const float* cart, const int32_t* graph_ptr, const int32_t* site_graph,
+                        const int32_t* box, const float* cut, float atol, int levels, int64_t n_sites,
+                        const int32_t* crystal_level, int64_t* count, alignn_stream_t stream);
+int alignn_radius_emit(const float* lat, const float* cart, const int32_t* graph_ptr, const int32_t* site_graph,
+                       const int32_t* box, const float* cut, float atol, int levels, int64_t n_sites,
+                       const int32_t* crystal_level, const int64_t* offset, int64_t* u, int64_t* v, float* r, int32_t* image,
+                       alignn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

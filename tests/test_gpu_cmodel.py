@@ -176,6 +176,16 @@ def test_cases_the_c_side_does_not_take_fall_back_to_the_operators():
         m(batch)
     assert cmodel.STATS["fwd"] == 0
     m = _mk(1)
+    seen = []
+    h = m.alignn_layers[0].edge_update.register_forward_hook(lambda _m, _i, out: seen.append(out[0].shape))
+    torch.nn.functional.l1_loss(m(batch), target).backward()  # a hook on a layer: its forward has to run
+    assert cmodel.STATS["fwd"] == 0 and len(seen) == 1
+    h.remove()
+    torch.nn.functional.l1_loss(m(batch), target).backward()
+    assert cmodel.STATS["fwd"] == 1
+    for k in cmodel.STATS:
+        cmodel.STATS[k] = 0
+    m = _mk(1)
     torch.nn.functional.l1_loss(m(batch), target).backward()
     assert cmodel.STATS["fwd"] == 1 and cmodel.STATS["bwd"] == 1
 

@@ -252,9 +252,21 @@ def test_float64_model_on_the_gpu_reproduces_the_float64_reference():
     loss.backward()
     assert float((pred.detach().cpu() - torch.from_numpy(z["pred64"])).abs().max()) < 1e-10
     assert abs(loss.item() - float(z["loss64"])) < 1e-12
-    g = O.full_size_sample(dict(model.named_parameters())["alignn_layers.0.edge_update.edge_gate.weight"].grad, 512)
-    ref = z["grad64.alignn_layers.0.edge_update.edge_gate.weight"]
-    assert np.abs(g[:-4] - ref[:-4]).max() < 1e-9 * np.abs(ref[:-4]).max()
+    # EVERY parameter gradient the reference's float64 backward stored (512 strided samples + 4 moments each), not one:
+    # 1e-9 of the gradient's own scale, with a floor of 1e-12 of the model's largest gradient for the analytically-zero ones
+    # (Linear biases in front of a norm hold rounding noise on both sides)
+    named = dict(model.named_parameters())
+    keys = [k for k in z if k.startswith("grad64.")]
+    assert len(keys) > 100
+    gmax = max(float(np.abs(z[k][:-4]).max()) for k in keys)
+    worst = 0.0
+    for k in keys:
+        g = O.full_size_sample(named[k[len("grad64."):]].grad, 512)
+        ref = z[k]
+        err = np.abs(g[:-4] - ref[:-4]).max() / max(np.abs(ref[:-4]).max(), 1e-3 * gmax)
+        worst = max(worst, err)
+        assert err < 1e-9, (k, err)
+    print(f"float64 torch path vs the reference's float64 backward: {len(keys)} gradients, worst {worst:.2e}")
 
 
 # ---------------------------------------------------------------------------------------------
@@ -434,6 +446,34 @@ def test_welford_column_statistics_are_well_conditioned(rows, F, offset):
     assert float(((stat[1].double().cpu() - rstd64) / rstd64).abs().max()) < 1e-4
     unb = X64.var(0, unbiased=True) if rows > 1 else var64
     assert float(((rv.double().cpu() - (0.9 + 0.1 * unb)) / (0.9 + 0.1 * unb)).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("ratio", [0.0, 3.0, 30.0])
+def test_projection_epilogue_statistics_at_the_conditioning_the_model_sees(ratio):
+    """The STATS epilogue of the split-product projections (alignn_gemm_nt_f16x3_stats: BatchNorm statistics of the product
+    without another pass over it) keeps plain sum / sum-of-squares slabs (float32 inside a 64-row strip, float64 across
+    strips) - unlike the pivot slabs of the statistics pass and the gate passes above.  What that costs, measured against
+    float64 statistics of the kernel's OWN float32 output: |mean| / std = 0 .. 30 covers every norm input of the model
+    (the projections' outputs are centred by construction: |mean| / std < 3 at the benchmark, profiles/r03_parity_full_size
+    .txt); a pre-activation with |mean| >> std in front of such a layer is the one place where the pivot pass
+    (ops.STATS_FUSED = False) is the better choice, and the bound asserted here says by how much."""
+    rows, K, N = 50712, 64, 256
+    g = torch.Generator().manual_seed(int(ratio) + 5)
+    a = torch.randn(rows, K, generator=g).to(DEV)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV)  # unit-variance outputs
+    b = (ratio * (1.0 + 0.1 * torch.rand(N, generator=g))).to(DEV)
+    out, partial, slabs = ops.gemm_nt_f16x3_stats(a, ops.absmax(a), ops.split_f16x2(w), b)
+    gamma, beta = torch.ones(N, device=DEV), torch.zeros(N, device=DEV)
+    stat = ops._bn_finalize(partial, slabs, rows, gamma, beta, None, None, False)
+    torch.cuda.synchronize()
+    o64 = out.double()
+    mean64, var64 = o64.mean(0), o64.var(0, unbiased=False)
+    rstd64 = 1.0 / torch.sqrt(var64 + 1e-5)
+    e_mean = float((stat[0].double() - mean64).abs().max() / (mean64.abs().max() + 1.0))
+    e_rstd = float(((stat[1].double() - rstd64) / rstd64).abs().max())
+    print(f"|mean|/std = {ratio}: mean {e_mean:.2e}, rstd {e_rstd:.2e} (relative)")
+    assert e_mean < 1e-6
+    assert e_rstd < {0.0: 1e-5, 3.0: 3e-5, 30.0: 1e-3}[ratio]
 
 
 def test_conv_with_nearly_constant_node_features_matches_float64():

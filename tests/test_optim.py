@@ -193,3 +193,25 @@ def test_flat_adamw_puts_rehomed_parameters_back():
         assert torch.equal(p, q), n
     lo = o2.flat.data_ptr()
     assert lo <= m2.lin.weight.data_ptr() < lo + o2.flat.numel() * 4
+
+
+def test_flat_adamw_refuses_a_plain_torch_state_dict_and_compares_layouts_by_content():
+    """a standard torch AdamW state dict must not silently replace the parameter lists with index lists; a saved
+    layout with the same NUMBER of live parameters but other members is another layout."""
+    import copy
+
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(4, 8), torch.nn.Linear(8, 2))
+    ref = torch.optim.AdamW(net.parameters(), lr=1e-3)
+    net(torch.randn(3, 4)).sum().backward()
+    ref.step()
+    opt = FlatAdamW(net, lr=1e-3)
+    opt.step()
+    with pytest.raises(ValueError):
+        opt.load_state_dict(ref.state_dict())
+    assert all(isinstance(p, torch.nn.Parameter) for g in opt.param_groups for p in g["params"])
+    sd = copy.deepcopy(opt.state_dict())
+    with pytest.raises(ValueError):
+        opt.load_state_dict({"param_groups": sd["param_groups"]})
+    opt.load_state_dict(sd)  # round trip still works
+    assert all(isinstance(p, torch.nn.Parameter) for g in opt.param_groups for p in g["params"])
