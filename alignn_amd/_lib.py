@@ -100,13 +100,6 @@ SIGNATURES = {
     "alignn_egc_conv_wgrad": (_i32, [_p, _p]),
     "alignn_egc_args_sizeof": (_sz, [_i32]),
     "alignn_fork_events_init": (_i32, []),
-    "alignn_rbf_mlp_supported": (_i32, [_i32, _i32]),
-    "alignn_rbf_mlp_slabs": (_i32, [_i64]),
-    "alignn_rbf_mlp_stats": (_i32, [_p, _p, _f32, _p, _p, _i64, _i32, _i32, _p, _p]),
-    "alignn_rbf_mlp_fwd": (_i32, [_p, _p, _f32, _p, _p, _i64, _i32, _i32, _p, _p, _p, _p]),
-    "alignn_rbf_mlp_bwd_reduce": (_i32, [_p, _p, _f32, _p, _p, _i64, _i32, _i32, _p, _p, _p, _p]),
-    "alignn_rbf_mlp_bwd_apply": (_i32, [_p, _p, _f32, _p, _p, _i64, _i32, _i32, _p, _p, _p, _i32, _p, _p, _p, _p]),
-    "alignn_rbf_mlp_wgrad": (_i32, [_p, _p, _f32, _p, _i64, _i32, _i32, _p, _p]),
     "alignn_knn_levels": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i64, _p, _p]),
     "alignn_knn_kth": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i64, _p, _p, _p]),
     "alignn_knn_count": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i64, _p, _p, _p, _p]),

@@ -291,25 +291,6 @@ class EdgeGatedGraphConv(nn.Module):
         return x, y
 
 
-def _embed(seq: nn.Sequential, d: torch.Tensor) -> torch.Tensor:
-    """``nn.Sequential(RBFExpansion, MLPLayer, MLPLayer)(d)`` (alignn/models/alignn.py:201-222) with the RBF expansion and
-    the first layer fused (``ops.RbfMLPLayerFn``: the [rows, bins] matrix and the first pre-activation never reach memory)
-    where that applies; otherwise module by module."""
-    rbf, first = seq[0], seq[1]
-    if (isinstance(rbf, RBFExpansion) and isinstance(first, MLPLayer) and not torch_path.wanted(d, first.layer[0].weight)
-            and ops.rbf_mlp_applies(d, first.layer[0].weight, first._norm)
-            and (first.training or not torch.is_grad_enabled())):
-        lin, bn = first.layer[0], first.layer[1]
-        _bump(bn, first.training)
-        with _lib.device_guard(d):
-            x = ops.rbf_mlp_layer(d, rbf.centers, rbf.gamma, lin.weight, lin.bias, bn.weight, bn.bias, bn.running_mean,
-                                  bn.running_var, first.training)
-        for m in list(seq)[2:]:
-            x = m(x)
-        return x
-    return seq(d)
-
-
 def _prepare_split_weights(model: nn.Module):
     """max|W| + slice images of every weight a split-product projection of this forward / backward may use (the fused node
     projection and the edge gate of every convolution, the wide MLP layers) in one batched call - ``ops.WeightPrep``."""
@@ -442,9 +423,9 @@ class ALIGNN(nn.Module):
         if len(self.alignn_layers) > 0:
             if b.lg is None or b.h is None:
                 raise ValueError("alignn_layers > 0 needs the line graph with edata['h']")
-            z = _embed(self.angle_embedding, b.h)
+            z = self.angle_embedding(b.h)
         x = self.atom_embedding(b.atom_features)
-        y = _embed(self.edge_embedding, ops.bond_length(b.r))
+        y = self.edge_embedding(ops.bond_length(b.r))
         # the triplet features of the last ALIGNN layer and the bond features of the last GCN layer are
         # never read again (alignn.py:317-325): do not materialise them
         n_a, n_g = len(self.alignn_layers), len(self.gcn_layers)

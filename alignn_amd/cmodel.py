@@ -89,7 +89,7 @@ def _flags_default() -> bool:
     o = ops
     return (o.F16X3 and o.GATHER_FUSED and o.STATS_FUSED and o.BNRED_FUSED and o.SPLIT_BOTH and o.BATCHED_WEIGHT_PREP
             and o.NN_SPLIT and o.APPLY_SUM and o.FUSED_LG_BACKWARD and o.DENSE_LG_BACKWARD and o.COMPOSITE
-            and not o.RBF_MLP_FUSED and o.KERNEL_TIMER is None and o.FOLD_ABOVE == 1024 and o._PARAM_GRADS["on"])
+            and o.KERNEL_TIMER is None and o.FOLD_ABOVE == 1024 and o._PARAM_GRADS["on"])
 
 
 class disabled:

@@ -1107,282 +1107,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2))) void ge
     gemm_nt_f16p_body<false, 4>(g);
 }
 
-// ---------------------------------------------------------------------------------------------
-// PIPELINED persistent form of the gather (+ statistics) projection, K = 256 (16 k-steps), N = 256.
-//
-// The fused epilogues above are bound by the latency of their operand loads (31 k cycles for the gathers against 34 k for
-// the whole k-loop), and with 250 registers per wave only two workgroups fit a CU, so nothing but the other workgroup's
-// k-loop hides an epilogue.  Here ONE workgroup per CU (one wave per SIMD, up to 512 registers) keeps TWO accumulator sets:
-// while the 16 k-steps of tile j run, the 16 half rounds of tile j-1's epilogue are issued one per k-step out of the
-// other set - its gathers are requested two k-steps before they are used, its stores drain under the next MFMAs.
-// Straight-line code (the k-loop is unrolled, no branch around a memory operation): the counted vmcnt waits on the DMA
-// ring below include the epilogue's loads and stores of the steps in between (W()); where an exact count is not known it
-// is a LOWER bound (waiting for more than necessary is safe, for less is not).  Every k-step issues a ring stage - past the
-// last tile a dummy one - so that the counts are the same for every tile.  Same arithmetic in the same order as
-// gemm_nt_f16p_body<false, 2 | 4>: bit-identical results (tests flip ALIGNN_AMD_X6PP).
-// STATUS (round 3): correct and bit-identical, and NOT faster - 455 us against 430 us for the two-workgroup form at T rows
-// (470 us with a look-ahead of four half rounds).  With one wave per SIMD nothing hides that wave's own LDS round trips
-// (~6 lgkmcnt waits per k-step; the k-loop alone runs ~1 400 cycles per step against 768 of MFMA work), and hipcc's waits for
-// the gathered operands count only the loads it knows - not the ring's DMA instructions in between - so they land one
-// k-step early.  Off by default (ALIGNN_AMD_X6PP=1); kept as the base for a k-loop whose LDS reads run one step ahead.
-// ---------------------------------------------------------------------------------------------
-constexpr int PP_NK = 16, PP_D = 2, PP_PLD = 32 + 4, PP_PATCH = 32 * PP_PLD * 4;
-constexpr int PP_STAGE = Geo<2>::A_BYTES + 2 * B_PLANE, PP_LDS = 3 * PP_STAGE + (NT / 64) * PP_PATCH;
-constexpr int PP_PIECES = Geo<2>::A_DMA + 2 * B_PLANE / 1024 / (NT / 64);
-// known memory operations of epilogue half round q (gathers for half round q + D, two stores); the column-sum stores of
-// the statistics are left out: a lower bound
-constexpr int pp_ops(int q) { return (q + PP_D < PP_NK ? 4 : 0) + 2; }
-// vmcnt that guarantees ring stage s (issued two k-steps earlier) has landed, in the steady state of the pipelined loop
-constexpr int pp_wait(int s) {
-    return s == 0 ? PP_PIECES : s == 1 ? 2 * PP_PIECES : pp_ops(s - 2) + PP_PIECES + pp_ops(s - 1);
-}
-
-template <bool STATS>
-__global__ __launch_bounds__(NT) void gemm_nt_f16pp_gather_kernel(X6Args g) {
-    constexpr int RM = 2, BM = Geo<2>::BM, TM = Geo<2>::TM, A_BYTES = Geo<2>::A_BYTES, A_DMA = Geo<2>::A_DMA;
-    constexpr int NPL = 2, STAGE_BYTES = PP_STAGE, B_DMA = NPL * B_PLANE / 1024 / (NT / 64), NS = 3, PIECES = PP_PIECES;
-    constexpr int nk = PP_NK, D = PP_D, PLD = PP_PLD, NH = 2 * RN * RM;
-    static_assert(NH == PP_NK, "one epilogue half round per k-step");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int t = threadIdx.x;
-    const int lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    const int il = lane & 31, half = lane >> 5;
-    const int tiles = (int)((g.M + BM - 1) / BM);  // (N == 256: one column tile)
-    int tile_first = blockIdx.x, tile_step = gridDim.x, tile_end = tiles;
-    if (g.xcd_map && (gridDim.x & 7) == 0) {  // each XCD a contiguous range of row tiles (see gemm_nt_f16p_body)
-        const int per = gridDim.x >> 3, xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-        const int chunk = (tiles + 7) >> 3;
-        tile_first = xcd * chunk + q;
-        tile_step = per;
-        tile_end = (xcd + 1) * chunk < tiles ? (xcd + 1) * chunk : tiles;
-    }
-    const int J = tile_first < tile_end ? (tile_end - tile_first + tile_step - 1) / tile_step : 0;
-    if (J == 0) return;
-
-    // ---- DMA side
-    const int64_t kb_stride = (int64_t)(NPL * B_PLANE);
-    const unsigned b_lane = lane * 16;
-    unsigned a_lane[A_DMA];
-    const float* a_base = g.A;
-    const unsigned char* b_base = g.Ws + (wave * B_DMA) * 1024;
-    int it_tile = tile_first, it_kt = 0;
-    auto set_issue_tile = [&](int tile) {
-        const int64_t row0 = (int64_t)tile * BM;
-        a_base = g.A + row0 * g.lda;
-#pragma unroll
-        for (int i = 0; i < A_DMA; ++i) {
-            const int p = (wave * A_DMA + i) * 64 + lane;
-            const int row = p >> 2, c = (p & 3) ^ ((row >> 2) & 3);
-            int64_t grow = row0 + row;
-            if (grow >= g.M) grow = g.M - 1;
-            a_lane[i] = (unsigned)(((grow - row0) * g.lda + c * 4) * 4);
-        }
-    };
-    auto issue_next = [&](int slot) {  // (past the last tile: the last tile's stages again, into slots nobody reads)
-        unsigned char* stage = smem + slot * STAGE_BYTES;
-#pragma unroll
-        for (int i = 0; i < A_DMA; ++i) dma16<0>(a_base + it_kt * BK, a_lane[i], stage + (wave * A_DMA + i) * 1024);
-#pragma unroll
-        for (int i = 0; i < B_DMA; ++i)
-            dma16<0>(b_base + it_kt * kb_stride + i * 1024, b_lane, stage + A_BYTES + (wave * B_DMA + i) * 1024);
-        if (++it_kt == nk) {
-            it_kt = 0;
-            if (it_tile + tile_step < tile_end) {
-                it_tile += tile_step;
-                set_issue_tile(it_tile);
-            }
-        }
-    };
-    set_issue_tile(it_tile);
-
-    int a_off0[RM], a_off1[RM];
-#pragma unroll
-    for (int a = 0; a < RM; ++a) {
-        const int arow = wm * TM + a * 32 + il;
-        const int a_f = (arow >> 2) & 3;
-        a_off0[a] = arow * (BK * 4) + (((2 * half) ^ a_f) << 4);
-        a_off1[a] = arow * (BK * 4) + (((2 * half + 1) ^ a_f) << 4);
-    }
-    int b_off[RN];
-#pragma unroll
-    for (int b = 0; b < RN; ++b) {
-        const int n = wn * TN + b * 32 + il;
-        b_off[b] = A_BYTES + n * (BK * 2) + ((half ^ ((n >> 3) & 1)) << 4);
-    }
-    const float sa = f16_scale(*g.a_amax), inv_sa = 1.0f / sa, inv_sw = 1.0f / f16_scale(*g.w_amax);
-    float* patch = reinterpret_cast<float*>(smem + NS * STAGE_BYTES + wave * PP_PATCH);
-    const int prow = lane >> 3, pc4 = (lane & 7) * 4;
-    const int col0 = wn * TN + pc4;
-    const float* bd_tab = g.gp2 ? g.gp2 : g.gp + g.N;
-    const int64_t bd_ld = g.gp2 ? g.ldgp2 : g.ldgp;
-    float4 bias_all[RN];
-#pragma unroll
-    for (int b = 0; b < RN; ++b) bias_all[b] = g.bias ? f4_ld(g.bias + col0 + b * 32) : f4_zero();
-
-    issue_next(0);
-    issue_next(1);
-
-    f32x16 accC[RM][RN], accP[RM][RN];
-    int slot = 0;
-
-    // one k-step into accC: ring slot `slot`, stage (tile, kt) must have landed (the caller waited)
-    auto k_step = [&]() {
-        const unsigned char* stage = smem + slot * STAGE_BYTES;
-        slot = slot == NS - 1 ? 0 : slot + 1;
-        f16x8 ah[RM], al[RM], bh[RN], bl[RN];
-        float xs[RM][8];
-#pragma unroll
-        for (int a = 0; a < RM; ++a)
-            slice8_f16_hi(*reinterpret_cast<const float4*>(stage + a_off0[a]), *reinterpret_cast<const float4*>(stage + a_off1[a]),
-                          sa, xs[a], ah[a]);
-#pragma unroll
-        for (int b = 0; b < RN; ++b) {
-            const unsigned char* q = stage + b_off[b];
-            bh[b] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(q));
-            bl[b] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(q + B_PLANE));
-        }
-#define PP_PASS(AA, BB)                                                                              \
-    _Pragma("unroll") for (int a = 0; a < RM; ++a) _Pragma("unroll") for (int b = 0; b < RN; ++b)    \
-        accC[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AA[a], BB[b], accC[a][b], 0, 0, 0);
-        PP_PASS(ah, bh)
-#pragma unroll
-        for (int a = 0; a < RM; ++a) slice8_f16_lo(xs[a], ah[a], al[a]);
-        PP_PASS(ah, bl)
-        PP_PASS(al, bh)
-#undef PP_PASS
-    };
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int a = 0; a < RM; ++a)
-#pragma unroll
-            for (int b = 0; b < RN; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) accC[a][b][r] = 0.0f;
-    };
-
-    // ---- state of the tile whose accumulators wait in accP
-    int64_t m0p = 0;
-    int src_p = 0, dst_p = 0, last_row_p = 0;
-    float4 av[D][2], s0 = f4_zero(), s1 = f4_zero();
-    auto row_of = [&](int a, int i) {
-        const int rrel = wm * TM + a * 32 + prow + i * 8;
-        return rrel < last_row_p ? rrel : last_row_p;
-    };
-    auto load_half = [&](int q) {
-        const int b = q / (2 * RM), a = (q / 2) % RM, h = q & 1, col = col0 + b * 32, sl = q % D;
-        int ui[2], vi[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int holder = a * 32 + (2 * h + i) * 8 + prow;
-            ui[i] = __shfl(src_p, holder);
-            vi[i] = __shfl(dst_p, holder);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            av[sl][i] = f4_add(f4_ld(g.gp + (int64_t)ui[i] * g.ldgp + col), f4_ld(bd_tab + (int64_t)vi[i] * bd_ld + col));
-    };
-    // half round q of the waiting tile's epilogue (q a compile-time constant after unrolling)
-    auto epi_half = [&](int q) {
-        const int rd = q / 2, h = q & 1, b = rd / RM, a = rd % RM, sl = q % D;
-        const int col = col0 + b * 32;
-        float* c_t = g.C + m0p * g.ldc;
-        if (h == 0) {
-            if (a == 0 && STATS) s0 = s1 = f4_zero();
-#pragma unroll
-            for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * half) * PLD + il] = accP[a][b][r];
-        }
-        float4 v[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            v[i] = f4_ld(patch + ((2 * h + i) * 8 + prow) * PLD + pc4);
-            v[i] = f4_scale(f4_scale(v[i], inv_sa), inv_sw);
-            v[i] = f4_add(v[i], bias_all[b]);
-            v[i] = f4_add(v[i], av[sl][i]);
-            if constexpr (STATS) {
-                const bool valid = wm * TM + a * 32 + prow + (2 * h + i) * 8 <= last_row_p;
-                const float4 u = valid ? v[i] : f4_zero();
-                s0 = f4_add(s0, u);
-                s1 = f4_fma(u, u, s1);
-            }
-        }
-        if (q + D < NH) load_half(q + D);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) f4_sts<true>(c_t + (row_of(a, 2 * h + i) * (int)g.ldc + col), v[i]);
-        if (STATS && a == RM - 1 && h == 1) {
-#pragma unroll
-            for (int d = 8; d < 64; d <<= 1) {
-                s0 = f4_add(s0, make_float4(__shfl_xor(s0.x, d), __shfl_xor(s0.y, d), __shfl_xor(s0.z, d), __shfl_xor(s0.w, d)));
-                s1 = f4_add(s1, make_float4(__shfl_xor(s1.x, d), __shfl_xor(s1.y, d), __shfl_xor(s1.z, d), __shfl_xor(s1.w, d)));
-            }
-            const int64_t n_strips = (g.M + TM - 1) / TM;
-            int64_t strip = m0p / TM + wm;
-            strip = strip < n_strips ? strip : n_strips;
-            f4_st(g.red_partial + (strip * 2 + 0) * g.N + col, s0);
-            f4_st(g.red_partial + (strip * 2 + 1) * g.N + col, s1);
-        }
-    };
-    // the tile in accC becomes the waiting tile
-    auto hand_over = [&](int tile, int s_l, int d_l) {
-#pragma unroll
-        for (int a = 0; a < RM; ++a)
-#pragma unroll
-            for (int b = 0; b < RN; ++b) accP[a][b] = accC[a][b];
-        m0p = (int64_t)tile * BM;
-        src_p = s_l;
-        dst_p = d_l;
-        last_row_p = (int)(g.M - 1 - m0p < BM - 1 ? g.M - 1 - m0p : BM - 1);
-#pragma unroll
-        for (int q = 0; q < D; ++q) load_half(q);
-    };
-    auto tile_indices = [&](int tile, int& s_l, int& d_l) {  // node pair of the strip's row `lane` (one coalesced load)
-        int64_t row = (int64_t)tile * BM + wm * TM + lane;
-        row = row < g.M ? row : g.M - 1;
-        s_l = g.gsrc[row];
-        d_l = g.gdst[row];
-    };
-
-    // ---- first tile: plain k-loop (nothing to drain yet); the ring counts only DMA pieces here
-    int tile = tile_first;
-    {
-        int s_l, d_l;
-        tile_indices(tile, s_l, d_l);
-        zero_acc();
-        for (int kt = 0; kt < nk; ++kt) {
-            wait_vmcnt<PIECES>();  // (+ the two index loads in front of the first step: a lower bound)
-            block_barrier();
-            issue_next(slot == 0 ? 2 : slot - 1);
-            k_step();
-        }
-        hand_over(tile, s_l, d_l);
-    }
-    // ---- steady state: tile j into accC, tile j-1 out of accP, one half round per k-step
-    for (int j = 1; j < J; ++j) {
-        tile += tile_step;
-        int s_l, d_l;
-        tile_indices(tile, s_l, d_l);
-        zero_acc();
-#pragma unroll
-        for (int kt = 0; kt < nk; ++kt) {
-            switch (kt) {  // (constant after unrolling)
-#define PP_W(S) case S: wait_vmcnt<pp_wait(S)>(); break;
-                PP_W(0) PP_W(1) PP_W(2) PP_W(3) PP_W(4) PP_W(5) PP_W(6) PP_W(7)
-                PP_W(8) PP_W(9) PP_W(10) PP_W(11) PP_W(12) PP_W(13) PP_W(14) PP_W(15)
-#undef PP_W
-            }
-            block_barrier();
-            issue_next(slot == 0 ? 2 : slot - 1);
-            k_step();
-            epi_half(kt);
-        }
-        hand_over(tile, s_l, d_l);
-    }
-    // ---- drain the last tile
-    wait_vmcnt<0>();
-#pragma unroll
-    for (int q = 0; q < NH; ++q) epi_half(q);
-}
 
 // ---------------------------------------------------------------------------------------------
 // Weight gradient on the same split product:  dW[n,k] = sum_m G[m,n] X[m,k]  (both operands are activations,
@@ -1954,37 +1678,12 @@ int launch_nt_p(const X6Args& g_in, hipStream_t st) {
     }
     if (g_in.ldc >= (1 << 20) || g_in.ldadd >= (1 << 20) || g_in.ldxn >= (1 << 20)) return (int)hipErrorInvalidValue;
     X6Args g = g_in;
-    static const bool xcd_map = [] { const char* e = getenv("ALIGNN_AMD_X6P_XCD"); return !(e && e[0] == '0'); }();
-    g.xcd_map = xcd_map ? 1 : 0;
+    g.xcd_map = 1;  // (each XCD a contiguous range of row tiles; round-robin measured the same: profiles/README.md round 3)
     const int64_t tiles = alignn_ceil_div(g.M, 128) * (int64_t)(g.Npad / BN);
-    // ALIGNN_AMD_X6P_WGS (experiment): fewer resident workgroups than two per CU leave some CUs half free for the small
-    // kernels of the other lane, which otherwise queue behind this kernel for its whole duration
-    static const int resident = [] { const char* e = getenv("ALIGNN_AMD_X6P_WGS"); int v = e ? atoi(e) : 0; return v > 0 ? v : kResidentP; }();
+    // (fewer resident workgroups than two per CU - leaving room for the other lane's small kernels - measured slower in
+    // round 3: 256 workgroups 16.05 vs 15.68 ms per step, 384: 15.93)
+    constexpr int resident = kResidentP;
     const dim3 grid((unsigned)(tiles < resident ? tiles : resident)), block(NT);
-    // ALIGNN_AMD_X6PP=1: the pipelined form of the gather projection (one workgroup per CU, the previous tile's epilogue
-    // under the k-loop; gemm_nt_f16pp_gather_kernel) where it applies
-    const char* pp_env = getenv("ALIGNN_AMD_X6PP");  // (read per call: tests flip it)
-    const bool pipelined = pp_env != nullptr && pp_env[0] == '1';
-    if (pipelined && g.gp != nullptr && g.K == PP_NK * BK && g.Npad == BN && g.N == BN && g.addend == nullptr && tiles >= 512) {
-        static bool pp_attr = false;
-        if (!pp_attr) {
-            hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_f16pp_gather_kernel<true>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
-            if (e == hipSuccess)
-                e = hipFuncSetAttribute((const void*)gemm_nt_f16pp_gather_kernel<false>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS);
-            if (e != hipSuccess) return (int)e;
-            pp_attr = true;
-        }
-        static const int pp_wgs = [] { const char* e = getenv("ALIGNN_AMD_X6PP_WGS"); int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
-        const dim3 pgrid((unsigned)pp_wgs);
-        if (g.red_partial)
-            hipLaunchKernelGGL(gemm_nt_f16pp_gather_kernel<true>, pgrid, block, PP_LDS, st, g);
-        else
-            hipLaunchKernelGGL(gemm_nt_f16pp_gather_kernel<false>, pgrid, block, PP_LDS, st, g);
-        ALIGNN_CHECK_LAUNCH();
-        return 0;
-    }
     if (g.gp != nullptr) {
         if (g.red_partial)
             hipLaunchKernelGGL(gemm_nt_f16p_gather_kernel<true>, grid, block, lds, st, g);
@@ -2008,15 +1707,9 @@ int launch_nt_p(const X6Args& g_in, hipStream_t st) {
 }
 // rows per reduction slab of the f16x3 kernels' column sums (EPI flags BNRED / STATS): the block tile of the one-tile
 // kernels, the 64-row wave strip of the persistent one
-// a product with fewer 128-row tiles than this runs on 64-row tiles (default: fewer than one per CU; ALIGNN_AMD_X6_RM1_BELOW
-// moves the line for A/B runs - e.g. 512 puts the bond-row products, 397 tiles = one thin generation, on 793 half tiles)
-inline int64_t rm1_below() {
-    static const int64_t v = [] {
-        const char* e = getenv("ALIGNN_AMD_X6_RM1_BELOW");
-        return e ? (int64_t)atoll(e) : (int64_t)256;
-    }();
-    return v;
-}
+// a product with fewer 128-row tiles than this runs on 64-row tiles: fewer than one per CU (512 - the bond-row products, 397
+// tiles = one thin generation, on 793 half tiles - measured slower on every variant in round 3)
+inline int64_t rm1_below() { return 256; }
 inline int nt_block_rows(int64_t M, int N, int K) {
 #ifdef X6_FORCE_RM
     return 64 * X6_FORCE_RM;
@@ -2037,8 +1730,7 @@ int launch_nt(const X6Args& g, hipStream_t st) {
             // measured per variant at T x 256 x 256, kernels interleaved (tools/x6_family_check.py): persistent -5 % plain,
             // -4 % statistics, -7..-9 % gather (+ statistics), -2 % BatchNorm-backward sums; +3 % with an addend and +10 %
             // for sums + addend (its operand look-ahead spills) - those two stay on the one-tile kernel, with strip slabs
-            static const bool addend_too = [] { const char* e = getenv("ALIGNN_AMD_X6P_ADDEND"); return e && e[0] == '1'; }();
-            if (g.addend == nullptr || addend_too) return launch_nt_p(g, st);
+            if (g.addend == nullptr) return launch_nt_p(g, st);
             X6Args gs = g;
             gs.strip_slabs = 1;
             return launch_nt_rm<F16, 2>(gs, st);

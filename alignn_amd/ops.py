@@ -112,7 +112,7 @@ def on_side_stream(fn, inputs, params=(), wait=()):
         return fn()
     side = _SIDE["streams"].get(dev)
     if side is None:
-        side = _SIDE["streams"][dev] = torch.cuda.Stream(device=dev, priority=int(_os.environ.get("ALIGNN_AMD_SIDE_PRIORITY", "0")))
+        side = _SIDE["streams"][dev] = torch.cuda.Stream(device=dev)
     side.wait_stream(main)
     for ev in wait:  # work of lane T that ``fn`` reads
         if ev is not None:
@@ -155,7 +155,7 @@ def on_side_stream(fn, inputs, params=(), wait=()):
 # events cost nothing at replay; eagerly launched steps are bound by the host's enqueue rate on most hosts and the extra
 # event / stream calls (+1-4 ms per step) cost more than the overlap returns (-0.5 ms) -, "1" = always, "0" = never.
 _LANE = {"enabled": _os.environ.get("ALIGNN_AMD_LANES", "auto"), "min_rows": 131072, "active": False,
-         "streams": {}, "main": None, "T": None, "priority": int(_os.environ.get("ALIGNN_AMD_LANE_PRIORITY", "0"))}
+         "streams": {}, "main": None, "T": None, "priority": 0}
 _ON_T = {}  # id -> weakref: tensors whose producer kernel ran on lane T (consumers on lane T need no event)
 
 
@@ -299,7 +299,7 @@ def gemm_nt(a, w, bias=None, addend=None, out=None):
     return out
 
 
-X6_MIN_TILES = int(_os.environ.get("ALIGNN_AMD_X6_MIN_TILES", "256"))  # 64x256 tiles below which the fp32-MFMA kernel's finer tiles win (100-512 measured the same)
+X6_MIN_TILES = 256  # 64x256 tiles below which the fp32-MFMA kernel's finer tiles win (100-512 measured the same)
 F16X3 = True  # use the three-product fp16 scheme wherever max|A| is known (False: always bf16x6)
 
 # max|x| of activations, tracked by the kernels that produce them (one device float per tensor).  Keyed by object
@@ -381,7 +381,7 @@ def new_amax(like):
     return a["buf"][i:i + 1]
 
 
-AMAX_MIN_ROWS = int(_os.environ.get("ALIGNN_AMD_AMAX_MIN_ROWS", "4096"))  # below this no projection of the tensor can reach X6_MIN_TILES 64-row tiles (N <= 1024): skip tracking
+AMAX_MIN_ROWS = 4096  # below this no projection of the tensor can reach X6_MIN_TILES 64-row tiles (N <= 1024): skip tracking
 
 
 def _track(rows):
@@ -442,11 +442,11 @@ def _wstamp(w):
 from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_step_hook  # noqa: E402
 
 _reg_step_hook(new_weight_generation)
-SPLIT_BOTH = _os.environ.get("ALIGNN_AMD_SPLIT_BOTH", "1") != "0"  # both slice images of a weight from one launch (tests flip it: same bits)
+SPLIT_BOTH = True  # both slice images of a weight from one launch (tests flip it: same bits)
 
 
 _W_IMG = {}  # id(w) -> (weakref, stamp, SplitWeight of w): images made ahead of the step by WeightPrep (below)
-BATCHED_WEIGHT_PREP = _os.environ.get("ALIGNN_AMD_WEIGHT_PREP", "1") != "0"  # tests flip it: same bits
+BATCHED_WEIGHT_PREP = True  # tests flip it: same bits
 
 
 WEIGHT_PREP_STATS = {"runs": 0, "weights": 0}
@@ -648,7 +648,7 @@ def _f16x3_applies(a, a_amax, N, K):
             and bool(lib.alignn_gemm_nt_x6_supported(M, N, K)))
 
 
-BD_SEGMENT_TABLE = _os.environ.get("ALIGNN_AMD_BD_TABLE", "1") != "0"  # line graphs: destination term from a segment-ordered copy (tests flip it: same bits)
+BD_SEGMENT_TABLE = True  # line graphs: destination term from a segment-ordered copy (tests flip it: same bits)
 BD_TABLE_STATS = {"used": 0}  # edge-gate projections that read the table (tests)
 
 
@@ -733,7 +733,7 @@ def gemm_nt_x6(a, ws, bias=None, addend=None, out=None):
     return out
 
 
-NN_SPLIT = _os.environ.get("ALIGNN_AMD_NN_SPLIT", "1") != "0"  # split-reduction input gradients on atom rows (tests flip it)
+NN_SPLIT = True  # split-reduction input gradients on atom rows (tests flip it)
 
 
 def project(a, w, bias=None, addend=None, transpose_w=False, a_amax=None):
@@ -1114,7 +1114,7 @@ def linear(x, w, b=None):
 # ---------------------------------------------------------------------------------------------
 # MLPLayer = Linear + BatchNorm1d + SiLU   (alignn/models/alignn.py:170-184)
 # ---------------------------------------------------------------------------------------------
-APPLY_SUM = _os.environ.get("ALIGNN_AMD_APPLY_SUM", "1") != "0"  # bias gradient from the norm-backward pass (tests flip it)
+APPLY_SUM = True  # bias gradient from the norm-backward pass (tests flip it)
 
 
 class MLPLayerFn(torch.autograd.Function):
@@ -1235,144 +1235,13 @@ class MLPLayerFn(torch.autograd.Function):
 
 
 # ---------------------------------------------------------------------------------------------
-# RBFExpansion + MLPLayer fused (the head of the edge / angle embeddings, alignn/models/alignn.py:201-222)
-# ---------------------------------------------------------------------------------------------
-# OFF by default: measured on MI355X at T = 676 200 rows (tools/rbf_mlp_time.py, profiles/README.md round 3) the two forward
-# passes win (66 + 81 us against rbf 30 + GEMM 86..170 + statistics 32 + normalise 45), the three backward passes lose
-# (210 + 167 + 374 us against ~250): the F x bins products of a row run on the vector ALU with wave-uniform weights from
-# scalar loads, whose latency the compiler does not hide - the step gets 1.0 ms SLOWER (16.7 vs 15.7 ms).  An MFMA
-# formulation (weights resident in registers as the B operand) would make every pass HBM-bound (~250 us in total); until
-# then the materialised RBF expansion + GEMM stays the default.  ALIGNN_AMD_RBF_MLP=1 / tests switch it on.
-RBF_MLP_FUSED = _os.environ.get("ALIGNN_AMD_RBF_MLP", "0") == "1"
-
-
-def rbf_mlp_applies(d, w, norm):
-    """Can ``RbfMLPLayerFn`` take this embedding head?  BatchNorm flavour, no gradient w.r.t. the distances / cosines
-    (the force paths differentiate them: those keep the materialised RBF expansion), supported widths."""
-    return (RBF_MLP_FUSED and norm == "batch" and d.is_cuda and d.dtype == torch.float32 and not d.requires_grad
-            and w.dtype == torch.float32 and bool(_lib.load().alignn_rbf_mlp_supported(w.shape[0], w.shape[1])))
-
-
-class RbfMLPLayerFn(torch.autograd.Function):
-    """y = silu(BatchNorm(rbf(d) W^T + b)) without materialising the RBF matrix or the pre-activation
-    (csrc/rbf_mlp.hip).  T-row inputs (the bond-angle cosines) run on lane T inside ``lanes()``."""
-
-    @staticmethod
-    def _fwd(ctx, d, centers, gamma_rbf, Wt, b, gamma, beta, rm, rv, training):
-        lib = _lib.load()
-        rows, (bins, F) = d.numel(), Wt.shape
-        if training:
-            slabs = lib.alignn_rbf_mlp_slabs(rows)
-            partial = _welford_slabs(slabs, F, d)
-            check(lib.alignn_rbf_mlp_stats(ptr(d), ptr(centers), gamma_rbf, ptr(Wt), ptr(b), rows, bins, F, ptr(partial),
-                                           stream()), "rbf_mlp_stats")
-            stat = _bn_finalize(partial, slabs, rows, gamma, beta, rm, rv, True, welford=True)
-        else:
-            stat = _bn_finalize(None, 0, rows, gamma, beta, rm, rv, False)
-        y = _empty(rows, F, like=d)
-        amax = new_amax(d) if _track(rows) else None
-        check(lib.alignn_rbf_mlp_fwd(ptr(d), ptr(centers), gamma_rbf, ptr(Wt), ptr(b), rows, bins, F, ptr(stat), ptr(y),
-                                     ptr(amax), stream()), "rbf_mlp_fwd")
-        if amax is not None:
-            set_amax(y, amax)
-        return y, stat
-
-    @staticmethod
-    def forward(ctx, d, centers, gamma_rbf, w, b, gamma, beta, running_mean, running_var, training):
-        require_f32(d, centers, w, b, gamma, beta)
-        d = d.contiguous().reshape(-1)
-        lane = _lane_for(d.numel())
-        ctx.lane = lane is not None
-        if lane is not None:
-            with _on_T(*lane, reads=(d,)):
-                Wt = w.t().contiguous()
-                y, stat = RbfMLPLayerFn._fwd(ctx, d, centers, float(gamma_rbf), Wt, b, gamma, beta, running_mean, running_var,
-                                             training)
-            _mark_on_T(y)
-        else:
-            _main_reads(d)
-            Wt = w.t().contiguous()
-            y, stat = RbfMLPLayerFn._fwd(ctx, d, centers, float(gamma_rbf), Wt, b, gamma, beta, running_mean, running_var,
-                                         training)
-        ctx.save_for_backward(d, centers, Wt, b, stat, gamma, beta)
-        ctx.gamma_rbf = float(gamma_rbf)
-        ctx.training = training
-        ctx.param_grads = _PARAM_GRADS["on"]
-        ctx.wb = (w, b)
-        return y
-
-    @staticmethod
-    def _bwd(ctx, gy, d, centers, Wt, b, stat):
-        lib = _lib.load()
-        rows, (bins, F) = d.numel(), Wt.shape
-        slabs = lib.alignn_rbf_mlp_slabs(rows)
-        red = None
-        if ctx.training:
-            part = _empty(slabs, 2, F, like=d)
-            check(lib.alignn_rbf_mlp_bwd_reduce(ptr(d), ptr(centers), ctx.gamma_rbf, ptr(Wt), ptr(b), rows, bins, F, ptr(stat),
-                                                ptr(gy), ptr(part), stream()), "rbf_mlp_bwd_reduce")
-            red = _empty(2, F, like=d)
-            check(lib.alignn_bn_bwd_finalize(ptr(part), slabs, F, ptr(red), stream()), "bn_bwd_finalize")
-        gpre = _empty(rows, F, like=d)
-        gb_part = _empty(slabs, F, like=d)
-        check(lib.alignn_rbf_mlp_bwd_apply(ptr(d), ptr(centers), ctx.gamma_rbf, ptr(Wt), ptr(b), rows, bins, F, ptr(stat),
-                                           ptr(gy), ptr(red), int(not ctx.training), ptr(gpre), ptr(gb_part), None, stream()),
-              "rbf_mlp_bwd_apply")
-        return gpre, gb_part, red, slabs
-
-    @staticmethod
-    def backward(ctx, gy):
-        lib = _lib.load()
-        d, centers, Wt, b, stat, gamma, beta = ctx.saved_tensors
-        gy = gy.contiguous()
-        bins, F = Wt.shape
-        rows = d.numel()
-        ev = None
-        if ctx.lane:
-            main, T = _lane_streams(gy.device)
-            with _on_T(main, T, reads=(gy,)):
-                gpre, gb_part, red, slabs = RbfMLPLayerFn._bwd(ctx, gy, d, centers, Wt, b, stat)
-            ev = _event_after(T)
-            if not ctx.param_grads or _deferred_join_is_safe((gamma, beta)):
-                _arm_backward_join()
-            else:
-                main.wait_event(ev)
-                if red is not None:
-                    red.record_stream(main)
-        else:
-            _main_reads(gy)
-            gpre, gb_part, red, slabs = RbfMLPLayerFn._bwd(ctx, gy, d, centers, Wt, b, stat)
-        if not ctx.param_grads:
-            return (None,) * 10
-        if red is None:  # eval mode: the norm's affine parameters still receive gradients through z = (x - mean) scale + beta
-            raise NotImplementedError("RbfMLPLayerFn: parameter gradients in eval mode are not implemented (use the unfused layers)")
-
-        def _wgrads():
-            wpart = _empty(slabs, F * bins, like=d)
-            check(lib.alignn_rbf_mlp_wgrad(ptr(d), ptr(centers), ctx.gamma_rbf, ptr(gpre), rows, bins, F, ptr(wpart), stream()),
-                  "rbf_mlp_wgrad")
-            gw = _empty(F, bins, like=d)
-            check(lib.alignn_slab_sum(ptr(wpart), slabs, F * bins, ptr(gw), stream()), "slab_sum")
-            gb = _empty(F, like=d)
-            check(lib.alignn_slab_sum(ptr(gb_part), slabs, F, ptr(gb), stream()), "slab_sum")
-            return gw, gb
-
-        gw, gb = on_side_stream(_wgrads, [gpre, d, gb_part], ctx.wb, wait=(ev,))
-        return None, None, None, gw, gb, red[1], red[0], None, None, None
-
-
-def rbf_mlp_layer(d, centers, gamma_rbf, w, b, gamma, beta, running_mean, running_var, training):
-    return RbfMLPLayerFn.apply(d, centers, gamma_rbf, w, b, gamma, beta, running_mean, running_var, training)
-
-
-# ---------------------------------------------------------------------------------------------
 # EdgeGatedGraphConv   (alignn/models/alignn.py:78-129)
 # ---------------------------------------------------------------------------------------------
 # Composite entry points (csrc/composite.hip): the launches of a convolution's forward / backward issued by ONE C call each
 # instead of ~11 / ~20 (same kernels, same arguments, same order: bit-identical - tests flip this flag).  Used for the
 # BatchNorm flavour in training mode on one stream; lanes (hipGraph capture: host cost is irrelevant there), LayerNorm,
 # eval mode and the rare kernel choices the composites do not carry take the per-kernel path below.
-COMPOSITE = _os.environ.get("ALIGNN_AMD_COMPOSITE", "1") != "0"
+COMPOSITE = True
 # composite backward: node input gradient on a second stream beside the edge one.  "auto": inside a stream capture only (like the
 # lanes: -0.15 ms per replayed step at 64 crystals, -0.24 ms at 8; eagerly launched the four event calls per convolution cost
 # the host more than the overlap returns: 16.96 vs 16.81 ms); "1": always; "0": never.

@@ -434,36 +434,6 @@ int alignn_egc_dual_bwd_src(const float* GM, const float* GMt, const float* M, c
                             int64_t n, int H, float* GP, float* GPt, float* gp_amax2, alignn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
- * RBF expansion fused with the first MLPLayer of an embedding (csrc/rbf_mlp.hip):
- *   y = silu(BatchNorm(rbf(d) W^T + b)),  rbf_k(d) = exp(-gamma (d - c_k)^2)
- * Replaces nn.Sequential(RBFExpansion(bins), MLPLayer(bins, F)) - the head of ALIGNN's edge / angle embeddings,
- * alignn/models/alignn.py:201-222 (RBFExpansion.forward alignn/models/utils.py:40-44; MLPLayer :170-184) - and
- * torch.autograd's backward of it.  Neither the RBF matrix [rows, bins] nor the pre-activation [rows, F] goes to memory:
- * every pass recomputes them from the scalar d[row].  Wt = W^T as [bins][F]; F in {16, 32, 48, 64}, bins <= 128
- * (alignn_rbf_mlp_supported); slabs = alignn_rbf_mlp_slabs(rows).
- *   stats:      BatchNorm statistics of the pre-activation as pivot slabs, partial[slabs*(3F+1)] (alignn_bn_finalize_welford)
- *   fwd:        Y[rows][F] (stat = [4][F] from the finalize; amax optional, raised to max|Y|)
- *   bwd_reduce: partial[slabs][2][F] = (sum gz, sum gz*xhat) for alignn_bn_bwd_finalize
- *   bwd_apply:  GPRE[rows][F] = gradient of the pre-activation (eval_mode != 0: running statistics, red unused);
- *               gb_partial[slabs][F] = column sums of GPRE (the Linear's bias gradient, alignn_slab_sum)
- *   wgrad:      partial[slabs][F][bins] slabs of dW = GPRE^T rbf(d) (alignn_slab_sum with width F*bins)
- * ------------------------------------------------------------------------------------------ */
-int alignn_rbf_mlp_supported(int F, int bins);
-int alignn_rbf_mlp_slabs(int64_t rows);
-int alignn_rbf_mlp_stats(const float* d, const float* centers, float gamma, const float* Wt, const float* bias, int64_t rows,
-                         int bins, int F, float* partial, alignn_stream_t stream);
-int alignn_rbf_mlp_fwd(const float* d, const float* centers, float gamma, const float* Wt, const float* bias, int64_t rows,
-                       int bins, int F, const float* stat, float* Y, float* amax, alignn_stream_t stream);
-int alignn_rbf_mlp_bwd_reduce(const float* d, const float* centers, float gamma, const float* Wt, const float* bias,
-                              int64_t rows, int bins, int F, const float* stat, const float* GY, float* partial,
-                              alignn_stream_t stream);
-int alignn_rbf_mlp_bwd_apply(const float* d, const float* centers, float gamma, const float* Wt, const float* bias,
-                             int64_t rows, int bins, int F, const float* stat, const float* GY, const float* red,
-                             int eval_mode, float* GPRE, float* gb_partial, float* amax, alignn_stream_t stream);
-int alignn_rbf_mlp_wgrad(const float* d, const float* centers, float gamma, const float* GPRE, int64_t rows, int bins, int F,
-                         float* partial, alignn_stream_t stream);
-
-/* ------------------------------------------------------------------------------------------
  * Periodic k-nearest-neighbour bond lists on the device (csrc/knn.hip).
  * Replace alignn/graphs.py:155-264 (nearest_neighbor_edges on jarvis' get_all_neighbors, canonize_edge :128-153,
  * build_undirected_edgedata :230-264), which alignn/ff/calculators.py:280-291 re-runs at every MD step.

@@ -504,88 +504,6 @@ def test_conv_with_nearly_constant_node_features_matches_float64():
 
 
 # ---------------------------------------------------------------------------------------------
-# RBF expansion + first embedding layer fused (csrc/rbf_mlp.hip)
-# ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("rows,bins,F", [(1, 40, 64), (1000, 40, 64), (50712, 80, 64), (200001, 40, 64), (333, 20, 16), (4097, 128, 48)])
-def test_fused_rbf_mlp_layer_against_float64(rows, bins, F):
-    """forward, BatchNorm running statistics, and all five gradients (W, b, gamma, beta of the fused layer; via a loss that
-    weights every output) against the same layer in float64 torch."""
-    from alignn_amd.alignn import MLPLayer, RBFExpansion
-
-    torch.manual_seed(rows + bins)
-    rbf = RBFExpansion(vmin=-1, vmax=1.0, bins=bins).to(DEV)
-    layer = MLPLayer(bins, F).to(DEV).train()
-    with torch.no_grad():
-        layer.layer[1].weight.uniform_(0.5, 1.5)
-        layer.layer[1].bias.uniform_(-0.5, 0.5)
-    d = (torch.rand(rows, device=DEV) * 2 - 1)
-    coef = torch.randn(rows, F, device=DEV)
-    lin, bn = layer.layer[0], layer.layer[1]
-    y = ops.rbf_mlp_layer(d, rbf.centers, rbf.gamma, lin.weight, lin.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, True)
-    (y * coef).sum().backward()
-    torch.cuda.synchronize()
-    # float64 reference
-    W, b, g, be = (t.detach().double().cpu().requires_grad_(True) for t in (lin.weight, lin.bias, bn.weight, bn.bias))
-    d64 = d.double().cpu()
-    r = torch.exp(-rbf.gamma * (d64[:, None] - rbf.centers.double().cpu()) ** 2)
-    pre = r @ W.t() + b
-    mean, var = pre.mean(0), pre.var(0, unbiased=False)
-    y64 = torch.nn.functional.silu((pre - mean) / torch.sqrt(var + 1e-5) * g + be)
-    (y64 * coef.double().cpu()).sum().backward()
-    assert float((y.double().cpu() - y64).abs().max()) < 2e-5 * float(y64.abs().max() + 1e-30) if rows > 1 else True
-    for name, mine, ref in (("W", lin.weight.grad, W.grad), ("gamma", bn.weight.grad, g.grad), ("beta", bn.bias.grad, be.grad)):
-        if rows > 1:
-            assert float((mine.double().cpu() - ref).abs().max()) < 2e-4 * float(ref.abs().max() + 1e-30), name
-    if rows > 1:
-        assert float(lin.bias.grad.abs().max()) < 1e-3 * float(coef.abs().sum(0).max())  # analytically zero (bias before BatchNorm)
-        unb = pre.var(0, unbiased=True).detach()
-        assert float((bn.running_mean.double().cpu() - 0.1 * mean.detach()).abs().max()) < 1e-6 * float(mean.abs().max() + 1)
-        assert float(((bn.running_var.double().cpu() - (0.9 + 0.1 * unb)) / (0.9 + 0.1 * unb)).abs().max()) < 1e-5
-
-
-@pytest.mark.parametrize("case", ["small", "default_16x60"])
-def test_fused_embedding_head_equals_the_unfused_layers(case):
-    """A training step with the fused RBF + first embedding layer against RBFExpansion -> MLPLayer (GEMM path): same
-    model state to rounding."""
-    if case == "small":
-        raw = make_batch(5, 16, seed0=78)
-
-        def mk():
-            torch.manual_seed(21)
-            return ALIGNN(ALIGNNConfig(name="alignn", alignn_layers=2, gcn_layers=1, hidden_features=64,
-                                       embedding_features=32)).to(DEV).train()
-    else:
-        raw = make_batch(16, 60, seed0=77)
-
-        def mk():
-            torch.manual_seed(0)
-            return ALIGNN(ALIGNNConfig(name="alignn")).to(DEV).train()
-    batch = GraphBatch.from_raw(raw, device=DEV)
-    target = torch.randn(raw.batch_size, generator=torch.Generator().manual_seed(2)).to(DEV)
-
-    def run(flag):
-        prev = ops.RBF_MLP_FUSED
-        ops.RBF_MLP_FUSED = flag
-        try:
-            return _train_state(mk, batch, target, True, steps=1)[0]
-        finally:
-            ops.RBF_MLP_FUSED = prev
-
-    a, b = run(True), run(False)
-    gmax = max(float(v.abs().max()) for k, v in b.items() if k.startswith("g."))
-    for k in b:
-        if not b[k].is_floating_point():
-            assert torch.equal(a[k], b[k]), k
-            continue
-        if k.startswith("s.") and "running" not in k:
-            continue  # (parameters AFTER the AdamW step: Adam turns the rounding noise of an analytically-zero gradient into +-lr)
-        # gradients: against max(own scale, 1e-3 of the largest gradient) - the Linear biases in front of BatchNorm hold
-        # rounding noise only; everything else: against the tensor's own scale
-        scale = max(float(b[k].abs().max()), 1e-3 * gmax) if k.startswith("g.") else max(float(b[k].abs().max()), 1e-6)
-        assert float((a[k] - b[k]).abs().max()) <= 2e-4 * scale, (k, float((a[k] - b[k]).abs().max()), scale)
-
-
-# ---------------------------------------------------------------------------------------------
 # BatchNorm backward of the node norm with the quotient's adjoints in the same pass
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("rows,F", [(1, 64), (3840, 256), (50712, 256), (140001, 256)])
@@ -665,11 +583,10 @@ def test_graphed_force_field_replays_equal_the_eager_evaluation():
         GraphedForceField(model.train())
 
 
-def test_pipelined_gather_projection_is_bit_identical_to_the_shipped_one():
-    """csrc/gemm_x6.hip gemm_nt_f16pp_gather_kernel (ALIGNN_AMD_X6PP=1, off by default: one workgroup per CU, the previous
-    tile's epilogue issued under the k-loop) against the two-workgroup persistent kernel: output and column-sum slabs."""
-    import os
-
+def test_gather_projection_with_and_without_the_segment_table_against_float64():
+    """The T-row edge-gate projection with DGL's u_add_v in its epilogue (alignn_gemm_nt_f16x3_gather / _gather2, persistent
+    kernel): destination term from P or from the segment-ordered table - same bits -, with and without the BatchNorm
+    column sums, against float64."""
     raw = make_batch(48, 60, seed0=3)
     lg = GraphBatch.from_raw(raw, device=DEV).lg
     T, E, H = lg.n_edges, lg.n_nodes, 256
@@ -682,26 +599,18 @@ def test_pipelined_gather_projection_is_bit_identical_to_the_shipped_one():
     wh, am = ops.split_f16x2(w), ops.absmax(y)
     bd2 = ops.segment_ordered_bd(P, lg, H)
 
-    def run(flag, stats, table):
-        prev = os.environ.get("ALIGNN_AMD_X6PP")
-        os.environ["ALIGNN_AMD_X6PP"] = flag
-        try:
-            r = ops.gemm_nt_f16x3_gather(y, am, wh, bias, P, lg.src, lg.dst, want_stats=stats, bd2=bd2 if table else None,
-                                         rank=lg.seg_rank if table else None)
-            torch.cuda.synchronize()
-            return (r[0], r[1][:r[2]]) if stats else (r, None)
-        finally:
-            if prev is None:
-                os.environ.pop("ALIGNN_AMD_X6PP", None)
-            else:
-                os.environ["ALIGNN_AMD_X6PP"] = prev
+    def run(stats, table):
+        r = ops.gemm_nt_f16x3_gather(y, am, wh, bias, P, lg.src, lg.dst, want_stats=stats, bd2=bd2 if table else None,
+                                     rank=lg.seg_rank if table else None)
+        torch.cuda.synchronize()
+        return (r[0], r[1][:r[2]]) if stats else (r, None)
 
-    for stats in (True, False):
-        for table in (True, False):
-            a, pa = run("0", stats, table)
-            b, pb = run("1", stats, table)
-            assert torch.equal(a, b), (stats, table)
-            if stats:
-                assert torch.equal(pa, pb), (stats, table)
     ref = y.double() @ w.double().t() + bias.double() + P[lg.src.long(), :H].double() + P[lg.dst.long(), H:2 * H].double()
-    assert float((b.double() - ref).abs().max()) < 2e-6 * float(ref.abs().max())
+    for stats in (True, False):
+        a, pa = run(stats, True)
+        b, pb = run(stats, False)
+        assert torch.equal(a, b), stats
+        assert float((b.double() - ref).abs().max()) < 2e-6 * float(ref.abs().max())
+        if stats:
+            assert torch.equal(pa, pb)
+            assert float((pa[:, 0].double().sum(0) - ref.sum(0)).abs().max()) < 1e-5 * float(ref.sum(0).abs().max() + T ** 0.5)
