@@ -1,0 +1,93 @@
+"""Host-only checks of the whole-model entry points (csrc/model.hip): ``alignn_model_plan`` is pure host arithmetic (which
+kernel every product takes, the workspace layout), so its decisions are testable without a GPU - the launches themselves are
+covered by tests/test_gpu_cmodel.py."""
+
+import ctypes as C
+
+import pytest
+
+from alignn_amd import cmodel
+
+NOT_SUPPORTED = 801
+
+
+def _desc(H=256, la=4, lg=4, images=True, lanes=True):
+    d = cmodel.ModelDesc()
+    n = 2 * la + lg
+    arr = (cmodel.ConvParams * n)()
+    for i in range(n):
+        for f, _ in cmodel.ConvParams._fields_:
+            setattr(arr[i], f, 0x1000)
+        if not images:
+            for f in ("wcat_img", "wcat_img_t", "weg_img", "weg_img_t"):
+                setattr(arr[i], f, None)
+    d.convs = C.cast(arr, C.POINTER(cmodel.ConvParams))
+    d.alignn_layers, d.gcn_layers, d.H, d.out_features = la, lg, H, 1
+    d.atom_in, d.edge_bins, d.angle_bins, d.embed = 92, 80, 40, 64
+    for name, (i, o) in dict(atom=(92, H), edge1=(80, 64), edge2=(64, H), angle1=(40, 64), angle2=(64, H)).items():
+        blk = getattr(d, name)
+        for f, _ in cmodel.MlpParams._fields_[:12]:
+            setattr(blk, f, 0x1000)
+        blk.in_, blk.out = i, o
+        if not images:
+            blk.img = blk.img_t = None
+    d.x6_min_tiles, d.bd_segment_table = 256, 1
+    d.amax_min_rows, d.lane_min_rows, d.side_min_rows = 4096, 131072, 32768
+    d.fc_W = d.fc_b = d.g_fc_W = d.g_fc_b = 0x1000
+    if lanes:
+        d.lane_T, d.side, d.aux = 0x10, 0x20, 0x30
+    return d, arr
+
+
+def _batch(N, E, T, B):
+    mb = cmodel.ModelBatch()
+    for g, (n, m) in ((mb.g, (N, E)), (mb.lg, (E, T))):
+        g.n, g.m = n, m
+        for f in ("seg_ptr", "src", "dst", "out_ptr", "out_slot"):
+            setattr(g, f, 0x1000)
+    mb.lg.seg_node = mb.lg.seg_rank = mb.lg.grp_seg_ptr = mb.lg.grp_src_ptr = 0x1000
+    mb.lg.n_groups, mb.lg.dense_max_src = N, 16
+    mb.graph_ptr = mb.atom_features = mb.r = mb.h = 0x1000
+    mb.B = B
+    return mb
+
+
+def _plan(d, mb):
+    lib = cmodel._lib_model()
+    f, t = C.c_size_t(0), C.c_size_t(0)
+    rc = lib.alignn_model_plan(C.addressof(d), C.addressof(mb), C.addressof(f), C.addressof(t))
+    return rc, f.value, t.value
+
+
+@pytest.mark.parametrize("N,E,T,B", [(3840, 50712, 676200, 64), (480, 6339, 84525, 8), (15360, 202848, 2704800, 256)])
+def test_workspace_of_the_baseline_batches(N, E, T, B):
+    d, _keep = _desc()
+    rc, fwd, tot = _plan(d, _batch(N, E, T, B))
+    assert rc == 0
+    t_row = T * 256 * 4
+    # forward tape: 2 T-row tensors per line-graph convolution (7: the last edge output is dead) + the angle embedding (2.5)
+    assert 9 * t_row < fwd < 16 * t_row, fwd / t_row
+    # backward: two more T-row tensors per line-graph convolution + the angle embedding's
+    assert fwd + 9 * t_row < tot < fwd + 16 * t_row, (tot - fwd) / t_row
+    assert fwd % 256 == 0 and tot % 256 == 0
+    # the layout does not depend on whether the helper streams exist beyond the stream-local scratch regions
+    d1, _k1 = _desc(lanes=False)
+    rc1, fwd1, tot1 = _plan(d1, _batch(N, E, T, B))
+    assert rc1 == 0 and fwd1 == fwd and tot1 <= tot
+
+
+def test_kernel_choices_the_c_side_does_not_carry_are_reported():
+    d, _keep = _desc(images=False)  # split-product shapes without slice images: the per-operator path slices for itself
+    assert _plan(d, _batch(3840, 50712, 676200, 64))[0] == NOT_SUPPORTED
+    d, _keep = _desc(H=32, la=2, lg=2, images=False)  # nothing reaches the split-product kernels: fine without images
+    rc, fwd, tot = _plan(d, _batch(24, 200, 1500, 3))
+    assert rc == 0 and 0 < fwd < tot < 64 << 20
+
+
+def test_argument_checks():
+    d, _keep = _desc()
+    mb = _batch(100, 1000, 9000, 2)
+    mb.lg.n = 999  # L(g)'s nodes must be g's bonds
+    assert _plan(d, mb)[0] == 1
+    d.alignn_layers = 0
+    assert _plan(d, _batch(100, 1000, 9000, 2))[0] == 1
