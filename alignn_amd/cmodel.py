@@ -467,4 +467,9 @@ def forward(model, b):
         nbytes = total if need_bwd else fwd_bytes
         arena, owns = bind.take_arena(nbytes, capturing, need_bwd)
         ops.new_weight_generation()
-        return _ModelFn.apply(bind, mb, (b, af, r, h), arena, nbytes, owns, *bind.params)
+        try:
+            return _ModelFn.apply(bind, mb, (b, af, r, h), arena, nbytes, owns, *bind.params)
+        except BaseException:
+            if owns:  # (the forward raised before a lease existed: hand the shared workspace back)
+                bind.arena_busy = False
+            raise
