@@ -55,6 +55,7 @@ SIGNATURES = {
     "alignn_egc_node_dual_bwd": (_i32, [_p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p]),
     "alignn_egc_dual_bwd_dst": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p]),
     "alignn_egc_dual_bwd_src": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p]),
+    "alignn_egc_dual_bwd_lg_dense": (_i32, [_p] * 10 + [_i64, _p, _p, _i64, _p, _p, _i32] + [_p] * 7 + [_p]),
     "alignn_slab_fold_slabs": (_i32, []),
     "alignn_slab_fold": (_i32, [_p, _i32, _i32, _p, _p]),
     "alignn_col_stats_slabs": (_i32, [_i64]),

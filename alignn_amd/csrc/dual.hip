@@ -452,6 +452,144 @@ __global__ __launch_bounds__(kT) void egc_dual_bwd_src_kernel(
     amax2_commit(pam, pamt, gp_amax2);
 }
 
+// The two passes above as ONE for line graphs whose blocks are dense and source-sorted (CSRGraph.dense_max_src > 0; the
+// structure and the index arithmetic of egc_bwd_lg_dense_kernel, csrc/conv.hip): the workgroup of centre atom j walks its
+// (sources x segments) block segment by segment; wave w owns the sources q = w, w + 4, ... and keeps their Bh / Bh-dot rows
+// and their four source-side sums (g_A, g_A-dot, g_Bh, g_Bh-dot) in registers for the whole block, a segment's four adjoint
+// rows Q are loaded once per segment, g_Bd / g_Bd-dot of the segment are the fixed-order sums of the four waves' partial
+// sums.  Every T-row of M, Mt, GL, GLt is read once and GM, GMt written once: 6 row passes instead of the 10 of
+// egc_dual_bwd_dst + egc_dual_bwd_src (which re-reads M, Mt, GM, GMt by source).  Same values; sums in a different but
+// fixed order.
+constexpr int kDualDenseK = 4;  // sources per wave and pass: 16 per workgroup
+
+template <bool HAS_GL, bool STREAM>
+__global__ __launch_bounds__(kT) void egc_dual_bwd_lg_dense_kernel(
+    const float* __restrict__ GL, const float* __restrict__ GLt, const float* __restrict__ M,
+    const float* __restrict__ Mt, const float* __restrict__ P, const float* __restrict__ Pt,
+    const float* __restrict__ Q1, const float* __restrict__ Q0, const float* __restrict__ Q1t,
+    const float* __restrict__ Q0t, const int32_t* __restrict__ grp_seg_ptr, const int32_t* __restrict__ grp_src_ptr,
+    const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ seg_node, int H, float* __restrict__ GM,
+    float* __restrict__ GMt, float* __restrict__ GP, float* __restrict__ GPt, float* __restrict__ gb_partial,
+    float* __restrict__ gm_amax2, float* __restrict__ gp_amax2) {
+    constexpr int KMAX = kDualDenseK;
+    __shared__ float4 sh[2][2][kW][ALIGNN_WAVE];  // [buffer][value | tangent][wave][lane]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t ldp = 4 * (int64_t)H;
+    const int j = blockIdx.x;
+    const int p_beg = grp_src_ptr[j], n_src = grp_src_ptr[j + 1] - p_beg;
+    const int s_beg = grp_seg_ptr[j], s_end = grp_seg_ptr[j + 1];
+    float am = 0.0f, amt = 0.0f, pam = 0.0f, pamt = 0.0f;
+    for (int c0 = 0; c0 < H; c0 += 4 * ALIGNN_WAVE) {
+        const int f = c0 + 4 * lane;
+        const bool active = f < H;
+        float4 gb = f4_zero();
+        for (int qb = 0; qb < n_src || qb == 0; qb += kW * KMAX) {
+            float4 bh[KMAX], bht[KMAX], ga[KMAX], gat[KMAX], gbh[KMAX], gbht[KMAX];
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                const int q = qb + wave + kW * k;
+                const bool have = active && q < n_src;
+                bh[k] = have ? f4_ld(P + (int64_t)(p_beg + q) * ldp + 2 * H + f) : f4_zero();
+                bht[k] = have ? f4_ld(Pt + (int64_t)(p_beg + q) * ldp + 2 * H + f) : f4_zero();
+                ga[k] = gat[k] = gbh[k] = gbht[k] = f4_zero();
+            }
+            for (int s = s_beg; s < s_end; ++s) {
+                const int i = seg_node ? seg_node[s] : s;
+                const int e0 = seg_ptr[s];
+                int self_q = i - p_beg;  // the segment's own bond among the sources (self image) is not listed
+                if (self_q < 0 || self_q >= n_src || seg_ptr[s + 1] - e0 == n_src) self_q = -1;
+                float4 gbd = f4_zero(), gbdt = f4_zero();
+                if (active) {
+                    const float4 q1 = f4_ld(Q1 + (int64_t)i * H + f), q0 = f4_ld(Q0 + (int64_t)i * H + f);
+                    const float4 q1t = f4_ld(Q1t + (int64_t)i * H + f), q0t = f4_ld(Q0t + (int64_t)i * H + f);
+                    float4 m[KMAX], mt[KMAX], gm[KMAX], gmt[KMAX];
+                    int row[KMAX];
+#pragma unroll
+                    for (int k = 0; k < KMAX; ++k) {
+                        const int q = qb + wave + kW * k;
+                        row[k] = (q < n_src && q != self_q) ? e0 + q - ((self_q >= 0 && q > self_q) ? 1 : 0) : -1;
+                        if (row[k] >= 0) {
+                            m[k] = f4_lds<STREAM>(M + (int64_t)row[k] * H + f);
+                            mt[k] = f4_lds<STREAM>(Mt + (int64_t)row[k] * H + f);
+                            gm[k] = HAS_GL ? f4_lds<STREAM>(GL + (int64_t)row[k] * H + f) : f4_zero();
+                            gmt[k] = HAS_GL ? f4_lds<STREAM>(GLt + (int64_t)row[k] * H + f) : f4_zero();
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < KMAX; ++k) {
+                        if (row[k] >= 0) {
+#define ALIGNN_GDD(c)                                                                                     \
+    {                                                                                                     \
+        const float sg = sig_f(m[k].c), sp = sg * (1.0f - sg);                                            \
+        const float gs = q1.c * bh[k].c + q0.c + q1t.c * bht[k].c; /* adjoint of sigma */                  \
+        const float gst = q1t.c * bh[k].c + q0t.c;                 /* adjoint of sigma-dot */              \
+        gm[k].c += gs * sp + gst * sp * (1.0f - 2.0f * sg) * mt[k].c;                                      \
+        gmt[k].c += gst * sp;                                                                             \
+        const float sgt = sp * mt[k].c;                                                                   \
+        gbh[k].c += sg * q1.c + sgt * q1t.c;                                                              \
+        gbht[k].c += sg * q1t.c;                                                                          \
+    }
+                            ALIGNN_GDD(x) ALIGNN_GDD(y) ALIGNN_GDD(z) ALIGNN_GDD(w)
+#undef ALIGNN_GDD
+                            f4_sts<STREAM>(GM + (int64_t)row[k] * H + f, gm[k]);
+                            f4_sts<STREAM>(GMt + (int64_t)row[k] * H + f, gmt[k]);
+                            am = fmaxf(am, f4_absmax(gm[k]));
+                            amt = fmaxf(amt, f4_absmax(gmt[k]));
+                            ga[k] = f4_add(ga[k], gm[k]);
+                            gat[k] = f4_add(gat[k], gmt[k]);
+                            gbd = f4_add(gbd, gm[k]);
+                            gbdt = f4_add(gbdt, gmt[k]);
+                        }
+                    }
+                }
+                // g_Bd[s], g_Bd-dot[s]: the four waves' partial sums in wave order (double-buffered, one barrier per segment)
+                float4(*buf)[kW][ALIGNN_WAVE] = sh[(s - s_beg) & 1];
+                buf[0][wave][lane] = gbd;
+                buf[1][wave][lane] = gbdt;
+                __syncthreads();
+                if (wave == 0 && active) {
+                    float4 a = buf[0][0][lane], at = buf[1][0][lane];
+#pragma unroll
+                    for (int w = 1; w < kW; ++w) {
+                        a = f4_add(a, buf[0][w][lane]);
+                        at = f4_add(at, buf[1][w][lane]);
+                    }
+                    gb = f4_add(gb, a);
+                    float* out = GP + (int64_t)i * ldp + H + f;
+                    float* outt = GPt + (int64_t)i * ldp + H + f;
+                    if (qb > 0) {  // (written by this very thread in the previous pass)
+                        a = f4_add(f4_ld(out), a);
+                        at = f4_add(f4_ld(outt), at);
+                    }
+                    f4_st(out, a);
+                    f4_st(outt, at);
+                    pam = fmaxf(pam, f4_absmax(a));
+                    pamt = fmaxf(pamt, f4_absmax(at));
+                }
+            }
+            if (active) {
+#pragma unroll
+                for (int k = 0; k < KMAX; ++k) {
+                    const int q = qb + wave + kW * k;
+                    if (q < n_src) {
+                        f4_st(GP + (int64_t)(p_beg + q) * ldp + f, ga[k]);
+                        f4_st(GPt + (int64_t)(p_beg + q) * ldp + f, gat[k]);
+                        f4_st(GP + (int64_t)(p_beg + q) * ldp + 2 * H + f, gbh[k]);
+                        f4_st(GPt + (int64_t)(p_beg + q) * ldp + 2 * H + f, gbht[k]);
+                        pam = fmaxf(pam, fmaxf(f4_absmax(ga[k]), f4_absmax(gbh[k])));
+                        pamt = fmaxf(pamt, fmaxf(f4_absmax(gat[k]), f4_absmax(gbht[k])));
+                    }
+                }
+            }
+            __syncthreads();  // sh is reused by the next pass / feature panel
+        }
+        if (active && gb_partial && wave == 0) f4_st(gb_partial + (size_t)blockIdx.x * H + f, gb);
+    }
+    amax2_commit(am, amt, gm_amax2);
+    amax2_commit(pam, pamt, gp_amax2);
+}
+
 inline bool feat_ok(int F) { return F >= 4 && (F & 3) == 0 && F <= 1024; }
 inline bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -549,6 +687,31 @@ int alignn_egc_dual_bwd_src(const float* GM, const float* GMt, const float* M, c
     if (n == 0) return 0;
     hipLaunchKernelGGL(egc_dual_bwd_src_kernel, dim3(row_blocks(n)), dim3(kT), 0, (hipStream_t)stream, GM, GMt, M, Mt, q1,
                        q1t, out_ptr, out_slot, dst, (int)n, H, GP, GPt, gp_amax2);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_egc_dual_bwd_lg_dense(const float* GL, const float* GLt, const float* M, const float* Mt, const float* P,
+                                 const float* Pt, const float* q1, const float* q0, const float* q1t, const float* q0t,
+                                 int64_t m_rows, const int32_t* grp_seg_ptr, const int32_t* grp_src_ptr, int64_t n_groups,
+                                 const int32_t* seg_ptr, const int32_t* seg_node, int H, float* GM, float* GMt, float* GP,
+                                 float* GPt, float* gb_partial, float* gm_amax2, float* gp_amax2, alignn_stream_t stream) {
+    if (!feat_ok(H) || (GL == nullptr) != (GLt == nullptr) || n_groups < 0 || n_groups > INT32_MAX) return (int)hipErrorInvalidValue;
+    if (n_groups == 0) return 0;
+    const bool big = m_rows * (int64_t)H * 4 >= ((int64_t)128 << 20);  // the T-row tensors cannot stay in the last-level cache
+    const dim3 grid((unsigned)n_groups), block(kT);
+    hipStream_t st = (hipStream_t)stream;
+#define ALIGNN_LAUNCH_DD(GLF, ST)                                                                                         \
+    hipLaunchKernelGGL((egc_dual_bwd_lg_dense_kernel<GLF, ST>), grid, block, 0, st, GL, GLt, M, Mt, P, Pt, q1, q0, q1t, q0t, \
+                       grp_seg_ptr, grp_src_ptr, seg_ptr, seg_node, H, GM, GMt, GP, GPt, gb_partial, gm_amax2, gp_amax2)
+    if (GL != nullptr) {
+        if (big) ALIGNN_LAUNCH_DD(true, true);
+        else ALIGNN_LAUNCH_DD(true, false);
+    } else {
+        if (big) ALIGNN_LAUNCH_DD(false, true);
+        else ALIGNN_LAUNCH_DD(false, false);
+    }
+#undef ALIGNN_LAUNCH_DD
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }

@@ -55,6 +55,9 @@ def _track(rows):
     return ops._track(rows)
 
 
+DENSE_LG_REVERSE = True  # line graphs: the dual reverse of the gate pass as one dense-block kernel (tests flip it to compare)
+
+
 class Dual:
     """value ``p`` and tangent ``t`` of one activation (+ the max|.| scalars their producer tracked, or None)"""
 
@@ -199,15 +202,27 @@ def conv_bwd(entry, gx: Dual, gy, grads: _Grads):
         grads.add(conv.bn_edges.bias, e_red[0])
         grads.add(conv.bn_edges.weight, e_red[1])
     GM = Dual(_empty(m, H, like=x.p), _empty(m, H, like=x.p), _amax2(x.p) if _track(m) else None)
-    slabs = lib.alignn_dual_slabs(n)
-    gb_part = _empty(slabs, H, like=x.p)
-    check(lib.alignn_egc_dual_bwd_dst(ptr(GL.p) if GL else None, ptr(GL.t) if GL else None, ptr(M.p), ptr(M.t), ptr(P.p),
-                                      ptr(P.t), ptr(q1), ptr(q0), ptr(q1t), ptr(q0t), ptr(graph.seg_ptr),
-                                      ptr(graph.seg_node), ptr(graph.src), n, H, ptr(GM.p), ptr(GM.t), ptr(GP.p),
-                                      ptr(GP.t), ptr(gb_part), ptr(GM.amax), ptr(GP.amax), stream()), "egc_dual_bwd_dst")
-    check(lib.alignn_egc_dual_bwd_src(ptr(GM.p), ptr(GM.t), ptr(M.p), ptr(M.t), ptr(q1), ptr(q1t), ptr(graph.out_ptr),
-                                      ptr(graph.out_slot), ptr(graph.dst), n, H, ptr(GP.p), ptr(GP.t), ptr(GP.amax),
-                                      stream()), "egc_dual_bwd_src")
+    dense = (DENSE_LG_REVERSE and graph.grp_seg_ptr is not None and graph.dense_max_src > 0 and ops.FUSED_LG_BACKWARD
+             and ops.DENSE_LG_BACKWARD)
+    if dense:  # line graph: destination- and source-ordered halves in one pass over the dense blocks (6 row passes, not 10)
+        slabs = graph.grp_seg_ptr.numel() - 1
+        gb_part = _empty(slabs, H, like=x.p)
+        check(lib.alignn_egc_dual_bwd_lg_dense(ptr(GL.p) if GL else None, ptr(GL.t) if GL else None, ptr(M.p), ptr(M.t),
+                                               ptr(P.p), ptr(P.t), ptr(q1), ptr(q0), ptr(q1t), ptr(q0t), m,
+                                               ptr(graph.grp_seg_ptr), ptr(graph.grp_src_ptr), slabs, ptr(graph.seg_ptr),
+                                               ptr(graph.seg_node), H, ptr(GM.p), ptr(GM.t), ptr(GP.p), ptr(GP.t),
+                                               ptr(gb_part), ptr(GM.amax), ptr(GP.amax), stream()), "egc_dual_bwd_lg_dense")
+    else:
+        slabs = lib.alignn_dual_slabs(n)
+        gb_part = _empty(slabs, H, like=x.p)
+    if not dense:
+        check(lib.alignn_egc_dual_bwd_dst(ptr(GL.p) if GL else None, ptr(GL.t) if GL else None, ptr(M.p), ptr(M.t), ptr(P.p),
+                                          ptr(P.t), ptr(q1), ptr(q0), ptr(q1t), ptr(q0t), ptr(graph.seg_ptr),
+                                          ptr(graph.seg_node), ptr(graph.src), n, H, ptr(GM.p), ptr(GM.t), ptr(GP.p),
+                                          ptr(GP.t), ptr(gb_part), ptr(GM.amax), ptr(GP.amax), stream()), "egc_dual_bwd_dst")
+        check(lib.alignn_egc_dual_bwd_src(ptr(GM.p), ptr(GM.t), ptr(M.p), ptr(M.t), ptr(q1), ptr(q1t), ptr(graph.out_ptr),
+                                          ptr(graph.out_slot), ptr(graph.dst), n, H, ptr(GP.p), ptr(GP.t), ptr(GP.amax),
+                                          stream()), "egc_dual_bwd_src")
     wcat, _ = conv._fused_node_projection()
     res = conv.residual
     g_x = _dgrad(GP, wcat, gx if res else None)

@@ -432,6 +432,15 @@ int alignn_egc_dual_bwd_dst(const float* GL, const float* GLt, const float* M, c
 int alignn_egc_dual_bwd_src(const float* GM, const float* GMt, const float* M, const float* Mt, const float* q1,
                             const float* q1t, const int32_t* out_ptr, const int32_t* out_slot, const int32_t* dst,
                             int64_t n, int H, float* GP, float* GPt, float* gp_amax2, alignn_stream_t stream);
+/* egc_dual_bwd_dst + egc_dual_bwd_src as ONE pass for line graphs with dense, source-sorted blocks (see
+ * alignn_egc_bwd_lg_dense: one workgroup per centre atom, rows by index arithmetic): M, Mt, GL, GLt read once, GM, GMt
+ * written once - 6 T-row passes instead of 10; same outputs, sums in a different but fixed order; gb_partial
+ * [n_groups][H]. */
+int alignn_egc_dual_bwd_lg_dense(const float* GL, const float* GLt, const float* M, const float* Mt, const float* P,
+                                 const float* Pt, const float* q1, const float* q0, const float* q1t, const float* q0t,
+                                 int64_t m_rows, const int32_t* grp_seg_ptr, const int32_t* grp_src_ptr, int64_t n_groups,
+                                 const int32_t* seg_ptr, const int32_t* seg_node, int H, float* GM, float* GMt, float* GP,
+                                 float* GPt, float* gb_partial, float* gm_amax2, float* gp_amax2, alignn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Periodic k-nearest-neighbour bond lists on the device (csrc/knn.hip).

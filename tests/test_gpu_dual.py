@@ -179,3 +179,47 @@ def test_forward_over_reverse_equals_reverse_over_reverse():
         worst = max(worst, e)
         assert e < 2e-3, (k, e)
     print("forward-over-reverse vs reverse-over-reverse: worst per-parameter gradient difference", worst)
+
+
+@pytest.mark.parametrize("shape", ["small", "deg_over_16"])
+def test_dense_block_dual_reverse_equals_the_two_pass_kernels(shape):
+    """alignn_egc_dual_bwd_lg_dense (one pass over a line graph's dense blocks, 6 row passes) against alignn_egc_dual_bwd_dst
+    + _src (10): the same parameter gradients of an energy + force + stress loss up to summation order - on a small batch
+    and on one whose atoms have more than 16 in-edges (the kernel then takes several passes of 16 sources)."""
+    from alignn_amd import ALIGNNAtomWise, ALIGNNAtomWiseConfig
+
+    raw = make_batch(3, 14, seed0=31) if shape == "small" else make_batch(4, 3, seed0=11)  # tiny cells: many self images, up to 19 in-edges
+    batch = GraphBatch.from_raw(raw, device=DEV)
+    if shape == "deg_over_16":
+        sp = batch.g.seg_ptr.long()
+        assert int((sp[1:] - sp[:-1]).max()) > 16, "this case is meant to exceed 16 in-edges per atom"
+    assert batch.lg.dense_max_src > 0
+    gen = torch.Generator().manual_seed(4)
+    B = raw.batch_size
+    te, tf, ts = (torch.randn(B, generator=gen).to(DEV), torch.randn(raw.num_nodes, 3, generator=gen).to(DEV),
+                  torch.randn(B, 3, 3, generator=gen).to(DEV))
+    outs = []
+    for dense in (True, False):
+        torch.manual_seed(7)
+        cfg = ALIGNNAtomWiseConfig(name="alignn_atomwise", alignn_layers=2, gcn_layers=1, hidden_features=64,
+                                   embedding_features=32, atom_input_features=92, calculate_gradient=True,
+                                   stresswise_weight=0.05)
+        model = ALIGNNAtomWise(cfg).to(DEV).train()
+        ff2.DENSE_LG_REVERSE = dense
+        try:
+            res = model(batch)
+            loss = F.l1_loss(res["out"], te) + F.l1_loss(res["grad"], tf) + 0.05 * F.l1_loss(res["stresses"], ts)
+            loss.backward()
+            torch.cuda.synchronize()
+        finally:
+            ff2.DENSE_LG_REVERSE = True
+        outs.append({k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+    ga, gb = outs
+    assert ga.keys() == gb.keys() and len(ga) > 40
+    gmax = max(float(v.abs().max()) for v in gb.values())
+    worst = 0.0
+    for k in ga:
+        e = float((ga[k] - gb[k]).abs().max()) / max(float(gb[k].abs().max()), 1e-3 * gmax)
+        worst = max(worst, e)
+        assert e < 2e-5, (k, e)
+    print(f"dense-block dual reverse vs two passes ({shape}): worst per-parameter gradient difference {worst:.2e}")
