@@ -478,6 +478,52 @@ def main():
                  "host_enqueue_ms_per_step": round(e_enq / args.eager_steps * 1e3, 3)}
         log(f"eager launches: {edt * 1e3:.2f} ms/step")
 
+    # ---- the dominant kernel INSIDE a training step (measured here, before any hipGraph exists in the process - see the
+    # note on eager steps above): HIP events around every T-row launch of the f16x3 NT kernel during
+    # one eagerly launched step (the weight-gradient GEMMs of the previous layer run beside it on the side stream, as
+    # in every real step) - reported in `roofline.in_step` next to the stand-alone micro-timing
+    in_step = None
+    if args.model == "alignn":  # (every rank runs the step: it contains the gradient all-reduce)
+        if rank == 0:
+            ops.KERNEL_TIMER = {"min_rows": raw.num_triplets, "events": []}
+        try:
+            eager_step()
+            torch.cuda.synchronize()
+            ev = ops.KERNEL_TIMER["events"] if rank == 0 else []
+        finally:
+            ops.KERNEL_TIMER = None
+        # T-row launches of the f16x3 NT kernel family by epilogue variant; algorithmic (compulsory, unique-footprint)
+        # rows of H fp32 moved per output row: plain (read A, write C) 2; addend 3; gather 2 + the two E-row tables
+        # A[u], Bd[v] it gathers from, counted ONCE (E/T rows each: they are re-read from L2/MALL, not from HBM, when
+        # the kernel is doing well); bnred (+ the pre-activation read for the BatchNorm-backward sums) 3, with addend 4
+        tables = 2.0 * raw.num_edges / raw.num_triplets
+        rows_moved = {"plain": 2, "addend": 3, "gather": 2 + tables, "bnred": 3, "bnred_addend": 4, "stats": 2}
+        by = {}
+        for (label, n_, k_, e0, e1) in ev:
+            if n_ == H and k_ == H:
+                by.setdefault(label, []).append(e0.elapsed_time(e1))
+        if by:
+            row_bytes = raw.num_triplets * H * 4.0
+            in_step = {"how": "HIP events on the launch stream around every T-row launch (M=T, N=K=256) of one eagerly "
+                              "launched training step, by epilogue variant; side-stream weight-gradient GEMMs share the CUs"}
+            for label, ts in sorted(by.items()):
+                ms_ = sum(ts) / len(ts)
+                gbs_ = rows_moved[label] * row_bytes / (ms_ * 1e-3) / 1e9
+                in_step[label] = {"launches": len(ts), "ms_per_launch": round(ms_, 4), "min_ms": round(min(ts), 4),
+                                  "max_ms": round(max(ts), 4), "algorithmic_rows_per_output_row": round(rows_moved[label], 3),
+                                  "GBps": round(gbs_, 1), "frac": round(gbs_ / HBM_PEAK_GBS, 4)}
+            n_l = sum(len(ts) for ts in by.values())
+            t_all = sum(sum(ts) for ts in by.values())
+            b_all = sum(rows_moved[label] * row_bytes * len(ts) for label, ts in by.items())
+            pmc = None
+            pv = PMC["variants"] if (PMC is not None and raw.num_triplets == PMC["triplets"]) else {}
+            if pv and all(label in pv for label in by):
+                pmc = sum(pv[label]["bytes_per_launch"] * len(ts) for label, ts in by.items()) / n_l
+            in_step["family"] = {"launches_per_step": n_l, "ms_per_launch": t_all / n_l, "algorithmic_bytes_per_launch": b_all / n_l,
+                                 "GBps": b_all / (t_all * 1e-3) / 1e9, "traffic": pmc}
+
+    torch.cuda.reset_peak_memory_stats(dev)  # (peak_hbm_GB below: the training steps, not the per-operator measurement run above)
+
     # ---- streamed batches (informational, N=1): a FRESH batch every step through alignn_amd.loader - one pinned
     # 2.4 MB buffer per batch over PCIe, CSR + L(g) + cosines rebuilt on a staging stream under the previous step.
     # `value` above stays the resident-input number the contract asks for; this is the PCIe-inclusive rate.
@@ -625,49 +671,6 @@ def main():
         fence()
         eager["ms_per_step_after_a_graph_replay"] = round((time.perf_counter() - t0) / args.eager_steps * 1e3, 3)
         log(f"eager launches after the capture: {eager['ms_per_step_after_a_graph_replay']} ms/step")
-
-    # ---- the dominant kernel INSIDE a training step: HIP events around every T-row launch of the f16x3 NT kernel during
-    # one eagerly launched step (the weight-gradient GEMMs of the previous layer run beside it on the side stream, as
-    # in every real step) - reported in `roofline.in_step` next to the stand-alone micro-timing
-    in_step = None
-    if args.model == "alignn":  # (every rank runs the step: it contains the gradient all-reduce)
-        if rank == 0:
-            ops.KERNEL_TIMER = {"min_rows": raw.num_triplets, "events": []}
-        try:
-            eager_step()
-            torch.cuda.synchronize()
-            ev = ops.KERNEL_TIMER["events"] if rank == 0 else []
-        finally:
-            ops.KERNEL_TIMER = None
-        # T-row launches of the f16x3 NT kernel family by epilogue variant; algorithmic (compulsory, unique-footprint)
-        # rows of H fp32 moved per output row: plain (read A, write C) 2; addend 3; gather 2 + the two E-row tables
-        # A[u], Bd[v] it gathers from, counted ONCE (E/T rows each: they are re-read from L2/MALL, not from HBM, when
-        # the kernel is doing well); bnred (+ the pre-activation read for the BatchNorm-backward sums) 3, with addend 4
-        tables = 2.0 * raw.num_edges / raw.num_triplets
-        rows_moved = {"plain": 2, "addend": 3, "gather": 2 + tables, "bnred": 3, "bnred_addend": 4, "stats": 2}
-        by = {}
-        for (label, n_, k_, e0, e1) in ev:
-            if n_ == H and k_ == H:
-                by.setdefault(label, []).append(e0.elapsed_time(e1))
-        if by:
-            row_bytes = raw.num_triplets * H * 4.0
-            in_step = {"how": "HIP events on the launch stream around every T-row launch (M=T, N=K=256) of one eagerly "
-                              "launched training step, by epilogue variant; side-stream weight-gradient GEMMs share the CUs"}
-            for label, ts in sorted(by.items()):
-                ms_ = sum(ts) / len(ts)
-                gbs_ = rows_moved[label] * row_bytes / (ms_ * 1e-3) / 1e9
-                in_step[label] = {"launches": len(ts), "ms_per_launch": round(ms_, 4), "min_ms": round(min(ts), 4),
-                                  "max_ms": round(max(ts), 4), "algorithmic_rows_per_output_row": round(rows_moved[label], 3),
-                                  "GBps": round(gbs_, 1), "frac": round(gbs_ / HBM_PEAK_GBS, 4)}
-            n_l = sum(len(ts) for ts in by.values())
-            t_all = sum(sum(ts) for ts in by.values())
-            b_all = sum(rows_moved[label] * row_bytes * len(ts) for label, ts in by.items())
-            pmc = None
-            pv = PMC["variants"] if (PMC is not None and raw.num_triplets == PMC["triplets"]) else {}
-            if pv and all(label in pv for label in by):
-                pmc = sum(pv[label]["bytes_per_launch"] * len(ts) for label, ts in by.items()) / n_l
-            in_step["family"] = {"launches_per_step": n_l, "ms_per_launch": t_all / n_l, "algorithmic_bytes_per_launch": b_all / n_l,
-                                 "GBps": b_all / (t_all * 1e-3) / 1e9, "traffic": pmc}
 
     out = None
     if rank == 0:
