@@ -279,7 +279,19 @@ def host_calibration(dev):
     out["event_record_wait_us"] = round(per_call(pair, 2000), 3)
     torch.cuda.synchronize()
     out["host_cpus"] = os.cpu_count()
-    del ctypes
+    # ... and what this GPU gives a plain streaming copy (boxes of one pool differ by a few per cent in sustained HBM rate):
+    # 10 x (read 0.5 GiB + write 0.5 GiB), HIP events
+    src = torch.empty(128 << 20, dtype=torch.float32, device=dev).normal_()
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    out["gpu_copy_GBps"] = round(10 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+    del ctypes, src, dst
     return out
 
 
@@ -781,7 +793,7 @@ def main():
                 "algorithmic_bytes_over_step_time_frac_of_8TBs": round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "mfma_frac_of_157TF": round(step_flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4),
             },
-            "host_calibration": host_calibration(dev),
+            "host_calibration": host_calibration(dev),  # (+ gpu_copy_GBps: this GPU's streaming-copy rate)
             "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3),
             "optimizer": opt_desc,
             "multi_gpu": multi,

@@ -90,3 +90,21 @@ def test_random_multigraphs_with_self_loops_and_isolated_atoms(seed):
 def test_periodic_crystal_batch():
     raw = make_batch(5, 17, seed0=3)  # small cells: self-image bonds and multi-edges
     _compare(raw.u, raw.v, raw.num_nodes)
+
+
+def test_pack_derives_sizes_and_small_tables_on_the_host():
+    """loader.pack computes what the one-call staging needs before it runs: T = rows of L(g), the dense-block bound, the atom
+    offsets and the cell volumes - no device value is read back later."""
+    from alignn_amd import loader
+
+    raw = make_batch(6, 23, seed0=9)
+    p = loader.pack_raw(raw, target=np.zeros(6, dtype=np.float32), pin=False)
+    assert p.num_triplets == raw.num_triplets and p.num_edges == raw.num_edges and p.num_nodes == raw.num_nodes
+    g = build_csr(torch.from_numpy(raw.u), torch.from_numpy(raw.v), raw.num_nodes)
+    assert p.max_in_degree == line_graph_of(g).dense_max_src
+    gp = p.host("graph_ptr").numpy()
+    assert gp.dtype == np.int32 and np.array_equal(gp, np.concatenate([[0], np.cumsum(raw.batch_num_nodes)]))
+    vol = p.host("volume").numpy()
+    assert np.allclose(vol, np.abs(np.linalg.det(raw.lattice.astype(np.float64))), rtol=1e-6)
+    with pytest.raises(ValueError):
+        loader.pack(raw.u, raw.v + raw.num_nodes, raw.batch_num_nodes, raw.r, raw.lattice, atom_features=raw.atom_features, pin=False)
