@@ -210,3 +210,25 @@ def test_flat_adamw_rehoming_is_followed():
         return _steps(m, [batch] * 3, [target] * 3, use_c, opt_cls=mkopt)
 
     _same(run(True), run(False), "flat adamw")
+
+
+def test_irregular_graphs_isolated_atoms_self_loops_single_graph():
+    """A hand-made batch the synthetic generator never produces: atoms nobody points to, an atom with no bond at all, self
+    loops, multi-edges, one graph of a single atom - through both launch paths, bit for bit."""
+    from alignn_amd import ops as _ops
+
+    u = torch.tensor([0, 1, 1, 2, 2, 2, 3, 0, 5, 5, 6, 7, 7, 8, 8, 8, 9, 9])
+    v = torch.tensor([1, 0, 2, 1, 2, 2, 0, 3, 6, 6, 5, 8, 7, 7, 8, 9, 8, 8])  # atom 4: isolated; 2, 7, 8: self loops; multi-edges
+    bnn = torch.tensor([5, 2, 3, 1])  # last graph: atom 10 alone, no bonds
+    n = int(bnn.sum())
+    gen = torch.Generator().manual_seed(3)
+    r = torch.randn(u.numel(), 3, generator=gen) + 0.5
+    af = torch.randn(n, 92, generator=gen)
+    batch = GraphBatch.from_coo(u, v, n, bnn, atom_features=af, r=r, device=DEV, build_line_graph=True)
+    batch.h = _ops.bond_cosines(batch.r, batch.lg.src, batch.lg.dst)
+    assert batch.lg.n_edges > 0 and batch.batch_size == 4
+    target = torch.randn(4, generator=gen).to(DEV)
+    a = _steps(_mk(5, alignn_layers=2, gcn_layers=2, hidden_features=64, embedding_features=32), [batch] * 2, [target] * 2, True)
+    b = _steps(_mk(5, alignn_layers=2, gcn_layers=2, hidden_features=64, embedding_features=32), [batch] * 2, [target] * 2, False)
+    _same(a, b, "irregular")
+    assert all(bool(torch.isfinite(t).all()) for t in a.values())
