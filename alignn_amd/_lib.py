@@ -52,6 +52,7 @@ SIGNATURES = {
     "alignn_ln_silu_dual_fwd": (_i32, [_p, _p, _i64, _p, _p, _i64, _p, _p, _f32, _p, _p, _i64, _p, _i64, _i32, _p, _p]),
     "alignn_ln_silu_dual_bwd": (_i32, [_p, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p, _i64, _p, _i64, _i32, _p, _p]),
     "alignn_egc_gate_dual_fwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p]),
+    "alignn_egc_gate_dual_fwd_tangent": (_i32, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p]),
     "alignn_egc_node_dual_bwd": (_i32, [_p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p]),
     "alignn_egc_dual_bwd_dst": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p]),
     "alignn_egc_dual_bwd_src": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p]),

@@ -114,12 +114,14 @@ __global__ __launch_bounds__(kT) void ln_silu_dual_fwd_kernel(
                 ALIGNN_LN_DUAL(x) ALIGNN_LN_DUAL(y) ALIGNN_LN_DUAL(z) ALIGNN_LN_DUAL(w)
 #undef ALIGNN_LN_DUAL
                 if (R) {
-                    o = f4_add(o, f4_ld(R + r * ldr + f));
+                    if (Y) o = f4_add(o, f4_ld(R + r * ldr + f));
                     ot = f4_add(ot, f4_ld(Rt + r * ldr + f));
                 }
-                f4_st(Y + r * ldy + f, o);
+                if (Y) {  // (NULL: the caller holds the value output already - tangent-only forward, see ff2.py)
+                    f4_st(Y + r * ldy + f, o);
+                    am = fmaxf(am, f4_absmax(o));
+                }
                 f4_st(Yt + r * ldy + f, ot);
-                am = fmaxf(am, f4_absmax(o));
                 amt = fmaxf(amt, f4_absmax(ot));
             }
         }
@@ -293,6 +295,51 @@ __global__ __launch_bounds__(kT) void egc_gate_dual_fwd_kernel(
             f4_st(XPREt + (int64_t)i * H + f, f4_add(f4_ld(Pt + (int64_t)i * ldp + 3 * H + f), ht));
             f4_st(S0 + (int64_t)i * H + f, s0);
             f4_st(HH + (int64_t)i * H + f, h);
+            f4_st(S0t + (int64_t)i * H + f, s0t);
+            f4_st(HHt + (int64_t)i * H + f, ht);
+        }
+    }
+}
+
+// The TANGENT half of the gate pass alone, for a forward whose values are already known (the force evaluation that preceded
+// the dual pass computed them: M holds m, S0 / HH the node sums): Mt holds Ct on entry and mt on exit; writes xpre_t, S0_t,
+// h_t.  One read of m and one read + write of mt per row instead of two of each.  Same formulas as egc_gate_dual_fwd_kernel.
+__global__ __launch_bounds__(kT) void egc_gate_dual_tan_kernel(
+    const float* __restrict__ P, const float* __restrict__ Pt, const float* __restrict__ M, float* __restrict__ Mt,
+    const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ seg_node, const int32_t* __restrict__ src,
+    int n_seg, int H, float* __restrict__ XPREt, const float* __restrict__ S0, const float* __restrict__ HH,
+    float* __restrict__ S0t, float* __restrict__ HHt) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t ldp = 4 * (int64_t)H;
+    const int first = blockIdx.x * kW + wave, stride = gridDim.x * kW;
+    for (int c0 = 0; c0 < H; c0 += 4 * ALIGNN_WAVE) {
+        const int f = c0 + 4 * lane;
+        if (f >= H) continue;
+        for (int s = first; s < n_seg; s += stride) {
+            const int beg = seg_ptr[s], end = seg_ptr[s + 1];
+            const int i = seg_node ? seg_node[s] : s;
+            const float4 bdt = f4_ld(Pt + (int64_t)i * ldp + H + f);
+            float4 s1t = f4_zero(), s0t = f4_zero();
+            for (int e = beg; e < end; ++e) {
+                const int64_t u = src[e];
+                const float4 m = f4_ld(M + (int64_t)e * H + f);
+                const float4 mt = f4_add(f4_add(f4_ld(Pt + u * ldp + f), bdt), f4_ld(Mt + (int64_t)e * H + f));
+                const float4 bh = f4_ld(P + u * ldp + 2 * H + f), bht = f4_ld(Pt + u * ldp + 2 * H + f);
+                f4_st(Mt + (int64_t)e * H + f, mt);
+                const float4 sg = f4_sigmoid(m);
+                const float4 sgt = make_float4(sg.x * (1.0f - sg.x) * mt.x, sg.y * (1.0f - sg.y) * mt.y,
+                                               sg.z * (1.0f - sg.z) * mt.z, sg.w * (1.0f - sg.w) * mt.w);
+                s1t = f4_fma(sgt, bh, f4_fma(sg, bht, s1t));
+                s0t = f4_add(s0t, sgt);
+            }
+            const float4 s0 = f4_ld(S0 + (int64_t)i * H + f), h = f4_ld(HH + (int64_t)i * H + f);
+            float4 ht;
+            ht.x = (s1t.x - h.x * s0t.x) / (s0.x + ALIGNN_EPS_GATE);
+            ht.y = (s1t.y - h.y * s0t.y) / (s0.y + ALIGNN_EPS_GATE);
+            ht.z = (s1t.z - h.z * s0t.z) / (s0.z + ALIGNN_EPS_GATE);
+            ht.w = (s1t.w - h.w * s0t.w) / (s0.w + ALIGNN_EPS_GATE);
+            f4_st(XPREt + (int64_t)i * H + f, f4_add(f4_ld(Pt + (int64_t)i * ldp + 3 * H + f), ht));
             f4_st(S0t + (int64_t)i * H + f, s0t);
             f4_st(HHt + (int64_t)i * H + f, ht);
         }
@@ -649,6 +696,18 @@ int alignn_egc_gate_dual_fwd(const float* P, const float* Pt, float* M, float* M
     if (n == 0) return 0;
     hipLaunchKernelGGL(egc_gate_dual_fwd_kernel, dim3(row_blocks(n)), dim3(kT), 0, (hipStream_t)stream, P, Pt, M, Mt,
                        seg_ptr, seg_node, src, (int)n, H, xpre, xpre_t, s0, hh, s0t, hht);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_egc_gate_dual_fwd_tangent(const float* P, const float* Pt, const float* M, float* Mt, const int32_t* seg_ptr,
+                                     const int32_t* seg_node, const int32_t* src, int64_t n, int64_t m, int H, float* xpre_t,
+                                     const float* s0, const float* hh, float* s0t, float* hht, alignn_stream_t stream) {
+    if (!feat_ok(H)) return (int)hipErrorInvalidValue;
+    (void)m;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(egc_gate_dual_tan_kernel, dim3(row_blocks(n)), dim3(kT), 0, (hipStream_t)stream, P, Pt, M, Mt, seg_ptr,
+                       seg_node, src, (int)n, H, xpre_t, s0, hh, s0t, hht);
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }

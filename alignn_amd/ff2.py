@@ -58,16 +58,31 @@ def _track(rows):
 DENSE_LG_REVERSE = True  # line graphs: the dual reverse of the gate pass as one dense-block kernel (tests flip it to compare)
 
 
+# The dual forward repeats, value for value, what the force evaluation in ForcesFn.forward has just computed (12 T-row
+# projections and the value half of every dual kernel).  With this on, that evaluation files its activations
+# (ops.FORWARD_TAPE) and the dual forward computes TANGENTS only: tangent projections, alignn_egc_gate_dual_fwd_tangent,
+# alignn_ln_silu_dual_fwd with Y = NULL.  Tests flip it to compare.
+REUSE_FORWARD = True
+
+
 class Dual:
-    """value ``p`` and tangent ``t`` of one activation (+ the max|.| scalars their producer tracked, or None)"""
+    """value ``p`` and tangent ``t`` of one activation (+ the max|.| scalars their producer tracked, or None; ``amax_p``: the
+    value's scalar when it comes from another producer than the tangent's - a value taken over from the force evaluation)"""
 
-    __slots__ = ("p", "t", "amax")
+    __slots__ = ("p", "t", "amax", "amax_p")
 
-    def __init__(self, p, t, amax=None):
-        self.p, self.t, self.amax = p, t, amax
+    def __init__(self, p, t, amax=None, amax_p=None):
+        self.p, self.t, self.amax, self.amax_p = p, t, amax, amax_p
 
     def am(self, i):
+        if i == 0 and self.amax_p is not None:
+            return self.amax_p
         return None if self.amax is None else self.amax[i:i + 1]
+
+
+def _taken_over(t):
+    """(tensor without autograd history, its tracked max|.| or None) of an activation of the force evaluation"""
+    return t.detach(), ops.get_amax(t)
 
 
 def _project(x: Dual, w, b):
@@ -75,17 +90,20 @@ def _project(x: Dual, w, b):
     return (ops.project(x.p, w, b, a_amax=x.am(0)), ops.project(x.t, w, None, a_amax=x.am(1)))
 
 
-def _ln_fwd(x: Dual, res, gamma, beta):
+def _ln_fwd(x: Dual, res, gamma, beta, value_out=None):
+    """``value_out``: the value output is known already (taken over from the force evaluation): only the tangent is written."""
     lib = _lib.load()
     rows, F = x.p.shape
-    yp, yt = _empty(rows, F, like=x.p), _empty(rows, F, like=x.p)
+    known = value_out is not None
+    yp = value_out[0] if known else _empty(rows, F, like=x.p)
+    yt = _empty(rows, F, like=x.p)
     stats = _empty(rows, 2, like=x.p)
     amax = _amax2(x.p) if _track(rows) else None
     check(lib.alignn_ln_silu_dual_fwd(ptr(x.p), ptr(x.t), x.p.stride(0), ptr(res.p) if res else None,
                                       ptr(res.t) if res else None, res.p.stride(0) if res else 0, ptr(gamma), ptr(beta),
-                                      LN_EPS, ptr(yp), ptr(yt), F, ptr(stats), rows, F, ptr(amax), stream()),
+                                      LN_EPS, None if known else ptr(yp), ptr(yt), F, ptr(stats), rows, F, ptr(amax), stream()),
           "ln_silu_dual_fwd")
-    return Dual(yp, yt, amax), stats
+    return Dual(yp, yt, amax, value_out[1] if known else None), stats
 
 
 def _ln_bwd(g: Dual, x: Dual, gamma, beta, stats, out_p=None, out_t=None, amax=None):
@@ -139,10 +157,15 @@ def _dgrad(g: Dual, w, addend: Dual = None):
 # ---------------------------------------------------------------------------------------------
 # layers
 # ---------------------------------------------------------------------------------------------
-def mlp_fwd(layer, x: Dual, tape):
+def mlp_fwd(layer, x: Dual, tape, fwd=None):
     lin, ln = layer.layer[0], layer.layer[1]
-    pre = Dual(*_project(x, lin.weight, lin.bias))
-    y, stats = _ln_fwd(pre, None, ln.weight, ln.bias)
+    ent = fwd.get(lin.weight.data_ptr()) if fwd else None
+    if ent is not None and ent[0] == "mlp" and ent[2].shape[0] == x.t.shape[0]:
+        pre = Dual(ent[2].detach(), ops.project(x.t, lin.weight, None, a_amax=x.am(1)))  # the tangent projection only
+        y, stats = _ln_fwd(pre, None, ln.weight, ln.bias, value_out=_taken_over(ent[3]))
+    else:
+        pre = Dual(*_project(x, lin.weight, lin.bias))
+        y, stats = _ln_fwd(pre, None, ln.weight, ln.bias)
     tape.append(("mlp", layer, x, pre, stats))
     return y
 
@@ -158,11 +181,30 @@ def mlp_bwd(entry, g: Dual, grads: _Grads, need_input_grad=True):
     return _dgrad(gpre, lin.weight) if need_input_grad else None
 
 
-def conv_fwd(conv, graph: CSRGraph, x: Dual, y: Dual, need_y, tape):
+def conv_fwd(conv, graph: CSRGraph, x: Dual, y: Dual, need_y, tape, fwd=None):
     lib = _lib.load()
     n, H = x.p.shape
     m = y.p.shape[0]
     wcat, bcat = conv._fused_node_projection()
+    res = conv.residual
+    ent = fwd.get(conv.edge_gate.weight.data_ptr()) if fwd else None
+    if (ent is not None and ent[0] == "conv" and tuple(ent[3].shape) == (n, 4 * H) and tuple(ent[4].shape) == (m, H)
+            and (ent[9] is not None or not need_y)):
+        # values from the force evaluation; here the tangents only: two tangent projections, the tangent half of the gate pass
+        _, _x, _y, P_p, M_p, xpre_p, s0, hh, xo, yo = ent
+        P = Dual(P_p.detach(), ops.project(x.t, wcat, None, a_amax=x.am(1)))
+        M = Dual(M_p.detach(), ops.project(y.t, conv.edge_gate.weight, None, a_amax=y.am(1)))
+        xpre = Dual(xpre_p.detach(), _empty(n, H, like=x.p))
+        s0t, hht = _empty(n, H, like=x.p), _empty(n, H, like=x.p)
+        check(lib.alignn_egc_gate_dual_fwd_tangent(ptr(P.p), ptr(P.t), ptr(M.p), ptr(M.t), ptr(graph.seg_ptr), ptr(graph.seg_node),
+                                                   ptr(graph.src), n, m, H, ptr(xpre.t), ptr(s0), ptr(hh), ptr(s0t), ptr(hht),
+                                                   stream()), "egc_gate_dual_fwd_tangent")
+        x_out, n_stats = _ln_fwd(xpre, x if res else None, conv.bn_nodes.weight, conv.bn_nodes.bias, value_out=_taken_over(xo))
+        y_out, e_stats = (None, None)
+        if need_y:
+            y_out, e_stats = _ln_fwd(M, y if res else None, conv.bn_edges.weight, conv.bn_edges.bias, value_out=_taken_over(yo))
+        tape.append(("conv", conv, graph, x, y, P, M, xpre, (s0, hh, s0t, hht), n_stats, e_stats))
+        return x_out, y_out
     P = Dual(*_project(x, wcat, bcat))
     M = Dual(*_project(y, conv.edge_gate.weight, conv.edge_gate.bias))
     xpre = Dual(_empty(n, H, like=x.p), _empty(n, H, like=x.p))
@@ -170,7 +212,6 @@ def conv_fwd(conv, graph: CSRGraph, x: Dual, y: Dual, need_y, tape):
     check(lib.alignn_egc_gate_dual_fwd(ptr(P.p), ptr(P.t), ptr(M.p), ptr(M.t), ptr(graph.seg_ptr), ptr(graph.seg_node),
                                        ptr(graph.src), n, m, H, ptr(xpre.p), ptr(xpre.t), ptr(s0), ptr(hh), ptr(s0t),
                                        ptr(hht), stream()), "egc_gate_dual_fwd")
-    res = conv.residual
     x_out, n_stats = _ln_fwd(xpre, x if res else None, conv.bn_nodes.weight, conv.bn_nodes.bias)
     y_out, e_stats = (None, None)
     if need_y:
@@ -268,7 +309,7 @@ def supported(cfg) -> bool:
             and (cfg.stresswise_weight == 0 or cfg.batch_stress))
 
 
-def dual_pass(model, b: GraphBatch, rt, g_energy, gt_energy):
+def dual_pass(model, b: GraphBatch, rt, g_energy, gt_energy, fwd=None):
     """Parameter gradients of  sum_g g_energy[g] E_g + sum_g gt_energy[g] (D_rt E)_g  -> {id(param): (param, grad)}"""
     cfg = model.config
     tape, grads = [], _Grads()
@@ -277,19 +318,19 @@ def dual_pass(model, b: GraphBatch, rt, g_energy, gt_energy):
     d = r.norm(dim=1)
     dt = (r * rt).sum(1) / d
     af = b.atom_features
-    x = mlp_fwd(model.atom_embedding, Dual(af, torch.zeros_like(af)), tape)
-    y = mlp_fwd(model.edge_embedding[2], mlp_fwd(model.edge_embedding[1], _rbf_dual(d, dt, model.edge_embedding[0]), tape), tape)
+    x = mlp_fwd(model.atom_embedding, Dual(af, torch.zeros_like(af)), tape, fwd)
+    y = mlp_fwd(model.edge_embedding[2], mlp_fwd(model.edge_embedding[1], _rbf_dual(d, dt, model.edge_embedding[0]), tape, fwd), tape, fwd)
     if n_a > 0:
         if cfg.lg_on_fly:
             h, ht = _cos_dual(r, rt, b.lg)
         else:
             h, ht = b.h, torch.zeros_like(b.h)
-        z = mlp_fwd(model.angle_embedding[2], mlp_fwd(model.angle_embedding[1], _rbf_dual(h, ht, model.angle_embedding[0]), tape), tape)
+        z = mlp_fwd(model.angle_embedding[2], mlp_fwd(model.angle_embedding[1], _rbf_dual(h, ht, model.angle_embedding[0]), tape, fwd), tape, fwd)
     for i, layer in enumerate(model.alignn_layers):
-        x, m = conv_fwd(layer.node_update, b.g, x, y, True, tape)
-        y, z = conv_fwd(layer.edge_update, b.lg, m, z, i + 1 < n_a, tape)
+        x, m = conv_fwd(layer.node_update, b.g, x, y, True, tape, fwd)
+        y, z = conv_fwd(layer.edge_update, b.lg, m, z, i + 1 < n_a, tape, fwd)
     for i, layer in enumerate(model.gcn_layers):
-        x, y = conv_fwd(layer, b.g, x, y, i + 1 < n_g, tape)
+        x, y = conv_fwd(layer, b.g, x, y, i + 1 < n_g, tape, fwd)
     # readout: E_g = fc(mean_i x_i)  (alignn_atomwise.py:464-466); reverse with the two seeds
     counts = (b.graph_ptr[1:] - b.graph_ptr[:-1]).to(torch.float32)
     hp = ops.AvgPoolFn.apply(x.p, b.graph_ptr)
@@ -330,8 +371,12 @@ class ForcesFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, model, batch, *params):
-        with torch.enable_grad(), ops.no_param_grad():
-            res = model._forward_fused(batch, True)
+        prev, ops.FORWARD_TAPE = ops.FORWARD_TAPE, ({} if REUSE_FORWARD else None)
+        try:
+            with torch.enable_grad(), ops.no_param_grad():
+                res = model._forward_fused(batch, True)
+        finally:
+            ctx.fwd_tape, ops.FORWARD_TAPE = ops.FORWARD_TAPE, prev
         ctx.model, ctx.batch = model, batch
         ctx.params = params
         ctx.has_stress = torch.is_tensor(res["stresses"]) and res["stresses"].dim() == 3
@@ -367,5 +412,6 @@ class ForcesFn(torch.autograd.Function):
             # the scale of the values, and undo the factor in the seed
             wmax = w.abs().max()
             scale = torch.where(wmax > 0, torch.exp2(torch.floor(torch.log2(wmax.clamp_min(1e-30)))), torch.ones_like(wmax))
-            grads = dual_pass(model, b, (w / scale).contiguous(), ge.contiguous(), (gt * scale).contiguous())
+            grads = dual_pass(model, b, (w / scale).contiguous(), ge.contiguous(), (gt * scale).contiguous(), ctx.fwd_tape)
+            ctx.fwd_tape = None  # (its tensors are the force evaluation's activations: let them go)
         return (None, None) + tuple(grads.get(p) for p in ctx.params)

@@ -568,6 +568,11 @@ def split_f16x2(w, transpose=False):
     return sw
 
 
+# Force training (alignn_amd/ff2.py): while this is a dict, the LayerNorm-flavoured layers file what their forward computed
+# under the address of their weight - MLPLayerFn: ("mlp", x, pre, y); EdgeGatedConvFn: ("conv", x, y, P, M, xpre, s0, hh,
+# x_out, y_out) - so that the dual pass that follows the force evaluation computes TANGENTS only instead of repeating the values
+FORWARD_TAPE = None
+
 KERNEL_TIMER = None  # bench.py: {"min_rows": r, "events": []} -> HIP events around every f16x3 NT launch of >= r rows
 
 
@@ -1167,6 +1172,8 @@ class MLPLayerFn(torch.autograd.Function):
         ctx.norm = norm
         ctx.param_grads = _PARAM_GRADS["on"]
         ctx.wb = (w, b)  # the leaves whose gradients come off the side stream (see _deferred_join_is_safe)
+        if FORWARD_TAPE is not None and norm == "layer":
+            FORWARD_TAPE[w.data_ptr()] = ("mlp", x, pre, y)
         return y
 
     @staticmethod
@@ -1452,6 +1459,8 @@ class EdgeGatedConvFn(torch.autograd.Function):
         ctx.param_grads = _PARAM_GRADS["on"]
         ctx.leaves = (w_sg, w_dg, w_du, w_su, b_sg, b_dg, b_du, b_su, w_eg, b_eg)
         ctx.save_for_backward(x, y, wcat, w_eg, P, M, xpre, s0, hh, n_stat, e_stat, n_gamma, e_gamma, n_beta, e_beta)
+        if FORWARD_TAPE is not None and norm == "layer":
+            FORWARD_TAPE[w_eg.data_ptr()] = ("conv", x, y, P, M, xpre, s0, hh, x_out, y_out)
         return x_out, y_out
 
     @staticmethod

@@ -421,6 +421,12 @@ int alignn_ln_silu_dual_bwd(const float* GY, const float* GYt, int64_t ldg, cons
 int alignn_egc_gate_dual_fwd(const float* P, const float* Pt, float* M, float* Mt, const int32_t* seg_ptr,
                              const int32_t* seg_node, const int32_t* src, int64_t n, int64_t m, int H, float* xpre,
                              float* xpre_t, float* s0, float* hh, float* s0t, float* hht, alignn_stream_t stream);
+/* the tangent half of alignn_egc_gate_dual_fwd alone, for a caller that already holds the values (M = m, s0, hh from the force
+ * evaluation): Mt holds Ct on entry and mt on exit; writes xpre_t, s0t, hht.  alignn_ln_silu_dual_fwd likewise takes Y == NULL
+ * (value output not written, R not read). */
+int alignn_egc_gate_dual_fwd_tangent(const float* P, const float* Pt, const float* M, float* Mt, const int32_t* seg_ptr,
+                                     const int32_t* seg_node, const int32_t* src, int64_t n, int64_t m, int H, float* xpre_t,
+                                     const float* s0, const float* hh, float* s0t, float* hht, alignn_stream_t stream);
 int alignn_egc_node_dual_bwd(const float* g, const float* gt, int64_t ldg, const float* s0, const float* hh,
                              const float* s0t, const float* hht, float* q1, float* q0, float* q1t, float* q0t, int64_t n,
                              int H, alignn_stream_t stream);

@@ -223,3 +223,43 @@ def test_dense_block_dual_reverse_equals_the_two_pass_kernels(shape):
         worst = max(worst, e)
         assert e < 2e-5, (k, e)
     print(f"dense-block dual reverse vs two passes ({shape}): worst per-parameter gradient difference {worst:.2e}")
+
+
+def test_tangent_only_dual_forward_equals_the_full_dual_forward():
+    """ff2.REUSE_FORWARD: the dual forward takes its VALUES from the force evaluation that preceded it (ops.FORWARD_TAPE) and
+    computes tangents only - same parameter gradients as the dual forward that recomputes both, up to the rounding of two
+    different kernels writing the same value (1e-5 of every gradient's scale)."""
+    from alignn_amd import ALIGNNAtomWise, ALIGNNAtomWiseConfig
+
+    raw = make_batch(6, 40, seed0=17)  # E = 3 k, T = 40 k rows
+    batch = GraphBatch.from_raw(raw, device=DEV)
+    gen = torch.Generator().manual_seed(4)
+    B = raw.batch_size
+    te, tf, ts = (torch.randn(B, generator=gen).to(DEV), torch.randn(raw.num_nodes, 3, generator=gen).to(DEV),
+                  torch.randn(B, 3, 3, generator=gen).to(DEV))
+    outs = []
+    for reuse in (True, False):
+        torch.manual_seed(7)
+        cfg = ALIGNNAtomWiseConfig(name="alignn_atomwise", alignn_layers=2, gcn_layers=2, hidden_features=128,
+                                   embedding_features=32, atom_input_features=92, calculate_gradient=True,
+                                   stresswise_weight=0.05)
+        model = ALIGNNAtomWise(cfg).to(DEV).train()
+        ff2.REUSE_FORWARD = reuse
+        try:
+            res = model(batch)
+            loss = F.l1_loss(res["out"], te) + F.l1_loss(res["grad"], tf) + 0.05 * F.l1_loss(res["stresses"], ts)
+            loss.backward()
+            torch.cuda.synchronize()
+        finally:
+            ff2.REUSE_FORWARD = True
+        assert ops.FORWARD_TAPE is None
+        outs.append({k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+    ga, gb = outs
+    assert ga.keys() == gb.keys() and len(ga) > 60
+    gmax = max(float(v.abs().max()) for v in gb.values())
+    worst = 0.0
+    for k in ga:
+        e = float((ga[k] - gb[k]).abs().max()) / max(float(gb[k].abs().max()), 1e-3 * gmax)
+        worst = max(worst, e)
+        assert e < 2e-5, (k, e)
+    print(f"tangent-only dual forward vs full dual forward: worst per-parameter gradient difference {worst:.2e}")
