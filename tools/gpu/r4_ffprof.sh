@@ -1,0 +1,11 @@
+#!/bin/bash
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+rm -rf /tmp/p_ff
+ALIGNN_AMD_SIDE_STREAM=0 timeout 600 rocprofv3 --kernel-trace -d /tmp/p_ff -o r -- python bench.py --model alignn_ff --batch 16 --atoms 200 --steps 5 --warmup 2 --no-cpu-baseline --streamed-steps 0 --eager-steps 0 --no-micro --other-configs 0 > gpurun_out/prof_cfg4_ff_bench.json 2> gpurun_out/prof_cfg4_ff.err
+db=$(find /tmp/p_ff -name "*.db" | head -1)
+python tools/rocpd_stats.py $db > gpurun_out/prof_cfg4_ff_kernel_stats.txt
+python tools/rocpd_stats.py $db --grid > gpurun_out/prof_cfg4_ff_kernel_stats_by_grid.txt
+python tools/rocpd_timeline.py $db 2 > gpurun_out/prof_cfg4_ff_timeline.txt
+python tools/rocpd_sequence.py $db 2 > gpurun_out/prof_cfg4_ff_sequence.txt
+sed -n 2,4p gpurun_out/prof_cfg4_ff_timeline.txt
