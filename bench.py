@@ -472,22 +472,23 @@ def main():
     # enqueued by two C calls (alignn_amd/cmodel.py), or from Python (ALIGNN_AMD_CMODEL=0)
     eager_step = step
     eager = None
-    if args.eager_steps > 0 and os.environ.get("ALIGNN_BENCH_EAGER", "0") != "1":
+    n_eager = max(args.eager_steps, args.steps) if args.eager_steps > 0 else 0  # (K steps: the same protocol as the replays)
+    if n_eager > 0 and os.environ.get("ALIGNN_BENCH_EAGER", "0") != "1":
         for _ in range(2):
             eager_step()
         fence()
         t0 = time.perf_counter()
-        for _ in range(args.eager_steps):
+        for _ in range(n_eager):
             eager_step()
         e_enq = time.perf_counter() - t0
         fence()
-        edt = (time.perf_counter() - t0) / args.eager_steps
+        edt = (time.perf_counter() - t0) / n_eager
         if world > 1:
             t = torch.tensor([edt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             edt = float(t.item())
-        eager = {"ms_per_step": round(edt * 1e3, 3), "graphs_per_s": round(world * B / edt, 1), "steps": args.eager_steps,
-                 "host_enqueue_ms_per_step": round(e_enq / args.eager_steps * 1e3, 3)}
+        eager = {"ms_per_step": round(edt * 1e3, 3), "graphs_per_s": round(world * B / edt, 1), "steps": n_eager,
+                 "host_enqueue_ms_per_step": round(e_enq / n_eager * 1e3, 3)}
         log(f"eager launches: {edt * 1e3:.2f} ms/step")
 
     # ---- the dominant kernel INSIDE a training step (measured here, before any hipGraph exists in the process - see the
@@ -669,6 +670,22 @@ def main():
         assert multi["ranks_seen"] == world, multi
     ms = dt / args.steps * 1e3
     gps = world * B * args.steps / dt
+    # Launch mode of the headline, chosen per host the way a training script would: the SAME K steps were timed eagerly
+    # launched (before any capture; two C calls per step for the default model) and replayed from the hipGraph, with the same
+    # barrier + synchronize protocol.  Replays do not depend on the host at all; eager launches are what a loop over
+    # never-seen batches runs and - where the host keeps up - cost the runtime less than a replay does (0.1-0.3 ms per step
+    # on every box of round 4).  One GPU: the faster of the two is `value` and the other is reported beside it; N > 1
+    # stays on the replay (eight ranks share one host, and the `multi_gpu` instrumentation below belongs to those steps).
+    replayed = None
+    if use_graph:
+        replayed = {"ms_per_step": round(ms, 3), "graphs_per_s": round(gps, 2), "steps": args.steps,
+                    "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3)}
+    headline_eager = (use_graph and world == 1 and eager is not None and eager["steps"] >= args.steps
+                      and eager["ms_per_step"] < ms and os.environ.get("ALIGNN_BENCH_HEADLINE", "auto") != "replay")
+    if headline_eager:
+        ms, gps = eager["ms_per_step"], B * 1e3 / eager["ms_per_step"]
+        t_enq = eager["host_enqueue_ms_per_step"] * 1e-3 * args.steps
+        log(f"headline: eagerly launched steps ({ms:.2f} ms) beat the replays ({replayed['ms_per_step']:.2f} ms) on this host")
     peak_train_bytes = torch.cuda.max_memory_allocated(dev)  # (before the informational per-operator / micro-timing runs below)
     log(f"{ms:.2f} ms/step, {gps:.1f} graphs/s (host enqueue {t_enq / args.steps * 1e3:.2f} ms/step)")
 
@@ -797,7 +814,10 @@ def main():
             "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3),
             "optimizer": opt_desc,
             "multi_gpu": multi,
-            "step_launch": "hipGraph replay of forward+loss+backward, eager all-reduce + fused AdamW" if use_graph else "eager",
+            "step_launch": ("eager launches: forward and backward one C call each (alignn_amd/cmodel.py), fused AdamW; timed before any "
+                            "hipGraph existed in the process" if headline_eager else
+                            "hipGraph replay of forward+loss+backward, eager all-reduce + fused AdamW" if use_graph else "eager"),
+            "replayed_steps": replayed,
             "peak_hbm_GB": round(peak_train_bytes / 1e9, 2),  # training steps (eager, streamed, captured + replayed) only
             "peak_hbm_GB_incl_measurement_runs": round(torch.cuda.max_memory_allocated(dev) / 1e9, 2),
             "streamed_batches": streamed,
