@@ -115,6 +115,8 @@ SIGNATURES = {
     "alignn_model_plan": (_i32, [_p, _p, _p, _p]),
     "alignn_model_fwd": (_i32, [_p, _p, _p, _sz, _p, _p]),
     "alignn_model_bwd": (_i32, [_p, _p, _p, _sz, _p, _p]),
+    "alignn_model_infer_workspace": (_sz, [_p, _p]),
+    "alignn_model_infer": (_i32, [_p, _p, _p, _sz, _p, _p]),
     "alignn_knn_emit": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i64, _p, _p, _p, _p, _p, _p, _p, _p]),
 }
 

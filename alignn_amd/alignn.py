@@ -403,6 +403,10 @@ class ALIGNN(nn.Module):
             out = cmodel.forward(self, b)
             if out is not None:
                 return self._head(out)
+        elif cmodel.infer_applicable(self, b):  # eval mode, no autograd: one C call (BatchNorm folded into the gate passes)
+            out = cmodel.infer(self, b)
+            if out is not None:
+                return self._head(out)
         ops.new_weight_generation()  # weight images cached by an earlier forward are not this forward's (ops._WGEN)
         with _lib.device_guard(self.fc.weight), _deferred_bumps():
             _prepare_split_weights(self)  # (on the caller's stream, BEFORE the lanes fork: lane T waits for it)

@@ -396,7 +396,17 @@ class _ModelFn(torch.autograd.Function):
 
 
 def applicable(model, b) -> bool:
-    if not (ENABLED and model.training and _flags_default()):
+    """Can the training-mode forward of this (model, batch) go through alignn_model_fwd / _bwd?"""
+    return model.training and _structure_ok(model, b, torch.is_grad_enabled())
+
+
+def infer_applicable(model, b) -> bool:
+    """... and the eval-mode forward without autograd through alignn_model_infer?"""
+    return (not model.training) and (not torch.is_grad_enabled()) and ops.INFER_FUSED and _structure_ok(model, b, False)
+
+
+def _structure_ok(model, b, need_grad) -> bool:
+    if not (ENABLED and _flags_default()):
         return False
     cfg = model.config
     if cfg.extra_features != 0 or cfg.alignn_layers < 1 or cfg.gcn_layers < 1 or cfg.hidden_features % 4:
@@ -434,13 +444,12 @@ def applicable(model, b) -> bool:
     if slots is None:  # [(module._parameters, name, parameter)]: a replaced Parameter object is noticed without walking the tree
         slots = model.__dict__["_cmodel_slots"] = [(mod._parameters, name, p) for mod in model.modules()
                                                    for name, p in mod._parameters.items() if p is not None]
-    need_grad = torch.is_grad_enabled()
     for d, name, p in slots:
         if d.get(name) is not p:
             model.__dict__.pop("_cmodel_slots", None)
             model.__dict__.pop("_cmodel_submodules", None)
             model.__dict__.pop("_cmodel", None)
-            return applicable(model, b)
+            return _structure_ok(model, b, need_grad)
         if need_grad and not p.requires_grad:
             return False
     if any(p.dtype != torch.float32 for p in (model.atom_embedding.layer[0].weight, model.fc.bias)):
@@ -473,3 +482,30 @@ def forward(model, b):
             if owns:  # (the forward raised before a lease existed: hand the shared workspace back)
                 bind.arena_busy = False
             raise
+
+
+def infer(model, b):
+    """-> ``fc(AvgPooling(...))`` [B, out_features] of an eval-mode forward without autograd (one C call), or None when the C
+    side does not carry a kernel choice this (model, batch) needs."""
+    bind = binding_of(model)
+    lib = _lib_model()
+    with _lib.device_guard(model.fc.weight):
+        bind.refresh()
+        capturing = bind.set_mode()
+        mb = bind.batch_struct(b)
+        af, r, h = b.atom_features.contiguous(), b.r.contiguous(), b.h.contiguous()
+        if af.shape != (b.g.n_nodes, bind.desc.atom_in) or r.shape != (b.g.n_edges, 3) or h.numel() != b.lg.n_edges:
+            raise ValueError("feature rows do not match the graphs")
+        mb.atom_features, mb.r, mb.h = af.data_ptr(), r.data_ptr(), h.data_ptr()
+        key = ("infer", mb.g.n, mb.g.m, mb.lg.m, mb.B, bool(bind.desc.lane_T), bind.desc.lane_min_rows)
+        nbytes = bind.plans.get(key)
+        if nbytes is None:
+            nbytes = bind.plans[key] = lib.alignn_model_infer_workspace(bind.desc_addr, C.addressof(mb))
+        if not nbytes:
+            return None
+        arena, _owns = bind.take_arena(nbytes, capturing, False)
+        out = torch.empty(mb.B, bind.desc.out_features, dtype=torch.float32, device=bind.device)
+        _lib.check(lib.alignn_model_infer(bind.desc_addr, C.addressof(mb), arena.data_ptr(), nbytes, out.data_ptr(), _lib.stream()),
+                   "model_infer")
+        STATS["infer"] = STATS.get("infer", 0) + 1
+        return out

@@ -667,6 +667,106 @@ void run_backward(Ctx& c, const Tape& tp, const float* g_out) {
     c.sync(c.main, c.side);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// inference: ALIGNN.forward in eval mode without autograd (alignn/pretrained.py, model.eval() under no_grad) - BatchNorm is
+// the affine map of its running statistics, the edge output comes straight out of the gate pass (alignn_egc_gate_infer), m
+// is never written and nothing is kept: ops.MLPLayerFn._fwd (eval) / ops.edge_gated_conv_infer launch for launch.
+// ---------------------------------------------------------------------------------------------------------------------
+Act mlp_infer(Ctx& c, const alignn_mlp_params& p, const Act& x, int64_t rows) {
+    const int F = p.out, K = p.in;
+    const bool lane = c.T != c.main && rows >= c.d->lane_min_rows;
+    hipStream_t st = lane ? c.T : c.main;
+    if (lane != x.on_T) c.sync(st, x.on_T ? c.T : c.main);
+    float* pre = c.alloc((size_t)rows * F);
+    float* stat = c.alloc((size_t)4 * F);
+    project(c, x.p, K, x.amax, p.W, K, p.img, p.w_amax, p.b, pre, F, rows, F, K, st);
+    L(alignn_bn_finalize(nullptr, 0, rows, F, p.gamma, p.beta, c.d->eps, c.d->momentum, p.rm, p.rv, stat, st));
+    Act y;
+    y.p = c.alloc((size_t)rows * F);
+    y.amax = c.track(rows) ? c.new_amax() : nullptr;
+    L(alignn_bn_silu_fwd(pre, F, nullptr, 0, stat, y.p, F, rows, F, y.amax, st));
+    y.on_T = lane;
+    return y;
+}
+
+void conv_infer(Ctx& c, const alignn_conv_params& p, const alignn_graph_csr& g, const Act& x, const Act& y, bool need_y,
+                Act& x_out, Act& y_out) {
+    const int H = c.d->H, Kin = H;
+    const int64_t n = g.n, m = g.m;
+    const bool lane = c.T != c.main && m >= c.d->lane_min_rows;
+    hipStream_t main = c.main, T = lane ? c.T : c.main;
+    if (x.on_T) c.sync(main, c.T);
+    if (!lane && y.on_T) c.sync(main, c.T);
+    float* P = c.alloc((size_t)n * 4 * H);
+    project(c, x.p, Kin, x.amax, p.wcat, Kin, p.wcat_img, p.wcat_amax, p.bcat, P, 4 * H, n, 4 * H, Kin, main);
+    float* stats = c.alloc((size_t)8 * H);
+    L(alignn_bn_finalize(nullptr, 0, n, H, p.n_gamma, p.n_beta, c.d->eps, c.d->momentum, p.n_rm, p.n_rv, stats, main));
+    L(alignn_bn_finalize(nullptr, 0, m, H, p.e_gamma, p.e_beta, c.d->eps, c.d->momentum, p.e_rm, p.e_rv, stats + 4 * H, main));
+    if (lane) c.sync(T, main);
+    float* Cm = c.alloc((size_t)m * H);
+    project(c, y.p, Kin, y.amax, p.w_eg, Kin, p.weg_img, p.weg_amax, p.b_eg, Cm, H, m, H, Kin, T);
+    float* xpre = c.alloc((size_t)n * H);
+    Act yo;
+    if (need_y) {
+        yo.p = c.alloc((size_t)m * H);
+        yo.amax = c.track(m) ? c.new_amax() : nullptr;
+        yo.on_T = lane;
+    }
+    L(alignn_egc_gate_infer(P, Cm, g.seg_ptr, g.seg_node, g.src, n, m, H, xpre, stats + 4 * H, y.p, yo.p, yo.amax, T));
+    if (lane) c.sync(main, T);
+    x_out = Act{};
+    x_out.p = c.alloc((size_t)n * H);
+    x_out.amax = c.track(n) ? c.new_amax() : nullptr;
+    L(alignn_bn_silu_fwd(xpre, H, x.p, Kin, stats, x_out.p, H, n, H, x_out.amax, main));
+    y_out = yo;
+}
+
+void run_infer(Ctx& c, float* out) {
+    const alignn_model_desc& d = *c.d;
+    const alignn_model_batch& b = *c.b;
+    const int64_t N = b.g.n, E = b.g.m, Tn = b.lg.m;
+    c.amax_arena = c.alloc(kAmaxSlots);
+    c.amax_next = 0;
+    fill(c, c.amax_arena, kAmaxSlots, 0.0f, c.main);
+    if (d.n_weights > 0) L(alignn_prepare_weights(d.weight_descs, d.n_weights, d.weight_amax, c.main));
+    c.sync(c.T, c.main);
+    float* rbf_a = c.alloc((size_t)Tn * d.angle_bins);
+    L(alignn_rbf_fwd(b.h, d.angle_centers, d.angle_gamma, rbf_a, Tn, d.angle_bins, c.main));
+    Act za;
+    za.p = rbf_a;
+    Act z = mlp_infer(c, d.angle2, mlp_infer(c, d.angle1, za, Tn), Tn);
+    Act xa;
+    xa.p = const_cast<float*>(b.atom_features);
+    Act x = mlp_infer(c, d.atom, xa, N);
+    float* bl = c.alloc((size_t)E);
+    L(alignn_norm3_fwd(b.r, bl, E, c.main));
+    float* rbf_e = c.alloc((size_t)E * d.edge_bins);
+    L(alignn_rbf_fwd(bl, d.edge_centers, d.edge_gamma, rbf_e, E, d.edge_bins, c.main));
+    Act ye;
+    ye.p = rbf_e;
+    Act y = mlp_infer(c, d.edge2, mlp_infer(c, d.edge1, ye, E), E);
+    if (c.unsupported) return;
+    int k = 0;
+    for (int i = 0; i < d.alignn_layers; ++i) {
+        Act xo, m_, yo, zo;
+        conv_infer(c, d.convs[k++], b.g, x, y, true, xo, m_);
+        conv_infer(c, d.convs[k++], b.lg, m_, z, i + 1 < d.alignn_layers, yo, zo);
+        x = xo, y = yo, z = zo;
+        if (c.unsupported) return;
+    }
+    for (int i = 0; i < d.gcn_layers; ++i) {
+        Act xo, yo;
+        conv_infer(c, d.convs[k++], b.g, x, y, i + 1 < d.gcn_layers, xo, yo);
+        x = xo, y = yo;
+        if (c.unsupported) return;
+    }
+    if (x.on_T) c.sync(c.main, c.T);
+    float* pool = c.alloc((size_t)b.B * d.H);
+    L(alignn_segment_mean_fwd(x.p, b.graph_ptr, pool, b.B, d.H, c.main));
+    L(alignn_gemm_nt(pool, d.H, d.fc_W, d.H, d.fc_b, nullptr, 0, out, d.out_features, b.B, d.out_features, d.H, c.main));
+    c.sync(c.main, c.T);
+}
+
 bool desc_ok(const alignn_model_desc* d, const alignn_model_batch* b) {
     if (d == nullptr || b == nullptr || d->convs == nullptr) return false;
     if (d->alignn_layers < 1 || d->gcn_layers < 1 || d->H <= 0 || (d->H & 3) || d->out_features <= 0) return false;
@@ -818,6 +918,27 @@ int alignn_model_bwd(const alignn_model_desc* d, const alignn_model_batch* b, vo
         fprintf(stderr, "alignn_model_bwd: %.3f ms host (plans %.3f ms, %d stream syncs %.3f ms, %d launch calls)\n", tot * 1e3,
                 std::chrono::duration<double>(t1 - t0).count() * 1e3, c.n_sync, c.t_sync * 1e3, c.n_launch);
     }
+    if (c.unsupported) return (int)hipErrorNotSupported;
+    return c.rc;
+}
+
+size_t alignn_model_infer_workspace(const alignn_model_desc* d, const alignn_model_batch* b) {
+    if (!desc_ok(d, b)) return 0;
+    Ctx c{d, b, reinterpret_cast<char*>(4096)};
+    set_streams(c, nullptr);
+    run_infer(c, nullptr);
+    return (c.unsupported || c.rc != 0) ? 0 : c.off;
+}
+
+int alignn_model_infer(const alignn_model_desc* d, const alignn_model_batch* b, void* workspace, size_t workspace_bytes,
+                       float* out, alignn_stream_t stream) {
+    if (!desc_ok(d, b) || workspace == nullptr || out == nullptr) return (int)hipErrorInvalidValue;
+    Ctx c{d, b, static_cast<char*>(workspace)};
+    c.cap = workspace_bytes;
+    c.launch = true;
+    set_streams(c, stream);
+    if (c.T != c.main && !take_pool(c)) return (int)hipErrorNotInitialized;
+    run_infer(c, out);
     if (c.unsupported) return (int)hipErrorNotSupported;
     return c.rc;
 }

@@ -633,6 +633,12 @@ int alignn_model_fwd(const alignn_model_desc* desc, const alignn_model_batch* ba
                      float* out, alignn_stream_t stream);
 int alignn_model_bwd(const alignn_model_desc* desc, const alignn_model_batch* batch, void* workspace, size_t workspace_bytes,
                      const float* g_out, alignn_stream_t stream);
+/* ALIGNN.forward in eval mode without autograd (alignn/pretrained.py; model.eval() under torch.no_grad()): BatchNorm = the
+ * affine map of its running statistics, edge outputs straight from alignn_egc_gate_infer, nothing kept.  _workspace: bytes
+ * for this (desc, batch), 0 when a kernel choice is not carried here.  Uses desc->lane_T only. */
+size_t alignn_model_infer_workspace(const alignn_model_desc* desc, const alignn_model_batch* batch);
+int alignn_model_infer(const alignn_model_desc* desc, const alignn_model_batch* batch, void* workspace, size_t workspace_bytes,
+                       float* out, alignn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Batch staging in one call (csrc/stage.hip): canonical CSR of g (slots = bonds stably sorted by

@@ -232,3 +232,36 @@ def test_irregular_graphs_isolated_atoms_self_loops_single_graph():
     b = _steps(_mk(5, alignn_layers=2, gcn_layers=2, hidden_features=64, embedding_features=32), [batch] * 2, [target] * 2, False)
     _same(a, b, "irregular")
     assert all(bool(torch.isfinite(t).all()) for t in a.values())
+
+
+def test_inference_in_one_c_call_equals_the_per_operator_eval_path():
+    """model.eval() under no_grad: alignn_model_infer (BatchNorm folded into the gate passes, nothing kept) against the
+    per-operator eval path - same kernels, same bits; running statistics untouched; with and without lane T."""
+    raw = make_batch(24, 60, seed0=31)
+    batch = GraphBatch.from_raw(raw, device=DEV)
+    target = torch.randn(24, generator=torch.Generator().manual_seed(4)).to(DEV)
+    model = _mk(4)
+    _steps(model, [batch] * 2, [target] * 2, True)  # (running statistics that are not the initial 0 / 1)
+    model.eval()
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    for k in cmodel.STATS:
+        cmodel.STATS[k] = 0
+    with torch.no_grad():
+        a = model(batch)
+        assert cmodel.STATS.get("infer", 0) == 1
+        with cmodel.disabled():
+            b = model(batch)
+        saved = ops._LANE["enabled"]
+        ops._LANE["enabled"] = "0"
+        try:
+            c = model(batch)
+        finally:
+            ops._LANE["enabled"] = saved
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and torch.equal(a, c)
+    after = model.state_dict()
+    assert all(torch.equal(before[k], after[k]) for k in before)
+    # with autograd enabled the eval forward stays on the operators (somebody may differentiate it)
+    n = cmodel.STATS.get("infer", 0)
+    model(batch)
+    assert cmodel.STATS.get("infer", 0) == n

@@ -18,6 +18,10 @@ def t(n=10):
         torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n, out
 tf, of = t()
+from alignn_amd import cmodel
+cmodel.ENABLED = False
+tp, op_ = t()
+print(f"one C call {tf*1e3:.2f} ms ({64/tf:.0f} graphs/s) vs per-operator launches {tp*1e3:.2f} ms; bit-identical: {bool(torch.equal(of, op_))}")
 ops.INFER_FUSED = False
 ts, os_ = t()
 print(f"inference, 64 x 60 atoms: folded {tf*1e3:.2f} ms ({64/tf:.0f} graphs/s), unfolded eval {ts*1e3:.2f} ms ({64/ts:.0f} graphs/s), "
