@@ -156,6 +156,63 @@ def line_graph_of(g: CSRGraph) -> CSRGraph:
     )
 
 
+STAGE_HIP = True  # device COO -> (g, L(g)) through ONE C call (csrc/stage.hip) where it applies; tests flip it to compare
+
+
+def csr_and_line_graph(u: torch.Tensor, v: torch.Tensor, n_nodes: int, r: Optional[torch.Tensor] = None):
+    """``(build_csr(u, v, n), line_graph_of(g), r[g.perm])`` - the canonical bond graph, its canonical line graph and the
+    bond vectors in slot order - for a bond list that already lives on the device.  On a HIP device this is ONE host read
+    (T = rows of L(g) and the largest in-degree, both functions of the bond list) + ONE C call, ``alignn_stage_batch``
+    (two radix sorts of E keys, two prefix sums, index arithmetic for the T rows: csrc/stage.hip) instead of the ~45 torch
+    index operations of the two builders, whose arrays it reproduces bit for bit (tests/test_gpu_stage.py) - what an MD
+    step pays between the neighbour search and the model (alignn/ff/calculators.py:280-291 rebuilds the graph every step).
+    Elsewhere (CPU, empty graphs, the switch off): the two builders."""
+    dev = u.device
+    E = int(u.numel())
+    if not (STAGE_HIP and dev.type == "cuda" and E > 0 and n_nodes > 0):
+        g = build_csr(u, v, n_nodes)
+        return g, line_graph_of(g), (None if r is None else r[g.perm].contiguous())
+    from . import _lib
+
+    lib = _lib.load()
+    u32, v32 = u.to(torch.int32).contiguous(), v.to(torch.int32).contiguous()
+    din = torch.bincount(v32, minlength=n_nodes)
+    din_u = din[u32.long()]
+    # the one host read: T = sum over bonds e2 of (in-degree of src(e2)) - [e2 is a self image]; the dense-block bound
+    T, max_in = torch.stack([din_u.sum() - (u32 == v32).sum(), din_u.max()]).tolist()
+    T, N = int(T), int(n_nodes)
+    i32, i64, f32 = torch.int32, torch.int64, torch.float32
+    want = [("seg_ptr", i32, N + 1), ("src", i32, E), ("dst", i32, E), ("out_ptr", i32, N + 1), ("out_slot", i32, E),
+            ("perm", i64, E), ("inv", i64, E), ("r", f32, 3 * E if r is not None else 0), ("lg_seg_ptr", i32, E + 1),
+            ("lg_src", i32, T), ("lg_dst", i32, T), ("lg_out_ptr", i32, E + 1), ("lg_out_slot", i32, T), ("seg_rank", i32, T),
+            ("ident", i64, T)]
+    offs, off = {}, 0
+    for name, dt, n in want:
+        offs[name] = off
+        off = (off + n * (8 if dt is i64 else 4) + 63) // 64 * 64
+    ws_bytes = lib.alignn_stage_batch_workspace(N, E)
+    out = torch.empty(off + ws_bytes, dtype=torch.uint8, device=dev)
+    base = out.data_ptr()
+    a = {name: (out[offs[name]:offs[name] + n * (8 if dt is i64 else 4)].view(dt) if n else None) for name, dt, n in want}
+    rr = None if r is None else r.to(f32).contiguous()
+    with _lib.device_guard(out):
+        _lib.check(lib.alignn_stage_batch(
+            u32.data_ptr(), v32.data_ptr(), None if rr is None else rr.data_ptr(), N, E, T,
+            base + offs["seg_ptr"], base + offs["src"], base + offs["dst"], base + offs["out_ptr"], base + offs["out_slot"],
+            base + offs["perm"], base + offs["inv"], (base + offs["r"]) if rr is not None else None, base + offs["lg_seg_ptr"],
+            base + offs["lg_src"], base + offs["lg_dst"], base + offs["lg_out_ptr"], base + offs["lg_out_slot"],
+            base + offs["seg_rank"], base + offs["ident"], None, base + off, ws_bytes, _lib.stream()), "stage_batch")
+    g = CSRGraph(n_nodes=N, n_edges=E, seg_ptr=a["seg_ptr"], seg_node=None, src=a["src"], dst=a["dst"], out_ptr=a["out_ptr"],
+                 out_slot=a["out_slot"], perm=a["perm"], inv=a["inv"])
+    ident = a["ident"] if T else torch.empty(0, dtype=i64, device=dev)
+    z32 = torch.empty(0, dtype=i32, device=dev)
+    lg = CSRGraph(n_nodes=E, n_edges=T, seg_ptr=a["lg_seg_ptr"], seg_node=a["out_slot"], src=a["lg_src"] if T else z32,
+                  dst=a["lg_dst"] if T else z32, out_ptr=a["lg_out_ptr"], out_slot=a["lg_out_slot"] if T else z32, perm=ident,
+                  inv=ident, grp_seg_ptr=a["out_ptr"], grp_src_ptr=a["seg_ptr"], dense_max_src=int(max_in),
+                  seg_rank=a["seg_rank"] if T else z32)
+    return g, lg, (None if r is None else a["r"].view(E, 3))
+
+
 def _dense_blocks(g: CSRGraph, lg: CSRGraph) -> int:
     """Largest source count of any block if L(g)'s blocks are dense and source-sorted (CSRGraph.dense_max_src), else 0.
 
@@ -226,8 +283,11 @@ class GraphBatch:
             return GraphBatch._attach(out, dev, atom_features, r, h, volume)
         u = torch.as_tensor(u).to(dev)
         v = torch.as_tensor(v).to(dev)
-        g = build_csr(u, v, int(n_nodes))
-        lg = None
+        if lg_u is None and build_line_graph:
+            g, lg, _ = csr_and_line_graph(u, v, int(n_nodes))
+        else:
+            g = build_csr(u, v, int(n_nodes))
+            lg = None
         if lg_u is not None:
             e1 = g.inv[torch.as_tensor(lg_u).to(dev).to(torch.int64)]
             e2 = g.inv[torch.as_tensor(lg_v).to(dev).to(torch.int64)]
@@ -242,8 +302,6 @@ class GraphBatch:
                 lg.grp_seg_ptr, lg.grp_src_ptr = g.out_ptr, g.seg_ptr
                 lg.dense_max_src = _dense_blocks(g, lg)
             lg.segment_rank()
-        elif build_line_graph:
-            lg = line_graph_of(g)
         bnn = torch.as_tensor(batch_num_nodes).to(dev).to(torch.int64)
         gp = _ptr_from_counts(bnn).to(torch.int32)
         out = GraphBatch(g=g, lg=lg, graph_ptr=gp, batch_size=int(bnn.numel()))

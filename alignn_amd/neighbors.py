@@ -29,7 +29,7 @@ from typing import Optional, Sequence
 
 import torch
 
-from .graph import GraphBatch, _ptr_from_counts, build_csr, line_graph_of
+from .graph import GraphBatch, _ptr_from_counts, build_csr, csr_and_line_graph, line_graph_of
 
 __all__ = ["knn_multigraph", "knn_multigraph_batch", "knn_multigraph_batch_hip", "radius_graph", "radius_graph_batch",
            "radius_graph_batch_hip", "crystal_batch", "clear_lattice_cache"]
@@ -433,11 +433,15 @@ def crystal_batch(lattices: Sequence, fracs: Sequence, atom_features: Optional[S
     else:
         u, v, r, nn = knn_multigraph_batch(lattices, fracs, cutoff, max_neighbors, device=dev)
     off = sum(nn)
-    g = build_csr(u, v, off)
-    lg = line_graph_of(g) if line_graph else None
-    bnn = torch.tensor(nn, dtype=torch.int64, device=dev)
-    batch = GraphBatch(g=g, lg=lg, graph_ptr=_ptr_from_counts(bnn).to(torch.int32), batch_size=len(nn))
-    batch.r = r[g.perm].contiguous()
+    if line_graph:  # (on the GPU: one host read + one C call, graph.csr_and_line_graph)
+        g, lg, r_canon = csr_and_line_graph(u, v, off, r)
+    else:
+        g, lg = build_csr(u, v, off), None
+        r_canon = r[g.perm].contiguous()
+    gp = torch.zeros(len(nn) + 1, dtype=torch.int32)
+    gp[1:] = torch.cumsum(torch.tensor(nn, dtype=torch.int32), 0)  # (on the host: B small integers)
+    batch = GraphBatch(g=g, lg=lg, graph_ptr=gp.to(dev), batch_size=len(nn))
+    batch.r = r_canon
     if atom_features is not None:
         batch.atom_features = torch.cat([torch.as_tensor(a) for a in atom_features]).to(dev, torch.float32).contiguous()
     if dev.type == "cuda" and volume is not None:  # (derived with - and cached under the same key as - the lattice tables)

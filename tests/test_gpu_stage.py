@@ -74,3 +74,53 @@ def test_prefetch_loader_hands_over_staged_batches():
         assert float(b.h.abs().max()) <= 1.0
         seen += 1
     assert seen == 4
+
+
+def test_device_coo_to_canonical_graphs_equals_the_torch_builders():
+    """graph.csr_and_line_graph (what neighbors.crystal_batch and GraphBatch.from_coo(build_line_graph=True) use on the GPU:
+    one host read + alignn_stage_batch) against build_csr + line_graph_of, incl. a bond list with self loops and an atom
+    without bonds, and int64 inputs as the neighbour kernels emit them."""
+    from alignn_amd import graph as G
+
+    raw = make_batch(5, 23, seed0=8)
+    cases = [(torch.from_numpy(raw.u).long(), torch.from_numpy(raw.v).long(), raw.num_nodes, torch.from_numpy(raw.r)),
+             (torch.tensor([0, 1, 1, 2, 2, 2, 3, 0]), torch.tensor([1, 0, 2, 1, 2, 2, 0, 3]), 5, torch.randn(8, 3))]
+    for u, v, n, r in cases:
+        u, v, r = u.to(DEV), v.to(DEV), r.to(DEV)
+        g1, lg1, r1 = G.csr_and_line_graph(u, v, n, r)
+        G.STAGE_HIP = False
+        try:
+            g0, lg0, r0 = G.csr_and_line_graph(u, v, n, r)
+        finally:
+            G.STAGE_HIP = True
+        for a, b in ((g1, g0), (lg1, lg0)):
+            assert (a.n_nodes, a.n_edges, a.dense_max_src) == (b.n_nodes, b.n_edges, b.dense_max_src)
+            for f in FIELDS:
+                x, y = getattr(a, f), getattr(b, f)
+                assert (x is None) == (y is None), f
+                if x is not None:
+                    assert x.dtype == y.dtype and torch.equal(x, y), f
+        assert torch.equal(r1, r0)
+
+
+def test_crystal_batch_runs_the_force_field_after_the_one_call_staging():
+    from alignn_amd import ALIGNNAtomWise, ALIGNNAtomWiseConfig, neighbors
+    from alignn_amd import graph as G
+    from alignn_amd.synthetic import make_crystal
+
+    lat, frac, _ = make_crystal(40, 77)
+    lat_d, frac_d = torch.from_numpy(lat).to(DEV), torch.from_numpy(frac).to(DEV)
+    feats = torch.randn(40, 92, device=DEV)
+    torch.manual_seed(0)
+    model = ALIGNNAtomWise(ALIGNNAtomWiseConfig(name="alignn_atomwise", alignn_layers=2, gcn_layers=1, hidden_features=64,
+                                                embedding_features=32, atom_input_features=92, calculate_gradient=True)).to(DEV).eval()
+    outs = []
+    for flag in (True, False):
+        G.STAGE_HIP = flag
+        try:
+            b = neighbors.crystal_batch([lat_d], [frac_d], atom_features=[feats])
+            res = model(b)
+            outs.append((res["out"].detach().clone(), res["grad"].detach().clone()))
+        finally:
+            G.STAGE_HIP = True
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
