@@ -109,7 +109,8 @@ SIGNATURES = {
     "alignn_radius_count": (_i32, [_p, _p, _p, _p, _p, _p, _f32, _i32, _i64, _p, _p, _p]),
     "alignn_radius_emit": (_i32, [_p, _p, _p, _p, _p, _p, _f32, _i32, _i64, _p, _p, _p, _p, _p, _p, _p]),
     "alignn_stage_batch_workspace": (_sz, [_i64, _i64]),
-    "alignn_stage_batch": (_i32, [_p, _p, _p, _i64, _i64, _i64] + [_p] * 16 + [_p, _sz, _p]),
+    "alignn_stage_batch": (_i32, [_p, _p, _p, _i64, _i64, _i64] + [_p] * 17 + [_p, _sz, _p]),
+    "alignn_map_line_graph_rows": (_i32, [_p] * 8 + [_i64, _i64, _p, _p, _p, _p]),
     "alignn_model_init": (_i32, []),
     "alignn_model_sizeof": (_sz, [_i32]),
     "alignn_model_plan": (_i32, [_p, _p, _p, _p]),

@@ -136,6 +136,45 @@ __global__ void lg_out_slot_kernel(const int32_t* __restrict__ seg_ptr, const in
     lg_out_slot[q] = lg_seg_ptr[s] + (e1 - base) - ((seg_has_self && e2 < e1) ? 1 : 0);
 }
 
+// A caller's OWN edge list of L(g) (DGL: g.line_graph(shared=True); lg_u[k] -> lg_v[k] in the caller's ids of g's edges) ->
+// for every caller edge k the canonical row t(k) it is, by index arithmetic on the canonical layout (no T-sized sort):
+// e1 = inv[lg_u[k]], e2 = inv[lg_v[k]] are g's slots; the row lies in the segment of e2 (rank out_rank[e2]) at the position
+// of e1 among the in-edges of the centre atom j = src[e2], minus one if e2 itself precedes it there.  perm[t] = k (the
+// caller pre-fills perm with -1), inv_lg[k] = t; *bad counts edges that are not edges of the line graph at all
+// (dst[e1] != src[e2], or e1 == e2) or that repeat an earlier one: n_triplets edges with bad == 0 are a bijection.
+__global__ void map_lg_rows_kernel(const int64_t* __restrict__ lg_u, const int64_t* __restrict__ lg_v,
+                                   const int64_t* __restrict__ inv, const int32_t* __restrict__ seg_ptr,
+                                   const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
+                                   const int32_t* __restrict__ out_rank, const int32_t* __restrict__ lg_seg_ptr, int64_t E,
+                                   int64_t T, int64_t* __restrict__ perm, int64_t* __restrict__ inv_lg,
+                                   int32_t* __restrict__ bad) {
+    const int64_t k = (int64_t)blockIdx.x * kT + threadIdx.x;
+    if (k >= T) return;
+    const int64_t a = lg_u[k], b = lg_v[k];
+    bool ok = a >= 0 && a < E && b >= 0 && b < E;
+    int64_t t = 0;
+    if (ok) {
+        const int32_t e1 = (int32_t)inv[a], e2 = (int32_t)inv[b];
+        const int32_t j = src[e2];
+        ok = dst[e1] == j && e1 != e2;
+        if (ok) {
+            const int32_t base = seg_ptr[j];
+            t = (int64_t)lg_seg_ptr[out_rank[e2]] + (e1 - base) - ((dst[e2] == j && e2 < e1) ? 1 : 0);
+            ok = t >= 0 && t < T;
+        }
+    }
+    if (ok) {  // a row claimed twice (a duplicated caller edge) is counted as bad: T edges, none bad => a bijection
+        const unsigned long long before = atomicExch(reinterpret_cast<unsigned long long*>(perm + t), (unsigned long long)k);
+        ok = before == ~0ull;
+    }
+    if (ok) {
+        inv_lg[k] = t;
+    } else {
+        inv_lg[k] = -1;
+        atomicAdd(bad, 1);  // (integer count: order independent)
+    }
+}
+
 struct Scratch {
     size_t iota, keys, vals, cnt_seg, cnt_out, out_rank, prim, total, prim_bytes;
 };
@@ -177,7 +216,7 @@ int alignn_stage_batch(const int32_t* u, const int32_t* v, const float* r, int64
                        int32_t* seg_ptr, int32_t* src, int32_t* dst, int32_t* out_ptr, int32_t* out_slot, int64_t* perm,
                        int64_t* inv, float* r_canon, int32_t* lg_seg_ptr, int32_t* lg_src, int32_t* lg_dst,
                        int32_t* lg_out_ptr, int32_t* lg_out_slot, int32_t* lg_seg_rank, int64_t* lg_ident, float* h,
-                       void* workspace, size_t workspace_bytes, alignn_stream_t stream) {
+                       int32_t* out_rank_out, void* workspace, size_t workspace_bytes, alignn_stream_t stream) {
     if (N <= 0 || E <= 0 || T < 0 || E >= ((int64_t)1 << 31) - 1 || T >= ((int64_t)1 << 31) - 1 || N >= ((int64_t)1 << 31) - 1)
         return (int)hipErrorInvalidValue;
     if (!u || !v || !seg_ptr || !src || !dst || !out_ptr || !out_slot || !perm || !inv || !lg_seg_ptr || !lg_src || !lg_dst ||
@@ -193,7 +232,7 @@ int alignn_stage_batch(const int32_t* u, const int32_t* v, const float* r, int64
     int32_t* vals = reinterpret_cast<int32_t*>(ws + sc.vals);
     int32_t* cnt_seg = reinterpret_cast<int32_t*>(ws + sc.cnt_seg);
     int32_t* cnt_out = reinterpret_cast<int32_t*>(ws + sc.cnt_out);
-    int32_t* out_rank = reinterpret_cast<int32_t*>(ws + sc.out_rank);
+    int32_t* out_rank = out_rank_out != nullptr ? out_rank_out : reinterpret_cast<int32_t*>(ws + sc.out_rank);
     void* prim = ws + sc.prim;
     size_t pb = sc.prim_bytes;
     const unsigned nbits = bits_for(N);
@@ -228,6 +267,19 @@ int alignn_stage_batch(const int32_t* u, const int32_t* v, const float* r, int64
     ALIGNN_CHECK_LAUNCH();
     // ---- bond-angle cosines on the canonical rows (compute_bond_cosines, alignn/graphs.py:847-864)
     if (h != nullptr && T > 0) return alignn_bond_cosine_fwd(r_canon, lg_src, lg_dst, h, T, stream);
+    return 0;
+}
+
+int alignn_map_line_graph_rows(const int64_t* lg_u, const int64_t* lg_v, const int64_t* inv, const int32_t* seg_ptr,
+                               const int32_t* src, const int32_t* dst, const int32_t* out_rank, const int32_t* lg_seg_ptr,
+                               int64_t n_edges, int64_t n_triplets, int64_t* perm, int64_t* inv_lg, int32_t* bad,
+                               alignn_stream_t stream) {
+    if (n_triplets <= 0) return 0;
+    if (!lg_u || !lg_v || !inv || !seg_ptr || !src || !dst || !out_rank || !lg_seg_ptr || !perm || !inv_lg || !bad || n_edges <= 0)
+        return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(map_lg_rows_kernel, dim3(blocks(n_triplets)), dim3(kT), 0, (hipStream_t)stream, lg_u, lg_v, inv, seg_ptr, src,
+                       dst, out_rank, lg_seg_ptr, n_edges, n_triplets, perm, inv_lg, bad);
+    ALIGNN_CHECK_LAUNCH();
     return 0;
 }
 

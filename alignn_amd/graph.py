@@ -159,17 +159,25 @@ def line_graph_of(g: CSRGraph) -> CSRGraph:
 STAGE_HIP = True  # device COO -> (g, L(g)) through ONE C call (csrc/stage.hip) where it applies; tests flip it to compare
 
 
-def csr_and_line_graph(u: torch.Tensor, v: torch.Tensor, n_nodes: int, r: Optional[torch.Tensor] = None):
+def csr_and_line_graph(u: torch.Tensor, v: torch.Tensor, n_nodes: int, r: Optional[torch.Tensor] = None, lg_edges=None):
     """``(build_csr(u, v, n), line_graph_of(g), r[g.perm])`` - the canonical bond graph, its canonical line graph and the
     bond vectors in slot order - for a bond list that already lives on the device.  On a HIP device this is ONE host read
     (T = rows of L(g) and the largest in-degree, both functions of the bond list) + ONE C call, ``alignn_stage_batch``
     (two radix sorts of E keys, two prefix sums, index arithmetic for the T rows: csrc/stage.hip) instead of the ~45 torch
     index operations of the two builders, whose arrays it reproduces bit for bit (tests/test_gpu_stage.py) - what an MD
     step pays between the neighbour search and the model (alignn/ff/calculators.py:280-291 rebuilds the graph every step).
-    Elsewhere (CPU, empty graphs, the switch off): the two builders."""
+    Elsewhere (CPU, empty graphs, the switch off): the two builders.
+
+    ``lg_edges = (lg_u, lg_v)``: the caller's OWN edge list of L(g) (the ``lg`` of the reference's ``(g, lg)`` pair,
+    alignn/graphs.py:588,995 ``g.line_graph(shared=True)``, in the caller's ids of g's edges).  The canonical rows are the
+    same; ``lg.perm`` / ``lg.inv`` then map the caller's edge order onto them (``alignn_map_line_graph_rows``: index
+    arithmetic, second host read = its error count).  Returns ``None`` when that list is NOT the line graph of g (a
+    filtered one, duplicates, a different size) or the device path does not apply - the caller takes the generic builder."""
     dev = u.device
     E = int(u.numel())
     if not (STAGE_HIP and dev.type == "cuda" and E > 0 and n_nodes > 0):
+        if lg_edges is not None:
+            return None
         g = build_csr(u, v, n_nodes)
         return g, line_graph_of(g), (None if r is None else r[g.perm].contiguous())
     from . import _lib
@@ -181,11 +189,13 @@ def csr_and_line_graph(u: torch.Tensor, v: torch.Tensor, n_nodes: int, r: Option
     # the one host read: T = sum over bonds e2 of (in-degree of src(e2)) - [e2 is a self image]; the dense-block bound
     T, max_in = torch.stack([din_u.sum() - (u32 == v32).sum(), din_u.max()]).tolist()
     T, N = int(T), int(n_nodes)
+    if lg_edges is not None and (T == 0 or int(lg_edges[0].numel()) != T or int(lg_edges[1].numel()) != T):
+        return None
     i32, i64, f32 = torch.int32, torch.int64, torch.float32
     want = [("seg_ptr", i32, N + 1), ("src", i32, E), ("dst", i32, E), ("out_ptr", i32, N + 1), ("out_slot", i32, E),
             ("perm", i64, E), ("inv", i64, E), ("r", f32, 3 * E if r is not None else 0), ("lg_seg_ptr", i32, E + 1),
             ("lg_src", i32, T), ("lg_dst", i32, T), ("lg_out_ptr", i32, E + 1), ("lg_out_slot", i32, T), ("seg_rank", i32, T),
-            ("ident", i64, T)]
+            ("ident", i64, T if lg_edges is None else 0), ("out_rank", i32, E if lg_edges is not None else 0)]
     offs, off = {}, 0
     for name, dt, n in want:
         offs[name] = off
@@ -201,14 +211,27 @@ def csr_and_line_graph(u: torch.Tensor, v: torch.Tensor, n_nodes: int, r: Option
             base + offs["seg_ptr"], base + offs["src"], base + offs["dst"], base + offs["out_ptr"], base + offs["out_slot"],
             base + offs["perm"], base + offs["inv"], (base + offs["r"]) if rr is not None else None, base + offs["lg_seg_ptr"],
             base + offs["lg_src"], base + offs["lg_dst"], base + offs["lg_out_ptr"], base + offs["lg_out_slot"],
-            base + offs["seg_rank"], base + offs["ident"], None, base + off, ws_bytes, _lib.stream()), "stage_batch")
+            base + offs["seg_rank"], (base + offs["ident"]) if lg_edges is None else None, None,
+            (base + offs["out_rank"]) if lg_edges is not None else None, base + off, ws_bytes, _lib.stream()), "stage_batch")
+        perm_lg = inv_lg = None
+        if lg_edges is not None:
+            lu, lv = (torch.as_tensor(x).to(dev).to(i64).contiguous() for x in lg_edges)
+            perm_lg = torch.full((T,), -1, dtype=i64, device=dev)
+            inv_lg = torch.empty(T, dtype=i64, device=dev)
+            bad = torch.zeros(1, dtype=i32, device=dev)
+            _lib.check(lib.alignn_map_line_graph_rows(
+                lu.data_ptr(), lv.data_ptr(), base + offs["inv"], base + offs["seg_ptr"], base + offs["src"], base + offs["dst"],
+                base + offs["out_rank"], base + offs["lg_seg_ptr"], E, T, perm_lg.data_ptr(), inv_lg.data_ptr(), bad.data_ptr(),
+                _lib.stream()), "map_line_graph_rows")
+            if int(bad) != 0:
+                return None
     g = CSRGraph(n_nodes=N, n_edges=E, seg_ptr=a["seg_ptr"], seg_node=None, src=a["src"], dst=a["dst"], out_ptr=a["out_ptr"],
                  out_slot=a["out_slot"], perm=a["perm"], inv=a["inv"])
-    ident = a["ident"] if T else torch.empty(0, dtype=i64, device=dev)
+    ident = perm_lg if perm_lg is not None else (a["ident"] if T else torch.empty(0, dtype=i64, device=dev))
     z32 = torch.empty(0, dtype=i32, device=dev)
     lg = CSRGraph(n_nodes=E, n_edges=T, seg_ptr=a["lg_seg_ptr"], seg_node=a["out_slot"], src=a["lg_src"] if T else z32,
                   dst=a["lg_dst"] if T else z32, out_ptr=a["lg_out_ptr"], out_slot=a["lg_out_slot"] if T else z32, perm=ident,
-                  inv=ident, grp_seg_ptr=a["out_ptr"], grp_src_ptr=a["seg_ptr"], dense_max_src=int(max_in),
+                  inv=inv_lg if inv_lg is not None else ident, grp_seg_ptr=a["out_ptr"], grp_src_ptr=a["seg_ptr"], dense_max_src=int(max_in),
                   seg_rank=a["seg_rank"] if T else z32)
     return g, lg, (None if r is None else a["r"].view(E, 3))
 
@@ -283,12 +306,17 @@ class GraphBatch:
             return GraphBatch._attach(out, dev, atom_features, r, h, volume)
         u = torch.as_tensor(u).to(dev)
         v = torch.as_tensor(v).to(dev)
-        if lg_u is None and build_line_graph:
+        staged = None
+        if lg_u is not None:  # the caller's own L(g): one device pass if it is the line graph of g, else the generic builder
+            staged = csr_and_line_graph(u, v, int(n_nodes), lg_edges=(lg_u, lg_v))
+        if staged is not None:
+            g, lg, _ = staged
+        elif lg_u is None and build_line_graph:
             g, lg, _ = csr_and_line_graph(u, v, int(n_nodes))
         else:
             g = build_csr(u, v, int(n_nodes))
             lg = None
-        if lg_u is not None:
+        if lg_u is not None and staged is None:
             e1 = g.inv[torch.as_tensor(lg_u).to(dev).to(torch.int64)]
             e2 = g.inv[torch.as_tensor(lg_v).to(dev).to(torch.int64)]
             m = g.n_edges

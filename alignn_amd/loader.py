@@ -185,7 +185,7 @@ def _stage_hip(packed: PackedBatch, dev, d, view, feature_table, cosines):
         base + offs["seg_ptr"], base + offs["src"], base + offs["dst"], base + offs["out_ptr"], base + offs["out_slot"],
         base + offs["perm"], base + offs["inv"], base + offs["r"], base + offs["lg_seg_ptr"], base + offs["lg_src"],
         base + offs["lg_dst"], base + offs["lg_out_ptr"], base + offs["lg_out_slot"], base + offs["seg_rank"],
-        base + offs["ident"], (base + offs["h"]) if cosines else None, base + off, ws_bytes, _lib.stream()), "stage_batch")
+        base + offs["ident"], (base + offs["h"]) if cosines else None, None, base + off, ws_bytes, _lib.stream()), "stage_batch")
     from .graph import CSRGraph
 
     g = CSRGraph(n_nodes=N, n_edges=E, seg_ptr=a["seg_ptr"], seg_node=None, src=a["src"], dst=a["dst"], out_ptr=a["out_ptr"],

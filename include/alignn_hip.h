@@ -659,7 +659,17 @@ int alignn_stage_batch(const int32_t* u, const int32_t* v, const float* r, int64
                        int32_t* seg_ptr, int32_t* src, int32_t* dst, int32_t* out_ptr, int32_t* out_slot, int64_t* perm,
                        int64_t* inv, float* r_canon, int32_t* lg_seg_ptr, int32_t* lg_src, int32_t* lg_dst,
                        int32_t* lg_out_ptr, int32_t* lg_out_slot, int32_t* lg_seg_rank, int64_t* lg_ident, float* h,
+                       int32_t* out_rank /* optional [E]: rank of every slot in the by-source order */,
                        void* workspace, size_t workspace_bytes, alignn_stream_t stream);
+/* The caller's OWN edge list of L(g) (the lg of the reference's (g, lg) pair: dgl's g.line_graph(shared=True), edges lg_u[k] ->
+ * lg_v[k] in the caller's ids of g's edges, int64) mapped onto the canonical rows alignn_stage_batch laid out, by index
+ * arithmetic (no T-sized sort): perm[t] = k (pre-fill with -1), inv_lg[k] = t, *bad (zeroed by the caller) += edges that are
+ * not line-graph edges of g or repeat an earlier one.  n_triplets (= the T alignn_stage_batch was given) edges with bad == 0:
+ * the caller's lg IS the line graph, perm a bijection, and its edge features go to canonical order as h[perm]. */
+int alignn_map_line_graph_rows(const int64_t* lg_u, const int64_t* lg_v, const int64_t* inv, const int32_t* seg_ptr,
+                               const int32_t* src, const int32_t* dst, const int32_t* out_rank, const int32_t* lg_seg_ptr,
+                               int64_t n_edges, int64_t n_triplets, int64_t* perm, int64_t* inv_lg, int32_t* bad,
+                               alignn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Radius bond graphs on the device (csrc/radius.hip): alignn/graphs.py:267-364 (radius_graph),

@@ -124,3 +124,69 @@ def test_crystal_batch_runs_the_force_field_after_the_one_call_staging():
         finally:
             G.STAGE_HIP = True
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def _from_raw_both(raw, **edit):
+    from alignn_amd import GraphBatch, graph
+
+    t = torch.from_numpy
+    args = dict(lg_u=t(raw.lg_u), lg_v=t(raw.lg_v))
+    args.update(edit)
+    mk = lambda: GraphBatch.from_coo(t(raw.u), t(raw.v), raw.num_nodes, t(raw.batch_num_nodes), args["lg_u"], args["lg_v"],
+                                     t(raw.atom_features), t(raw.r), args.get("h", t(raw.h)), device=DEV)
+    a = mk()
+    graph.STAGE_HIP = False
+    try:
+        b = mk()
+    finally:
+        graph.STAGE_HIP = True
+    torch.cuda.synchronize()
+    return a, b
+
+
+@pytest.mark.parametrize("n,atoms,kind,shuffle", [(1, 5, "crystal", False), (8, 60, "crystal", True), (64, 60, "crystal", False),
+                                                  (40, (9, 27), "molecule", True)])
+def test_the_callers_own_line_graph_is_mapped_onto_the_canonical_rows(n, atoms, kind, shuffle):
+    """GraphBatch.from_coo with the (g, lg) pair the reference hands over (alignn/models/alignn.py:293): on the GPU the
+    caller's L(g) edge list is mapped by alignn_map_line_graph_rows; every array, lg.perm / lg.inv included, and the gathered
+    cosines must equal what the generic torch builder makes of the same input - also with the caller's edges shuffled."""
+    raw = make_batch(n, atoms, seed0=23 + n, kind=kind)
+    edit = {}
+    if shuffle:
+        k = torch.randperm(raw.lg_u.size, generator=torch.Generator().manual_seed(n))
+        edit = dict(lg_u=torch.from_numpy(raw.lg_u)[k], lg_v=torch.from_numpy(raw.lg_v)[k], h=torch.from_numpy(raw.h)[k])
+    a, b = _from_raw_both(raw, **edit)
+    assert a.lg.perm is not a.lg.inv or a.lg.n_edges == 0
+    for name, ga, gb in (("g", a.g, b.g), ("lg", a.lg, b.lg)):
+        assert (ga.n_nodes, ga.n_edges, ga.dense_max_src) == (gb.n_nodes, gb.n_edges, gb.dense_max_src), name
+        for f in FIELDS:
+            x, y = getattr(ga, f), getattr(gb, f)
+            assert (x is None) == (y is None), (name, f)
+            if x is not None:
+                assert x.dtype == y.dtype and torch.equal(x, y), (name, f)
+    assert torch.equal(a.h, b.h) and torch.equal(a.r, b.r)
+
+
+def test_a_list_that_is_not_the_line_graph_takes_the_generic_builder():
+    """A filtered line graph (fewer edges), a duplicated edge and a non-adjacent pair: csr_and_line_graph(lg_edges=...)
+    declines (None) and from_coo builds what the torch builder builds."""
+    from alignn_amd import graph
+
+    raw = make_batch(4, 12, seed0=3)
+    t = torch.from_numpy
+    u, v = t(raw.u).to(DEV), t(raw.v).to(DEV)
+    lu, lv = t(raw.lg_u).to(DEV), t(raw.lg_v).to(DEV)
+    assert graph.csr_and_line_graph(u, v, raw.num_nodes, lg_edges=(lu, lv)) is not None
+    assert graph.csr_and_line_graph(u, v, raw.num_nodes, lg_edges=(lu[:-3], lv[:-3])) is None  # filtered
+    dup_u, dup_v = lu.clone(), lv.clone()
+    dup_u[5], dup_v[5] = lu[6], lv[6]
+    assert graph.csr_and_line_graph(u, v, raw.num_nodes, lg_edges=(dup_u, dup_v)) is None  # a repeated edge
+    bad_u = lu.clone()
+    wrong = (t(raw.v).to(DEV)[lu] != t(raw.v).to(DEV)[lu[0]]).nonzero()[0, 0]  # an edge ending at another atom
+    bad_u[0] = lu[wrong]
+    assert graph.csr_and_line_graph(u, v, raw.num_nodes, lg_edges=(bad_u, lv)) is None  # not adjacent
+    a, b = _from_raw_both(raw, lg_u=t(raw.lg_u)[:-3], lg_v=t(raw.lg_v)[:-3], h=t(raw.h)[:-3])
+    for f in FIELDS:
+        x, y = getattr(a.lg, f), getattr(b.lg, f)
+        assert (x is None) == (y is None) and (x is None or torch.equal(x, y)), f
+    assert torch.equal(a.h, b.h)
