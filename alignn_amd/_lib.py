@@ -113,6 +113,11 @@ SIGNATURES = {
     "alignn_map_line_graph_rows": (_i32, [_p] * 8 + [_i64, _i64, _p, _p, _p, _p]),
     "alignn_model_init": (_i32, []),
     "alignn_model_sizeof": (_sz, [_i32]),
+    "alignn_angle_embed_supported": (_i32, [_i32, _i32, _i32]),
+    "alignn_angle_embed_workspace": (_sz, [_i64, _i32, _i32]),
+    "alignn_angle_args_sizeof": (_sz, []),
+    "alignn_angle_embed_fwd": (_i32, [_p, _p]),
+    "alignn_angle_embed_bwd": (_i32, [_p, _p]),
     "alignn_model_plan": (_i32, [_p, _p, _p, _p]),
     "alignn_model_fwd": (_i32, [_p, _p, _p, _sz, _p, _p]),
     "alignn_model_bwd": (_i32, [_p, _p, _p, _sz, _p, _p]),

@@ -1,0 +1,1162 @@
+// The bond-angle embedding of ALIGNN on T rows without materialising anything T x 256 but its output:
+//   z = MLPLayer(64 -> 256)( MLPLayer(bins -> 64)( RBFExpansion(h) ) ),   MLPLayer = Linear + BatchNorm1d (batch statistics) + SiLU
+// (alignn/models/alignn.py:215-222 angle_embedding, :170-184 MLPLayer; alignn/models/utils.py:9-47 RBFExpansion).
+//
+// Every row of the embedding is a function of ONE scalar, the cosine h[t]: the [T, bins] expansion, the [T, 64] and [T, 256]
+// pre-activations and the [T, 64] activation (1.15 GB per 64 crystals) exist in the chain of separate kernels only to be
+// read again by the next one - 3.2 GB of traffic forward and 4.5 GB backward for 0.69 GB of result.  Here every pass
+// RECOMPUTES what it needs from h (2.7 MB) on the matrix cores and only the real operands cross HBM:
+//   forward   pass 1  statistics of layer 1's pre-activation               reads h
+//             pass 2  statistics of layer 2's pre-activation               reads h
+//             pass 3  z = SiLU(BatchNorm(.))                               reads h, writes z [T, 256]
+//   backward  pass 4  BatchNorm-backward sums of layer 2                   reads h, g_z [T, 256]
+//             pass 5  dW2 = dx2^T a1 (and db2)                             reads h, g_z
+//             pass 6  da1 = dx2 W2                                         reads h, g_z, writes da1 [T, 64]
+//             pass 7  BatchNorm-backward sums of layer 1                   reads h, da1
+//             pass 8  dW1 = dx1^T rbf (and db1)                            reads h, da1
+// BatchNorm's global statistics are what forces the passes apart (each is a grid-wide dependency).
+//
+// Arithmetic: products as f16x3 split products (hi * hi + hi * lo + lo * hi, fp32 accumulation: v_mfma_f32_32x32x16_f16) of
+// operands scaled by powers of two from tracked / bounded maxima, like the projections of csrc/gemm_x6.hip; everything
+// else fp32, column sums in float64.  Register tiles change orientation (rows <-> features across lanes) by a product
+// with an identity fragment - exact for fp16 payloads - instead of an LDS round trip.
+//
+// Work decomposition of the T x 256 passes: a workgroup = 4 waves owns a tile of 128 rows.  Phase A: wave w computes the
+// layer-1 activations of rows [32w, 32w + 32) - the MFMA leaves them (lane = row, registers = features), which IS the
+// operand layout of the next product - and files their fp16 slices in LDS.  Phase B: wave w owns features [64w, 64w + 64)
+// (its slices of W2 live in registers for the whole kernel) and walks the four row blocks.
+#include "../../include/alignn_hip.h"
+#include "common.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kE = 64;         // embedding_features: layer-1 outputs
+constexpr int kH = 256;        // hidden_features: layer-2 outputs
+constexpr int kBinsMax = 48;   // three k-steps of 16
+constexpr int kThreads = 256;
+constexpr int kTile = 128;
+constexpr int kGrid = 512;     // two workgroups per compute unit
+// scal[] (device scalars that live from the forward to the backward of one step)
+constexpr int kAmaxW1 = 0, kAmaxW2 = 1, kBoundA1 = 2, kBoundDx2 = 3, kBoundDx1 = 4, kAmaxGz2 = 5, kAmaxXh2 = 6, kAmaxGz1 = 7,
+              kAmaxXh1 = 8, kShift = 16,  // kShift .. kShift + 63: layer-1 shift of the statistics pass
+              kScalFloats = 128;
+constexpr float kRbfScale = 16384.0f;     // rbf values lie in (0, 1]
+
+__device__ __forceinline__ f32x16 mfma(const f16x8& a, const f16x8& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.0f;
+    return z;
+}
+// power-of-two scale that puts max|x| just below 2^15 (csrc/gemm_x6.hip f16_scale)
+__device__ __forceinline__ float f16_scale(float amax) {
+    const int e = (int)((__float_as_uint(amax) >> 23) & 255u);
+    if (e == 0 || e == 255) return 1.0f;
+    int se = 268 - e;
+    se = se > 254 ? 254 : se;
+    return __uint_as_float((unsigned)se << 23);
+}
+// three products of a split pair
+__device__ __forceinline__ f32x16 mfma3(const f16x8& ah, const f16x8& al, const f16x8& bh, const f16x8& bl, f32x16 c) {
+    c = mfma(ah, bh, c);
+    c = mfma(ah, bl, c);
+    c = mfma(al, bh, c);
+    return c;
+}
+
+// 8 floats already scaled -> hi = RN_f16(x), lo = RN_f16(x - hi): v_cvt_pk_f16_f32 for the high slice, one v_fma_mix per
+// element for the low one (csrc/gemm_x6.hip slice8_f16_lo: same bits as the two-conversion form hipcc emits, half the work)
+__device__ __forceinline__ void split8s(const float (&xs)[8], f16x8& h, f16x8& l) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h[j] = (_Float16)xs[j];
+    const uint4 hp = __builtin_bit_cast(uint4, h);
+    const unsigned hw[4] = {hp.x, hp.y, hp.z, hp.w};
+    unsigned lw[4];
+#pragma unroll
+    for (int p2 = 0; p2 < 4; ++p2) {
+        asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(lw[p2]) : "v"(xs[2 * p2]), "v"(hw[p2]));
+        asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lw[p2]) : "v"(xs[2 * p2 + 1]), "v"(hw[p2]));
+    }
+    l = __builtin_bit_cast(f16x8, make_uint4(lw[0], lw[1], lw[2], lw[3]));
+}
+constexpr float kLog2e = 1.4426950408889634f;
+// x * sigmoid(x * k) with k folded by the caller: silu of a value that carries a scale (k = 1 / scale); k = 1: silu_f
+__device__ __forceinline__ float silu_scaled(float x, float neg_k_log2e) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * neg_k_log2e));
+}
+__device__ __forceinline__ float dsilu_fast(float z) {
+    const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -kLog2e));
+    return s * fmaf(z, 1.0f - s, 1.0f);
+}
+
+struct P {  // kernel parameters (by value)
+    const float* h;
+    int64_t rows;
+    const float* centers;
+    float gamma;
+    int bins;
+    const float *W1, *b1, *gamma1, *beta1, *W2, *b2;
+    const float *stat1, *stat2;  // [4, 64], [4, 256]: mean | rstd | gamma * rstd | beta
+    float* scal;
+    float *z, *z_amax;
+    const float* gz;
+    const float *red1, *red2;    // [2, F]: sum gz | sum gz * xhat
+    float* da1;
+    void* partial;
+    float* partial_b;
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Layer 1 on a block of 32 rows (one wave): x1^T = W1 rbf^T as D[m = feature][n = row] - lane = row (il), register r of
+// block cb = feature 32 cb + 8 (r >> 2) + 4 hh + (r & 3).  W1's fragments (A operand: lane m = feature 32 cb + il,
+// k = bin 16 s + 8 hh + i) and the per-feature constants of what follows live in LDS (registers are what the T x 256
+// passes are short of).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kL1Consts = 7;
+struct L1Shared {
+    uint4 w[2][3][2][64];       // [cb][s][hi | lo][lane]
+    float c[kL1Consts][kE];     // per pass, see l1_setup
+};
+enum L1Mode { kL1Stats, kL1Act, kL1Bwd };
+
+// feature of register r of block cb for a lane of half hh
+__device__ __forceinline__ int l1_col(int cb, int r, int hh) { return 32 * cb + 8 * (r >> 2) + 4 * hh + (r & 3); }
+
+// all threads of the workgroup; ends with a barrier.  kL1Act: the activations come out scaled by sa (operand scale of a1).
+__device__ __forceinline__ void l1_setup(const P& p, L1Shared& sh, L1Mode mode, float sa) {
+    const int lane = threadIdx.x & 63, il = lane & 31, hh = lane >> 5, w = threadIdx.x >> 6;
+    const float sw = f16_scale(p.scal[kAmaxW1]);
+    const float inv = 1.0f / (kRbfScale * sw);
+    for (int combo = w; combo < 6; combo += kThreads / 64) {
+        const int cb = combo / 3, s = combo % 3;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = 16 * s + 8 * hh + i;
+            v[i] = k < p.bins ? p.W1[(32 * cb + il) * p.bins + k] * sw : 0.0f;
+        }
+        f16x8 hi, lo;
+        split8s(v, hi, lo);
+        sh.w[cb][s][0][lane] = __builtin_bit_cast(uint4, hi);
+        sh.w[cb][s][1][lane] = __builtin_bit_cast(uint4, lo);
+    }
+    if (threadIdx.x < kE) {
+        const int f = threadIdx.x;
+        const float b1 = p.b1[f];
+        if (mode == kL1Stats) {  // d = x1 - shift = acc * c0 + c1
+            sh.c[0][f] = inv;
+            sh.c[1][f] = b1 - p.scal[kShift + f];
+        } else {
+            const float mean = p.stat1[f], rstd = p.stat1[kE + f], sc = p.stat1[2 * kE + f], be = p.stat1[3 * kE + f];
+            if (mode == kL1Act) {  // sa z1 = acc * c0 + c1
+                sh.c[0][f] = sc * inv * sa;
+                sh.c[1][f] = fmaf(b1 - mean, sc, be) * sa;
+            } else {  // xhat = acc * c0 + c1;  z1 = xhat * c2 + c3;  dx1 = c4 gz1 + xhat c5 + c6  (c5, c6 carry -1/n sums)
+                const float inv_n = 1.0f / (float)p.rows;
+                sh.c[0][f] = rstd * inv;
+                sh.c[1][f] = (b1 - mean) * rstd;
+                sh.c[2][f] = p.gamma1[f];
+                sh.c[3][f] = be;
+                sh.c[4][f] = sc * sa;
+                sh.c[5][f] = p.red1 != nullptr ? -sc * sa * p.red1[kE + f] * inv_n : 0.0f;
+                sh.c[6][f] = p.red1 != nullptr ? -sc * sa * p.red1[f] * inv_n : 0.0f;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// the centres this lane's slots need (k = 16 s + 8 hh + i), padded far away so that the padded bins expand to 0
+struct Rbf {
+    float cen[3][8];
+    float g2;  // -gamma log2(e)
+    __device__ __forceinline__ void load(const P& p, int hh) {
+        g2 = -p.gamma * kLog2e;
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int k = 16 * s + 8 * hh + i;
+                cen[s][i] = k < p.bins ? p.centers[k] : 1.0e18f;
+            }
+    }
+    // 2^14 exp(-gamma (h - c)^2) as fragments (lane = row, k = bin 16 s + 8 hh + i); ONES: slot `ones` holds 2^14 (a column of
+    // ones: the product with it sums the other operand's columns)
+    template <bool ONES>
+    __device__ __forceinline__ void expand(float hv, int hh, int ones, f16x8 (&r_hi)[3], f16x8 (&r_lo)[3]) const {
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float t = hv - cen[s][i];
+                // (the multiply is also what keeps a transcendental's result from feeding split8s' inline assembly directly:
+                // gfx950 wants a wait state there and the compiler cannot see into the asm to insert it)
+                v[i] = __builtin_amdgcn_exp2f(g2 * t * t) * kRbfScale;
+                if (ONES && 16 * s + 8 * hh + i == ones) v[i] = kRbfScale;
+            }
+            split8s(v, r_hi[s], r_lo[s]);
+        }
+    }
+};
+__device__ __forceinline__ void l1_product(const L1Shared& sh, int lane, const f16x8 (&r_hi)[3], const f16x8 (&r_lo)[3],
+                                           f32x16 (&acc)[2]) {
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        acc[cb] = zero16();
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const f16x8 wh = __builtin_bit_cast(f16x8, sh.w[cb][s][0][lane]);
+            const f16x8 wl = __builtin_bit_cast(f16x8, sh.w[cb][s][1][lane]);
+            acc[cb] = mfma3(wh, wl, r_hi[s], r_lo[s], acc[cb]);
+        }
+    }
+}
+// constants k of the four features registers [4 q, 4 q + 4) of block cb hold
+__device__ __forceinline__ void l1_const4(const L1Shared& sh, int k, int cb, int q, int hh, float (&o)[4]) {
+    const float4 v = f4_ld(&sh.c[k][32 * cb + 8 * q + 4 * hh]);
+    o[0] = v.x, o[1] = v.y, o[2] = v.z, o[3] = v.w;
+}
+
+// cross-lane sum / max over the 32 rows of a half (lanes il = 0..31 keep hh)
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float half_max(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ void atomic_max_pos(float* p, float v) {
+    if (v > 0.0f && v > *reinterpret_cast<volatile float*>(p)) atomicMax(reinterpret_cast<unsigned*>(p), __float_as_uint(v));
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// prep: max|W1|, max|W2| and the shift of the layer-1 statistics (x1 of row 0 - any value near the column means will do)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void angle_prep_kernel(P p) {
+    __shared__ float sh[kThreads];
+    const int t = threadIdx.x;
+    float m1 = 0.0f, m2 = 0.0f;
+    for (int i = t; i < kE * p.bins; i += kThreads) m1 = fmaxf(m1, fabsf(p.W1[i]));
+    for (int i = t; i < kH * kE; i += kThreads) m2 = fmaxf(m2, fabsf(p.W2[i]));
+    for (int pass = 0; pass < 2; ++pass) {
+        sh[t] = pass == 0 ? m1 : m2;
+        __syncthreads();
+        for (int o = kThreads / 2; o > 0; o >>= 1) {
+            if (t < o) sh[t] = fmaxf(sh[t], sh[t + o]);
+            __syncthreads();
+        }
+        if (t == 0) p.scal[pass == 0 ? kAmaxW1 : kAmaxW2] = sh[0];
+        __syncthreads();
+    }
+    if (t < kE) {
+        const float hv = p.rows > 0 ? p.h[0] : 0.0f;
+        float acc = p.b1[t];
+        for (int k = 0; k < p.bins; ++k) {
+            const float d = hv - p.centers[k];
+            acc = fmaf(__expf(-p.gamma * d * d), p.W1[t * p.bins + k], acc);
+        }
+        p.scal[kShift + t] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// pass 1: shifted column sums of x1 = W1 rbf(h) + b1.  One wave per block of 32 rows; partial[wave][3][64] =
+// sum (x - c) | sum (x - c)^2 | max |x - c|.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads, 2) void angle_l1_stats_kernel(P p) {
+    __shared__ L1Shared sh;
+    l1_setup(p, sh, kL1Stats, 1.0f);
+    const int lane = threadIdx.x & 63, il = lane & 31, hh = lane >> 5;
+    const int wave = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6), nwaves = gridDim.x * (kThreads / 64);
+    Rbf rbf;
+    rbf.load(p, hh);
+    float s1[2][16], s2[2][16], dm[2][16];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s1[cb][r] = s2[cb][r] = dm[cb][r] = 0.0f;
+    const int64_t nblk = (p.rows + 31) / 32;
+    for (int64_t blk = wave; blk < nblk; blk += nwaves) {
+        const int64_t row = blk * 32 + il;
+        const float ok = row < p.rows ? 1.0f : 0.0f;
+        const float hv = row < p.rows ? p.h[row] : 0.0f;
+        f16x8 r_hi[3], r_lo[3];
+        rbf.expand<false>(hv, hh, 0, r_hi, r_lo);
+        f32x16 acc[2];
+        l1_product(sh, lane, r_hi, r_lo, acc);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float u[4], v[4];
+                l1_const4(sh, 0, cb, q, hh, u);
+                l1_const4(sh, 1, cb, q, hh, v);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * q + e;
+                    const float d = ok * fmaf(acc[cb][r], u[e], v[e]);
+                    s1[cb][r] += d;
+                    s2[cb][r] = fmaf(d, d, s2[cb][r]);
+                    dm[cb][r] = fmaxf(dm[cb][r], fabsf(d));
+                }
+            }
+    }
+    float* out = static_cast<float*>(p.partial) + (size_t)wave * 3 * kE;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float a = half_sum(s1[cb][r]), b = half_sum(s2[cb][r]), c = half_max(dm[cb][r]);
+            if (il == 0) {
+                const int col = l1_col(cb, r, hh);
+                out[col] = a;
+                out[kE + col] = b;
+                out[2 * kE + col] = c;
+            }
+        }
+}
+
+// statistics of a layer from slabs.  LAYER2 = false: float slabs [slabs][3][F] = shifted sum | shifted sum of squares | max
+// |x - c| with the shift in scal[kShift..] (layer 1: also writes the bound of |a1|); true: double slabs [slabs][2][F] of the RAW
+// accumulator sums: x2 = acc * unit + bias with unit = 1 / (a1 scale * W2 scale) - the variance does not see the bias.
+// 4 columns x 64 slab lanes per workgroup (csrc/norm.hip bn_finalize_kernel).
+template <bool LAYER2>
+__global__ __launch_bounds__(256) void angle_stat_finalize_kernel(const void* __restrict__ partial, int slabs, int64_t rows, int F,
+                                                                  const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, float eps, float momentum,
+                                                                  float* __restrict__ rm, float* __restrict__ rv,
+                                                                  float* __restrict__ stat, float* __restrict__ scal) {
+    __shared__ double shs[64][4], shq[64][4];
+    __shared__ float shm[64][4];
+    const int c = threadIdx.x & 3, y = threadIdx.x >> 2;
+    const int f = blockIdx.x * 4 + c;
+    double s = 0.0, q = 0.0;
+    float dmax = 0.0f;
+    for (int k = y; k < slabs; k += 64) {
+        if constexpr (LAYER2) {
+            const double* pp = static_cast<const double*>(partial) + (size_t)k * 2 * F;
+            s += pp[f];
+            q += pp[F + f];
+        } else {
+            const float* pp = static_cast<const float*>(partial) + (size_t)k * 3 * F;
+            s += (double)pp[f];
+            q += (double)pp[F + f];
+            dmax = fmaxf(dmax, pp[2 * F + f]);
+        }
+    }
+    shs[y][c] = s;
+    shq[y][c] = q;
+    shm[y][c] = dmax;
+    __syncthreads();
+    if (y != 0) return;
+    s = 0.0, q = 0.0, dmax = 0.0f;
+    for (int k = 0; k < 64; ++k) s += shs[k][c], q += shq[k][c], dmax = fmaxf(dmax, shm[k][c]);
+    const double n = (double)rows;
+    double unit = 1.0, shift;
+    if constexpr (LAYER2) {
+        unit = 1.0 / ((double)f16_scale(scal[kBoundA1]) * (double)f16_scale(scal[kAmaxW2]));
+        shift = (double)bias[f];
+    } else
+        shift = (double)scal[kShift + f];
+    const double dm = s / n * unit;
+    double v = (q / n) * unit * unit - dm * dm;
+    if (v < 0.0) v = 0.0;
+    const float mean = (float)(shift + dm), var = (float)v;
+    if (rm != nullptr) {
+        const double unbiased = rows > 1 ? v * n / (n - 1.0) : v;
+        rm[f] = (1.0f - momentum) * rm[f] + momentum * mean;
+        rv[f] = (1.0f - momentum) * rv[f] + momentum * (float)unbiased;
+    }
+    const float rstd = 1.0f / sqrtf(var + eps);
+    const float g = gamma[f], b = beta[f];
+    stat[f] = mean;
+    stat[F + f] = rstd;
+    stat[2 * F + f] = g * rstd;
+    stat[3 * F + f] = b;
+    if constexpr (!LAYER2) {  // |a1| = |silu(z)| <= |z| <= |gamma rstd| (max|x - c| + |c - mean|) + |beta|
+        const float bound = fabsf(g * rstd) * (dmax + fabsf((float)dm)) + fabsf(b);
+        atomic_max_pos(scal + kBoundA1, bound);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Phase A of the T x 256 passes: the layer-1 activations a1 of 32 rows as fp16 slices in operand layout.
+// K-step s2 = 2 cb + s of the layer-2 products takes registers [8 s, 8 s + 8) of block cb: slot (hh, i) of that step is
+// feature 16 s2 + 8 (i >> 2) + 4 hh + (i & 3) - W2's fragments are loaded with the same permutation.
+// LDS: a_frag[rb][s2][hi | lo][lane] (16 B each).
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int afrag_idx(int rb, int s2, int hl, int lane) { return ((rb * 4 + s2) * 2 + hl) * 64 + lane; }
+
+template <bool KEEP>
+__device__ __forceinline__ void phase_a(const P& p, const L1Shared& sh, const Rbf& rbf, float neg_k, int64_t row0, int lane, int rb,
+                                        uint4* a_frag, f16x8 (&keep_hi)[4], f16x8 (&keep_lo)[4]) {
+    const int il = lane & 31, hh = lane >> 5;
+    const int64_t row = row0 + il;
+    const float hv = row < p.rows ? p.h[row] : 0.0f;
+    f16x8 r_hi[3], r_lo[3];
+    rbf.expand<false>(hv, hh, 0, r_hi, r_lo);
+    f32x16 acc[2];
+    l1_product(sh, lane, r_hi, r_lo, acc);
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float a[8];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float u[4], v[4];
+                l1_const4(sh, 0, cb, 2 * s + q, hh, u);
+                l1_const4(sh, 1, cb, 2 * s + q, hh, v);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[4 * q + e] = silu_scaled(fmaf(acc[cb][8 * s + 4 * q + e], u[e], v[e]), neg_k);
+            }
+            f16x8 hi, lo;
+            split8s(a, hi, lo);
+            a_frag[afrag_idx(rb, 2 * cb + s, 0, lane)] = __builtin_bit_cast(uint4, hi);
+            a_frag[afrag_idx(rb, 2 * cb + s, 1, lane)] = __builtin_bit_cast(uint4, lo);
+            if constexpr (KEEP) keep_hi[2 * cb + s] = hi, keep_lo[2 * cb + s] = lo;
+        }
+}
+
+// W2 fragments of a wave's 64 features for the recomputation: lane n = feature f0 + 32 fb + il, slot (hh, i) of step s2 =
+// input feature 16 s2 + 8 (i >> 2) + 4 hh + (i & 3)
+struct W2Frag {
+    f16x8 hi[2][4], lo[2][4];
+    __device__ __forceinline__ void load(const P& p, float sw, int f0, int il, int hh) {
+#pragma unroll
+        for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                const float* w = p.W2 + (size_t)(f0 + 32 * fb + il) * kE + 16 * s2 + 4 * hh;
+                const float4 a = f4_ld(w), b = f4_ld(w + 8);
+                const float v[8] = {a.x * sw, a.y * sw, a.z * sw, a.w * sw, b.x * sw, b.y * sw, b.z * sw, b.w * sw};
+                split8s(v, hi[fb][s2], lo[fb][s2]);
+            }
+    }
+};
+
+__device__ __forceinline__ void wave_double_pair_store(double a, double b, double* out_a, double* out_b, int hh) {
+    // the two halves of a wave hold different rows of the same feature
+    a += __shfl_xor(a, 32, 64);
+    b += __shfl_xor(b, 32, 64);
+    if (hh == 0) *out_a = a, *out_b = b;
+}
+
+// row of register r of row block rb for a lane of half hh, relative to the tile
+__device__ __forceinline__ int n_row(int rb, int r, int hh) { return 32 * rb + 8 * (r >> 2) + 4 * hh + (r & 3); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// passes 2, 3, 4: x2 = a1 W2^T + b2 recomputed as D[m = row][n = feature] (lane = feature, register r = row
+// 8 (r >> 2) + 4 hh + (r & 3) of the block), then
+//   MODE 0  column sums of the raw accumulators and their squares    -> partial[workgroup][2][256] double
+//   MODE 1  z = silu((x2 - mean) gamma rstd + beta), max|z|           -> z
+//   MODE 2  sums of gz = g_z silu'(.) and gz xhat (float64), maxima   -> partial[workgroup][2][256] double
+// Per-feature constants folded:  zl = acc A + B,  xhat = acc C + D.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(kThreads, 2) void angle_l2_kernel(P p) {
+    __shared__ L1Shared sh;
+    __shared__ uint4 a_frag[4 * 4 * 2 * 64];  // 32 KiB
+    const float sa = f16_scale(p.scal[kBoundA1]), sw = f16_scale(p.scal[kAmaxW2]);
+    l1_setup(p, sh, kL1Act, sa);
+    const int lane = threadIdx.x & 63, il = lane & 31, hh = lane >> 5, w = threadIdx.x >> 6;
+    const float inv2 = 1.0f / (sa * sw), neg_k = -kLog2e / sa;
+    Rbf rbf;
+    rbf.load(p, hh);
+    W2Frag w2;
+    w2.load(p, sw, 64 * w, il, hh);
+    float cA[2], cB[2], cC[2], cD[2];
+    double acc_a[2] = {0.0, 0.0}, acc_b[2] = {0.0, 0.0};
+    float am0 = 0.0f, am1 = 0.0f;
+#pragma unroll
+    for (int fb = 0; fb < 2; ++fb) {
+        const int f = 64 * w + 32 * fb + il;
+        cA[fb] = cB[fb] = cC[fb] = cD[fb] = 0.0f;
+        if constexpr (MODE != 0) {
+            const float d = p.b2[f] - p.stat2[f], rstd = p.stat2[kH + f], sc = p.stat2[2 * kH + f];
+            cA[fb] = inv2 * sc;
+            cB[fb] = fmaf(d, sc, p.stat2[3 * kH + f]);
+            cC[fb] = inv2 * rstd;
+            cD[fb] = d * rstd;
+        }
+    }
+    const int64_t ntiles = (p.rows + kTile - 1) / kTile;
+    f16x8 none_hi[4], none_lo[4];
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t row0 = tile * kTile;
+        const bool full = row0 + kTile <= p.rows;  // uniform
+        phase_a<false>(p, sh, rbf, neg_k, row0 + 32 * w, lane, w, a_frag, none_hi, none_lo);
+        __syncthreads();
+#pragma unroll 1
+        for (int rb = 0; rb < 4; ++rb) {
+            float g[2][16];
+            if constexpr (MODE == 2) {  // g_z of this block, issued before the products that hide its latency
+#pragma unroll
+                for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        int64_t row = row0 + n_row(rb, r, hh);
+                        row = row < p.rows ? row : p.rows - 1;
+                        g[fb][r] = p.gz[row * kH + 64 * w + 32 * fb + il];
+                    }
+            }
+            f32x16 acc[2] = {zero16(), zero16()};
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                const f16x8 ah = __builtin_bit_cast(f16x8, a_frag[afrag_idx(rb, s2, 0, lane)]);
+                const f16x8 al = __builtin_bit_cast(f16x8, a_frag[afrag_idx(rb, s2, 1, lane)]);
+#pragma unroll
+                for (int fb = 0; fb < 2; ++fb) acc[fb] = mfma3(ah, al, w2.hi[fb][s2], w2.lo[fb][s2], acc[fb]);
+            }
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb) {
+                const int f = 64 * w + 32 * fb + il;
+                float s = 0.0f, q = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t row = row0 + n_row(rb, r, hh);
+                    const bool ok = full || row < p.rows;
+                    if constexpr (MODE == 0) {
+                        const float a = ok ? acc[fb][r] : 0.0f;
+                        s += a;
+                        q = fmaf(a, a, q);
+                    } else {
+                        const float zl = fmaf(acc[fb][r], cA[fb], cB[fb]);
+                        if constexpr (MODE == 1) {
+                            const float zz = silu_scaled(zl, -kLog2e);
+                            if (ok) p.z[row * kH + f] = zz;
+                            am0 = fmaxf(am0, ok ? fabsf(zz) : 0.0f);
+                        } else {
+                            const float gz = ok ? g[fb][r] * dsilu_fast(zl) : 0.0f;
+                            const float xh = fmaf(acc[fb][r], cC[fb], cD[fb]);
+                            s += gz;
+                            q = fmaf(gz, xh, q);
+                            am0 = fmaxf(am0, fabsf(gz));
+                            am1 = fmaxf(am1, ok ? fabsf(xh) : 0.0f);
+                        }
+                    }
+                }
+                if constexpr (MODE != 1) acc_a[fb] += (double)s, acc_b[fb] += (double)q;
+            }
+        }
+        __syncthreads();
+    }
+    if constexpr (MODE != 1) {
+        double* out = static_cast<double*>(p.partial) + (size_t)blockIdx.x * 2 * kH;
+#pragma unroll
+        for (int fb = 0; fb < 2; ++fb) {
+            const int f = 64 * w + 32 * fb + il;
+            wave_double_pair_store(acc_a[fb], acc_b[fb], out + f, out + kH + f, hh);
+        }
+    }
+    if constexpr (MODE == 1) block_amax_commit(am0, p.z_amax);
+    if constexpr (MODE == 2) {
+        block_amax_commit(am0, p.scal + kAmaxGz2);
+        block_amax_commit(am1, p.scal + kAmaxXh2);
+    }
+}
+
+// BatchNorm-backward sums from double slabs [slabs][2][F] -> red [2, F]; and the bound of |dx| = |gamma rstd (gz - (c0 + xhat c1) / n)|
+__global__ __launch_bounds__(256) void angle_red_finalize_kernel(const double* __restrict__ partial, int slabs, int64_t rows, int F,
+                                                                 const float* __restrict__ stat, float* __restrict__ red,
+                                                                 float* __restrict__ scal, int amax_gz, int amax_xh, int bound) {
+    __shared__ double shs[64][4], shq[64][4];
+    const int c = threadIdx.x & 3, y = threadIdx.x >> 2;
+    const int f = blockIdx.x * 4 + c;
+    double s = 0.0, q = 0.0;
+    for (int k = y; k < slabs; k += 64) {
+        s += partial[(size_t)k * 2 * F + f];
+        q += partial[(size_t)k * 2 * F + F + f];
+    }
+    shs[y][c] = s;
+    shq[y][c] = q;
+    __syncthreads();
+    if (y != 0) return;
+    s = 0.0, q = 0.0;
+    for (int k = 0; k < 64; ++k) s += shs[k][c], q += shq[k][c];
+    red[f] = (float)s;
+    red[F + f] = (float)q;
+    const float inv_n = 1.0f / (float)rows;
+    const float b = fabsf(stat[2 * F + f]) * (scal[amax_gz] + inv_n * (fabsf((float)s) + scal[amax_xh] * fabsf((float)q)));
+    atomic_max_pos(scal + bound, b);
+}
+
+// identity fragments for changing the orientation of a register tile: B[k][n] = 1 where slot k of step s names feature n
+//   PERM: slot (hh, i) of step s = 16 s + 8 (i >> 2) + 4 hh + (i & 3)   (tiles that came out of an MFMA)
+//   else: slot (hh, i) of step s = 16 s + 8 hh + i                      (tiles built in natural order)
+template <bool PERM>
+__device__ __forceinline__ f16x8 identity_frag(int s, int il, int hh) {
+    f16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int k = PERM ? 16 * s + 8 * (i >> 2) + 4 * hh + (i & 3) : 16 * s + 8 * hh + i;
+        v[i] = k == il ? (_Float16)1.0f : (_Float16)0.0f;
+    }
+    return v;
+}
+// registers [8 s, 8 s + 8) of an accumulator that holds fp16 payloads exactly -> fragment
+__device__ __forceinline__ f16x8 pack8(const f32x16& d, int s) {
+    f16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (_Float16)d[8 * s + i];
+    return v;
+}
+
+// dx2 scaled by sd, per-feature constants folded:  sd dx2 = E gz + (acc F + G)  with  E = sd gamma rstd,
+// F = -E c1 rstd / (n scale),  G = -E (c0 + (b2 - mean) rstd c1) / n
+struct Dx2Const {
+    float A, B, E, F, G;
+    __device__ __forceinline__ void load(const P& p, int f, float inv2, float sd) {
+        const float inv_n = 1.0f / (float)p.rows;
+        const float d = p.b2[f] - p.stat2[f], rstd = p.stat2[kH + f], sc = p.stat2[2 * kH + f];
+        const float c0 = p.red2[f] * inv_n, c1 = p.red2[kH + f] * inv_n;
+        A = inv2 * sc;
+        B = fmaf(d, sc, p.stat2[3 * kH + f]);
+        E = sd * sc;
+        F = -E * c1 * rstd * inv2;
+        G = -E * fmaf(d * rstd, c1, c0);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// pass 5: dW2[f][j] = sum_rows dx2[row][f] a1[row][j],  dx2 = gamma rstd (gz - (c0 + xhat c1) / n): the recomputed tile
+// D[row][feature] (lane = feature, registers = rows) IS the A operand [m = feature][k = rows] of that product; its B operand,
+// a1 as (lane = j, registers = rows), is a1's fragment turned by an identity product in phase A and filed in LDS.
+// partial[workgroup][256][64], partial_b[workgroup][256] (column sums of dx2 = db2) floats.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int bfrag_idx(int rb, int jb, int s, int hl, int lane) { return (((rb * 2 + jb) * 2 + s) * 2 + hl) * 64 + lane; }
+
+__global__ __launch_bounds__(kThreads, 2) void angle_dw2_kernel(P p) {
+    __shared__ L1Shared sh;
+    __shared__ uint4 a_frag[4 * 4 * 2 * 64];      // 32 KiB
+    __shared__ uint4 b_frag[4 * 2 * 2 * 2 * 64];  // 32 KiB
+    const float sa = f16_scale(p.scal[kBoundA1]), sw = f16_scale(p.scal[kAmaxW2]), sd = f16_scale(p.scal[kBoundDx2]);
+    l1_setup(p, sh, kL1Act, sa);
+    const int lane = threadIdx.x & 63, il = lane & 31, hh = lane >> 5, w = threadIdx.x >> 6;
+    const float inv2 = 1.0f / (sa * sw), neg_k = -kLog2e / sa;
+    Rbf rbf;
+    rbf.load(p, hh);
+    W2Frag w2;
+    w2.load(p, sw, 64 * w, il, hh);
+    const f16x8 id0 = identity_frag<true>(0, il, hh), id1 = identity_frag<true>(1, il, hh);
+    Dx2Const k[2];
+    float gb[2] = {0.0f, 0.0f};
+#pragma unroll
+    for (int fb = 0; fb < 2; ++fb) k[fb].load(p, 64 * w + 32 * fb + il, inv2, sd);
+    f32x16 dw[2][2] = {{zero16(), zero16()}, {zero16(), zero16()}};
+    const int64_t ntiles = (p.rows + kTile - 1) / kTile;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t row0 = tile * kTile;
+        const bool full = row0 + kTile <= p.rows;  // uniform
+        {
+            f16x8 k_hi[4], k_lo[4];
+            phase_a<true>(p, sh, rbf, neg_k, row0 + 32 * w, lane, w, a_frag, k_hi, k_lo);
+            // a1 of this wave's rows as (lane = j, registers = rows): features 32 jb .. 32 jb + 31 sit in steps 2 jb, 2 jb + 1
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb) {
+                f32x16 th = mfma(k_hi[2 * jb], id0, zero16());
+                th = mfma(k_hi[2 * jb + 1], id1, th);
+                f32x16 tl = mfma(k_lo[2 * jb], id0, zero16());
+                tl = mfma(k_lo[2 * jb + 1], id1, tl);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    b_frag[bfrag_idx(w, jb, s, 0, lane)] = __builtin_bit_cast(uint4, pack8(th, s));
+                    b_frag[bfrag_idx(w, jb, s, 1, lane)] = __builtin_bit_cast(uint4, pack8(tl, s));
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int rb = 0; rb < 4; ++rb) {
+            float g[2][16];
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int64_t row = row0 + n_row(rb, r, hh);
+                    row = row < p.rows ? row : p.rows - 1;
+                    g[fb][r] = p.gz[row * kH + 64 * w + 32 * fb + il];
+                }
+            f32x16 acc[2] = {zero16(), zero16()};
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                const f16x8 ah = __builtin_bit_cast(f16x8, a_frag[afrag_idx(rb, s2, 0, lane)]);
+                const f16x8 al = __builtin_bit_cast(f16x8, a_frag[afrag_idx(rb, s2, 1, lane)]);
+#pragma unroll
+                for (int fb = 0; fb < 2; ++fb) acc[fb] = mfma3(ah, al, w2.hi[fb][s2], w2.lo[fb][s2], acc[fb]);
+            }
+            f16x8 d_hi[2][2], d_lo[2][2];
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    float dx[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int r = 8 * s + i;
+                        const bool ok = full || row0 + n_row(rb, r, hh) < p.rows;
+                        const float a = acc[fb][r];
+                        const float gz = g[fb][r] * dsilu_fast(fmaf(a, k[fb].A, k[fb].B));
+                        const float o = ok ? fmaf(k[fb].E, gz, fmaf(a, k[fb].F, k[fb].G)) : 0.0f;
+                        dx[i] = o;
+                        gb[fb] += o;
+                    }
+                    split8s(dx, d_hi[fb][s], d_lo[fb][s]);
+                }
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const f16x8 bh = __builtin_bit_cast(f16x8, b_frag[bfrag_idx(rb, jb, s, 0, lane)]);
+                    const f16x8 bl = __builtin_bit_cast(f16x8, b_frag[bfrag_idx(rb, jb, s, 1, lane)]);
+#pragma unroll
+                    for (int fb = 0; fb < 2; ++fb) dw[fb][jb] = mfma3(d_hi[fb][s], d_lo[fb][s], bh, bl, dw[fb][jb]);
+                }
+        }
+        __syncthreads();
+    }
+    // dw[fb][jb]: D[m = feature][n = j]: lane = j, register r = feature 8 (r >> 2) + 4 hh + (r & 3) of block fb
+    float* out = static_cast<float*>(p.partial) + (size_t)blockIdx.x * (kH * kE);
+    const float invd = 1.0f / (sd * sa);
+#pragma unroll
+    for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int f = 64 * w + 32 * fb + 8 * (r >> 2) + 4 * hh + (r & 3);
+                out[f * kE + 32 * jb + il] = dw[fb][jb][r] * invd;
+            }
+#pragma unroll
+    for (int fb = 0; fb < 2; ++fb) {
+        float v = gb[fb];
+        v += __shfl_xor(v, 32, 64);
+        if (hh == 0) p.partial_b[(size_t)blockIdx.x * kH + 64 * w + 32 * fb + il] = v / sd;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// pass 6: da1 = dx2 W2.  x2 recomputed in the OTHER orientation (operands swapped: D[m = feature][n = row], lane = row,
+// registers = features), so that dx2 is the A operand [m = row][k = features] of the product; each wave contracts its own
+// 64 features and the four partial [32 x 64] tiles are added through LDS in wave order (two rounds of 32 columns).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads, 2) void angle_da1_kernel(P p) {
+    __shared__ L1Shared sh;
+    __shared__ uint4 a_frag[4 * 4 * 2 * 64];   // 32 KiB
+    __shared__ float4 red[4 * 4 * 64];          // 16 KiB: [wave][register quad][lane]
+    __shared__ float cst[5][kH];                // Dx2Const per feature
+    const float sa = f16_scale(p.scal[kBoundA1]), sw = f16_scale(p.scal[kAmaxW2]), sd = f16_scale(p.scal[kBoundDx2]);
+    const float inv2 = 1.0f / (sa * sw), invd = 1.0f / (sd * sw), neg_k = -kLog2e / sa;
+    for (int f = threadIdx.x; f < kH; f += kThreads) {
+        Dx2Const k;
+        k.load(p, f, inv2, sd);
+        cst[0][f] = k.A, cst[1][f] = k.B, cst[2][f] = k.E, cst[3][f] = k.F, cst[4][f] = k.G;
+    }
+    l1_setup(p, sh, kL1Act, sa);
+    const int lane = threadIdx.x & 63, il = lane & 31, hh = lane >> 5, w = threadIdx.x >> 6;
+    Rbf rbf;
+    rbf.load(p, hh);
+    W2Frag w2;
+    w2.load(p, sw, 64 * w, il, hh);
+    // B fragments of the da1 product: lane n = j = 32 jb + il, slot (hh, i) of step (fb, s) = feature
+    // 64 w + 32 fb + 16 s + 8 (i >> 2) + 4 hh + (i & 3)
+    f16x8 c_hi[2][2][2], c_lo[2][2][2];
+#pragma unroll
+    for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int f = 64 * w + 32 * fb + 16 * s + 8 * (i >> 2) + 4 * hh + (i & 3);
+                    v[i] = p.W2[(size_t)f * kE + 32 * jb + il] * sw;
+                }
+                split8s(v, c_hi[fb][s][jb], c_lo[fb][s][jb]);
+            }
+    const int64_t ntiles = (p.rows + kTile - 1) / kTile;
+    f16x8 none_hi[4], none_lo[4];
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t row0 = tile * kTile;
+        phase_a<false>(p, sh, rbf, neg_k, row0 + 32 * w, lane, w, a_frag, none_hi, none_lo);
+        __syncthreads();
+#pragma unroll 1
+        for (int rb = 0; rb < 4; ++rb) {
+            // acc[fb][r]: row = row0 + 32 rb + il, feature = 64 w + 32 fb + 8 (r >> 2) + 4 hh + (r & 3)
+            const int64_t row = row0 + 32 * rb + il;
+            const bool ok = row < p.rows;
+            const float* grow = p.gz + (ok ? row : p.rows - 1) * kH + 64 * w + 4 * hh;
+            float4 g[2][4];
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) g[fb][q] = f4_ld(grow + 32 * fb + 8 * q);
+            f32x16 acc[2] = {zero16(), zero16()};
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                const f16x8 ah = __builtin_bit_cast(f16x8, a_frag[afrag_idx(rb, s2, 0, lane)]);
+                const f16x8 al = __builtin_bit_cast(f16x8, a_frag[afrag_idx(rb, s2, 1, lane)]);
+#pragma unroll
+                for (int fb = 0; fb < 2; ++fb) acc[fb] = mfma3(w2.hi[fb][s2], w2.lo[fb][s2], ah, al, acc[fb]);
+            }
+            f32x16 da[2] = {zero16(), zero16()};
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb) {
+                f16x8 d_hi[2], d_lo[2];
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    float dx[8];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int f = 64 * w + 32 * fb + 8 * (2 * s + q) + 4 * hh;
+                        const float4 A4 = f4_ld(&cst[0][f]), B4 = f4_ld(&cst[1][f]), E4 = f4_ld(&cst[2][f]);
+                        const float4 F4 = f4_ld(&cst[3][f]), G4 = f4_ld(&cst[4][f]), g4 = g[fb][2 * s + q];
+                        const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, cA[4] = {A4.x, A4.y, A4.z, A4.w}, cB[4] = {B4.x, B4.y, B4.z, B4.w};
+                        const float cE[4] = {E4.x, E4.y, E4.z, E4.w}, cF[4] = {F4.x, F4.y, F4.z, F4.w}, cG[4] = {G4.x, G4.y, G4.z, G4.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float a = acc[fb][8 * s + 4 * q + e];
+                            const float gz = gg[e] * dsilu_fast(fmaf(a, cA[e], cB[e]));
+                            dx[4 * q + e] = ok ? fmaf(cE[e], gz, fmaf(a, cF[e], cG[e])) : 0.0f;
+                        }
+                    }
+                    split8s(dx, d_hi[s], d_lo[s]);
+                }
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int jb = 0; jb < 2; ++jb) da[jb] = mfma3(d_hi[s], d_lo[s], c_hi[fb][s][jb], c_lo[fb][s][jb], da[jb]);
+            }
+            // da[jb][r]: row = 32 rb + 8 (r >> 2) + 4 hh + (r & 3), j = 32 jb + il - this wave's 64 features only.
+            // Round jb: every wave files its four register quads; wave w then adds quad w of the four tiles in wave order.
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    red[(w * 4 + q) * 64 + lane] = make_float4(da[jb][4 * q], da[jb][4 * q + 1], da[jb][4 * q + 2], da[jb][4 * q + 3]);
+                __syncthreads();
+                float4 s = red[(0 * 4 + w) * 64 + lane];
+#pragma unroll
+                for (int o = 1; o < 4; ++o) s = f4_add(s, red[(o * 4 + w) * 64 + lane]);
+                const float v[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int64_t orow = row0 + 32 * rb + 8 * w + 4 * hh + e;
+                    if (orow < p.rows) p.da1[orow * kE + 32 * jb + il] = v[e] * invd;
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// passes 7, 8 (one wave per block of 32 rows, nothing shared): gz1 = da1 silu'(z1), then
+//   MODE 0  sums of gz1 and gz1 xhat1, maxima                        -> partial[wave][2][64] double
+//   MODE 1  dx1 = gamma rstd (gz1 - (c0 + xhat c1) / n);  dW1[c][k] = sum_rows dx1[row][c] rbf[row][k]: both operands turned to
+//           (registers = rows) by identity products; the expansion carries a column of ones in slot `bins`, so column `bins`
+//           of the product is db1                                      -> partial[wave][64][bins + 1] floats
+// ---------------------------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(kThreads, 2) void angle_l1_bwd_kernel(P p) {
+    __shared__ L1Shared sh;
+    const float sx = MODE == 1 ? f16_scale(p.scal[kBoundDx1]) : 1.0f;
+    l1_setup(p, sh, kL1Bwd, sx);
+    const int lane = threadIdx.x & 63, il = lane & 31, hh = lane >> 5;
+    const int wave = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6), nwaves = gridDim.x * (kThreads / 64);
+    Rbf rbf;
+    rbf.load(p, hh);
+    float s0[2][16], s1[2][16];
+    float am0 = 0.0f, am1 = 0.0f;
+    f32x16 dw[2][2];
+    f16x8 ip0, ip1, in0, in1;
+    if constexpr (MODE == 0) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s0[cb][r] = s1[cb][r] = 0.0f;
+    } else {
+        ip0 = identity_frag<true>(0, il, hh), ip1 = identity_frag<true>(1, il, hh);
+        in0 = identity_frag<false>(0, il, hh), in1 = identity_frag<false>(1, il, hh);
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) dw[jb][nb] = zero16();
+    }
+    const int64_t nblk = (p.rows + 31) / 32;
+    for (int64_t blk = wave; blk < nblk; blk += nwaves) {
+        const int64_t row = blk * 32 + il;
+        const bool ok = row < p.rows;
+        const float hv = ok ? p.h[row] : 0.0f;
+        const float* drow = p.da1 + (ok ? row : p.rows - 1) * kE + 4 * hh;
+        float4 g4[2][4];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) g4[cb][q] = f4_ld(drow + 32 * cb + 8 * q);
+        f16x8 r_hi[3], r_lo[3];
+        rbf.expand<MODE == 1>(hv, hh, p.bins, r_hi, r_lo);
+        f32x16 acc[2];
+        l1_product(sh, lane, r_hi, r_lo, acc);
+        f16x8 b_hi[2][2], b_lo[2][2];
+        if constexpr (MODE == 1) {
+            // rbf (lane = row, slots = bins in natural order) -> (lane = bin 32 nb + il, registers = rows)
+            f32x16 th = mfma(r_hi[0], in0, zero16());
+            th = mfma(r_hi[1], in1, th);
+            f32x16 tl = mfma(r_lo[0], in0, zero16());
+            tl = mfma(r_lo[1], in1, tl);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) b_hi[0][s] = pack8(th, s), b_lo[0][s] = pack8(tl, s);
+            th = mfma(r_hi[2], in0, zero16());
+            tl = mfma(r_lo[2], in0, zero16());
+#pragma unroll
+            for (int s = 0; s < 2; ++s) b_hi[1][s] = pack8(th, s), b_lo[1][s] = pack8(tl, s);
+        }
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            f16x8 x_hi[2], x_lo[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float dx[8];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int qq = 2 * s + q;
+                    const float4 gq = g4[cb][qq];
+                    const float gg[4] = {gq.x, gq.y, gq.z, gq.w};
+                    float ux[4], vx[4], ga[4], be[4];
+                    l1_const4(sh, 0, cb, qq, hh, ux);
+                    l1_const4(sh, 1, cb, qq, hh, vx);
+                    l1_const4(sh, 2, cb, qq, hh, ga);
+                    l1_const4(sh, 3, cb, qq, hh, be);
+                    float c4[4], c5[4], c6[4];
+                    if constexpr (MODE == 1) {
+                        l1_const4(sh, 4, cb, qq, hh, c4);
+                        l1_const4(sh, 5, cb, qq, hh, c5);
+                        l1_const4(sh, 6, cb, qq, hh, c6);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * qq + e;
+                        const float xh = fmaf(acc[cb][r], ux[e], vx[e]);
+                        const float gz = ok ? gg[e] * dsilu_fast(fmaf(xh, ga[e], be[e])) : 0.0f;
+                        if constexpr (MODE == 0) {
+                            s0[cb][r] += gz;
+                            s1[cb][r] = fmaf(gz, xh, s1[cb][r]);
+                            am0 = fmaxf(am0, fabsf(gz));
+                            am1 = fmaxf(am1, ok ? fabsf(xh) : 0.0f);
+                        } else
+                            dx[4 * q + e] = ok ? fmaf(c4[e], gz, fmaf(xh, c5[e], c6[e])) : 0.0f;
+                    }
+                }
+                if constexpr (MODE == 1) split8s(dx, x_hi[s], x_lo[s]);
+            }
+            if constexpr (MODE == 1) {
+                // dx1 (lane = row, slots = features of block cb) -> (lane = feature 32 cb + il, registers = rows)
+                f32x16 th = mfma(x_hi[0], ip0, zero16());
+                th = mfma(x_hi[1], ip1, th);
+                f32x16 tl = mfma(x_lo[0], ip0, zero16());
+                tl = mfma(x_lo[1], ip1, tl);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const f16x8 ah = pack8(th, s), al = pack8(tl, s);
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) dw[cb][nb] = mfma3(ah, al, b_hi[nb][s], b_lo[nb][s], dw[cb][nb]);
+                }
+            }
+        }
+    }
+    if constexpr (MODE == 0) {
+        double* out = static_cast<double*>(p.partial) + (size_t)wave * 2 * kE;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float a = half_sum(s0[cb][r]), b = half_sum(s1[cb][r]);
+                if (il == 0) {
+                    const int col = l1_col(cb, r, hh);
+                    out[col] = (double)a;
+                    out[kE + col] = (double)b;
+                }
+            }
+        block_amax_commit(am0, p.scal + kAmaxGz1);
+        block_amax_commit(am1, p.scal + kAmaxXh1);
+    } else {
+        // dw[jb][nb]: D[m = feature][n = bin]: lane = bin 32 nb + il, register r = feature 32 jb + 8 (r >> 2) + 4 hh + (r & 3)
+        const int ld = p.bins + 1;
+        float* out = static_cast<float*>(p.partial) + (size_t)wave * kE * ld;
+        const float inv = 1.0f / (sx * kRbfScale);
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                const int bin = 32 * nb + il;
+                if (bin < ld) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) out[(32 * jb + 8 * (r >> 2) + 4 * hh + (r & 3)) * ld + bin] = dw[jb][nb][r] * inv;
+                }
+            }
+    }
+}
+
+// dW1 | db1 from the reduced [64][bins + 1] product
+__global__ void angle_unpack_dw1_kernel(const float* __restrict__ src, int bins, float* __restrict__ gW, float* __restrict__ gb) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= kE * (bins + 1)) return;
+    const int c = i / (bins + 1), k = i - c * (bins + 1);
+    if (k < bins) gW[c * bins + k] = src[i];
+    else gb[c] = src[i];
+}
+
+inline int grid_for(int64_t rows, int rows_per_block) {
+    const int64_t need = (rows + rows_per_block - 1) / rows_per_block;
+    return (int)(need < kGrid ? (need > 0 ? need : 1) : kGrid);
+}
+inline size_t al256(size_t b) { return (b + 255) / 256 * 256; }
+
+P make_params(const alignn_angle_args& a) {
+    P p{};
+    p.h = a.h;
+    p.rows = a.rows;
+    p.centers = a.centers;
+    p.gamma = a.gamma;
+    p.bins = a.bins;
+    p.W1 = a.l1.W, p.b1 = a.l1.b, p.gamma1 = a.l1.gamma, p.beta1 = a.l1.beta;
+    p.W2 = a.l2.W, p.b2 = a.l2.b;
+    p.stat1 = a.stat1, p.stat2 = a.stat2;
+    p.scal = a.scal;
+    p.z = a.z, p.z_amax = a.z_amax;
+    p.gz = a.gz;
+    p.red1 = a.l1.red, p.red2 = a.l2.red;
+    return p;
+}
+
+bool shape_ok(const alignn_angle_args& a) {
+    return a.rows > 0 && a.bins > 0 && a.bins < kBinsMax && a.l1.in == a.bins && a.l1.out == kE && a.l2.in == kE && a.l2.out == kH;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t alignn_angle_args_sizeof(void) { return sizeof(alignn_angle_args); }
+
+int alignn_angle_embed_supported(int bins, int embed, int hidden) { return bins > 0 && bins < kBinsMax && embed == kE && hidden == kH; }
+
+size_t alignn_angle_embed_workspace(int64_t rows, int bins, int backward) {
+    (void)rows;
+    const size_t waves = (size_t)kGrid * (kThreads / 64);
+    if (!backward) {
+        const size_t a = al256(waves * 3 * kE * sizeof(float)), b = al256((size_t)kGrid * 2 * kH * sizeof(double));
+        return a > b ? a : b;
+    }
+    size_t total = al256((size_t)rows * kE * sizeof(float));                       // da1
+    total += al256((size_t)kGrid * 2 * kH * sizeof(double));                        // sums (layer 2, then layer 1: waves * 2 * 64)
+    total += al256((size_t)kGrid * kH * kE * sizeof(float));                        // dW2 slabs
+    total += al256((size_t)kGrid * kH * sizeof(float));                             // db2 slabs
+    total += al256((size_t)alignn_slab_fold_slabs() * kH * kE * sizeof(float));     // folded dW2 slabs
+    total += al256(waves * kE * (size_t)(bins + 1) * sizeof(float));                // dW1 | db1 slabs
+    total += 2 * al256((size_t)alignn_slab_fold_slabs() * kE * (size_t)(bins + 1) * sizeof(float));
+    return total;
+}
+
+// forward: z [rows, 256] (+ max|z|), stat1 / stat2 / scal kept for the backward, running statistics updated
+int alignn_angle_embed_fwd(const alignn_angle_args* a, alignn_stream_t stream) {
+    if (a == nullptr || !shape_ok(*a) || !a->h || !a->centers || !a->stat1 || !a->stat2 || !a->scal || !a->z || !a->workspace)
+        return (int)hipErrorInvalidValue;
+    if (a->workspace_bytes < alignn_angle_embed_workspace(a->rows, a->bins, 0)) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    P p = make_params(*a);
+    p.partial = a->workspace;
+    hipError_t e = hipMemsetAsync(a->scal, 0, kScalFloats * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(angle_prep_kernel, dim3(1), dim3(kThreads), 0, st, p);
+    const int g1 = grid_for(a->rows, 32 * (kThreads / 64)), g2 = grid_for(a->rows, kTile);
+    hipLaunchKernelGGL(angle_l1_stats_kernel, dim3(g1), dim3(kThreads), 0, st, p);
+    hipLaunchKernelGGL(angle_stat_finalize_kernel<false>, dim3(kE / 4), dim3(256), 0, st, (const void*)p.partial, g1 * (kThreads / 64),
+                       a->rows, kE, a->l1.b, a->l1.gamma, a->l1.beta, a->eps, a->momentum, a->l1.rm, a->l1.rv, a->stat1, a->scal);
+    hipLaunchKernelGGL(angle_l2_kernel<0>, dim3(g2), dim3(kThreads), 0, st, p);
+    hipLaunchKernelGGL(angle_stat_finalize_kernel<true>, dim3(kH / 4), dim3(256), 0, st, (const void*)p.partial, g2, a->rows, kH,
+                       a->l2.b, a->l2.gamma, a->l2.beta, a->eps, a->momentum, a->l2.rm, a->l2.rv, a->stat2, a->scal);
+    hipLaunchKernelGGL(angle_l2_kernel<1>, dim3(g2), dim3(kThreads), 0, st, p);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+// backward: gradients of both layers' parameters (gW, gb, red = dbeta | dgamma) from g_z [rows, 256]; `side` (optional):
+// the stream the slab reductions of the weight gradients go to (the caller orders it before and after)
+int alignn_angle_embed_bwd(const alignn_angle_args* a, alignn_stream_t stream) {
+    if (a == nullptr || !shape_ok(*a) || !a->h || !a->centers || !a->stat1 || !a->stat2 || !a->scal || !a->gz || !a->workspace ||
+        !a->l1.gW || !a->l1.gb || !a->l1.red || !a->l2.gW || !a->l2.gb || !a->l2.red)
+        return (int)hipErrorInvalidValue;
+    if (a->workspace_bytes < alignn_angle_embed_workspace(a->rows, a->bins, 1)) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    const int waves_per = kThreads / 64;
+    const size_t waves = (size_t)kGrid * waves_per;
+    char* ws = static_cast<char*>(a->workspace);
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        void* q = ws + off;
+        off += al256(bytes);
+        return q;
+    };
+    float* da1 = static_cast<float*>(take((size_t)a->rows * kE * sizeof(float)));
+    double* sums = static_cast<double*>(take((size_t)kGrid * 2 * kH * sizeof(double)));
+    float* dw2 = static_cast<float*>(take((size_t)kGrid * kH * kE * sizeof(float)));
+    float* db2 = static_cast<float*>(take((size_t)kGrid * kH * sizeof(float)));
+    float* dw2f = static_cast<float*>(take((size_t)alignn_slab_fold_slabs() * kH * kE * sizeof(float)));
+    const int ld1 = a->bins + 1;
+    float* dw1 = static_cast<float*>(take(waves * kE * (size_t)ld1 * sizeof(float)));
+    float* dw1f = static_cast<float*>(take((size_t)alignn_slab_fold_slabs() * kE * (size_t)ld1 * sizeof(float)));
+    float* dw1s = static_cast<float*>(take((size_t)alignn_slab_fold_slabs() * kE * (size_t)ld1 * sizeof(float)));
+    P p = make_params(*a);
+    p.da1 = da1;
+    const int g1 = grid_for(a->rows, 32 * waves_per), g2 = grid_for(a->rows, kTile);
+    // layer 2
+    p.partial = sums;
+    hipLaunchKernelGGL(angle_l2_kernel<2>, dim3(g2), dim3(kThreads), 0, st, p);
+    hipLaunchKernelGGL(angle_red_finalize_kernel, dim3(kH / 4), dim3(256), 0, st, (const double*)sums, g2, a->rows, kH, a->stat2,
+                       a->l2.red, a->scal, kAmaxGz2, kAmaxXh2, kBoundDx2);
+    p.partial = dw2;
+    p.partial_b = db2;
+    hipLaunchKernelGGL(angle_dw2_kernel, dim3(g2), dim3(kThreads), 0, st, p);
+    hipLaunchKernelGGL(angle_da1_kernel, dim3(g2), dim3(kThreads), 0, st, p);
+    ALIGNN_CHECK_LAUNCH();
+    int rc;
+    if (g2 > alignn_slab_fold_slabs()) {
+        if ((rc = alignn_slab_fold(dw2, g2, kH * kE, dw2f, stream)) != 0) return rc;
+        if ((rc = alignn_slab_sum(dw2f, alignn_slab_fold_slabs(), kH * kE, a->l2.gW, stream)) != 0) return rc;
+    } else if ((rc = alignn_slab_sum(dw2, g2, kH * kE, a->l2.gW, stream)) != 0)
+        return rc;
+    if ((rc = alignn_slab_sum(db2, g2, kH, a->l2.gb, stream)) != 0) return rc;
+    // layer 1
+    p.partial = sums;
+    hipLaunchKernelGGL(angle_l1_bwd_kernel<0>, dim3(g1), dim3(kThreads), 0, st, p);
+    hipLaunchKernelGGL(angle_red_finalize_kernel, dim3(kE / 4), dim3(256), 0, st, (const double*)sums, g1 * waves_per, a->rows, kE,
+                       a->stat1, a->l1.red, a->scal, kAmaxGz1, kAmaxXh1, kBoundDx1);
+    p.partial = dw1;
+    hipLaunchKernelGGL(angle_l1_bwd_kernel<1>, dim3(g1), dim3(kThreads), 0, st, p);
+    ALIGNN_CHECK_LAUNCH();
+    const int slabs1 = g1 * waves_per, w1 = kE * ld1;
+    if (slabs1 > alignn_slab_fold_slabs()) {
+        if ((rc = alignn_slab_fold(dw1, slabs1, w1, dw1f, stream)) != 0) return rc;
+        if ((rc = alignn_slab_sum(dw1f, alignn_slab_fold_slabs(), w1, dw1s, stream)) != 0) return rc;
+    } else if ((rc = alignn_slab_sum(dw1, slabs1, w1, dw1s, stream)) != 0)
+        return rc;
+    hipLaunchKernelGGL(angle_unpack_dw1_kernel, dim3((w1 + 255) / 256), dim3(256), 0, st, (const float*)dw1s, (int)a->bins, a->l1.gW,
+                       a->l1.gb);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

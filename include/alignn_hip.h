@@ -641,6 +641,37 @@ int alignn_model_infer(const alignn_model_desc* desc, const alignn_model_batch* 
                        float* out, alignn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The bond-angle embedding on T rows (csrc/angle.hip):  z = MLPLayer(64 -> 256)(MLPLayer(bins -> 64)(RBFExpansion(h)))
+ * (alignn/models/alignn.py:215-222 angle_embedding, :170-184 MLPLayer, alignn/models/utils.py:9-47 RBFExpansion) and
+ * the gradients of its eight parameter tensors, WITHOUT the [T, bins] / [T, 64] / [T, 256] intermediates: every row is a
+ * function of one cosine, so each pass recomputes what it needs from h on the matrix cores (f16x3 split products) and only z
+ * (forward) / g_z and a [T, 64] gradient (backward) cross HBM.  Shapes carried: bins <= 48, 64 embedding features, 256
+ * hidden features (alignn_angle_embed_supported).  BatchNorm in training mode: batch statistics, running statistics
+ * updated (momentum), statistics kept in stat1 / stat2 for the backward; l1 / l2: the two layers' parameters, running
+ * statistics and gradient destinations (img / img_t / w_amax unused).  scal: 128 floats the forward zeroes and both
+ * directions use (operand scales, bounds).  Backward writes l?.gW, l?.gb, l?.red (= dbeta | dgamma); h gets no gradient. */
+typedef struct alignn_angle_args {
+    const float* h;                /* [rows] cosines */
+    int64_t rows;
+    const float* centers;          /* [bins] */
+    float gamma;
+    int32_t bins;
+    alignn_mlp_params l1, l2;
+    float eps, momentum;
+    float *stat1, *stat2;          /* [4, 64], [4, 256]: mean | rstd | gamma rstd | beta */
+    float* scal;                   /* [128] */
+    float *z, *z_amax;             /* forward: [rows, 256] and (optional) the tracked max|z| */
+    const float* gz;               /* backward: [rows, 256] */
+    void* workspace;
+    size_t workspace_bytes;
+} alignn_angle_args;
+int alignn_angle_embed_supported(int bins, int embed, int hidden);
+size_t alignn_angle_embed_workspace(int64_t rows, int bins, int backward);
+size_t alignn_angle_args_sizeof(void);
+int alignn_angle_embed_fwd(const alignn_angle_args* args, alignn_stream_t stream);
+int alignn_angle_embed_bwd(const alignn_angle_args* args, alignn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Batch staging in one call (csrc/stage.hip): canonical CSR of g (slots = bonds stably sorted by
  * destination atom), its by-source view, the canonical line graph L(g) with its by-source view and segment ranks, the
  * bond vectors in slot order and the bond-angle cosines - from the COO bond list (u -> v, caller's order, int32) a loader

@@ -1,0 +1,90 @@
+"""csrc/angle.hip: the bond-angle embedding (RBF -> MLPLayer -> MLPLayer, alignn/models/alignn.py:215-222) computed without
+its [T, bins] / [T, 64] / [T, 256] intermediates, against the same chain of torch modules in float64: the output, the
+running statistics and the gradients of all eight parameter tensors."""
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from alignn_amd.alignn import MLPLayer, RBFExpansion  # noqa: E402
+from alignn_amd.angle import AngleEmbedding  # noqa: E402
+
+DEV = "cuda"
+
+
+def _modules(seed, bins=40):
+    torch.manual_seed(seed)
+    rbf = RBFExpansion(vmin=-1.0, vmax=1.0, bins=bins)
+    l1, l2 = MLPLayer(bins, 64), MLPLayer(64, 256)
+    with torch.no_grad():  # non-trivial affine parameters and running statistics
+        for m in (l1, l2):
+            m.layer[1].weight.uniform_(0.5, 1.5)
+            m.layer[1].bias.uniform_(-0.5, 0.5)
+    return rbf, l1, l2
+
+
+def _reference(rbf, l1, l2, h, gz):
+    """float64 torch: z, parameter gradients, running statistics after one training-mode forward"""
+    import copy
+
+    r64 = torch.exp(-rbf.gamma * (h.double()[:, None] - rbf.centers.double()[None, :]) ** 2)
+    m1, m2 = copy.deepcopy(l1.layer).double(), copy.deepcopy(l2.layer).double()
+    m1.train(), m2.train()
+    z = m2(m1(r64))
+    z.backward(gz.double())
+    grads = [[m[0].weight.grad, m[0].bias.grad, m[1].bias.grad, m[1].weight.grad] for m in (m1, m2)]
+    stats = [[m[1].running_mean, m[1].running_var] for m in (m1, m2)]
+    return z.detach(), grads, stats
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("rows,bins,seed", [(1000, 40, 0), (128 * 37 + 5, 40, 1), (31, 40, 2), (200_003, 40, 3), (4097, 24, 4),
+                                            (676_200, 40, 5)])
+def test_forward_and_parameter_gradients_against_float64(rows, bins, seed):
+    rbf, l1, l2 = _modules(seed, bins)
+    g = torch.Generator().manual_seed(seed)
+    h = torch.rand(rows, generator=g) * 2 - 1  # cosines
+    gz = torch.randn(rows, 256, generator=g) * (torch.rand(256, generator=g) + 0.1) + 0.05
+    z_ref, grads_ref, stats_ref = _reference(rbf, l1, l2, h, gz)
+    rbf, l1, l2 = rbf.to(DEV), l1.to(DEV).train(), l2.to(DEV).train()
+    emb = AngleEmbedding(rbf.centers, rbf.gamma, (l1, l2))
+    z, amax = emb.forward(h.to(DEV))
+    (gW1, gb1, red1), (gW2, gb2, red2) = emb.backward(gz.to(DEV))
+    torch.cuda.synchronize()
+    z, z_ref = z.cpu(), z_ref
+    # activations: 1e-4 rel is the north-star bar; float32 arithmetic on float64's problem lands two orders below it
+    assert _rel(z, z_ref) < 2e-6, _rel(z, z_ref)
+    assert abs(float(amax) - float(z.abs().max())) == 0.0
+    for m, (rm, rv) in zip((l1, l2), stats_ref):
+        assert _rel(m.layer[1].running_mean.cpu(), rm) < 1e-5
+        assert _rel(m.layer[1].running_var.cpu(), rv) < 1e-5
+    got = [[gW1, gb1, red1[:64], red1[64:]], [gW2, gb2, red2[:256], red2[256:]]]
+    names = ["weight", "bias (analytically 0)", "norm.bias", "norm.weight"]
+    for layer, (gl, rl) in enumerate(zip(got, grads_ref)):
+        for name, a, b in zip(names, gl, rl):
+            a = a.cpu().reshape(b.shape)
+            if name.startswith("bias"):  # Linear bias in front of BatchNorm: exact gradient 0, both sides hold rounding noise
+                scale = float(rl[0].abs().max())
+                assert float(a.abs().max()) < 1e-4 * max(scale, 1.0), (layer, name, float(a.abs().max()))
+                continue
+            assert _rel(a, b) < 2e-5, (layer, name, _rel(a, b))
+
+
+def test_two_runs_are_bit_identical():
+    rbf, l1, l2 = _modules(7)
+    g = torch.Generator().manual_seed(7)
+    h = (torch.rand(50_000, generator=g) * 2 - 1).to(DEV)
+    gz = torch.randn(50_000, 256, generator=g).to(DEV)
+    rbf, l1, l2 = rbf.to(DEV), l1.to(DEV).train(), l2.to(DEV).train()
+    outs = []
+    for _ in range(2):
+        emb = AngleEmbedding(rbf.centers, rbf.gamma, (l1, l2))
+        z, _ = emb.forward(h)
+        grads = emb.backward(gz)
+        torch.cuda.synchronize()
+        outs.append([z.clone()] + [t.clone() for g3 in grads for t in g3])
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
