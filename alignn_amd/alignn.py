@@ -427,7 +427,15 @@ class ALIGNN(nn.Module):
         if len(self.alignn_layers) > 0:
             if b.lg is None or b.h is None:
                 raise ValueError("alignn_layers > 0 needs the line graph with edata['h']")
-            z = self.angle_embedding(b.h)
+            rbf, l1, l2 = self.angle_embedding[0], self.angle_embedding[1], self.angle_embedding[2]
+            if (len(self.angle_embedding) == 3 and type(l1) is MLPLayer and type(l2) is MLPLayer
+                    and not (self.angle_embedding._forward_hooks or self.angle_embedding._forward_pre_hooks)
+                    and ops.angle_fused_applies(b.h, rbf, l1, l2, self.training)):
+                _bump(l1.layer[1], True)
+                _bump(l2.layer[1], True)
+                z = ops.angle_embed(b.h, rbf, l1, l2)  # csrc/angle.hip: no [T, bins] / [T, 64] / [T, 256] intermediates
+            else:
+                z = self.angle_embedding(b.h)
         x = self.atom_embedding(b.atom_features)
         y = self.edge_embedding(ops.bond_length(b.r))
         # the triplet features of the last ALIGNN layer and the bond features of the last GCN layer are

@@ -92,6 +92,8 @@ struct ConvTape {
 };
 struct Tape {
     float *bl = nullptr, *rbf_e = nullptr, *rbf_a = nullptr, *pool = nullptr;
+    bool angle_fused = false, angle_lane = false;  // the angle embedding went through csrc/angle.hip: only these survive
+    float *a_stat1 = nullptr, *a_stat2 = nullptr, *a_scal = nullptr;
     MlpTape atom, e1, e2, a1, a2;
     std::vector<ConvTape> convs;
 };
@@ -346,6 +348,25 @@ void conv_fwd(Ctx& c, ConvTape& t, const alignn_conv_params& p, const alignn_gra
 
 int conv_count(const alignn_model_desc& d) { return 2 * d.alignn_layers + d.gcn_layers; }
 
+// the arguments both directions of the fused angle embedding share; the three small buffers live on the forward tape
+alignn_angle_args angle_args(Ctx& c, const Tape& tp) {
+    const alignn_model_desc& d = *c.d;
+    alignn_angle_args a{};
+    a.h = c.b->h;
+    a.rows = c.b->lg.m;
+    a.centers = d.angle_centers;
+    a.gamma = d.angle_gamma;
+    a.bins = d.angle_bins;
+    a.l1 = d.angle1;
+    a.l2 = d.angle2;
+    a.eps = d.eps;
+    a.momentum = d.momentum;
+    a.stat1 = tp.a_stat1;
+    a.stat2 = tp.a_stat2;
+    a.scal = tp.a_scal;
+    return a;
+}
+
 // the whole forward; with c.launch == false only the workspace plan (the tape's pointers) is produced
 void run_forward(Ctx& c, Tape& tp, float* out) {
     const alignn_model_desc& d = *c.d;
@@ -362,11 +383,30 @@ void run_forward(Ctx& c, Tape& tp, float* out) {
     }
     c.sync(c.T, c.main);  // parameters, weight images, the zeroed arena
     // ---- angle embedding (T rows: lane T), alignn.py:215-222
-    tp.rbf_a = c.alloc((size_t)Tn * d.angle_bins);
-    L(alignn_rbf_fwd(b.h, d.angle_centers, d.angle_gamma, tp.rbf_a, Tn, d.angle_bins, c.main));
-    Act za;
-    za.p = tp.rbf_a;
-    Act z = mlp_fwd(c, tp.a2, d.angle2, mlp_fwd(c, tp.a1, d.angle1, za, Tn), Tn);
+    Act z;
+    tp.angle_fused = d.angle_fused != 0 && Tn > 0 && alignn_angle_embed_supported(d.angle_bins, d.angle1.out, d.angle2.out) != 0;
+    if (tp.angle_fused) {  // recomputing passes: nothing T x bins / T x 64 / T x 256 but z itself is written (csrc/angle.hip)
+        tp.angle_lane = c.T != c.main && Tn >= d.lane_min_rows;
+        hipStream_t st = tp.angle_lane ? c.T : c.main;
+        tp.a_stat1 = c.alloc((size_t)4 * d.angle1.out);
+        tp.a_stat2 = c.alloc((size_t)4 * d.angle2.out);
+        tp.a_scal = c.alloc(128);
+        alignn_angle_args a = angle_args(c, tp);
+        z.p = c.alloc((size_t)Tn * H);
+        z.amax = c.track(Tn) ? c.new_amax() : nullptr;
+        z.on_T = tp.angle_lane;
+        a.z = z.p;
+        a.z_amax = z.amax;
+        a.workspace_bytes = alignn_angle_embed_workspace(Tn, d.angle_bins, 0);
+        a.workspace = c.alloc(a.workspace_bytes / sizeof(float));
+        L(alignn_angle_embed_fwd(&a, st));
+    } else {
+        tp.rbf_a = c.alloc((size_t)Tn * d.angle_bins);
+        L(alignn_rbf_fwd(b.h, d.angle_centers, d.angle_gamma, tp.rbf_a, Tn, d.angle_bins, c.main));
+        Act za;
+        za.p = tp.rbf_a;
+        z = mlp_fwd(c, tp.a2, d.angle2, mlp_fwd(c, tp.a1, d.angle1, za, Tn), Tn);
+    }
     // ---- atom embedding, alignn.py:197-199
     Act xa;
     xa.p = const_cast<float*>(b.atom_features);
@@ -649,8 +689,18 @@ void run_backward(Ctx& c, const Tape& tp, const float* g_out) {
         gz = nz;
         have_gz = true;
         if (i == 0) {  // the angle embedding's backward (lane T) can start now, under the last bond-graph backward
-            Grad ga = mlp_bwd(c, tp.a2, gz, true);
-            mlp_bwd(c, tp.a1, ga, false);
+            if (tp.angle_fused) {
+                hipStream_t st = tp.angle_lane ? c.T : c.main;
+                if (tp.angle_lane != gz.on_T) c.sync(st, gz.on_T ? c.T : c.main);
+                alignn_angle_args a = angle_args(c, tp);
+                a.gz = gz.p;
+                a.workspace_bytes = alignn_angle_embed_workspace(a.rows, d.angle_bins, 1);
+                a.workspace = c.alloc(a.workspace_bytes / sizeof(float));
+                L(alignn_angle_embed_bwd(&a, st));
+            } else {
+                Grad ga = mlp_bwd(c, tp.a2, gz, true);
+                mlp_bwd(c, tp.a1, ga, false);
+            }
         }
         Grad nx, ny;
         conv_bwd(c, tp.convs[k], gx, &gm, nx, ny);

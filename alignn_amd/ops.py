@@ -1242,6 +1242,137 @@ class MLPLayerFn(torch.autograd.Function):
 
 
 # ---------------------------------------------------------------------------------------------
+# The bond-angle embedding as one node: RBFExpansion -> MLPLayer -> MLPLayer (alignn/models/alignn.py:215-222) on T rows
+# ---------------------------------------------------------------------------------------------
+ANGLE_FUSED = True  # csrc/angle.hip where its shapes allow (training mode, BatchNorm flavour); tests flip it to compare
+
+
+def angle_fused_applies(h, rbf, l1, l2, training) -> bool:
+    """Shapes / modes csrc/angle.hip carries: float32 cosines without gradient on a HIP device, training-mode BatchNorm
+    layers with running statistics, bins < 48 -> 64 -> 256 features, no hooks on the three modules."""
+    if not (ANGLE_FUSED and training and h.is_cuda and h.dtype == torch.float32 and not h.requires_grad and h.dim() == 1
+            and h.numel() > 0):
+        return False
+    lin1, bn1, lin2, bn2 = l1.layer[0], l1.layer[1], l2.layer[0], l2.layer[1]
+    if not (isinstance(bn1, torch.nn.BatchNorm1d) and isinstance(bn2, torch.nn.BatchNorm1d)):
+        return False
+    for bn in (bn1, bn2):
+        if bn.running_mean is None or bn.momentum is None or bn.weight is None or abs(bn.momentum - BN_MOMENTUM) > 0 or bn.eps != BN_EPS:
+            return False
+    for m in (rbf, l1, l2, lin1, bn1, lin2, bn2, l1.layer, l2.layer):
+        if m._forward_hooks or m._forward_pre_hooks or m._backward_hooks:
+            return False
+    if lin1.weight.dtype != torch.float32 or lin1.bias is None or lin2.bias is None:
+        return False
+    return bool(_lib.load().alignn_angle_embed_supported(lin1.weight.shape[1], lin1.weight.shape[0], lin2.weight.shape[0])) and (
+        lin1.weight.shape[1] == rbf.centers.numel() and lin2.weight.shape[1] == lin1.weight.shape[0])
+
+
+def _angle_args(h, centers, gamma, p1, p2, bufs, stat1, stat2, scal):
+    from .angle import AngleArgs
+    from .cmodel import MlpParams
+
+    a = AngleArgs()
+    a.h, a.rows = ptr(h), h.numel()
+    a.centers, a.gamma, a.bins = ptr(centers), float(gamma), centers.numel()
+    for dst, (w, b, g, be), (rm, rv) in ((a.l1, p1, bufs[0]), (a.l2, p2, bufs[1])):
+        dst.W, dst.b, dst.gamma, dst.beta, dst.rm, dst.rv = ptr(w), ptr(b), ptr(g), ptr(be), ptr(rm), ptr(rv)
+        dst.in_, dst.out = w.shape[1], w.shape[0]
+    a.eps, a.momentum = BN_EPS, BN_MOMENTUM
+    a.stat1, a.stat2, a.scal = ptr(stat1), ptr(stat2), ptr(scal)
+    return a
+
+
+class AngleEmbedFn(torch.autograd.Function):
+    """z [T, 256] from the cosines h [T] and the eight parameter tensors of the two layers; backward = their gradients (h
+    gets none).  Forward and backward each are ONE C call (``alignn_angle_embed_fwd / _bwd``); inside ``lanes()`` both run on
+    lane T like the T-row layers they replace."""
+
+    @staticmethod
+    def forward(ctx, h, centers, gamma, w1, b1, g1, be1, w2, b2, g2, be2, rm1, rv1, rm2, rv2):
+        import ctypes as C
+
+        lib = _lib.load()
+        h = h.contiguous()
+        T = h.numel()
+        lane = _lane_for(T)
+        ctx.lane = lane is not None
+
+        def run():
+            z = _empty(T, w2.shape[0], like=h)
+            amax = new_amax(z) if _track(T) else None
+            stat1, stat2, scal = _empty(4 * w1.shape[0], like=h), _empty(4 * w2.shape[0], like=h), _empty(128, like=h)
+            a = _angle_args(h, centers, gamma, (w1, b1, g1, be1), (w2, b2, g2, be2), ((rm1, rv1), (rm2, rv2)), stat1, stat2, scal)
+            nbytes = lib.alignn_angle_embed_workspace(T, centers.numel(), 0)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=h.device)
+            a.z, a.z_amax, a.workspace, a.workspace_bytes = ptr(z), ptr(amax), ptr(ws), nbytes
+            check(lib.alignn_angle_embed_fwd(C.byref(a), stream()), "angle_embed_fwd")
+            return z, amax, stat1, stat2, scal
+
+        if lane is not None:
+            with _on_T(*lane, reads=(h,)):
+                z, amax, stat1, stat2, scal = run()
+            _mark_on_T(z)
+        else:
+            z, amax, stat1, stat2, scal = run()
+        if amax is not None:
+            set_amax(z, amax)
+        ctx.save_for_backward(h, centers, w1, b1, g1, be1, w2, b2, g2, be2, rm1, rv1, rm2, rv2, stat1, stat2, scal)
+        ctx.gamma = gamma
+        ctx.param_grads = _PARAM_GRADS["on"]
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        import ctypes as C
+
+        lib = _lib.load()
+        h, centers, w1, b1, g1, be1, w2, b2, g2, be2, rm1, rv1, rm2, rv2, stat1, stat2, scal = ctx.saved_tensors
+        none = (None,) * 15
+        if not ctx.param_grads:
+            return none
+        gz = gz.contiguous()
+        T = h.numel()
+
+        def run():
+            out = [(_empty(*w.shape, like=w), _empty(w.shape[0], like=w), _empty(2, w.shape[0], like=w)) for w in (w1, w2)]
+            a = _angle_args(h, centers, ctx.gamma, (w1, b1, g1, be1), (w2, b2, g2, be2), ((rm1, rv1), (rm2, rv2)), stat1, stat2, scal)
+            for dst, (gw, gb, red) in ((a.l1, out[0]), (a.l2, out[1])):
+                dst.gW, dst.gb, dst.red = ptr(gw), ptr(gb), ptr(red)
+            nbytes = lib.alignn_angle_embed_workspace(T, centers.numel(), 1)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=h.device)
+            a.gz, a.workspace, a.workspace_bytes = ptr(gz), ptr(ws), nbytes
+            check(lib.alignn_angle_embed_bwd(C.byref(a), stream()), "angle_embed_bwd")
+            return out
+
+        params = (w1, b1, g1, be1, w2, b2, g2, be2)
+        if ctx.lane:
+            main, T_ = _lane_streams(gz.device)
+            with _on_T(main, T_, reads=(gz,)):
+                out = run()
+            ev = _event_after(T_)
+            if _deferred_join_is_safe(params):  # the gradients stay on lane T until the end of backward()
+                _arm_backward_join()
+            else:
+                main.wait_event(ev)
+                for grp in out:
+                    for t in grp:
+                        t.record_stream(main)
+        else:
+            _main_reads(gz)
+            out = run()
+        (gw1, gb1, red1), (gw2, gb2, red2) = out
+        return (None, None, None, gw1, gb1, red1[1], red1[0], gw2, gb2, red2[1], red2[0], None, None, None, None)
+
+
+def angle_embed(h, rbf, l1, l2):
+    """``l2(l1(rbf(h)))`` through ``AngleEmbedFn`` (the caller checked ``angle_fused_applies``)."""
+    lin1, bn1, lin2, bn2 = l1.layer[0], l1.layer[1], l2.layer[0], l2.layer[1]
+    return AngleEmbedFn.apply(h, rbf.centers, rbf.gamma, lin1.weight, lin1.bias, bn1.weight, bn1.bias, lin2.weight, lin2.bias,
+                              bn2.weight, bn2.bias, bn1.running_mean, bn1.running_var, bn2.running_mean, bn2.running_var)
+
+
+# ---------------------------------------------------------------------------------------------
 # EdgeGatedGraphConv   (alignn/models/alignn.py:78-129)
 # ---------------------------------------------------------------------------------------------
 # Composite entry points (csrc/composite.hip): the launches of a convolution's forward / backward issued by ONE C call each

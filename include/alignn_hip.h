@@ -622,6 +622,7 @@ typedef struct alignn_model_desc {
     const void* bump_ptrs;                     /* device array of n_bump int64_t* (num_batches_tracked), each += 1 per forward */
     int32_t n_weights, n_bump;
     int32_t x6_min_tiles, bd_segment_table;    /* kernel-choice constants of the per-operator path (256, 1) */
+    int32_t angle_fused, pad_;                 /* 1: the angle embedding through alignn_angle_embed_fwd / _bwd where its shapes allow */
     int64_t amax_min_rows, lane_min_rows, side_min_rows; /* 4096; rows from which a kernel goes to lane_T / side */
     alignn_stream_t lane_T, side, aux;
 } alignn_model_desc;

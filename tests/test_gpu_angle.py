@@ -88,3 +88,45 @@ def test_two_runs_are_bit_identical():
         torch.cuda.synchronize()
         outs.append([z.clone()] + [t.clone() for g3 in grads for t in g3])
     assert all(torch.equal(a, b) for a, b in zip(*outs))
+
+
+def test_a_training_step_with_the_fused_embedding_matches_the_chain_of_layers():
+    """ALIGNN.forward takes csrc/angle.hip for its angle embedding (ops.ANGLE_FUSED): one optimizer-free training step on
+    both code paths (per-operator and whole-model C path) against the same step with the embedding as a chain of layers -
+    predictions, every gradient and the running statistics agree to float32 rounding; the two code paths agree bit for bit."""
+    from alignn_amd import ALIGNN, ALIGNNConfig, GraphBatch, cmodel, ops
+    from alignn_amd.synthetic import make_batch
+
+    raw = make_batch(16, 60, seed0=17)
+    batch = GraphBatch.from_raw(raw, device=DEV)
+    target = torch.randn(16, generator=torch.Generator().manual_seed(1)).to(DEV)
+
+    def step(fused, use_c):
+        ops.ANGLE_FUSED = fused
+        prev = cmodel.ENABLED
+        cmodel.ENABLED = use_c
+        try:
+            torch.manual_seed(0)
+            m = ALIGNN(ALIGNNConfig(name="alignn")).to(DEV).train()
+            pred = m(batch)
+            torch.nn.functional.l1_loss(pred, target).backward()
+            torch.cuda.synchronize()
+            out = {"pred": pred.detach().clone()}
+            out.update({"g." + k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+            out.update({"s." + k: v.clone() for k, v in m.state_dict().items()})
+            return out
+        finally:
+            ops.ANGLE_FUSED, cmodel.ENABLED = True, prev
+
+    fused_c, fused_ops, chain = step(True, True), step(True, False), step(False, True)
+    assert fused_c.keys() == fused_ops.keys() == chain.keys()
+    for k in fused_c:
+        assert torch.equal(fused_c[k], fused_ops[k]), k
+    gmax = max(float(v.abs().max()) for k, v in chain.items() if k.startswith("g."))
+    for k, b in chain.items():
+        a = fused_c[k]
+        if b.dtype.is_floating_point:
+            tol = 2e-5 * (gmax if k.startswith("g.") else max(float(b.abs().max()), 1e-6))
+            assert float((a - b).abs().max()) <= tol, (k, float((a - b).abs().max()), tol)
+        else:
+            assert torch.equal(a, b), k

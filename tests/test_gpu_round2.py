@@ -434,8 +434,9 @@ def test_forces_against_finite_differences_of_the_float64_oracle(nodes):
 def test_batchnorm_backward_reductions_from_the_projection_epilogue():
     """alignn_gemm_nt_f16x3_bnred: the column sums BatchNorm's backward starts with, taken in the epilogue of the
     projection that produces the gradient.  Default config on 16 x 60-atom crystals (T ~ 169 k): the fused route is
-    taken for the three line-graph convolutions that feed another one and for the angle embedding, and the training
-    step agrees with the separate reduction kernel to rounding (the summation order differs)."""
+    taken for the three line-graph convolutions that feed another one - and for the angle embedding when that runs as a
+    chain of layers (ops.ANGLE_FUSED off; csrc/angle.hip keeps no pre-activation a projection could reduce against) -, and
+    the training step agrees with the separate reduction kernel to rounding (the summation order differs)."""
     raw = make_batch(16, 60, seed0=91)
     batch = GraphBatch.from_raw(raw, device=DEV)
     target = torch.randn(16, generator=torch.Generator().manual_seed(3)).to(DEV)
@@ -454,7 +455,18 @@ def test_batchnorm_backward_reductions_from_the_projection_epilogue():
         finally:
             ops.BNRED_FUSED = True
         res[fused] = ({k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}, dict(ops.BNRED_STATS))
-    assert res[True][1] == {"fused": 4, "used": 4} and res[False][1] == {"fused": 0, "used": 0}
+    assert res[True][1] == {"fused": 3, "used": 3} and res[False][1] == {"fused": 0, "used": 0}
+    ops.ANGLE_FUSED = False
+    try:
+        ops.BNRED_STATS.update(fused=0, used=0)
+        torch.manual_seed(0)
+        model = ALIGNN(ALIGNNConfig(name="alignn")).to(DEV).train()
+        with cmodel.disabled():
+            torch.nn.functional.l1_loss(model(batch), target).backward()
+        torch.cuda.synchronize()
+        assert dict(ops.BNRED_STATS) == {"fused": 4, "used": 4}
+    finally:
+        ops.ANGLE_FUSED = True
     ga, gb = res[True][0], res[False][0]
     gmax = max(float(v.abs().max()) for v in gb.values())
     for k in gb:

@@ -188,10 +188,12 @@ def test_registry_hits_of_a_default_config_step_plain_and_under_ddp():
     # (amax_miss counts tall tensors that arrive without a tracked max|.| - the raw inputs and the RBF expansions, whose
     # projections are not split-product shapes; a miss that COSTS something shows up as bf16x6_fallback above)
     # measured on MI355X at this batch (16 x 60 atoms: only the T-row products are split-product shapes):
-    # amax_hit 18, wimg_hit 4 (the W^T images of the four line-graph edge gates), fused = used = 4
-    assert plain["amax_hit"] >= 16, plain
+    # amax_hit 18, wimg_hit 4 (the W^T images of the four line-graph edge gates), fused = used = 4 with the angle embedding
+    # as a chain of layers; with csrc/angle.hip (the default) the embedding's own projections and its BatchNorm-backward
+    # sums leave the registries: 3 fused reductions (the line-graph convolutions that feed another one)
+    assert plain["amax_hit"] >= 13, plain
     assert plain["wimg_hit"] >= 4
-    assert bn_plain["fused"] == bn_plain["used"] == plain["pre_red_hit"] and bn_plain["fused"] >= 4
+    assert bn_plain["fused"] == bn_plain["used"] == plain["pre_red_hit"] and bn_plain["fused"] >= 3
     ddp, bn_ddp = _default_step_stats(True)
     print("registry stats, DDP-wrapped:", ddp, bn_ddp)
     assert ddp == plain and bn_ddp == bn_plain  # the reducer's hooks and bucket views cost no registry hit
