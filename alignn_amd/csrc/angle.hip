@@ -26,6 +26,8 @@
 // operand layout of the next product - and files their fp16 slices in LDS.  Phase B: wave w owns features [64w, 64w + 64)
 // (its slices of W2 live in registers for the whole kernel) and walks the four row blocks.
 #include "../../include/alignn_hip.h"
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -41,7 +43,7 @@ constexpr int kTile = 128;
 constexpr int kGrid = 512;     // two workgroups per compute unit
 // scal[] (device scalars that live from the forward to the backward of one step)
 constexpr int kAmaxW1 = 0, kAmaxW2 = 1, kBoundA1 = 2, kBoundDx2 = 3, kBoundDx1 = 4, kAmaxGz2 = 5, kAmaxXh2 = 6, kAmaxGz1 = 7,
-              kAmaxXh1 = 8, kShift = 16,  // kShift .. kShift + 63: layer-1 shift of the statistics pass
+              kAmaxXh1 = 8, kDall = 9, kShift = 16,  // kShift .. kShift + 63: layer-1 shift of the statistics pass
               kScalFloats = 128;
 constexpr float kRbfScale = 16384.0f;     // rbf values lie in (0, 1]
 
@@ -71,19 +73,31 @@ __device__ __forceinline__ f32x16 mfma3(const f16x8& ah, const f16x8& al, const 
 }
 
 // 8 floats already scaled -> hi = RN_f16(x), lo = RN_f16(x - hi): v_cvt_pk_f16_f32 for the high slice, one v_fma_mix per
-// element for the low one (csrc/gemm_x6.hip slice8_f16_lo: same bits as the two-conversion form hipcc emits, half the work)
+// element for the low one (csrc/gemm_x6.hip slice8_f16_lo: same bits as the two-conversion form hipcc emits, half the work).
+// The compiler does not look into inline assembly when it places the wait states gfx950 wants between dependent
+// instructions of different pipes (a transcendental's result into a VALU read; a VALU result into an MFMA operand): the
+// block carries its own - s_nop in front for whatever produced its inputs, s_nop behind for whatever consumes its outputs.
+// (Without them: results that change from run to run, 1e-3 off.)
 __device__ __forceinline__ void split8s(const float (&xs)[8], f16x8& h, f16x8& l) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) h[j] = (_Float16)xs[j];
     const uint4 hp = __builtin_bit_cast(uint4, h);
-    const unsigned hw[4] = {hp.x, hp.y, hp.z, hp.w};
-    unsigned lw[4];
-#pragma unroll
-    for (int p2 = 0; p2 < 4; ++p2) {
-        asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(lw[p2]) : "v"(xs[2 * p2]), "v"(hw[p2]));
-        asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lw[p2]) : "v"(xs[2 * p2 + 1]), "v"(hw[p2]));
-    }
-    l = __builtin_bit_cast(f16x8, make_uint4(lw[0], lw[1], lw[2], lw[3]));
+    unsigned l0, l1, l2, l3;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_fma_mixlo_f16 %0, %4, 1.0, -%12 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %1, %6, 1.0, -%13 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %2, %8, 1.0, -%14 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %3, %10, 1.0, -%15 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %0, %5, 1.0, -%12 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %7, 1.0, -%13 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %2, %9, 1.0, -%14 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %3, %11, 1.0, -%15 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "s_nop 3"
+        : "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3)
+        : "v"(xs[0]), "v"(xs[1]), "v"(xs[2]), "v"(xs[3]), "v"(xs[4]), "v"(xs[5]), "v"(xs[6]), "v"(xs[7]), "v"(hp.x), "v"(hp.y),
+          "v"(hp.z), "v"(hp.w));
+    l = __builtin_bit_cast(f16x8, make_uint4(l0, l1, l2, l3));
 }
 constexpr float kLog2e = 1.4426950408889634f;
 // x * sigmoid(x * k) with k folded by the caller: silu of a value that carries a scale (k = 1 / scale); k = 1: silu_f
@@ -122,6 +136,7 @@ constexpr int kL1Consts = 7;
 struct L1Shared {
     uint4 w[2][3][2][64];       // [cb][s][hi | lo][lane]
     float c[kL1Consts][kE];     // per pass, see l1_setup
+    float cen[kBinsMax];        // the centres, padded far away so that the padded bins expand to 0
 };
 enum L1Mode { kL1Stats, kL1Act, kL1Bwd };
 
@@ -145,6 +160,10 @@ __device__ __forceinline__ void l1_setup(const P& p, L1Shared& sh, L1Mode mode, 
         split8s(v, hi, lo);
         sh.w[cb][s][0][lane] = __builtin_bit_cast(uint4, hi);
         sh.w[cb][s][1][lane] = __builtin_bit_cast(uint4, lo);
+    }
+    if (threadIdx.x >= kThreads - kBinsMax) {
+        const int k = threadIdx.x - (kThreads - kBinsMax);
+        sh.cen[k] = k < p.bins ? p.centers[k] : 1.0e18f;
     }
     if (threadIdx.x < kE) {
         const int f = threadIdx.x;
@@ -172,39 +191,26 @@ __device__ __forceinline__ void l1_setup(const P& p, L1Shared& sh, L1Mode mode, 
     __syncthreads();
 }
 
-// the centres this lane's slots need (k = 16 s + 8 hh + i), padded far away so that the padded bins expand to 0
-struct Rbf {
-    float cen[3][8];
-    float g2;  // -gamma log2(e)
-    __device__ __forceinline__ void load(const P& p, int hh) {
-        g2 = -p.gamma * kLog2e;
+// 2^14 exp(-gamma (h - c)^2) of this lane's row as fragments (lane = row, k = bin 16 s + 8 hh + i); ONES: slot `ones` holds
+// 2^14 instead (a column of ones: the product with it sums the other operand's columns)
+template <bool ONES>
+__device__ __forceinline__ void l1_rbf(const L1Shared& sh, float g2, float hv, int hh, int ones, f16x8 (&r_hi)[3], f16x8 (&r_lo)[3]) {
 #pragma unroll
-        for (int s = 0; s < 3; ++s)
+    for (int s = 0; s < 3; ++s) {
+        const float4 c0 = f4_ld(&sh.cen[16 * s + 8 * hh]), c1 = f4_ld(&sh.cen[16 * s + 8 * hh + 4]);
+        const float cen[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        float v[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int k = 16 * s + 8 * hh + i;
-                cen[s][i] = k < p.bins ? p.centers[k] : 1.0e18f;
-            }
-    }
-    // 2^14 exp(-gamma (h - c)^2) as fragments (lane = row, k = bin 16 s + 8 hh + i); ONES: slot `ones` holds 2^14 (a column of
-    // ones: the product with it sums the other operand's columns)
-    template <bool ONES>
-    __device__ __forceinline__ void expand(float hv, int hh, int ones, f16x8 (&r_hi)[3], f16x8 (&r_lo)[3]) const {
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            float v[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float t = hv - cen[s][i];
-                // (the multiply is also what keeps a transcendental's result from feeding split8s' inline assembly directly:
-                // gfx950 wants a wait state there and the compiler cannot see into the asm to insert it)
-                v[i] = __builtin_amdgcn_exp2f(g2 * t * t) * kRbfScale;
-                if (ONES && 16 * s + 8 * hh + i == ones) v[i] = kRbfScale;
-            }
-            split8s(v, r_hi[s], r_lo[s]);
+        for (int i = 0; i < 8; ++i) {
+            const float t = hv - cen[i];
+            // (the multiply is also what keeps a transcendental's result from feeding split8s' inline assembly directly:
+            // gfx950 wants a wait state there and the compiler cannot see into the asm to insert it)
+            v[i] = __builtin_amdgcn_exp2f(g2 * t * t) * kRbfScale;
+            if (ONES && 16 * s + 8 * hh + i == ones) v[i] = kRbfScale;
         }
+        split8s(v, r_hi[s], r_lo[s]);
     }
-};
+}
 __device__ __forceinline__ void l1_product(const L1Shared& sh, int lane, const f16x8 (&r_hi)[3], const f16x8 (&r_lo)[3],
                                            f32x16 (&acc)[2]) {
 #pragma unroll
@@ -223,6 +229,9 @@ __device__ __forceinline__ void l1_const4(const L1Shared& sh, int k, int cb, int
     const float4 v = f4_ld(&sh.c[k][32 * cb + 8 * q + 4 * hh]);
     o[0] = v.x, o[1] = v.y, o[2] = v.z, o[3] = v.w;
 }
+
+// the cosine of row `row` (rows past the end read the last one; what they produce is masked)
+__device__ __forceinline__ float load_h(const P& p, int64_t row) { return p.h[row < p.rows ? row : p.rows - 1]; }
 
 // cross-lane sum / max over the 32 rows of a half (lanes il = 0..31 keep hh)
 __device__ __forceinline__ float half_sum(float v) {
@@ -243,22 +252,25 @@ __device__ __forceinline__ void atomic_max_pos(float* p, float v) {
 // prep: max|W1|, max|W2| and the shift of the layer-1 statistics (x1 of row 0 - any value near the column means will do)
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void angle_prep_kernel(P p) {
+    // blocks 0 .. gridDim.x - 2: a slice of W2 each; the last block: W1 and the shift.  scal[] was zeroed before.
     __shared__ float sh[kThreads];
-    const int t = threadIdx.x;
-    float m1 = 0.0f, m2 = 0.0f;
-    for (int i = t; i < kE * p.bins; i += kThreads) m1 = fmaxf(m1, fabsf(p.W1[i]));
-    for (int i = t; i < kH * kE; i += kThreads) m2 = fmaxf(m2, fabsf(p.W2[i]));
-    for (int pass = 0; pass < 2; ++pass) {
-        sh[t] = pass == 0 ? m1 : m2;
-        __syncthreads();
-        for (int o = kThreads / 2; o > 0; o >>= 1) {
-            if (t < o) sh[t] = fmaxf(sh[t], sh[t + o]);
-            __syncthreads();
-        }
-        if (t == 0) p.scal[pass == 0 ? kAmaxW1 : kAmaxW2] = sh[0];
+    const int t = threadIdx.x, nb = gridDim.x - 1;
+    const bool last = (int)blockIdx.x == nb;
+    float m = 0.0f;
+    if (last) {
+        for (int i = t; i < kE * p.bins; i += kThreads) m = fmaxf(m, fabsf(p.W1[i]));
+    } else {
+        const int per = (kH * kE + nb - 1) / nb, beg = blockIdx.x * per, end = beg + per < kH * kE ? beg + per : kH * kE;
+        for (int i = beg + t; i < end; i += kThreads) m = fmaxf(m, fabsf(p.W2[i]));
+    }
+    sh[t] = m;
+    __syncthreads();
+    for (int o = kThreads / 2; o > 0; o >>= 1) {
+        if (t < o) sh[t] = fmaxf(sh[t], sh[t + o]);
         __syncthreads();
     }
-    if (t < kE) {
+    if (t == 0) atomic_max_pos(p.scal + (last ? kAmaxW1 : kAmaxW2), sh[0]);
+    if (last && t < kE) {
         const float hv = p.rows > 0 ? p.h[0] : 0.0f;
         float acc = p.b1[t];
         for (int k = 0; k < p.bins; ++k) {
@@ -270,28 +282,29 @@ __global__ __launch_bounds__(kThreads) void angle_prep_kernel(P p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// pass 1: shifted column sums of x1 = W1 rbf(h) + b1.  One wave per block of 32 rows; partial[wave][3][64] =
-// sum (x - c) | sum (x - c)^2 | max |x - c|.
+// pass 1: shifted column sums of x1 = W1 rbf(h) + b1.  One wave per block of 32 rows; partial[wave][2][64] =
+// sum (x - c) | sum (x - c)^2; scal[kDall] = max |x - c| over everything.
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads, 2) void angle_l1_stats_kernel(P p) {
     __shared__ L1Shared sh;
     l1_setup(p, sh, kL1Stats, 1.0f);
     const int lane = threadIdx.x & 63, il = lane & 31, hh = lane >> 5;
     const int wave = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6), nwaves = gridDim.x * (kThreads / 64);
-    Rbf rbf;
-    rbf.load(p, hh);
-    float s1[2][16], s2[2][16], dm[2][16];
+    const float g2 = -p.gamma * kLog2e;
+    float s1[2][16], s2[2][16], dall = 0.0f;
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s1[cb][r] = s2[cb][r] = dm[cb][r] = 0.0f;
+        for (int r = 0; r < 16; ++r) s1[cb][r] = s2[cb][r] = 0.0f;
     const int64_t nblk = (p.rows + 31) / 32;
+    float hv_next = load_h(p, (int64_t)wave * 32 + il);
     for (int64_t blk = wave; blk < nblk; blk += nwaves) {
         const int64_t row = blk * 32 + il;
         const float ok = row < p.rows ? 1.0f : 0.0f;
-        const float hv = row < p.rows ? p.h[row] : 0.0f;
+        const float hv = hv_next;
+        hv_next = load_h(p, (blk + nwaves) * 32 + il);
         f16x8 r_hi[3], r_lo[3];
-        rbf.expand<false>(hv, hh, 0, r_hi, r_lo);
+        l1_rbf<false>(sh, g2, hv, hh, 0, r_hi, r_lo);
         f32x16 acc[2];
         l1_product(sh, lane, r_hi, r_lo, acc);
 #pragma unroll
@@ -307,27 +320,27 @@ __global__ __launch_bounds__(kThreads, 2) void angle_l1_stats_kernel(P p) {
                     const float d = ok * fmaf(acc[cb][r], u[e], v[e]);
                     s1[cb][r] += d;
                     s2[cb][r] = fmaf(d, d, s2[cb][r]);
-                    dm[cb][r] = fmaxf(dm[cb][r], fabsf(d));
+                    dall = fmaxf(dall, fabsf(d));
                 }
             }
     }
-    float* out = static_cast<float*>(p.partial) + (size_t)wave * 3 * kE;
+    float* out = static_cast<float*>(p.partial) + (size_t)wave * 2 * kE;
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float a = half_sum(s1[cb][r]), b = half_sum(s2[cb][r]), c = half_max(dm[cb][r]);
+            const float a = half_sum(s1[cb][r]), b = half_sum(s2[cb][r]);
             if (il == 0) {
                 const int col = l1_col(cb, r, hh);
                 out[col] = a;
                 out[kE + col] = b;
-                out[2 * kE + col] = c;
             }
         }
+    block_amax_commit(dall, p.scal + kDall);
 }
 
-// statistics of a layer from slabs.  LAYER2 = false: float slabs [slabs][3][F] = shifted sum | shifted sum of squares | max
-// |x - c| with the shift in scal[kShift..] (layer 1: also writes the bound of |a1|); true: double slabs [slabs][2][F] of the RAW
+// statistics of a layer from slabs.  LAYER2 = false: float slabs [slabs][2][F] = shifted sum | shifted sum of squares
+// (shift in scal[kShift..], max |x - c| in scal[kDall]) (layer 1: also writes the bound of |a1|); true: double slabs [slabs][2][F] of the RAW
 // accumulator sums: x2 = acc * unit + bias with unit = 1 / (a1 scale * W2 scale) - the variance does not see the bias.
 // 4 columns x 64 slab lanes per workgroup (csrc/norm.hip bn_finalize_kernel).
 template <bool LAYER2>
@@ -348,10 +361,9 @@ __global__ __launch_bounds__(256) void angle_stat_finalize_kernel(const void* __
             s += pp[f];
             q += pp[F + f];
         } else {
-            const float* pp = static_cast<const float*>(partial) + (size_t)k * 3 * F;
+            const float* pp = static_cast<const float*>(partial) + (size_t)k * 2 * F;
             s += (double)pp[f];
             q += (double)pp[F + f];
-            dmax = fmaxf(dmax, pp[2 * F + f]);
         }
     }
     shs[y][c] = s;
@@ -384,7 +396,7 @@ __global__ __launch_bounds__(256) void angle_stat_finalize_kernel(const void* __
     stat[2 * F + f] = g * rstd;
     stat[3 * F + f] = b;
     if constexpr (!LAYER2) {  // |a1| = |silu(z)| <= |z| <= |gamma rstd| (max|x - c| + |c - mean|) + |beta|
-        const float bound = fabsf(g * rstd) * (dmax + fabsf((float)dm)) + fabsf(b);
+        const float bound = fabsf(g * rstd) * (scal[kDall] + fabsf((float)dm)) + fabsf(b);
         atomic_max_pos(scal + kBoundA1, bound);
     }
 }
@@ -397,18 +409,19 @@ __global__ __launch_bounds__(256) void angle_stat_finalize_kernel(const void* __
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int afrag_idx(int rb, int s2, int hl, int lane) { return ((rb * 4 + s2) * 2 + hl) * 64 + lane; }
 
-template <bool KEEP>
-__device__ __forceinline__ void phase_a(const P& p, const L1Shared& sh, const Rbf& rbf, float neg_k, int64_t row0, int lane, int rb,
-                                        uint4* a_frag, f16x8 (&keep_hi)[4], f16x8 (&keep_lo)[4]) {
-    const int il = lane & 31, hh = lane >> 5;
-    const int64_t row = row0 + il;
-    const float hv = row < p.rows ? p.h[row] : 0.0f;
-    f16x8 r_hi[3], r_lo[3];
-    rbf.expand<false>(hv, hh, 0, r_hi, r_lo);
+template <bool KEEP, typename PerBlock>
+__device__ __forceinline__ void phase_a(const L1Shared& sh, float g2, float neg_k, float hv, int lane, int rb, uint4* a_frag,
+                                        PerBlock per_block) {
+    const int hh = lane >> 5;
     f32x16 acc[2];
-    l1_product(sh, lane, r_hi, r_lo, acc);
+    {
+        f16x8 r_hi[3], r_lo[3];
+        l1_rbf<false>(sh, g2, hv, hh, 0, r_hi, r_lo);
+        l1_product(sh, lane, r_hi, r_lo, acc);
+    }
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
+    for (int cb = 0; cb < 2; ++cb) {
+        f16x8 keep_hi[2], keep_lo[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             float a[8];
@@ -424,9 +437,14 @@ __device__ __forceinline__ void phase_a(const P& p, const L1Shared& sh, const Rb
             split8s(a, hi, lo);
             a_frag[afrag_idx(rb, 2 * cb + s, 0, lane)] = __builtin_bit_cast(uint4, hi);
             a_frag[afrag_idx(rb, 2 * cb + s, 1, lane)] = __builtin_bit_cast(uint4, lo);
-            if constexpr (KEEP) keep_hi[2 * cb + s] = hi, keep_lo[2 * cb + s] = lo;
+            if constexpr (KEEP) keep_hi[s] = hi, keep_lo[s] = lo;
         }
+        if constexpr (KEEP) per_block(cb, keep_hi, keep_lo);  // steps 2 cb, 2 cb + 1 = features 32 cb .. 32 cb + 31
+    }
 }
+struct NoBlock {
+    __device__ __forceinline__ void operator()(int, const f16x8 (&)[2], const f16x8 (&)[2]) const {}
+};
 
 // W2 fragments of a wave's 64 features for the recomputation: lane n = feature f0 + 32 fb + il, slot (hh, i) of step s2 =
 // input feature 16 s2 + 8 (i >> 2) + 4 hh + (i & 3)
@@ -471,8 +489,7 @@ __global__ __launch_bounds__(kThreads, 2) void angle_l2_kernel(P p) {
     l1_setup(p, sh, kL1Act, sa);
     const int lane = threadIdx.x & 63, il = lane & 31, hh = lane >> 5, w = threadIdx.x >> 6;
     const float inv2 = 1.0f / (sa * sw), neg_k = -kLog2e / sa;
-    Rbf rbf;
-    rbf.load(p, hh);
+    const float g2 = -p.gamma * kLog2e;
     W2Frag w2;
     w2.load(p, sw, 64 * w, il, hh);
     float cA[2], cB[2], cC[2], cD[2];
@@ -491,64 +508,83 @@ __global__ __launch_bounds__(kThreads, 2) void angle_l2_kernel(P p) {
         }
     }
     const int64_t ntiles = (p.rows + kTile - 1) / kTile;
-    f16x8 none_hi[4], none_lo[4];
+    // g_z of (row block rb, feature block fb) of a tile: the 16 rows this lane's registers stand for
+    auto load_g = [&](int64_t row0, int rb, int fb, float (&g)[16]) {
+        if constexpr (MODE == 2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int64_t row = row0 + n_row(rb, r, hh);
+                row = row < p.rows ? row : p.rows - 1;
+                g[r] = p.gz[row * kH + 64 * w + 32 * fb + il];
+            }
+        }
+    };
+    auto product = [&](int rb, int fb, f32x16& acc) {
+        acc = zero16();
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            const f16x8 ah = __builtin_bit_cast(f16x8, a_frag[afrag_idx(rb, s2, 0, lane)]);
+            const f16x8 al = __builtin_bit_cast(f16x8, a_frag[afrag_idx(rb, s2, 1, lane)]);
+            acc = mfma3(ah, al, w2.hi[fb][s2], w2.lo[fb][s2], acc);
+        }
+    };
+    // FULL (a compile-time flag, chosen per tile by a uniform branch): every row of the tile exists - no masks.  Otherwise
+    // rows past the end are multiplied out (no per-element branches: they would serialise the transcendentals).
+    auto epilogue = [&](auto full_c, int64_t row0, int rb, int fb, const f32x16& acc, const float (&g)[16]) {
+        constexpr bool FULL = decltype(full_c)::value;
+        const int f = 64 * w + 32 * fb + il;
+        float s = 0.0f, q = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t row = row0 + n_row(rb, r, hh);
+            const float m = FULL || row < p.rows ? 1.0f : 0.0f;
+            if constexpr (MODE == 0) {
+                const float a = FULL ? acc[r] : acc[r] * m;
+                s += a;
+                q = fmaf(a, a, q);
+            } else {
+                const float zl = fmaf(acc[r], cA[fb], cB[fb]);
+                if constexpr (MODE == 1) {
+                    const float zz = silu_scaled(zl, -kLog2e);
+                    if (FULL || row < p.rows) p.z[row * kH + f] = zz;
+                    am0 = fmaxf(am0, FULL ? fabsf(zz) : fabsf(zz) * m);
+                } else {
+                    float gz = g[r] * dsilu_fast(zl), xh = fmaf(acc[r], cC[fb], cD[fb]);
+                    if constexpr (!FULL) gz *= m, xh *= m;
+                    s += gz;
+                    q = fmaf(gz, xh, q);
+                    am0 = fmaxf(am0, fabsf(gz));
+                    am1 = fmaxf(am1, fabsf(xh));
+                }
+            }
+        }
+        if constexpr (MODE != 1) acc_a[fb] += (double)s, acc_b[fb] += (double)q;
+    };
+    auto row_blocks = [&](auto full_c, int64_t row0, float (&g0)[16], float (&g1)[16]) {
+#pragma unroll 1
+        for (int rb = 0; rb < 4; ++rb) {
+            f32x16 acc;
+            load_g(row0, rb, 1, g1);
+            product(rb, 0, acc);
+            epilogue(full_c, row0, rb, 0, acc, g0);
+            if (rb < 3) load_g(row0, rb + 1, 0, g0);
+            product(rb, 1, acc);
+            epilogue(full_c, row0, rb, 1, acc, g1);
+        }
+    };
+    float hv = load_h(p, (int64_t)blockIdx.x * kTile + 32 * w + il);
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t row0 = tile * kTile;
         const bool full = row0 + kTile <= p.rows;  // uniform
-        phase_a<false>(p, sh, rbf, neg_k, row0 + 32 * w, lane, w, a_frag, none_hi, none_lo);
+        float g0[16], g1[16];
+        load_g(row0, 0, 0, g0);
+        phase_a<false>(sh, g2, neg_k, hv, lane, w, a_frag, NoBlock());
+        hv = load_h(p, row0 + (int64_t)gridDim.x * kTile + 32 * w + il);  // the next tile's cosine, a whole tile early
         __syncthreads();
-#pragma unroll 1
-        for (int rb = 0; rb < 4; ++rb) {
-            float g[2][16];
-            if constexpr (MODE == 2) {  // g_z of this block, issued before the products that hide its latency
-#pragma unroll
-                for (int fb = 0; fb < 2; ++fb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        int64_t row = row0 + n_row(rb, r, hh);
-                        row = row < p.rows ? row : p.rows - 1;
-                        g[fb][r] = p.gz[row * kH + 64 * w + 32 * fb + il];
-                    }
-            }
-            f32x16 acc[2] = {zero16(), zero16()};
-#pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) {
-                const f16x8 ah = __builtin_bit_cast(f16x8, a_frag[afrag_idx(rb, s2, 0, lane)]);
-                const f16x8 al = __builtin_bit_cast(f16x8, a_frag[afrag_idx(rb, s2, 1, lane)]);
-#pragma unroll
-                for (int fb = 0; fb < 2; ++fb) acc[fb] = mfma3(ah, al, w2.hi[fb][s2], w2.lo[fb][s2], acc[fb]);
-            }
-#pragma unroll
-            for (int fb = 0; fb < 2; ++fb) {
-                const int f = 64 * w + 32 * fb + il;
-                float s = 0.0f, q = 0.0f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int64_t row = row0 + n_row(rb, r, hh);
-                    const bool ok = full || row < p.rows;
-                    if constexpr (MODE == 0) {
-                        const float a = ok ? acc[fb][r] : 0.0f;
-                        s += a;
-                        q = fmaf(a, a, q);
-                    } else {
-                        const float zl = fmaf(acc[fb][r], cA[fb], cB[fb]);
-                        if constexpr (MODE == 1) {
-                            const float zz = silu_scaled(zl, -kLog2e);
-                            if (ok) p.z[row * kH + f] = zz;
-                            am0 = fmaxf(am0, ok ? fabsf(zz) : 0.0f);
-                        } else {
-                            const float gz = ok ? g[fb][r] * dsilu_fast(zl) : 0.0f;
-                            const float xh = fmaf(acc[fb][r], cC[fb], cD[fb]);
-                            s += gz;
-                            q = fmaf(gz, xh, q);
-                            am0 = fmaxf(am0, fabsf(gz));
-                            am1 = fmaxf(am1, ok ? fabsf(xh) : 0.0f);
-                        }
-                    }
-                }
-                if constexpr (MODE != 1) acc_a[fb] += (double)s, acc_b[fb] += (double)q;
-            }
-        }
+        if (full)
+            row_blocks(std::true_type{}, row0, g0, g1);
+        else
+            row_blocks(std::false_type{}, row0, g0, g1);
         __syncthreads();
     }
     if constexpr (MODE != 1) {
@@ -636,113 +672,124 @@ struct Dx2Const {
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int bfrag_idx(int rb, int jb, int s, int hl, int lane) { return (((rb * 2 + jb) * 2 + s) * 2 + hl) * 64 + lane; }
 
-__global__ __launch_bounds__(kThreads, 2) void angle_dw2_kernel(P p) {
+// This pass keeps 64 x 64 of dW2 per 64 features in accumulators: with four waves of 64 features each that, W2's fragments
+// and one block of g_z leave no registers (hipcc spilled 90-230 of them: 0.3-0.7 ms).  So: EIGHT waves per workgroup, a
+// tile of 256 rows (wave w: phase A of row block w), 32 features per wave (16 + 16 fragment registers of W2, 32 of dW2),
+// one workgroup per compute unit (142 KiB of LDS).
+constexpr int kDwThreads = 512, kDwTile = 256, kDwGrid = 256;
+
+__global__ __launch_bounds__(kDwThreads, 1) void angle_dw2_kernel(P p) {
     __shared__ L1Shared sh;
-    __shared__ uint4 a_frag[4 * 4 * 2 * 64];      // 32 KiB
-    __shared__ uint4 b_frag[4 * 2 * 2 * 2 * 64];  // 32 KiB
+    __shared__ uint4 a_frag[8 * 4 * 2 * 64];      // 64 KiB
+    __shared__ uint4 b_frag[8 * 2 * 2 * 2 * 64];  // 64 KiB
     const float sa = f16_scale(p.scal[kBoundA1]), sw = f16_scale(p.scal[kAmaxW2]), sd = f16_scale(p.scal[kBoundDx2]);
     l1_setup(p, sh, kL1Act, sa);
     const int lane = threadIdx.x & 63, il = lane & 31, hh = lane >> 5, w = threadIdx.x >> 6;
     const float inv2 = 1.0f / (sa * sw), neg_k = -kLog2e / sa;
-    Rbf rbf;
-    rbf.load(p, hh);
-    W2Frag w2;
-    w2.load(p, sw, 64 * w, il, hh);
-    const f16x8 id0 = identity_frag<true>(0, il, hh), id1 = identity_frag<true>(1, il, hh);
-    Dx2Const k[2];
-    float gb[2] = {0.0f, 0.0f};
+    const float g2 = -p.gamma * kLog2e;
+    const int f = 32 * w + il;  // this lane's feature
+    // W2 fragments of the wave's 32 features (W2Frag's layout, one feature block)
+    f16x8 w_hi[4], w_lo[4];
 #pragma unroll
-    for (int fb = 0; fb < 2; ++fb) k[fb].load(p, 64 * w + 32 * fb + il, inv2, sd);
-    f32x16 dw[2][2] = {{zero16(), zero16()}, {zero16(), zero16()}};
-    const int64_t ntiles = (p.rows + kTile - 1) / kTile;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t row0 = tile * kTile;
-        const bool full = row0 + kTile <= p.rows;  // uniform
-        {
-            f16x8 k_hi[4], k_lo[4];
-            phase_a<true>(p, sh, rbf, neg_k, row0 + 32 * w, lane, w, a_frag, k_hi, k_lo);
-            // a1 of this wave's rows as (lane = j, registers = rows): features 32 jb .. 32 jb + 31 sit in steps 2 jb, 2 jb + 1
-#pragma unroll
-            for (int jb = 0; jb < 2; ++jb) {
-                f32x16 th = mfma(k_hi[2 * jb], id0, zero16());
-                th = mfma(k_hi[2 * jb + 1], id1, th);
-                f32x16 tl = mfma(k_lo[2 * jb], id0, zero16());
-                tl = mfma(k_lo[2 * jb + 1], id1, tl);
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    b_frag[bfrag_idx(w, jb, s, 0, lane)] = __builtin_bit_cast(uint4, pack8(th, s));
-                    b_frag[bfrag_idx(w, jb, s, 1, lane)] = __builtin_bit_cast(uint4, pack8(tl, s));
-                }
-            }
-        }
-        __syncthreads();
-#pragma unroll 1
-        for (int rb = 0; rb < 4; ++rb) {
-            float g[2][16];
-#pragma unroll
-            for (int fb = 0; fb < 2; ++fb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    int64_t row = row0 + n_row(rb, r, hh);
-                    row = row < p.rows ? row : p.rows - 1;
-                    g[fb][r] = p.gz[row * kH + 64 * w + 32 * fb + il];
-                }
-            f32x16 acc[2] = {zero16(), zero16()};
-#pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) {
-                const f16x8 ah = __builtin_bit_cast(f16x8, a_frag[afrag_idx(rb, s2, 0, lane)]);
-                const f16x8 al = __builtin_bit_cast(f16x8, a_frag[afrag_idx(rb, s2, 1, lane)]);
-#pragma unroll
-                for (int fb = 0; fb < 2; ++fb) acc[fb] = mfma3(ah, al, w2.hi[fb][s2], w2.lo[fb][s2], acc[fb]);
-            }
-            f16x8 d_hi[2][2], d_lo[2][2];
-#pragma unroll
-            for (int fb = 0; fb < 2; ++fb)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    float dx[8];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const int r = 8 * s + i;
-                        const bool ok = full || row0 + n_row(rb, r, hh) < p.rows;
-                        const float a = acc[fb][r];
-                        const float gz = g[fb][r] * dsilu_fast(fmaf(a, k[fb].A, k[fb].B));
-                        const float o = ok ? fmaf(k[fb].E, gz, fmaf(a, k[fb].F, k[fb].G)) : 0.0f;
-                        dx[i] = o;
-                        gb[fb] += o;
-                    }
-                    split8s(dx, d_hi[fb][s], d_lo[fb][s]);
-                }
-#pragma unroll
-            for (int jb = 0; jb < 2; ++jb)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const f16x8 bh = __builtin_bit_cast(f16x8, b_frag[bfrag_idx(rb, jb, s, 0, lane)]);
-                    const f16x8 bl = __builtin_bit_cast(f16x8, b_frag[bfrag_idx(rb, jb, s, 1, lane)]);
-#pragma unroll
-                    for (int fb = 0; fb < 2; ++fb) dw[fb][jb] = mfma3(d_hi[fb][s], d_lo[fb][s], bh, bl, dw[fb][jb]);
-                }
-        }
-        __syncthreads();
+    for (int s2 = 0; s2 < 4; ++s2) {
+        const float* wp = p.W2 + (size_t)f * kE + 16 * s2 + 4 * hh;
+        const float4 a = f4_ld(wp), b = f4_ld(wp + 8);
+        const float v[8] = {a.x * sw, a.y * sw, a.z * sw, a.w * sw, b.x * sw, b.y * sw, b.z * sw, b.w * sw};
+        split8s(v, w_hi[s2], w_lo[s2]);
     }
-    // dw[fb][jb]: D[m = feature][n = j]: lane = j, register r = feature 8 (r >> 2) + 4 hh + (r & 3) of block fb
-    float* out = static_cast<float*>(p.partial) + (size_t)blockIdx.x * (kH * kE);
-    const float invd = 1.0f / (sd * sa);
+    const f16x8 id0 = identity_frag<true>(0, il, hh), id1 = identity_frag<true>(1, il, hh);
+    Dx2Const k;
+    k.load(p, f, inv2, sd);
+    float gb = 0.0f;
+    f32x16 dw[2] = {zero16(), zero16()};
+    const int64_t ntiles = (p.rows + kDwTile - 1) / kDwTile;
+    auto load_g = [&](int64_t row0, int rb, float (&g)[16]) {
 #pragma unroll
-    for (int fb = 0; fb < 2; ++fb)
+        for (int r = 0; r < 16; ++r) {
+            int64_t row = row0 + n_row(rb, r, hh);
+            row = row < p.rows ? row : p.rows - 1;
+            g[r] = p.gz[row * kH + f];
+        }
+    };
+    // one row block: recompute the wave's 32 features, dx2, its share of dW2
+    auto block = [&](auto full_c, int64_t row0, int rb, const float (&g)[16]) {
+        constexpr bool FULL = decltype(full_c)::value;
+        f32x16 acc = zero16();
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            const f16x8 ah = __builtin_bit_cast(f16x8, a_frag[afrag_idx(rb, s2, 0, lane)]);
+            const f16x8 al = __builtin_bit_cast(f16x8, a_frag[afrag_idx(rb, s2, 1, lane)]);
+            acc = mfma3(ah, al, w_hi[s2], w_lo[s2], acc);
+        }
+        f16x8 d_hi[2], d_lo[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float dx[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = 8 * s + i;
+                const float a = acc[r];
+                const float gz = g[r] * dsilu_fast(fmaf(a, k.A, k.B));
+                float o = fmaf(k.E, gz, fmaf(a, k.F, k.G));
+                if constexpr (!FULL) o *= row0 + n_row(rb, r, hh) < p.rows ? 1.0f : 0.0f;  // (a multiply, not a branch)
+                dx[i] = o;
+                gb += o;
+            }
+            split8s(dx, d_hi[s], d_lo[s]);
+        }
 #pragma unroll
         for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int f = 64 * w + 32 * fb + 8 * (r >> 2) + 4 * hh + (r & 3);
-                out[f * kE + 32 * jb + il] = dw[fb][jb][r] * invd;
+            for (int s = 0; s < 2; ++s) {
+                const f16x8 bh = __builtin_bit_cast(f16x8, b_frag[bfrag_idx(rb, jb, s, 0, lane)]);
+                const f16x8 bl = __builtin_bit_cast(f16x8, b_frag[bfrag_idx(rb, jb, s, 1, lane)]);
+                dw[jb] = mfma3(d_hi[s], d_lo[s], bh, bl, dw[jb]);
             }
+    };
+    float hv = load_h(p, (int64_t)blockIdx.x * kDwTile + 32 * w + il);
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t row0 = tile * kDwTile;
+        const bool full = row0 + kDwTile <= p.rows;  // uniform
+        float g0[16], g1[16];
+        load_g(row0, 0, g0);
+        // a1 of this wave's rows also as (lane = j, registers = rows), block of 32 features by block
+        phase_a<true>(sh, g2, neg_k, hv, lane, w, a_frag, [&](int jb, const f16x8 (&k_hi)[2], const f16x8 (&k_lo)[2]) {
+            f32x16 th = mfma(k_hi[0], id0, zero16());
+            th = mfma(k_hi[1], id1, th);
+            f32x16 tl = mfma(k_lo[0], id0, zero16());
+            tl = mfma(k_lo[1], id1, tl);
 #pragma unroll
-    for (int fb = 0; fb < 2; ++fb) {
-        float v = gb[fb];
-        v += __shfl_xor(v, 32, 64);
-        if (hh == 0) p.partial_b[(size_t)blockIdx.x * kH + 64 * w + 32 * fb + il] = v / sd;
+            for (int s = 0; s < 2; ++s) {
+                b_frag[bfrag_idx(w, jb, s, 0, lane)] = __builtin_bit_cast(uint4, pack8(th, s));
+                b_frag[bfrag_idx(w, jb, s, 1, lane)] = __builtin_bit_cast(uint4, pack8(tl, s));
+            }
+        });
+        hv = load_h(p, row0 + (int64_t)gridDim.x * kDwTile + 32 * w + il);
+        __syncthreads();
+        auto row_blocks = [&](auto full_c) {
+#pragma unroll 1
+            for (int rb = 0; rb < 8; rb += 2) {  // g_z of the next row block in flight under the current one
+                load_g(row0, rb + 1, g1);
+                block(full_c, row0, rb, g0);
+                if (rb < 6) load_g(row0, rb + 2, g0);
+                block(full_c, row0, rb + 1, g1);
+            }
+        };
+        if (full)
+            row_blocks(std::true_type{});
+        else
+            row_blocks(std::false_type{});
+        __syncthreads();
     }
+    // dw[jb]: D[m = feature][n = j]: lane = j, register r = feature 32 w + 8 (r >> 2) + 4 hh + (r & 3)
+    float* out = static_cast<float*>(p.partial) + (size_t)blockIdx.x * (kH * kE);
+    const float invd = 1.0f / (sd * sa);
+#pragma unroll
+    for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[(32 * w + 8 * (r >> 2) + 4 * hh + (r & 3)) * kE + 32 * jb + il] = dw[jb][r] * invd;
+    gb += __shfl_xor(gb, 32, 64);
+    if (hh == 0) p.partial_b[(size_t)blockIdx.x * kH + f] = gb / sd;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -764,8 +811,7 @@ __global__ __launch_bounds__(kThreads, 2) void angle_da1_kernel(P p) {
     }
     l1_setup(p, sh, kL1Act, sa);
     const int lane = threadIdx.x & 63, il = lane & 31, hh = lane >> 5, w = threadIdx.x >> 6;
-    Rbf rbf;
-    rbf.load(p, hh);
+    const float g2 = -p.gamma * kLog2e;
     W2Frag w2;
     w2.load(p, sw, 64 * w, il, hh);
     // B fragments of the da1 product: lane n = j = 32 jb + il, slot (hh, i) of step (fb, s) = feature
@@ -786,58 +832,64 @@ __global__ __launch_bounds__(kThreads, 2) void angle_da1_kernel(P p) {
                 split8s(v, c_hi[fb][s][jb], c_lo[fb][s][jb]);
             }
     const int64_t ntiles = (p.rows + kTile - 1) / kTile;
-    f16x8 none_hi[4], none_lo[4];
+    // g_z of (row block rb, feature block fb): this lane's row, its 16 features as four quads
+    auto load_g = [&](int64_t row0, int rb, int fb, float4 (&g)[4]) {
+        int64_t row = row0 + 32 * rb + il;
+        row = row < p.rows ? row : p.rows - 1;
+        const float* grow = p.gz + row * kH + 64 * w + 32 * fb + 4 * hh;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g[q] = f4_ld(grow + 8 * q);
+    };
+    // one feature block of one row block: recompute (lane = row, registers = features), dx2, its share of da1
+    auto block = [&](int64_t row0, int rb, int fb, const float4 (&g)[4], f32x16 (&da)[2]) {
+        const float okf = row0 + 32 * rb + il < p.rows ? 1.0f : 0.0f;
+        f32x16 acc = zero16();
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            const f16x8 ah = __builtin_bit_cast(f16x8, a_frag[afrag_idx(rb, s2, 0, lane)]);
+            const f16x8 al = __builtin_bit_cast(f16x8, a_frag[afrag_idx(rb, s2, 1, lane)]);
+            acc = mfma3(w2.hi[fb][s2], w2.lo[fb][s2], ah, al, acc);
+        }
+        f16x8 d_hi[2], d_lo[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float dx[8];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int f = 64 * w + 32 * fb + 8 * (2 * s + q) + 4 * hh;
+                const float4 A4 = f4_ld(&cst[0][f]), B4 = f4_ld(&cst[1][f]), E4 = f4_ld(&cst[2][f]);
+                const float4 F4 = f4_ld(&cst[3][f]), G4 = f4_ld(&cst[4][f]), g4 = g[2 * s + q];
+                const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, cA[4] = {A4.x, A4.y, A4.z, A4.w}, cB[4] = {B4.x, B4.y, B4.z, B4.w};
+                const float cE[4] = {E4.x, E4.y, E4.z, E4.w}, cF[4] = {F4.x, F4.y, F4.z, F4.w}, cG[4] = {G4.x, G4.y, G4.z, G4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a = acc[8 * s + 4 * q + e];
+                    const float gz = gg[e] * dsilu_fast(fmaf(a, cA[e], cB[e]));
+                    dx[4 * q + e] = fmaf(cE[e], gz, fmaf(a, cF[e], cG[e])) * okf;  // (a multiply, not a branch)
+                }
+            }
+            split8s(dx, d_hi[s], d_lo[s]);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb) da[jb] = mfma3(d_hi[s], d_lo[s], c_hi[fb][s][jb], c_lo[fb][s][jb], da[jb]);
+    };
+    float hv = load_h(p, (int64_t)blockIdx.x * kTile + 32 * w + il);
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t row0 = tile * kTile;
-        phase_a<false>(p, sh, rbf, neg_k, row0 + 32 * w, lane, w, a_frag, none_hi, none_lo);
+        float4 g0[4], g1[4];
+        load_g(row0, 0, 0, g0);
+        phase_a<false>(sh, g2, neg_k, hv, lane, w, a_frag, NoBlock());
+        hv = load_h(p, row0 + (int64_t)gridDim.x * kTile + 32 * w + il);
         __syncthreads();
 #pragma unroll 1
         for (int rb = 0; rb < 4; ++rb) {
-            // acc[fb][r]: row = row0 + 32 rb + il, feature = 64 w + 32 fb + 8 (r >> 2) + 4 hh + (r & 3)
-            const int64_t row = row0 + 32 * rb + il;
-            const bool ok = row < p.rows;
-            const float* grow = p.gz + (ok ? row : p.rows - 1) * kH + 64 * w + 4 * hh;
-            float4 g[2][4];
-#pragma unroll
-            for (int fb = 0; fb < 2; ++fb)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) g[fb][q] = f4_ld(grow + 32 * fb + 8 * q);
-            f32x16 acc[2] = {zero16(), zero16()};
-#pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) {
-                const f16x8 ah = __builtin_bit_cast(f16x8, a_frag[afrag_idx(rb, s2, 0, lane)]);
-                const f16x8 al = __builtin_bit_cast(f16x8, a_frag[afrag_idx(rb, s2, 1, lane)]);
-#pragma unroll
-                for (int fb = 0; fb < 2; ++fb) acc[fb] = mfma3(w2.hi[fb][s2], w2.lo[fb][s2], ah, al, acc[fb]);
-            }
             f32x16 da[2] = {zero16(), zero16()};
-#pragma unroll
-            for (int fb = 0; fb < 2; ++fb) {
-                f16x8 d_hi[2], d_lo[2];
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    float dx[8];
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const int f = 64 * w + 32 * fb + 8 * (2 * s + q) + 4 * hh;
-                        const float4 A4 = f4_ld(&cst[0][f]), B4 = f4_ld(&cst[1][f]), E4 = f4_ld(&cst[2][f]);
-                        const float4 F4 = f4_ld(&cst[3][f]), G4 = f4_ld(&cst[4][f]), g4 = g[fb][2 * s + q];
-                        const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, cA[4] = {A4.x, A4.y, A4.z, A4.w}, cB[4] = {B4.x, B4.y, B4.z, B4.w};
-                        const float cE[4] = {E4.x, E4.y, E4.z, E4.w}, cF[4] = {F4.x, F4.y, F4.z, F4.w}, cG[4] = {G4.x, G4.y, G4.z, G4.w};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float a = acc[fb][8 * s + 4 * q + e];
-                            const float gz = gg[e] * dsilu_fast(fmaf(a, cA[e], cB[e]));
-                            dx[4 * q + e] = ok ? fmaf(cE[e], gz, fmaf(a, cF[e], cG[e])) : 0.0f;
-                        }
-                    }
-                    split8s(dx, d_hi[s], d_lo[s]);
-                }
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int jb = 0; jb < 2; ++jb) da[jb] = mfma3(d_hi[s], d_lo[s], c_hi[fb][s][jb], c_lo[fb][s][jb], da[jb]);
-            }
+            load_g(row0, rb, 1, g1);
+            block(row0, rb, 0, g0, da);
+            if (rb < 3) load_g(row0, rb + 1, 0, g0);
+            block(row0, rb, 1, g1, da);
             // da[jb][r]: row = 32 rb + 8 (r >> 2) + 4 hh + (r & 3), j = 32 jb + il - this wave's 64 features only.
             // Round jb: every wave files its four register quads; wave w then adds quad w of the four tiles in wave order.
 #pragma unroll
@@ -875,8 +927,7 @@ __global__ __launch_bounds__(kThreads, 2) void angle_l1_bwd_kernel(P p) {
     l1_setup(p, sh, kL1Bwd, sx);
     const int lane = threadIdx.x & 63, il = lane & 31, hh = lane >> 5;
     const int wave = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6), nwaves = gridDim.x * (kThreads / 64);
-    Rbf rbf;
-    rbf.load(p, hh);
+    const float g2 = -p.gamma * kLog2e;
     float s0[2][16], s1[2][16];
     float am0 = 0.0f, am1 = 0.0f;
     f32x16 dw[2][2];
@@ -895,18 +946,33 @@ __global__ __launch_bounds__(kThreads, 2) void angle_l1_bwd_kernel(P p) {
             for (int nb = 0; nb < 2; ++nb) dw[jb][nb] = zero16();
     }
     const int64_t nblk = (p.rows + 31) / 32;
-    for (int64_t blk = wave; blk < nblk; blk += nwaves) {
-        const int64_t row = blk * 32 + il;
-        const bool ok = row < p.rows;
-        const float hv = ok ? p.h[row] : 0.0f;
-        const float* drow = p.da1 + (ok ? row : p.rows - 1) * kE + 4 * hh;
-        float4 g4[2][4];
+    auto load_d = [&](int64_t blk, float4 (&g)[2][4]) {
+        int64_t row = blk * 32 + il;
+        row = row < p.rows ? row : p.rows - 1;
+        const float* drow = p.da1 + row * kE + 4 * hh;
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) g4[cb][q] = f4_ld(drow + 32 * cb + 8 * q);
+            for (int q = 0; q < 4; ++q) g[cb][q] = f4_ld(drow + 32 * cb + 8 * q);
+    };
+    float hv_next = load_h(p, (int64_t)wave * 32 + il);
+    float4 g4[2][4], g4n[2][4];
+    if constexpr (MODE == 0) load_d(wave, g4n);
+    for (int64_t blk = wave; blk < nblk; blk += nwaves) {
+        const int64_t row = blk * 32 + il;
+        const float okf = row < p.rows ? 1.0f : 0.0f;
+        const float hv = hv_next;
+        hv_next = load_h(p, (blk + nwaves) * 32 + il);
+        if constexpr (MODE == 0) {  // (the weight-gradient pass has no registers left for a second set)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) g4[cb][q] = g4n[cb][q];
+            load_d(blk + nwaves, g4n);
+        } else
+            load_d(blk, g4);
         f16x8 r_hi[3], r_lo[3];
-        rbf.expand<MODE == 1>(hv, hh, p.bins, r_hi, r_lo);
+        l1_rbf<MODE == 1>(sh, g2, hv, hh, p.bins, r_hi, r_lo);
         f32x16 acc[2];
         l1_product(sh, lane, r_hi, r_lo, acc);
         f16x8 b_hi[2][2], b_lo[2][2];
@@ -949,14 +1015,14 @@ __global__ __launch_bounds__(kThreads, 2) void angle_l1_bwd_kernel(P p) {
                     for (int e = 0; e < 4; ++e) {
                         const int r = 4 * qq + e;
                         const float xh = fmaf(acc[cb][r], ux[e], vx[e]);
-                        const float gz = ok ? gg[e] * dsilu_fast(fmaf(xh, ga[e], be[e])) : 0.0f;
+                        const float gz = gg[e] * dsilu_fast(fmaf(xh, ga[e], be[e])) * okf;
                         if constexpr (MODE == 0) {
                             s0[cb][r] += gz;
                             s1[cb][r] = fmaf(gz, xh, s1[cb][r]);
                             am0 = fmaxf(am0, fabsf(gz));
-                            am1 = fmaxf(am1, ok ? fabsf(xh) : 0.0f);
+                            am1 = fmaxf(am1, fabsf(xh) * okf);
                         } else
-                            dx[4 * q + e] = ok ? fmaf(c4[e], gz, fmaf(xh, c5[e], c6[e])) : 0.0f;
+                            dx[4 * q + e] = fmaf(c4[e], gz, fmaf(xh, c5[e], c6[e])) * okf;
                     }
                 }
                 if constexpr (MODE == 1) split8s(dx, x_hi[s], x_lo[s]);
@@ -1057,7 +1123,7 @@ size_t alignn_angle_embed_workspace(int64_t rows, int bins, int backward) {
     (void)rows;
     const size_t waves = (size_t)kGrid * (kThreads / 64);
     if (!backward) {
-        const size_t a = al256(waves * 3 * kE * sizeof(float)), b = al256((size_t)kGrid * 2 * kH * sizeof(double));
+        const size_t a = al256(waves * 2 * kE * sizeof(float)), b = al256((size_t)kGrid * 2 * kH * sizeof(double));
         return a > b ? a : b;
     }
     size_t total = al256((size_t)rows * kE * sizeof(float));                       // da1
@@ -1080,7 +1146,7 @@ int alignn_angle_embed_fwd(const alignn_angle_args* a, alignn_stream_t stream) {
     p.partial = a->workspace;
     hipError_t e = hipMemsetAsync(a->scal, 0, kScalFloats * sizeof(float), st);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(angle_prep_kernel, dim3(1), dim3(kThreads), 0, st, p);
+    hipLaunchKernelGGL(angle_prep_kernel, dim3(17), dim3(kThreads), 0, st, p);
     const int g1 = grid_for(a->rows, 32 * (kThreads / 64)), g2 = grid_for(a->rows, kTile);
     hipLaunchKernelGGL(angle_l1_stats_kernel, dim3(g1), dim3(kThreads), 0, st, p);
     hipLaunchKernelGGL(angle_stat_finalize_kernel<false>, dim3(kE / 4), dim3(256), 0, st, (const void*)p.partial, g1 * (kThreads / 64),
@@ -1129,16 +1195,17 @@ int alignn_angle_embed_bwd(const alignn_angle_args* a, alignn_stream_t stream) {
                        a->l2.red, a->scal, kAmaxGz2, kAmaxXh2, kBoundDx2);
     p.partial = dw2;
     p.partial_b = db2;
-    hipLaunchKernelGGL(angle_dw2_kernel, dim3(g2), dim3(kThreads), 0, st, p);
+    const int gdw = grid_for(a->rows, kDwTile) < kDwGrid ? grid_for(a->rows, kDwTile) : kDwGrid;
+    hipLaunchKernelGGL(angle_dw2_kernel, dim3(gdw), dim3(kDwThreads), 0, st, p);
     hipLaunchKernelGGL(angle_da1_kernel, dim3(g2), dim3(kThreads), 0, st, p);
     ALIGNN_CHECK_LAUNCH();
     int rc;
-    if (g2 > alignn_slab_fold_slabs()) {
-        if ((rc = alignn_slab_fold(dw2, g2, kH * kE, dw2f, stream)) != 0) return rc;
+    if (gdw > alignn_slab_fold_slabs()) {
+        if ((rc = alignn_slab_fold(dw2, gdw, kH * kE, dw2f, stream)) != 0) return rc;
         if ((rc = alignn_slab_sum(dw2f, alignn_slab_fold_slabs(), kH * kE, a->l2.gW, stream)) != 0) return rc;
-    } else if ((rc = alignn_slab_sum(dw2, g2, kH * kE, a->l2.gW, stream)) != 0)
+    } else if ((rc = alignn_slab_sum(dw2, gdw, kH * kE, a->l2.gW, stream)) != 0)
         return rc;
-    if ((rc = alignn_slab_sum(db2, g2, kH, a->l2.gb, stream)) != 0) return rc;
+    if ((rc = alignn_slab_sum(db2, gdw, kH, a->l2.gb, stream)) != 0) return rc;
     // layer 1
     p.partial = sums;
     hipLaunchKernelGGL(angle_l1_bwd_kernel<0>, dim3(g1), dim3(kThreads), 0, st, p);
