@@ -161,7 +161,7 @@ __device__ __forceinline__ void l1_setup(const P& p, L1Shared& sh, L1Mode mode, 
         sh.w[cb][s][0][lane] = __builtin_bit_cast(uint4, hi);
         sh.w[cb][s][1][lane] = __builtin_bit_cast(uint4, lo);
     }
-    if (threadIdx.x >= kThreads - kBinsMax) {
+    if (threadIdx.x >= kThreads - kBinsMax && threadIdx.x < kThreads) {  // (workgroups of 256 or 512 threads)
         const int k = threadIdx.x - (kThreads - kBinsMax);
         sh.cen[k] = k < p.bins ? p.centers[k] : 1.0e18f;
     }
@@ -708,7 +708,7 @@ __global__ __launch_bounds__(kDwThreads, 1) void angle_dw2_kernel(P p) {
         for (int r = 0; r < 16; ++r) {
             int64_t row = row0 + n_row(rb, r, hh);
             row = row < p.rows ? row : p.rows - 1;
-            g[r] = p.gz[row * kH + f];
+            g[r] = __builtin_nontemporal_load(p.gz + row * kH + f);
         }
     };
     // one row block: recompute the wave's 32 features, dx2, its share of dW2
@@ -910,6 +910,255 @@ __global__ __launch_bounds__(kThreads, 2) void angle_da1_kernel(P p) {
                 __syncthreads();
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The T x 256 passes, one wave per block of 32 rows: eight waves per workgroup, one workgroup per compute unit, W2's
+// fragments in LDS (64 KiB per orientation) - so a wave keeps its rows' layer-1 activations in REGISTERS (they are its own
+// MFMA output), shares nothing with the other waves and meets them at no barrier after the set-up.  Per feature block fb of
+// 32: 12 products recompute x2, then
+//   MODE 0  column sums of the raw accumulators and their squares    -> partial[wave][2][256] double
+//   MODE 1  z = silu((x2 - mean) gamma rstd + beta), max|z|           -> z
+//   MODE 2  sums of gz = g_z silu'(.) and gz xhat, maxima             -> partial[wave][2][256] double
+//   MODE 3  da1 += dx2 W2 (x2 recomputed with the operands swapped: lane = row, registers = features, which IS the A
+//           operand of that product; a wave owns all 256 features of its rows, so da1 needs no reduction across waves)
+// Per-feature constants folded:  zl = acc A + B,  xhat = acc C + D,  sd dx2 = E gz + acc F + G (Dx2Const).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kRbThreads = 512, kRbGrid = 256;
+__device__ __forceinline__ int w2a_idx(int fb, int s2, int hl, int lane) { return ((fb * 4 + s2) * 2 + hl) * 64 + lane; }
+__device__ __forceinline__ int w2b_idx(int fb, int s, int jb, int hl, int lane) { return ((((fb * 2 + s) * 2 + jb) * 2) + hl) * 64 + lane; }
+
+template <int MODE>
+__global__ __launch_bounds__(kRbThreads, 1) void angle_rb_kernel(P p) {
+    __shared__ L1Shared sh;
+    __shared__ uint4 w2a[8 * 4 * 2 * 64];                         // 64 KiB: lane = feature 32 fb + il, slots = permuted inputs
+    __shared__ uint4 w2b[MODE == 3 ? 8 * 2 * 2 * 2 * 64 : 1];     // 64 KiB: lane = j 32 jb + il, slots = permuted features
+    __shared__ float cst[MODE == 0 ? 1 : 5][kH];
+    const float sa = f16_scale(p.scal[kBoundA1]), sw = f16_scale(p.scal[kAmaxW2]);
+    const float sd = MODE == 3 ? f16_scale(p.scal[kBoundDx2]) : 1.0f;
+    const float inv2 = 1.0f / (sa * sw), neg_k = -kLog2e / sa, g2 = -p.gamma * kLog2e;
+    const int lane = threadIdx.x & 63, il = lane & 31, hh = lane >> 5, w = threadIdx.x >> 6;
+    {   // wave w builds feature block w of both orientations
+        const int fb = w;
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            const float* wp = p.W2 + (size_t)(32 * fb + il) * kE + 16 * s2 + 4 * hh;
+            const float4 a = f4_ld(wp), b = f4_ld(wp + 8);
+            const float v[8] = {a.x * sw, a.y * sw, a.z * sw, a.w * sw, b.x * sw, b.y * sw, b.z * sw, b.w * sw};
+            f16x8 hi, lo;
+            split8s(v, hi, lo);
+            w2a[w2a_idx(fb, s2, 0, lane)] = __builtin_bit_cast(uint4, hi);
+            w2a[w2a_idx(fb, s2, 1, lane)] = __builtin_bit_cast(uint4, lo);
+        }
+        if constexpr (MODE == 3) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb) {
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int f = 32 * fb + 16 * s + 8 * (i >> 2) + 4 * hh + (i & 3);
+                        v[i] = p.W2[(size_t)f * kE + 32 * jb + il] * sw;
+                    }
+                    f16x8 hi, lo;
+                    split8s(v, hi, lo);
+                    w2b[w2b_idx(fb, s, jb, 0, lane)] = __builtin_bit_cast(uint4, hi);
+                    w2b[w2b_idx(fb, s, jb, 1, lane)] = __builtin_bit_cast(uint4, lo);
+                }
+        }
+    }
+    if constexpr (MODE != 0) {
+        for (int f = threadIdx.x; f < kH; f += kRbThreads) {
+            const float d = p.b2[f] - p.stat2[f], rstd = p.stat2[kH + f], sc = p.stat2[2 * kH + f];
+            cst[0][f] = inv2 * sc;                           // A
+            cst[1][f] = fmaf(d, sc, p.stat2[3 * kH + f]);    // B
+            if constexpr (MODE == 2) {
+                cst[2][f] = inv2 * rstd;  // C
+                cst[3][f] = d * rstd;     // D
+            }
+            if constexpr (MODE == 3) {
+                Dx2Const k;
+                k.load(p, f, inv2, sd);
+                cst[2][f] = k.E, cst[3][f] = k.F, cst[4][f] = k.G;
+            }
+        }
+    }
+    l1_setup(p, sh, kL1Act, sa);  // (ends with the barrier that also publishes w2a / w2b / cst)
+    const int wave = blockIdx.x * (kRbThreads / 64) + w, nwaves = gridDim.x * (kRbThreads / 64);
+    double acc_a[8], acc_b[8];
+    float am0 = 0.0f, am1 = 0.0f;
+#pragma unroll
+    for (int fb = 0; fb < 8; ++fb) acc_a[fb] = acc_b[fb] = 0.0;
+    const float invd = MODE == 3 ? 1.0f / (sd * sw) : 1.0f;
+    const int64_t nblk = (p.rows + 31) / 32;
+    float hv_next = load_h(p, (int64_t)wave * 32 + il);
+    for (int64_t blk = wave; blk < nblk; blk += nwaves) {
+        const int64_t row0 = blk * 32;
+        const bool full = row0 + 32 <= p.rows;  // uniform
+        const float hv = hv_next;
+        hv_next = load_h(p, (blk + nwaves) * 32 + il);
+        // ---- layer 1 -> a1 fragments (registers): step s2 = 2 cb + s, slots = permuted features (see phase_a)
+        f16x8 a_hi[4], a_lo[4];
+        {
+            f32x16 acc1[2];
+            {
+                f16x8 r_hi[3], r_lo[3];
+                l1_rbf<false>(sh, g2, hv, hh, 0, r_hi, r_lo);
+                l1_product(sh, lane, r_hi, r_lo, acc1);
+            }
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    float a[8];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        float u[4], v[4];
+                        l1_const4(sh, 0, cb, 2 * s + q, hh, u);
+                        l1_const4(sh, 1, cb, 2 * s + q, hh, v);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) a[4 * q + e] = silu_scaled(fmaf(acc1[cb][8 * s + 4 * q + e], u[e], v[e]), neg_k);
+                    }
+                    split8s(a, a_hi[2 * cb + s], a_lo[2 * cb + s]);
+                }
+        }
+        // ---- the eight feature blocks
+        auto run = [&](auto full_c) {
+            constexpr bool FULL = decltype(full_c)::value;
+            f32x16 da[2] = {zero16(), zero16()};
+            const float okf = FULL || row0 + il < p.rows ? 1.0f : 0.0f;  // MODE 3: this lane's row
+            int64_t grow3 = row0 + il;
+            grow3 = grow3 < p.rows ? grow3 : p.rows - 1;
+            // g_z of feature block fb: MODE 2: 16 rows of feature 32 fb + il;  MODE 3: 16 features of row row0 + il
+            auto load_g = [&](int fb, float (&g)[16]) {
+                if constexpr (MODE == 2) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        int64_t row = row0 + n_row(0, r, hh);
+                        row = FULL || row < p.rows ? row : p.rows - 1;
+                        g[r] = __builtin_nontemporal_load(p.gz + row * kH + 32 * fb + il);
+                    }
+                }
+                if constexpr (MODE == 3) {
+                    const float* gp = p.gz + grow3 * kH + 32 * fb + 4 * hh;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 v = f4_ld(gp + 8 * q);  // (cached: the four quads and two halves of a row share lines)
+                        g[4 * q] = v.x, g[4 * q + 1] = v.y, g[4 * q + 2] = v.z, g[4 * q + 3] = v.w;
+                    }
+                }
+            };
+            auto block = [&](int fb, const float (&g)[16]) {
+                f32x16 acc = zero16();
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    const f16x8 wh = __builtin_bit_cast(f16x8, w2a[w2a_idx(fb, s2, 0, lane)]);
+                    const f16x8 wl = __builtin_bit_cast(f16x8, w2a[w2a_idx(fb, s2, 1, lane)]);
+                    if constexpr (MODE == 3)
+                        acc = mfma3(wh, wl, a_hi[s2], a_lo[s2], acc);  // D[m = feature][n = row]
+                    else
+                        acc = mfma3(a_hi[s2], a_lo[s2], wh, wl, acc);  // D[m = row][n = feature]
+                }
+                if constexpr (MODE == 3) {
+                    f16x8 d_hi[2], d_lo[2];
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        float dx[8];
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int f = 32 * fb + 8 * (2 * s + q) + 4 * hh;
+                            const float4 A4 = f4_ld(&cst[0][f]), B4 = f4_ld(&cst[1][f]), E4 = f4_ld(&cst[2][f]);
+                            const float4 F4 = f4_ld(&cst[3][f]), G4 = f4_ld(&cst[4][f]);
+                            const float cA[4] = {A4.x, A4.y, A4.z, A4.w}, cB[4] = {B4.x, B4.y, B4.z, B4.w};
+                            const float cE[4] = {E4.x, E4.y, E4.z, E4.w}, cF[4] = {F4.x, F4.y, F4.z, F4.w}, cG[4] = {G4.x, G4.y, G4.z, G4.w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int r = 8 * s + 4 * q + e;
+                                const float a = acc[r];
+                                const float gz = g[r] * dsilu_fast(fmaf(a, cA[e], cB[e]));
+                                float o = fmaf(cE[e], gz, fmaf(a, cF[e], cG[e]));
+                                if constexpr (!FULL) o *= okf;  // (a multiply, not a branch)
+                                dx[4 * q + e] = o;
+                            }
+                        }
+                        split8s(dx, d_hi[s], d_lo[s]);
+                    }
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+#pragma unroll
+                        for (int jb = 0; jb < 2; ++jb) {
+                            const f16x8 bh = __builtin_bit_cast(f16x8, w2b[w2b_idx(fb, s, jb, 0, lane)]);
+                            const f16x8 bl = __builtin_bit_cast(f16x8, w2b[w2b_idx(fb, s, jb, 1, lane)]);
+                            da[jb] = mfma3(d_hi[s], d_lo[s], bh, bl, da[jb]);
+                        }
+                } else {
+                    const int f = 32 * fb + il;
+                    float cA = 0.0f, cB = 0.0f, cC = 0.0f, cD = 0.0f;
+                    if constexpr (MODE != 0) cA = cst[0][f], cB = cst[1][f];
+                    if constexpr (MODE == 2) cC = cst[2][f], cD = cst[3][f];
+                    float s = 0.0f, q = 0.0f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int64_t row = row0 + n_row(0, r, hh);
+                        const float m = FULL || row < p.rows ? 1.0f : 0.0f;
+                        if constexpr (MODE == 0) {
+                            const float a = FULL ? acc[r] : acc[r] * m;
+                            s += a;
+                            q = fmaf(a, a, q);
+                        } else {
+                            const float zl = fmaf(acc[r], cA, cB);
+                            if constexpr (MODE == 1) {
+                                const float zz = silu_scaled(zl, -kLog2e);
+                                if (FULL || row < p.rows) __builtin_nontemporal_store(zz, p.z + row * kH + f);
+                                am0 = fmaxf(am0, FULL ? fabsf(zz) : fabsf(zz) * m);
+                            } else {
+                                float gz = g[r] * dsilu_fast(zl), xh = fmaf(acc[r], cC, cD);
+                                if constexpr (!FULL) gz *= m, xh *= m;
+                                s += gz;
+                                q = fmaf(gz, xh, q);
+                                am0 = fmaxf(am0, fabsf(gz));
+                                am1 = fmaxf(am1, fabsf(xh));
+                            }
+                        }
+                    }
+                    if constexpr (MODE != 1) acc_a[fb] += (double)s, acc_b[fb] += (double)q;
+                }
+            };
+            float g0[16], g1[16];
+            load_g(0, g0);
+#pragma unroll
+            for (int fb = 0; fb < 8; fb += 2) {  // g_z of the next feature block in flight under the current one
+                load_g(fb + 1, g1);
+                block(fb, g0);
+                if (fb < 6) load_g(fb + 2, g0);
+                block(fb + 1, g1);
+            }
+            if constexpr (MODE == 3) {  // da[jb][r]: row = row0 + 8 (r >> 2) + 4 hh + (r & 3), j = 32 jb + il
+#pragma unroll
+                for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int64_t orow = row0 + n_row(0, r, hh);
+                        if (FULL || orow < p.rows) p.da1[orow * kE + 32 * jb + il] = da[jb][r] * invd;
+                    }
+            }
+        };
+        if (full)
+            run(std::true_type{});
+        else
+            run(std::false_type{});
+    }
+    if constexpr (MODE == 0 || MODE == 2) {
+        double* out = static_cast<double*>(p.partial) + (size_t)wave * 2 * kH;
+#pragma unroll
+        for (int fb = 0; fb < 8; ++fb) wave_double_pair_store(acc_a[fb], acc_b[fb], out + 32 * fb + il, out + kH + 32 * fb + il, hh);
+    }
+    if constexpr (MODE == 1) block_amax_commit(am0, p.z_amax);
+    if constexpr (MODE == 2) {
+        block_amax_commit(am0, p.scal + kAmaxGz2);
+        block_amax_commit(am1, p.scal + kAmaxXh2);
     }
 }
 
@@ -1122,12 +1371,13 @@ int alignn_angle_embed_supported(int bins, int embed, int hidden) { return bins 
 size_t alignn_angle_embed_workspace(int64_t rows, int bins, int backward) {
     (void)rows;
     const size_t waves = (size_t)kGrid * (kThreads / 64);
+    const size_t sums = al256((size_t)kRbGrid * (kRbThreads / 64) * 2 * kH * sizeof(double));  // one slab per wave
     if (!backward) {
-        const size_t a = al256(waves * 2 * kE * sizeof(float)), b = al256((size_t)kGrid * 2 * kH * sizeof(double));
-        return a > b ? a : b;
+        const size_t a = al256(waves * 2 * kE * sizeof(float));
+        return a > sums ? a : sums;
     }
     size_t total = al256((size_t)rows * kE * sizeof(float));                       // da1
-    total += al256((size_t)kGrid * 2 * kH * sizeof(double));                        // sums (layer 2, then layer 1: waves * 2 * 64)
+    total += sums;                                                                  // sums (layer 2, then layer 1: waves * 2 * 64)
     total += al256((size_t)kGrid * kH * kE * sizeof(float));                        // dW2 slabs
     total += al256((size_t)kGrid * kH * sizeof(float));                             // db2 slabs
     total += al256((size_t)alignn_slab_fold_slabs() * kH * kE * sizeof(float));     // folded dW2 slabs
@@ -1151,10 +1401,13 @@ int alignn_angle_embed_fwd(const alignn_angle_args* a, alignn_stream_t stream) {
     hipLaunchKernelGGL(angle_l1_stats_kernel, dim3(g1), dim3(kThreads), 0, st, p);
     hipLaunchKernelGGL(angle_stat_finalize_kernel<false>, dim3(kE / 4), dim3(256), 0, st, (const void*)p.partial, g1 * (kThreads / 64),
                        a->rows, kE, a->l1.b, a->l1.gamma, a->l1.beta, a->eps, a->momentum, a->l1.rm, a->l1.rv, a->stat1, a->scal);
-    hipLaunchKernelGGL(angle_l2_kernel<0>, dim3(g2), dim3(kThreads), 0, st, p);
-    hipLaunchKernelGGL(angle_stat_finalize_kernel<true>, dim3(kH / 4), dim3(256), 0, st, (const void*)p.partial, g2, a->rows, kH,
+    const int grb = grid_for(a->rows, 32 * (kRbThreads / 64)) < kRbGrid ? grid_for(a->rows, 32 * (kRbThreads / 64)) : kRbGrid;
+    const int rb_slabs = grb * (kRbThreads / 64);
+    (void)g2;
+    hipLaunchKernelGGL(angle_rb_kernel<0>, dim3(grb), dim3(kRbThreads), 0, st, p);
+    hipLaunchKernelGGL(angle_stat_finalize_kernel<true>, dim3(kH / 4), dim3(256), 0, st, (const void*)p.partial, rb_slabs, a->rows, kH,
                        a->l2.b, a->l2.gamma, a->l2.beta, a->eps, a->momentum, a->l2.rm, a->l2.rv, a->stat2, a->scal);
-    hipLaunchKernelGGL(angle_l2_kernel<1>, dim3(g2), dim3(kThreads), 0, st, p);
+    hipLaunchKernelGGL(angle_rb_kernel<1>, dim3(grb), dim3(kRbThreads), 0, st, p);
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }
@@ -1177,7 +1430,7 @@ int alignn_angle_embed_bwd(const alignn_angle_args* a, alignn_stream_t stream) {
         return q;
     };
     float* da1 = static_cast<float*>(take((size_t)a->rows * kE * sizeof(float)));
-    double* sums = static_cast<double*>(take((size_t)kGrid * 2 * kH * sizeof(double)));
+    double* sums = static_cast<double*>(take((size_t)kRbGrid * (kRbThreads / 64) * 2 * kH * sizeof(double)));
     float* dw2 = static_cast<float*>(take((size_t)kGrid * kH * kE * sizeof(float)));
     float* db2 = static_cast<float*>(take((size_t)kGrid * kH * sizeof(float)));
     float* dw2f = static_cast<float*>(take((size_t)alignn_slab_fold_slabs() * kH * kE * sizeof(float)));
@@ -1190,14 +1443,15 @@ int alignn_angle_embed_bwd(const alignn_angle_args* a, alignn_stream_t stream) {
     const int g1 = grid_for(a->rows, 32 * waves_per), g2 = grid_for(a->rows, kTile);
     // layer 2
     p.partial = sums;
-    hipLaunchKernelGGL(angle_l2_kernel<2>, dim3(g2), dim3(kThreads), 0, st, p);
-    hipLaunchKernelGGL(angle_red_finalize_kernel, dim3(kH / 4), dim3(256), 0, st, (const double*)sums, g2, a->rows, kH, a->stat2,
+    const int grb = grid_for(a->rows, 32 * (kRbThreads / 64)) < kRbGrid ? grid_for(a->rows, 32 * (kRbThreads / 64)) : kRbGrid;
+    hipLaunchKernelGGL(angle_rb_kernel<2>, dim3(grb), dim3(kRbThreads), 0, st, p);
+    hipLaunchKernelGGL(angle_red_finalize_kernel, dim3(kH / 4), dim3(256), 0, st, (const double*)sums, grb * (kRbThreads / 64), a->rows, kH, a->stat2,
                        a->l2.red, a->scal, kAmaxGz2, kAmaxXh2, kBoundDx2);
     p.partial = dw2;
     p.partial_b = db2;
     const int gdw = grid_for(a->rows, kDwTile) < kDwGrid ? grid_for(a->rows, kDwTile) : kDwGrid;
     hipLaunchKernelGGL(angle_dw2_kernel, dim3(gdw), dim3(kDwThreads), 0, st, p);
-    hipLaunchKernelGGL(angle_da1_kernel, dim3(g2), dim3(kThreads), 0, st, p);
+    hipLaunchKernelGGL(angle_rb_kernel<3>, dim3(grb), dim3(kRbThreads), 0, st, p);
     ALIGNN_CHECK_LAUNCH();
     int rc;
     if (gdw > alignn_slab_fold_slabs()) {
