@@ -21,10 +21,13 @@
 // else fp32, column sums in float64.  Register tiles change orientation (rows <-> features across lanes) by a product
 // with an identity fragment - exact for fp16 payloads - instead of an LDS round trip.
 //
-// Work decomposition of the T x 256 passes: a workgroup = 4 waves owns a tile of 128 rows.  Phase A: wave w computes the
-// layer-1 activations of rows [32w, 32w + 32) - the MFMA leaves them (lane = row, registers = features), which IS the
-// operand layout of the next product - and files their fp16 slices in LDS.  Phase B: wave w owns features [64w, 64w + 64)
-// (its slices of W2 live in registers for the whole kernel) and walks the four row blocks.
+// Work decomposition.  Layer 1 of 32 rows is one wave's MFMA output with (lane = row, registers = features) - which IS the
+// operand layout of the layer-2 product, so a wave keeps its rows' activations in registers.  Passes 2, 3, 4, 6: one wave
+// per block of 32 rows, W2's fragments in LDS, no barrier after the set-up (angle_rb_kernel).  Pass 5 accumulates dW2 and
+// therefore splits the FEATURES over the waves of a workgroup (32 each), which share the rows' activations through LDS
+// (angle_dw2_kernel).  Passes 1, 7, 8 work on 64 features only (angle_l1_stats_kernel, angle_l1_bwd_kernel).
+// Measured at T = 676 200 on MI355X (tools/angle_time.py, profiles/r04_angle_*): forward 0.34 ms, backward 0.83 ms, against
+// 0.70 ms + 1.38 ms for the chain of kernels it replaces.
 #include "../../include/alignn_hip.h"
 #include <type_traits>
 
@@ -442,26 +445,6 @@ __device__ __forceinline__ void phase_a(const L1Shared& sh, float g2, float neg_
         if constexpr (KEEP) per_block(cb, keep_hi, keep_lo);  // steps 2 cb, 2 cb + 1 = features 32 cb .. 32 cb + 31
     }
 }
-struct NoBlock {
-    __device__ __forceinline__ void operator()(int, const f16x8 (&)[2], const f16x8 (&)[2]) const {}
-};
-
-// W2 fragments of a wave's 64 features for the recomputation: lane n = feature f0 + 32 fb + il, slot (hh, i) of step s2 =
-// input feature 16 s2 + 8 (i >> 2) + 4 hh + (i & 3)
-struct W2Frag {
-    f16x8 hi[2][4], lo[2][4];
-    __device__ __forceinline__ void load(const P& p, float sw, int f0, int il, int hh) {
-#pragma unroll
-        for (int fb = 0; fb < 2; ++fb)
-#pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) {
-                const float* w = p.W2 + (size_t)(f0 + 32 * fb + il) * kE + 16 * s2 + 4 * hh;
-                const float4 a = f4_ld(w), b = f4_ld(w + 8);
-                const float v[8] = {a.x * sw, a.y * sw, a.z * sw, a.w * sw, b.x * sw, b.y * sw, b.z * sw, b.w * sw};
-                split8s(v, hi[fb][s2], lo[fb][s2]);
-            }
-    }
-};
 
 __device__ __forceinline__ void wave_double_pair_store(double a, double b, double* out_a, double* out_b, int hh) {
     // the two halves of a wave hold different rows of the same feature
@@ -472,135 +455,6 @@ __device__ __forceinline__ void wave_double_pair_store(double a, double b, doubl
 
 // row of register r of row block rb for a lane of half hh, relative to the tile
 __device__ __forceinline__ int n_row(int rb, int r, int hh) { return 32 * rb + 8 * (r >> 2) + 4 * hh + (r & 3); }
-
-// ---------------------------------------------------------------------------------------------------------------------
-// passes 2, 3, 4: x2 = a1 W2^T + b2 recomputed as D[m = row][n = feature] (lane = feature, register r = row
-// 8 (r >> 2) + 4 hh + (r & 3) of the block), then
-//   MODE 0  column sums of the raw accumulators and their squares    -> partial[workgroup][2][256] double
-//   MODE 1  z = silu((x2 - mean) gamma rstd + beta), max|z|           -> z
-//   MODE 2  sums of gz = g_z silu'(.) and gz xhat (float64), maxima   -> partial[workgroup][2][256] double
-// Per-feature constants folded:  zl = acc A + B,  xhat = acc C + D.
-// ---------------------------------------------------------------------------------------------------------------------
-template <int MODE>
-__global__ __launch_bounds__(kThreads, 2) void angle_l2_kernel(P p) {
-    __shared__ L1Shared sh;
-    __shared__ uint4 a_frag[4 * 4 * 2 * 64];  // 32 KiB
-    const float sa = f16_scale(p.scal[kBoundA1]), sw = f16_scale(p.scal[kAmaxW2]);
-    l1_setup(p, sh, kL1Act, sa);
-    const int lane = threadIdx.x & 63, il = lane & 31, hh = lane >> 5, w = threadIdx.x >> 6;
-    const float inv2 = 1.0f / (sa * sw), neg_k = -kLog2e / sa;
-    const float g2 = -p.gamma * kLog2e;
-    W2Frag w2;
-    w2.load(p, sw, 64 * w, il, hh);
-    float cA[2], cB[2], cC[2], cD[2];
-    double acc_a[2] = {0.0, 0.0}, acc_b[2] = {0.0, 0.0};
-    float am0 = 0.0f, am1 = 0.0f;
-#pragma unroll
-    for (int fb = 0; fb < 2; ++fb) {
-        const int f = 64 * w + 32 * fb + il;
-        cA[fb] = cB[fb] = cC[fb] = cD[fb] = 0.0f;
-        if constexpr (MODE != 0) {
-            const float d = p.b2[f] - p.stat2[f], rstd = p.stat2[kH + f], sc = p.stat2[2 * kH + f];
-            cA[fb] = inv2 * sc;
-            cB[fb] = fmaf(d, sc, p.stat2[3 * kH + f]);
-            cC[fb] = inv2 * rstd;
-            cD[fb] = d * rstd;
-        }
-    }
-    const int64_t ntiles = (p.rows + kTile - 1) / kTile;
-    // g_z of (row block rb, feature block fb) of a tile: the 16 rows this lane's registers stand for
-    auto load_g = [&](int64_t row0, int rb, int fb, float (&g)[16]) {
-        if constexpr (MODE == 2) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int64_t row = row0 + n_row(rb, r, hh);
-                row = row < p.rows ? row : p.rows - 1;
-                g[r] = p.gz[row * kH + 64 * w + 32 * fb + il];
-            }
-        }
-    };
-    auto product = [&](int rb, int fb, f32x16& acc) {
-        acc = zero16();
-#pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) {
-            const f16x8 ah = __builtin_bit_cast(f16x8, a_frag[afrag_idx(rb, s2, 0, lane)]);
-            const f16x8 al = __builtin_bit_cast(f16x8, a_frag[afrag_idx(rb, s2, 1, lane)]);
-            acc = mfma3(ah, al, w2.hi[fb][s2], w2.lo[fb][s2], acc);
-        }
-    };
-    // FULL (a compile-time flag, chosen per tile by a uniform branch): every row of the tile exists - no masks.  Otherwise
-    // rows past the end are multiplied out (no per-element branches: they would serialise the transcendentals).
-    auto epilogue = [&](auto full_c, int64_t row0, int rb, int fb, const f32x16& acc, const float (&g)[16]) {
-        constexpr bool FULL = decltype(full_c)::value;
-        const int f = 64 * w + 32 * fb + il;
-        float s = 0.0f, q = 0.0f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t row = row0 + n_row(rb, r, hh);
-            const float m = FULL || row < p.rows ? 1.0f : 0.0f;
-            if constexpr (MODE == 0) {
-                const float a = FULL ? acc[r] : acc[r] * m;
-                s += a;
-                q = fmaf(a, a, q);
-            } else {
-                const float zl = fmaf(acc[r], cA[fb], cB[fb]);
-                if constexpr (MODE == 1) {
-                    const float zz = silu_scaled(zl, -kLog2e);
-                    if (FULL || row < p.rows) p.z[row * kH + f] = zz;
-                    am0 = fmaxf(am0, FULL ? fabsf(zz) : fabsf(zz) * m);
-                } else {
-                    float gz = g[r] * dsilu_fast(zl), xh = fmaf(acc[r], cC[fb], cD[fb]);
-                    if constexpr (!FULL) gz *= m, xh *= m;
-                    s += gz;
-                    q = fmaf(gz, xh, q);
-                    am0 = fmaxf(am0, fabsf(gz));
-                    am1 = fmaxf(am1, fabsf(xh));
-                }
-            }
-        }
-        if constexpr (MODE != 1) acc_a[fb] += (double)s, acc_b[fb] += (double)q;
-    };
-    auto row_blocks = [&](auto full_c, int64_t row0, float (&g0)[16], float (&g1)[16]) {
-#pragma unroll 1
-        for (int rb = 0; rb < 4; ++rb) {
-            f32x16 acc;
-            load_g(row0, rb, 1, g1);
-            product(rb, 0, acc);
-            epilogue(full_c, row0, rb, 0, acc, g0);
-            if (rb < 3) load_g(row0, rb + 1, 0, g0);
-            product(rb, 1, acc);
-            epilogue(full_c, row0, rb, 1, acc, g1);
-        }
-    };
-    float hv = load_h(p, (int64_t)blockIdx.x * kTile + 32 * w + il);
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t row0 = tile * kTile;
-        const bool full = row0 + kTile <= p.rows;  // uniform
-        float g0[16], g1[16];
-        load_g(row0, 0, 0, g0);
-        phase_a<false>(sh, g2, neg_k, hv, lane, w, a_frag, NoBlock());
-        hv = load_h(p, row0 + (int64_t)gridDim.x * kTile + 32 * w + il);  // the next tile's cosine, a whole tile early
-        __syncthreads();
-        if (full)
-            row_blocks(std::true_type{}, row0, g0, g1);
-        else
-            row_blocks(std::false_type{}, row0, g0, g1);
-        __syncthreads();
-    }
-    if constexpr (MODE != 1) {
-        double* out = static_cast<double*>(p.partial) + (size_t)blockIdx.x * 2 * kH;
-#pragma unroll
-        for (int fb = 0; fb < 2; ++fb) {
-            const int f = 64 * w + 32 * fb + il;
-            wave_double_pair_store(acc_a[fb], acc_b[fb], out + f, out + kH + f, hh);
-        }
-    }
-    if constexpr (MODE == 1) block_amax_commit(am0, p.z_amax);
-    if constexpr (MODE == 2) {
-        block_amax_commit(am0, p.scal + kAmaxGz2);
-        block_amax_commit(am1, p.scal + kAmaxXh2);
-    }
-}
 
 // BatchNorm-backward sums from double slabs [slabs][2][F] -> red [2, F]; and the bound of |dx| = |gamma rstd (gz - (c0 + xhat c1) / n)|
 __global__ __launch_bounds__(256) void angle_red_finalize_kernel(const double* __restrict__ partial, int slabs, int64_t rows, int F,
@@ -790,127 +644,6 @@ __global__ __launch_bounds__(kDwThreads, 1) void angle_dw2_kernel(P p) {
         for (int r = 0; r < 16; ++r) out[(32 * w + 8 * (r >> 2) + 4 * hh + (r & 3)) * kE + 32 * jb + il] = dw[jb][r] * invd;
     gb += __shfl_xor(gb, 32, 64);
     if (hh == 0) p.partial_b[(size_t)blockIdx.x * kH + f] = gb / sd;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// pass 6: da1 = dx2 W2.  x2 recomputed in the OTHER orientation (operands swapped: D[m = feature][n = row], lane = row,
-// registers = features), so that dx2 is the A operand [m = row][k = features] of the product; each wave contracts its own
-// 64 features and the four partial [32 x 64] tiles are added through LDS in wave order (two rounds of 32 columns).
-// ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads, 2) void angle_da1_kernel(P p) {
-    __shared__ L1Shared sh;
-    __shared__ uint4 a_frag[4 * 4 * 2 * 64];   // 32 KiB
-    __shared__ float4 red[4 * 4 * 64];          // 16 KiB: [wave][register quad][lane]
-    __shared__ float cst[5][kH];                // Dx2Const per feature
-    const float sa = f16_scale(p.scal[kBoundA1]), sw = f16_scale(p.scal[kAmaxW2]), sd = f16_scale(p.scal[kBoundDx2]);
-    const float inv2 = 1.0f / (sa * sw), invd = 1.0f / (sd * sw), neg_k = -kLog2e / sa;
-    for (int f = threadIdx.x; f < kH; f += kThreads) {
-        Dx2Const k;
-        k.load(p, f, inv2, sd);
-        cst[0][f] = k.A, cst[1][f] = k.B, cst[2][f] = k.E, cst[3][f] = k.F, cst[4][f] = k.G;
-    }
-    l1_setup(p, sh, kL1Act, sa);
-    const int lane = threadIdx.x & 63, il = lane & 31, hh = lane >> 5, w = threadIdx.x >> 6;
-    const float g2 = -p.gamma * kLog2e;
-    W2Frag w2;
-    w2.load(p, sw, 64 * w, il, hh);
-    // B fragments of the da1 product: lane n = j = 32 jb + il, slot (hh, i) of step (fb, s) = feature
-    // 64 w + 32 fb + 16 s + 8 (i >> 2) + 4 hh + (i & 3)
-    f16x8 c_hi[2][2][2], c_lo[2][2][2];
-#pragma unroll
-    for (int fb = 0; fb < 2; ++fb)
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int jb = 0; jb < 2; ++jb) {
-                float v[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int f = 64 * w + 32 * fb + 16 * s + 8 * (i >> 2) + 4 * hh + (i & 3);
-                    v[i] = p.W2[(size_t)f * kE + 32 * jb + il] * sw;
-                }
-                split8s(v, c_hi[fb][s][jb], c_lo[fb][s][jb]);
-            }
-    const int64_t ntiles = (p.rows + kTile - 1) / kTile;
-    // g_z of (row block rb, feature block fb): this lane's row, its 16 features as four quads
-    auto load_g = [&](int64_t row0, int rb, int fb, float4 (&g)[4]) {
-        int64_t row = row0 + 32 * rb + il;
-        row = row < p.rows ? row : p.rows - 1;
-        const float* grow = p.gz + row * kH + 64 * w + 32 * fb + 4 * hh;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) g[q] = f4_ld(grow + 8 * q);
-    };
-    // one feature block of one row block: recompute (lane = row, registers = features), dx2, its share of da1
-    auto block = [&](int64_t row0, int rb, int fb, const float4 (&g)[4], f32x16 (&da)[2]) {
-        const float okf = row0 + 32 * rb + il < p.rows ? 1.0f : 0.0f;
-        f32x16 acc = zero16();
-#pragma unroll
-        for (int s2 = 0; s2 < 4; ++s2) {
-            const f16x8 ah = __builtin_bit_cast(f16x8, a_frag[afrag_idx(rb, s2, 0, lane)]);
-            const f16x8 al = __builtin_bit_cast(f16x8, a_frag[afrag_idx(rb, s2, 1, lane)]);
-            acc = mfma3(w2.hi[fb][s2], w2.lo[fb][s2], ah, al, acc);
-        }
-        f16x8 d_hi[2], d_lo[2];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            float dx[8];
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int f = 64 * w + 32 * fb + 8 * (2 * s + q) + 4 * hh;
-                const float4 A4 = f4_ld(&cst[0][f]), B4 = f4_ld(&cst[1][f]), E4 = f4_ld(&cst[2][f]);
-                const float4 F4 = f4_ld(&cst[3][f]), G4 = f4_ld(&cst[4][f]), g4 = g[2 * s + q];
-                const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, cA[4] = {A4.x, A4.y, A4.z, A4.w}, cB[4] = {B4.x, B4.y, B4.z, B4.w};
-                const float cE[4] = {E4.x, E4.y, E4.z, E4.w}, cF[4] = {F4.x, F4.y, F4.z, F4.w}, cG[4] = {G4.x, G4.y, G4.z, G4.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float a = acc[8 * s + 4 * q + e];
-                    const float gz = gg[e] * dsilu_fast(fmaf(a, cA[e], cB[e]));
-                    dx[4 * q + e] = fmaf(cE[e], gz, fmaf(a, cF[e], cG[e])) * okf;  // (a multiply, not a branch)
-                }
-            }
-            split8s(dx, d_hi[s], d_lo[s]);
-        }
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int jb = 0; jb < 2; ++jb) da[jb] = mfma3(d_hi[s], d_lo[s], c_hi[fb][s][jb], c_lo[fb][s][jb], da[jb]);
-    };
-    float hv = load_h(p, (int64_t)blockIdx.x * kTile + 32 * w + il);
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t row0 = tile * kTile;
-        float4 g0[4], g1[4];
-        load_g(row0, 0, 0, g0);
-        phase_a<false>(sh, g2, neg_k, hv, lane, w, a_frag, NoBlock());
-        hv = load_h(p, row0 + (int64_t)gridDim.x * kTile + 32 * w + il);
-        __syncthreads();
-#pragma unroll 1
-        for (int rb = 0; rb < 4; ++rb) {
-            f32x16 da[2] = {zero16(), zero16()};
-            load_g(row0, rb, 1, g1);
-            block(row0, rb, 0, g0, da);
-            if (rb < 3) load_g(row0, rb + 1, 0, g0);
-            block(row0, rb, 1, g1, da);
-            // da[jb][r]: row = 32 rb + 8 (r >> 2) + 4 hh + (r & 3), j = 32 jb + il - this wave's 64 features only.
-            // Round jb: every wave files its four register quads; wave w then adds quad w of the four tiles in wave order.
-#pragma unroll
-            for (int jb = 0; jb < 2; ++jb) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    red[(w * 4 + q) * 64 + lane] = make_float4(da[jb][4 * q], da[jb][4 * q + 1], da[jb][4 * q + 2], da[jb][4 * q + 3]);
-                __syncthreads();
-                float4 s = red[(0 * 4 + w) * 64 + lane];
-#pragma unroll
-                for (int o = 1; o < 4; ++o) s = f4_add(s, red[(o * 4 + w) * 64 + lane]);
-                const float v[4] = {s.x, s.y, s.z, s.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int64_t orow = row0 + 32 * rb + 8 * w + 4 * hh + e;
-                    if (orow < p.rows) p.da1[orow * kE + 32 * jb + il] = v[e] * invd;
-                }
-                __syncthreads();
-            }
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
