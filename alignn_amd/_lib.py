@@ -118,6 +118,7 @@ SIGNATURES = {
     "alignn_angle_args_sizeof": (_sz, []),
     "alignn_angle_embed_fwd": (_i32, [_p, _p]),
     "alignn_angle_embed_bwd": (_i32, [_p, _p]),
+    "alignn_angle_embed_infer": (_i32, [_p, _p]),
     "alignn_model_plan": (_i32, [_p, _p, _p, _p]),
     "alignn_model_fwd": (_i32, [_p, _p, _p, _sz, _p, _p]),
     "alignn_model_bwd": (_i32, [_p, _p, _p, _sz, _p, _p]),

@@ -431,9 +431,12 @@ class ALIGNN(nn.Module):
             if (len(self.angle_embedding) == 3 and type(l1) is MLPLayer and type(l2) is MLPLayer
                     and not (self.angle_embedding._forward_hooks or self.angle_embedding._forward_pre_hooks)
                     and ops.angle_fused_applies(b.h, rbf, l1, l2, self.training)):
-                _bump(l1.layer[1], True)
-                _bump(l2.layer[1], True)
-                z = ops.angle_embed(b.h, rbf, l1, l2)  # csrc/angle.hip: no [T, bins] / [T, 64] / [T, 256] intermediates
+                if self.training:
+                    _bump(l1.layer[1], True)
+                    _bump(l2.layer[1], True)
+                    z = ops.angle_embed(b.h, rbf, l1, l2)  # csrc/angle.hip: no [T, bins] / [T, 64] / [T, 256] intermediates
+                else:
+                    z = ops.angle_embed_infer(b.h, rbf, l1, l2)
             else:
                 z = self.angle_embedding(b.h)
         x = self.atom_embedding(b.atom_features)

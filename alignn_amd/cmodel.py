@@ -499,7 +499,7 @@ def infer(model, b):
         if af.shape != (b.g.n_nodes, bind.desc.atom_in) or r.shape != (b.g.n_edges, 3) or h.numel() != b.lg.n_edges:
             raise ValueError("feature rows do not match the graphs")
         mb.atom_features, mb.r, mb.h = af.data_ptr(), r.data_ptr(), h.data_ptr()
-        key = ("infer", mb.g.n, mb.g.m, mb.lg.m, mb.B, bool(bind.desc.lane_T), bind.desc.lane_min_rows)
+        key = ("infer", mb.g.n, mb.g.m, mb.lg.m, mb.B, bool(bind.desc.lane_T), bind.desc.lane_min_rows, bind.desc.angle_fused)
         nbytes = bind.plans.get(key)
         if nbytes is None:
             nbytes = bind.plans[key] = lib.alignn_model_infer_workspace(bind.desc_addr, C.addressof(mb))

@@ -284,6 +284,15 @@ __global__ __launch_bounds__(kThreads) void angle_prep_kernel(P p) {
     }
 }
 
+// evaluation mode: the bound of |a1| from the weights alone - rbf lies in (0, 1], so |x1 - b1| <= sum_k |W1[f][k]|
+__global__ __launch_bounds__(kE) void angle_infer_bound_kernel(P p) {
+    const int f = threadIdx.x;
+    float l1 = 0.0f;
+    for (int k = 0; k < p.bins; ++k) l1 += fabsf(p.W1[f * p.bins + k]);
+    const float bound = fabsf(p.stat1[2 * kE + f]) * (l1 + fabsf(p.b1[f] - p.stat1[f])) + fabsf(p.stat1[3 * kE + f]);
+    atomic_max_pos(p.scal + kBoundA1, bound);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // pass 1: shifted column sums of x1 = W1 rbf(h) + b1.  One wave per block of 32 rows; partial[wave][2][64] =
 // sum (x - c) | sum (x - c)^2; scal[kDall] = max |x - c| over everything.
@@ -1140,6 +1149,29 @@ int alignn_angle_embed_fwd(const alignn_angle_args* a, alignn_stream_t stream) {
     hipLaunchKernelGGL(angle_rb_kernel<0>, dim3(grb), dim3(kRbThreads), 0, st, p);
     hipLaunchKernelGGL(angle_stat_finalize_kernel<true>, dim3(kH / 4), dim3(256), 0, st, (const void*)p.partial, rb_slabs, a->rows, kH,
                        a->l2.b, a->l2.gamma, a->l2.beta, a->eps, a->momentum, a->l2.rm, a->l2.rv, a->stat2, a->scal);
+    hipLaunchKernelGGL(angle_rb_kernel<1>, dim3(grb), dim3(kRbThreads), 0, st, p);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+// evaluation mode (BatchNorm = the affine map of its running statistics, nothing kept): one pass, z only
+int alignn_angle_embed_infer(const alignn_angle_args* a, alignn_stream_t stream) {
+    if (a == nullptr || !shape_ok(*a) || !a->h || !a->centers || !a->stat1 || !a->stat2 || !a->scal || !a->z || !a->l1.rm || !a->l1.rv ||
+        !a->l2.rm || !a->l2.rv)
+        return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    P p = make_params(*a);
+    hipError_t e = hipMemsetAsync(a->scal, 0, kScalFloats * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(angle_prep_kernel, dim3(17), dim3(kThreads), 0, st, p);
+    ALIGNN_CHECK_LAUNCH();
+    int rc;
+    if ((rc = alignn_bn_finalize(nullptr, 0, a->rows, kE, a->l1.gamma, a->l1.beta, a->eps, a->momentum, a->l1.rm, a->l1.rv, a->stat1, stream)) != 0)
+        return rc;
+    if ((rc = alignn_bn_finalize(nullptr, 0, a->rows, kH, a->l2.gamma, a->l2.beta, a->eps, a->momentum, a->l2.rm, a->l2.rv, a->stat2, stream)) != 0)
+        return rc;
+    hipLaunchKernelGGL(angle_infer_bound_kernel, dim3(1), dim3(kE), 0, st, p);
+    const int grb = grid_for(a->rows, 32 * (kRbThreads / 64)) < kRbGrid ? grid_for(a->rows, 32 * (kRbThreads / 64)) : kRbGrid;
     hipLaunchKernelGGL(angle_rb_kernel<1>, dim3(grb), dim3(kRbThreads), 0, st, p);
     ALIGNN_CHECK_LAUNCH();
     return 0;

@@ -780,11 +780,27 @@ void run_infer(Ctx& c, float* out) {
     fill(c, c.amax_arena, kAmaxSlots, 0.0f, c.main);
     if (d.n_weights > 0) L(alignn_prepare_weights(d.weight_descs, d.n_weights, d.weight_amax, c.main));
     c.sync(c.T, c.main);
-    float* rbf_a = c.alloc((size_t)Tn * d.angle_bins);
-    L(alignn_rbf_fwd(b.h, d.angle_centers, d.angle_gamma, rbf_a, Tn, d.angle_bins, c.main));
-    Act za;
-    za.p = rbf_a;
-    Act z = mlp_infer(c, d.angle2, mlp_infer(c, d.angle1, za, Tn), Tn);
+    Act z;
+    if (d.angle_fused != 0 && Tn > 0 && alignn_angle_embed_supported(d.angle_bins, d.angle1.out, d.angle2.out) != 0) {
+        const bool lane = c.T != c.main && Tn >= d.lane_min_rows;
+        Tape tp;
+        tp.a_stat1 = c.alloc((size_t)4 * d.angle1.out);
+        tp.a_stat2 = c.alloc((size_t)4 * d.angle2.out);
+        tp.a_scal = c.alloc(128);
+        alignn_angle_args a = angle_args(c, tp);
+        z.p = c.alloc((size_t)Tn * d.H);
+        z.amax = c.track(Tn) ? c.new_amax() : nullptr;
+        z.on_T = lane;
+        a.z = z.p;
+        a.z_amax = z.amax;
+        L(alignn_angle_embed_infer(&a, lane ? c.T : c.main));
+    } else {
+        float* rbf_a = c.alloc((size_t)Tn * d.angle_bins);
+        L(alignn_rbf_fwd(b.h, d.angle_centers, d.angle_gamma, rbf_a, Tn, d.angle_bins, c.main));
+        Act za;
+        za.p = rbf_a;
+        z = mlp_infer(c, d.angle2, mlp_infer(c, d.angle1, za, Tn), Tn);
+    }
     Act xa;
     xa.p = const_cast<float*>(b.atom_features);
     Act x = mlp_infer(c, d.atom, xa, N);

@@ -1248,9 +1248,12 @@ ANGLE_FUSED = True  # csrc/angle.hip where its shapes allow (training mode, Batc
 
 
 def angle_fused_applies(h, rbf, l1, l2, training) -> bool:
-    """Shapes / modes csrc/angle.hip carries: float32 cosines without gradient on a HIP device, training-mode BatchNorm
-    layers with running statistics, bins < 48 -> 64 -> 256 features, no hooks on the three modules."""
-    if not (ANGLE_FUSED and training and h.is_cuda and h.dtype == torch.float32 and not h.requires_grad and h.dim() == 1
+    """Shapes / modes csrc/angle.hip carries: float32 cosines without gradient on a HIP device, BatchNorm layers with running
+    statistics - in training mode, or in evaluation mode without autograd -, bins < 48 -> 64 -> 256 features, no hooks on the
+    three modules."""
+    if not training and (torch.is_grad_enabled() or not INFER_FUSED):
+        return False
+    if not (ANGLE_FUSED and h.is_cuda and h.dtype == torch.float32 and not h.requires_grad and h.dim() == 1
             and h.numel() > 0):
         return False
     lin1, bn1, lin2, bn2 = l1.layer[0], l1.layer[1], l2.layer[0], l2.layer[1]
@@ -1363,6 +1366,38 @@ class AngleEmbedFn(torch.autograd.Function):
             out = run()
         (gw1, gb1, red1), (gw2, gb2, red2) = out
         return (None, None, None, gw1, gb1, red1[1], red1[0], gw2, gb2, red2[1], red2[0], None, None, None, None)
+
+
+def angle_embed_infer(h, rbf, l1, l2):
+    """Evaluation mode without autograd: one pass (``alignn_angle_embed_infer``)."""
+    import ctypes as C
+
+    lib = _lib.load()
+    lin1, bn1, lin2, bn2 = l1.layer[0], l1.layer[1], l2.layer[0], l2.layer[1]
+    h = h.contiguous()
+    T = h.numel()
+    lane = _lane_for(T)
+
+    def run():
+        z = _empty(T, lin2.weight.shape[0], like=h)
+        amax = new_amax(z) if _track(T) else None
+        stat1, stat2, scal = _empty(4 * lin1.weight.shape[0], like=h), _empty(4 * lin2.weight.shape[0], like=h), _empty(128, like=h)
+        a = _angle_args(h, rbf.centers, rbf.gamma, (lin1.weight, lin1.bias, bn1.weight, bn1.bias),
+                        (lin2.weight, lin2.bias, bn2.weight, bn2.bias),
+                        ((bn1.running_mean, bn1.running_var), (bn2.running_mean, bn2.running_var)), stat1, stat2, scal)
+        a.z, a.z_amax = ptr(z), ptr(amax)
+        check(lib.alignn_angle_embed_infer(C.byref(a), stream()), "angle_embed_infer")
+        return z, amax
+
+    if lane is not None:
+        with _on_T(*lane, reads=(h,)):
+            z, amax = run()
+        _mark_on_T(z)
+    else:
+        z, amax = run()
+    if amax is not None:
+        set_amax(z, amax)
+    return z
 
 
 def angle_embed(h, rbf, l1, l2):

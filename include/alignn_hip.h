@@ -671,6 +671,9 @@ size_t alignn_angle_embed_workspace(int64_t rows, int bins, int backward);
 size_t alignn_angle_args_sizeof(void);
 int alignn_angle_embed_fwd(const alignn_angle_args* args, alignn_stream_t stream);
 int alignn_angle_embed_bwd(const alignn_angle_args* args, alignn_stream_t stream);
+/* evaluation mode: BatchNorm as the affine map of l?.rm / l?.rv (not updated); writes z (and z_amax), uses stat1 / stat2 /
+ * scal as scratch, needs no workspace */
+int alignn_angle_embed_infer(const alignn_angle_args* args, alignn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Batch staging in one call (csrc/stage.hip): canonical CSR of g (slots = bonds stably sorted by

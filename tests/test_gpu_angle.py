@@ -130,3 +130,36 @@ def test_a_training_step_with_the_fused_embedding_matches_the_chain_of_layers():
             assert float((a - b).abs().max()) <= tol, (k, float((a - b).abs().max()), tol)
         else:
             assert torch.equal(a, b), k
+
+
+def test_evaluation_mode_without_autograd_takes_the_one_pass_embedding():
+    """model.eval() under no_grad: alignn_angle_embed_infer (BatchNorm from the running statistics, one pass) in the per-operator
+    path and in the whole-model C path - bit-identical to each other, equal to the chain of layers to float32 rounding, and
+    the running statistics untouched."""
+    from alignn_amd import ALIGNN, ALIGNNConfig, GraphBatch, cmodel, ops
+    from alignn_amd.synthetic import make_batch
+
+    raw = make_batch(16, 60, seed0=23)
+    batch = GraphBatch.from_raw(raw, device=DEV)
+    torch.manual_seed(0)
+    m = ALIGNN(ALIGNNConfig(name="alignn")).to(DEV)
+    m.train()
+    for _ in range(2):  # running statistics away from their initial values
+        m(batch)
+    m.eval()
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    outs = {}
+    with torch.no_grad():
+        for name, fused, use_c in (("c", True, True), ("ops", True, False), ("chain", False, True)):
+            ops.ANGLE_FUSED, prev = fused, cmodel.ENABLED
+            cmodel.ENABLED = use_c
+            try:
+                outs[name] = m(batch).clone()
+            finally:
+                ops.ANGLE_FUSED, cmodel.ENABLED = True, prev
+    torch.cuda.synchronize()
+    assert torch.equal(outs["c"], outs["ops"])
+    scale = float(outs["chain"].abs().max())
+    assert float((outs["c"] - outs["chain"]).abs().max()) <= 2e-5 * scale
+    after = m.state_dict()
+    assert all(torch.equal(before[k], after[k]) for k in before)
