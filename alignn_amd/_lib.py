@@ -13,6 +13,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libalignn_hip.so")
+LIB_PATH = os.environ.get("ALIGNN_AMD_LIB_PATH", LIB_PATH)  # (A/B runs of differently compiled libraries: tools/gpu/*.sh)
 
 _p, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 
