@@ -311,3 +311,31 @@ def test_md_batch_signature_and_static_copy():
     for (k, x), (_, y) in zip(_tensors(st), _tensors(b)):
         assert torch.equal(x, y), k
     assert (st.g.n_nodes, st.g.n_edges, st.lg.n_edges) == (b.g.n_nodes, b.g.n_edges, b.lg.n_edges)
+
+
+def test_angle_embedding_dispatch_rules_on_the_host():
+    """ops.angle_fused_applies: csrc/angle.hip is taken only for what it carries - float32 cosines on a HIP device without
+    gradient, BatchNorm layers with running statistics and the default momentum / eps, no hooks; everything else (CPU tensors
+    here) keeps the chain of layers.  No kernel runs."""
+    import torch
+
+    from alignn_amd import ops
+    from alignn_amd.alignn import MLPLayer, RBFExpansion
+
+    rbf, l1, l2 = RBFExpansion(vmin=-1.0, vmax=1.0, bins=40), MLPLayer(40, 64), MLPLayer(64, 256)
+    h = torch.rand(100) * 2 - 1
+    assert not ops.angle_fused_applies(h, rbf, l1, l2, True)  # CPU tensor
+    assert not ops.angle_fused_applies(h, rbf, l1, l2, False)  # evaluation mode with autograd on
+    prev = ops.ANGLE_FUSED
+    ops.ANGLE_FUSED = False
+    try:
+        assert not ops.angle_fused_applies(h, rbf, l1, l2, True)
+    finally:
+        ops.ANGLE_FUSED = prev
+    # the library agrees on the shapes it carries (loads on a CPU-only host: symbols only)
+    from alignn_amd import _lib
+
+    lib = _lib.load()
+    assert lib.alignn_angle_embed_supported(40, 64, 256) == 1
+    assert lib.alignn_angle_embed_supported(48, 64, 256) == 0 and lib.alignn_angle_embed_supported(40, 32, 256) == 0
+    assert lib.alignn_angle_embed_workspace(1000, 40, 1) > lib.alignn_angle_embed_workspace(1000, 40, 0) > 0
