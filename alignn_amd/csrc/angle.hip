@@ -31,6 +31,7 @@
 #include "../../include/alignn_hip.h"
 #include <type_traits>
 
+
 #include "common.h"
 
 namespace {
@@ -282,6 +283,13 @@ __global__ __launch_bounds__(kThreads) void angle_prep_kernel(P p) {
         }
         p.scal[kShift + t] = acc;
     }
+}
+
+// scal[] = 0 (a kernel, not hipMemsetAsync: a memset node captured into a hipGraph raced with the launch behind it in round 3,
+// profiles/README.md "hipMemsetAsync inside a hipGraph")
+__global__ void angle_zero_kernel(float* __restrict__ p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.0f;
 }
 
 // evaluation mode: the bound of |a1| from the weights alone - rbf lies in (0, 1], so |x1 - b1| <= sum_k |W1[f][k]|
@@ -667,12 +675,17 @@ __global__ __launch_bounds__(kDwThreads, 1) void angle_dw2_kernel(P p) {
 //           operand of that product; a wave owns all 256 features of its rows, so da1 needs no reduction across waves)
 // Per-feature constants folded:  zl = acc A + B,  xhat = acc C + D,  sd dx2 = E gz + acc F + G (Dx2Const).
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int kRbThreads = 512, kRbGrid = 256;
+constexpr int kRbGrid = 256, kRbThreadsMax = 768;
+// waves per workgroup (= per compute unit) by pass
+// (measured: the statistics pass 96-99 us with twelve waves, 101-107 with eight; the z pass 143 us with eight and its feature
+// loop unrolled, 151-158 with eight / twelve / sixteen waves and the loop rolled to fit them - occupancy is not its limit)
+constexpr int rb_threads(int mode) { return mode == 0 ? 768 : 512; }
 __device__ __forceinline__ int w2a_idx(int fb, int s2, int hl, int lane) { return ((fb * 4 + s2) * 2 + hl) * 64 + lane; }
 __device__ __forceinline__ int w2b_idx(int fb, int s, int jb, int hl, int lane) { return ((((fb * 2 + s) * 2 + jb) * 2) + hl) * 64 + lane; }
 
 template <int MODE>
-__global__ __launch_bounds__(kRbThreads, 1) void angle_rb_kernel(P p) {
+__global__ __launch_bounds__(rb_threads(MODE), 1) void angle_rb_kernel(P p) {
+    constexpr int kRbThreads = rb_threads(MODE);
     __shared__ L1Shared sh;
     __shared__ uint4 w2a[8 * 4 * 2 * 64];                         // 64 KiB: lane = feature 32 fb + il, slots = permuted inputs
     __shared__ uint4 w2b[MODE == 3 ? 8 * 2 * 2 * 2 * 64 : 1];     // 64 KiB: lane = j 32 jb + il, slots = permuted features
@@ -681,7 +694,7 @@ __global__ __launch_bounds__(kRbThreads, 1) void angle_rb_kernel(P p) {
     const float sd = MODE == 3 ? f16_scale(p.scal[kBoundDx2]) : 1.0f;
     const float inv2 = 1.0f / (sa * sw), neg_k = -kLog2e / sa, g2 = -p.gamma * kLog2e;
     const int lane = threadIdx.x & 63, il = lane & 31, hh = lane >> 5, w = threadIdx.x >> 6;
-    {   // wave w builds feature block w of both orientations
+    if (w < 8) {  // wave w builds feature block w of both orientations
         const int fb = w;
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2) {
@@ -1080,6 +1093,10 @@ inline int grid_for(int64_t rows, int rows_per_block) {
     return (int)(need < kGrid ? (need > 0 ? need : 1) : kGrid);
 }
 inline size_t al256(size_t b) { return (b + 255) / 256 * 256; }
+inline int rb_grid(int64_t rows, int mode) {
+    const int g = grid_for(rows, 32 * (rb_threads(mode) / 64));
+    return g < kRbGrid ? g : kRbGrid;
+}
 
 P make_params(const alignn_angle_args& a) {
     P p{};
@@ -1113,7 +1130,7 @@ int alignn_angle_embed_supported(int bins, int embed, int hidden) { return bins 
 size_t alignn_angle_embed_workspace(int64_t rows, int bins, int backward) {
     (void)rows;
     const size_t waves = (size_t)kGrid * (kThreads / 64);
-    const size_t sums = al256((size_t)kRbGrid * (kRbThreads / 64) * 2 * kH * sizeof(double));  // one slab per wave
+    const size_t sums = al256((size_t)kRbGrid * (kRbThreadsMax / 64) * 2 * kH * sizeof(double));  // one slab per wave
     if (!backward) {
         const size_t a = al256(waves * 2 * kE * sizeof(float));
         return a > sums ? a : sums;
@@ -1136,20 +1153,19 @@ int alignn_angle_embed_fwd(const alignn_angle_args* a, alignn_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
     P p = make_params(*a);
     p.partial = a->workspace;
-    hipError_t e = hipMemsetAsync(a->scal, 0, kScalFloats * sizeof(float), st);
-    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(angle_zero_kernel, dim3(1), dim3(kScalFloats), 0, st, a->scal, kScalFloats);
     hipLaunchKernelGGL(angle_prep_kernel, dim3(17), dim3(kThreads), 0, st, p);
     const int g1 = grid_for(a->rows, 32 * (kThreads / 64)), g2 = grid_for(a->rows, kTile);
     hipLaunchKernelGGL(angle_l1_stats_kernel, dim3(g1), dim3(kThreads), 0, st, p);
     hipLaunchKernelGGL(angle_stat_finalize_kernel<false>, dim3(kE / 4), dim3(256), 0, st, (const void*)p.partial, g1 * (kThreads / 64),
                        a->rows, kE, a->l1.b, a->l1.gamma, a->l1.beta, a->eps, a->momentum, a->l1.rm, a->l1.rv, a->stat1, a->scal);
-    const int grb = grid_for(a->rows, 32 * (kRbThreads / 64)) < kRbGrid ? grid_for(a->rows, 32 * (kRbThreads / 64)) : kRbGrid;
-    const int rb_slabs = grb * (kRbThreads / 64);
+    const int grb = rb_grid(a->rows, 0);
+    const int rb_slabs = grb * (rb_threads(0) / 64);
     (void)g2;
-    hipLaunchKernelGGL(angle_rb_kernel<0>, dim3(grb), dim3(kRbThreads), 0, st, p);
+    hipLaunchKernelGGL(angle_rb_kernel<0>, dim3(grb), dim3(rb_threads(0)), 0, st, p);
     hipLaunchKernelGGL(angle_stat_finalize_kernel<true>, dim3(kH / 4), dim3(256), 0, st, (const void*)p.partial, rb_slabs, a->rows, kH,
                        a->l2.b, a->l2.gamma, a->l2.beta, a->eps, a->momentum, a->l2.rm, a->l2.rv, a->stat2, a->scal);
-    hipLaunchKernelGGL(angle_rb_kernel<1>, dim3(grb), dim3(kRbThreads), 0, st, p);
+    hipLaunchKernelGGL(angle_rb_kernel<1>, dim3(rb_grid(a->rows, 1)), dim3(rb_threads(1)), 0, st, p);
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }
@@ -1161,8 +1177,7 @@ int alignn_angle_embed_infer(const alignn_angle_args* a, alignn_stream_t stream)
         return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
     P p = make_params(*a);
-    hipError_t e = hipMemsetAsync(a->scal, 0, kScalFloats * sizeof(float), st);
-    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(angle_zero_kernel, dim3(1), dim3(kScalFloats), 0, st, a->scal, kScalFloats);
     hipLaunchKernelGGL(angle_prep_kernel, dim3(17), dim3(kThreads), 0, st, p);
     ALIGNN_CHECK_LAUNCH();
     int rc;
@@ -1171,8 +1186,7 @@ int alignn_angle_embed_infer(const alignn_angle_args* a, alignn_stream_t stream)
     if ((rc = alignn_bn_finalize(nullptr, 0, a->rows, kH, a->l2.gamma, a->l2.beta, a->eps, a->momentum, a->l2.rm, a->l2.rv, a->stat2, stream)) != 0)
         return rc;
     hipLaunchKernelGGL(angle_infer_bound_kernel, dim3(1), dim3(kE), 0, st, p);
-    const int grb = grid_for(a->rows, 32 * (kRbThreads / 64)) < kRbGrid ? grid_for(a->rows, 32 * (kRbThreads / 64)) : kRbGrid;
-    hipLaunchKernelGGL(angle_rb_kernel<1>, dim3(grb), dim3(kRbThreads), 0, st, p);
+    hipLaunchKernelGGL(angle_rb_kernel<1>, dim3(rb_grid(a->rows, 1)), dim3(rb_threads(1)), 0, st, p);
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }
@@ -1195,7 +1209,7 @@ int alignn_angle_embed_bwd(const alignn_angle_args* a, alignn_stream_t stream) {
         return q;
     };
     float* da1 = static_cast<float*>(take((size_t)a->rows * kE * sizeof(float)));
-    double* sums = static_cast<double*>(take((size_t)kRbGrid * (kRbThreads / 64) * 2 * kH * sizeof(double)));
+    double* sums = static_cast<double*>(take((size_t)kRbGrid * (kRbThreadsMax / 64) * 2 * kH * sizeof(double)));
     float* dw2 = static_cast<float*>(take((size_t)kGrid * kH * kE * sizeof(float)));
     float* db2 = static_cast<float*>(take((size_t)kGrid * kH * sizeof(float)));
     float* dw2f = static_cast<float*>(take((size_t)alignn_slab_fold_slabs() * kH * kE * sizeof(float)));
@@ -1208,15 +1222,15 @@ int alignn_angle_embed_bwd(const alignn_angle_args* a, alignn_stream_t stream) {
     const int g1 = grid_for(a->rows, 32 * waves_per), g2 = grid_for(a->rows, kTile);
     // layer 2
     p.partial = sums;
-    const int grb = grid_for(a->rows, 32 * (kRbThreads / 64)) < kRbGrid ? grid_for(a->rows, 32 * (kRbThreads / 64)) : kRbGrid;
-    hipLaunchKernelGGL(angle_rb_kernel<2>, dim3(grb), dim3(kRbThreads), 0, st, p);
-    hipLaunchKernelGGL(angle_red_finalize_kernel, dim3(kH / 4), dim3(256), 0, st, (const double*)sums, grb * (kRbThreads / 64), a->rows, kH, a->stat2,
+    const int grb = rb_grid(a->rows, 2);
+    hipLaunchKernelGGL(angle_rb_kernel<2>, dim3(grb), dim3(rb_threads(2)), 0, st, p);
+    hipLaunchKernelGGL(angle_red_finalize_kernel, dim3(kH / 4), dim3(256), 0, st, (const double*)sums, grb * (rb_threads(2) / 64), a->rows, kH, a->stat2,
                        a->l2.red, a->scal, kAmaxGz2, kAmaxXh2, kBoundDx2);
     p.partial = dw2;
     p.partial_b = db2;
     const int gdw = grid_for(a->rows, kDwTile) < kDwGrid ? grid_for(a->rows, kDwTile) : kDwGrid;
     hipLaunchKernelGGL(angle_dw2_kernel, dim3(gdw), dim3(kDwThreads), 0, st, p);
-    hipLaunchKernelGGL(angle_rb_kernel<3>, dim3(grb), dim3(kRbThreads), 0, st, p);
+    hipLaunchKernelGGL(angle_rb_kernel<3>, dim3(rb_grid(a->rows, 3)), dim3(rb_threads(3)), 0, st, p);
     ALIGNN_CHECK_LAUNCH();
     int rc;
     if (gdw > alignn_slab_fold_slabs()) {
