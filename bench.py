@@ -124,6 +124,41 @@ def time_kernel(fn, iters=10):
     return s.elapsed_time(e) / iters
 
 
+def angle_embedding_timings(model, h):
+    """The bond-angle embedding alone at this batch's T rows, forward and backward, HIP events on the launch stream:
+    csrc/angle.hip (recomputing passes, what the step runs) beside the chain of layers it replaced (ops.ANGLE_FUSED = False).
+    Training-mode BatchNorm on throw-away copies of the three modules.  None when the model has no such embedding."""
+    import copy
+
+    from alignn_amd import ops
+
+    emb = getattr(model, "angle_embedding", None)
+    if emb is None or len(emb) != 3 or not ops.angle_fused_applies(h, emb[0], emb[1], emb[2], True):
+        return None
+    rbf, l1, l2 = (copy.deepcopy(m).train() for m in emb)
+    params = [p for m in (l1, l2) for p in m.parameters()]
+    gz = torch.randn(h.numel(), l2.layer[0].weight.shape[0], device=h.device)
+    out = {"rows": int(h.numel())}
+    for name, fused in (("fused", True), ("chain_of_layers", False)):
+        ops.ANGLE_FUSED = fused
+        try:
+            def fwd():
+                return ops.angle_embed(h, rbf, l1, l2) if fused else l2(l1(rbf(h)))
+
+            def fwd_bwd():
+                for p in params:
+                    p.grad = None
+                fwd().backward(gz)
+
+            with torch.no_grad():
+                t_f = time_kernel(fwd, iters=5)
+            t_fb = time_kernel(fwd_bwd, iters=5)
+            out[name] = {"forward_ms": round(t_f, 3), "backward_ms": round(t_fb - t_f, 3)}
+        finally:
+            ops.ANGLE_FUSED = True
+    return out
+
+
 def cpu_baseline_ff(n_atoms, sample=4):
     """BASELINE configs[3] (ALIGNN-FF: energy + forces + stress, loss differentiated THROUGH the forces): the oracle's
     ``alignn_atomwise_forward`` (reference arithmetic of alignn_atomwise.py:364-660 on torch-CPU, autograd.grad with
@@ -718,6 +753,12 @@ def main():
             buf = torch.empty(T, H, device=dev)
             ws = ops.split_bf16x3(w)
             wh, z_amax = ops.split_f16x2(w), ops.absmax(zt)
+        angle_emb = None
+        if not args.no_micro and args.model == "alignn":
+            try:
+                angle_emb = angle_embedding_timings(model, batch.h)
+            except Exception as exc:  # (informational: never fails the line)
+                angle_emb = {"error": repr(exc)[:200]}
         if args.no_micro:
             t_h3 = t_x6 = t_f32 = float("nan")
         else:
@@ -755,6 +796,7 @@ def main():
                 "parallelism": f"dp{world}",
             },
             "eager_launches": eager,
+            "angle_embedding": angle_emb,
             # the dominant kernel: the f16x3 NT projection at M=T, N=K=256 (csrc/gemm_x6.hip, gemm_nt_x6_body).  Inside a
             # training step it is launched 8 times with fused epilogues (4x edge projection + u_add_v gather + BatchNorm
             # statistics, 3x input gradient + residual + BatchNorm-backward sums, 1x the same without residual): `achieved`
