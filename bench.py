@@ -709,16 +709,17 @@ def main():
     # launched (before any capture; two C calls per step for the default model) and replayed from the hipGraph, with the same
     # barrier + synchronize protocol.  Replays do not depend on the host at all; eager launches are what a loop over
     # never-seen batches runs and - where the host keeps up - cost the runtime less than a replay does (0.1-0.3 ms per step
-    # on every box of round 4).  One GPU: the faster of the two is `value` and the other is reported beside it; N > 1
-    # stays on the replay (eight ranks share one host, and the `multi_gpu` instrumentation below belongs to those steps).
+    # on every box of round 4).  The faster of the two is `value` and the other is reported beside it - for every N (both
+    # times are the maximum over the ranks, so every rank decides alike; where eight ranks crowd one host the replay wins by
+    # itself).  The `multi_gpu` instrumentation below is taken on the replayed steps.
     replayed = None
     if use_graph:
         replayed = {"ms_per_step": round(ms, 3), "graphs_per_s": round(gps, 2), "steps": args.steps,
                     "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3)}
-    headline_eager = (use_graph and world == 1 and eager is not None and eager["steps"] >= args.steps
+    headline_eager = (use_graph and eager is not None and eager["steps"] >= args.steps
                       and eager["ms_per_step"] < ms and os.environ.get("ALIGNN_BENCH_HEADLINE", "auto") != "replay")
     if headline_eager:
-        ms, gps = eager["ms_per_step"], B * 1e3 / eager["ms_per_step"]
+        ms, gps = eager["ms_per_step"], world * B * 1e3 / eager["ms_per_step"]
         t_enq = eager["host_enqueue_ms_per_step"] * 1e-3 * args.steps
         log(f"headline: eagerly launched steps ({ms:.2f} ms) beat the replays ({replayed['ms_per_step']:.2f} ms) on this host")
     peak_train_bytes = torch.cuda.max_memory_allocated(dev)  # (before the informational per-operator / micro-timing runs below)
