@@ -117,6 +117,7 @@ SIGNATURES = {
     "alignn_angle_embed_supported": (_i32, [_i32, _i32, _i32]),
     "alignn_angle_embed_workspace": (_sz, [_i64, _i32, _i32]),
     "alignn_angle_args_sizeof": (_sz, []),
+    "alignn_angle_embed_scal_floats": (_i32, []),
     "alignn_angle_embed_fwd": (_i32, [_p, _p]),
     "alignn_angle_embed_bwd": (_i32, [_p, _p]),
     "alignn_angle_embed_infer": (_i32, [_p, _p]),

@@ -39,7 +39,7 @@ class AngleEmbedding:
         dev = centers.device
         self.stat1 = torch.empty(4 * 64, device=dev)
         self.stat2 = torch.empty(4 * 256, device=dev)
-        self.scal = torch.empty(128, device=dev)
+        self.scal = torch.empty(self.lib.alignn_angle_embed_scal_floats(), device=dev)
         (l1, b1), (l2, b2) = ((m.layer[0], m.layer[1]) for m in layers)
         self.grads = [(torch.empty_like(l.weight), torch.empty_like(l.bias), torch.empty(2 * l.weight.shape[0], device=dev))
                       for l in (l1, l2)]

@@ -7,13 +7,14 @@
 // read again by the next one - 3.2 GB of traffic forward and 4.5 GB backward for 0.69 GB of result.  Here every pass
 // RECOMPUTES what it needs from h (2.7 MB) on the matrix cores and only the real operands cross HBM:
 //   forward   pass 1  statistics of layer 1's pre-activation               reads h
-//             pass 2  statistics of layer 2's pre-activation               reads h
+//             pass 2  statistics of layer 2's pre-activation,
+//                     mean and covariance of layer 1's activation a1       reads h
 //             pass 3  z = SiLU(BatchNorm(.))                               reads h, writes z [T, 256]
-//   backward  pass 4  BatchNorm-backward sums of layer 2                   reads h, g_z [T, 256]
-//             pass 5  dW2 = dx2^T a1 (and db2)                             reads h, g_z
-//             pass 6  da1 = dx2 W2                                         reads h, g_z, writes da1 [T, 64]
-//             pass 7  BatchNorm-backward sums of layer 1                   reads h, da1
-//             pass 8  dW1 = dx1^T rbf (and db1)                            reads h, da1
+//   backward  pass 4  BatchNorm-backward sums of layer 2 AND
+//                     G = sum gz (a1 - mean), which becomes dW2            reads h, g_z [T, 256]
+//             pass 5  da1 = dx2 W2                                         reads h, g_z, writes da1 [T, 64]
+//             pass 6  BatchNorm-backward sums of layer 1                   reads h, da1
+//             pass 7  dW1 = dx1^T rbf (and db1)                            reads h, da1
 // BatchNorm's global statistics are what forces the passes apart (each is a grid-wide dependency).
 //
 // Arithmetic: products as f16x3 split products (hi * hi + hi * lo + lo * hi, fp32 accumulation: v_mfma_f32_32x32x16_f16) of
@@ -22,15 +23,14 @@
 // with an identity fragment - exact for fp16 payloads - instead of an LDS round trip.
 //
 // Work decomposition.  Layer 1 of 32 rows is one wave's MFMA output with (lane = row, registers = features) - which IS the
-// operand layout of the layer-2 product, so a wave keeps its rows' activations in registers.  Passes 2, 3, 4, 6: one wave
-// per block of 32 rows, W2's fragments in LDS, no barrier after the set-up (angle_rb_kernel).  Pass 5 accumulates dW2 and
+// operand layout of the layer-2 product, so a wave keeps its rows' activations in registers.  Passes 2, 3, 5: one wave
+// per block of 32 rows, W2's fragments in LDS, no barrier after the set-up (angle_rb_kernel).  Pass 4 accumulates dW2 and
 // therefore splits the FEATURES over the waves of a workgroup (32 each), which share the rows' activations through LDS
-// (angle_dw2_kernel).  Passes 1, 7, 8 work on 64 features only (angle_l1_stats_kernel, angle_l1_bwd_kernel).
-// Measured at T = 676 200 on MI355X (tools/angle_time.py, profiles/r04_angle_*): forward 0.34 ms, backward 0.83 ms, against
+// (angle_sums_dw2_kernel).  Passes 1, 6, 7 work on 64 features only (angle_l1_stats_kernel, angle_l1_bwd_kernel).
+// Measured at T = 676 200 on MI355X (tools/angle_time.py, profiles/r04_angle_*): forward 0.36 ms, backward 0.71 ms, against
 // 0.70 ms + 1.38 ms for the chain of kernels it replaces.
 #include "../../include/alignn_hip.h"
 #include <type_traits>
-
 
 #include "common.h"
 
@@ -48,7 +48,10 @@ constexpr int kGrid = 512;     // two workgroups per compute unit
 // scal[] (device scalars that live from the forward to the backward of one step)
 constexpr int kAmaxW1 = 0, kAmaxW2 = 1, kBoundA1 = 2, kBoundDx2 = 3, kBoundDx1 = 4, kAmaxGz2 = 5, kAmaxXh2 = 6, kAmaxGz1 = 7,
               kAmaxXh1 = 8, kDall = 9, kShift = 16,  // kShift .. kShift + 63: layer-1 shift of the statistics pass
-              kScalFloats = 128;
+              kScalHead = 128,             // what the forward zeroes (scalars that kernels raise atomically)
+              kMeanA1 = 128,               // [64] mean of a1 (layer-1 activations), written by the forward
+              kCovA1 = 192,                // [64][64] sum over rows of (a1 - mean)(a1 - mean)^T, written by the forward
+              kScalFloats = 192 + 64 * 64; // 4288
 constexpr float kRbfScale = 16384.0f;     // rbf values lie in (0, 1]
 
 __device__ __forceinline__ f32x16 mfma(const f16x8& a, const f16x8& b, const f32x16& c) {
@@ -128,6 +131,7 @@ struct P {  // kernel parameters (by value)
     float* da1;
     void* partial;
     float* partial_b;
+    double* partial_d;
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -429,9 +433,11 @@ __global__ __launch_bounds__(256) void angle_stat_finalize_kernel(const void* __
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int afrag_idx(int rb, int s2, int hl, int lane) { return ((rb * 4 + s2) * 2 + hl) * 64 + lane; }
 
+// KEEP: the fragments of each block of 32 features are also handed to per_block - of a1 MINUS `centre` (64 floats in LDS,
+// scaled like a1) when that is given: the caller's product with them is then free of a1's mean
 template <bool KEEP, typename PerBlock>
 __device__ __forceinline__ void phase_a(const L1Shared& sh, float g2, float neg_k, float hv, int lane, int rb, uint4* a_frag,
-                                        PerBlock per_block) {
+                                        PerBlock per_block, const float* centre = nullptr) {
     const int hh = lane >> 5;
     f32x16 acc[2];
     {
@@ -457,7 +463,17 @@ __device__ __forceinline__ void phase_a(const L1Shared& sh, float g2, float neg_
             split8s(a, hi, lo);
             a_frag[afrag_idx(rb, 2 * cb + s, 0, lane)] = __builtin_bit_cast(uint4, hi);
             a_frag[afrag_idx(rb, 2 * cb + s, 1, lane)] = __builtin_bit_cast(uint4, lo);
-            if constexpr (KEEP) keep_hi[s] = hi, keep_lo[s] = lo;
+            if constexpr (KEEP) {
+                if (centre != nullptr) {  // (uniform)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const float4 c4 = f4_ld(centre + 32 * cb + 8 * (2 * s + q) + 4 * hh);
+                        a[4 * q] -= c4.x, a[4 * q + 1] -= c4.y, a[4 * q + 2] -= c4.z, a[4 * q + 3] -= c4.w;
+                    }
+                    split8s(a, keep_hi[s], keep_lo[s]);
+                } else
+                    keep_hi[s] = hi, keep_lo[s] = lo;
+            }
         }
         if constexpr (KEEP) per_block(cb, keep_hi, keep_lo);  // steps 2 cb, 2 cb + 1 = features 32 cb .. 32 cb + 31
     }
@@ -496,6 +512,19 @@ __global__ __launch_bounds__(256) void angle_red_finalize_kernel(const double* _
     const float inv_n = 1.0f / (float)rows;
     const float b = fabsf(stat[2 * F + f]) * (scal[amax_gz] + inv_n * (fabsf((float)s) + scal[amax_xh] * fabsf((float)q)));
     atomic_max_pos(scal + bound, b);
+}
+
+// moments of a1 from their reduced sums [64 + 64 x 64] (scaled by sa, sa^2) -> scal[kMeanA1] = mean,
+// scal[kCovA1] = sum_rows (a1 - mean)(a1 - mean)^T
+__global__ __launch_bounds__(256) void angle_moments_finalize_kernel(const float* __restrict__ sums, int64_t rows,
+                                                                     float* __restrict__ scal) {
+    const int i = blockIdx.x * 256 + threadIdx.x;  // 0 .. 64 * 64 - 1: (k, j)
+    if (i >= kE * kE) return;
+    const int k = i / kE, j = i % kE;
+    const double sa = (double)f16_scale(scal[kBoundA1]), n = (double)rows;
+    const double mk = (double)sums[k] / (n * sa), mj = (double)sums[j] / (n * sa);
+    scal[kCovA1 + i] = (float)((double)sums[kE + i] / (sa * sa) - n * mk * mj);
+    if (k == 0) scal[kMeanA1 + j] = (float)mj;
 }
 
 // identity fragments for changing the orientation of a register tile: B[k][n] = 1 where slot k of step s names feature n
@@ -547,19 +576,32 @@ __device__ __forceinline__ int bfrag_idx(int rb, int jb, int s, int hl, int lane
 // and one block of g_z leave no registers (hipcc spilled 90-230 of them: 0.3-0.7 ms).  So: EIGHT waves per workgroup, a
 // tile of 256 rows (wave w: phase A of row block w), 32 features per wave (16 + 16 fragment registers of W2, 32 of dW2),
 // one workgroup per compute unit (142 KiB of LDS).
+//
+// ONE pass for the BatchNorm-backward sums AND dW2.  dx2 = gamma rstd (gz - c0 / n - xhat c1 / n) needs the sums c0 = sum gz,
+// c1 = sum gz xhat first - but its product with a1 does not:
+//   dW2[f][j] = gamma rstd [ sum_r gz[r][f] (a1[r][j] - mean_j)  -  (c1[f] / n) rstd[f] sum_k W2[f][k] Cov[k][j] ],
+// with mean and Cov = sum_r (a1 - mean)(a1 - mean)^T of a1 known from the forward (scal[kMeanA1], scal[kCovA1]): the c0 term
+// drops out against the centred a1, and xhat[r][f] = rstd[f] sum_k W2[f][k] (a1[r][k] - mean_k).  So this kernel reads g_z
+// once, accumulates c0, c1 and G[f][j] = sum_r gz (a1 - mean), and angle_dw2_fixup_kernel finishes dW2 once c1 is known.  (db2,
+// the column sums of dx2, is zero by construction and is written as such.)
+// gz has no known bound here (its maximum comes out of THIS pass): every 32 x 32 tile is sliced with its own power-of-two
+// scale, multiplied into a fresh accumulator and added to dW2's with the inverse scale - the fp32 addition the MFMA itself
+// would have made.
 constexpr int kDwThreads = 512, kDwTile = 256, kDwGrid = 256;
 
-__global__ __launch_bounds__(kDwThreads, 1) void angle_dw2_kernel(P p) {
+__global__ __launch_bounds__(kDwThreads, 1) void angle_sums_dw2_kernel(P p) {
     __shared__ L1Shared sh;
     __shared__ uint4 a_frag[8 * 4 * 2 * 64];      // 64 KiB
     __shared__ uint4 b_frag[8 * 2 * 2 * 2 * 64];  // 64 KiB
-    const float sa = f16_scale(p.scal[kBoundA1]), sw = f16_scale(p.scal[kAmaxW2]), sd = f16_scale(p.scal[kBoundDx2]);
-    l1_setup(p, sh, kL1Act, sa);
+    __shared__ __attribute__((aligned(16))) float centre[kE];  // sa * mean of a1
+    const float sa = f16_scale(p.scal[kBoundA1]), sw = f16_scale(p.scal[kAmaxW2]);
+    if (threadIdx.x < kE) centre[threadIdx.x] = sa * p.scal[kMeanA1 + threadIdx.x];
+    l1_setup(p, sh, kL1Act, sa);  // (ends with a barrier)
     const int lane = threadIdx.x & 63, il = lane & 31, hh = lane >> 5, w = threadIdx.x >> 6;
     const float inv2 = 1.0f / (sa * sw), neg_k = -kLog2e / sa;
     const float g2 = -p.gamma * kLog2e;
     const int f = 32 * w + il;  // this lane's feature
-    // W2 fragments of the wave's 32 features (W2Frag's layout, one feature block)
+    // W2 fragments of the wave's 32 features: lane n = feature, slot (hh, i) of step s2 = input 16 s2 + 8 (i >> 2) + 4 hh + (i & 3)
     f16x8 w_hi[4], w_lo[4];
 #pragma unroll
     for (int s2 = 0; s2 < 4; ++s2) {
@@ -568,10 +610,11 @@ __global__ __launch_bounds__(kDwThreads, 1) void angle_dw2_kernel(P p) {
         const float v[8] = {a.x * sw, a.y * sw, a.z * sw, a.w * sw, b.x * sw, b.y * sw, b.z * sw, b.w * sw};
         split8s(v, w_hi[s2], w_lo[s2]);
     }
-    const f16x8 id0 = identity_frag<true>(0, il, hh), id1 = identity_frag<true>(1, il, hh);
-    Dx2Const k;
-    k.load(p, f, inv2, sd);
-    float gb = 0.0f;
+    // zl = acc A + B,  xhat = acc C + D
+    const float d_ = p.b2[f] - p.stat2[f], rstd_ = p.stat2[kH + f], sc_ = p.stat2[2 * kH + f];
+    const float cA = inv2 * sc_, cB = fmaf(d_, sc_, p.stat2[3 * kH + f]), cC = inv2 * rstd_, cD = d_ * rstd_;
+    double c0 = 0.0, c1 = 0.0;
+    float am0 = 0.0f, am1 = 0.0f;
     f32x16 dw[2] = {zero16(), zero16()};
     const int64_t ntiles = (p.rows + kDwTile - 1) / kDwTile;
     auto load_g = [&](int64_t row0, int rb, float (&g)[16]) {
@@ -582,8 +625,10 @@ __global__ __launch_bounds__(kDwThreads, 1) void angle_dw2_kernel(P p) {
             g[r] = __builtin_nontemporal_load(p.gz + row * kH + f);
         }
     };
-    // one row block: recompute the wave's 32 features, dx2, its share of dW2
-    auto block = [&](auto full_c, int64_t row0, int rb, const float (&g)[16]) {
+    // one row block: recompute the wave's 32 features, gz and the sums, its share of G
+    // (g: g_z of this row block on entry; refilled with the NEXT block's - of row0n / rbn - as soon as it has been consumed, so
+    // one set of registers is both the operand and the prefetch: a second set spilled 85-91 registers)
+    auto block = [&](auto full_c, int64_t row0, int rb, float (&g)[16], int64_t row0n, int rbn) {
         constexpr bool FULL = decltype(full_c)::value;
         f32x16 acc = zero16();
 #pragma unroll
@@ -592,59 +637,74 @@ __global__ __launch_bounds__(kDwThreads, 1) void angle_dw2_kernel(P p) {
             const f16x8 al = __builtin_bit_cast(f16x8, a_frag[afrag_idx(rb, s2, 1, lane)]);
             acc = mfma3(ah, al, w_hi[s2], w_lo[s2], acc);
         }
+        float gzv[16], s0 = 0.0f, s1 = 0.0f, mx = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float a = acc[r];
+            float gz = g[r] * dsilu_fast(fmaf(a, cA, cB)), xh = fmaf(a, cC, cD);
+            if constexpr (!FULL) {  // (multiplies, not branches)
+                const float m = row0 + n_row(rb, r, hh) < p.rows ? 1.0f : 0.0f;
+                gz *= m, xh *= m;
+            }
+            gzv[r] = gz;
+            s0 += gz;
+            s1 = fmaf(gz, xh, s1);
+            mx = fmaxf(mx, fabsf(gz));
+            am1 = fmaxf(am1, fabsf(xh));
+        }
+        load_g(row0n, rbn, g);
+        c0 += (double)s0;
+        c1 += (double)s1;
+        am0 = fmaxf(am0, mx);
+        // the tile's own scale (wave-uniform: the 32 x 32 tile is the wave's)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        const float sl = f16_scale(mx), inv_sl = 1.0f / sl;
         f16x8 d_hi[2], d_lo[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             float dx[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int r = 8 * s + i;
-                const float a = acc[r];
-                const float gz = g[r] * dsilu_fast(fmaf(a, k.A, k.B));
-                float o = fmaf(k.E, gz, fmaf(a, k.F, k.G));
-                if constexpr (!FULL) o *= row0 + n_row(rb, r, hh) < p.rows ? 1.0f : 0.0f;  // (a multiply, not a branch)
-                dx[i] = o;
-                gb += o;
-            }
+            for (int i = 0; i < 8; ++i) dx[i] = gzv[8 * s + i] * sl;
             split8s(dx, d_hi[s], d_lo[s]);
         }
 #pragma unroll
-        for (int jb = 0; jb < 2; ++jb)
+        for (int jb = 0; jb < 2; ++jb) {
+            f32x16 t = zero16();
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const f16x8 bh = __builtin_bit_cast(f16x8, b_frag[bfrag_idx(rb, jb, s, 0, lane)]);
                 const f16x8 bl = __builtin_bit_cast(f16x8, b_frag[bfrag_idx(rb, jb, s, 1, lane)]);
-                dw[jb] = mfma3(d_hi[s], d_lo[s], bh, bl, dw[jb]);
+                t = mfma3(d_hi[s], d_lo[s], bh, bl, t);
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dw[jb][r] = fmaf(t[r], inv_sl, dw[jb][r]);
+        }
     };
     float hv = load_h(p, (int64_t)blockIdx.x * kDwTile + 32 * w + il);
+    float g0[16];
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t row0 = tile * kDwTile;
         const bool full = row0 + kDwTile <= p.rows;  // uniform
-        float g0[16], g1[16];
-        load_g(row0, 0, g0);
-        // a1 of this wave's rows also as (lane = j, registers = rows), block of 32 features by block
+        if (tile == (int64_t)blockIdx.x) load_g(row0, 0, g0);  // (later tiles: requested by the previous tile's last block)
+        // a1 - mean of this wave's rows also as (lane = j, registers = rows), block of 32 features by block
         phase_a<true>(sh, g2, neg_k, hv, lane, w, a_frag, [&](int jb, const f16x8 (&k_hi)[2], const f16x8 (&k_lo)[2]) {
-            f32x16 th = mfma(k_hi[0], id0, zero16());
-            th = mfma(k_hi[1], id1, th);
-            f32x16 tl = mfma(k_lo[0], id0, zero16());
-            tl = mfma(k_lo[1], id1, tl);
+            const f16x8 id0 = identity_frag<true>(0, il, hh), id1 = identity_frag<true>(1, il, hh);  // (rebuilt: registers)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                b_frag[bfrag_idx(w, jb, s, 0, lane)] = __builtin_bit_cast(uint4, pack8(th, s));
-                b_frag[bfrag_idx(w, jb, s, 1, lane)] = __builtin_bit_cast(uint4, pack8(tl, s));
+            for (int hl = 0; hl < 2; ++hl) {  // high slices, then low slices: one 16-register tile at a time
+                f32x16 t = mfma(hl ? k_lo[0] : k_hi[0], id0, zero16());
+                t = mfma(hl ? k_lo[1] : k_hi[1], id1, t);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) b_frag[bfrag_idx(w, jb, s, hl, lane)] = __builtin_bit_cast(uint4, pack8(t, s));
+                __builtin_amdgcn_sched_barrier(0);
             }
-        });
+        }, centre);
         hv = load_h(p, row0 + (int64_t)gridDim.x * kDwTile + 32 * w + il);
         __syncthreads();
+        const int64_t row0_next = row0 + (int64_t)gridDim.x * kDwTile;
         auto row_blocks = [&](auto full_c) {
 #pragma unroll 1
-            for (int rb = 0; rb < 8; rb += 2) {  // g_z of the next row block in flight under the current one
-                load_g(row0, rb + 1, g1);
-                block(full_c, row0, rb, g0);
-                if (rb < 6) load_g(row0, rb + 2, g0);
-                block(full_c, row0, rb + 1, g1);
-            }
+            for (int rb = 0; rb < 8; ++rb) block(full_c, row0, rb, g0, rb < 7 ? row0 : row0_next, rb < 7 ? rb + 1 : 0);
         };
         if (full)
             row_blocks(std::true_type{});
@@ -652,15 +712,28 @@ __global__ __launch_bounds__(kDwThreads, 1) void angle_dw2_kernel(P p) {
             row_blocks(std::false_type{});
         __syncthreads();
     }
-    // dw[jb]: D[m = feature][n = j]: lane = j, register r = feature 32 w + 8 (r >> 2) + 4 hh + (r & 3)
+    // dw[jb]: D[m = feature][n = j]: lane = j, register r = feature 32 w + 8 (r >> 2) + 4 hh + (r & 3); G = dw / sa
     float* out = static_cast<float*>(p.partial) + (size_t)blockIdx.x * (kH * kE);
-    const float invd = 1.0f / (sd * sa);
+    const float inv_sa = 1.0f / sa;
 #pragma unroll
     for (int jb = 0; jb < 2; ++jb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) out[(32 * w + 8 * (r >> 2) + 4 * hh + (r & 3)) * kE + 32 * jb + il] = dw[jb][r] * invd;
-    gb += __shfl_xor(gb, 32, 64);
-    if (hh == 0) p.partial_b[(size_t)blockIdx.x * kH + f] = gb / sd;
+        for (int r = 0; r < 16; ++r) out[(32 * w + 8 * (r >> 2) + 4 * hh + (r & 3)) * kE + 32 * jb + il] = dw[jb][r] * inv_sa;
+    double* so = p.partial_d + (size_t)blockIdx.x * 2 * kH;
+    wave_double_pair_store(c0, c1, so + f, so + kH + f, hh);
+    block_amax_commit(am0, p.scal + kAmaxGz2);
+    block_amax_commit(am1, p.scal + kAmaxXh2);
+}
+
+// dW2 = gamma rstd (G - (c1 / n) rstd W2 Cov) in place on the reduced G;  db2 = 0
+__global__ __launch_bounds__(kE) void angle_dw2_fixup_kernel(P p, float* __restrict__ gW, float* __restrict__ gb) {
+    const int f = blockIdx.x, j = threadIdx.x;
+    const float* cov = p.scal + kCovA1;
+    float x = 0.0f;
+    for (int k = 0; k < kE; ++k) x = fmaf(p.W2[f * kE + k], cov[k * kE + j], x);
+    const float rstd = p.stat2[kH + f], sc = p.stat2[2 * kH + f], c1n = p.red2[kH + f] / (float)p.rows;
+    gW[f * kE + j] = sc * (gW[f * kE + j] - c1n * rstd * x);
+    if (j == 0) gb[f] = 0.0f;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -675,11 +748,12 @@ __global__ __launch_bounds__(kDwThreads, 1) void angle_dw2_kernel(P p) {
 //           operand of that product; a wave owns all 256 features of its rows, so da1 needs no reduction across waves)
 // Per-feature constants folded:  zl = acc A + B,  xhat = acc C + D,  sd dx2 = E gz + acc F + G (Dx2Const).
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int kRbGrid = 256, kRbThreadsMax = 768;
+constexpr int kRbGrid = 256, kRbThreadsMax = 512;
 // waves per workgroup (= per compute unit) by pass
-// (measured: the statistics pass 96-99 us with twelve waves, 101-107 with eight; the z pass 143 us with eight and its feature
-// loop unrolled, 151-158 with eight / twelve / sixteen waves and the loop rolled to fit them - occupancy is not its limit)
-constexpr int rb_threads(int mode) { return mode == 0 ? 768 : 512; }
+// (measured before the statistics pass also took a1's moments: that pass 96-99 us with twelve waves, 101-107 with eight; the z
+// pass 143 us with eight and its feature loop unrolled, 151-158 with eight / twelve / sixteen waves and the loop rolled to fit
+// them - occupancy is not their limit)
+constexpr int rb_threads(int mode) { return mode >= 0 ? 512 : 0; }
 __device__ __forceinline__ int w2a_idx(int fb, int s2, int hl, int lane) { return ((fb * 4 + s2) * 2 + hl) * 64 + lane; }
 __device__ __forceinline__ int w2b_idx(int fb, int s, int jb, int hl, int lane) { return ((((fb * 2 + s) * 2 + jb) * 2) + hl) * 64 + lane; }
 
@@ -690,6 +764,11 @@ __global__ __launch_bounds__(rb_threads(MODE), 1) void angle_rb_kernel(P p) {
     __shared__ uint4 w2a[8 * 4 * 2 * 64];                         // 64 KiB: lane = feature 32 fb + il, slots = permuted inputs
     __shared__ uint4 w2b[MODE == 3 ? 8 * 2 * 2 * 2 * 64 : 1];     // 64 KiB: lane = j 32 jb + il, slots = permuted features
     __shared__ float cst[MODE == 0 ? 1 : 5][kH];
+    // MODE 0 also takes the first two moments of a1 (sum and sum of outer products, 64 + 64 x 64 per workgroup): what the
+    // backward needs to get dW2 without knowing BatchNorm's backward sums first (angle_sums_dw2_kernel)
+    // (its cross-wave reduction at the end reuses w2a's 64 KiB: 4 x 50 x 64 floats)
+    __shared__ double col_sums[MODE == 0 ? kRbThreads / 64 : 1][MODE == 0 ? 2 * kH : 1];  // MODE 0: per wave, 4 KiB each
+    float (*mom_red)[50][64] = reinterpret_cast<float (*)[50][64]>(w2a);
     const float sa = f16_scale(p.scal[kBoundA1]), sw = f16_scale(p.scal[kAmaxW2]);
     const float sd = MODE == 3 ? f16_scale(p.scal[kBoundDx2]) : 1.0f;
     const float inv2 = 1.0f / (sa * sw), neg_k = -kLog2e / sa, g2 = -p.gamma * kLog2e;
@@ -726,13 +805,9 @@ __global__ __launch_bounds__(rb_threads(MODE), 1) void angle_rb_kernel(P p) {
     }
     if constexpr (MODE != 0) {
         for (int f = threadIdx.x; f < kH; f += kRbThreads) {
-            const float d = p.b2[f] - p.stat2[f], rstd = p.stat2[kH + f], sc = p.stat2[2 * kH + f];
+            const float d = p.b2[f] - p.stat2[f], sc = p.stat2[2 * kH + f];
             cst[0][f] = inv2 * sc;                           // A
             cst[1][f] = fmaf(d, sc, p.stat2[3 * kH + f]);    // B
-            if constexpr (MODE == 2) {
-                cst[2][f] = inv2 * rstd;  // C
-                cst[3][f] = d * rstd;     // D
-            }
             if constexpr (MODE == 3) {
                 Dx2Const k;
                 k.load(p, f, inv2, sd);
@@ -742,10 +817,19 @@ __global__ __launch_bounds__(rb_threads(MODE), 1) void angle_rb_kernel(P p) {
     }
     l1_setup(p, sh, kL1Act, sa);  // (ends with the barrier that also publishes w2a / w2b / cst)
     const int wave = blockIdx.x * (kRbThreads / 64) + w, nwaves = gridDim.x * (kRbThreads / 64);
-    double acc_a[8], acc_b[8];
-    float am0 = 0.0f, am1 = 0.0f;
+    float am0 = 0.0f;
+    if constexpr (MODE == 0)
+        for (int i = lane; i < 2 * kH; i += 64) col_sums[w][i] = 0.0;  // (a wave's own block: no barrier needed)
+    f32x16 m2[2][2];       // MODE 0: sum over rows of (sa a1)[j] (sa a1)[j'] - D[m = j][n = j']: lane = j' 32 jb2 + il, registers = j of block jb
+    float m1[2] = {0.0f, 0.0f};  // MODE 0: sum over rows of (sa a1)[j], j = 32 jb + il
+    f16x8 idp0, idp1;
+    if constexpr (MODE == 0) {
 #pragma unroll
-    for (int fb = 0; fb < 8; ++fb) acc_a[fb] = acc_b[fb] = 0.0;
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) m2[a][b] = zero16();
+        idp0 = identity_frag<true>(0, il, hh), idp1 = identity_frag<true>(1, il, hh);
+    }
     const float invd = MODE == 3 ? 1.0f / (sd * sw) : 1.0f;
     const int64_t nblk = (p.rows + 31) / 32;
     float hv_next = load_h(p, (int64_t)wave * 32 + il);
@@ -776,8 +860,37 @@ __global__ __launch_bounds__(rb_threads(MODE), 1) void angle_rb_kernel(P p) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) a[4 * q + e] = silu_scaled(fmaf(acc1[cb][8 * s + 4 * q + e], u[e], v[e]), neg_k);
                     }
+                    if constexpr (MODE == 0) {  // rows past the end must not reach the moments (their x2 is masked anyway)
+                        const float okf = row0 + il < p.rows ? 1.0f : 0.0f;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) a[i] *= okf;
+                    }
                     split8s(a, a_hi[2 * cb + s], a_lo[2 * cb + s]);
                 }
+        }
+        if constexpr (MODE == 0) {
+            // a1 turned to (lane = j, registers = rows) by identity products, then  m2 += a1^T a1,  m1 += column sums
+            f16x8 t_hi[2][2], t_lo[2][2];
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb) {
+                f32x16 th = mfma(a_hi[2 * jb], idp0, zero16());
+                th = mfma(a_hi[2 * jb + 1], idp1, th);
+                f32x16 tl = mfma(a_lo[2 * jb], idp0, zero16());
+                tl = mfma(a_lo[2 * jb + 1], idp1, tl);
+                float cs = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cs += th[r] + tl[r];
+                m1[jb] += cs;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) t_hi[jb][s] = pack8(th, s), t_lo[jb][s] = pack8(tl, s);
+            }
+#pragma unroll
+            for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+                for (int jb2 = jb; jb2 < 2; ++jb2)  // (symmetric: block (1, 0) is the transpose of (0, 1))
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) m2[jb][jb2] = mfma3(t_hi[jb][s], t_lo[jb][s], t_hi[jb2][s], t_lo[jb2][s], m2[jb][jb2]);
+            __builtin_amdgcn_sched_barrier(0);  // (keep the feature-block loop's operands out of this block's registers)
         }
         // ---- the eight feature blocks
         auto run = [&](auto full_c) {
@@ -786,16 +899,8 @@ __global__ __launch_bounds__(rb_threads(MODE), 1) void angle_rb_kernel(P p) {
             const float okf = FULL || row0 + il < p.rows ? 1.0f : 0.0f;  // MODE 3: this lane's row
             int64_t grow3 = row0 + il;
             grow3 = grow3 < p.rows ? grow3 : p.rows - 1;
-            // g_z of feature block fb: MODE 2: 16 rows of feature 32 fb + il;  MODE 3: 16 features of row row0 + il
+            // g_z of feature block fb (MODE 3): 16 features of row row0 + il
             auto load_g = [&](int fb, float (&g)[16]) {
-                if constexpr (MODE == 2) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        int64_t row = row0 + n_row(0, r, hh);
-                        row = FULL || row < p.rows ? row : p.rows - 1;
-                        g[r] = __builtin_nontemporal_load(p.gz + row * kH + 32 * fb + il);
-                    }
-                }
                 if constexpr (MODE == 3) {
                     const float* gp = p.gz + grow3 * kH + 32 * fb + 4 * hh;
 #pragma unroll
@@ -850,9 +955,8 @@ __global__ __launch_bounds__(rb_threads(MODE), 1) void angle_rb_kernel(P p) {
                         }
                 } else {
                     const int f = 32 * fb + il;
-                    float cA = 0.0f, cB = 0.0f, cC = 0.0f, cD = 0.0f;
+                    float cA = 0.0f, cB = 0.0f;
                     if constexpr (MODE != 0) cA = cst[0][f], cB = cst[1][f];
-                    if constexpr (MODE == 2) cC = cst[2][f], cD = cst[3][f];
                     float s = 0.0f, q = 0.0f;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -864,24 +968,24 @@ __global__ __launch_bounds__(rb_threads(MODE), 1) void angle_rb_kernel(P p) {
                             q = fmaf(a, a, q);
                         } else {
                             const float zl = fmaf(acc[r], cA, cB);
-                            if constexpr (MODE == 1) {
-                                const float zz = silu_scaled(zl, -kLog2e);
-                                if (FULL || row < p.rows) __builtin_nontemporal_store(zz, p.z + row * kH + f);
-                                am0 = fmaxf(am0, FULL ? fabsf(zz) : fabsf(zz) * m);
-                            } else {
-                                float gz = g[r] * dsilu_fast(zl), xh = fmaf(acc[r], cC, cD);
-                                if constexpr (!FULL) gz *= m, xh *= m;
-                                s += gz;
-                                q = fmaf(gz, xh, q);
-                                am0 = fmaxf(am0, fabsf(gz));
-                                am1 = fmaxf(am1, fabsf(xh));
-                            }
+                            const float zz = silu_scaled(zl, -kLog2e);
+                            if (FULL || row < p.rows) __builtin_nontemporal_store(zz, p.z + row * kH + f);
+                            am0 = fmaxf(am0, FULL ? fabsf(zz) : fabsf(zz) * m);
                         }
                     }
-                    if constexpr (MODE != 1) acc_a[fb] += (double)s, acc_b[fb] += (double)q;
+                    if constexpr (MODE == 0) {  // float64 column sums of this wave in its LDS block (the two halves hold
+                        s += __shfl_xor(s, 32, 64);  // different rows of feature f)
+                        q += __shfl_xor(q, 32, 64);
+                        if (hh == 0) col_sums[w][f] += (double)s, col_sums[w][kH + f] += (double)q;
+                    }
                 }
             };
             float g0[16], g1[16];
+            if constexpr (MODE == 0) {  // (nothing indexed by fb lives in registers: rolled, the moments need the registers)
+#pragma unroll 1
+                for (int fb = 0; fb < 8; ++fb) block(fb, g0);
+                return;
+            }
             load_g(0, g0);
 #pragma unroll
             for (int fb = 0; fb < 8; fb += 2) {  // g_z of the next feature block in flight under the current one
@@ -905,16 +1009,58 @@ __global__ __launch_bounds__(rb_threads(MODE), 1) void angle_rb_kernel(P p) {
         else
             run(std::false_type{});
     }
-    if constexpr (MODE == 0 || MODE == 2) {
+    if constexpr (MODE == 0) {
         double* out = static_cast<double*>(p.partial) + (size_t)wave * 2 * kH;
+        for (int i = lane; i < 2 * kH; i += 64) out[i] = col_sums[w][i];
+        // moments: the eight waves' 48 + 2 registers added through LDS in a fixed order (4..7 onto 0..3, 2..3 onto 0..1, 1 onto 0)
+        m1[0] += __shfl_xor(m1[0], 32, 64);  // (the two halves of a wave hold different rows of the same j)
+        m1[1] += __shfl_xor(m1[1], 32, 64);
+        auto put = [&](int slot) {
 #pragma unroll
-        for (int fb = 0; fb < 8; ++fb) wave_double_pair_store(acc_a[fb], acc_b[fb], out + 32 * fb + il, out + kH + 32 * fb + il, hh);
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = a; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mom_red[slot][(a + b) * 16 + r][lane] = m2[a][b][r];
+            mom_red[slot][48][lane] = m1[0];
+            mom_red[slot][49][lane] = m1[1];
+        };
+        auto take = [&](int slot) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = a; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) m2[a][b][r] += mom_red[slot][(a + b) * 16 + r][lane];
+            m1[0] += mom_red[slot][48][lane];
+            m1[1] += mom_red[slot][49][lane];
+        };
+        static_assert(rb_threads(0) == 512, "the reduction below is written for eight waves");
+        for (int span = 4; span >= 1; span >>= 1) {
+            __syncthreads();
+            if (w >= span && w < 2 * span) put(w - span);
+            __syncthreads();
+            if (w < span) take(w);
+        }
+        if (w == 0) {  // slab of this workgroup: [64] sums | [64][64] outer products (row = j, column = j')
+            float* mo = p.partial_b + (size_t)blockIdx.x * (kE + kE * kE);
+            if (hh == 0) {
+                mo[il] = m1[0];
+                mo[32 + il] = m1[1];
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = a; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int j = 32 * a + 8 * (r >> 2) + 4 * hh + (r & 3), j2 = 32 * b + il;
+                        mo[kE + j * kE + j2] = m2[a][b][r];
+                        if (a != b) mo[kE + j2 * kE + j] = m2[a][b][r];  // the transposed block
+                    }
+        }
     }
     if constexpr (MODE == 1) block_amax_commit(am0, p.z_amax);
-    if constexpr (MODE == 2) {
-        block_amax_commit(am0, p.scal + kAmaxGz2);
-        block_amax_commit(am1, p.scal + kAmaxXh2);
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1124,6 +1270,7 @@ bool shape_ok(const alignn_angle_args& a) {
 extern "C" {
 
 size_t alignn_angle_args_sizeof(void) { return sizeof(alignn_angle_args); }
+int alignn_angle_embed_scal_floats(void) { return kScalFloats; }
 
 int alignn_angle_embed_supported(int bins, int embed, int hidden) { return bins > 0 && bins < kBinsMax && embed == kE && hidden == kH; }
 
@@ -1133,7 +1280,7 @@ size_t alignn_angle_embed_workspace(int64_t rows, int bins, int backward) {
     const size_t sums = al256((size_t)kRbGrid * (kRbThreadsMax / 64) * 2 * kH * sizeof(double));  // one slab per wave
     if (!backward) {
         const size_t a = al256(waves * 2 * kE * sizeof(float));
-        return a > sums ? a : sums;
+        return (a > sums ? a : sums) + al256((size_t)(kRbGrid + 1) * (kE + kE * kE) * sizeof(float));  // + the moment slabs of a1
     }
     size_t total = al256((size_t)rows * kE * sizeof(float));                       // da1
     total += sums;                                                                  // sums (layer 2, then layer 1: waves * 2 * 64)
@@ -1153,7 +1300,13 @@ int alignn_angle_embed_fwd(const alignn_angle_args* a, alignn_stream_t stream) {
     hipStream_t st = (hipStream_t)stream;
     P p = make_params(*a);
     p.partial = a->workspace;
-    hipLaunchKernelGGL(angle_zero_kernel, dim3(1), dim3(kScalFloats), 0, st, a->scal, kScalFloats);
+    p.partial_b = reinterpret_cast<float*>(static_cast<char*>(a->workspace) + a->workspace_bytes -
+                                           al256((size_t)(kRbGrid + 1) * (kE + kE * kE) * sizeof(float)));  // moment slabs (at the end)
+    if (a->workspace_bytes != alignn_angle_embed_workspace(a->rows, a->bins, 0)) {  // (any larger block: keep the layout of the exact one)
+        p.partial_b = reinterpret_cast<float*>(static_cast<char*>(a->workspace) + alignn_angle_embed_workspace(a->rows, a->bins, 0) -
+                                               al256((size_t)(kRbGrid + 1) * (kE + kE * kE) * sizeof(float)));
+    }
+    hipLaunchKernelGGL(angle_zero_kernel, dim3(1), dim3(kScalHead), 0, st, a->scal, kScalHead);
     hipLaunchKernelGGL(angle_prep_kernel, dim3(17), dim3(kThreads), 0, st, p);
     const int g1 = grid_for(a->rows, 32 * (kThreads / 64)), g2 = grid_for(a->rows, kTile);
     hipLaunchKernelGGL(angle_l1_stats_kernel, dim3(g1), dim3(kThreads), 0, st, p);
@@ -1163,6 +1316,12 @@ int alignn_angle_embed_fwd(const alignn_angle_args* a, alignn_stream_t stream) {
     const int rb_slabs = grb * (rb_threads(0) / 64);
     (void)g2;
     hipLaunchKernelGGL(angle_rb_kernel<0>, dim3(grb), dim3(rb_threads(0)), 0, st, p);
+    {   // the workgroups' moment slabs -> one [64 + 64 x 64] block behind them -> mean and covariance
+        float* msum = p.partial_b + (size_t)kRbGrid * (kE + kE * kE);
+        const int rc = alignn_slab_sum(p.partial_b, grb, kE + kE * kE, msum, stream);
+        if (rc != 0) return rc;
+        hipLaunchKernelGGL(angle_moments_finalize_kernel, dim3(kE * kE / 256), dim3(256), 0, st, (const float*)msum, a->rows, a->scal);
+    }
     hipLaunchKernelGGL(angle_stat_finalize_kernel<true>, dim3(kH / 4), dim3(256), 0, st, (const void*)p.partial, rb_slabs, a->rows, kH,
                        a->l2.b, a->l2.gamma, a->l2.beta, a->eps, a->momentum, a->l2.rm, a->l2.rv, a->stat2, a->scal);
     hipLaunchKernelGGL(angle_rb_kernel<1>, dim3(rb_grid(a->rows, 1)), dim3(rb_threads(1)), 0, st, p);
@@ -1177,7 +1336,7 @@ int alignn_angle_embed_infer(const alignn_angle_args* a, alignn_stream_t stream)
         return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
     P p = make_params(*a);
-    hipLaunchKernelGGL(angle_zero_kernel, dim3(1), dim3(kScalFloats), 0, st, a->scal, kScalFloats);
+    hipLaunchKernelGGL(angle_zero_kernel, dim3(1), dim3(kScalHead), 0, st, a->scal, kScalHead);
     hipLaunchKernelGGL(angle_prep_kernel, dim3(17), dim3(kThreads), 0, st, p);
     ALIGNN_CHECK_LAUNCH();
     int rc;
@@ -1211,7 +1370,7 @@ int alignn_angle_embed_bwd(const alignn_angle_args* a, alignn_stream_t stream) {
     float* da1 = static_cast<float*>(take((size_t)a->rows * kE * sizeof(float)));
     double* sums = static_cast<double*>(take((size_t)kRbGrid * (kRbThreadsMax / 64) * 2 * kH * sizeof(double)));
     float* dw2 = static_cast<float*>(take((size_t)kGrid * kH * kE * sizeof(float)));
-    float* db2 = static_cast<float*>(take((size_t)kGrid * kH * sizeof(float)));
+    (void)take((size_t)kGrid * kH * sizeof(float));  // (db2 slabs of the earlier form: the layout stays)
     float* dw2f = static_cast<float*>(take((size_t)alignn_slab_fold_slabs() * kH * kE * sizeof(float)));
     const int ld1 = a->bins + 1;
     float* dw1 = static_cast<float*>(take(waves * kE * (size_t)ld1 * sizeof(float)));
@@ -1219,18 +1378,14 @@ int alignn_angle_embed_bwd(const alignn_angle_args* a, alignn_stream_t stream) {
     float* dw1s = static_cast<float*>(take((size_t)alignn_slab_fold_slabs() * kE * (size_t)ld1 * sizeof(float)));
     P p = make_params(*a);
     p.da1 = da1;
-    const int g1 = grid_for(a->rows, 32 * waves_per), g2 = grid_for(a->rows, kTile);
-    // layer 2
-    p.partial = sums;
-    const int grb = rb_grid(a->rows, 2);
-    hipLaunchKernelGGL(angle_rb_kernel<2>, dim3(grb), dim3(rb_threads(2)), 0, st, p);
-    hipLaunchKernelGGL(angle_red_finalize_kernel, dim3(kH / 4), dim3(256), 0, st, (const double*)sums, grb * (rb_threads(2) / 64), a->rows, kH, a->stat2,
-                       a->l2.red, a->scal, kAmaxGz2, kAmaxXh2, kBoundDx2);
+    const int g1 = grid_for(a->rows, 32 * waves_per);
+    // layer 2: BatchNorm-backward sums and G = sum gz (a1 - mean) in one pass over g_z, then dW2 from G once c1 is known
     p.partial = dw2;
-    p.partial_b = db2;
+    p.partial_d = sums;
     const int gdw = grid_for(a->rows, kDwTile) < kDwGrid ? grid_for(a->rows, kDwTile) : kDwGrid;
-    hipLaunchKernelGGL(angle_dw2_kernel, dim3(gdw), dim3(kDwThreads), 0, st, p);
-    hipLaunchKernelGGL(angle_rb_kernel<3>, dim3(rb_grid(a->rows, 3)), dim3(rb_threads(3)), 0, st, p);
+    hipLaunchKernelGGL(angle_sums_dw2_kernel, dim3(gdw), dim3(kDwThreads), 0, st, p);
+    hipLaunchKernelGGL(angle_red_finalize_kernel, dim3(kH / 4), dim3(256), 0, st, (const double*)sums, gdw, a->rows, kH, a->stat2,
+                       a->l2.red, a->scal, kAmaxGz2, kAmaxXh2, kBoundDx2);
     ALIGNN_CHECK_LAUNCH();
     int rc;
     if (gdw > alignn_slab_fold_slabs()) {
@@ -1238,7 +1393,9 @@ int alignn_angle_embed_bwd(const alignn_angle_args* a, alignn_stream_t stream) {
         if ((rc = alignn_slab_sum(dw2f, alignn_slab_fold_slabs(), kH * kE, a->l2.gW, stream)) != 0) return rc;
     } else if ((rc = alignn_slab_sum(dw2, gdw, kH * kE, a->l2.gW, stream)) != 0)
         return rc;
-    if ((rc = alignn_slab_sum(db2, gdw, kH, a->l2.gb, stream)) != 0) return rc;
+    hipLaunchKernelGGL(angle_dw2_fixup_kernel, dim3(kH), dim3(kE), 0, st, p, a->l2.gW, a->l2.gb);
+    hipLaunchKernelGGL(angle_rb_kernel<3>, dim3(rb_grid(a->rows, 3)), dim3(rb_threads(3)), 0, st, p);
+    ALIGNN_CHECK_LAUNCH();
     // layer 1
     p.partial = sums;
     hipLaunchKernelGGL(angle_l1_bwd_kernel<0>, dim3(g1), dim3(kThreads), 0, st, p);

@@ -390,7 +390,7 @@ void run_forward(Ctx& c, Tape& tp, float* out) {
         hipStream_t st = tp.angle_lane ? c.T : c.main;
         tp.a_stat1 = c.alloc((size_t)4 * d.angle1.out);
         tp.a_stat2 = c.alloc((size_t)4 * d.angle2.out);
-        tp.a_scal = c.alloc(128);
+        tp.a_scal = c.alloc((size_t)alignn_angle_embed_scal_floats());
         alignn_angle_args a = angle_args(c, tp);
         z.p = c.alloc((size_t)Tn * H);
         z.amax = c.track(Tn) ? c.new_amax() : nullptr;
@@ -786,7 +786,7 @@ void run_infer(Ctx& c, float* out) {
         Tape tp;
         tp.a_stat1 = c.alloc((size_t)4 * d.angle1.out);
         tp.a_stat2 = c.alloc((size_t)4 * d.angle2.out);
-        tp.a_scal = c.alloc(128);
+        tp.a_scal = c.alloc((size_t)alignn_angle_embed_scal_floats());
         alignn_angle_args a = angle_args(c, tp);
         z.p = c.alloc((size_t)Tn * d.H);
         z.amax = c.track(Tn) ? c.new_amax() : nullptr;

@@ -1304,7 +1304,7 @@ class AngleEmbedFn(torch.autograd.Function):
         def run():
             z = _empty(T, w2.shape[0], like=h)
             amax = new_amax(z) if _track(T) else None
-            stat1, stat2, scal = _empty(4 * w1.shape[0], like=h), _empty(4 * w2.shape[0], like=h), _empty(128, like=h)
+            stat1, stat2, scal = _empty(4 * w1.shape[0], like=h), _empty(4 * w2.shape[0], like=h), _empty(lib.alignn_angle_embed_scal_floats(), like=h)
             a = _angle_args(h, centers, gamma, (w1, b1, g1, be1), (w2, b2, g2, be2), ((rm1, rv1), (rm2, rv2)), stat1, stat2, scal)
             nbytes = lib.alignn_angle_embed_workspace(T, centers.numel(), 0)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=h.device)
@@ -1381,7 +1381,7 @@ def angle_embed_infer(h, rbf, l1, l2):
     def run():
         z = _empty(T, lin2.weight.shape[0], like=h)
         amax = new_amax(z) if _track(T) else None
-        stat1, stat2, scal = _empty(4 * lin1.weight.shape[0], like=h), _empty(4 * lin2.weight.shape[0], like=h), _empty(128, like=h)
+        stat1, stat2, scal = _empty(4 * lin1.weight.shape[0], like=h), _empty(4 * lin2.weight.shape[0], like=h), _empty(lib.alignn_angle_embed_scal_floats(), like=h)
         a = _angle_args(h, rbf.centers, rbf.gamma, (lin1.weight, lin1.bias, bn1.weight, bn1.bias),
                         (lin2.weight, lin2.bias, bn2.weight, bn2.bias),
                         ((bn1.running_mean, bn1.running_var), (bn2.running_mean, bn2.running_var)), stat1, stat2, scal)

@@ -660,7 +660,7 @@ typedef struct alignn_angle_args {
     alignn_mlp_params l1, l2;
     float eps, momentum;
     float *stat1, *stat2;          /* [4, 64], [4, 256]: mean | rstd | gamma rstd | beta */
-    float* scal;                   /* [128] */
+    float* scal;                   /* [alignn_angle_embed_scal_floats()] */
     float *z, *z_amax;             /* forward: [rows, 256] and (optional) the tracked max|z| */
     const float* gz;               /* backward: [rows, 256] */
     void* workspace;
@@ -669,6 +669,7 @@ typedef struct alignn_angle_args {
 int alignn_angle_embed_supported(int bins, int embed, int hidden);
 size_t alignn_angle_embed_workspace(int64_t rows, int bins, int backward);
 size_t alignn_angle_args_sizeof(void);
+int alignn_angle_embed_scal_floats(void);
 int alignn_angle_embed_fwd(const alignn_angle_args* args, alignn_stream_t stream);
 int alignn_angle_embed_bwd(const alignn_angle_args* args, alignn_stream_t stream);
 /* evaluation mode: BatchNorm as the affine map of l?.rm / l?.rv (not updated); writes z (and z_amax), uses stat1 / stat2 /
