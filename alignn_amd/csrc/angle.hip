@@ -241,15 +241,10 @@ __device__ __forceinline__ void l1_const4(const L1Shared& sh, int k, int cb, int
 // the cosine of row `row` (rows past the end read the last one; what they produce is masked)
 __device__ __forceinline__ float load_h(const P& p, int64_t row) { return p.h[row < p.rows ? row : p.rows - 1]; }
 
-// cross-lane sum / max over the 32 rows of a half (lanes il = 0..31 keep hh)
+// cross-lane sum over the 32 rows of a half (lanes il = 0..31 keep hh)
 __device__ __forceinline__ float half_sum(float v) {
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ float half_max(float v) {
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
 __device__ __forceinline__ void atomic_max_pos(float* p, float v) {
