@@ -519,8 +519,49 @@ def case_atomwise_extra_forces():
     print("extra features + forces: pred", out["pred"].reshape(-1), "|F|max", np.abs(out["forces"]).max(), "loss", loss.item())
 
 
+def case_bare_graph():
+    """``alignn_layers == 0``: the reference's forward takes a BARE graph, no line graph, no angle embedding used
+    (alignn/models/alignn.py:290-305); gcn layers only.  Train step + eval prediction."""
+    torch.manual_seed(71)
+    cfg = ALIGNNConfig(name="alignn", alignn_layers=0, gcn_layers=3, hidden_features=64, embedding_features=32)
+    model = ALIGNN(cfg)
+    with torch.no_grad():
+        for n_, p_ in model.named_parameters():
+            if ".bn_" in n_ or ".layer.1." in n_:
+                p_.add_(0.1 * torch.randn_like(p_))
+    raw = batch_raw([_one(n, 700 + i, "crystal", 92) for i, n in enumerate((7, 12, 5, 9))])
+    g, _lg, _lat = to_dgl(raw)
+    out = {"cfg.alignn_layers": 0, "cfg.gcn_layers": 3, "cfg.hidden_features": 64, "cfg.embedding_features": 32}
+    out.update(raw_arrays(raw))
+    out.update({"sd." + k: v.numpy().copy() for k, v in model.state_dict().items()})
+    target = torch.linspace(-1.0, 1.0, raw.batch_size)
+    out["target"] = target.numpy()
+    acts = {}
+    model.train()
+    handles = hook_layers(model, acts)
+    pred = model(g)  # the bare graph, alignn.py:305
+    loss = torch.nn.functional.l1_loss(pred, target)
+    loss.backward()
+    for h_ in handles:
+        h_.remove()
+    out["pred"] = pred.detach().numpy()
+    out["loss"] = loss.item()
+    out.update({"grad." + k: p.grad.numpy().copy() for k, p in model.named_parameters() if p.grad is not None})
+    out["nograd"] = np.array([k for k, p in model.named_parameters() if p.grad is None])
+    out.update({"sd_after." + k: v.numpy().copy() for k, v in model.state_dict().items() if "running" in k or "tracked" in k})
+    out.update({"act." + k: v for k, v in acts.items()})
+    model.eval()
+    with torch.no_grad():
+        out["pred_eval"] = model(g).numpy()
+    np.savez_compressed(os.path.join(OUT, "alignn_bare_graph.npz"), **out)
+    print("bare graph: pred", out["pred"], "loss", out["loss"], "nograd", len(out["nograd"]))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "bare":
+        case_bare_graph()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "extraff":
         case_atomwise_extra_forces()
         sys.exit(0)
@@ -549,3 +590,4 @@ if __name__ == "__main__":
     case_atomwise_position_branches()
     case_atomwise_cutoff_penalty()
     case_atomwise_extra_forces()
+    case_bare_graph()

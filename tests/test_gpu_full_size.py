@@ -195,6 +195,29 @@ def _hook(model):
     ("cfg5", lambda: make_batch(256, (9, 27), kind="molecule")),
 ])
 def test_alignn_training_step_at_baseline_size_vs_reference_class(tag, mk):
+    """Per-operator launch path: the forward hooks that collect the 22 convolution outputs make ``cmodel`` step aside."""
+    _golden_training_step(tag, mk, hooked=True)
+
+
+@pytest.mark.parametrize("tag,mk", [
+    ("cfg1", lambda: make_batch(8, 60)),
+    ("cfg2", lambda: make_batch(64, 60)),
+    ("cfg5", lambda: make_batch(256, (9, 27), kind="molecule")),
+])
+def test_headline_launch_path_directly_against_the_reference_goldens(tag, mk):
+    """The SAME goldens without hooks, i.e. through ``alignn_model_fwd`` / ``alignn_model_bwd`` - one C call each, what
+    ``bench.py`` times (until now the whole-model path met the reference's numbers only through its bit
+    equality with the per-operator path): prediction, loss, every parameter gradient (float32 and float64 goldens) and the
+    running statistics; no activations (one C call has no layer outputs to hook)."""
+    from alignn_amd import cmodel
+
+    for k in cmodel.STATS:
+        cmodel.STATS[k] = 0
+    _golden_training_step(tag, mk, hooked=False)
+    assert cmodel.STATS["fwd"] == 1 and cmodel.STATS["bwd"] == 1, cmodel.STATS
+
+
+def _golden_training_step(tag, mk, hooked):
     z = load_golden(f"full_{tag}.npz")
     raw = mk()
     assert np.array_equal(O.input_signature(raw), z["in.sig"]), "make_batch did not regenerate the golden's inputs"
@@ -202,21 +225,22 @@ def test_alignn_training_step_at_baseline_size_vs_reference_class(tag, mk):
     model = ALIGNN(ALIGNNConfig(name="alignn"))
     model.load_state_dict(O.perturbed_norm_state_dict(O.init_state_dict(seed=seed), seed=seed + 1))
     model = model.to(DEV).train()
-    acts = _hook(model)
+    acts = _hook(model) if hooked else None
     batch = GraphBatch.from_raw(raw, device=DEV)
     target = torch.from_numpy(z["target"]).to(DEV)
     pred = model(batch)
     loss = torch.nn.functional.l1_loss(pred, target)
     loss.backward()
     torch.cuda.synchronize()
-    report = [f"{tag}: N={raw.num_nodes} E={raw.num_edges} T={raw.num_triplets}"]
+    report = [f"{tag}{'' if hooked else ' (whole-model C path, no hooks)'}: N={raw.num_nodes} E={raw.num_edges} T={raw.num_triplets}"]
     try:
         p, pr = pred.detach().cpu().numpy(), z["pred"]
         e_n, e_e = normwise(p, pr), elementwise(p, pr, 0.01 * np.abs(pr).mean())
         report.append(f"pred: normwise {e_n:.2e}, elementwise {e_e:.2e}; loss {loss.item():.6f} vs {float(z['loss']):.6f}")
         assert e_n < 1e-4 and e_e < 1e-3
         assert abs(loss.item() - float(z["loss"])) < 1e-4 * max(1.0, abs(float(z["loss"])))
-        assert _check_acts(acts, z, batch, report) >= 20
+        if hooked:
+            assert _check_acts(acts, z, batch, report) >= 20
         assert _check_grads(model, z, 1e-3, report) > 80
         if "loss64" in z:  # cfg 1 and cfg 2 carry the reference's float64 backward
             assert _check_grads64(model, z, report) > 80
@@ -240,7 +264,7 @@ def test_alignn_training_step_at_baseline_size_vs_reference_class(tag, mk):
         report.append(f"pred vs float64 reference: ours {e64:.2e}, float32 reference {normwise(pr, z['pred64']):.2e}")
         assert e64 < 1e-4
     finally:
-        _emit(tag, report)
+        _emit(tag if hooked else tag + "_c_path", report)
 
 
 def test_alignn_ff_training_step_at_cfg4_size_vs_reference_class():

@@ -158,6 +158,70 @@ def test_dgl_like_tuple_input_and_edge_order_invariance():
     assert rel_err(a, b) < 1e-5
 
 
+def test_bare_graph_call_form_with_no_alignn_layers_against_the_reference_class():
+    """``alignn_layers == 0``: ``forward(g)`` on a BARE graph (alignn/models/alignn.py:290-305; SURVEY 8(b) names the call
+    form) - no line graph, the angle embedding unused.  Golden from the reference's own class (oracle/make_golden.py
+    ``case_bare_graph``): training step (prediction, loss, every gradient, running statistics, the three convolutions'
+    outputs) and the eval prediction; through the DGL-shaped container AND a GraphBatch without a line graph."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "shims"))
+    import dgl  # the shim: only used here as a DGL-shaped container
+
+    z = load_golden("alignn_bare_graph.npz")
+    raw = raw_from_golden(z)
+    g = dgl.graph((torch.from_numpy(raw.u), torch.from_numpy(raw.v)), num_nodes=raw.num_nodes)
+    g._bnn = torch.from_numpy(raw.batch_num_nodes)
+    g._bne = torch.from_numpy(raw.batch_num_edges)
+    g.ndata["atom_features"] = torch.from_numpy(raw.atom_features)
+    g.edata["r"] = torch.from_numpy(raw.r)
+    cfg = dict(alignn_layers=0, gcn_layers=3, hidden_features=64, embedding_features=32)
+    model = _model_from(state_dict_from_golden(z), **cfg).train()
+    acts = {}
+    for name, mod in model.named_modules():
+        if isinstance(mod, EdgeGatedGraphConv):
+            mod.register_forward_hook(lambda _m, _i, out, name=name: acts.__setitem__(name, out))
+    pred = model(g)  # the bare graph
+    assert pred.shape == (4,) and rel_err(pred, z["pred"]) < 1e-4
+    loss = torch.nn.functional.l1_loss(pred, torch.from_numpy(z["target"]).to(DEV))
+    assert abs(loss.item() - float(z["loss"])) < 1e-5
+    loss.backward()
+    topo = g._alignn_amd_topology[0]
+    inv = topo.g.inv.long()  # caller edge -> canonical row
+    for name, (x, y) in acts.items():
+        assert rel_err(x, z[f"act.{name}.x_out"]) < 1e-4, name
+        if y is not None:  # (the last layer's bond features are dead and not materialised)
+            assert rel_err(y[inv], z[f"act.{name}.y_out"]) < 1e-4, name
+    assert len(acts) == 3
+    nograd = set(z["nograd"].tolist())
+    assert len(nograd) == 10 and all(k.startswith("angle_embedding") for k in nograd)
+    gfloor = 1e-2 * max(float(np.abs(v).max()) for k, v in z.items() if k.startswith("grad."))
+    n = 0
+    for k, p in model.named_parameters():
+        if k in nograd:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+        else:
+            assert rel_err(p.grad, z["grad." + k], floor=gfloor) < 1e-3, k
+            n += 1
+    assert n > 30
+    sd = model.state_dict()
+    for k, v in z.items():
+        if k.startswith("sd_after."):
+            assert rel_err(sd[k[9:]], v, floor=1e-3) < 1e-4, k
+    # eval prediction with the statistics that step left behind (the golden's eval call follows its training step too);
+    # a tuple / list whose first entry is the graph is accepted as well when there are no ALIGNN layers
+    model.eval()
+    with torch.no_grad():
+        assert rel_err(model(g), z["pred_eval"]) < 1e-4
+        assert rel_err(model([g]), z["pred_eval"]) < 1e-4
+    # ... and a prebuilt GraphBatch that carries no line graph
+    fresh = _model_from(state_dict_from_golden(z), **cfg).train()
+    t = torch.from_numpy
+    b = GraphBatch.from_coo(t(raw.u), t(raw.v), raw.num_nodes, t(raw.batch_num_nodes), atom_features=t(raw.atom_features),
+                            r=t(raw.r), device=DEV)
+    assert b.lg is None and b.h is None
+    assert rel_err(fresh(b), z["pred"]) < 1e-4
+
+
 def test_single_graph_squeezes_to_scalar():
     raw = make_batch(1, 8, seed0=5)
     model = ALIGNN(ALIGNNConfig(name="alignn", alignn_layers=1, gcn_layers=1, hidden_features=32, embedding_features=16)).to(DEV).eval()

@@ -26,11 +26,19 @@ OUT = os.path.join(PROFILES, "pmc_traffic.json")
 # epilogue variant of the T-row f16x3 NT projection -> kernel names that implement it (persistent and one-tile forms)
 VARIANT_KERNELS = {
     "plain": ["gemm_nt_f16p_kernel<false>"],
+    # input gradient + residual addend WITHOUT the BatchNorm-backward sums (since round 4: the first line-graph convolution's
+    # edge input gradient - the fused angle embedding keeps no pre-activation to reduce against)
+    "addend": ["gemm_nt_x6_kernel<true, true, 2, false>", "gemm_nt_f16p_kernel<true>"],
     "gather": ["gemm_nt_f16p_gather_kernel<true>", "gemm_nt_f16p_gather_kernel<false>", "gemm_nt_x6_gather_kernel<2, true>"],
     "stats": ["gemm_nt_f16p_stats_kernel", "gemm_nt_x6_stats_kernel<2>"],
     "bnred": ["gemm_nt_f16p_bnred_kernel<false>", "gemm_nt_x6_bnred_kernel<false, 2>"],
     "bnred_addend": ["gemm_nt_f16p_bnred_kernel<true>", "gemm_nt_x6_bnred_kernel<true, 2>"],
 }
+# what ONE training step of the headline workload launches at T rows (bench.py `roofline.in_step` labels): every one of them
+# must have a PMC constant, or bench.py's `roofline.traffic` is null (tests/test_bench_launch.py, tests/test_gpu_cmodel.py)
+STEP_VARIANTS = ("gather", "bnred", "bnred_addend", "addend")
+# algorithmic H-wide fp32 rows moved per output row, by variant (bench.py uses the same table; gather: + 2 E/T for its tables)
+ROWS_MOVED = {"plain": 2, "addend": 3, "gather": 2.15, "stats": 2, "bnred": 3, "bnred_addend": 4}
 GATHER_LAUNCHES_PER_STEP = 4  # one per line-graph convolution of the default 4-layer model: fixes steps-per-profile
 T_ROW_MIN_WRITE_MIB = 600.0  # a T = 676 200 x 256 fp32 output is 660 MiB
 
