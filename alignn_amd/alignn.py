@@ -296,9 +296,10 @@ def _prepare_split_weights(model: nn.Module):
     projection and the edge gate of every convolution, the wide MLP layers) in one batched call - ``ops.WeightPrep``."""
     if not model.training and not torch.is_grad_enabled():
         return  # (inference: the per-weight path slices what it needs, nothing is reused by a backward)
-    prep = model.__dict__.get("_weight_prep")
+    mc = cmodel.model_cache(model)  # (not model.__dict__: the preparation holds weak references and device buffers)
+    prep = mc.get("weight_prep")
     if prep is None:
-        prep = model.__dict__["_weight_prep"] = ops.WeightPrep()
+        prep = mc["weight_prep"] = ops.WeightPrep()
     if prep.modules is None:  # (the module tree is walked once; the weights are looked up afresh every step)
         prep.modules = ([m for m in model.modules() if isinstance(m, EdgeGatedGraphConv)],
                         [m for m in model.modules() if isinstance(m, MLPLayer) and m.layer[0].weight.shape[0] >= 128
@@ -430,6 +431,8 @@ class ALIGNN(nn.Module):
             rbf, l1, l2 = self.angle_embedding[0], self.angle_embedding[1], self.angle_embedding[2]
             if (len(self.angle_embedding) == 3 and type(l1) is MLPLayer and type(l2) is MLPLayer
                     and not (self.angle_embedding._forward_hooks or self.angle_embedding._forward_pre_hooks)
+                    # (the fused passes run ONE mode for both layers: a block frozen with .eval() takes the chain of layers)
+                    and all(m.training == self.training for m in (l1, l2, l1.layer[1], l2.layer[1]))
                     and ops.angle_fused_applies(b.h, rbf, l1, l2, self.training)):
                 if self.training:
                     _bump(l1.layer[1], True)

@@ -19,6 +19,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import time
+import weakref
 
 import torch
 
@@ -72,6 +73,20 @@ class ModelDesc(C.Structure):
 
 _SIGS_DONE = False
 
+# Per-model state (the Binding with its ctypes blocks and helper streams, the cached module walks, the weight-image
+# preparation) lives HERE, keyed weakly by the model - not in ``model.__dict__``: ctypes structs with pointer fields and
+# stream objects cannot be pickled, and ``copy.deepcopy(model)`` / ``torch.save(model)`` / ``pickle.dumps(model)`` (EMA / SWA
+# copies, best-model snapshots) copy ``__dict__``.  Nothing in a value may hold the model strongly.
+_PER_MODEL = weakref.WeakKeyDictionary()
+
+
+def model_cache(model) -> dict:
+    c = _PER_MODEL.get(model)
+    if c is None:
+        c = _PER_MODEL[model] = {}
+    return c
+
+
 
 def _lib_model():
     global _SIGS_DONE
@@ -117,7 +132,7 @@ class Binding:
     def __init__(self, model):
         from .alignn import EdgeGatedGraphConv, MLPLayer
 
-        self.model = model
+        self._model = weakref.ref(model)
         cfg = model.config
         dev = model.fc.weight.device
         self.device = dev
@@ -127,6 +142,7 @@ class Binding:
         self.convs += list(model.gcn_layers)
         self.mlps = [model.atom_embedding, model.edge_embedding[1], model.edge_embedding[2], model.angle_embedding[1],
                      model.angle_embedding[2]]
+        self.norms = [mod.layer[1] for mod in self.mlps] + [bn for cv in self.convs for bn in (cv.bn_nodes, cv.bn_edges)]
         self.dead_edge = {2 * cfg.alignn_layers - 1, len(self.convs) - 1}  # convs whose edge output nobody reads
         assert all(isinstance(m, EdgeGatedGraphConv) for m in self.convs) and all(isinstance(m, MLPLayer) for m in self.mlps)
         self.desc = ModelDesc()
@@ -139,10 +155,16 @@ class Binding:
         self.desc_addr = C.addressof(self.desc)
         self.arena = None
         self.arena_busy = False
+        self.arena_gen = 0  # bumped by every forward that takes the shared block (a retained graph's second backward checks it)
+        self.arena_stream = None
         self.pinned = []
         self.plans = {}
         self.bump = None
         self._layout()
+
+    @property
+    def model(self):
+        return self._model()
 
     # ---- gradient layout: one flat buffer per backward, every parameter's gradient a view of it
     def _layout(self):
@@ -190,14 +212,20 @@ class Binding:
         self.no_grad = [id(p) in dead for p in self.params]
 
     def param_sig(self):
-        return tuple([p.data_ptr() for p in self.params])
+        """Where every parameter AND every BatchNorm buffer the C side writes lives (a reassigned ``running_mean`` /
+        ``running_var`` / ``num_batches_tracked`` must not leave the kernels a stale pointer)."""
+        sig = [p.data_ptr() for p in self.params]
+        for bn in self.norms:
+            sig += [bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr()]
+        return tuple(sig)
 
     # ---- parameter blocks (rebuilt when a parameter moved: .to(), FlatAdamW re-homing, load_state_dict(assign=True))
     def refresh(self):
         m, d = self.model, self.desc
-        prep = m.__dict__.get("_weight_prep")
+        mc = model_cache(m)
+        prep = mc.get("weight_prep")
         if prep is None:
-            prep = m.__dict__["_weight_prep"] = ops.WeightPrep()
+            prep = mc["weight_prep"] = ops.WeightPrep()
         psig = self.param_sig()
         if psig == self.psig and prep.sig is not None and prep.sig == self.prep_sig:
             return  # nothing moved since the blocks were filled (the fused buffers alias the parameters)
@@ -306,24 +334,35 @@ class Binding:
         return hit
 
     def take_arena(self, nbytes, capturing, need_backward):
-        """The workspace of one forward (+ backward).  Eagerly launched steps share ONE grow-only block (a fresh 15 GB
-        allocation per step would fragment the caching allocator when no two batches are alike); a forward that finds it
-        still held by an earlier one whose backward has not run, and every forward inside a stream capture (the block
-        then has to belong to the graph's own memory pool), allocates its own."""
+        """The workspace of one forward (+ backward) -> (block, owns the shared block, generation).  Eagerly launched steps
+        share ONE grow-only block (a fresh 15 GB allocation per step would fragment the caching allocator when no two
+        batches are alike); a forward that finds it still held by an earlier one whose backward has not run, and every
+        forward inside a stream capture whose block would have to grow (it then has to belong to the graph's own memory
+        pool), allocates its own.  A block a captured graph replays into is never leased to an eager step that needs a
+        backward (a replay between that forward and its backward would overwrite the tape): such steps get another shared
+        block.  Forwards issued from different streams are ordered on the block by a stream wait."""
         if self.arena_busy:
-            return torch.empty(nbytes, dtype=torch.uint8, device=self.device), False
+            return torch.empty(nbytes, dtype=torch.uint8, device=self.device), False, 0
+        if (not capturing) and need_backward and self.arena is not None and any(a is self.arena for a in self.pinned):
+            self.arena = None
         if self.arena is None or self.arena.numel() < nbytes:
             if capturing:  # (the shared block would have to be allocated outside the capture: let the graph's pool own one)
-                return torch.empty(nbytes, dtype=torch.uint8, device=self.device), False
+                return torch.empty(nbytes, dtype=torch.uint8, device=self.device), False, 0
             self.arena = None
             self.arena = torch.empty(int(nbytes * 1.05) + 4096, dtype=torch.uint8, device=self.device)
+            self.arena_stream = None
             STATS["arena_bytes"] = self.arena.numel()
         if capturing and not any(a is self.arena for a in self.pinned):
             # a captured graph replays into THIS block for as long as it lives: never free it (a later, larger batch
-            # allocates a new shared block; eager steps in between only overwrite what every replay recomputes)
+            # allocates a new shared block; eager forwards in between only overwrite what every replay recomputes)
             self.pinned.append(self.arena)
+        cur = torch.cuda.current_stream(self.device)
+        if self.arena_stream is not None and self.arena_stream != cur and not capturing:
+            cur.wait_stream(self.arena_stream)  # (the last user of the block ran on another stream)
+        self.arena_stream = cur
         self.arena_busy = need_backward
-        return self.arena, need_backward
+        self.arena_gen += 1
+        return self.arena, need_backward, self.arena_gen
 
 
 class _Lease:
@@ -342,15 +381,16 @@ class _Lease:
 
 
 def binding_of(model) -> Binding:
-    b = model.__dict__.get("_cmodel")
+    mc = model_cache(model)
+    b = mc.get("binding")
     if b is None or b.device != model.fc.weight.device:
-        b = model.__dict__["_cmodel"] = Binding(model)
+        b = mc["binding"] = Binding(model)
     return b
 
 
 class _ModelFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, bind, mb, keep, arena, arena_bytes, owns, *params):
+    def forward(ctx, bind, mb, keep, arena, arena_bytes, lease, *params):
         lib = _lib_model()
         out = torch.empty(mb.B, bind.desc.out_features, dtype=torch.float32, device=bind.device)
         t0 = time.perf_counter() if TIMING is not None else 0.0
@@ -359,7 +399,9 @@ class _ModelFn(torch.autograd.Function):
         if TIMING is not None:
             TIMING["cfwd"] = TIMING.get("cfwd", 0.0) + time.perf_counter() - t0
         STATS["fwd"] += 1
+        owns, gen = lease
         ctx.bind, ctx.mb, ctx.keep, ctx.arena, ctx.arena_bytes, ctx.lease = bind, mb, keep, arena, arena_bytes, _Lease(bind, owns)
+        ctx.shared_gen = gen if arena is bind.arena else 0  # (0: a block of its own - nobody else writes into it)
         ctx.sig = bind.sig
         return out
 
@@ -368,7 +410,14 @@ class _ModelFn(torch.autograd.Function):
         bind = ctx.bind
         lib = _lib_model()
         if ctx.arena is None:
-            raise RuntimeError("alignn_amd.cmodel: backward called twice on the same forward (its workspace is gone)")
+            raise RuntimeError("alignn_amd.cmodel: backward called twice on a forward that ran in a workspace of its own "
+                               "(released after the first backward)")
+        if ctx.shared_gen and (bind.arena is not ctx.arena or bind.arena_gen != ctx.shared_gen or
+                               (bind.arena_busy and not ctx.lease.owns)):
+            # loss.backward(retain_graph=True) followed by another backward is fine as long as the forward's tape is intact
+            # (the backward only reads it); once another forward has taken the shared workspace it is not
+            raise RuntimeError("alignn_amd.cmodel: backward through a forward whose workspace another forward has reused "
+                               "(retain_graph across model calls: set ALIGNN_AMD_CMODEL=0 for the per-operator path)")
         if bind.sig != ctx.sig:
             raise RuntimeError("alignn_amd.cmodel: the model's parameters moved between forward and backward")
         t_in = time.perf_counter() if TIMING is not None else 0.0
@@ -385,8 +434,9 @@ class _ModelFn(torch.autograd.Function):
         finally:
             if TIMING is not None:
                 TIMING["cbwd"] = TIMING.get("cbwd", 0.0) + time.perf_counter() - t0
-            ctx.lease.release()
-            ctx.arena = None
+            ctx.lease.release()  # (the next forward may take the block; a second backward of THIS graph re-checks above)
+            if not ctx.shared_gen:
+                ctx.arena = None  # a block of its own (up to 20 GB): do not keep it for as long as the graph object lives
         STATS["bwd"] += 1
         pieces = gflat.split_with_sizes(bind.sizes)
         grads = []
@@ -421,36 +471,40 @@ def _structure_ok(model, b, need_grad) -> bool:
             return False
     if type(model).__name__ != "ALIGNN":
         return False
-    ok = model.__dict__.get("_cmodel_static_ok")
+    mc = model_cache(model)
+    ok = mc.get("static_ok")
     if ok is None:
         from .alignn import EdgeGatedGraphConv, MLPLayer
 
         ok = all(getattr(m, "_norm", "batch") == "batch" and (not isinstance(m, EdgeGatedGraphConv) or m.residual)
                  for m in model.modules() if isinstance(m, (EdgeGatedGraphConv, MLPLayer)))
-        model.__dict__["_cmodel_static_ok"] = ok
+        mc["static_ok"] = ok
     if not ok:
         return False
     # hooks on a layer (feature extraction, the activation checks of tests/test_gpu_full_size.py, DDP-style wrappers of a
     # submodule) fire from the layers' own forward: the per-operator path calls those, one C call for the whole model does not
-    subs = model.__dict__.get("_cmodel_submodules")
+    subs = mc.get("submodules")
     if subs is None:
-        subs = model.__dict__["_cmodel_submodules"] = [m for m in model.modules() if m is not model]
+        subs = mc["submodules"] = [m for m in model.modules() if m is not model]
     import torch.nn.modules.module as _tm
 
     if _tm._global_forward_hooks or _tm._global_forward_pre_hooks or _tm._global_backward_hooks:
         return False
+    mode = model.training
     for m in subs:
         if m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or m._backward_pre_hooks:
             return False
-    slots = model.__dict__.get("_cmodel_slots")
+        # a model in train() with some blocks in eval() (frozen-statistics fine-tuning): every layer of the per-operator path
+        # follows ITS OWN flag (batch statistics vs running statistics, which counters are bumped); one C call runs one mode
+        if m.training != mode:
+            return False
+    slots = mc.get("slots")
     if slots is None:  # [(module._parameters, name, parameter)]: a replaced Parameter object is noticed without walking the tree
-        slots = model.__dict__["_cmodel_slots"] = [(mod._parameters, name, p) for mod in model.modules()
-                                                   for name, p in mod._parameters.items() if p is not None]
+        slots = mc["slots"] = [(mod._parameters, name, p) for mod in model.modules()
+                               for name, p in mod._parameters.items() if p is not None]
     for d, name, p in slots:
         if d.get(name) is not p:
-            model.__dict__.pop("_cmodel_slots", None)
-            model.__dict__.pop("_cmodel_submodules", None)
-            model.__dict__.pop("_cmodel", None)
+            mc.clear()
             return _structure_ok(model, b, need_grad)
         if need_grad and not p.requires_grad:
             return False
@@ -476,10 +530,10 @@ def forward(model, b):
             return None
         need_bwd = torch.is_grad_enabled()
         nbytes = total if need_bwd else fwd_bytes
-        arena, owns = bind.take_arena(nbytes, capturing, need_bwd)
+        arena, owns, gen = bind.take_arena(nbytes, capturing, need_bwd)
         ops.new_weight_generation()
         try:
-            return _ModelFn.apply(bind, mb, (b, af, r, h), arena, nbytes, owns, *bind.params)
+            return _ModelFn.apply(bind, mb, (b, af, r, h), arena, nbytes, (owns, gen), *bind.params)
         except BaseException:
             if owns:  # (the forward raised before a lease existed: hand the shared workspace back)
                 bind.arena_busy = False
@@ -505,7 +559,7 @@ def infer(model, b):
             nbytes = bind.plans[key] = lib.alignn_model_infer_workspace(bind.desc_addr, C.addressof(mb))
         if not nbytes:
             return None
-        arena, _owns = bind.take_arena(nbytes, capturing, False)
+        arena, _owns, _gen = bind.take_arena(nbytes, capturing, False)
         out = torch.empty(mb.B, bind.desc.out_features, dtype=torch.float32, device=bind.device)
         _lib.check(lib.alignn_model_infer(bind.desc_addr, C.addressof(mb), arena.data_ptr(), nbytes, out.data_ptr(), _lib.stream()),
                    "model_infer")

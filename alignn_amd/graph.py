@@ -184,10 +184,17 @@ def csr_and_line_graph(u: torch.Tensor, v: torch.Tensor, n_nodes: int, r: Option
 
     lib = _lib.load()
     u32, v32 = u.to(torch.int32).contiguous(), v.to(torch.int32).contiguous()
-    din = torch.bincount(v32, minlength=n_nodes)
-    din_u = din[u32.long()]
+    # in-degrees by a scatter-add over CLAMPED endpoints (no hidden host read as in torch.bincount, no device-side assert on a
+    # bad index); the range of the endpoints travels in the same host read as T and is checked right after it - the radix
+    # sorts below use bits_for(N) key bits and would silently build a corrupted CSR from an endpoint outside [0, N)
+    uc, vc = u32.long().clamp(0, n_nodes - 1), v32.long().clamp(0, n_nodes - 1)
+    din = torch.zeros(n_nodes, dtype=torch.int64, device=dev).scatter_add_(0, vc, torch.ones_like(vc))
+    din_u = din[uc]
     # the one host read: T = sum over bonds e2 of (in-degree of src(e2)) - [e2 is a self image]; the dense-block bound
-    T, max_in = torch.stack([din_u.sum() - (u32 == v32).sum(), din_u.max()]).tolist()
+    T, max_in, lo, hi = torch.stack([din_u.sum() - (u32 == v32).sum(), din_u.max(), torch.minimum(u32.min(), v32.min()).long(),
+                                     torch.maximum(u32.max(), v32.max()).long()]).tolist()
+    if lo < 0 or hi >= n_nodes:
+        raise ValueError(f"edge endpoint out of range: ids span [{int(lo)}, {int(hi)}] but the graph has {int(n_nodes)} nodes")
     T, N = int(T), int(n_nodes)
     if lg_edges is not None and (T == 0 or int(lg_edges[0].numel()) != T or int(lg_edges[1].numel()) != T):
         return None

@@ -180,12 +180,18 @@ def _stage_hip(packed: PackedBatch, dev, d, view, feature_table, cosines):
     out = torch.empty(off + ws_bytes, dtype=torch.uint8, device=dev)
     base = out.data_ptr()
     a = {name: (out[offs[name]:offs[name] + n * (8 if dt is _I64 else 4)].view(dt) if n else None) for name, dt, n in want}
-    _lib.check(lib.alignn_stage_batch(
+    if T == 0:  # (no bond pair shares an atom: empty arrays, as graph.csr_and_line_graph gives - never None inside a CSRGraph)
+        for name, dt, _n in want:
+            if a[name] is None and name != "h":
+                a[name] = torch.empty(0, dtype=dt, device=dev)
+    with _lib.device_guard(out):  # (_lib.stream() is the CURRENT device's stream: stage(packed, "cuda:1") while cuda:0 is current)
+        rc = lib.alignn_stage_batch(
         view("u").data_ptr(), view("v").data_ptr(), view("r").data_ptr(), N, E, T,
         base + offs["seg_ptr"], base + offs["src"], base + offs["dst"], base + offs["out_ptr"], base + offs["out_slot"],
         base + offs["perm"], base + offs["inv"], base + offs["r"], base + offs["lg_seg_ptr"], base + offs["lg_src"],
         base + offs["lg_dst"], base + offs["lg_out_ptr"], base + offs["lg_out_slot"], base + offs["seg_rank"],
-        base + offs["ident"], (base + offs["h"]) if cosines else None, None, base + off, ws_bytes, _lib.stream()), "stage_batch")
+        base + offs["ident"], (base + offs["h"]) if cosines else None, None, base + off, ws_bytes, _lib.stream())
+    _lib.check(rc, "stage_batch")
     from .graph import CSRGraph
 
     g = CSRGraph(n_nodes=N, n_edges=E, seg_ptr=a["seg_ptr"], seg_node=None, src=a["src"], dst=a["dst"], out_ptr=a["out_ptr"],

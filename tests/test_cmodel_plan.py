@@ -91,3 +91,26 @@ def test_argument_checks():
     assert _plan(d, mb)[0] == 1
     d.alignn_layers = 0
     assert _plan(d, _batch(100, 1000, 9000, 2))[0] == 1
+
+
+def test_per_model_state_is_not_part_of_the_module():
+    """ctypes blocks with pointer fields cannot be pickled or deep-copied, so nothing of the C path's per-model
+    state may sit in ``model.__dict__`` (``copy.deepcopy(model)`` for EMA / SWA copies and best-model snapshots walks it).
+    The state lives in a weak dictionary keyed by the model and dies with it."""
+    import copy
+    import gc
+    import pickle
+
+    from alignn_amd import ALIGNN, ALIGNNConfig
+
+    with pytest.raises(ValueError):
+        pickle.dumps(cmodel.ModelDesc())  # (what used to sit in model.__dict__['_cmodel'])
+    m = ALIGNN(ALIGNNConfig(name="alignn", alignn_layers=1, gcn_layers=1, hidden_features=32, embedding_features=16, link="log"))
+    cmodel.model_cache(m)["binding"] = cmodel.ModelDesc()
+    twin = copy.deepcopy(m)
+    assert pickle.loads(pickle.dumps(m)).fc.weight.shape == m.fc.weight.shape
+    assert "binding" in cmodel.model_cache(m) and cmodel.model_cache(twin) == {}
+    n = len(cmodel._PER_MODEL)
+    del m, twin
+    gc.collect()
+    assert len(cmodel._PER_MODEL) == n - 2

@@ -265,3 +265,148 @@ def test_inference_in_one_c_call_equals_the_per_operator_eval_path():
     n = cmodel.STATS.get("infer", 0)
     model(batch)
     assert cmodel.STATS.get("infer", 0) == n
+
+
+def test_model_copies_and_snapshots_after_a_c_path_step():
+    """the binding (ctypes blocks with pointers, stream objects) must not live in ``model.__dict__`` -
+    ``copy.deepcopy`` (EMA / SWA copies, best-model snapshots) and ``torch.save(model)`` of a model that has trained through
+    the C path work, and the copy trains on, bit-identically to the original."""
+    import io
+
+    raw = make_batch(8, 30, seed0=13)
+    batch = GraphBatch.from_raw(raw, device=DEV)
+    target = torch.randn(8, generator=torch.Generator().manual_seed(3)).to(DEV)
+    torch.manual_seed(0)
+    m = ALIGNN(ALIGNNConfig(name="alignn", link="log")).to(DEV).train()  # (link="log": torch.exp - the identity link is a lambda,
+    for k in cmodel.STATS:                                                #  which no pickle takes, in the reference either)
+        cmodel.STATS[k] = 0
+    _steps(m, [batch], [target], True)
+    assert cmodel.STATS["fwd"] == 1
+    assert not any(k.startswith("_cmodel") or k == "_weight_prep" for k in m.__dict__)
+    twin = copy.deepcopy(m)
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    loaded = torch.load(buf, weights_only=False).to(DEV)
+    a = _steps(m, [batch] * 2, [target] * 2, True)
+    b = _steps(twin, [batch] * 2, [target] * 2, True)
+    c = _steps(loaded, [batch] * 2, [target] * 2, True)
+    _same(a, b, "deepcopy")
+    _same(a, c, "torch.save / load")
+    assert cmodel.STATS["fwd"] == 7
+
+
+def test_blocks_frozen_with_eval_take_the_per_operator_path_and_keep_their_statistics():
+    """a model in train() with some blocks in eval() (frozen-statistics fine-tuning) must not run batch statistics
+    everywhere: every layer follows ITS OWN flag - the whole-model call steps aside, the frozen blocks' running statistics
+    and counters stay untouched, and the result equals the per-operator path's."""
+    raw = make_batch(8, 30, seed0=14)
+    batch = GraphBatch.from_raw(raw, device=DEV)
+    target = torch.randn(8, generator=torch.Generator().manual_seed(3)).to(DEV)
+
+    def run(use_c):
+        m = _mk(6)
+        _steps(m, [batch], [target], use_c)  # statistics that are not the initial 0 / 1
+        m.alignn_layers[1].eval()
+        m.angle_embedding[1].eval()
+        m.gcn_layers[0].bn_nodes.eval()
+        frozen = {k: v.clone() for k, v in m.state_dict().items()
+                  if k.startswith(("alignn_layers.1.", "angle_embedding.1.", "gcn_layers.0.bn_nodes.")) and ("running" in k or "tracked" in k)}
+        for k in cmodel.STATS:
+            cmodel.STATS[k] = 0
+        out = _steps(m, [batch] * 2, [target] * 2, use_c)
+        assert cmodel.STATS["fwd"] == 0
+        sd = m.state_dict()
+        assert frozen and all(torch.equal(sd[k], v) for k, v in frozen.items())
+        assert int(sd["alignn_layers.0.node_update.bn_nodes.num_batches_tracked"]) == 3
+        return out
+
+    _same(run(True), run(False), "partially frozen")
+
+
+def test_a_reassigned_batchnorm_buffer_is_followed():
+    """``running_mean`` / ``running_var`` replaced by new tensors (a checkpoint loader that assigns, a reset):
+    the C description must be rebuilt - the statistics land in the NEW buffers."""
+    raw = make_batch(8, 30, seed0=15)
+    batch = GraphBatch.from_raw(raw, device=DEV)
+    target = torch.randn(8, generator=torch.Generator().manual_seed(3)).to(DEV)
+
+    def run(use_c):
+        m = _mk(7)
+        _steps(m, [batch], [target], use_c)
+        for bn in (m.atom_embedding.layer[1], m.gcn_layers[1].bn_edges):
+            bn.running_mean = torch.zeros_like(bn.running_mean)
+            bn.running_var = torch.ones_like(bn.running_var)
+            bn.num_batches_tracked = torch.zeros_like(bn.num_batches_tracked)
+        return _steps(m, [batch] * 2, [target] * 2, use_c)
+
+    a, b = run(True), run(False)
+    _same(a, b, "reassigned buffers")
+    assert int(a["s.atom_embedding.layer.1.num_batches_tracked"]) == 2
+    assert float(a["s.atom_embedding.layer.1.running_mean"].abs().max()) > 0
+
+
+def test_second_backward_of_a_retained_graph():
+    """``loss.backward(retain_graph=True)`` followed by another backward works while the forward's tape is intact
+    (gradients accumulate: twice the single backward's), and raises - instead of reading another forward's tape - once a
+    later forward has taken the shared workspace."""
+    raw = make_batch(8, 30, seed0=16)
+    batch = GraphBatch.from_raw(raw, device=DEV)
+    target = torch.randn(8, generator=torch.Generator().manual_seed(3)).to(DEV)
+    m = _mk(8)
+    loss = torch.nn.functional.l1_loss(m(batch), target)
+    loss.backward(retain_graph=True)
+    once = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    loss.backward(retain_graph=True)
+    torch.cuda.synchronize()
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            assert torch.equal(p.grad, once[k] + once[k]), k
+    torch.nn.functional.l1_loss(m(batch), target)  # another forward reuses the shared workspace
+    with pytest.raises(RuntimeError, match="workspace"):
+        loss.backward()
+
+
+def test_out_of_range_endpoints_are_rejected_before_the_sorts():
+    """the device builder sorts on bits_for(N) key bits - an endpoint outside [0, N) must raise, not build a
+    corrupted CSR silently."""
+    from alignn_amd import graph
+
+    u = torch.tensor([0, 1, 2, 3], device=DEV)
+    v = torch.tensor([1, 0, 3, 2], device=DEV)
+    graph.csr_and_line_graph(u, v, 4)
+    with pytest.raises(ValueError, match="out of range"):
+        graph.csr_and_line_graph(u, torch.tensor([1, 0, 3, 4], device=DEV), 4)
+    with pytest.raises(ValueError, match="out of range"):
+        graph.csr_and_line_graph(torch.tensor([0, -1, 2, 3], device=DEV), v, 4)
+
+
+def test_every_timed_projection_variant_has_a_pmc_constant():
+    """bench.py's ``roofline.traffic`` is the PMC figure of the variants its in-step timer SEES; a variant
+    that is timed but has no constant in profiles/pmc_traffic.json makes the driver's line carry ``traffic: null``.  One
+    training step of the headline batch under the timer: every label it produces has a constant."""
+    import json
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pmc = json.load(open(os.path.join(root, "profiles", "pmc_traffic.json")))
+    raw = make_batch(64, 60)
+    assert raw.num_triplets == pmc["triplets"]
+    batch = GraphBatch.from_raw(raw, device=DEV)
+    target = torch.randn(64, generator=torch.Generator().manual_seed(1)).to(DEV)
+    m = _mk()
+    ops.KERNEL_TIMER = {"min_rows": raw.num_triplets, "events": []}
+    try:
+        torch.nn.functional.l1_loss(m(batch), target).backward()
+        torch.cuda.synchronize()
+        labels = {lab for (lab, n_, k_, _e0, _e1) in ops.KERNEL_TIMER["events"] if n_ == 256 and k_ == 256}
+    finally:
+        ops.KERNEL_TIMER = None
+    assert labels and labels <= set(pmc["variants"]), (labels, sorted(pmc["variants"]))
+    sys_path_tools = os.path.join(root, "tools")
+    import sys
+
+    sys.path.insert(0, sys_path_tools)
+    import pmc_constants
+
+    assert labels == set(pmc_constants.STEP_VARIANTS), labels
