@@ -129,11 +129,14 @@ class MLPLayer(nn.Module):
         lin, bn = self.layer[0], self.layer[1]
         if torch_path.wanted(x, lin.weight):
             return torch_path.mlp_layer(self, x)
-        _bump(bn, self.training)
+        # batch statistics or running statistics: the NORM module's own flag decides, as in the reference's nn.Sequential
+        # (``for m in model.modules(): if isinstance(m, BatchNorm1d): m.eval()`` freezes the statistics of a training model)
+        training = bn.training
+        _bump(bn, training)
         with _lib.device_guard(x):
             return ops.MLPLayerFn.apply(
                 x, lin.weight, lin.bias, bn.weight, bn.bias, getattr(bn, "running_mean", None),
-                getattr(bn, "running_var", None), self.training, self._norm,
+                getattr(bn, "running_var", None), training, self._norm,
             )
 
 
@@ -258,7 +261,13 @@ class EdgeGatedGraphConv(nn.Module):
         y_in = edge_feats if canonical else ops.main_reads(edge_feats)[csr.perm]
         # fused node projection: P = x [W_sg; W_dg; W_du; W_su]^T -> A | Bd | Bh | Ux
         wcat, bcat = self._fused_node_projection()
-        if (self._norm == "batch" and not self.training and ops.INFER_FUSED
+        # the norm modules' own flags decide between batch and running statistics (see MLPLayer.forward); the kernels carry
+        # ONE mode per convolution
+        training = self.bn_nodes.training
+        if self._norm == "batch" and self.bn_edges.training != training:
+            raise NotImplementedError("EdgeGatedGraphConv: bn_nodes and bn_edges in different modes (one .eval(), one .train()) "
+                                      "- the fused convolution runs one mode; freeze both or neither")
+        if (self._norm == "batch" and not training and ops.INFER_FUSED
                 and not (torch.is_grad_enabled() and (node_feats.requires_grad or edge_feats.requires_grad
                                                       or self._own_params_need_grad()))):
             # (with grad enabled the shortcut is taken only if NOTHING here can receive a gradient: frozen upstream
@@ -273,8 +282,8 @@ class EdgeGatedGraphConv(nn.Module):
             if not canonical and y is not None:
                 y = ops.main_reads(y)[csr.inv]
             return x, y
-        _bump(self.bn_nodes, self.training)
-        _bump(self.bn_edges, self.training)
+        _bump(self.bn_nodes, training)
+        _bump(self.bn_edges, training)
         x, y = ops.EdgeGatedConvFn.apply(
             csr, node_feats, y_in, wcat, bcat,
             self.src_gate.weight, self.dst_gate.weight, self.dst_update.weight, self.src_update.weight,
@@ -284,7 +293,7 @@ class EdgeGatedGraphConv(nn.Module):
             getattr(self.bn_nodes, "running_var", None),
             self.bn_edges.weight, self.bn_edges.bias, getattr(self.bn_edges, "running_mean", None),
             getattr(self.bn_edges, "running_var", None),
-            self.training, self.residual, need_edge_out, self._norm,
+            training, self.residual, need_edge_out, self._norm,
         )
         if not canonical and y is not None:
             y = ops.main_reads(y)[csr.inv]

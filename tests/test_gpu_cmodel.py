@@ -309,9 +309,10 @@ def test_blocks_frozen_with_eval_take_the_per_operator_path_and_keep_their_stati
         _steps(m, [batch], [target], use_c)  # statistics that are not the initial 0 / 1
         m.alignn_layers[1].eval()
         m.angle_embedding[1].eval()
-        m.gcn_layers[0].bn_nodes.eval()
+        m.gcn_layers[0].bn_nodes.eval()  # (the BatchNorm-only freeze: the norm modules' own flags decide, as in the reference)
+        m.gcn_layers[0].bn_edges.eval()
         frozen = {k: v.clone() for k, v in m.state_dict().items()
-                  if k.startswith(("alignn_layers.1.", "angle_embedding.1.", "gcn_layers.0.bn_nodes.")) and ("running" in k or "tracked" in k)}
+                  if k.startswith(("alignn_layers.1.", "angle_embedding.1.", "gcn_layers.0.bn_")) and ("running" in k or "tracked" in k)}
         for k in cmodel.STATS:
             cmodel.STATS[k] = 0
         out = _steps(m, [batch] * 2, [target] * 2, use_c)
@@ -322,6 +323,10 @@ def test_blocks_frozen_with_eval_take_the_per_operator_path_and_keep_their_stati
         return out
 
     _same(run(True), run(False), "partially frozen")
+    m = _mk(6)
+    m.gcn_layers[1].bn_edges.eval()  # the two norms of ONE convolution in different modes: refused loudly, not guessed
+    with pytest.raises(NotImplementedError, match="different modes"):
+        m(batch)
 
 
 def test_a_reassigned_batchnorm_buffer_is_followed():
