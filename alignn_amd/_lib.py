@@ -127,6 +127,23 @@ SIGNATURES = {
     "alignn_model_infer_workspace": (_sz, [_p, _p]),
     "alignn_model_infer": (_i32, [_p, _p, _p, _sz, _p, _p]),
     "alignn_knn_emit": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i64, _p, _p, _p, _p, _p, _p, _p, _p]),
+    # whole-model force field (csrc/model.hip) and the small kernels of its head (csrc/ff.hip)
+    "alignn_ff_desc_sizeof": (_sz, []),
+    "alignn_ff_plan": (_i32, [_p, _p, _p, _p, _p]),
+    "alignn_ff_eval": (_i32, [_p, _p, _p, _p, _sz, _p, _p, _p, _p]),
+    "alignn_ff_grad": (_i32, [_p, _p, _p, _p, _sz, _p, _p, _p, _p, _p, _i64, _p]),
+    "alignn_pair_force_reduce": (_i32, [_p, _f32, _p, _p, _p, _i32, _p, _i64, _p]),
+    "alignn_virial_stress": (_i32, [_p, _p, _f32, _p, _p, _p, _f32, _p, _i32, _p]),
+    "alignn_ff_energy": (_i32, [_p, _p, _p, _i32, _i64, _i32, _i32, _f32, _f32, _p, _p, _p]),
+    "alignn_ff_penalty_bwd": (_i32, [_p, _p, _i64, _i32, _f32, _f32, _p]),
+    "alignn_ff_pair_weights": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _f32, _i32, _i32, _i64, _p, _p, _p]),
+    "alignn_ff_tangent_geometry": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _p]),
+    "alignn_rbf_tangent": (_i32, [_p, _p, _p, _f32, _p, _i64, _i32, _p]),
+    "alignn_bond_cosine_tangent": (_i32, [_p, _p, _p, _p, _p, _i64, _p]),
+    "alignn_ff_readout_seed": (_i32, [_p, _f32, _i32, _p, _p, _p, _p, _p, _i32, _i64, _i32, _p]),
+    "alignn_ff_fc_grad": (_i32, [_p, _f32, _i32, _p, _p, _p, _p, _p, _p, _i32, _i32, _p]),
+    "alignn_add_inplace": (_i32, [_p, _p, _i64, _p]),
+    "alignn_add3": (_i32, [_p, _p, _p, _p, _i64, _p]),
 }
 
 # argument blocks of the composite entry points (include/alignn_hip.h: alignn_egc_fwd_args / _bwd_args / _wgrad_args), packed

@@ -345,10 +345,13 @@ class ALIGNNAtomWise(nn.Module):
             # float64 / 16-bit module (alignn/train.py:89-95): the composed path on plain torch operations (alignn_amd/ff.py
             # switches per dtype), energies with or without forces - twice differentiable by autograd like the reference
             return self._forward_ff(self._batch(g), with_forces=bool(cfg.calculate_gradient))
+        b = self._batch(g)
+        res = self._forward_c(b)  # the whole model as one or two C calls (alignn_amd/cmodel.py) where that applies
+        if res is not None:
+            return res
         ops.new_weight_generation()  # (see ops._WGEN)
         with _lib.device_guard(self.fc.weight):
             _bn._prepare_split_weights(self)  # all weight images of the step in one call (ops.WeightPrep)
-        b = self._batch(g)
         # Forces: in training the loss differentiates THROUGH them -> composed, twice-differentiable path.  In eval
         # mode (MD / calculators: alignn/ff/calculators.py) only the first derivative is needed -> the fused kernels
         # with their hand-written backward, r as a leaf.
@@ -370,6 +373,43 @@ class ALIGNNAtomWise(nn.Module):
                 return self._forward_fused(b, True)
         with ops.lanes(self.fc.weight.device):
             return self._forward_fused(b, False)
+
+    def _forward_c(self, b: GraphBatch):
+        """The whole-model C entry points (csrc/model.hip) where they apply - the plain energy / force / stress head, float32 on
+        a HIP device, no hooks, every kernel-choice switch at its default: training through the forces (``alignn_ff_eval`` +
+        ``alignn_ff_grad``: what alignn/train.py:291-387 runs), force evaluation in eval mode (``alignn_ff_eval``: MD,
+        alignn/ff/calculators.py:280-291) and energy-only training (``alignn_model_fwd / _bwd``, LayerNorm flavour).  None:
+        the per-operator path below."""
+        from . import cmodel, ff2
+
+        cfg = self.config
+        grad = torch.is_grad_enabled()
+        if cfg.calculate_gradient:
+            if not (grad and ff2.supported(cfg) and ff2.REUSE_FORWARD):
+                return None
+            if self.training:
+                if not (FUSED_FORCE_TRAINING and cmodel.atomwise_applicable(self, b, True)):
+                    return None
+                res = cmodel.ff_train(self, b)
+            else:
+                if not cmodel.atomwise_applicable(self, b, False):
+                    return None
+                res = cmodel.ff_eval(self, b)
+            if res is None:
+                return None
+            out, forces, stress = res
+            has_stress = cfg.stresswise_weight != 0
+            return self._finish(torch.squeeze(out), torch.empty(1), torch.squeeze(forces), stress if has_stress else torch.empty(1),
+                                torch.empty(1))
+        if not (self.training and cfg.output_features is not None and (not cfg.use_penalty or cfg.energy_mult_natoms)
+                and cmodel.atomwise_applicable(self, b, grad)):
+            return None
+        with _lib.device_guard(self.fc.weight):
+            h = ops.bond_cosines(b.r, b.lg) if cfg.lg_on_fly else b.h
+        out = cmodel.forward(self, b, h=h)
+        if out is None:
+            return None
+        return self._finish(torch.squeeze(out), torch.empty(1), torch.empty(1), torch.empty(1), torch.empty(1))
 
     def _forward_fused(self, b: GraphBatch, fused_forces: bool):
         cfg = self.config
@@ -447,19 +487,32 @@ class ALIGNNAtomWise(nn.Module):
             f = ops._segment_sum_raw(pair_forces, gg.seg_ptr, None, gg.seg_node, gg.n_nodes)
             f = f - ops._segment_sum_raw(pair_forces, gg.out_ptr, gg.out_slot, None, gg.n_nodes)
             return torch.squeeze(f) * gg.n_nodes, torch.empty(1)
-        if cfg.force_mult_natoms:
-            pair_forces = pair_forces * b.g.n_nodes
-        forces = ops._segment_sum_raw(pair_forces, gg.seg_ptr, None, gg.seg_node, gg.n_nodes)  # copy_e / sum by destination
-        if cfg.add_reverse_forces:
-            forces = forces - ops._segment_sum_raw(pair_forces, gg.out_ptr, gg.out_slot, None, gg.n_nodes)
+        if cfg.stresswise_weight != 0 and not cfg.batch_stress:
+            if b.volume is None:
+                raise ValueError("stress needs the cell volumes: g.ndata['V'] (or GraphBatch.volume)")
+            if cfg.force_mult_natoms:
+                pair_forces = pair_forces * b.g.n_nodes
+            forces = ops._segment_sum_raw(pair_forces, gg.seg_ptr, None, gg.seg_node, gg.n_nodes)
+            if cfg.add_reverse_forces:
+                forces = forces - ops._segment_sum_raw(pair_forces, gg.out_ptr, gg.out_slot, None, gg.n_nodes)
+            return torch.squeeze(forces), _single_virial(b, pair_forces)
+        # forces per atom = in-minus-out reduction of the pair forces (copy_e / sum on g and on dgl.reverse(g)), virial stress per
+        # crystal: one kernel each (csrc/ff.hip) - the same two the whole-model call alignn_ff_eval launches
+        lib = _lib.load()
+        g_r = g_r.contiguous()
+        scale = float(cfg.grad_multiplier) * (gg.n_nodes if cfg.force_mult_natoms else 1)
+        forces = torch.empty(gg.n_nodes, 3, dtype=torch.float32, device=g_r.device)
+        _lib.check(lib.alignn_pair_force_reduce(g_r.data_ptr(), scale, gg.seg_ptr.data_ptr(), gg.out_ptr.data_ptr(),
+                                                gg.out_slot.data_ptr(), int(cfg.add_reverse_forces), forces.data_ptr(), gg.n_nodes,
+                                                _lib.stream()), "pair_force_reduce")
         forces = torch.squeeze(forces)
         stress = torch.empty(1)
         if cfg.stresswise_weight != 0:
             if b.volume is None:
                 raise ValueError("stress needs the cell volumes: g.ndata['V'] (or GraphBatch.volume)")
-            if not cfg.batch_stress:
-                return forces, _single_virial(b, pair_forces)
-            outer = (r.detach().unsqueeze(2) * pair_forces.unsqueeze(1)).reshape(-1, 9)
-            st = ops._segment_sum_raw(outer, b.edge_graph_ptr, None, None, b.batch_size).reshape(-1, 3, 3)
-            stress = cfg.stress_multiplier * (-160.21766208) * st / b.volume.reshape(-1, 1, 1)
+            stress = torch.empty(b.batch_size, 3, 3, dtype=torch.float32, device=g_r.device)
+            rr = r.detach().contiguous()
+            _lib.check(lib.alignn_virial_stress(rr.data_ptr(), g_r.data_ptr(), scale, b.graph_ptr.data_ptr(), gg.seg_ptr.data_ptr(),
+                                                b.volume.data_ptr(), float(cfg.stress_multiplier) * (-160.21766208), stress.data_ptr(),
+                                                b.batch_size, _lib.stream()), "virial_stress")
         return forces, stress

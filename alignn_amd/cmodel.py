@@ -66,9 +66,16 @@ class ModelDesc(C.Structure):
         ("fc_W", _p), ("fc_b", _p), ("g_fc_W", _p), ("g_fc_b", _p),
         ("weight_descs", _p), ("weight_amax", _p), ("bump_ptrs", _p),
         ("n_weights", _i32), ("n_bump", _i32), ("x6_min_tiles", _i32), ("bd_segment_table", _i32),
-        ("angle_fused", _i32), ("pad_", _i32),
+        ("angle_fused", _i32), ("norm", _i32),
         ("amax_min_rows", _i64), ("lane_min_rows", _i64), ("side_min_rows", _i64),
         ("lane_T", _p), ("side", _p), ("aux", _p)]
+
+
+class FFDesc(C.Structure):
+    """alignn_ff_desc: the force / stress head's switches (ALIGNNAtomWiseConfig) + the cell volumes of the batch"""
+    _fields_ = [(n, _i32) for n in ("lg_on_fly", "add_reverse_forces", "force_mult_natoms", "energy_mult_natoms", "has_stress",
+                                    "use_penalty", "dense_lg_reverse", "pad_")] + [
+        (n, _f32) for n in ("grad_multiplier", "stress_multiplier", "penalty_factor", "penalty_threshold")] + [("volume", _p)]
 
 
 _SIGS_DONE = False
@@ -96,6 +103,8 @@ def _lib_model():
             if lib.alignn_model_sizeof(which) != C.sizeof(st):
                 raise RuntimeError(f"alignn_model struct {which}: library says {lib.alignn_model_sizeof(which)} bytes, "
                                    f"the binding lays out {C.sizeof(st)}")
+        if lib.alignn_ff_desc_sizeof() != C.sizeof(FFDesc):
+            raise RuntimeError("alignn_ff_desc: the binding's layout differs from the library's")
         _SIGS_DONE = True
     return lib
 
@@ -142,7 +151,9 @@ class Binding:
         self.convs += list(model.gcn_layers)
         self.mlps = [model.atom_embedding, model.edge_embedding[1], model.edge_embedding[2], model.angle_embedding[1],
                      model.angle_embedding[2]]
-        self.norms = [mod.layer[1] for mod in self.mlps] + [bn for cv in self.convs for bn in (cv.bn_nodes, cv.bn_edges)]
+        self.norm = 1 if getattr(self.convs[0], "_norm", "batch") == "layer" else 0  # alignn_model_desc.norm
+        self.norms = [] if self.norm else ([mod.layer[1] for mod in self.mlps] +
+                                           [bn for cv in self.convs for bn in (cv.bn_nodes, cv.bn_edges)])
         self.dead_edge = {2 * cfg.alignn_layers - 1, len(self.convs) - 1}  # convs whose edge output nobody reads
         assert all(isinstance(m, EdgeGatedGraphConv) for m in self.convs) and all(isinstance(m, MLPLayer) for m in self.mlps)
         self.desc = ModelDesc()
@@ -201,6 +212,10 @@ class Binding:
             place(blk, "e_red", [cv.bn_edges.bias, cv.bn_edges.weight])
         place(d, "g_fc_W", [m.fc.weight])
         place(d, "g_fc_b", [m.fc.bias])
+        pad = -off % 4  # (alignn_ff_grad adds the tangent halves with float4 accesses)
+        if pad:
+            entries.append((None, pad))
+            off += pad
         self.grad_floats = off
         self.params = [p for p, _ in entries if p is not None]
         self.sizes = [n for _, n in entries]
@@ -262,30 +277,34 @@ class Binding:
         for blk, mod in zip((d.atom, d.edge1, d.edge2, d.angle1, d.angle2), self.mlps):
             lin, bn = mod.layer[0], mod.layer[1]
             blk.W, blk.b, blk.gamma, blk.beta = lin.weight.data_ptr(), lin.bias.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr()
-            blk.rm, blk.rv = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+            blk.rm, blk.rv = (None, None) if self.norm else (bn.running_mean.data_ptr(), bn.running_var.data_ptr())
             i3 = img.get(id(lin.weight), (None, None, None))
             blk.img, blk.img_t, blk.w_amax = i3
             blk.in_, blk.out = lin.weight.shape[1], lin.weight.shape[0]
-            bumps.append(bn.num_batches_tracked)
+            if not self.norm:
+                bumps.append(bn.num_batches_tracked)
         for i, (cv, (wcat, bcat)) in enumerate(zip(self.convs, fused)):
             blk = self.conv_arr[i]
             blk.wcat, blk.bcat = wcat.data_ptr(), bcat.data_ptr()
             blk.w_eg, blk.b_eg = cv.edge_gate.weight.data_ptr(), cv.edge_gate.bias.data_ptr()
             blk.n_gamma, blk.n_beta = cv.bn_nodes.weight.data_ptr(), cv.bn_nodes.bias.data_ptr()
             blk.e_gamma, blk.e_beta = cv.bn_edges.weight.data_ptr(), cv.bn_edges.bias.data_ptr()
-            blk.n_rm, blk.n_rv = cv.bn_nodes.running_mean.data_ptr(), cv.bn_nodes.running_var.data_ptr()
-            blk.e_rm, blk.e_rv = cv.bn_edges.running_mean.data_ptr(), cv.bn_edges.running_var.data_ptr()
+            if not self.norm:
+                blk.n_rm, blk.n_rv = cv.bn_nodes.running_mean.data_ptr(), cv.bn_nodes.running_var.data_ptr()
+                blk.e_rm, blk.e_rv = cv.bn_edges.running_mean.data_ptr(), cv.bn_edges.running_var.data_ptr()
             blk.wcat_img, blk.wcat_img_t, blk.wcat_amax = img.get(id(wcat), (None, None, None))
             blk.weg_img, blk.weg_img_t, blk.weg_amax = img.get(id(cv.edge_gate.weight), (None, None, None))
-            bumps += [cv.bn_nodes.num_batches_tracked, cv.bn_edges.num_batches_tracked]
+            if not self.norm:
+                bumps += [cv.bn_nodes.num_batches_tracked, cv.bn_edges.num_batches_tracked]
         d.fc_W, d.fc_b = m.fc.weight.data_ptr(), m.fc.bias.data_ptr()
         if have_images:
             d.weight_descs, d.weight_amax, d.n_weights = prep.desc.data_ptr(), prep.amax.data_ptr(), len(weights)
         else:
             d.weight_descs, d.weight_amax, d.n_weights = None, None, 0
         self.bump_keep = bumps
-        self.bump = torch.tensor([t.data_ptr() for t in bumps], dtype=torch.int64).to(self.device)
-        d.bump_ptrs, d.n_bump = self.bump.data_ptr(), len(bumps)
+        self.bump = torch.tensor([t.data_ptr() for t in bumps], dtype=torch.int64).to(self.device) if bumps else None
+        d.bump_ptrs, d.n_bump = (self.bump.data_ptr() if bumps else None), len(bumps)
+        d.norm = self.norm
         d.x6_min_tiles, d.bd_segment_table = ops.X6_MIN_TILES, int(ops.BD_SEGMENT_TABLE)
         d.amax_min_rows = ops.AMAX_MIN_ROWS if ops.F16X3 else (1 << 62)
         self.plans = {}
@@ -457,26 +476,39 @@ def infer_applicable(model, b) -> bool:
     return (not model.training) and (not torch.is_grad_enabled()) and ops.INFER_FUSED and _structure_ok(model, b, False)
 
 
-def _structure_ok(model, b, need_grad) -> bool:
+def _atomwise_cfg_ok(cfg) -> bool:
+    """ALIGNNAtomWise configurations the C side carries: the plain energy (+ force / stress) head"""
+    return (cfg.extra_features == 0 and cfg.output_features == 1 and not cfg.classification and cfg.link == "identity"
+            and cfg.additional_output_features == 0 and not (cfg.atomwise_output_features > 0 and cfg.atomwise_weight != 0)
+            and not cfg.use_cutoff_function and not cfg.include_pos_deriv)
+
+
+def _structure_ok(model, b, need_grad, flavour="ALIGNN") -> bool:
     if not (ENABLED and _flags_default()):
         return False
     cfg = model.config
     if cfg.extra_features != 0 or cfg.alignn_layers < 1 or cfg.gcn_layers < 1 or cfg.hidden_features % 4:
         return False
     w = model.fc.weight
-    if not w.is_cuda or w.dtype != torch.float32 or b.lg is None or b.h is None or b.atom_features is None or b.r is None:
+    if not w.is_cuda or w.dtype != torch.float32 or b.lg is None or b.atom_features is None or b.r is None:
         return False
-    for t in (b.atom_features, b.r, b.h):
-        if t.dtype != torch.float32 or t.requires_grad or not t.is_cuda:
+    if type(model).__name__ != flavour:
+        return False
+    need_h = flavour == "ALIGNN" or not cfg.lg_on_fly
+    if need_h and b.h is None:
+        return False
+    for t in (b.atom_features, b.r, b.h if need_h else None):
+        if t is not None and (t.dtype != torch.float32 or t.requires_grad or not t.is_cuda):
             return False
-    if type(model).__name__ != "ALIGNN":
+    if flavour == "ALIGNNAtomWise" and not _atomwise_cfg_ok(cfg):
         return False
+    want_norm = "batch" if flavour == "ALIGNN" else "layer"
     mc = model_cache(model)
     ok = mc.get("static_ok")
     if ok is None:
         from .alignn import EdgeGatedGraphConv, MLPLayer
 
-        ok = all(getattr(m, "_norm", "batch") == "batch" and (not isinstance(m, EdgeGatedGraphConv) or m.residual)
+        ok = all(getattr(m, "_norm", "batch") == want_norm and (not isinstance(m, EdgeGatedGraphConv) or m.residual)
                  for m in model.modules() if isinstance(m, (EdgeGatedGraphConv, MLPLayer)))
         mc["static_ok"] = ok
     if not ok:
@@ -505,7 +537,7 @@ def _structure_ok(model, b, need_grad) -> bool:
     for d, name, p in slots:
         if d.get(name) is not p:
             mc.clear()
-            return _structure_ok(model, b, need_grad)
+            return _structure_ok(model, b, need_grad, flavour)
         if need_grad and not p.requires_grad:
             return False
     if any(p.dtype != torch.float32 for p in (model.atom_embedding.layer[0].weight, model.fc.bias)):
@@ -513,15 +545,16 @@ def _structure_ok(model, b, need_grad) -> bool:
     return True
 
 
-def forward(model, b):
+def forward(model, b, h=None):
     """-> ``fc(AvgPooling(...))`` [B, out_features] of a training-mode forward, or None when the C side does not carry a
-    kernel choice this (model, batch) needs (the caller then takes the per-operator path)."""
+    kernel choice this (model, batch) needs (the caller then takes the per-operator path).  ``h``: bond-angle cosines to use
+    instead of ``b.h`` (ALIGNNAtomWise with lg_on_fly recomputes them from the bond vectors)."""
     bind = binding_of(model)
     with _lib.device_guard(model.fc.weight):
         bind.refresh()
         capturing = bind.set_mode()
         mb = bind.batch_struct(b)
-        af, r, h = b.atom_features.contiguous(), b.r.contiguous(), b.h.contiguous()
+        af, r, h = b.atom_features.contiguous(), b.r.contiguous(), (b.h if h is None else h).contiguous()
         if af.shape != (b.g.n_nodes, bind.desc.atom_in) or r.shape != (b.g.n_edges, 3) or h.numel() != b.lg.n_edges:
             raise ValueError("feature rows do not match the graphs")
         mb.atom_features, mb.r, mb.h = af.data_ptr(), r.data_ptr(), h.data_ptr()
@@ -565,3 +598,161 @@ def infer(model, b):
                    "model_infer")
         STATS["infer"] = STATS.get("infer", 0) + 1
         return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# ALIGNNAtomWise with the force / stress head: alignn_ff_eval / alignn_ff_grad (csrc/model.hip, csrc/ff.hip)
+# ---------------------------------------------------------------------------------------------------------------------
+def atomwise_applicable(model, b, need_param_grads) -> bool:
+    """Can this (ALIGNNAtomWise, batch) go through the whole-model C entry points?  (LayerNorm flavour, the plain energy
+    / force / stress head - ``_atomwise_cfg_ok`` -, float32 on a HIP device, every parameter trainable when gradients are wanted)"""
+    return _structure_ok(model, b, need_param_grads, "ALIGNNAtomWise")
+
+
+def _ff_desc(model, b):
+    cfg = model.config
+    f = FFDesc()
+    f.lg_on_fly, f.add_reverse_forces = int(cfg.lg_on_fly), int(cfg.add_reverse_forces)
+    f.force_mult_natoms, f.energy_mult_natoms = int(cfg.force_mult_natoms), int(cfg.energy_mult_natoms)
+    f.has_stress = int(cfg.stresswise_weight != 0)
+    f.use_penalty = int(cfg.use_penalty)
+    from . import ff2
+
+    f.dense_lg_reverse = int(ff2.DENSE_LG_REVERSE and ops.FUSED_LG_BACKWARD and ops.DENSE_LG_BACKWARD)
+    f.grad_multiplier, f.stress_multiplier = float(cfg.grad_multiplier), float(cfg.stress_multiplier)
+    f.penalty_factor, f.penalty_threshold = float(cfg.penalty_factor), float(cfg.penalty_threshold)
+    if f.has_stress:
+        if b.volume is None:
+            raise ValueError("stress needs the cell volumes: g.ndata['V'] (or GraphBatch.volume)")
+        f.volume = b.volume.data_ptr()
+    return f
+
+
+def _ff_prepare(model, b, need_grad):
+    """-> (bind, mb, ffd, keep-alive tuple, arena, bytes, (owns, gen)) or None (kernel choice not carried)"""
+    bind = binding_of(model)
+    bind.refresh()
+    capturing = bind.set_mode()
+    mb = bind.batch_struct(b)
+    af, r = b.atom_features.contiguous(), b.r.contiguous()
+    h = None if model.config.lg_on_fly else b.h.contiguous()
+    if af.shape != (b.g.n_nodes, bind.desc.atom_in) or r.shape != (b.g.n_edges, 3) or (h is not None and h.numel() != b.lg.n_edges):
+        raise ValueError("feature rows do not match the graphs")
+    mb.atom_features, mb.r, mb.h = af.data_ptr(), r.data_ptr(), _ptr(h)
+    ffd = _ff_desc(model, b)
+    key = ("ff", mb.g.n, mb.g.m, mb.lg.m, mb.B, mb.lg.dense_max_src, bool(mb.lg.grp_seg_ptr), bool(mb.lg.seg_rank),
+           bool(bind.desc.lane_T), bool(bind.desc.side), bool(bind.desc.aux), bind.desc.side_min_rows, bind.desc.lane_min_rows,
+           ffd.lg_on_fly, ffd.has_stress, ffd.dense_lg_reverse)
+    hit = bind.plans.get(key)
+    if hit is None:
+        ev, tot = C.c_size_t(0), C.c_size_t(0)
+        rc = _lib_model().alignn_ff_plan(bind.desc_addr, C.addressof(mb), C.addressof(ffd), C.addressof(ev), C.addressof(tot))
+        STATS["plans"] += 1
+        if rc == _NOT_SUPPORTED:
+            hit = (None, None)
+        else:
+            _lib.check(rc, "ff_plan")
+            hit = (ev.value, tot.value)
+        bind.plans[key] = hit
+    if hit[1] is None:
+        return None
+    nbytes = hit[1] if need_grad else hit[0]
+    arena, owns, gen = bind.take_arena(nbytes, capturing, need_grad)
+    ops.new_weight_generation()
+    return bind, mb, ffd, (b, af, r, h, b.volume), arena, nbytes, (owns, gen)
+
+
+def _ff_outputs(bind, mb, ffd):
+    dev = bind.device
+    out = torch.empty(mb.B, dtype=torch.float32, device=dev)
+    forces = torch.empty(mb.g.n, 3, dtype=torch.float32, device=dev)
+    stress = torch.empty(mb.B, 3, 3, dtype=torch.float32, device=dev) if ffd.has_stress else None
+    return out, forces, stress
+
+
+class _FFFn(torch.autograd.Function):
+    """(energies, forces, stresses) of ALIGNNAtomWise as ONE autograd node over two C calls: forward = alignn_ff_eval (values;
+    the tape stays in the workspace), backward = alignn_ff_grad (the loss gradient THROUGH the forces as one reverse pass over a
+    tangent-carrying forward pass - alignn_amd/ff2.py's scheme, issued from C)."""
+
+    @staticmethod
+    def forward(ctx, bind, mb, ffd, keep, arena, arena_bytes, lease, *params):
+        lib = _lib_model()
+        out, forces, stress = _ff_outputs(bind, mb, ffd)
+        _lib.check(lib.alignn_ff_eval(bind.desc_addr, C.addressof(mb), C.addressof(ffd), arena.data_ptr(), arena_bytes,
+                                      out.data_ptr(), forces.data_ptr(), _ptr(stress), _lib.stream()), "ff_eval")
+        STATS["ff_eval"] = STATS.get("ff_eval", 0) + 1
+        owns, gen = lease
+        ctx.bind, ctx.mb, ctx.ffd, ctx.keep, ctx.arena, ctx.arena_bytes, ctx.lease = bind, mb, ffd, keep, arena, arena_bytes, _Lease(bind, owns)
+        ctx.shared_gen = gen if arena is bind.arena else 0
+        ctx.sig = bind.sig
+        ctx.has_stress = stress is not None
+        if stress is None:
+            stress = torch.empty(1, device=out.device)
+            ctx.mark_non_differentiable(stress)
+        return out, forces, stress
+
+    @staticmethod
+    def backward(ctx, g_out, g_forces, g_stress):
+        bind = ctx.bind
+        lib = _lib_model()
+        if ctx.arena is None:
+            raise RuntimeError("alignn_amd.cmodel: backward called twice on a forward that ran in a workspace of its own")
+        if ctx.shared_gen and (bind.arena is not ctx.arena or bind.arena_gen != ctx.shared_gen):
+            raise RuntimeError("alignn_amd.cmodel: backward through a forward whose workspace another forward has reused "
+                               "(retain_graph across model calls: set ALIGNN_AMD_CMODEL=0 for the per-operator path)")
+        if bind.sig != ctx.sig:
+            raise RuntimeError("alignn_amd.cmodel: the model's parameters moved between forward and backward")
+        g_out = None if g_out is None else g_out.reshape(-1).to(torch.float32).contiguous()
+        g_forces = None if g_forces is None else g_forces.reshape(-1, 3).to(torch.float32).contiguous()
+        g_stress = None if (g_stress is None or not ctx.has_stress) else g_stress.reshape(-1, 3, 3).to(torch.float32).contiguous()
+        gflat = torch.empty(2, bind.grad_floats, dtype=torch.float32, device=bind.device)
+        base = gflat.data_ptr()
+        for owner, field, off in bind.grad_fields:
+            setattr(owner, field, base + 4 * off)
+        bind.set_mode()
+        try:
+            _lib.check(lib.alignn_ff_grad(bind.desc_addr, C.addressof(ctx.mb), C.addressof(ctx.ffd), ctx.arena.data_ptr(),
+                                          ctx.arena_bytes, _ptr(g_out), _ptr(g_forces), _ptr(g_stress), gflat[0].data_ptr(),
+                                          gflat[1].data_ptr(), bind.grad_floats, _lib.stream()), "ff_grad")
+        finally:
+            ctx.lease.release()
+            if not ctx.shared_gen:
+                ctx.arena = None
+        STATS["ff_grad"] = STATS.get("ff_grad", 0) + 1
+        pieces = gflat[0].split_with_sizes(bind.sizes)
+        grads = []
+        for i, shape, dead in zip(bind.keep, bind.shapes, bind.no_grad):
+            grads.append(None if dead else (pieces[i] if len(shape) == 1 else pieces[i].view(shape)))
+        return (None,) * 7 + tuple(grads)
+
+
+def ff_train(model, b):
+    """-> (out [B], forces [N, 3], stresses [B, 3, 3] or a placeholder) differentiable w.r.t. the parameters, or None when the C
+    side does not carry a kernel choice this (model, batch) needs."""
+    with _lib.device_guard(model.fc.weight):
+        prep = _ff_prepare(model, b, True)
+        if prep is None:
+            return None
+        bind, mb, ffd, keep, arena, nbytes, lease = prep
+        try:
+            return _FFFn.apply(bind, mb, ffd, keep, arena, nbytes, lease, *bind.params)
+        except BaseException:
+            if lease[0]:
+                bind.arena_busy = False
+            raise
+
+
+def ff_eval(model, b):
+    """-> (out, forces, stresses or None) as plain values (MD / calculators: alignn/ff/calculators.py:280-291), ONE C call; None
+    when the C side does not carry a kernel choice this (model, batch) needs."""
+    with _lib.device_guard(model.fc.weight):
+        prep = _ff_prepare(model, b, False)
+        if prep is None:
+            return None
+        bind, mb, ffd, _keep, arena, nbytes, _lease = prep
+        out, forces, stress = _ff_outputs(bind, mb, ffd)
+        _lib.check(_lib_model().alignn_ff_eval(bind.desc_addr, C.addressof(mb), C.addressof(ffd), arena.data_ptr(), nbytes,
+                                               out.data_ptr(), forces.data_ptr(), _ptr(stress), _lib.stream()), "ff_eval")
+        STATS["ff_eval"] = STATS.get("ff_eval", 0) + 1
+        return out, forces, stress

@@ -1,0 +1,367 @@
+// The force-field head around the LayerNorm stack (ALIGNNAtomWise, alignn/models/alignn_atomwise.py:494-638) and the
+// seeds of the second-order pass (alignn_amd/ff2.py) as a handful of small kernels - what used to be ~100 torch
+// element-wise / index / reduce launches (and one vendor GEMM: torch.einsum for a 3 x 3 mat-vec per bond) per training step.
+//
+//   energy          E_g = pred_g * n_g (energy_mult_natoms) + the short-bond penalty of the whole batch   (:494-510)
+//   pair forces     f_e = grad_multiplier * dE_tot/dr_e (* N if force_mult_natoms)                          (:530-545)
+//   forces          F_i = sum_{e into i} f_e - sum_{e out of i} f_e   (copy_e / sum on g and on dgl.reverse(g), :547-565)
+//   stresses        S_g = stress_multiplier * (-160.21766208) * sum_{e in g} r_e (x) f_e / V_g             (:615-638)
+//   second order    w_e = dL/df_e from dL/dF, dL/dS;  the tangent direction rt = w / 2^k and the tangents of the geometry
+//                   features (bond length -> RBF, bond cosine -> RBF); the readout seeds and the fc gradient
+//
+// All reductions run in a fixed order (no float atomics): a step is bit-reproducible.  max|w| is one integer atomicMax per
+// workgroup on the bit pattern of a non-negative float (order independent).
+#include "../../include/alignn_hip.h"
+#include "common.h"
+
+namespace {
+
+inline int grid_for(int64_t n, int block = 256, int cap = 65535) {
+    int64_t g = (n + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+// largest power of two <= x (x > 0), 1 for x == 0: the normalisation of the tangent direction
+__device__ __forceinline__ float pow2_floor(float x) {
+    if (!(x > 0.0f)) return 1.0f;
+    int e;
+    frexpf(x, &e);  // x = m 2^e, 0.5 <= m < 1
+    return ldexpf(1.0f, e - 1);
+}
+
+// crystal of row k given the B + 1 offsets off[g] = inner[outer[g]] (inner == NULL: off = outer)
+__device__ __forceinline__ int owner_of(int k, const int32_t* __restrict__ outer, const int32_t* __restrict__ inner, int B) {
+    int lo = 0, hi = B;  // invariant: off[lo] <= k < off[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        const int o = inner ? inner[outer[mid]] : outer[mid];
+        if (o <= k)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+__global__ void pair_force_reduce_kernel(const float* __restrict__ g_r, float scale, const int32_t* __restrict__ seg_ptr,
+                                         const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_slot,
+                                         int add_reverse, float* __restrict__ forces, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * n) return;
+    const int64_t node = i / 3;
+    const int c = (int)(i - 3 * node);
+    float in = 0.0f, out = 0.0f;
+    for (int k = seg_ptr[node]; k < seg_ptr[node + 1]; ++k) in += g_r[3 * (int64_t)k + c];
+    if (add_reverse)
+        for (int k = out_ptr[node]; k < out_ptr[node + 1]; ++k) out += g_r[3 * (int64_t)out_slot[k] + c];
+    forces[i] = scale * (in - out);
+}
+
+// one workgroup per crystal; thread t walks bonds t, t + 256, ...; nine sums each, added across the workgroup in a fixed tree
+__global__ __launch_bounds__(256) void virial_stress_kernel(const float* __restrict__ r, const float* __restrict__ g_r, float scale,
+                                                            const int32_t* __restrict__ graph_ptr,
+                                                            const int32_t* __restrict__ seg_ptr, const float* __restrict__ volume,
+                                                            float k, float* __restrict__ stress) {
+    __shared__ float sh[256][9];
+    const int g = blockIdx.x;
+    const int beg = seg_ptr[graph_ptr[g]], end = seg_ptr[graph_ptr[g + 1]];
+    float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int e = beg + threadIdx.x; e < end; e += 256) {
+        const float rx = r[3 * (int64_t)e], ry = r[3 * (int64_t)e + 1], rz = r[3 * (int64_t)e + 2];
+        const float fx = g_r[3 * (int64_t)e], fy = g_r[3 * (int64_t)e + 1], fz = g_r[3 * (int64_t)e + 2];
+        acc[0] += rx * fx, acc[1] += rx * fy, acc[2] += rx * fz;
+        acc[3] += ry * fx, acc[4] += ry * fy, acc[5] += ry * fz;
+        acc[6] += rz * fx, acc[7] += rz * fy, acc[8] += rz * fz;
+    }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) sh[threadIdx.x][j] = acc[j];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+#pragma unroll
+            for (int j = 0; j < 9; ++j) sh[threadIdx.x][j] += sh[threadIdx.x + s][j];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 9) stress[9 * g + threadIdx.x] = (k * scale / volume[g]) * sh[0][threadIdx.x];
+}
+
+// ONE workgroup: the short-bond penalty of the whole batch (fixed-order tree), then the B energies
+__global__ __launch_bounds__(256) void ff_energy_kernel(const float* __restrict__ pred, const float* __restrict__ bl,
+                                                        const int32_t* __restrict__ graph_ptr, int B, int64_t E, int mult_natoms,
+                                                        int use_penalty, float factor, float thr, float* __restrict__ out,
+                                                        float* __restrict__ seed) {
+    __shared__ float sh[256];
+    float pen = 0.0f;
+    if (use_penalty)
+        for (int64_t e = threadIdx.x; e < E; e += 256) {
+            const float d = bl[e];
+            if (d < thr) pen += factor * (thr - d);
+        }
+    sh[threadIdx.x] = pen;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    pen = sh[0];
+    for (int g = threadIdx.x; g < B; g += 256) {
+        const float cnt = (float)(graph_ptr[g + 1] - graph_ptr[g]);
+        // alignn_atomwise.py:494-510: with energy_mult_natoms the returned `out` is the per-atom prediction (the penalty only
+        // reaches en_out, i.e. the forces); without it en_out IS out and `en_out += penalty` is in place
+        out[g] = mult_natoms ? pred[g] : (use_penalty ? pred[g] + pen : pred[g]);
+        seed[g] = mult_natoms ? cnt : 1.0f;  // d(sum_g en_out_g) / d pred_g
+    }
+}
+
+__global__ void ff_penalty_bwd_kernel(const float* __restrict__ bl, float* __restrict__ g_bl, int64_t E, float coef, float thr) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < E && bl[e] < thr) g_bl[e] += coef;
+}
+
+__global__ __launch_bounds__(256) void ff_pair_weights_kernel(const float* __restrict__ gF, const float* __restrict__ gS,
+                                                              const float* __restrict__ r, const int32_t* __restrict__ src,
+                                                              const int32_t* __restrict__ dst, const int32_t* __restrict__ graph_ptr,
+                                                              const int32_t* __restrict__ seg_ptr, const float* __restrict__ volume,
+                                                              float kS, int add_reverse, int B, int64_t E, float* __restrict__ w,
+                                                              float* __restrict__ wmax) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float am = 0.0f;
+    if (e < E) {
+        float wx = 0.0f, wy = 0.0f, wz = 0.0f;
+        if (gF != nullptr) {
+            const float* a = gF + 3 * (int64_t)dst[e];
+            wx = a[0], wy = a[1], wz = a[2];
+            if (add_reverse) {
+                const float* b = gF + 3 * (int64_t)src[e];
+                wx -= b[0], wy -= b[1], wz -= b[2];
+            }
+        }
+        if (gS != nullptr) {
+            // stress_g = k_g sum_e r_e (x) f_e  ->  dL/df_e = k_g gS_g^T r_e
+            const int g = owner_of((int)e, graph_ptr, seg_ptr, B);
+            const float kg = kS / volume[g];
+            const float* s = gS + 9 * (int64_t)g;
+            const float rx = r[3 * e], ry = r[3 * e + 1], rz = r[3 * e + 2];
+            wx += (kg * s[0]) * rx + (kg * s[3]) * ry + (kg * s[6]) * rz;
+            wy += (kg * s[1]) * rx + (kg * s[4]) * ry + (kg * s[7]) * rz;
+            wz += (kg * s[2]) * rx + (kg * s[5]) * ry + (kg * s[8]) * rz;
+        }
+        w[3 * e] = wx, w[3 * e + 1] = wy, w[3 * e + 2] = wz;
+        am = fmaxf(fmaxf(fabsf(wx), fabsf(wy)), fabsf(wz));
+    }
+    block_amax_commit(am, wmax);
+}
+
+__global__ void ff_tangent_geometry_kernel(const float* __restrict__ r, const float* __restrict__ w, const float* __restrict__ wmax,
+                                           const float* __restrict__ d, float* __restrict__ rt, float* __restrict__ dt, int64_t E) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const float inv = 1.0f / pow2_floor(*wmax);  // (a power of two: exact)
+    const float tx = w[3 * e] * inv, ty = w[3 * e + 1] * inv, tz = w[3 * e + 2] * inv;
+    rt[3 * e] = tx, rt[3 * e + 1] = ty, rt[3 * e + 2] = tz;
+    dt[e] = (r[3 * e] * tx + r[3 * e + 1] * ty + r[3 * e + 2] * tz) / d[e];
+}
+
+__global__ void rbf_tangent_kernel(const float* __restrict__ d, const float* __restrict__ dt, const float* __restrict__ centers,
+                                   float gamma, float* __restrict__ out, int64_t rows, int bins) {
+    const int64_t total = rows * bins;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / bins;
+        const int k = (int)(i - row * bins);
+        const float t = d[row] - centers[k];
+        out[i] = __expf(-gamma * t * t) * (-2.0f * gamma * t) * dt[row];
+    }
+}
+
+// derivative of compute_bond_cosines (alignn/graphs.py:847-864: r1 = -r[e1], r2 = r[e2]) along rt; 0 where the clamp is active
+__global__ void bond_cosine_tangent_kernel(const float* __restrict__ r, const float* __restrict__ rt, const int32_t* __restrict__ e1,
+                                           const int32_t* __restrict__ e2, float* __restrict__ ht, int64_t T) {
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < T; k += (int64_t)gridDim.x * blockDim.x) {
+        const float* a = r + 3 * (int64_t)e1[k];
+        const float* b = r + 3 * (int64_t)e2[k];
+        const float* at = rt + 3 * (int64_t)e1[k];
+        const float* bt = rt + 3 * (int64_t)e2[k];
+        const float ax = -a[0], ay = -a[1], az = -a[2], atx = -at[0], aty = -at[1], atz = -at[2];
+        const float na2 = ax * ax + ay * ay + az * az, nb2 = b[0] * b[0] + b[1] * b[1] + b[2] * b[2];
+        const float inv = 1.0f / (sqrtf(na2) * sqrtf(nb2));
+        const float c = (ax * b[0] + ay * b[1] + az * b[2]) * inv;
+        const float ct = ((atx * b[0] + aty * b[1] + atz * b[2]) + (ax * bt[0] + ay * bt[1] + az * bt[2])) * inv -
+                         c * ((ax * atx + ay * aty + az * atz) / na2 + (b[0] * bt[0] + b[1] * bt[1] + b[2] * bt[2]) / nb2);
+        ht[k] = (c > -1.0f && c < 1.0f) ? ct : 0.0f;
+    }
+}
+
+// readout reversed: E_g = fc(mean_i x_i)  ->  the adjoint of x_i is (seed_g / n_g) fc_w, for the value seed ge and the
+// tangent seed c_g 2^k (2^k undoes the normalisation of the tangent direction)
+__global__ void ff_readout_seed_kernel(const float* __restrict__ ge, float c, int mult_natoms, const float* __restrict__ wmax,
+                                       const int32_t* __restrict__ graph_ptr, const float* __restrict__ fc_w,
+                                       float* __restrict__ gx, float* __restrict__ gxt, int B, int64_t N, int H) {
+    const int Q = H >> 2;
+    const int64_t total = N * Q;
+    const float scale = pow2_floor(*wmax);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t node = i / Q;
+        const int q = (int)(i - node * Q);
+        const int g = owner_of((int)node, graph_ptr, nullptr, B);
+        const float cnt = (float)(graph_ptr[g + 1] - graph_ptr[g]);
+        const float sp = (ge ? ge[g] : 0.0f) / cnt;
+        const float st = (c * (mult_natoms ? cnt : 1.0f) * scale) / cnt;
+        const float4 wv = f4_ld(fc_w + 4 * q);
+        f4_st(gx + node * H + 4 * q, f4_scale(wv, sp));
+        f4_st(gxt + node * H + 4 * q, f4_scale(wv, st));
+    }
+}
+
+__global__ void ff_fc_grad_kernel(const float* __restrict__ ge, float c, int mult_natoms, const float* __restrict__ wmax,
+                                  const int32_t* __restrict__ graph_ptr, const float* __restrict__ hp, const float* __restrict__ hpt,
+                                  float* __restrict__ gW, float* __restrict__ gb, int B, int H) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    const float scale = pow2_floor(*wmax);
+    if (f < H) {
+        float acc = 0.0f;
+        for (int g = 0; g < B; ++g) {
+            const float cnt = (float)(graph_ptr[g + 1] - graph_ptr[g]);
+            const float gt = c * (mult_natoms ? cnt : 1.0f) * scale;
+            acc += (ge ? ge[g] : 0.0f) * hp[(int64_t)g * H + f] + gt * hpt[(int64_t)g * H + f];
+        }
+        gW[f] = acc;
+    }
+    if (f == 0) {
+        float s = 0.0f;
+        if (ge)
+            for (int g = 0; g < B; ++g) s += ge[g];
+        gb[0] = s;
+    }
+}
+
+__global__ void add3_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                            float* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (a[i] + b[i]) + c[i];
+}
+
+__global__ void add_inplace_kernel(float* __restrict__ a, const float* __restrict__ b, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
+        f4_st(a + 4 * i, f4_add(f4_ld(a + 4 * i), f4_ld(b + 4 * i)));
+}
+
+}  // namespace
+
+extern "C" {
+
+int alignn_pair_force_reduce(const float* g_r, float scale, const int32_t* seg_ptr, const int32_t* out_ptr, const int32_t* out_slot,
+                             int add_reverse, float* forces, int64_t n_nodes, alignn_stream_t stream) {
+    if (n_nodes <= 0) return 0;
+    if (g_r == nullptr || seg_ptr == nullptr || forces == nullptr || (add_reverse && (out_ptr == nullptr || out_slot == nullptr)))
+        return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(pair_force_reduce_kernel, dim3(grid_for(3 * n_nodes)), dim3(256), 0, (hipStream_t)stream, g_r, scale,
+                       seg_ptr, out_ptr, out_slot, add_reverse, forces, n_nodes);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_virial_stress(const float* r, const float* g_r, float scale, const int32_t* graph_ptr, const int32_t* seg_ptr,
+                         const float* volume, float k, float* stress, int B, alignn_stream_t stream) {
+    if (B <= 0) return 0;
+    if (r == nullptr || g_r == nullptr || graph_ptr == nullptr || seg_ptr == nullptr || volume == nullptr || stress == nullptr)
+        return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(virial_stress_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, r, g_r, scale, graph_ptr, seg_ptr, volume,
+                       k, stress);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_ff_energy(const float* pred, const float* bl, const int32_t* graph_ptr, int B, int64_t E, int mult_natoms,
+                     int use_penalty, float factor, float thr, float* out, float* seed, alignn_stream_t stream) {
+    if (B <= 0 || pred == nullptr || graph_ptr == nullptr || out == nullptr || seed == nullptr || (use_penalty && bl == nullptr))
+        return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(ff_energy_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pred, bl, graph_ptr, B, E, mult_natoms,
+                       use_penalty, factor, thr, out, seed);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_ff_penalty_bwd(const float* bl, float* g_bl, int64_t E, int B, float factor, float thr, alignn_stream_t stream) {
+    if (E <= 0) return 0;
+    // d(sum_g en_out_g)/d bl_e: every one of the B energies carries the batch's total penalty factor * (thr - bl)
+    hipLaunchKernelGGL(ff_penalty_bwd_kernel, dim3(grid_for(E)), dim3(256), 0, (hipStream_t)stream, bl, g_bl, E,
+                       -factor * (float)B, thr);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_ff_pair_weights(const float* gF, const float* gS, const float* r, const int32_t* src, const int32_t* dst,
+                           const int32_t* graph_ptr, const int32_t* seg_ptr, const float* volume, float kS, int add_reverse, int B,
+                           int64_t E, float* w, float* wmax, alignn_stream_t stream) {
+    if (E <= 0) return 0;
+    if (w == nullptr || wmax == nullptr || src == nullptr || dst == nullptr ||
+        (gS != nullptr && (r == nullptr || graph_ptr == nullptr || seg_ptr == nullptr || volume == nullptr)))
+        return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(ff_pair_weights_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gF, gS, r, src,
+                       dst, graph_ptr, seg_ptr, volume, kS, add_reverse, B, E, w, wmax);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_ff_tangent_geometry(const float* r, const float* w, const float* wmax, const float* d, float* rt, float* dt, int64_t E,
+                               alignn_stream_t stream) {
+    if (E <= 0) return 0;
+    hipLaunchKernelGGL(ff_tangent_geometry_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, (hipStream_t)stream, r, w, wmax,
+                       d, rt, dt, E);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_rbf_tangent(const float* d, const float* dt, const float* centers, float gamma, float* out_t, int64_t rows, int bins,
+                       alignn_stream_t stream) {
+    if (bins <= 0) return (int)hipErrorInvalidValue;
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(rbf_tangent_kernel, dim3(grid_for(rows * bins, 256, 16384)), dim3(256), 0, (hipStream_t)stream, d, dt, centers,
+                       gamma, out_t, rows, bins);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_bond_cosine_tangent(const float* r, const float* rt, const int32_t* e1, const int32_t* e2, float* ht, int64_t T,
+                               alignn_stream_t stream) {
+    if (T == 0) return 0;
+    hipLaunchKernelGGL(bond_cosine_tangent_kernel, dim3(grid_for(T)), dim3(256), 0, (hipStream_t)stream, r, rt, e1, e2, ht, T);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_ff_readout_seed(const float* ge, float c, int mult_natoms, const float* wmax, const int32_t* graph_ptr, const float* fc_w,
+                           float* gx, float* gxt, int B, int64_t N, int H, alignn_stream_t stream) {
+    if (B <= 0 || N <= 0 || H <= 0 || (H & 3)) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(ff_readout_seed_kernel, dim3(grid_for(N * (H >> 2))), dim3(256), 0, (hipStream_t)stream, ge, c, mult_natoms,
+                       wmax, graph_ptr, fc_w, gx, gxt, B, N, H);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_ff_fc_grad(const float* ge, float c, int mult_natoms, const float* wmax, const int32_t* graph_ptr, const float* hp,
+                      const float* hpt, float* gW, float* gb, int B, int H, alignn_stream_t stream) {
+    if (B <= 0 || H <= 0) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(ff_fc_grad_kernel, dim3((H + 255) / 256), dim3(256), 0, (hipStream_t)stream, ge, c, mult_natoms, wmax,
+                       graph_ptr, hp, hpt, gW, gb, B, H);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_add_inplace(float* a, const float* b, int64_t n, alignn_stream_t stream) {
+    if (n <= 0) return 0;
+    if (n & 3) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(add_inplace_kernel, dim3(grid_for(n >> 2, 256, 4096)), dim3(256), 0, (hipStream_t)stream, a, b, n >> 2);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_add3(const float* a, const float* b, const float* c, float* out, int64_t n, alignn_stream_t stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(add3_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, a, b, c, out, n);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

@@ -92,6 +92,8 @@ struct ConvTape {
 };
 struct Tape {
     float *bl = nullptr, *rbf_e = nullptr, *rbf_a = nullptr, *pool = nullptr;
+    float *hcos_buf = nullptr, *pred = nullptr, *seed = nullptr, *g_r = nullptr;  // force-field calls
+    const float* hcos = nullptr;  // the bond-angle cosines the angle embedding read (batch->h, or recomputed from r)
     bool angle_fused = false, angle_lane = false;  // the angle embedding went through csrc/angle.hip: only these survive
     float *a_stat1 = nullptr, *a_stat2 = nullptr, *a_scal = nullptr;
     MlpTape atom, e1, e2, a1, a2;
@@ -141,7 +143,22 @@ struct Ctx {
         }
         return amax_arena + amax_next++;
     }
+    float* new_amax2() {  // two consecutive scalars: (value, tangent) of a dual activation
+        if (amax_next + 2 > kAmaxSlots) {
+            if (rc == 0) rc = (int)hipErrorInvalidValue;
+            return amax_arena;
+        }
+        amax_next += 2;
+        return amax_arena + amax_next - 2;
+    }
     bool track(int64_t rows) const { return rows >= d->amax_min_rows; }
+    // force-field calls (alignn_ff_eval / alignn_ff_grad)
+    const alignn_ff_desc* ff = nullptr;
+    bool param_grads = true;  // false: the reverse pass of alignn_ff_eval (gradients w.r.t. the bond vectors only)
+    bool geom = false;        // the first embedding layers hand back the gradient of their RBF input
+    float *g_rbf_e = nullptr, *g_rbf_a = nullptr;
+    bool g_rbf_a_on_T = false;
+    ptrdiff_t toff = 0;  // floats from a weight-gradient destination to its tangent twin (alignn_ff_grad)
     // `waiter` continues only after everything enqueued on `src` so far
     int n_sync = 0, n_launch = 0;
     double t_sync = 0.0;
@@ -224,7 +241,9 @@ void bn_bwd_finalize_folded(Ctx& c, float* partial, int slabs, int F, float* red
 // ---------------------------------------------------------------------------------------------------------------------
 
 // MLPLayer = Linear + BatchNorm1d (batch statistics) + SiLU, alignn/models/alignn.py:170-184  (ops.MLPLayerFn._fwd)
+Act mlp_fwd_ln(Ctx& c, MlpTape& t, const alignn_mlp_params& p, const Act& x, int64_t rows);
 Act mlp_fwd(Ctx& c, MlpTape& t, const alignn_mlp_params& p, const Act& x, int64_t rows) {
+    if (c.d->norm == 1) return mlp_fwd_ln(c, t, p, x, rows);
     const int F = p.out, K = p.in;
     t.p = &p;
     t.x = x;
@@ -264,8 +283,11 @@ Act mlp_fwd(Ctx& c, MlpTape& t, const alignn_mlp_params& p, const Act& x, int64_
 }
 
 // EdgeGatedGraphConv.forward, alignn/models/alignn.py:78-129  (ops.EdgeGatedConvFn.forward, BatchNorm / training)
+void conv_fwd_ln(Ctx& c, ConvTape& t, const alignn_conv_params& p, const alignn_graph_csr& g, const Act& x, const Act& y,
+                 bool need_y);
 void conv_fwd(Ctx& c, ConvTape& t, const alignn_conv_params& p, const alignn_graph_csr& g, const Act& x, const Act& y,
               bool need_y) {
+    if (c.d->norm == 1) return conv_fwd_ln(c, t, p, g, x, y, need_y);
     const int H = c.d->H, Kin = H;
     const int64_t n = g.n, m = g.m;
     t.p = &p;
@@ -346,13 +368,95 @@ void conv_fwd(Ctx& c, ConvTape& t, const alignn_conv_params& p, const alignn_gra
     t.y_out = yo;
 }
 
+// ---- LayerNorm flavour (ALIGNNAtomWise: alignn/models/alignn_atomwise.py:127-208 EdgeGatedGraphConv, alignn/models/utils.py:277-292
+// MLPLayer): per-row statistics, no grid-wide dependency, stat = [rows, 2] (mean, rstd).  ops.MLPLayerFn / ops.EdgeGatedConvFn
+// with norm == "layer", launch for launch.
+Act mlp_fwd_ln(Ctx& c, MlpTape& t, const alignn_mlp_params& p, const Act& x, int64_t rows) {
+    const int F = p.out, K = p.in;
+    t.p = &p;
+    t.x = x;
+    t.rows = rows;
+    t.lane = c.T != c.main && rows >= c.d->lane_min_rows;
+    hipStream_t st = t.lane ? c.T : c.main;
+    if (t.lane != x.on_T) c.sync(st, x.on_T ? c.T : c.main);
+    t.pre = c.alloc((size_t)rows * F);
+    project(c, x.p, K, x.amax, p.W, K, p.img, p.w_amax, p.b, t.pre, F, rows, F, K, st);
+    t.stat = c.alloc((size_t)rows * 2);
+    Act y;
+    y.p = c.alloc((size_t)rows * F);
+    y.amax = c.track(rows) ? c.new_amax() : nullptr;
+    L(alignn_ln_silu_fwd(t.pre, F, nullptr, 0, p.gamma, p.beta, c.d->eps, y.p, F, t.stat, rows, F, y.amax, st));
+    y.on_T = t.lane;
+    t.y = y;
+    return y;
+}
+
+void conv_fwd_ln(Ctx& c, ConvTape& t, const alignn_conv_params& p, const alignn_graph_csr& g, const Act& x, const Act& y,
+                 bool need_y) {
+    const int H = c.d->H, Kin = H;
+    const int64_t n = g.n, m = g.m;
+    t.p = &p;
+    t.g = &g;
+    t.x = x;
+    t.y = y;
+    t.need_y = need_y;
+    t.lane = c.T != c.main && m >= c.d->lane_min_rows;
+    hipStream_t main = c.main, T = t.lane ? c.T : c.main;
+    if (x.on_T) c.sync(main, c.T);
+    if (!t.lane && y.on_T) c.sync(main, c.T);
+    t.P = c.alloc((size_t)n * 4 * H);
+    project(c, x.p, Kin, x.amax, p.wcat, Kin, p.wcat_img, p.wcat_amax, p.bcat, t.P, 4 * H, n, 4 * H, Kin, main);
+    t.xpre = c.alloc((size_t)n * H);
+    t.s0 = c.alloc((size_t)n * H);
+    t.hh = c.alloc((size_t)n * H);
+    t.M = c.alloc((size_t)m * H);
+    const bool x6 = x6_shape_ok(c, m, Kin, H, Kin);
+    const bool pre_added = y.amax != nullptr && x6;  // u_add_v in the edge projection's epilogue (no statistics to take)
+    if (!pre_added && x6) UNSUP();                   // (bf16x6 scheme: per-operator path)
+    if (t.lane) c.sync(T, main);
+    if (pre_added) {
+        if (p.weg_img == nullptr) {
+            UNSUP();
+            return;
+        }
+        if (c.d->bd_segment_table && g.seg_node != nullptr && g.seg_rank != nullptr) {
+            float* bd2 = c.alloc((size_t)n * H);
+            L(alignn_gather_rows_ld(t.P + H, 4 * H, g.seg_node, bd2, H, n, H, T));
+            L(alignn_gemm_nt_f16x3_gather2(y.p, Kin, y.amax, p.weg_img, p.weg_amax, p.b_eg, t.M, H, m, H, Kin, t.P, 4 * H, g.src,
+                                           bd2, H, g.seg_rank, nullptr, T));
+        } else
+            L(alignn_gemm_nt_f16x3_gather(y.p, Kin, y.amax, p.weg_img, p.weg_amax, p.b_eg, t.M, H, m, H, Kin, t.P, 4 * H, g.src,
+                                          g.dst, nullptr, T));
+        L(alignn_egc_gate_fwd_pre(t.P, t.M, g.seg_ptr, g.seg_node, g.src, n, m, H, t.xpre, t.s0, t.hh, nullptr, nullptr, T));
+    } else {
+        L(alignn_gemm_nt(y.p, Kin, p.w_eg, Kin, p.b_eg, nullptr, 0, t.M, H, m, H, Kin, T));
+        L(alignn_egc_gate_fwd(t.P, t.M, g.seg_ptr, g.seg_node, g.src, n, m, H, t.xpre, t.s0, t.hh, nullptr, nullptr, T));
+    }
+    if (t.lane) c.sync(main, T);
+    Act yo;
+    if (need_y) {
+        yo.p = c.alloc((size_t)m * H);
+        yo.amax = c.track(m) ? c.new_amax() : nullptr;
+        t.e_stat = c.alloc((size_t)m * 2);
+        L(alignn_ln_silu_fwd(t.M, H, y.p, Kin, p.e_gamma, p.e_beta, c.d->eps, yo.p, H, t.e_stat, m, H, yo.amax, T));
+        yo.on_T = t.lane;
+    }
+    t.n_stat = c.alloc((size_t)n * 2);
+    Act xo;
+    xo.p = c.alloc((size_t)n * H);
+    xo.amax = c.track(n) ? c.new_amax() : nullptr;
+    L(alignn_ln_silu_fwd(t.xpre, H, x.p, Kin, p.n_gamma, p.n_beta, c.d->eps, xo.p, H, t.n_stat, n, H, xo.amax, main));
+    t.x_out = xo;
+    t.y_out = yo;
+}
+
 int conv_count(const alignn_model_desc& d) { return 2 * d.alignn_layers + d.gcn_layers; }
 
 // the arguments both directions of the fused angle embedding share; the three small buffers live on the forward tape
 alignn_angle_args angle_args(Ctx& c, const Tape& tp) {
     const alignn_model_desc& d = *c.d;
     alignn_angle_args a{};
-    a.h = c.b->h;
+    a.h = tp.hcos;
     a.rows = c.b->lg.m;
     a.centers = d.angle_centers;
     a.gamma = d.angle_gamma;
@@ -381,10 +485,19 @@ void run_forward(Ctx& c, Tape& tp, float* out) {
         hipLaunchKernelGGL(bump_kernel, dim3((d.n_bump + 63) / 64), dim3(64), 0, c.main, (int64_t* const*)d.bump_ptrs, d.n_bump);
         c.rc = (int)hipGetLastError();
     }
+    // ---- bond-angle cosines: the loader's lg.edata["h"], or - force field with lg_on_fly - recomputed from the bond vectors
+    // (compute_bond_cosines inside the forward, alignn_atomwise.py:424-431: the cosines then carry a gradient w.r.t. r)
+    tp.hcos = b.h;
+    if (c.ff != nullptr && c.ff->lg_on_fly) {
+        tp.hcos_buf = c.alloc((size_t)Tn);
+        L(alignn_bond_cosine_fwd(b.r, b.lg.src, b.lg.dst, tp.hcos_buf, Tn, c.main));
+        tp.hcos = tp.hcos_buf;
+    }
     c.sync(c.T, c.main);  // parameters, weight images, the zeroed arena
     // ---- angle embedding (T rows: lane T), alignn.py:215-222
     Act z;
-    tp.angle_fused = d.angle_fused != 0 && Tn > 0 && alignn_angle_embed_supported(d.angle_bins, d.angle1.out, d.angle2.out) != 0;
+    tp.angle_fused = d.norm == 0 && d.angle_fused != 0 && Tn > 0 &&
+                     alignn_angle_embed_supported(d.angle_bins, d.angle1.out, d.angle2.out) != 0;
     if (tp.angle_fused) {  // recomputing passes: nothing T x bins / T x 64 / T x 256 but z itself is written (csrc/angle.hip)
         tp.angle_lane = c.T != c.main && Tn >= d.lane_min_rows;
         hipStream_t st = tp.angle_lane ? c.T : c.main;
@@ -402,7 +515,7 @@ void run_forward(Ctx& c, Tape& tp, float* out) {
         L(alignn_angle_embed_fwd(&a, st));
     } else {
         tp.rbf_a = c.alloc((size_t)Tn * d.angle_bins);
-        L(alignn_rbf_fwd(b.h, d.angle_centers, d.angle_gamma, tp.rbf_a, Tn, d.angle_bins, c.main));
+        L(alignn_rbf_fwd(tp.hcos, d.angle_centers, d.angle_gamma, tp.rbf_a, Tn, d.angle_bins, c.main));
         Act za;
         za.p = tp.rbf_a;
         z = mlp_fwd(c, tp.a2, d.angle2, mlp_fwd(c, tp.a1, d.angle1, za, Tn), Tn);
@@ -522,7 +635,9 @@ void col_sum(Ctx& c, const float* x, int64_t ldx, int64_t rows, int F, float* ou
 hipStream_t side_for(Ctx& c, int64_t rows) { return (c.side != c.main && rows >= c.d->side_min_rows) ? c.side : c.main; }
 
 // ops.MLPLayerFn.backward
+Grad mlp_bwd_ln(Ctx& c, const MlpTape& t, const Grad& gy, bool need_gx);
 Grad mlp_bwd(Ctx& c, const MlpTape& t, const Grad& gy, bool need_gx) {
+    if (c.d->norm == 1) return mlp_bwd_ln(c, t, gy, need_gx);
     const alignn_mlp_params& p = *t.p;
     const int F = p.out, K = p.in;
     const int64_t rows = t.rows;
@@ -564,7 +679,9 @@ Grad mlp_bwd(Ctx& c, const MlpTape& t, const Grad& gy, bool need_gx) {
 }
 
 // ops.EdgeGatedConvFn.backward: -> gradients w.r.t. the node and edge inputs
-void conv_bwd(Ctx& c, const ConvTape& t, const Grad& gx_out, const Grad* gy_out, Grad& g_x, Grad& g_y) {
+void conv_bwd_ln(Ctx& c, const ConvTape& t, const Grad& gx_out, const Grad* gy_out, Grad& g_x, Grad& g_y, bool need_gx);
+void conv_bwd(Ctx& c, const ConvTape& t, const Grad& gx_out, const Grad* gy_out, Grad& g_x, Grad& g_y, bool need_gx = true) {
+    if (c.d->norm == 1) return conv_bwd_ln(c, t, gx_out, gy_out, g_x, g_y, need_gx);
     const alignn_conv_params& p = *t.p;
     const alignn_graph_csr& g = *t.g;
     const int H = c.d->H, Kin = H;
@@ -644,6 +761,118 @@ void conv_bwd(Ctx& c, const ConvTape& t, const Grad& gx_out, const Grad* gy_out,
     col_sum(c, GP, 4 * H, n, 4 * H, p.g_bcat, sd);
 }
 
+// ops.MLPLayerFn.backward, norm == "layer"
+Grad mlp_bwd_ln(Ctx& c, const MlpTape& t, const Grad& gy, bool need_gx) {
+    const alignn_mlp_params& p = *t.p;
+    const int F = p.out, K = p.in;
+    const int64_t rows = t.rows;
+    hipStream_t st = t.lane ? c.T : c.main;
+    if (t.lane != gy.on_T) c.sync(st, gy.on_T ? c.T : c.main);
+    float* gpre = c.alloc((size_t)rows * F);
+    float* g_amax = c.track(rows) ? c.new_amax() : nullptr;
+    const int slabs = alignn_ln_slabs(rows);
+    float* part = c.alloc((size_t)slabs * 2 * F);
+    L(alignn_ln_silu_bwd(gy.p, F, t.pre, F, p.gamma, p.beta, t.stat, gpre, F, part, rows, F, g_amax, st));
+    if (c.param_grads) L(alignn_bn_bwd_finalize(part, slabs, F, p.red, st));
+    Grad gx;
+    if (need_gx) {
+        gx.p = c.alloc((size_t)rows * K);
+        gx.on_T = t.lane;
+        dgrad(c, gpre, F, g_amax, p.W, F, K, p.img_t, p.w_amax, nullptr, 0, gx.p, rows, st, nullptr, nullptr);
+    }
+    if (!c.param_grads) return gx;
+    hipStream_t sd = side_for(c, rows);
+    if (sd != st) {
+        c.sync(sd, c.main);
+        if (t.lane) c.sync(sd, c.T);
+    }
+    c.tmp_reset(sd);
+    gemm_tn(c, gpre, F, g_amax, t.x.p, K, t.x.amax, p.gW, rows, F, K, sd);
+    col_sum(c, gpre, F, rows, F, p.gb, sd);
+    return gx;
+}
+
+// ops.EdgeGatedConvFn.backward, norm == "layer".  need_gx == false: nobody reads the gradient of the node input (the first
+// convolution of the force evaluation: the atom features are data)
+void conv_bwd_ln(Ctx& c, const ConvTape& t, const Grad& gx_out, const Grad* gy_out, Grad& g_x, Grad& g_y, bool need_gx) {
+    const alignn_conv_params& p = *t.p;
+    const alignn_graph_csr& g = *t.g;
+    const int H = c.d->H, Kin = H;
+    const int64_t n = g.n, m = g.m;
+    hipStream_t main = c.main, T = t.lane ? c.T : c.main;
+    if (gx_out.on_T) c.sync(main, c.T);
+    if (!t.lane && gy_out != nullptr && gy_out->on_T) c.sync(main, c.T);
+    float* GP = c.alloc((size_t)n * 4 * H);
+    float* gp_amax = c.track(n) ? c.new_amax() : nullptr;
+    float* gm_amax = c.track(m) ? c.new_amax() : nullptr;
+    float* g_xpre = GP + 3 * (size_t)H;
+    // ---- node branch: LayerNorm / SiLU backward straight into the Ux block of GP, the quotient's adjoints
+    const int n_slabs = alignn_ln_slabs(n);
+    float* n_part = c.alloc((size_t)n_slabs * 2 * H);
+    L(alignn_ln_silu_bwd(gx_out.p, H, t.xpre, H, p.n_gamma, p.n_beta, t.n_stat, g_xpre, 4 * H, n_part, n, H, gp_amax, main));
+    if (c.param_grads) L(alignn_bn_bwd_finalize(n_part, n_slabs, H, p.n_red, main));
+    float* gs1 = c.alloc((size_t)n * H);
+    float* gs0 = c.alloc((size_t)n * H);
+    L(alignn_egc_node_bwd(g_xpre, 4 * H, t.s0, t.hh, gs1, gs0, n, H, main));
+    // ---- edge branch (lane T for the line graph): the finished normalised-branch gradient, handed over as it is
+    const float* gy = gy_out != nullptr ? gy_out->p : nullptr;
+    if (t.lane && gy_out != nullptr && !gy_out->on_T) c.sync(T, main);
+    float* g_branch = nullptr;
+    if (gy != nullptr) {
+        g_branch = c.alloc((size_t)m * H);
+        const int e_slabs = alignn_ln_slabs(m);
+        float* e_part = c.alloc((size_t)e_slabs * 2 * H);
+        L(alignn_ln_silu_bwd(gy, H, t.M, H, p.e_gamma, p.e_beta, t.e_stat, g_branch, H, e_part, m, H, nullptr, T));
+        if (c.param_grads) L(alignn_bn_bwd_finalize(e_part, e_slabs, H, p.e_red, T));
+    }
+    if (t.lane) c.sync(T, main);
+    float* GM = c.alloc((size_t)m * H);
+    const bool lg_blocks = g.grp_seg_ptr != nullptr;
+    const bool dense = lg_blocks && g.dense_max_src > 0 && alignn_egc_bwd_lg_dense_supported(g.dense_max_src);
+    const int gslabs = lg_blocks ? (int)g.n_groups : alignn_egc_slabs(n);
+    float* gb_part = c.alloc((size_t)gslabs * H);
+    if (dense)
+        L(alignn_egc_bwd_lg_dense(g_branch, t.M, t.P, gs1, gs0, nullptr, nullptr, 0, m, g.grp_seg_ptr, g.grp_src_ptr, g.n_groups,
+                                  g.dense_max_src, g.seg_ptr, g.seg_node, H, GM, GP, gb_part, gm_amax, gp_amax, T));
+    else if (lg_blocks)
+        L(alignn_egc_bwd_lg_fused(g_branch, t.M, t.P, gs1, gs0, nullptr, nullptr, 0, m, g.grp_seg_ptr, g.grp_src_ptr, g.n_groups,
+                                  g.seg_ptr, g.seg_node, g.dst, g.out_ptr, g.out_slot, H, GM, GP, gb_part, gm_amax, gp_amax, T));
+    else {
+        L(alignn_egc_bwd_dst(g_branch, t.M, t.P, gs1, gs0, nullptr, p.e_gamma, nullptr, 0, m, g.seg_ptr, g.seg_node, g.src, n, H, GM,
+                             GP, gb_part, gm_amax, gp_amax, T));
+        L(alignn_egc_bwd_src(GM, t.M, gs1, g.out_ptr, g.out_slot, g.dst, n, H, GP, gp_amax, T));
+    }
+    if (t.lane) c.sync(main, T);
+    // ---- input gradients
+    g_y.p = c.alloc((size_t)m * Kin);
+    hipStream_t sx = main;
+    if (need_gx) {
+        g_x.p = c.alloc((size_t)n * Kin);
+        if (!t.lane && c.aux != main) {
+            c.sync(c.aux, main);
+            sx = c.aux;
+        }
+        dgrad(c, GP, 4 * H, gp_amax, p.wcat, 4 * H, Kin, p.wcat_img_t, p.wcat_amax, gx_out.p, H, g_x.p, n, sx, nullptr, nullptr);
+    }
+    dgrad(c, GM, H, gm_amax, p.w_eg, H, Kin, p.weg_img_t, p.weg_amax, gy, H, g_y.p, m, T, nullptr, nullptr);
+    g_y.on_T = t.lane;
+    g_x.on_T = false;
+    if (sx != main) c.sync(main, sx);
+    if (!c.param_grads) return;
+    // ---- weight / bias gradients
+    hipStream_t sd = side_for(c, m);
+    if (sd != main) {
+        c.sync(sd, main);
+        if (t.lane) c.sync(sd, c.T);
+    } else if (t.lane)
+        c.sync(main, c.T);
+    c.tmp_reset(sd);
+    L(alignn_slab_sum(gb_part, gslabs, H, p.g_beg, sd));
+    gemm_tn(c, GM, H, gm_amax, t.y.p, Kin, t.y.amax, p.g_weg, m, H, Kin, sd);
+    gemm_tn(c, GP, 4 * H, gp_amax, t.x.p, Kin, t.x.amax, p.g_wcat, n, 4 * H, Kin, sd);
+    col_sum(c, GP, 4 * H, n, 4 * H, p.g_bcat, sd);
+}
+
 void run_backward(Ctx& c, const Tape& tp, const float* g_out) {
     const alignn_model_desc& d = *c.d;
     const alignn_model_batch& b = *c.b;
@@ -657,14 +886,16 @@ void run_backward(Ctx& c, const Tape& tp, const float* g_out) {
     // ---- fc (ops.LinearFn.backward) and the pooling
     float* g_pool = c.alloc((size_t)B * H);
     dgrad(c, g_out, OF, nullptr, d.fc_W, OF, H, nullptr, nullptr, nullptr, 0, g_pool, B, c.main, nullptr, nullptr);
-    c.tmp_reset(c.main);
-    gemm_tn(c, g_out, OF, nullptr, tp.pool, H, nullptr, d.g_fc_W, B, OF, H, c.main);
-    if ((OF % 4) == 0)
-        col_sum(c, g_out, OF, B, OF, d.g_fc_b, c.main);
-    else {  // e.g. the 1-wide readout: gb[n] = (gy^T ones)[n]
-        float* ones = c.alloc((size_t)B);
-        fill(c, ones, B, 1.0f, c.main);
-        gemm_tn(c, g_out, OF, nullptr, ones, 1, nullptr, d.g_fc_b, B, OF, 1, c.main);
+    if (c.param_grads) {
+        c.tmp_reset(c.main);
+        gemm_tn(c, g_out, OF, nullptr, tp.pool, H, nullptr, d.g_fc_W, B, OF, H, c.main);
+        if ((OF % 4) == 0)
+            col_sum(c, g_out, OF, B, OF, d.g_fc_b, c.main);
+        else {  // e.g. the 1-wide readout: gb[n] = (gy^T ones)[n]
+            float* ones = c.alloc((size_t)B);
+            fill(c, ones, B, 1.0f, c.main);
+            gemm_tn(c, g_out, OF, nullptr, ones, 1, nullptr, d.g_fc_b, B, OF, 1, c.main);
+        }
     }
     Grad gx;
     gx.p = c.alloc((size_t)N * H);
@@ -681,6 +912,8 @@ void run_backward(Ctx& c, const Tape& tp, const float* g_out) {
         have_gy = true;
         if (c.unsupported) return;
     }
+    // the cosines carry a gradient w.r.t. the bond vectors only when the forward recomputed them from r
+    const bool angle_geom = c.geom && c.ff != nullptr && c.ff->lg_on_fly;
     for (int i = d.alignn_layers - 1; i >= 0; --i) {
         // line-graph convolution: node output = the bond features (gradient gy), edge output = the triplet features (gz)
         Grad gm, nz;
@@ -697,22 +930,26 @@ void run_backward(Ctx& c, const Tape& tp, const float* g_out) {
                 a.workspace_bytes = alignn_angle_embed_workspace(a.rows, d.angle_bins, 1);
                 a.workspace = c.alloc(a.workspace_bytes / sizeof(float));
                 L(alignn_angle_embed_bwd(&a, st));
-            } else {
+            } else if (c.param_grads || angle_geom) {
                 Grad ga = mlp_bwd(c, tp.a2, gz, true);
-                mlp_bwd(c, tp.a1, ga, false);
+                Grad gr = mlp_bwd(c, tp.a1, ga, angle_geom);
+                c.g_rbf_a = gr.p;
+                c.g_rbf_a_on_T = gr.on_T;
             }
         }
         Grad nx, ny;
-        conv_bwd(c, tp.convs[k], gx, &gm, nx, ny);
+        // (the atom features are data: without parameter gradients nobody reads the node input gradient of the first convolution)
+        conv_bwd(c, tp.convs[k], gx, &gm, nx, ny, i > 0 || c.param_grads);
         --k;
         gx = nx;
         gy = ny;
         if (c.unsupported) return;
     }
     // ---- embeddings
-    mlp_bwd(c, tp.atom, gx, false);
+    if (c.param_grads) mlp_bwd(c, tp.atom, gx, false);
     Grad ge = mlp_bwd(c, tp.e2, gy, true);
-    mlp_bwd(c, tp.e1, ge, false);
+    Grad gre = mlp_bwd(c, tp.e1, ge, c.geom);
+    c.g_rbf_e = gre.p;
     c.sync(c.main, c.T);
     c.sync(c.main, c.side);
 }
@@ -784,6 +1021,7 @@ void run_infer(Ctx& c, float* out) {
     if (d.angle_fused != 0 && Tn > 0 && alignn_angle_embed_supported(d.angle_bins, d.angle1.out, d.angle2.out) != 0) {
         const bool lane = c.T != c.main && Tn >= d.lane_min_rows;
         Tape tp;
+        tp.hcos = b.h;
         tp.a_stat1 = c.alloc((size_t)4 * d.angle1.out);
         tp.a_stat2 = c.alloc((size_t)4 * d.angle2.out);
         tp.a_scal = c.alloc((size_t)alignn_angle_embed_scal_floats());
@@ -831,6 +1069,335 @@ void run_infer(Ctx& c, float* out) {
     L(alignn_segment_mean_fwd(x.p, b.graph_ptr, pool, b.B, d.H, c.main));
     L(alignn_gemm_nt(pool, d.H, d.fc_W, d.H, d.fc_b, nullptr, 0, out, d.out_features, b.B, d.out_features, d.H, c.main));
     c.sync(c.main, c.T);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// ALIGNNAtomWise with the force / stress head (alignn/models/alignn_atomwise.py:364-660, calculate_gradient=True)
+// ---------------------------------------------------------------------------------------------------------------------
+
+// alignn_ff_eval: energies, forces, stresses as values = the LayerNorm forward with the bond vectors as a leaf + its reverse
+// w.r.t. them (ALIGNNAtomWise._forward_fused(b, True) under ops.no_param_grad: what MD runs and what ForcesFn.forward runs)
+void run_ff_eval(Ctx& c, Tape& tp, float* out, float* forces, float* stress) {
+    const alignn_model_desc& d = *c.d;
+    const alignn_model_batch& b = *c.b;
+    const alignn_ff_desc& f = *c.ff;
+    const int64_t N = b.g.n, E = b.g.m, Tn = b.lg.m;
+    const int B = b.B;
+    c.param_grads = false;
+    c.geom = true;
+    tp.pred = c.alloc((size_t)B);
+    tp.seed = c.alloc((size_t)B);
+    run_forward(c, tp, tp.pred);
+    if (c.unsupported) return;
+    // total energy per crystal (+ the short-bond penalty) and d(sum en_out)/d pred, alignn_atomwise.py:494-510
+    L(alignn_ff_energy(tp.pred, tp.bl, b.graph_ptr, B, E, f.energy_mult_natoms, f.use_penalty, f.penalty_factor, f.penalty_threshold,
+                       out, tp.seed, c.main));
+    run_backward(c, tp, tp.seed);
+    if (c.unsupported) return;
+    // ---- geometry: d/dr of the RBF inputs (bond length; bond cosines when they were recomputed from r)
+    float* g_bl = c.alloc((size_t)E);
+    L(alignn_rbf_bwd(tp.bl, d.edge_centers, d.edge_gamma, c.g_rbf_e, g_bl, E, d.edge_bins, c.main));
+    if (f.use_penalty) L(alignn_ff_penalty_bwd(tp.bl, g_bl, E, B, f.penalty_factor, f.penalty_threshold, c.main));
+    float* gr_bl = c.alloc((size_t)3 * E);
+    L(alignn_norm3_bwd(b.r, g_bl, gr_bl, E, c.main));
+    tp.g_r = gr_bl;
+    if (f.lg_on_fly) {
+        // (run_backward joined lane T into the caller's stream before it returned)
+        float* g_h = c.alloc((size_t)Tn);
+        L(alignn_rbf_bwd(tp.hcos, d.angle_centers, d.angle_gamma, c.g_rbf_a, g_h, Tn, d.angle_bins, c.main));
+        float* ga = c.alloc((size_t)3 * Tn);
+        float* gb = c.alloc((size_t)3 * Tn);
+        L(alignn_bond_cosine_bwd(b.r, b.lg.src, b.lg.dst, g_h, ga, gb, Tn, c.main));
+        // dh/dr[e]: the triplets where e is the first bond (by source of L(g)) + those where it is the second (by destination)
+        float* gra = c.alloc((size_t)3 * E);
+        float* grb = c.alloc((size_t)3 * E);
+        L(alignn_segment_sum(ga, 3, b.lg.out_ptr, b.lg.out_slot, nullptr, gra, 3, E, 3, c.main));
+        L(alignn_segment_sum(gb, 3, b.lg.seg_ptr, nullptr, b.lg.seg_node, grb, 3, E, 3, c.main));
+        tp.g_r = c.alloc((size_t)3 * E);
+        L(alignn_add3(gra, grb, gr_bl, tp.g_r, 3 * E, c.main));
+    }
+    // ---- pair forces -> forces per atom, virial stress per crystal (:530-638)
+    const float scale = f.grad_multiplier * (f.force_mult_natoms ? (float)N : 1.0f);
+    L(alignn_pair_force_reduce(tp.g_r, scale, b.g.seg_ptr, b.g.out_ptr, b.g.out_slot, f.add_reverse_forces, forces, N, c.main));
+    if (stress != nullptr && f.has_stress)
+        L(alignn_virial_stress(b.r, tp.g_r, scale, b.graph_ptr, b.g.seg_ptr, f.volume, f.stress_multiplier * -160.21766208f, stress, B,
+                               c.main));
+}
+
+// ---- the second-order pass (alignn_amd/ff2.py dual_pass, REUSE_FORWARD: tangents only - the values are alignn_ff_eval's tape)
+struct DAct {  // value p and tangent t of one activation + the max|.| scalars their producers tracked (or NULL)
+    float *p = nullptr, *t = nullptr, *amax_p = nullptr, *amax_t = nullptr;
+};
+struct DMlpTape {
+    const alignn_mlp_params* p = nullptr;
+    DAct x, pre;
+    float* stats = nullptr;
+    int64_t rows = 0;
+};
+struct DConvTape {
+    const alignn_conv_params* p = nullptr;
+    const alignn_graph_csr* g = nullptr;
+    DAct x, y, P, M, xpre;
+    float *s0 = nullptr, *hh = nullptr, *s0t = nullptr, *hht = nullptr, *n_stats = nullptr, *e_stats = nullptr;
+    bool need_y = true;
+};
+
+// ff2._ln_fwd with value_out: the tangent of y = res + silu(LayerNorm(x)); the value is `known`
+DAct dual_ln_fwd(Ctx& c, const DAct& x, const DAct* res, const float* gamma, const float* beta, const Act& known, int64_t rows, int F,
+                 float** stats_out) {
+    DAct y;
+    y.p = known.p;
+    y.amax_p = known.amax;
+    y.t = c.alloc((size_t)rows * F);
+    float* stats = c.alloc((size_t)rows * 2);
+    float* amax2 = c.track(rows) ? c.new_amax2() : nullptr;
+    L(alignn_ln_silu_dual_fwd(x.p, x.t, F, res ? res->p : nullptr, res ? res->t : nullptr, res ? F : 0, gamma, beta, c.d->eps, nullptr,
+                              y.t, F, stats, rows, F, amax2, c.main));
+    y.amax_t = amax2 ? amax2 + 1 : nullptr;
+    if (y.amax_p == nullptr && amax2 != nullptr) y.amax_p = amax2;  // (Dual.am(0) falls back to the pair's first scalar)
+    *stats_out = stats;
+    return y;
+}
+
+DAct dual_mlp_fwd(Ctx& c, DMlpTape& t, const alignn_mlp_params& p, const MlpTape& fwd, const DAct& x) {
+    const int F = p.out, K = p.in;
+    const int64_t rows = fwd.rows;
+    t.p = &p;
+    t.x = x;
+    t.rows = rows;
+    t.pre.p = fwd.pre;
+    t.pre.t = c.alloc((size_t)rows * F);
+    project(c, x.t, K, x.amax_t, p.W, K, p.img, p.w_amax, nullptr, t.pre.t, F, rows, F, K, c.main);  // the tangent of x W^T + b
+    return dual_ln_fwd(c, t.pre, nullptr, p.gamma, p.beta, fwd.y, rows, F, &t.stats);
+}
+
+void dual_conv_fwd(Ctx& c, DConvTape& t, const alignn_conv_params& p, const ConvTape& fwd, const DAct& x, const DAct& y, bool need_y,
+                   DAct& x_out, DAct& y_out) {
+    const alignn_graph_csr& g = *fwd.g;
+    const int H = c.d->H, Kin = H;
+    const int64_t n = g.n, m = g.m;
+    t.p = &p;
+    t.g = &g;
+    t.x = x;
+    t.y = y;
+    t.need_y = need_y;
+    t.P.p = fwd.P;
+    t.P.t = c.alloc((size_t)n * 4 * H);
+    project(c, x.t, Kin, x.amax_t, p.wcat, Kin, p.wcat_img, p.wcat_amax, nullptr, t.P.t, 4 * H, n, 4 * H, Kin, c.main);
+    t.M.p = fwd.M;
+    t.M.t = c.alloc((size_t)m * H);
+    project(c, y.t, Kin, y.amax_t, p.w_eg, Kin, p.weg_img, p.weg_amax, nullptr, t.M.t, H, m, H, Kin, c.main);
+    t.xpre.p = fwd.xpre;
+    t.xpre.t = c.alloc((size_t)n * H);
+    t.s0 = fwd.s0;
+    t.hh = fwd.hh;
+    t.s0t = c.alloc((size_t)n * H);
+    t.hht = c.alloc((size_t)n * H);
+    L(alignn_egc_gate_dual_fwd_tangent(t.P.p, t.P.t, t.M.p, t.M.t, g.seg_ptr, g.seg_node, g.src, n, m, H, t.xpre.t, t.s0, t.hh, t.s0t,
+                                       t.hht, c.main));
+    x_out = dual_ln_fwd(c, t.xpre, &x, p.n_gamma, p.n_beta, fwd.x_out, n, H, &t.n_stats);
+    y_out = DAct{};
+    if (need_y) y_out = dual_ln_fwd(c, t.M, &y, p.e_gamma, p.e_beta, fwd.y_out, m, H, &t.e_stats);
+}
+
+// ff2._ln_bwd: (g, gt) -> (gx, gxt) into out_p / out_t (leading dimension ldo); dbeta | dgamma -> red
+DAct dual_ln_bwd(Ctx& c, const DAct& g, const DAct& x, const float* gamma, const float* beta, const float* stats, float* out_p,
+                 float* out_t, int64_t ldo, float* amax2, int64_t rows, int F, float* red) {
+    const int slabs = alignn_dual_slabs(rows);
+    float* partial = c.alloc((size_t)slabs * 2 * F);
+    L(alignn_ln_silu_dual_bwd(g.p, g.t, F, x.p, x.t, F, gamma, beta, stats, out_p, out_t, ldo, partial, rows, F, amax2, c.main));
+    L(alignn_bn_bwd_finalize(partial, slabs, F, red, c.main));
+    DAct o;
+    o.p = out_p;
+    o.t = out_t;
+    o.amax_p = amax2;
+    o.amax_t = amax2 ? amax2 + 1 : nullptr;
+    return o;
+}
+
+// W-bar = g^T x + gt^T xt: the value half into dW, the tangent half into its twin (added once at the end of the call)
+void dual_wgrad(Ctx& c, const DAct& g, int64_t ldg, const DAct& x, int64_t ldx, float* dW, int64_t M, int N, int K, hipStream_t st) {
+    gemm_tn(c, g.p, ldg, g.amax_p, x.p, ldx, x.amax_p, dW, M, N, K, st);
+    gemm_tn(c, g.t, ldg, g.amax_t, x.t, ldx, x.amax_t, dW + c.toff, M, N, K, st);
+}
+
+DAct dual_dgrad(Ctx& c, const DAct& g, int64_t ldg, const float* w, int Nred, int Kout, const void* img_t, const float* w_amax,
+                const DAct* addend, int64_t M) {
+    DAct o;
+    o.p = c.alloc((size_t)M * Kout);
+    o.t = c.alloc((size_t)M * Kout);
+    dgrad(c, g.p, ldg, g.amax_p, w, Nred, Kout, img_t, w_amax, addend ? addend->p : nullptr, Kout, o.p, M, c.main, nullptr, nullptr);
+    dgrad(c, g.t, ldg, g.amax_t, w, Nred, Kout, img_t, w_amax, addend ? addend->t : nullptr, Kout, o.t, M, c.main, nullptr, nullptr);
+    return o;
+}
+
+DAct dual_mlp_bwd(Ctx& c, const DMlpTape& t, const DAct& g, bool need_gx) {
+    const alignn_mlp_params& p = *t.p;
+    const int F = p.out, K = p.in;
+    const int64_t rows = t.rows;
+    float* amax2 = c.track(rows) ? c.new_amax2() : nullptr;
+    float* gp = c.alloc((size_t)rows * F);
+    float* gt = c.alloc((size_t)rows * F);
+    DAct gpre = dual_ln_bwd(c, g, t.pre, p.gamma, p.beta, t.stats, gp, gt, F, amax2, rows, F, p.red);
+    DAct gx;
+    if (need_gx) gx = dual_dgrad(c, gpre, F, p.W, F, K, p.img_t, p.w_amax, nullptr, rows);
+    hipStream_t sd = side_for(c, rows);
+    if (sd != c.main) c.sync(sd, c.main);
+    c.tmp_reset(sd);
+    dual_wgrad(c, gpre, F, t.x, K, p.gW, rows, F, K, sd);
+    col_sum(c, gpre.p, F, rows, F, p.gb, sd);
+    return gx;
+}
+
+// ff2.conv_bwd: adjoints (gx, gy) of the outputs (gy.p == NULL: dead edge output) -> adjoints of the inputs
+void dual_conv_bwd(Ctx& c, const DConvTape& t, const DAct& gx, const DAct& gy, DAct& g_x, DAct& g_y) {
+    const alignn_conv_params& p = *t.p;
+    const alignn_graph_csr& g = *t.g;
+    const int H = c.d->H, Kin = H;
+    const int64_t n = g.n, m = g.m;
+    DAct GP, GM;
+    GP.p = c.alloc((size_t)n * 4 * H);
+    GP.t = c.alloc((size_t)n * 4 * H);
+    GP.amax_p = c.track(n) ? c.new_amax2() : nullptr;
+    GP.amax_t = GP.amax_p ? GP.amax_p + 1 : nullptr;
+    // node branch: LayerNorm / SiLU reverse straight into the Ux blocks
+    DAct gxpre = dual_ln_bwd(c, gx, t.xpre, p.n_gamma, p.n_beta, t.n_stats, GP.p + 3 * (size_t)H, GP.t + 3 * (size_t)H, 4 * H, GP.amax_p,
+                             n, H, p.n_red);
+    float* q1 = c.alloc((size_t)n * H);
+    float* q0 = c.alloc((size_t)n * H);
+    float* q1t = c.alloc((size_t)n * H);
+    float* q0t = c.alloc((size_t)n * H);
+    L(alignn_egc_node_dual_bwd(gxpre.p, gxpre.t, 4 * H, t.s0, t.hh, t.s0t, t.hht, q1, q0, q1t, q0t, n, H, c.main));
+    DAct GL;
+    if (gy.p != nullptr) {
+        float* amax2 = c.track(m) ? c.new_amax2() : nullptr;
+        float* lp = c.alloc((size_t)m * H);
+        float* lt = c.alloc((size_t)m * H);
+        GL = dual_ln_bwd(c, gy, t.M, p.e_gamma, p.e_beta, t.e_stats, lp, lt, H, amax2, m, H, p.e_red);
+    }
+    GM.p = c.alloc((size_t)m * H);
+    GM.t = c.alloc((size_t)m * H);
+    GM.amax_p = c.track(m) ? c.new_amax2() : nullptr;
+    GM.amax_t = GM.amax_p ? GM.amax_p + 1 : nullptr;
+    const bool dense = c.ff->dense_lg_reverse && g.grp_seg_ptr != nullptr && g.dense_max_src > 0;
+    int slabs;
+    float* gb_part;
+    if (dense) {  // line graph: destination- and source-ordered halves in one pass over the dense blocks
+        slabs = (int)g.n_groups;
+        gb_part = c.alloc((size_t)slabs * H);
+        L(alignn_egc_dual_bwd_lg_dense(GL.p, GL.t, t.M.p, t.M.t, t.P.p, t.P.t, q1, q0, q1t, q0t, m, g.grp_seg_ptr, g.grp_src_ptr, slabs,
+                                       g.seg_ptr, g.seg_node, H, GM.p, GM.t, GP.p, GP.t, gb_part, GM.amax_p, GP.amax_p, c.main));
+    } else {
+        slabs = alignn_dual_slabs(n);
+        gb_part = c.alloc((size_t)slabs * H);
+        L(alignn_egc_dual_bwd_dst(GL.p, GL.t, t.M.p, t.M.t, t.P.p, t.P.t, q1, q0, q1t, q0t, g.seg_ptr, g.seg_node, g.src, n, H, GM.p, GM.t,
+                                  GP.p, GP.t, gb_part, GM.amax_p, GP.amax_p, c.main));
+        L(alignn_egc_dual_bwd_src(GM.p, GM.t, t.M.p, t.M.t, q1, q1t, g.out_ptr, g.out_slot, g.dst, n, H, GP.p, GP.t, GP.amax_p, c.main));
+    }
+    g_x = dual_dgrad(c, GP, 4 * H, p.wcat, 4 * H, Kin, p.wcat_img_t, p.wcat_amax, &gx, n);
+    g_y = dual_dgrad(c, GM, H, p.w_eg, H, Kin, p.weg_img_t, p.weg_amax, gy.p != nullptr ? &gy : nullptr, m);
+    hipStream_t sd = side_for(c, m);
+    if (sd != c.main) c.sync(sd, c.main);
+    c.tmp_reset(sd);
+    dual_wgrad(c, GP, 4 * H, t.x, Kin, p.g_wcat, n, 4 * H, Kin, sd);
+    col_sum(c, GP.p, 4 * H, n, 4 * H, p.g_bcat, sd);
+    dual_wgrad(c, GM, H, t.y, Kin, p.g_weg, m, H, Kin, sd);
+    L(alignn_slab_sum(gb_part, slabs, H, p.g_beg, sd));
+}
+
+void run_ff_dual(Ctx& c, const Tape& tp, const float* g_out, const float* g_forces, const float* g_stress) {
+    const alignn_model_desc& d = *c.d;
+    const alignn_model_batch& b = *c.b;
+    const alignn_ff_desc& f = *c.ff;
+    const int64_t N = b.g.n, E = b.g.m, Tn = b.lg.m;
+    const int H = d.H, B = b.B;
+    c.param_grads = true;
+    c.amax_arena = c.alloc(kAmaxSlots);
+    c.amax_next = 0;
+    fill(c, c.amax_arena, kAmaxSlots, 0.0f, c.main);
+    c.sync(c.side, c.main);
+    // ---- w = dL/d(pair forces), the tangent direction rt = w / 2^k, the tangents of the geometry features
+    float* wmax = c.new_amax();
+    float* w = c.alloc((size_t)3 * E);
+    L(alignn_ff_pair_weights(g_forces, f.has_stress ? g_stress : nullptr, b.r, b.g.src, b.g.dst, b.graph_ptr, b.g.seg_ptr, f.volume,
+                             f.stress_multiplier * -160.21766208f, f.add_reverse_forces, B, E, w, wmax, c.main));
+    float* rt = c.alloc((size_t)3 * E);
+    float* dt = c.alloc((size_t)E);
+    L(alignn_ff_tangent_geometry(b.r, w, wmax, tp.bl, rt, dt, E, c.main));
+    const float cc = f.grad_multiplier * (f.force_mult_natoms ? (float)N : 1.0f);
+    // ---- dual forward (tangents only)
+    std::vector<DMlpTape> mt(5);
+    std::vector<DConvTape> ct(conv_count(d));
+    DAct xa;
+    xa.p = const_cast<float*>(b.atom_features);
+    xa.t = c.alloc((size_t)N * d.atom_in);
+    fill(c, xa.t, N * d.atom_in, 0.0f, c.main);
+    DAct x = dual_mlp_fwd(c, mt[0], d.atom, tp.atom, xa);
+    DAct ye;
+    ye.p = tp.rbf_e;
+    ye.t = c.alloc((size_t)E * d.edge_bins);
+    L(alignn_rbf_tangent(tp.bl, dt, d.edge_centers, d.edge_gamma, ye.t, E, d.edge_bins, c.main));
+    DAct y = dual_mlp_fwd(c, mt[2], d.edge2, tp.e2, dual_mlp_fwd(c, mt[1], d.edge1, tp.e1, ye));
+    float* ht = c.alloc((size_t)Tn);
+    if (f.lg_on_fly)
+        L(alignn_bond_cosine_tangent(b.r, rt, b.lg.src, b.lg.dst, ht, Tn, c.main));
+    else
+        fill(c, ht, Tn, 0.0f, c.main);
+    DAct za;
+    za.p = tp.rbf_a;
+    za.t = c.alloc((size_t)Tn * d.angle_bins);
+    L(alignn_rbf_tangent(tp.hcos, ht, d.angle_centers, d.angle_gamma, za.t, Tn, d.angle_bins, c.main));
+    DAct z = dual_mlp_fwd(c, mt[4], d.angle2, tp.a2, dual_mlp_fwd(c, mt[3], d.angle1, tp.a1, za));
+    if (c.unsupported) return;
+    int k = 0;
+    for (int i = 0; i < d.alignn_layers; ++i) {
+        DAct xo, mo, yo, zo;
+        dual_conv_fwd(c, ct[k], d.convs[k], tp.convs[k], x, y, true, xo, mo);
+        ++k;
+        dual_conv_fwd(c, ct[k], d.convs[k], tp.convs[k], mo, z, i + 1 < d.alignn_layers, yo, zo);
+        ++k;
+        x = xo, y = yo, z = zo;
+        if (c.unsupported) return;
+    }
+    for (int i = 0; i < d.gcn_layers; ++i) {
+        DAct xo, yo;
+        dual_conv_fwd(c, ct[k], d.convs[k], tp.convs[k], x, y, i + 1 < d.gcn_layers, xo, yo);
+        ++k;
+        x = xo, y = yo;
+        if (c.unsupported) return;
+    }
+    // ---- readout E_g = fc(mean_i x_i) (alignn_atomwise.py:464-466) and its reverse with the two seeds
+    float* hpt = c.alloc((size_t)B * H);
+    L(alignn_segment_mean_fwd(x.t, b.graph_ptr, hpt, B, H, c.main));
+    L(alignn_ff_fc_grad(g_out, cc, f.energy_mult_natoms, wmax, b.graph_ptr, tp.pool, hpt, d.g_fc_W, d.g_fc_b, B, H, c.main));
+    DAct gx, gy, gz;
+    gx.p = c.alloc((size_t)N * H);
+    gx.t = c.alloc((size_t)N * H);
+    L(alignn_ff_readout_seed(g_out, cc, f.energy_mult_natoms, wmax, b.graph_ptr, d.fc_W, gx.p, gx.t, B, N, H, c.main));
+    // ---- reverse over the tape
+    k = conv_count(d) - 1;
+    for (int i = d.gcn_layers - 1; i >= 0; --i, --k) {
+        DAct nx, ny;
+        dual_conv_bwd(c, ct[k], gx, gy, nx, ny);
+        gx = nx, gy = ny;
+        if (c.unsupported) return;
+    }
+    for (int i = d.alignn_layers - 1; i >= 0; --i) {
+        DAct gm, nz, nx, ny;
+        dual_conv_bwd(c, ct[k], gy, gz, gm, nz);  // edge_update: nodes = bonds, edges = triplets
+        --k;
+        gz = nz;
+        dual_conv_bwd(c, ct[k], gx, gm, nx, ny);  // node_update: outputs (x, m)
+        --k;
+        gx = nx, gy = ny;
+        if (c.unsupported) return;
+    }
+    DAct gz1 = dual_mlp_bwd(c, mt[4], gz, true);
+    dual_mlp_bwd(c, mt[3], gz1, false);
+    DAct gy1 = dual_mlp_bwd(c, mt[2], gy, true);
+    dual_mlp_bwd(c, mt[1], gy1, false);
+    dual_mlp_bwd(c, mt[0], gx, false);
+    c.sync(c.main, c.side);
 }
 
 bool desc_ok(const alignn_model_desc* d, const alignn_model_batch* b) {
@@ -887,9 +1454,99 @@ Plan make_plan(const alignn_model_desc* d, const alignn_model_batch* b, alignn_s
     return pl;
 }
 
+bool ff_ok(const alignn_model_desc* d, const alignn_model_batch* b, const alignn_ff_desc* f) {
+    if (!desc_ok(d, b) || f == nullptr || d->norm != 1 || d->out_features != 1) return false;
+    if (b->g.out_ptr == nullptr || b->g.out_slot == nullptr || b->lg.out_ptr == nullptr || b->lg.out_slot == nullptr) return false;
+    if (f->has_stress && f->volume == nullptr) return false;
+    if (!f->lg_on_fly && b->h == nullptr) return false;
+    return true;
+}
+
+Plan make_ff_plan(const alignn_model_desc* d, const alignn_model_batch* b, const alignn_ff_desc* f, alignn_stream_t stream) {
+    Plan pl;
+    Ctx c{d, b, reinterpret_cast<char*>(4096)};
+    c.ff = f;
+    set_streams(c, stream);
+    Tape tp;
+    run_ff_eval(c, tp, nullptr, nullptr, nullptr);
+    pl.fwd_persist = c.off;
+    for (int i = 0; i < 4; ++i) pl.peak_fwd[i] = c.speak[i];
+    if (!c.unsupported) run_ff_dual(c, tp, nullptr, nullptr, nullptr);
+    pl.all_persist = c.off;
+    for (int i = 0; i < 4; ++i) pl.peak_all[i] = c.speak[i];
+    pl.unsupported = c.unsupported;
+    pl.line = c.unsupported_line;
+    pl.rc = c.rc;
+    return pl;
+}
+
 }  // namespace
 
 extern "C" {
+
+size_t alignn_ff_desc_sizeof(void) { return sizeof(alignn_ff_desc); }
+
+int alignn_ff_plan(const alignn_model_desc* d, const alignn_model_batch* b, const alignn_ff_desc* f, size_t* eval_bytes,
+                   size_t* total_bytes) {
+    if (!ff_ok(d, b, f) || eval_bytes == nullptr || total_bytes == nullptr) return (int)hipErrorInvalidValue;
+    Plan pl = make_ff_plan(d, b, f, nullptr);
+    if (pl.unsupported) {
+        if (getenv("ALIGNN_AMD_DEBUG")) fprintf(stderr, "alignn_ff_plan: kernel choice not carried (model.hip:%d)\n", pl.line);
+        return (int)hipErrorNotSupported;
+    }
+    *eval_bytes = pl.fwd_total();
+    *total_bytes = pl.total();
+    return pl.rc;
+}
+
+int alignn_ff_eval(const alignn_model_desc* d, const alignn_model_batch* b, const alignn_ff_desc* f, void* workspace,
+                   size_t workspace_bytes, float* out, float* forces, float* stress, alignn_stream_t stream) {
+    if (!ff_ok(d, b, f) || workspace == nullptr || out == nullptr || forces == nullptr) return (int)hipErrorInvalidValue;
+    const Plan pl = make_ff_plan(d, b, f, stream);
+    if (pl.unsupported) return (int)hipErrorNotSupported;
+    Ctx c{d, b, static_cast<char*>(workspace)};
+    c.cap = workspace_bytes;
+    c.launch = true;
+    c.ff = f;
+    set_streams(c, stream);
+    if (workspace_bytes >= pl.total())
+        pl.place_scratch(c, true);
+    else if (workspace_bytes >= pl.fwd_total())
+        pl.place_scratch(c, false);  // (values only: MD, validation)
+    else
+        return (int)hipErrorInvalidValue;
+    if ((c.T != c.main || c.side != c.main || c.aux != c.main) && !take_pool(c)) return (int)hipErrorNotInitialized;
+    Tape tp;
+    run_ff_eval(c, tp, out, forces, stress);
+    if (c.unsupported) return (int)hipErrorNotSupported;
+    return c.rc;
+}
+
+int alignn_ff_grad(const alignn_model_desc* d, const alignn_model_batch* b, const alignn_ff_desc* f, void* workspace,
+                   size_t workspace_bytes, const float* g_out, const float* g_forces, const float* g_stress, float* gflat,
+                   float* gflat_t, int64_t grad_floats, alignn_stream_t stream) {
+    if (!ff_ok(d, b, f) || workspace == nullptr || gflat == nullptr || gflat_t == nullptr || grad_floats <= 0 || (grad_floats & 3))
+        return (int)hipErrorInvalidValue;
+    const Plan pl = make_ff_plan(d, b, f, stream);
+    if (pl.unsupported) return (int)hipErrorNotSupported;
+    if (workspace_bytes < pl.total()) return (int)hipErrorInvalidValue;
+    Ctx c{d, b, static_cast<char*>(workspace)};
+    c.cap = workspace_bytes;
+    c.ff = f;
+    set_streams(c, stream);
+    pl.place_scratch(c, true);
+    if ((c.T != c.main || c.side != c.main || c.aux != c.main) && !take_pool(c)) return (int)hipErrorNotInitialized;
+    Tape tp;
+    run_ff_eval(c, tp, nullptr, nullptr, nullptr);  // (plan only: where the evaluation left its tape)
+    if (c.unsupported) return (int)hipErrorNotSupported;
+    c.launch = true;
+    c.toff = gflat_t - gflat;
+    fill(c, gflat_t, grad_floats, 0.0f, c.main);  // (only the weight blocks get a tangent half)
+    run_ff_dual(c, tp, g_out, g_forces, g_stress);
+    if (c.unsupported) return (int)hipErrorNotSupported;
+    if (c.rc == 0) c.rc = alignn_add_inplace(gflat, gflat_t, grad_floats, c.main);
+    return c.rc;
+}
 
 int alignn_model_init(void) {
     int dev = -1;

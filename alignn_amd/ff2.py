@@ -284,21 +284,23 @@ def conv_bwd(entry, gx: Dual, gy, grads: _Grads):
 # geometry features and their tangents (a few element-wise operations on [E,3] / [T,3] / [T,bins] tensors)
 # ---------------------------------------------------------------------------------------------
 def _rbf_dual(d, dt, mod):
-    diff = d.unsqueeze(1) - mod.centers
-    val = torch.exp(-mod.gamma * diff * diff)
-    return Dual(val, val * (-2.0 * mod.gamma) * diff * dt.unsqueeze(1))
+    """(RBF expansion of d - the kernel the forward used -, its tangent along dt)"""
+    lib = _lib.load()
+    d = d.contiguous()
+    val = ops._rbf_raw(d, mod.centers, mod.gamma)
+    tan = _empty(d.numel(), mod.centers.numel(), like=d)
+    check(lib.alignn_rbf_tangent(ptr(d), ptr(dt), ptr(mod.centers), float(mod.gamma), ptr(tan), d.numel(), mod.centers.numel(),
+                                 stream()), "rbf_tangent")
+    return Dual(val, tan)
 
 
 def _cos_dual(r, rt, lg: CSRGraph):
     """compute_bond_cosines (alignn/graphs.py:847-864) and its derivative along rt; r1 = -r[e1], r2 = r[e2]"""
-    e1, e2 = lg.src.long(), lg.dst.long()
-    a, at = -r[e1], -rt[e1]
-    b, bt = r[e2], rt[e2]
-    na, nb = a.norm(dim=1), b.norm(dim=1)
-    c = (a * b).sum(1) / (na * nb)
-    ct = ((at * b).sum(1) + (a * bt).sum(1)) / (na * nb) - c * ((a * at).sum(1) / (na * na) + (b * bt).sum(1) / (nb * nb))
-    inside = (c > -1) & (c < 1)
-    return torch.clamp(c, -1, 1), torch.where(inside, ct, torch.zeros_like(ct))
+    lib = _lib.load()
+    h = ops._bond_cosines_raw(r, lg.src, lg.dst)
+    ht = _empty(lg.n_edges, like=r)
+    check(lib.alignn_bond_cosine_tangent(ptr(r), ptr(rt), ptr(lg.src), ptr(lg.dst), ptr(ht), lg.n_edges, stream()), "bond_cosine_tangent")
+    return h, ht
 
 
 def supported(cfg) -> bool:
@@ -309,14 +311,19 @@ def supported(cfg) -> bool:
             and (cfg.stresswise_weight == 0 or cfg.batch_stress))
 
 
-def dual_pass(model, b: GraphBatch, rt, g_energy, gt_energy, fwd=None):
-    """Parameter gradients of  sum_g g_energy[g] E_g + sum_g gt_energy[g] (D_rt E)_g  -> {id(param): (param, grad)}"""
+def dual_pass(model, b: GraphBatch, w, wmax, g_energy, c, fwd=None):
+    """Parameter gradients of  sum_g g_energy[g] E_g + c_g (D_w E)_g, c_g = c (* atoms of g: energy_mult_natoms)
+    -> {id(param): (param, grad)}.  ``w`` [E, 3] = dL/d(pair forces), ``wmax`` = max|w| (device scalar): the tangent direction is
+    w / 2^floor(log2 wmax) - tangent activations then have the scale of the values - and the seeds carry the factor back."""
+    lib = _lib.load()
     cfg = model.config
     tape, grads = [], _Grads()
     n_a, n_g = len(model.alignn_layers), len(model.gcn_layers)
-    r = b.r
-    d = r.norm(dim=1)
-    dt = (r * rt).sum(1) / d
+    r = b.r.contiguous()
+    E = r.shape[0]
+    d = ops._bond_length_raw(r)
+    rt, dt = _empty(E, 3, like=r), _empty(E, like=r)
+    check(lib.alignn_ff_tangent_geometry(ptr(r), ptr(w), ptr(wmax), ptr(d), ptr(rt), ptr(dt), E, stream()), "ff_tangent_geometry")
     af = b.atom_features
     x = mlp_fwd(model.atom_embedding, Dual(af, torch.zeros_like(af)), tape, fwd)
     y = mlp_fwd(model.edge_embedding[2], mlp_fwd(model.edge_embedding[1], _rbf_dual(d, dt, model.edge_embedding[0]), tape, fwd), tape, fwd)
@@ -332,17 +339,20 @@ def dual_pass(model, b: GraphBatch, rt, g_energy, gt_energy, fwd=None):
     for i, layer in enumerate(model.gcn_layers):
         x, y = conv_fwd(layer, b.g, x, y, i + 1 < n_g, tape, fwd)
     # readout: E_g = fc(mean_i x_i)  (alignn_atomwise.py:464-466); reverse with the two seeds
-    counts = (b.graph_ptr[1:] - b.graph_ptr[:-1]).to(torch.float32)
     hp = ops.AvgPoolFn.apply(x.p, b.graph_ptr)
     hpt = ops.AvgPoolFn.apply(x.t, b.graph_ptr)
     fc = model.fc
-    grads.add(fc.weight, (g_energy.unsqueeze(1) * hp + gt_energy.unsqueeze(1) * hpt).sum(0, keepdim=True))
-    grads.add(fc.bias, g_energy.sum().reshape(1))
-    if "node_graph" not in b.cache:
-        b.cache["node_graph"] = torch.repeat_interleave(torch.arange(b.batch_size, device=r.device), counts.long())
-    ng = b.cache["node_graph"]
-    wrow = fc.weight.reshape(1, -1)
-    gx = Dual(((g_energy / counts).unsqueeze(1) * wrow)[ng].contiguous(), ((gt_energy / counts).unsqueeze(1) * wrow)[ng].contiguous())
+    B, H = b.batch_size, hp.shape[1]
+    emn = int(cfg.energy_mult_natoms)
+    gW, gb = _empty(1, H, like=r), _empty(1, like=r)
+    check(lib.alignn_ff_fc_grad(ptr(g_energy), float(c), emn, ptr(wmax), ptr(b.graph_ptr), ptr(hp), ptr(hpt), ptr(gW), ptr(gb), B, H,
+                                stream()), "ff_fc_grad")
+    grads.add(fc.weight, gW)
+    grads.add(fc.bias, gb)
+    N = b.g.n_nodes
+    gx = Dual(_empty(N, H, like=r), _empty(N, H, like=r))
+    check(lib.alignn_ff_readout_seed(ptr(g_energy), float(c), emn, ptr(wmax), ptr(b.graph_ptr), ptr(fc.weight), ptr(gx.p), ptr(gx.t), B,
+                                     N, H, stream()), "ff_readout_seed")
     gy = None
     gz = None
     # reverse over the tape
@@ -387,31 +397,22 @@ class ForcesFn(torch.autograd.Function):
     def backward(ctx, g_out, g_forces, g_stress):
         model, b, cfg = ctx.model, ctx.batch, ctx.model.config
         gg = b.g
+        lib = _lib.load()
         with torch.no_grad():
             dev = b.r.device
             E = gg.n_edges
-            w = torch.zeros(E, 3, dtype=torch.float32, device=dev)
-            if g_forces is not None:
-                gF = g_forces.reshape(gg.n_nodes, 3)
-                w = w + gF[gg.dst.long()]
-                if cfg.add_reverse_forces:
-                    w = w - gF[gg.src.long()]
-            if ctx.has_stress and g_stress is not None:
-                # stress_g = k_g sum_e r_e (x) pf_e  ->  dL/dpf_e = k_g gS_g^T r_e
-                egp = b.edge_graph_ptr.long()
-                if "edge_graph" not in b.cache:
-                    b.cache["edge_graph"] = torch.repeat_interleave(torch.arange(b.batch_size, device=dev), egp[1:] - egp[:-1])
-                eg = b.cache["edge_graph"]
-                kg = cfg.stress_multiplier * (-160.21766208) / b.volume
-                w = w + torch.einsum("eab,ea->eb", (kg.reshape(-1, 1, 1) * g_stress)[eg], b.r)
-            counts = (b.graph_ptr[1:] - b.graph_ptr[:-1]).to(torch.float32)
+            # w_e = dL/d(pair force of bond e): gF[dst] - gF[src] (the in-minus-out force reduction reversed) + k_g gS_g^T r_e
+            # (stress_g = k_g sum_e r_e (x) pf_e), and max|w| - one kernel (csrc/ff.hip)
+            gF = None if g_forces is None else g_forces.reshape(gg.n_nodes, 3).to(torch.float32).contiguous()
+            gS = g_stress.reshape(-1, 3, 3).to(torch.float32).contiguous() if (ctx.has_stress and g_stress is not None) else None
+            r = b.r.contiguous()
+            w = _empty(E, 3, like=r)
+            wmax = torch.zeros(1, dtype=torch.float32, device=dev)
+            check(lib.alignn_ff_pair_weights(ptr(gF), ptr(gS), ptr(r), ptr(gg.src), ptr(gg.dst), ptr(b.graph_ptr), ptr(gg.seg_ptr),
+                                             ptr(b.volume) if gS is not None else None, float(cfg.stress_multiplier) * (-160.21766208),
+                                             int(cfg.add_reverse_forces), b.batch_size, E, ptr(w), ptr(wmax), stream()), "ff_pair_weights")
             c = float(cfg.grad_multiplier) * (gg.n_nodes if cfg.force_mult_natoms else 1)
-            gt = c * (counts if cfg.energy_mult_natoms else torch.ones_like(counts))
-            ge = g_out.reshape(-1).to(torch.float32) if g_out is not None else torch.zeros_like(counts)
-            # the tangent is linear in w: normalise it to unit size (a power of two) so that tangent activations have
-            # the scale of the values, and undo the factor in the seed
-            wmax = w.abs().max()
-            scale = torch.where(wmax > 0, torch.exp2(torch.floor(torch.log2(wmax.clamp_min(1e-30)))), torch.ones_like(wmax))
-            grads = dual_pass(model, b, (w / scale).contiguous(), ge.contiguous(), (gt * scale).contiguous(), ctx.fwd_tape)
+            ge = g_out.reshape(-1).to(torch.float32).contiguous() if g_out is not None else None
+            grads = dual_pass(model, b, w, wmax, ge, c, ctx.fwd_tape)
             ctx.fwd_tape = None  # (its tensors are the force evaluation's activations: let them go)
         return (None, None) + tuple(grads.get(p) for p in ctx.params)

@@ -622,7 +622,8 @@ typedef struct alignn_model_desc {
     const void* bump_ptrs;                     /* device array of n_bump int64_t* (num_batches_tracked), each += 1 per forward */
     int32_t n_weights, n_bump;
     int32_t x6_min_tiles, bd_segment_table;    /* kernel-choice constants of the per-operator path (256, 1) */
-    int32_t angle_fused, pad_;                 /* 1: the angle embedding through alignn_angle_embed_fwd / _bwd where its shapes allow */
+    int32_t angle_fused, norm;                 /* 1: the angle embedding through alignn_angle_embed_fwd / _bwd where its shapes allow;
+                                                  norm: 0 BatchNorm1d (ALIGNN), 1 LayerNorm (ALIGNNAtomWise: rm / rv / bump_ptrs unused) */
     int64_t amax_min_rows, lane_min_rows, side_min_rows; /* 4096; rows from which a kernel goes to lane_T / side */
     alignn_stream_t lane_T, side, aux;
 } alignn_model_desc;
@@ -640,6 +641,78 @@ int alignn_model_bwd(const alignn_model_desc* desc, const alignn_model_batch* ba
 size_t alignn_model_infer_workspace(const alignn_model_desc* desc, const alignn_model_batch* batch);
 int alignn_model_infer(const alignn_model_desc* desc, const alignn_model_batch* batch, void* workspace, size_t workspace_bytes,
                        float* out, alignn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * ALIGNNAtomWise with the force / stress head as whole-model calls (csrc/model.hip + csrc/ff.hip):
+ * alignn/models/alignn_atomwise.py:364-660 with calculate_gradient=True - what alignn/train.py:291-387 trains and what
+ * alignn/ff/calculators.py:280-291 evaluates at every MD step.  desc->norm must be 1 (LayerNorm flavour).
+ *   alignn_ff_eval: energies out[B] (:494-510), forces[N, 3] = reduce(grad_multiplier dE_tot/dr) (:530-565), stresses
+ *                   [B, 3, 3] (:615-638; NULL: none) - the forward pass with the bond vectors as a leaf and its reverse
+ *                   w.r.t. them (no parameter gradients); bond cosines recomputed from r when lg_on_fly (:424-431),
+ *                   else batch->h.
+ *   alignn_ff_grad: parameter gradients of a loss L(out, forces, stresses) given g_out[B], g_forces[N, 3], g_stress[B, 3, 3]
+ *                   (each may be NULL = zero): the force / stress part is linear in the pair forces, sum_e w_e . f_e =
+ *                   c D_w E_tot, so its parameter gradient is ONE reverse pass over a forward pass that carries a tangent
+ *                   next to every activation (forward-over-reverse instead of autograd.grad(create_graph=True) + a second
+ *                   backward; csrc/dual.hip).  The value halves are the tape alignn_ff_eval left in the workspace, which
+ *                   must be the one that call filled for the same (desc, batch, ff).  Gradients go to the g_* / *red
+ *                   pointers of desc, which must all lie inside gflat[0 .. grad_floats) ; gflat_t is scratch of the same
+ *                   size (the tangent halves of the weight gradients, added on return).
+ *   alignn_ff_plan: workspace bytes for eval alone / eval + grad; 801 when a kernel choice is not carried here.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct alignn_ff_desc {
+    int32_t lg_on_fly, add_reverse_forces, force_mult_natoms, energy_mult_natoms, has_stress, use_penalty;
+    int32_t dense_lg_reverse, pad_;
+    float grad_multiplier, stress_multiplier, penalty_factor, penalty_threshold;
+    const float* volume;                       /* [B] cell volumes (stress) or NULL */
+} alignn_ff_desc;
+size_t alignn_ff_desc_sizeof(void);
+int alignn_ff_plan(const alignn_model_desc* desc, const alignn_model_batch* batch, const alignn_ff_desc* ff, size_t* eval_bytes,
+                   size_t* total_bytes);
+int alignn_ff_eval(const alignn_model_desc* desc, const alignn_model_batch* batch, const alignn_ff_desc* ff, void* workspace,
+                   size_t workspace_bytes, float* out, float* forces, float* stress, alignn_stream_t stream);
+int alignn_ff_grad(const alignn_model_desc* desc, const alignn_model_batch* batch, const alignn_ff_desc* ff, void* workspace,
+                   size_t workspace_bytes, const float* g_out, const float* g_forces, const float* g_stress, float* gflat,
+                   float* gflat_t, int64_t grad_floats, alignn_stream_t stream);
+
+/* The small kernels of the force-field head (csrc/ff.hip), also used one by one by the per-operator path
+ * (alignn_amd/alignn_atomwise.py, alignn_amd/ff2.py) - they replace ~100 torch element-wise / index / reduce launches and a
+ * vendor GEMM (torch.einsum for a 3 x 3 mat-vec per bond) per training step:
+ *   pair_force_reduce   forces[i] = scale (sum_{e into i} g_r[e] - [add_reverse] sum_{e out of i} g_r[e])  (DGL copy_e / sum on
+ *                       g and dgl.reverse(g), alignn_atomwise.py:547-565); scale = grad_multiplier (* N: force_mult_natoms)
+ *   virial_stress       stress[g] = (k scale / V_g) sum_{e in g} r_e (x) g_r[e], k = stress_multiplier * -160.21766208 (:615-638)
+ *   ff_energy           out[g] per alignn_atomwise.py:494-510 (penalty summed over ALL bonds of the batch) and seed[g] =
+ *                       d(sum en_out)/d pred[g];  ff_penalty_bwd: g_bl[e] += -B factor [bl[e] < thr]
+ *   ff_pair_weights     w[e] = dL/d(pair force e) = gF[dst] - [add_reverse] gF[src] + (kS / V_g) gS_g^T r[e]; *wmax raised to
+ *                       max|w| (zeroed by the caller)
+ *   ff_tangent_geometry rt = w / 2^floor(log2 wmax) (1 if wmax == 0), dt = r . rt / d
+ *   rbf_tangent         out_t[r][k] = exp(-gamma (d - c_k)^2) (-2 gamma (d - c_k)) dt[r]
+ *   bond_cosine_tangent ht[k] = D_rt of compute_bond_cosines (alignn/graphs.py:847-864), 0 where its clamp is active
+ *   ff_readout_seed     adjoints of x_i under E_g = fc(mean_i x_i): gx[i] = (ge[g] / n_g) fc_w, gxt[i] = (c_g 2^k / n_g) fc_w,
+ *                       c_g = c (* n_g: energy_mult_natoms);  ff_fc_grad: gW = sum_g ge[g] hp[g] + c_g 2^k hpt[g], gb = sum ge
+ *   add_inplace / add3  a += b;  out = (a + b) + c   (n % 4 == 0 / any n) */
+int alignn_pair_force_reduce(const float* g_r, float scale, const int32_t* seg_ptr, const int32_t* out_ptr, const int32_t* out_slot,
+                             int add_reverse, float* forces, int64_t n_nodes, alignn_stream_t stream);
+int alignn_virial_stress(const float* r, const float* g_r, float scale, const int32_t* graph_ptr, const int32_t* seg_ptr,
+                         const float* volume, float k, float* stress, int B, alignn_stream_t stream);
+int alignn_ff_energy(const float* pred, const float* bl, const int32_t* graph_ptr, int B, int64_t E, int mult_natoms,
+                     int use_penalty, float factor, float thr, float* out, float* seed, alignn_stream_t stream);
+int alignn_ff_penalty_bwd(const float* bl, float* g_bl, int64_t E, int B, float factor, float thr, alignn_stream_t stream);
+int alignn_ff_pair_weights(const float* gF, const float* gS, const float* r, const int32_t* src, const int32_t* dst,
+                           const int32_t* graph_ptr, const int32_t* seg_ptr, const float* volume, float kS, int add_reverse, int B,
+                           int64_t E, float* w, float* wmax, alignn_stream_t stream);
+int alignn_ff_tangent_geometry(const float* r, const float* w, const float* wmax, const float* d, float* rt, float* dt, int64_t E,
+                               alignn_stream_t stream);
+int alignn_rbf_tangent(const float* d, const float* dt, const float* centers, float gamma, float* out_t, int64_t rows, int bins,
+                       alignn_stream_t stream);
+int alignn_bond_cosine_tangent(const float* r, const float* rt, const int32_t* e1, const int32_t* e2, float* ht, int64_t T,
+                               alignn_stream_t stream);
+int alignn_ff_readout_seed(const float* ge, float c, int mult_natoms, const float* wmax, const int32_t* graph_ptr, const float* fc_w,
+                           float* gx, float* gxt, int B, int64_t N, int H, alignn_stream_t stream);
+int alignn_ff_fc_grad(const float* ge, float c, int mult_natoms, const float* wmax, const int32_t* graph_ptr, const float* hp,
+                      const float* hpt, float* gW, float* gb, int B, int H, alignn_stream_t stream);
+int alignn_add_inplace(float* a, const float* b, int64_t n, alignn_stream_t stream);
+int alignn_add3(const float* a, const float* b, const float* c, float* out, int64_t n, alignn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * The bond-angle embedding on T rows (csrc/angle.hip):  z = MLPLayer(64 -> 256)(MLPLayer(bins -> 64)(RBFExpansion(h)))

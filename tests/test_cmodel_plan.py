@@ -114,3 +114,54 @@ def test_per_model_state_is_not_part_of_the_module():
     del m, twin
     gc.collect()
     assert len(cmodel._PER_MODEL) == n - 2
+
+
+def _ff(lg_on_fly=1, stress=1):
+    f = cmodel.FFDesc()
+    f.lg_on_fly, f.add_reverse_forces, f.force_mult_natoms, f.energy_mult_natoms = lg_on_fly, 1, 0, 1
+    f.has_stress, f.use_penalty, f.dense_lg_reverse = stress, 1, 1
+    f.grad_multiplier, f.stress_multiplier, f.penalty_factor, f.penalty_threshold = -1.0, 1.0, 0.1, 1.0
+    f.volume = 0x1000 if stress else None
+    return f
+
+
+def _ff_plan(d, mb, f):
+    lib = cmodel._lib_model()
+    a, b = C.c_size_t(0), C.c_size_t(0)
+    rc = lib.alignn_ff_plan(C.addressof(d), C.addressof(mb), C.addressof(f), C.addressof(a), C.addressof(b))
+    return rc, a.value, b.value
+
+
+def test_layernorm_flavour_and_force_field_plans():
+    """ALIGNNAtomWise on the whole-model entry points: the LayerNorm flavour of alignn_model_plan, and alignn_ff_plan (force
+    evaluation = forward + reverse w.r.t. the bond vectors; + the tangent-carrying second-order pass) at BASELINE configs[3]
+    (16 x 200 atoms) and at an MD cell (1 x 200 atoms).  Host arithmetic only."""
+    N, E, T, B = 3200, 42224, 561792, 16
+    d, _keep = _desc()
+    d.norm = 1
+    rc, fwd, tot = _plan(d, _batch(N, E, T, B))
+    assert rc == 0
+    t_row = T * 256 * 4
+    assert 9 * t_row < fwd < 18 * t_row and fwd < tot < fwd + 20 * t_row, (fwd / t_row, tot / t_row)
+    f = _ff()
+    rc, ev, full = _ff_plan(d, _batch(N, E, T, B), f)
+    assert rc == 0
+    # evaluation: the tape of the energy-only forward + its reverse w.r.t. r; the second-order pass about twice that again
+    assert fwd < ev < tot + 4 * t_row, (ev / t_row, fwd / t_row, tot / t_row)
+    assert ev + 20 * t_row < full < ev + 60 * t_row, ((full - ev) / t_row)
+    rc1, ev1, full1 = _ff_plan(d, _batch(200, 2644, 35326, 1), _ff(stress=0))
+    assert rc1 == 0 and 0 < ev1 < full1 < 4 << 30
+    # the force field is the LayerNorm model with a one-wide readout; stress needs the volumes; lg_on_fly = 0 needs the cosines
+    d.norm = 0
+    assert _ff_plan(d, _batch(N, E, T, B), f)[0] == 1
+    d.norm = 1
+    g = _ff()
+    g.volume = None
+    assert _ff_plan(d, _batch(N, E, T, B), g)[0] == 1
+    mb = _batch(N, E, T, B)
+    mb.h = None
+    assert _ff_plan(d, mb, _ff(lg_on_fly=0))[0] == 1 and _ff_plan(d, mb, _ff(lg_on_fly=1))[0] == 0
+    # no slice images: split-product shapes are not carried
+    d2, _k2 = _desc(images=False)
+    d2.norm = 1
+    assert _ff_plan(d2, _batch(N, E, T, B), f)[0] == NOT_SUPPORTED

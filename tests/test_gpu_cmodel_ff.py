@@ -1,0 +1,224 @@
+"""ALIGNNAtomWise on the whole-model C entry points (csrc/model.hip + csrc/ff.hip, alignn_amd/cmodel.py): energy-only training
+(``alignn_model_fwd / _bwd``, LayerNorm flavour), training THROUGH the forces (``alignn_ff_eval`` + ``alignn_ff_grad``) and the
+force evaluation of MD (``alignn_ff_eval``).  They issue the launches of the per-operator path (alignn_amd/ops.py, alignn_amd/ff2.py)
+with the same arguments, so the bar is BIT equality of energies, forces, stresses, every parameter gradient and the parameters
+after optimizer steps; the parity of both paths against the reference's own class is tests/test_gpu_round2.py /
+tests/test_gpu_full_size.py (which run through these calls by default)."""
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from alignn_amd import ALIGNNAtomWise, ALIGNNAtomWiseConfig, GraphBatch, cmodel, ops  # noqa: E402
+from alignn_amd.synthetic import make_batch  # noqa: E402
+
+DEV = "cuda"
+
+
+def _mk(seed=0, ff=True, **kw):
+    torch.manual_seed(seed)
+    cfg = dict(name="alignn_atomwise", alignn_layers=2, gcn_layers=2, hidden_features=256, atom_input_features=92,
+               calculate_gradient=ff, stresswise_weight=0.05 if ff else 0.0)
+    cfg.update(kw)
+    m = ALIGNNAtomWise(ALIGNNAtomWiseConfig(**cfg)).to(DEV).train()
+    with torch.no_grad():  # LayerNorm affine parameters that are not the initial 1 / 0
+        for n_, p_ in m.named_parameters():
+            if ".bn_" in n_ or ".layer.1." in n_:
+                p_.add_(0.1 * torch.randn_like(p_))
+    return m
+
+
+def _same(a, b, what=""):
+    assert a.keys() == b.keys(), set(a) ^ set(b)
+    for k in a:
+        assert torch.equal(a[k], b[k]), (what, k, float((a[k].double() - b[k].double()).abs().max()),
+                                        float(b[k].double().abs().max()))
+
+
+def _targets(raw, seed):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(raw.batch_size, generator=g).to(DEV), torch.randn(raw.num_nodes, 3, generator=g).to(DEV),
+            torch.randn(raw.batch_size, 3, 3, generator=g).to(DEV))
+
+
+def _train(model, batches, targets, use_c, ff=True, steps_opt=True):
+    prev = cmodel.ENABLED
+    cmodel.ENABLED = use_c
+    l1 = torch.nn.functional.l1_loss
+    try:
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, fused=True)
+        for b, (te, tf, ts) in zip(batches, targets):
+            opt.zero_grad(set_to_none=True)
+            o = model(b)
+            loss = l1(o["out"], te)
+            if ff:
+                loss = loss + l1(o["grad"], tf) + l1(o["stresses"], ts)
+            loss.backward()
+            if steps_opt:
+                opt.step()
+        torch.cuda.synchronize()
+        out = {"out": o["out"].detach().clone(), "loss": loss.detach().clone()}
+        if ff:
+            out["forces"], out["stress"] = o["grad"].detach().clone(), o["stresses"].detach().clone()
+        out.update({"g." + k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+        out.update({"p." + k: p.detach().clone() for k, p in model.named_parameters()})
+        return out
+    finally:
+        cmodel.ENABLED = prev
+
+
+def _reset_stats():
+    for k in list(cmodel.STATS):
+        cmodel.STATS[k] = 0
+
+
+@pytest.mark.parametrize("B,atoms", [(3, 30), (16, 60)])  # (the second: T = 169 k rows - lane T and the side stream are in use)
+def test_force_training_equals_the_per_operator_path_bit_for_bit(B, atoms):
+    raws = [make_batch(B, atoms, seed0=40 + i) for i in range(2)]
+    batches = [GraphBatch.from_raw(r, device=DEV) for r in raws]
+    targets = [_targets(r, i) for i, r in enumerate(raws)]
+    _reset_stats()
+    a = _train(_mk(1), batches, targets, True)
+    assert cmodel.STATS.get("ff_eval", 0) == 2 and cmodel.STATS.get("ff_grad", 0) == 2, cmodel.STATS
+    b = _train(_mk(1), batches, targets, False)
+    assert sum(k.startswith("g.") for k in a) > 100
+    _same(a, b, f"B={B}")
+    assert all(bool(torch.isfinite(t).all()) for t in a.values())
+
+
+def test_force_training_switches_energy_only_forces_only_no_reverse_natoms():
+    raw = make_batch(4, 24, seed0=7)
+    batch = GraphBatch.from_raw(raw, device=DEV)
+    tgt = _targets(raw, 3)
+    for kw in (dict(stresswise_weight=0.0), dict(add_reverse_forces=False), dict(force_mult_natoms=True),
+               dict(energy_mult_natoms=False, use_penalty=False), dict(lg_on_fly=False), dict(grad_multiplier=-2.0, stress_multiplier=0.5)):
+        _reset_stats()
+        a = _train(_mk(2, **kw), [batch], [tgt], True)
+        assert cmodel.STATS.get("ff_grad", 0) == 1, (kw, cmodel.STATS)
+        b = _train(_mk(2, **kw), [batch], [tgt], False)
+        _same(a, b, str(kw))
+
+
+def test_partial_losses_energy_only_or_forces_only():
+    """A loss that uses only some of the three outputs: the unused ones arrive as None in backward."""
+    raw = make_batch(4, 24, seed0=8)
+    batch = GraphBatch.from_raw(raw, device=DEV)
+    te, tf, ts = _targets(raw, 4)
+    l1 = torch.nn.functional.l1_loss
+
+    def run(use_c, which):
+        prev, cmodel.ENABLED = cmodel.ENABLED, use_c
+        try:
+            m = _mk(3)
+            o = m(batch)
+            loss = {"e": lambda: l1(o["out"], te), "f": lambda: l1(o["grad"], tf), "s": lambda: l1(o["stresses"], ts)}[which]()
+            loss.backward()
+            torch.cuda.synchronize()
+            return {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+        finally:
+            cmodel.ENABLED = prev
+
+    for which in "efs":
+        _same(run(True, which), run(False, which), which)
+
+
+def test_force_evaluation_in_eval_mode_is_one_c_call():
+    """MD / calculators (alignn/ff/calculators.py:280-291): model.eval(), grad enabled, forces as values."""
+    raw = make_batch(1, 200, seed0=5)
+    batch = GraphBatch.from_raw(raw, device=DEV)
+    m = _mk(4, alignn_layers=4, gcn_layers=4).eval()
+    _reset_stats()
+    a = m(batch)
+    assert cmodel.STATS.get("ff_eval", 0) == 1 and cmodel.STATS.get("ff_grad", 0) == 0
+    with cmodel.disabled():
+        b = m(batch)
+    torch.cuda.synchronize()
+    for k in ("out", "grad", "stresses"):
+        assert a[k].shape == b[k].shape and torch.equal(a[k], b[k]), (k, float((a[k] - b[k]).abs().max()))
+    assert not a["grad"].requires_grad and a["out"].dim() == 0
+
+
+def test_energy_only_training_of_the_layernorm_model():
+    raws = [make_batch(B, n, seed0=s) for B, n, s in ((6, 30, 1), (16, 60, 2), (5, 44, 3))]
+    batches = [GraphBatch.from_raw(r, device=DEV) for r in raws]
+    targets = [_targets(r, i) for i, r in enumerate(raws)]
+    _reset_stats()
+    a = _train(_mk(5, ff=False), batches, targets, True, ff=False)
+    assert cmodel.STATS["fwd"] == 3 and cmodel.STATS["bwd"] == 3, cmodel.STATS
+    b = _train(_mk(5, ff=False), batches, targets, False, ff=False)
+    _same(a, b, "energy only")
+    _same(a, _train(_mk(5, ff=False, lg_on_fly=False), batches, targets, True, ff=False), "loader cosines = cosines from r")
+
+
+def test_one_stream_and_helper_streams_give_the_same_bits_and_capture_replays():
+    raw = make_batch(16, 60, seed0=11)
+    batch = GraphBatch.from_raw(raw, device=DEV)
+    tgt = _targets(raw, 6)
+    ref = _train(_mk(6), [batch] * 2, [tgt] * 2, True)
+    saved = (ops._LANE["enabled"], ops._SIDE["enabled"], ops.FORK_DGRAD)
+    ops._LANE["enabled"], ops._SIDE["enabled"], ops.FORK_DGRAD = "0", False, "0"
+    try:
+        one = _train(_mk(6), [batch] * 2, [tgt] * 2, True)
+    finally:
+        ops._LANE["enabled"], ops._SIDE["enabled"], ops.FORK_DGRAD = saved
+    _same(ref, one, "streams")
+    for _ in range(2):
+        _same(ref, _train(_mk(6), [batch] * 2, [tgt] * 2, True), "repeat")
+    # captured into a hipGraph and replayed: same gradients as the eager step
+    l1 = torch.nn.functional.l1_loss
+    model = _mk(6)
+    eager = _train(_mk(6), [batch], [tgt], True, steps_opt=False)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        o = model(batch)
+        (l1(o["out"], tgt[0]) + l1(o["grad"], tgt[1]) + l1(o["stresses"], tgt[2])).backward()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    for p in model.parameters():
+        p.grad = None
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        o = model(batch)
+        loss = l1(o["out"], tgt[0]) + l1(o["grad"], tgt[1]) + l1(o["stresses"], tgt[2])
+        loss.backward()
+    grads = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+    for _ in range(2):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(loss, eager["loss"])
+    for k, g in grads.items():
+        assert torch.equal(g, eager["g." + k]), k
+
+
+def test_the_step_is_free_of_torch_and_vendor_kernels():
+    """nothing but this library's kernels between the model call and the end of backward (the einsum of
+    the stress seed was a hipBLASLt GEMM; ~80 at::native element-wise / index / reduce kernels per step)."""
+    from torch.profiler import ProfilerActivity, profile
+
+    raw = make_batch(4, 40, seed0=12)
+    batch = GraphBatch.from_raw(raw, device=DEV)
+    te, tf, ts = _targets(raw, 7)
+    l1 = torch.nn.functional.l1_loss
+    m = _mk(7)
+
+    def fwd_bwd():
+        for p_ in m.parameters():
+            p_.grad = None
+        o = m(batch)
+        # (the loss itself is the caller's: a few element-wise torch kernels on [B] / [N, 3] / [B, 3, 3] tensors)
+        gE, gF, gS = torch.ones_like(o["out"]), tf, ts
+        torch.autograd.backward([o["out"], o["grad"], o["stresses"]], [gE, gF, gS])
+
+    fwd_bwd()
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        fwd_bwd()
+        torch.cuda.synchronize()
+    names = [e.key for e in prof.key_averages()]
+    # (autograd's AccumulateGrad may copy a gradient that is a view of the flat buffer: those copies are the engine's)
+    foreign = [n for n in names if ("at::native" in n or n.startswith("Cijk_") or "elementwise" in n or "rocblas" in n.lower())
+               and "copy" not in n.lower()]
+    assert not foreign, foreign
+    assert any("gemm_nt" in n or "egc_" in n for n in names), names[:10]
