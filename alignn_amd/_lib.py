@@ -129,6 +129,7 @@ SIGNATURES = {
     "alignn_knn_emit": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i64, _p, _p, _p, _p, _p, _p, _p, _p]),
     # whole-model force field (csrc/model.hip) and the small kernels of its head (csrc/ff.hip)
     "alignn_ff_desc_sizeof": (_sz, []),
+    "alignn_debug_allocs": (_i32, [_p, _i32]),
     "alignn_ff_plan": (_i32, [_p, _p, _p, _p, _p]),
     "alignn_ff_eval": (_i32, [_p, _p, _p, _p, _sz, _p, _p, _p, _p]),
     "alignn_ff_grad": (_i32, [_p, _p, _p, _p, _sz, _p, _p, _p, _p, _p, _i64, _p]),

@@ -531,7 +531,7 @@ def main():
     # one eagerly launched step (the weight-gradient GEMMs of the previous layer run beside it on the side stream, as
     # in every real step) - reported in `roofline.in_step` next to the stand-alone micro-timing
     in_step = None
-    if args.model == "alignn":  # (every rank runs the step: it contains the gradient all-reduce)
+    if args.model in ("alignn", "alignn_ff"):  # (every rank runs the step: it contains the gradient all-reduce)
         if rank == 0:
             ops.KERNEL_TIMER = {"min_rows": raw.num_triplets, "events": []}
         try:
@@ -553,7 +553,11 @@ def main():
         if by:
             row_bytes = raw.num_triplets * H * 4.0
             in_step = {"how": "HIP events on the launch stream around every T-row launch (M=T, N=K=256) of one eagerly "
-                              "launched training step, by epilogue variant; side-stream weight-gradient GEMMs share the CUs"}
+                              "launched training step (per-operator launch path: same kernels, same arguments as the C calls), "
+                              "by epilogue variant; side-stream weight-gradient GEMMs share the CUs"
+                              + ("; force training: the force evaluation (gather), its reverse (addend / plain) and the "
+                                 "second-order pass (tangent projections: plain; value + tangent input gradients: addend)"
+                                 if args.model == "alignn_ff" else "")}
             for label, ts in sorted(by.items()):
                 ms_ = sum(ts) / len(ts)
                 gbs_ = rows_moved[label] * row_bytes / (ms_ * 1e-3) / 1e9
@@ -774,6 +778,16 @@ def main():
         pmc_step = PMC["pmc_bytes_per_step"] if (PMC is not None and T == PMC["triplets"] and args.model == "alignn") else None
         step_bytes = algorithmic_bytes_per_step(N, E, T)
         step_flops = algorithmic_flops_per_step(N, E, T)
+        step_passes = None
+        if args.model == "alignn_ff":
+            # a force-training step is ~3x the work of row 6's fwd + bwd: the force evaluation (forward +
+            # reverse w.r.t. the bond vectors), the tangent-carrying forward of the second-order pass and its reverse over
+            # (value, tangent) pairs.  Bytes: 3 x the 8(d) formula; GEMM flops: forward (1) + reverse input gradients (1) +
+            # tangent forward (1) + second-order reverse: input and weight gradients of values and tangents (4) = 7 forward
+            # equivalents against the 3 of a plain training step.
+            step_passes = {"bytes_x": 3.0, "flops_x": 7.0 / 3.0, "what": "force evaluation fwd + reverse w.r.t. r, tangent forward, "
+                           "second-order reverse (value + tangent) - SURVEY 8(a) row 9"}
+            step_bytes, step_flops = 3.0 * step_bytes, 7.0 / 3.0 * step_flops
         metric_name, workload_name = workload_of(args, B)
         out = {
             "metric": metric_name,
@@ -848,6 +862,7 @@ def main():
                 # SURVEY 8(d)'s algorithmic bytes of a maximally fused schedule over the same time: NOT a bandwidth the chip
                 # sustained (the schedule needs fewer passes than that accounting: 5 forward passes per line-graph
                 # convolution, dead last-layer outputs, fused reductions) - a distance to the 10.2 ms ceiling
+                "passes": step_passes,
                 "algorithmic_GB_per_step": round(step_bytes / 1e9, 2),
                 "algorithmic_GFLOP_per_step": round(step_flops / 1e9, 1),
                 "algorithmic_bytes_over_step_time_frac_of_8TBs": round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

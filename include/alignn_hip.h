@@ -667,6 +667,7 @@ typedef struct alignn_ff_desc {
     const float* volume;                       /* [B] cell volumes (stress) or NULL */
 } alignn_ff_desc;
 size_t alignn_ff_desc_sizeof(void);
+int alignn_debug_allocs(size_t* out, int cap); /* debugging aid, see csrc/model.hip */
 int alignn_ff_plan(const alignn_model_desc* desc, const alignn_model_batch* batch, const alignn_ff_desc* ff, size_t* eval_bytes,
                    size_t* total_bytes);
 int alignn_ff_eval(const alignn_model_desc* desc, const alignn_model_batch* batch, const alignn_ff_desc* ff, void* workspace,

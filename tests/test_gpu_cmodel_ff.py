@@ -53,14 +53,16 @@ def _train(model, batches, targets, use_c, ff=True, steps_opt=True):
             o = model(b)
             loss = l1(o["out"], te)
             if ff:
-                loss = loss + l1(o["grad"], tf) + l1(o["stresses"], ts)
+                loss = loss + l1(o["grad"], tf)
+                if o["stresses"].dim() == 3:  # (stresswise_weight == 0: the reference's placeholder)
+                    loss = loss + l1(o["stresses"], ts)
             loss.backward()
             if steps_opt:
                 opt.step()
         torch.cuda.synchronize()
         out = {"out": o["out"].detach().clone(), "loss": loss.detach().clone()}
         if ff:
-            out["forces"], out["stress"] = o["grad"].detach().clone(), o["stresses"].detach().clone()
+            out["forces"], out["stress"] = o["grad"].detach().clone(), o["stresses"].detach().clone().to(DEV)
         out.update({"g." + k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
         out.update({"p." + k: p.detach().clone() for k, p in model.named_parameters()})
         return out
@@ -148,7 +150,22 @@ def test_energy_only_training_of_the_layernorm_model():
     assert cmodel.STATS["fwd"] == 3 and cmodel.STATS["bwd"] == 3, cmodel.STATS
     b = _train(_mk(5, ff=False), batches, targets, False, ff=False)
     _same(a, b, "energy only")
-    _same(a, _train(_mk(5, ff=False, lg_on_fly=False), batches, targets, True, ff=False), "loader cosines = cosines from r")
+    c = _train(_mk(5, ff=False, lg_on_fly=False), batches, targets, True, ff=False)  # the loader's cosines instead of recomputed ones
+    assert float((a["out"] - c["out"]).abs().max()) < 1e-5 * float(a["out"].abs().max())
+
+
+@pytest.mark.parametrize("B", [16, 48])
+def test_a_step_is_bit_reproducible_run_to_run(B):
+    """Round 5 found the LayerNorm reverse kernel intermittently wrong in one float4 component of lanes 48-63 when another kernel
+    ran beside it (profiles/r05_ln_concurrency.txt): the LayerNorm flavour therefore runs on ONE stream.  Four runs of the same
+    step - energies, forces, stresses, every gradient - are bit-identical, at a size where the helper streams were not."""
+    raw = make_batch(B, 60, seed0=11)
+    batch = GraphBatch.from_raw(raw, device=DEV)
+    tgt = _targets(raw, 6)
+    m = _mk(9)
+    ref = _train(m, [batch], [tgt], True, steps_opt=False)
+    for _ in range(3):
+        _same(ref, _train(m, [batch], [tgt], True, steps_opt=False), "run to run")
 
 
 def test_one_stream_and_helper_streams_give_the_same_bits_and_capture_replays():
@@ -203,13 +220,14 @@ def test_the_step_is_free_of_torch_and_vendor_kernels():
     l1 = torch.nn.functional.l1_loss
     m = _mk(7)
 
+    gE = torch.ones(raw.batch_size, device=DEV)
+
     def fwd_bwd():
         for p_ in m.parameters():
             p_.grad = None
         o = m(batch)
         # (the loss itself is the caller's: a few element-wise torch kernels on [B] / [N, 3] / [B, 3, 3] tensors)
-        gE, gF, gS = torch.ones_like(o["out"]), tf, ts
-        torch.autograd.backward([o["out"], o["grad"], o["stresses"]], [gE, gF, gS])
+        torch.autograd.backward([o["out"], o["grad"], o["stresses"]], [gE, tf, ts])
 
     fwd_bwd()
     torch.cuda.synchronize()
