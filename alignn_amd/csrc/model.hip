@@ -509,35 +509,6 @@ void conv_fwd(Ctx& c, ConvTape& t, const alignn_conv_params& p, const alignn_gra
 // ---- LayerNorm flavour (ALIGNNAtomWise: alignn/models/alignn_atomwise.py:127-208 EdgeGatedGraphConv, alignn/models/utils.py:277-292
 // MLPLayer): per-row statistics, no grid-wide dependency, stat = [rows, 2] (mean, rstd).  ops.MLPLayerFn / ops.EdgeGatedConvFn
 // with norm == "layer", launch for launch.
-int dbg_barrier_mask() {
-    static int m = -1;
-    if (m < 0) {
-        const char* e = getenv("ALIGNN_AMD_FF_BARRIER_MASK");
-        m = e ? atoi(e) : 0;
-    }
-    return m;
-}
-void dbg_barrier(Ctx& c, int bit, bool lane = true) {
-    static int kind = -1, who = -1;
-    if (kind < 0) {
-        const char* e = getenv("ALIGNN_AMD_FF_BARRIER_KIND");
-        kind = e ? atoi(e) : 0;
-        e = getenv("ALIGNN_AMD_FF_BARRIER_WHO");
-        who = e ? atoi(e) : 3;
-    }
-    if ((dbg_barrier_mask() & bit) && (who & (lane ? 1 : 2))) {
-        if (kind != 2) c.sync(c.main, c.T);
-        if (kind != 1) c.sync(c.T, c.main);
-    }
-}
-int dbg_lane_mask() {
-    static int m = -1;
-    if (m < 0) {
-        const char* e = getenv("ALIGNN_AMD_FF_LANE_MASK");
-        m = e ? atoi(e) : 3;
-    }
-    return m;
-}
 Act mlp_fwd_ln(Ctx& c, MlpTape& t, const alignn_mlp_params& p, const Act& x, int64_t rows) {
     const int F = p.out, K = p.in;
     t.p = &p;
