@@ -379,136 +379,6 @@ void conv_fwd(Ctx& c, ConvTape& t, const alignn_conv_params& p, const alignn_gra
 // ---- LayerNorm flavour (ALIGNNAtomWise: alignn/models/alignn_atomwise.py:127-208 EdgeGatedGraphConv, alignn/models/utils.py:277-292
 // MLPLayer): per-row statistics, no grid-wide dependency, stat = [rows, 2] (mean, rstd).  ops.MLPLayerFn / ops.EdgeGatedConvFn
 // with norm == "layer", launch for launch.
-Act mlp_fwd_ln(Ctx& c, MlpTape& t, const alignn_mlp_params& p, const Act& x, int64_t rows);
-Act mlp_fwd(Ctx& c, MlpTape& t, const alignn_mlp_params& p, const Act& x, int64_t rows) {
-    if (c.d->norm == 1) return mlp_fwd_ln(c, t, p, x, rows);
-    const int F = p.out, K = p.in;
-    t.p = &p;
-    t.x = x;
-    t.rows = rows;
-    t.lane = c.T != c.main && rows >= c.d->lane_min_rows;
-    hipStream_t st = t.lane ? c.T : c.main;
-    if (t.lane != x.on_T) c.sync(st, x.on_T ? c.T : c.main);
-    t.pre = c.alloc((size_t)rows * F);
-    t.stat = c.alloc((size_t)4 * F);
-    const bool fused_stats = x.amax != nullptr && x6_shape_ok(c, rows, K, F, K);
-    if (fused_stats) {  // the projection's epilogue leaves the column sums BatchNorm needs
-        if (p.img == nullptr) {
-            UNSUP();
-            return Act{};
-        }
-        const int tiles = alignn_gemm_nt_x6_row_tiles(rows, F, K);
-        float* partial = c.alloc((size_t)(tiles + 1) * 2 * F);
-        L(alignn_gemm_nt_f16x3_stats(x.p, K, x.amax, p.img, p.w_amax, p.b, t.pre, F, rows, F, K, partial, st));
-        bn_finalize_folded(c, partial, tiles, rows, F, p.gamma, p.beta, p.rm, p.rv, t.stat, st);
-    } else {
-        project(c, x.p, K, x.amax, p.W, K, p.img, p.w_amax, p.b, t.pre, F, rows, F, K, st);
-        const int slabs = alignn_col_stats_slabs(rows);
-        float* partial = c.alloc((size_t)slabs * (3 * F + 1));
-        L(alignn_col_stats_welford(t.pre, F, rows, F, partial, st));
-        L(alignn_bn_finalize_welford(partial, slabs, rows, F, p.gamma, p.beta, c.d->eps, c.d->momentum, p.rm, p.rv, t.stat, st));
-    }
-    Act y;
-    y.p = c.alloc((size_t)rows * F);
-    y.amax = c.track(rows) ? c.new_amax() : nullptr;
-    L(alignn_bn_silu_fwd(t.pre, F, nullptr, 0, t.stat, y.p, F, rows, F, y.amax, st));
-    y.xn = t.pre;
-    y.stat = t.stat;
-    y.red = p.red;
-    y.on_T = t.lane;
-    t.y = y;
-    return y;
-}
-
-// EdgeGatedGraphConv.forward, alignn/models/alignn.py:78-129  (ops.EdgeGatedConvFn.forward, BatchNorm / training)
-void conv_fwd_ln(Ctx& c, ConvTape& t, const alignn_conv_params& p, const alignn_graph_csr& g, const Act& x, const Act& y,
-                 bool need_y);
-void conv_fwd(Ctx& c, ConvTape& t, const alignn_conv_params& p, const alignn_graph_csr& g, const Act& x, const Act& y,
-              bool need_y) {
-    if (c.d->norm == 1) return conv_fwd_ln(c, t, p, g, x, y, need_y);
-    const int H = c.d->H, Kin = H;
-    const int64_t n = g.n, m = g.m;
-    t.p = &p;
-    t.g = &g;
-    t.x = x;
-    t.y = y;
-    t.need_y = need_y;
-    t.lane = c.T != c.main && m >= c.d->lane_min_rows;
-    hipStream_t main = c.main, T = t.lane ? c.T : c.main;
-    if (x.on_T) c.sync(main, c.T);
-    if (!t.lane && y.on_T) c.sync(main, c.T);
-    // ---- node side, part 1: P = x [W_sg; W_dg; W_du; W_su]^T + b = A | Bd | Bh | Ux
-    t.P = c.alloc((size_t)n * 4 * H);
-    project(c, x.p, Kin, x.amax, p.wcat, Kin, p.wcat_img, p.wcat_amax, p.bcat, t.P, 4 * H, n, 4 * H, Kin, main);
-    t.xpre = c.alloc((size_t)n * H);
-    t.s0 = c.alloc((size_t)n * H);
-    t.hh = c.alloc((size_t)n * H);
-    const int n_slabs = alignn_egc_slabs(n);
-    float* n_part = c.alloc((size_t)n_slabs * (3 * H + 1));
-    t.M = c.alloc((size_t)m * H);
-    t.n_stat = c.alloc((size_t)8 * H);
-    t.e_stat = t.n_stat + 4 * H;
-    // u_add_v (and the BatchNorm statistics) in the edge projection's epilogue when it runs on the split-product kernel
-    const bool pre_added = y.amax != nullptr && x6_shape_ok(c, m, Kin, H, Kin);
-    if (!pre_added && x6_shape_ok(c, m, Kin, H, Kin)) UNSUP();  // (bf16x6 scheme: per-operator path)
-    if (t.lane) c.sync(T, main);  // lane T reads P (and y, if the caller's stream produced it)
-    Act yo;
-    if (need_y) {
-        yo.p = c.alloc((size_t)m * H);
-        yo.amax = c.track(m) ? c.new_amax() : nullptr;
-    }
-    if (pre_added) {
-        if (p.weg_img == nullptr) {
-            UNSUP();
-            return;
-        }
-        const int tiles = alignn_gemm_nt_x6_row_tiles(m, H, Kin);
-        float* e_part = c.alloc((size_t)(tiles + 1) * 2 * H);
-        if (c.d->bd_segment_table && g.seg_node != nullptr && g.seg_rank != nullptr) {
-            // line graphs: the destination term from a segment-ordered copy of Bd (consecutive rows, same values)
-            float* bd2 = c.alloc((size_t)n * H);
-            L(alignn_gather_rows_ld(t.P + H, 4 * H, g.seg_node, bd2, H, n, H, T));
-            L(alignn_gemm_nt_f16x3_gather2(y.p, Kin, y.amax, p.weg_img, p.weg_amax, p.b_eg, t.M, H, m, H, Kin, t.P, 4 * H, g.src,
-                                           bd2, H, g.seg_rank, e_part, T));
-        } else
-            L(alignn_gemm_nt_f16x3_gather(y.p, Kin, y.amax, p.weg_img, p.weg_amax, p.b_eg, t.M, H, m, H, Kin, t.P, 4 * H, g.src,
-                                          g.dst, e_part, T));
-        bn_finalize_folded(c, e_part, tiles, m, H, p.e_gamma, p.e_beta, p.e_rm, p.e_rv, t.e_stat, T);
-        if (need_y)
-            L(alignn_egc_gate_fwd_pre_norm(t.P, t.M, g.seg_ptr, g.seg_node, g.src, n, m, H, t.xpre, t.s0, t.hh, n_part, t.e_stat,
-                                           y.p, yo.p, yo.amax, T));
-        else
-            L(alignn_egc_gate_fwd_pre(t.P, t.M, g.seg_ptr, g.seg_node, g.src, n, m, H, t.xpre, t.s0, t.hh, nullptr, n_part, T));
-        if (t.lane) c.sync(main, T);
-    } else {
-        L(alignn_gemm_nt(y.p, Kin, p.w_eg, Kin, p.b_eg, nullptr, 0, t.M, H, m, H, Kin, T));
-        float* e_part = c.alloc((size_t)n_slabs * (3 * H + 1));
-        L(alignn_egc_gate_fwd(t.P, t.M, g.seg_ptr, g.seg_node, g.src, n, m, H, t.xpre, t.s0, t.hh, e_part, n_part, T));
-        if (t.lane) c.sync(main, T);
-        L(alignn_bn_finalize_welford(e_part, n_slabs, m, H, p.e_gamma, p.e_beta, c.d->eps, c.d->momentum, p.e_rm, p.e_rv,
-                                     t.e_stat, T));
-        if (need_y) L(alignn_bn_silu_fwd(t.M, H, y.p, Kin, t.e_stat, yo.p, H, m, H, yo.amax, T));
-    }
-    // ---- node side, part 2: node norm
-    L(alignn_bn_finalize_welford(n_part, n_slabs, n, H, p.n_gamma, p.n_beta, c.d->eps, c.d->momentum, p.n_rm, p.n_rv, t.n_stat,
-                                 main));
-    Act xo;
-    xo.p = c.alloc((size_t)n * H);
-    xo.amax = c.track(n) ? c.new_amax() : nullptr;
-    L(alignn_bn_silu_fwd(t.xpre, H, x.p, Kin, t.n_stat, xo.p, H, n, H, xo.amax, main));
-    if (need_y) {
-        yo.xn = t.M;
-        yo.stat = t.e_stat;
-        yo.red = p.e_red;
-        yo.on_T = t.lane;
-    }
-    t.x_out = xo;
-    t.y_out = yo;
-}
-
-// ---- LayerNorm flavour (ALIGNNAtomWise: alignn/models/alignn_atomwise.py:127-208 EdgeGatedGraphConv, alignn/models/utils.py:277-292
-// MLPLayer): per-row statistics, no grid-wide dependency, stat = [rows, 2] (mean, rstd).  ops.MLPLayerFn / ops.EdgeGatedConvFn
-// with norm == "layer", launch for launch.
 Act mlp_fwd_ln(Ctx& c, MlpTape& t, const alignn_mlp_params& p, const Act& x, int64_t rows) {
     const int F = p.out, K = p.in;
     t.p = &p;
@@ -947,7 +817,7 @@ void conv_bwd_ln(Ctx& c, const ConvTape& t, const Grad& gx_out, const Grad* gy_o
     // ---- node branch: LayerNorm / SiLU backward straight into the Ux block of GP, the quotient's adjoints
     const int n_slabs = alignn_ln_slabs(n);
     float* n_part = c.alloc((size_t)n_slabs * 2 * H);
-    // (helper streams for the LayerNorm flavour are off by default, see set_streams; with them on this wait keeps the node
+    // (helper streams for the LayerNorm flavour are off by default, see set_streams; with them on, this wait keeps the node
     // branch from running beside the T-row product of the convolution before it - the pairing the fault of round 5 was found in)
     if (t.lane) c.sync(main, c.T);
     L(alignn_ln_silu_bwd(gx_out.p, H, t.xpre, H, p.n_gamma, p.n_beta, t.n_stat, g_xpre, 4 * H, n_part, n, H, gp_amax, main));
@@ -1556,10 +1426,11 @@ void set_streams(Ctx& c, alignn_stream_t st) {
     // LayerNorm flavour: ONE stream (round 5).  With helper streams the LayerNorm reverse kernel (ln_silu_bwd_kernel, csrc/norm.hip)
     // intermittently returned ONE float4 component of lanes 48-63 of a row wrong (up to 10 %) when a T-row product ran beside it -
     // same inputs, same partial sums, every other lane bit-identical; first seen in hipGraph replays at 16 crystals, in eagerly
-    // launched steps at 48 (tools/ff_alloc_diff.py, tools/ff_repro_check.py, profiles/r05_ln_concurrency.txt).  Not a missing
-    // dependency (every placement of extra events was tried) and not understood; until it is, nothing runs beside the LayerNorm
-    // kernels.  ALIGNN_AMD_LN_STREAMS=1 restores the helper streams for experiments.  (The BatchNorm flavour - other kernels - is
-    // bit-reproducible on four streams: tests/test_gpu_cmodel.py.)
+    // launched steps at 48 (tools/ff_alloc_diff.py, tools/ff_repro_check.py, profiles/r05_ln_concurrency.txt); the per-operator
+    // path of round 4 (ops.lanes + side stream) shows it too.  Not a missing dependency (every placement of extra events was
+    // tried) and not understood; until it is, nothing runs beside the LayerNorm kernels: 0.4 ms of a 37 ms force-training step.
+    // ALIGNN_AMD_LN_STREAMS=1|2|3 restores lane T + aux / the side stream / all three for experiments.  (The BatchNorm flavour -
+    // other kernels - is bit-reproducible on four streams: tests/test_gpu_cmodel.py.)
     if (c.d->norm == 1) {
         static int ln_streams = -1;
         if (ln_streams < 0) ln_streams = getenv("ALIGNN_AMD_LN_STREAMS") ? atoi(getenv("ALIGNN_AMD_LN_STREAMS")) : 0;
@@ -1641,7 +1512,7 @@ extern "C" {
 size_t alignn_ff_desc_sizeof(void) { return sizeof(alignn_ff_desc); }
 
 // debugging aid (ALIGNN_AMD_DEBUG_ALLOCS=1): the (offset, bytes) pairs of the persistent workspace allocations of the launching
-// calls since the last query, in program order; returns the count (at most cap pairs are written)
+// calls since the last query, in program order; returns the count (at most cap pairs are written) - tools/ff_alloc_diff.py
 int alignn_debug_allocs(size_t* out, int cap) {
     const int n = (int)g_dbg_allocs.size();
     for (int i = 0; i < n && i < cap; ++i) {
