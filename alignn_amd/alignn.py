@@ -220,6 +220,12 @@ class EdgeGatedGraphConv(nn.Module):
         lins = (self.src_gate, self.dst_gate, self.dst_update, self.src_update)
         return [m.weight for m in lins], [m.bias for m in lins]
 
+    def _gradient_runs(self):
+        """Parameter lists whose GRADIENTS the whole-model backward (csrc/model.hip) writes as one contiguous block each, in
+        this order: a norm's (dbeta | dgamma) pair.  ``alignn_amd.optim.FlatAdamW`` keeps such a run adjacent in its flat
+        buffers, so that the backward can write straight into the optimizer's packed gradient buffer."""
+        return [[self.bn_nodes.bias, self.bn_nodes.weight], [self.bn_edges.bias, self.bn_edges.weight]]
+
     def _adopt_fused_buffers(self):
         """The four weights (biases) are already adjacent row blocks of one buffer somebody else owns: use THAT as the
         fused buffer instead of re-fusing into a new one (which would take the parameters away from their owner)."""

@@ -26,6 +26,7 @@ import torch
 from . import _lib, ops
 
 ENABLED = os.environ.get("ALIGNN_AMD_CMODEL", "1") != "0"
+GRAD_SINK = os.environ.get("ALIGNN_AMD_GRAD_SINK", "1") != "0"  # backward writes into FlatAdamW's packed gradient buffer
 STATS = {"fwd": 0, "bwd": 0, "plans": 0, "rebuilds": 0, "arena_bytes": 0}
 _NOT_SUPPORTED = 801  # hipErrorNotSupported
 TIMING = None  # tools/host_profile_c.py: {"cfwd": s, "cbwd": s, "bwd_py": s} accumulated host seconds
@@ -171,6 +172,7 @@ class Binding:
         self.pinned = []
         self.plans = {}
         self.bump = None
+        self._sink_key = self._sink_plan = None
         self._layout()
 
     @property
@@ -184,6 +186,8 @@ class Binding:
         self.grad_fields = []  # (struct, field name, float offset)
         off = 0
 
+        self.grad_blocks = []  # per grad field: the parameters whose gradients form that contiguous block, in order
+
         def place(owner, field, params):
             nonlocal off
             pad = -off % 64
@@ -191,6 +195,7 @@ class Binding:
                 entries.append((None, pad))
                 off += pad
             self.grad_fields.append((owner, field, off))
+            self.grad_blocks.append(list(params))
             for p in params:
                 entries.append((p, p.numel()))
                 off += p.numel()
@@ -225,6 +230,33 @@ class Binding:
         for i in self.dead_edge:
             dead.update((id(self.convs[i].bn_edges.bias), id(self.convs[i].bn_edges.weight)))
         self.no_grad = [id(p) in dead for p in self.params]
+
+    # ---- the optimizer's packed gradient buffer as the destination of the backward (alignn_amd.optim.FlatAdamW registers
+    # itself as the model's gradient sink): every block whose parameters sit adjacent and in order in that buffer is
+    # written THERE - no 124-view gather in step(), and the data-parallel all-reduce runs on the buffer the backward wrote
+    def sink_plan(self):
+        """-> (per grad field: device address inside the sink's buffer or None, per parameter: its slot view or None) or None"""
+        ref = model_cache(self.model).get("grad_sink")
+        sink = ref() if ref is not None else None
+        if sink is None or getattr(sink, "_inner", None) is None:
+            return None
+        key = (id(sink), id(sink._grad_all), sink._grad_all.data_ptr())
+        if self._sink_key != key:
+            fields, views = [], {}
+            for params in self.grad_blocks:
+                slots = [sink.gradient_slot(p) for p in params]
+                ok = all(sl is not None and sl.is_contiguous() and sl.device == self.device for sl in slots)
+                if ok:
+                    for a, b, pa in zip(slots, slots[1:], params):
+                        ok = ok and b.data_ptr() == a.data_ptr() + 4 * pa.numel()
+                if ok:
+                    fields.append(slots[0].data_ptr())
+                    for p_, sl in zip(params, slots):
+                        views[id(p_)] = sl
+                else:
+                    fields.append(None)
+            self._sink_key, self._sink_plan = key, (fields, [views.get(id(p_)) for p_ in self.params])
+        return self._sink_plan
 
     def param_sig(self):
         """Where every parameter AND every BatchNorm buffer the C side writes lives (a reassigned ``running_mean`` /
@@ -443,8 +475,15 @@ class _ModelFn(torch.autograd.Function):
         g_out = g_out.contiguous()
         gflat = torch.empty(bind.grad_floats, dtype=torch.float32, device=bind.device)
         base = gflat.data_ptr()
-        for owner, field, off in bind.grad_fields:
-            setattr(owner, field, base + 4 * off)
+        # straight into the optimizer's packed gradient buffer where it has one and this is the first gradient of the step
+        # (p.grad is None everywhere: otherwise autograd ACCUMULATES and the slot already holds the earlier gradient)
+        plan = bind.sink_plan() if GRAD_SINK else None
+        if plan is not None and any(p.grad is not None for p in bind.params):
+            plan = None
+        for k, (owner, field, off) in enumerate(bind.grad_fields):
+            dest = plan[0][k] if plan is not None else None
+            setattr(owner, field, dest if dest is not None else base + 4 * off)
+        STATS["sink"] = STATS.get("sink", 0) + (plan is not None)
         bind.set_mode()
         t0 = time.perf_counter() if TIMING is not None else 0.0
         try:
@@ -459,8 +498,14 @@ class _ModelFn(torch.autograd.Function):
         STATS["bwd"] += 1
         pieces = gflat.split_with_sizes(bind.sizes)
         grads = []
-        for i, shape, dead in zip(bind.keep, bind.shapes, bind.no_grad):
-            grads.append(None if dead else (pieces[i] if len(shape) == 1 else pieces[i].view(shape)))
+        slots = plan[1] if plan is not None else None
+        for j, (i, shape, dead) in enumerate(zip(bind.keep, bind.shapes, bind.no_grad)):
+            if dead:
+                grads.append(None)
+            elif slots is not None and slots[j] is not None:
+                grads.append(slots[j])
+            else:
+                grads.append(pieces[i] if len(shape) == 1 else pieces[i].view(shape))
         if TIMING is not None:
             TIMING["bwd_py"] = TIMING.get("bwd_py", 0.0) + time.perf_counter() - t_in
         return (None,) * 6 + tuple(grads)

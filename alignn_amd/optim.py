@@ -55,6 +55,19 @@ def _fused_groups(module: torch.nn.Module):
     return out
 
 
+def _gradient_runs(module: torch.nn.Module):
+    """Parameter lists a module wants adjacent (in that order) because its backward writes their gradients as one block."""
+    out = []
+    for m in module.modules():
+        f = getattr(m, "_gradient_runs", None)
+        if f is not None:
+            out += [list(r) for r in f()]
+    return out
+
+
+LAYOUT_VERSION = 2  # order of the parameters inside a group's flat range (2: + gradient runs); checked by load_state_dict
+
+
 class FlatAdamW(torch.optim.Optimizer):
     """``FlatAdamW(model)`` (one group, decay everywhere), ``FlatAdamW(group_decay(model), module=model)`` (the
     reference's two groups) or any iterable of parameters / group dicts.  ``module``: where to look for layers that keep
@@ -122,6 +135,7 @@ class FlatAdamW(torch.optim.Optimizer):
             if not any(live_idx):
                 raise RuntimeError("FlatAdamW.step() before any backward(): no parameter has a gradient")
         fused = _fused_groups(self.module) if self.module is not None else []
+        runs = _gradient_runs(self.module) if self.module is not None else []
         self._flat, self._live, self._live_idx, self._offsets, self._adopted = [], [], [], [], []
         flats = []
         # ONE buffer for all groups (each group a contiguous range of it: one all-reduce covers everything), ranges
@@ -152,6 +166,11 @@ class FlatAdamW(torch.optim.Optimizer):
                         for p in run:
                             order.append(p)
                             seen.add(id(p))
+            for run in runs:  # (dbeta | dgamma) pairs the whole-model backward writes as one block
+                if all(id(p) in ids for p in run) and not any(id(p) in seen for p in run):
+                    for p in run:
+                        order.append(p)
+                        seen.add(id(p))
             order += [p for p in members if id(p) not in seen]
             if any(p.dtype != first.dtype or p.device != first.device for p in order):
                 raise ValueError("FlatAdamW needs all parameters on one device in one dtype")
@@ -188,6 +207,30 @@ class FlatAdamW(torch.optim.Optimizer):
                 pin()
         self._inner = torch.optim.AdamW([dict(params=[fp], **{k: g[k] for k in _HYPER}) for fp, g in flats],
                                         fused=flats[0][0].is_cuda)
+        # where every live parameter's gradient lives in the packed buffer: a backward that can write whole blocks
+        # (alignn_amd/cmodel.py: the whole-model C calls) writes THERE, and step() has nothing left to gather
+        self._slot = {}
+        for fp, members, offs in zip(self._flat, self._live, self._offsets):
+            if fp is not None:
+                for p, off in zip(members, offs):
+                    self._slot[id(p)] = fp.grad[off:off + p.numel()].view(p.shape)
+        self._register_sink()
+
+    def _register_sink(self):
+        if self.module is None:
+            return
+        try:
+            import weakref
+
+            from . import cmodel
+
+            cmodel.model_cache(self.module)["grad_sink"] = weakref.ref(self)
+        except Exception:  # (a module that cannot be weakly referenced / hashed: the gather in step() stays)
+            pass
+
+    def gradient_slot(self, p):
+        """The view of the packed gradient buffer that belongs to parameter ``p`` (None: not a live parameter / not built)."""
+        return getattr(self, "_slot", {}).get(id(p))
 
     def _check_aliasing(self):
         """Every live parameter must still be its slice of the flat buffer; put back the ones that are not."""
@@ -223,13 +266,20 @@ class FlatAdamW(torch.optim.Optimizer):
         for g, fp, members in zip(self.param_groups, self._flat, self._live):
             if fp is None:
                 continue
-            grads = []
+            grads, src, dst = [], [], []
             for p in members:
                 if p.grad is None:
                     raise RuntimeError("a parameter that had a gradient at the first step() has none now: FlatAdamW's "
                                        "layout is fixed at the first step")
                 grads.append(p.grad.reshape(-1))
-            torch.cat(grads, out=fp.grad)  # one batched copy
+                slot = self._slot[id(p)]
+                if p.grad.data_ptr() != slot.data_ptr():
+                    src.append(p.grad)
+                    dst.append(slot)
+            if len(src) == len(members):
+                torch.cat(grads, out=fp.grad)  # one batched copy
+            elif src:  # the backward wrote most gradients in place: copy the few it could not
+                torch._foreach_copy_(dst, src)
             ig = self._inner.param_groups[k]
             for h in _HYPER:  # what a scheduler wrote into OUR groups since the last step
                 ig[h] = g[h]
@@ -263,6 +313,7 @@ class FlatAdamW(torch.optim.Optimizer):
         return {
             "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups],
             "live_idx": [list(ix) for ix in self._live_idx] if self._inner is not None else None,
+            "layout": LAYOUT_VERSION,
             "inner": self._inner.state_dict() if self._inner is not None else None,
         }
 
@@ -278,6 +329,9 @@ class FlatAdamW(torch.optim.Optimizer):
             g.update({k: v for k, v in sg.items() if k != "params"})  # (never the saved index lists: 'params' stay the tensors)
         if state.get("inner") is None:
             return
+        if state.get("layout", 1) != LAYOUT_VERSION and self.module is not None and _gradient_runs(self.module):
+            raise ValueError(f"FlatAdamW state dict with parameter layout {state.get('layout', 1)}, this version lays the flat "
+                             f"buffers out as {LAYOUT_VERSION} (the moments would be misaligned): re-create the optimizer state")
         if [list(ix) for ix in state["live_idx"]] != [list(ix) for ix in self._live_idx] or self._inner is None:
             self._build(state["live_idx"])  # (compared by CONTENT: an equal-length but different live set is another layout)
         self._inner.load_state_dict(state["inner"])

@@ -93,6 +93,61 @@ def spawn_ranks(n):
     return subprocess.run(cmd, env=env).returncode
 
 
+def bind_rank_to_its_gpus_cores(dev_index, local_rank, world):
+    """One rank per GPU on one host (the driver's 8-GPU launch): pin this process to the cores of its GPU's NUMA node - read
+    from sysfs by the GPU's PCI address (/sys/bus/pci/devices/<domain:bus:dev.fn>/local_cpulist) - divided among the ranks
+    that share the node; without that information an even split of the host's cores by local rank.  The eagerly launched
+    step needs ~3-6 ms of ONE core per rank: eight ranks hopping over 256 hardware threads and remote memory is what the
+    slow-host numbers of round 4 looked like.  ALIGNN_BENCH_BIND=0 leaves the affinity alone.  -> description (for the line)."""
+    if world <= 1 or os.environ.get("ALIGNN_BENCH_BIND", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except OSError:
+        return None
+    how, cpus = "even split of the allowed cores by local rank", None
+    try:
+        pr = torch.cuda.get_device_properties(dev_index)
+        addr = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        with open(f"/sys/bus/pci/devices/{addr}/local_cpulist") as f:
+            spec = f.read().strip()
+        node_cpus = []
+        for part in spec.split(","):
+            if part:
+                a, _, b = part.partition("-")
+                node_cpus += list(range(int(a), int(b or a) + 1))
+        node_cpus = [c for c in node_cpus if c in set(allowed)]
+        if node_cpus and len(node_cpus) < len(allowed):  # (a node that is the whole host says nothing)
+            with open(f"/sys/bus/pci/devices/{addr}/numa_node") as f:
+                node = int(f.read().strip())
+            # ranks whose GPUs sit on the same node share its cores: slice by the rank's position among them
+            peers = []
+            for r in range(world):
+                q = torch.cuda.get_device_properties(r % torch.cuda.device_count())
+                qa = f"{getattr(q, 'pci_domain_id', 0):04x}:{q.pci_bus_id:02x}:{q.pci_device_id:02x}.0"
+                try:
+                    with open(f"/sys/bus/pci/devices/{qa}/numa_node") as f:
+                        if int(f.read().strip()) == node:
+                            peers.append(r)
+                except OSError:
+                    peers.append(r)
+            k, n = (peers.index(local_rank) if local_rank in peers else 0), max(1, len(peers))
+            per = max(1, len(node_cpus) // n)
+            cpus = node_cpus[k * per:(k + 1) * per] or node_cpus
+            how = f"NUMA node {node} of GPU {addr}, slice {k + 1}/{n}"
+    except (OSError, ValueError, AttributeError, RuntimeError):
+        cpus = None
+    if cpus is None:
+        per = max(1, len(allowed) // world)
+        cpus = allowed[local_rank * per:(local_rank + 1) * per] or allowed
+    try:
+        os.sched_setaffinity(0, cpus)
+    except OSError:
+        return None
+    torch.set_num_threads(max(1, min(len(cpus), 8)))
+    return {"cores": len(cpus), "first_core": cpus[0], "how": how}
+
+
 def algorithmic_bytes_per_step(N, E, T, la=4, lg=4, h=H, he=64):
     """compulsory HBM traffic of a maximally fused schedule (fp32)."""
     row = 4 * h
@@ -413,6 +468,7 @@ def main():
         assert dist.get_world_size() == world
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
+    binding = bind_rank_to_its_gpus_cores(dev_index, local_rank, world)
 
     from alignn_amd import ALIGNN, ALIGNNConfig, GraphBatch, ops
     from alignn_amd.ddp import FlatGradSync, broadcast_parameters
@@ -700,7 +756,21 @@ def main():
             dist.all_reduce(buf)
         e1.record()
         torch.cuda.synchronize()
+        # what the HOST of every rank needed to enqueue a step (eight ranks share one host: the margin the eager headline has)
+        he = torch.tensor([t_enq / args.steps * 1e3, -t_enq / args.steps * 1e3], device=dev, dtype=torch.float64)
+        dist.all_reduce(he, op=dist.ReduceOp.MAX)
+        # data parallelism keeps the replicas identical: every rank must hold bit-identical parameters after the timed steps
+        # (the all-reduced gradient is the same tensor everywhere; a rank that missed a collective or raced one would drift)
+        bits = torch.cat([p_.detach().reshape(-1) for p_ in model.parameters()]).view(torch.int32).to(torch.int64)
+        chk = torch.stack([bits.sum(), (bits * (torch.arange(bits.numel(), device=dev) % 8191 + 1)).sum()])
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         multi = {"ranks_seen": int(seen.item()), "backend": backend, "rank_ms_per_step_max": round(dt / args.steps * 1e3, 3),
+                 "rank_host_enqueue_ms_per_step_max": round(float(he[0].item()), 3),
+                 "rank_host_enqueue_ms_per_step_min": round(-float(he[1].item()), 3),
+                 "parameters_bit_equal_across_ranks": bool(torch.equal(lo, hi)),
+                 "rank0_cpu_binding": binding,
                  "rank_ms_per_step_min": round(dt_min / args.steps * 1e3, 3), "rank0_ms_per_step": round(dt_rank / args.steps * 1e3, 3),
                  "allreduce_bytes": buf.numel() * buf.element_size(),
                  "allreduce_ms_in_step_incl_divide": None if ar_in_step is None else round(ar_in_step, 4),

@@ -132,6 +132,22 @@ def test_bench_two_ranks_on_one_gpu_with_hipgraph_capture_beside_the_collective(
     assert out["eager_launches"] is not None and out["loss"] == out["loss"]  # (not NaN)
 
 
+def test_eight_ranks_on_one_gpu_rehearsal_of_the_drivers_scaling_run():
+    """The launch shape of the driver's 8-GPU scaling run, rehearsed on the one GPU of this box: ``bench.py --gpus 8`` self-
+    spawned, eight ranks sharing the device (gloo collectives), 8 crystals per rank, eagerly launched steps AND hipGraph
+    replays beside the packed-gradient all-reduce.  Every rank is counted, nothing deadlocks, and after the timed steps every
+    rank holds BIT-identical parameters (the data-parallel invariant: a rank that missed or raced a collective would drift)."""
+    out, err = _bench(["--gpus", "8"] + SMALL, {"ALIGNN_BENCH_BACKEND": "gloo"}, timeout=1500)
+    assert out["n_gpus"] == 8 and out["config"]["global_batch"] == 64 and out["config"]["parallelism"] == "dp8"
+    mg = out["multi_gpu"]
+    assert mg["ranks_seen"] == 8 and mg["collectives_per_step"] == 1
+    assert mg["parameters_bit_equal_across_ranks"] is True, mg
+    assert mg["rank_host_enqueue_ms_per_step_min"] <= mg["rank_host_enqueue_ms_per_step_max"]
+    assert out["replayed_steps"] is not None and out["replayed_steps"]["ms_per_step"] > 0, (out["step_launch"], err[-1500:])
+    assert out["eager_launches"] is not None and out["eager_launches"]["ms_per_step"] > 0
+    assert out["loss"] == out["loss"]
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: exercised by the driver's multi-GPU box")
 def test_bench_two_ranks_over_rccl():
     """The real thing wherever >= 2 GPUs are visible: one rank per GPU, RCCL all-reduce of the packed gradient buffer
