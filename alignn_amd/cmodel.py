@@ -503,7 +503,9 @@ class _ModelFn(torch.autograd.Function):
             if dead:
                 grads.append(None)
             elif slots is not None and slots[j] is not None:
-                grads.append(slots[j])
+                # (a FRESH view object: autograd's AccumulateGrad adopts an incoming gradient only if nobody else holds it -
+                # a cached view would be cloned, param by param)
+                grads.append(slots[j].view(shape))
             else:
                 grads.append(pieces[i] if len(shape) == 1 else pieces[i].view(shape))
         if TIMING is not None:

@@ -62,7 +62,9 @@ def _train(model, batches, targets, use_c, ff=True, steps_opt=True):
         torch.cuda.synchronize()
         out = {"out": o["out"].detach().clone(), "loss": loss.detach().clone()}
         if ff:
-            out["forces"], out["stress"] = o["grad"].detach().clone(), o["stresses"].detach().clone().to(DEV)
+            out["forces"] = o["grad"].detach().clone()
+            if o["stresses"].dim() == 3:  # (else: the reference's uninitialised placeholder)
+                out["stress"] = o["stresses"].detach().clone()
         out.update({"g." + k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
         out.update({"p." + k: p.detach().clone() for k, p in model.named_parameters()})
         return out
