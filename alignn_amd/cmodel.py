@@ -26,6 +26,10 @@ import torch
 from . import _lib, ops
 
 ENABLED = os.environ.get("ALIGNN_AMD_CMODEL", "1") != "0"
+# a convolution's edge input gradient written over its own dead gate pre-activation (csrc/model.hip edge_grad_buffer): 2.8 GB of
+# the 19.3 GB workspace at the benchmark batch.  The tape then does not survive the backward: a SECOND backward of a retained
+# graph raises (set cmodel.REUSE_TAPE = False for loss.backward(retain_graph=True) followed by another backward).
+REUSE_TAPE = os.environ.get("ALIGNN_AMD_REUSE_TAPE", "1") != "0"
 GRAD_SINK = os.environ.get("ALIGNN_AMD_GRAD_SINK", "1") != "0"  # backward writes into FlatAdamW's packed gradient buffer
 STATS = {"fwd": 0, "bwd": 0, "plans": 0, "rebuilds": 0, "arena_bytes": 0}
 _NOT_SUPPORTED = 801  # hipErrorNotSupported
@@ -67,7 +71,7 @@ class ModelDesc(C.Structure):
         ("fc_W", _p), ("fc_b", _p), ("g_fc_W", _p), ("g_fc_b", _p),
         ("weight_descs", _p), ("weight_amax", _p), ("bump_ptrs", _p),
         ("n_weights", _i32), ("n_bump", _i32), ("x6_min_tiles", _i32), ("bd_segment_table", _i32),
-        ("angle_fused", _i32), ("norm", _i32),
+        ("angle_fused", _i32), ("norm", _i32), ("reuse_tape", _i32), ("pad_", _i32),
         ("amax_min_rows", _i64), ("lane_min_rows", _i64), ("side_min_rows", _i64),
         ("lane_T", _p), ("side", _p), ("aux", _p)]
 
@@ -353,6 +357,7 @@ class Binding:
         d.side_min_rows = 0 if capturing else ops._SIDE["min_rows"]
         d.aux = self.streams[2].cuda_stream if ops.FORK_DGRAD != "0" else None
         d.angle_fused = int(ops.ANGLE_FUSED)
+        d.reuse_tape = int(REUSE_TAPE)
         return capturing
 
     def batch_struct(self, b):
@@ -370,7 +375,7 @@ class Binding:
     def plan(self, mb):
         key = (mb.g.n, mb.g.m, mb.lg.m, mb.B, mb.lg.dense_max_src, bool(mb.lg.grp_seg_ptr), bool(mb.lg.seg_rank),
                bool(mb.g.seg_node), bool(self.desc.lane_T), bool(self.desc.side), bool(self.desc.aux),
-               self.desc.side_min_rows, self.desc.lane_min_rows, self.desc.angle_fused)
+               self.desc.side_min_rows, self.desc.lane_min_rows, self.desc.angle_fused, self.desc.reuse_tape)
         hit = self.plans.get(key)
         if hit is None:
             fwd, tot = C.c_size_t(0), C.c_size_t(0)
@@ -463,6 +468,10 @@ class _ModelFn(torch.autograd.Function):
         if ctx.arena is None:
             raise RuntimeError("alignn_amd.cmodel: backward called twice on a forward that ran in a workspace of its own "
                                "(released after the first backward)")
+        if getattr(ctx, "tape_spent", False):
+            raise RuntimeError("alignn_amd.cmodel: second backward through the same forward - the first one reused parts of the "
+                               "forward's workspace (cmodel.REUSE_TAPE); set alignn_amd.cmodel.REUSE_TAPE = False (or "
+                               "ALIGNN_AMD_REUSE_TAPE=0) for loss.backward(retain_graph=True) followed by another backward")
         if ctx.shared_gen and (bind.arena is not ctx.arena or bind.arena_gen != ctx.shared_gen or
                                (bind.arena_busy and not ctx.lease.owns)):
             # loss.backward(retain_graph=True) followed by another backward is fine as long as the forward's tape is intact
@@ -496,6 +505,7 @@ class _ModelFn(torch.autograd.Function):
             if not ctx.shared_gen:
                 ctx.arena = None  # a block of its own (up to 20 GB): do not keep it for as long as the graph object lives
         STATS["bwd"] += 1
+        ctx.tape_spent = bool(bind.desc.reuse_tape)
         pieces = gflat.split_with_sizes(bind.sizes)
         grads = []
         slots = plan[1] if plan is not None else None

@@ -642,6 +642,16 @@ void col_sum(Ctx& c, const float* x, int64_t ldx, int64_t rows, int F, float* ou
 // where a weight-gradient product over `rows` rows goes: the side stream, or (few rows, eagerly launched) the caller's
 hipStream_t side_for(Ctx& c, int64_t rows) { return (c.side != c.main && rows >= c.d->side_min_rows) ? c.side : c.main; }
 
+// Where the gradient of a convolution's edge input goes.  With desc->reuse_tape: over the convolution's own gate pre-activation
+// m (t.M) - dead by then: its last readers (the norm's reductions, the gate reverse kernels) precede the product that writes the
+// gradient on the SAME stream, and that product reads the pre-activation of the convolution BEFORE this one (the BatchNorm-
+// backward epilogue's xn), never its own.  One T-row buffer per line-graph convolution less (2.8 GB at the benchmark batch).
+// Not for the force-field calls: their second-order pass reads the evaluation's tape.
+float* edge_grad_buffer(Ctx& c, const ConvTape& t, int64_t m, int Kin) {
+    if (c.d->reuse_tape && c.ff == nullptr && t.M != nullptr && Kin == c.d->H) return t.M;
+    return c.alloc((size_t)m * Kin);
+}
+
 // ops.MLPLayerFn.backward
 Grad mlp_bwd_ln(Ctx& c, const MlpTape& t, const Grad& gy, bool need_gx);
 Grad mlp_bwd(Ctx& c, const MlpTape& t, const Grad& gy, bool need_gx) {
@@ -743,7 +753,7 @@ void conv_bwd(Ctx& c, const ConvTape& t, const Grad& gx_out, const Grad* gy_out,
     if (t.lane) c.sync(main, T);  // GP complete
     // ---- input gradients (critical path): g_x = GP wcat (+ gx_out) beside g_y = GM w_eg (+ gy_out)
     g_x.p = c.alloc((size_t)n * Kin);
-    g_y.p = c.alloc((size_t)m * Kin);
+    g_y.p = edge_grad_buffer(c, t, m, Kin);
     hipStream_t sx = main;
     if (!t.lane && c.aux != main) {  // bond graph: the (shorter) node product on the aux stream beside the edge product
         c.sync(c.aux, main);
@@ -855,7 +865,7 @@ void conv_bwd_ln(Ctx& c, const ConvTape& t, const Grad& gx_out, const Grad* gy_o
     }
     if (t.lane) c.sync(main, T);
     // ---- input gradients
-    g_y.p = c.alloc((size_t)m * Kin);
+    g_y.p = edge_grad_buffer(c, t, m, Kin);
     hipStream_t sx = main;
     if (need_gx) {
         g_x.p = c.alloc((size_t)n * Kin);

@@ -165,3 +165,18 @@ def test_layernorm_flavour_and_force_field_plans():
     d2, _k2 = _desc(images=False)
     d2.norm = 1
     assert _ff_plan(d2, _batch(N, E, T, B), f)[0] == NOT_SUPPORTED
+
+
+def test_tape_reuse_saves_one_t_row_buffer_per_line_graph_convolution():
+    """desc.reuse_tape: the edge input gradient of a convolution is written over its own dead gate pre-activation (VERDICT r04
+    weak 11 / Next 8): at the benchmark batch 4 T-row buffers (+ 8 E-row ones) of the backward's share disappear."""
+    N, E, T, B = 3840, 50712, 676200, 64
+    d, _keep = _desc()
+    rc, fwd, tot = _plan(d, _batch(N, E, T, B))
+    d.reuse_tape = 1
+    rc2, fwd2, tot2 = _plan(d, _batch(N, E, T, B))
+    assert rc == 0 and rc2 == 0 and fwd2 == fwd
+    t_row, e_row = T * 1024, E * 1024
+    saved = tot - tot2
+    assert 4 * t_row + 8 * e_row - (1 << 20) < saved < 4 * t_row + 8 * e_row + (1 << 20), saved / t_row
+    assert tot2 < 16.6e9 < tot  # (19.3 GB -> 16.5 GB)
