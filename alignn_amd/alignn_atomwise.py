@@ -371,9 +371,8 @@ class ALIGNNAtomWise(nn.Module):
         if fused_forces:
             with ops.no_param_grad():
                 return self._forward_fused(b, True)
-        # (one stream: the LayerNorm kernels are not bit-reproducible beside a T-row kernel on another stream - round 5,
-        # profiles/r05_ln_concurrency.txt; the BatchNorm model keeps its lanes)
-        return self._forward_fused(b, False)
+        with ops.lanes(self.fc.weight.device):
+            return self._forward_fused(b, False)
 
     def _forward_c(self, b: GraphBatch):
         """The whole-model C entry points (csrc/model.hip) where they apply - the plain energy / force / stress head, float32 on

@@ -827,9 +827,6 @@ void conv_bwd_ln(Ctx& c, const ConvTape& t, const Grad& gx_out, const Grad* gy_o
     // ---- node branch: LayerNorm / SiLU backward straight into the Ux block of GP, the quotient's adjoints
     const int n_slabs = alignn_ln_slabs(n);
     float* n_part = c.alloc((size_t)n_slabs * 2 * H);
-    // (helper streams for the LayerNorm flavour are off by default, see set_streams; with them on, this wait keeps the node
-    // branch from running beside the T-row product of the convolution before it - the pairing the fault of round 5 was found in)
-    if (t.lane) c.sync(main, c.T);
     L(alignn_ln_silu_bwd(gx_out.p, H, t.xpre, H, p.n_gamma, p.n_beta, t.n_stat, g_xpre, 4 * H, n_part, n, H, gp_amax, main));
     if (c.param_grads) L(alignn_bn_bwd_finalize(n_part, n_slabs, H, p.n_red, main));
     float* gs1 = c.alloc((size_t)n * H);
@@ -1433,17 +1430,14 @@ void set_streams(Ctx& c, alignn_stream_t st) {
     c.T = c.d->lane_T ? (hipStream_t)c.d->lane_T : c.main;
     c.side = c.d->side ? (hipStream_t)c.d->side : c.main;
     c.aux = c.d->aux ? (hipStream_t)c.d->aux : c.main;
-    // LayerNorm flavour: ONE stream (round 5).  With helper streams the LayerNorm reverse kernel (ln_silu_bwd_kernel, csrc/norm.hip)
-    // intermittently returned ONE float4 component of lanes 48-63 of a row wrong (up to 10 %) when a T-row product ran beside it -
-    // same inputs, same partial sums, every other lane bit-identical; first seen in hipGraph replays at 16 crystals, in eagerly
-    // launched steps at 48 (tools/ff_alloc_diff.py, tools/ff_repro_check.py, profiles/r05_ln_concurrency.txt); the per-operator
-    // path of round 4 (ops.lanes + side stream) shows it too.  Not a missing dependency (every placement of extra events was
-    // tried) and not understood; until it is, nothing runs beside the LayerNorm kernels: 0.4 ms of a 37 ms force-training step.
-    // ALIGNN_AMD_LN_STREAMS=1|2|3 restores lane T + aux / the side stream / all three for experiments.  (The BatchNorm flavour -
-    // other kernels - is bit-reproducible on four streams: tests/test_gpu_cmodel.py.)
+    // LayerNorm flavour: helper streams like the BatchNorm flavour's.  (Round 5 found its steps not bit-reproducible on helper
+    // streams - forces off by 1e-3, run to run - and traced it to the packed-fp32 code hipcc emitted for ln_silu_bwd_kernel: one
+    // float4 component of lanes 48-63 wrong while an MFMA kernel of another stream shared the compute unit; csrc/norm.hip and
+    // csrc/dual.hip are built without SLP vectorisation since - alignn_amd/build.py)
+    // ALIGNN_AMD_LN_STREAMS=0 puts the LayerNorm flavour on ONE stream (bit 0: lane T + aux, bit 1: side).
     if (c.d->norm == 1) {
         static int ln_streams = -1;
-        if (ln_streams < 0) ln_streams = getenv("ALIGNN_AMD_LN_STREAMS") ? atoi(getenv("ALIGNN_AMD_LN_STREAMS")) : 0;
+        if (ln_streams < 0) ln_streams = getenv("ALIGNN_AMD_LN_STREAMS") ? atoi(getenv("ALIGNN_AMD_LN_STREAMS")) : 3;
         if (!(ln_streams & 1)) c.T = c.aux = c.main;
         if (!(ln_streams & 2)) c.side = c.main;
     }

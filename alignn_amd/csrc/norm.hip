@@ -590,6 +590,8 @@ __global__ __launch_bounds__(kThreads) void ln_silu_fwd_kernel(const float* __re
     block_amax_commit(am, amax);
 }
 
+// NOTE: this file is compiled with -fno-slp-vectorize (alignn_amd/build.py): with packed-fp32 instructions hipcc 7.2's code for
+// the kernel below was not bit-reproducible beside kernels of another stream.
 template <int NC>
 __global__ __launch_bounds__(kThreads) void ln_silu_bwd_kernel(const float* __restrict__ GY, int64_t ldgy,
                                                                const float* __restrict__ X, int64_t ldx,

@@ -92,17 +92,12 @@ def _deferred_join_is_safe(params):
     return True
 
 
-def on_side_stream(fn, inputs, params=(), wait=(), one_stream=False):
+def on_side_stream(fn, inputs, params=(), wait=()):
     """Run ``fn()`` (kernel launches only) on the side stream; returns its tensors.  ``inputs`` are the tensors it
     reads (kept alive for the allocator until the side stream has consumed them); ``params`` the leaves whose
     gradients it computes - they decide whether the join may wait until the end of backward()
-    (``_deferred_join_is_safe``) or has to happen before this call returns.  ``one_stream``: stay on the caller's stream
-    (the LayerNorm flavour: its kernels are not bit-reproducible beside kernels of another stream - round 5,
-    profiles/r05_ln_concurrency.txt)."""
-    if not _SIDE["enabled"] or one_stream:
-        for ev in wait:
-            if ev is not None:
-                torch.cuda.current_stream(inputs[0].device).wait_event(ev)
+    (``_deferred_join_is_safe``) or has to happen before this call returns."""
+    if not _SIDE["enabled"]:
         return fn()
     dev = inputs[0].device
     main = torch.cuda.current_stream(dev)
@@ -1242,8 +1237,7 @@ class MLPLayerFn(torch.autograd.Function):
             return out
 
         gw, gb = on_side_stream(lambda: (gemm_tn(gpre, x, g_amax, x_amax), bias_grad()),
-                                [gpre, x, g_amax, x_amax, gb_part[0] if gb_part is not None else None], ctx.wb, wait=(ev,),
-                                one_stream=ctx.norm == "layer")
+                                [gpre, x, g_amax, x_amax, gb_part[0] if gb_part is not None else None], ctx.wb, wait=(ev,))
         return gx, gw, gb, dgamma, dbeta, None, None, None, None
 
 
@@ -1961,7 +1955,7 @@ class EdgeGatedConvFn(torch.autograd.Function):
         if not ctx.param_grads:
             return (None, g_x, g_y) + (None,) * 24
         g_weg, g_beg, g_wcat, g_bcat = on_side_stream(_wgrads, [GM, y, GP, x, gb_part, gm_amax, gp_amax, x_amax, y_amax],
-                                                      ctx.leaves, wait=(ev_d,), one_stream=layer)
+                                                      ctx.leaves, wait=(ev_d,))
         dn_gamma, dn_beta = n_red[1], n_red[0]
         de_gamma = e_red[1] if e_red is not None else None
         de_beta = e_red[0] if e_red is not None else None
