@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libalignn_hip.so")
-SOURCES = ["norm.hip", "conv.hip", "gemm_f32.hip", "gemm_x6.hip", "embed.hip", "dual.hip", "knn.hip", "composite.hip", "model.hip", "stage.hip", "radius.hip", "angle.hip", "ff.hip"]
+SOURCES = ["norm.hip", "conv.hip", "gemm_f32.hip", "gemm_x6.hip", "embed.hip", "dual.hip", "knn.hip", "composite.hip", "model.hip", "stage.hip", "radius.hip", "angle.hip", "ff.hip", "convln.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # Per-file additions.  norm.hip / dual.hip (the LayerNorm kernels and their dual-number twins): no SLP vectorisation, i.e. no
 # packed-fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 with op_sel).  With them hipcc 7.2's code for
@@ -24,7 +24,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # compiled without them (or at -O1) every run is bit-identical (round 5: DESIGN.md section 4e, profiles/r05_ln_concurrency.txt).
 # The streaming kernels of these two files are memory-bound: no measurable cost (headline 14.89 vs 14.84-14.89 ms, force training
 # 37.30 vs 37.24-37.28 ms, same box).  The whole library without SLP costs the headline 0.55 ms (projection / gate epilogues).
-EXTRA_FLAGS = {"norm.hip": ["-fno-slp-vectorize"], "dual.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"norm.hip": ["-fno-slp-vectorize"], "dual.hip": ["-fno-slp-vectorize"], "convln.hip": ["-fno-slp-vectorize"]}
 
 
 def _headers():

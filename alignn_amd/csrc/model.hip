@@ -435,19 +435,27 @@ void conv_fwd_ln(Ctx& c, ConvTape& t, const alignn_conv_params& p, const alignn_
         } else
             L(alignn_gemm_nt_f16x3_gather(y.p, Kin, y.amax, p.weg_img, p.weg_amax, p.b_eg, t.M, H, m, H, Kin, t.P, 4 * H, g.src,
                                           g.dst, nullptr, T));
-        L(alignn_egc_gate_fwd_pre(t.P, t.M, g.seg_ptr, g.seg_node, g.src, n, m, H, t.xpre, t.s0, t.hh, nullptr, nullptr, T));
+        if (!(need_y && alignn_egc_ln_fused_supported(H)))
+            L(alignn_egc_gate_fwd_pre(t.P, t.M, g.seg_ptr, g.seg_node, g.src, n, m, H, t.xpre, t.s0, t.hh, nullptr, nullptr, T));
     } else {
         L(alignn_gemm_nt(y.p, Kin, p.w_eg, Kin, p.b_eg, nullptr, 0, t.M, H, m, H, Kin, T));
         L(alignn_egc_gate_fwd(t.P, t.M, g.seg_ptr, g.seg_node, g.src, n, m, H, t.xpre, t.s0, t.hh, nullptr, nullptr, T));
     }
-    if (t.lane) c.sync(main, T);
     Act yo;
     if (need_y) {
         yo.p = c.alloc((size_t)m * H);
         yo.amax = c.track(m) ? c.new_amax() : nullptr;
         t.e_stat = c.alloc((size_t)m * 2);
-        L(alignn_ln_silu_fwd(t.M, H, y.p, Kin, p.e_gamma, p.e_beta, c.d->eps, yo.p, H, t.e_stat, m, H, yo.amax, T));
         yo.on_T = t.lane;
+    }
+    if (need_y && pre_added && alignn_egc_ln_fused_supported(H)) {
+        // the edge LayerNorm inside the gate pass (csrc/convln.hip): one read of m less
+        L(alignn_egc_gate_fwd_pre_ln(t.P, t.M, g.seg_ptr, g.seg_node, g.src, n, m, H, t.xpre, t.s0, t.hh, p.e_gamma, p.e_beta, c.d->eps,
+                                     y.p, yo.p, t.e_stat, yo.amax, T));
+        if (t.lane) c.sync(main, T);
+    } else {
+        if (t.lane) c.sync(main, T);
+        if (need_y) L(alignn_ln_silu_fwd(t.M, H, y.p, Kin, p.e_gamma, p.e_beta, c.d->eps, yo.p, H, t.e_stat, m, H, yo.amax, T));
     }
     t.n_stat = c.alloc((size_t)n * 2);
     Act xo;
@@ -835,8 +843,11 @@ void conv_bwd_ln(Ctx& c, const ConvTape& t, const Grad& gx_out, const Grad* gy_o
     // ---- edge branch (lane T for the line graph): the finished normalised-branch gradient, handed over as it is
     const float* gy = gy_out != nullptr ? gy_out->p : nullptr;
     if (t.lane && gy_out != nullptr && !gy_out->on_T) c.sync(T, main);
+    const bool lg_blocks = g.grp_seg_ptr != nullptr;
+    const bool dense = lg_blocks && g.dense_max_src > 0 && alignn_egc_bwd_lg_dense_supported(g.dense_max_src);
+    const bool ln_inside = gy != nullptr && dense && alignn_egc_ln_fused_supported(H);  // (csrc/convln.hip)
     float* g_branch = nullptr;
-    if (gy != nullptr) {
+    if (gy != nullptr && !ln_inside) {
         g_branch = c.alloc((size_t)m * H);
         const int e_slabs = alignn_ln_slabs(m);
         float* e_part = c.alloc((size_t)e_slabs * 2 * H);
@@ -845,11 +856,14 @@ void conv_bwd_ln(Ctx& c, const ConvTape& t, const Grad& gx_out, const Grad* gy_o
     }
     if (t.lane) c.sync(T, main);
     float* GM = c.alloc((size_t)m * H);
-    const bool lg_blocks = g.grp_seg_ptr != nullptr;
-    const bool dense = lg_blocks && g.dense_max_src > 0 && alignn_egc_bwd_lg_dense_supported(g.dense_max_src);
     const int gslabs = lg_blocks ? (int)g.n_groups : alignn_egc_slabs(n);
     float* gb_part = c.alloc((size_t)gslabs * H);
-    if (dense)
+    if (ln_inside) {
+        float* e_part = c.alloc((size_t)gslabs * 2 * H);
+        L(alignn_egc_bwd_lg_dense_ln(gy, t.M, t.P, gs1, gs0, p.e_gamma, p.e_beta, t.e_stat, m, g.grp_seg_ptr, g.grp_src_ptr, g.n_groups,
+                                     g.dense_max_src, g.seg_ptr, g.seg_node, H, GM, GP, gb_part, e_part, gm_amax, gp_amax, T));
+        if (c.param_grads) L(alignn_bn_bwd_finalize(e_part, gslabs, H, p.e_red, T));
+    } else if (dense)
         L(alignn_egc_bwd_lg_dense(g_branch, t.M, t.P, gs1, gs0, nullptr, nullptr, 0, m, g.grp_seg_ptr, g.grp_src_ptr, g.n_groups,
                                   g.dense_max_src, g.seg_ptr, g.seg_node, H, GM, GP, gb_part, gm_amax, gp_amax, T));
     else if (lg_blocks)
@@ -1211,10 +1225,24 @@ void dual_conv_fwd(Ctx& c, DConvTape& t, const alignn_conv_params& p, const Conv
     t.hh = fwd.hh;
     t.s0t = c.alloc((size_t)n * H);
     t.hht = c.alloc((size_t)n * H);
+    y_out = DAct{};
+    if (need_y && fwd.e_stat != nullptr && alignn_egc_ln_fused_supported(H)) {
+        // the tangent of the edge LayerNorm inside the gate pass (csrc/convln.hip); the row statistics are the evaluation's
+        y_out.p = fwd.y_out.p;
+        y_out.amax_p = fwd.y_out.amax;
+        y_out.t = c.alloc((size_t)m * H);
+        float* amax2 = c.track(m) ? c.new_amax2() : nullptr;
+        L(alignn_egc_gate_dual_tan_ln(t.P.p, t.P.t, t.M.p, t.M.t, g.seg_ptr, g.seg_node, g.src, n, m, H, t.xpre.t, t.s0, t.hh, t.s0t,
+                                      t.hht, p.e_gamma, p.e_beta, fwd.e_stat, y.t, y_out.t, amax2, c.main));
+        y_out.amax_t = amax2 ? amax2 + 1 : nullptr;
+        if (y_out.amax_p == nullptr && amax2 != nullptr) y_out.amax_p = amax2;
+        t.e_stats = fwd.e_stat;
+        x_out = dual_ln_fwd(c, t.xpre, &x, p.n_gamma, p.n_beta, fwd.x_out, n, H, &t.n_stats);
+        return;
+    }
     L(alignn_egc_gate_dual_fwd_tangent(t.P.p, t.P.t, t.M.p, t.M.t, g.seg_ptr, g.seg_node, g.src, n, m, H, t.xpre.t, t.s0, t.hh, t.s0t,
                                        t.hht, c.main));
     x_out = dual_ln_fwd(c, t.xpre, &x, p.n_gamma, p.n_beta, fwd.x_out, n, H, &t.n_stats);
-    y_out = DAct{};
     if (need_y) y_out = dual_ln_fwd(c, t.M, &y, p.e_gamma, p.e_beta, fwd.y_out, m, H, &t.e_stats);
 }
 
@@ -1286,8 +1314,10 @@ void dual_conv_bwd(Ctx& c, const DConvTape& t, const DAct& gx, const DAct& gy, D
     float* q1t = c.alloc((size_t)n * H);
     float* q0t = c.alloc((size_t)n * H);
     L(alignn_egc_node_dual_bwd(gxpre.p, gxpre.t, 4 * H, t.s0, t.hh, t.s0t, t.hht, q1, q0, q1t, q0t, n, H, c.main));
+    const bool dense = c.ff->dense_lg_reverse && g.grp_seg_ptr != nullptr && g.dense_max_src > 0;
+    const bool ln_inside = gy.p != nullptr && dense && alignn_egc_ln_fused_supported(H);  // (csrc/convln.hip)
     DAct GL;
-    if (gy.p != nullptr) {
+    if (gy.p != nullptr && !ln_inside) {
         float* amax2 = c.track(m) ? c.new_amax2() : nullptr;
         float* lp = c.alloc((size_t)m * H);
         float* lt = c.alloc((size_t)m * H);
@@ -1297,10 +1327,17 @@ void dual_conv_bwd(Ctx& c, const DConvTape& t, const DAct& gx, const DAct& gy, D
     GM.t = c.alloc((size_t)m * H);
     GM.amax_p = c.track(m) ? c.new_amax2() : nullptr;
     GM.amax_t = GM.amax_p ? GM.amax_p + 1 : nullptr;
-    const bool dense = c.ff->dense_lg_reverse && g.grp_seg_ptr != nullptr && g.dense_max_src > 0;
     int slabs;
     float* gb_part;
-    if (dense) {  // line graph: destination- and source-ordered halves in one pass over the dense blocks
+    if (ln_inside) {
+        slabs = (int)g.n_groups;
+        gb_part = c.alloc((size_t)slabs * H);
+        float* e_part = c.alloc((size_t)slabs * 2 * H);
+        L(alignn_egc_dual_bwd_lg_dense_ln(gy.p, gy.t, t.M.p, t.M.t, t.P.p, t.P.t, q1, q0, q1t, q0t, p.e_gamma, p.e_beta, t.e_stats, m,
+                                          g.grp_seg_ptr, g.grp_src_ptr, slabs, g.seg_ptr, g.seg_node, H, GM.p, GM.t, GP.p, GP.t, gb_part,
+                                          e_part, GM.amax_p, GP.amax_p, c.main));
+        L(alignn_bn_bwd_finalize(e_part, slabs, H, p.e_red, c.main));
+    } else if (dense) {  // line graph: destination- and source-ordered halves in one pass over the dense blocks
         slabs = (int)g.n_groups;
         gb_part = c.alloc((size_t)slabs * H);
         L(alignn_egc_dual_bwd_lg_dense(GL.p, GL.t, t.M.p, t.M.t, t.P.p, t.P.t, q1, q0, q1t, q0t, m, g.grp_seg_ptr, g.grp_src_ptr, slabs,

@@ -191,11 +191,25 @@ def conv_fwd(conv, graph: CSRGraph, x: Dual, y: Dual, need_y, tape, fwd=None):
     if (ent is not None and ent[0] == "conv" and tuple(ent[3].shape) == (n, 4 * H) and tuple(ent[4].shape) == (m, H)
             and (ent[9] is not None or not need_y)):
         # values from the force evaluation; here the tangents only: two tangent projections, the tangent half of the gate pass
-        _, _x, _y, P_p, M_p, xpre_p, s0, hh, xo, yo = ent
+        _, _x, _y, P_p, M_p, xpre_p, s0, hh, xo, yo, e_rows = ent
         P = Dual(P_p.detach(), ops.project(x.t, wcat, None, a_amax=x.am(1)))
         M = Dual(M_p.detach(), ops.project(y.t, conv.edge_gate.weight, None, a_amax=y.am(1)))
         xpre = Dual(xpre_p.detach(), _empty(n, H, like=x.p))
         s0t, hht = _empty(n, H, like=x.p), _empty(n, H, like=x.p)
+        if need_y and e_rows is not None and tuple(e_rows.shape) == (m, 2) and lib.alignn_egc_ln_fused_supported(H):
+            # the tangent of the edge LayerNorm inside the gate pass (csrc/convln.hip); row statistics from the evaluation
+            yp, yp_amax = _taken_over(yo)
+            yt = _empty(m, H, like=x.p)
+            amax = _amax2(x.p) if _track(m) else None
+            check(lib.alignn_egc_gate_dual_tan_ln(ptr(P.p), ptr(P.t), ptr(M.p), ptr(M.t), ptr(graph.seg_ptr), ptr(graph.seg_node),
+                                                  ptr(graph.src), n, m, H, ptr(xpre.t), ptr(s0), ptr(hh), ptr(s0t), ptr(hht),
+                                                  ptr(conv.bn_edges.weight), ptr(conv.bn_edges.bias), ptr(e_rows),
+                                                  ptr(y.t) if res else None, ptr(yt), ptr(amax), stream()),
+                  "egc_gate_dual_tan_ln")
+            y_out, e_stats = Dual(yp, yt, amax, yp_amax), e_rows.detach()
+            x_out, n_stats = _ln_fwd(xpre, x if res else None, conv.bn_nodes.weight, conv.bn_nodes.bias, value_out=_taken_over(xo))
+            tape.append(("conv", conv, graph, x, y, P, M, xpre, (s0, hh, s0t, hht), n_stats, e_stats))
+            return x_out, y_out
         check(lib.alignn_egc_gate_dual_fwd_tangent(ptr(P.p), ptr(P.t), ptr(M.p), ptr(M.t), ptr(graph.seg_ptr), ptr(graph.seg_node),
                                                    ptr(graph.src), n, m, H, ptr(xpre.t), ptr(s0), ptr(hh), ptr(s0t), ptr(hht),
                                                    stream()), "egc_gate_dual_fwd_tangent")
@@ -237,15 +251,30 @@ def conv_bwd(entry, gx: Dual, gy, grads: _Grads):
     q1, q0, q1t, q0t = (_empty(n, H, like=x.p) for _ in range(4))
     check(lib.alignn_egc_node_dual_bwd(ptr(gxpre.p), ptr(gxpre.t), 4 * H, ptr(s0), ptr(hh), ptr(s0t), ptr(hht), ptr(q1),
                                        ptr(q0), ptr(q1t), ptr(q0t), n, H, stream()), "egc_node_dual_bwd")
+    dense = (DENSE_LG_REVERSE and graph.grp_seg_ptr is not None and graph.dense_max_src > 0 and ops.FUSED_LG_BACKWARD
+             and ops.DENSE_LG_BACKWARD)
+    ln_inside = bool(gy is not None and dense and lib.alignn_egc_ln_fused_supported(H))  # (csrc/convln.hip)
     GL = None
-    if gy is not None:
+    if gy is not None and not ln_inside:
         GL, e_red = _ln_bwd(gy, M, conv.bn_edges.weight, conv.bn_edges.bias, e_stats)
         grads.add(conv.bn_edges.bias, e_red[0])
         grads.add(conv.bn_edges.weight, e_red[1])
     GM = Dual(_empty(m, H, like=x.p), _empty(m, H, like=x.p), _amax2(x.p) if _track(m) else None)
-    dense = (DENSE_LG_REVERSE and graph.grp_seg_ptr is not None and graph.dense_max_src > 0 and ops.FUSED_LG_BACKWARD
-             and ops.DENSE_LG_BACKWARD)
-    if dense:  # line graph: destination- and source-ordered halves in one pass over the dense blocks (6 row passes, not 10)
+    if ln_inside:  # the LayerNorm reverse inside the dense gate reverse
+        slabs = graph.grp_seg_ptr.numel() - 1
+        gb_part = _empty(slabs, H, like=x.p)
+        ln_part = _empty(slabs, 2, H, like=x.p)
+        check(lib.alignn_egc_dual_bwd_lg_dense_ln(ptr(gy.p), ptr(gy.t), ptr(M.p), ptr(M.t), ptr(P.p), ptr(P.t), ptr(q1), ptr(q0),
+                                                  ptr(q1t), ptr(q0t), ptr(conv.bn_edges.weight), ptr(conv.bn_edges.bias),
+                                                  ptr(e_stats), m, ptr(graph.grp_seg_ptr), ptr(graph.grp_src_ptr), slabs,
+                                                  ptr(graph.seg_ptr), ptr(graph.seg_node), H, ptr(GM.p), ptr(GM.t), ptr(GP.p),
+                                                  ptr(GP.t), ptr(gb_part), ptr(ln_part), ptr(GM.amax), ptr(GP.amax), stream()),
+              "egc_dual_bwd_lg_dense_ln")
+        e_red = _empty(2, H, like=x.p)
+        check(lib.alignn_bn_bwd_finalize(ptr(ln_part), slabs, H, ptr(e_red), stream()), "ln_dual_finalize")
+        grads.add(conv.bn_edges.bias, e_red[0])
+        grads.add(conv.bn_edges.weight, e_red[1])
+    elif dense:  # line graph: destination- and source-ordered halves in one pass over the dense blocks (6 row passes, not 10)
         slabs = graph.grp_seg_ptr.numel() - 1
         gb_part = _empty(slabs, H, like=x.p)
         check(lib.alignn_egc_dual_bwd_lg_dense(ptr(GL.p) if GL else None, ptr(GL.t) if GL else None, ptr(M.p), ptr(M.t),

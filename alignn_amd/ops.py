@@ -1567,6 +1567,19 @@ class EdgeGatedConvFn(torch.autograd.Function):
                     fused_out["y"] = set_amax(y_o, y_amax) if y_amax is not None else y_o
                     return
                 e_part = None  # dead edge output: plain pre-added gate pass, the statistics are already in e_stat
+            if norm == "layer" and pre_added and need_y and lib.alignn_egc_ln_fused_supported(H):
+                # LayerNorm flavour on a line graph: the edge LayerNorm inside the gate pass (csrc/convln.hip)
+                y_o = _empty(m, H, like=x)
+                y_amax = new_amax(x) if _track(m) else None
+                e_rows = _empty(m, 2, like=x)
+                check(
+                    lib.alignn_egc_gate_fwd_pre_ln(ptr(P), ptr(M), ptr(graph.seg_ptr), ptr(graph.seg_node), ptr(graph.src), n, m,
+                                                   H, ptr(xpre), ptr(s0), ptr(hh), ptr(e_gamma), ptr(e_beta), LN_EPS,
+                                                   ptr(y) if residual else None, ptr(y_o), ptr(e_rows), ptr(y_amax), stream()),
+                    "egc_gate_fwd_pre_ln",
+                )
+                fused_out["ln"] = (set_amax(y_o, y_amax) if y_amax is not None else y_o, e_rows)
+                return
             fn = lib.alignn_egc_gate_fwd_pre if pre_added else lib.alignn_egc_gate_fwd
             check(
                 fn(ptr(P), ptr(M), ptr(graph.seg_ptr), ptr(graph.seg_node), ptr(graph.src), n, m, H, ptr(xpre), ptr(s0),
@@ -1580,6 +1593,8 @@ class EdgeGatedConvFn(torch.autograd.Function):
                 _register_norm_src(y_o, M, fused_out["e_stat"])
                 return y_o, fused_out["e_stat"]
             if norm == "layer":  # LayerNorm flavour (alignn_atomwise.py:151,155): per-row statistics, no global barrier
+                if "ln" in fused_out:
+                    return fused_out["ln"]
                 if need_y:
                     return _ln_silu_fwd(M, y if residual else None, e_gamma, e_beta)
                 return None, _empty(1, 2, like=x)
@@ -1626,7 +1641,7 @@ class EdgeGatedConvFn(torch.autograd.Function):
         ctx.leaves = (w_sg, w_dg, w_du, w_su, b_sg, b_dg, b_du, b_su, w_eg, b_eg)
         ctx.save_for_backward(x, y, wcat, w_eg, P, M, xpre, s0, hh, n_stat, e_stat, n_gamma, e_gamma, n_beta, e_beta)
         if FORWARD_TAPE is not None and norm == "layer":
-            FORWARD_TAPE[w_eg.data_ptr()] = ("conv", x, y, P, M, xpre, s0, hh, x_out, y_out)
+            FORWARD_TAPE[w_eg.data_ptr()] = ("conv", x, y, P, M, xpre, s0, hh, x_out, y_out, e_stat)
         return x_out, y_out
 
     @staticmethod
@@ -1849,6 +1864,8 @@ class EdgeGatedConvFn(torch.autograd.Function):
             gy_out = gy_out.contiguous()
         lg_blocks = graph.grp_seg_ptr is not None and FUSED_LG_BACKWARD
         dense = lg_blocks and DENSE_LG_BACKWARD and lib.alignn_egc_bwd_lg_dense_supported(graph.dense_max_src)
+        ln_inside = bool(layer and dense and gy_out is not None and lib.alignn_egc_ln_fused_supported(H))  # (csrc/convln.hip)
+        fused_red = {}
 
         def edge_branch():
             """norm backward of the edge output, then the gate backward: writes GM [m,H], the A | Bd | Bh blocks of GP and
@@ -1856,7 +1873,9 @@ class EdgeGatedConvFn(torch.autograd.Function):
             e_red = None
             g_branch, e_stat_arg = gy_out, e_stat
             if gy_out is not None:
-                if layer:
+                if ln_inside:
+                    pass  # (LayerNorm backward inside the gate backward: gate_backward below)
+                elif layer:
                     # LayerNorm: finish the normalised-branch gradient here, hand it over as-is (e_stat = NULL)
                     g_branch = _empty(m, H, like=x)
                     e_red = _ln_silu_bwd(gy_out, M, e_gamma, e_beta, e_stat, g_branch)
@@ -1869,7 +1888,21 @@ class EdgeGatedConvFn(torch.autograd.Function):
 
         def gate_backward(e_red, g_branch, e_stat_arg):
             GM = _empty(m, H, like=x)
-            if dense:
+            if ln_inside:
+                gslabs = graph.grp_seg_ptr.numel() - 1
+                gb_part = _empty(gslabs, H, like=x)
+                ln_part = _empty(gslabs, 2, H, like=x)
+                check(
+                    lib.alignn_egc_bwd_lg_dense_ln(ptr(gy_out), ptr(M), ptr(P), ptr(gs1), ptr(gs0), ptr(e_gamma), ptr(e_beta),
+                                                   ptr(e_stat), m, ptr(graph.grp_seg_ptr), ptr(graph.grp_src_ptr), gslabs,
+                                                   graph.dense_max_src, ptr(graph.seg_ptr), ptr(graph.seg_node), H, ptr(GM),
+                                                   ptr(GP), ptr(gb_part), ptr(ln_part), ptr(gm_amax), ptr(gp_amax), stream()),
+                    "egc_bwd_lg_dense_ln",
+                )
+                red = _empty(2, H, like=x)
+                check(lib.alignn_bn_bwd_finalize(ptr(ln_part), gslabs, H, ptr(red), stream()), "ln_finalize")
+                fused_red["e"] = red
+            elif dense:
                 # line graph with dense, source-sorted blocks: one pass, rows addressed by index arithmetic
                 gslabs = graph.grp_seg_ptr.numel() - 1
                 gb_part = _empty(gslabs, H, like=x)
@@ -1922,6 +1955,7 @@ class EdgeGatedConvFn(torch.autograd.Function):
                 e_red, g_branch, e_stat_arg = edge_branch()  # (independent of the node branch: no wait yet)
                 T.wait_event(ev_n)
                 GM, gb_part, gslabs = gate_backward(e_red, g_branch, e_stat_arg)
+                e_red = fused_red.get("e", e_red)
                 ev_d = _event_after(T)
                 g_y = edge_dgrad(GM)
             main.wait_event(ev_d)  # GP complete: the node input gradient below reads it
@@ -1938,6 +1972,7 @@ class EdgeGatedConvFn(torch.autograd.Function):
         else:
             e_red, g_branch, e_stat_arg = edge_branch()
             GM, gb_part, gslabs = gate_backward(e_red, g_branch, e_stat_arg)
+            e_red = fused_red.get("e", e_red)
         # projections: weight gradients on the side stream, input gradients (critical path) on the main one
         def _wgrads():
             g_beg_ = _empty(H, like=x)  # column sum of GM, accumulated inside the destination-order pass

@@ -449,6 +449,44 @@ int alignn_egc_dual_bwd_lg_dense(const float* GL, const float* GLt, const float*
                                  float* GPt, float* gb_partial, float* gm_amax2, float* gp_amax2, alignn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Line-graph convolutions of the LayerNorm flavour with the edge LayerNorm inside the gate passes (csrc/convln.hip).
+ * Reference: EdgeGatedGraphConv.forward with nn.LayerNorm, alignn/models/alignn_atomwise.py:151-208 (:199-206 the two
+ * normalised branches), and its autograd / double backward for the reverse passes.  A wavefront of the gate passes holds a
+ * whole H <= 256 row of m, so the row statistics are wave reductions and y' = y + silu(LN(m)) (forward) resp. the LayerNorm /
+ * SiLU adjoint of g_y' (reverse) cost no pass of their own.  Same formulas and summation orders as the separate kernels
+ * (alignn_ln_silu_fwd / _bwd, alignn_ln_silu_dual_fwd / _bwd + the gate passes); LayerNorm parameter gradients leave as
+ * ln_partial [n_groups][2][H] (dbeta | dgamma per workgroup; alignn_bn_bwd_finalize sums the slabs in order).
+ * e_stat [m][2] = (mean, rstd) per row, written by the forward, read by everything else.
+ * alignn_egc_ln_fused_supported(H): 1 when they apply (H % 4 == 0, H <= 256, ALIGNN_AMD_LN_FUSED != 0). */
+int alignn_egc_ln_fused_supported(int H);
+/* alignn_egc_gate_fwd_pre (M holds m = A[u] + Bd[v] + C) + alignn_ln_silu_fwd(M, residual Y or NULL) -> YOUT, e_stat, y_amax */
+int alignn_egc_gate_fwd_pre_ln(const float* P, const float* M, const int32_t* seg_ptr, const int32_t* seg_node, const int32_t* src,
+                               int64_t n_seg, int64_t m_rows, int H, float* XPRE, float* S0, float* HH, const float* gamma,
+                               const float* beta, float eps, const float* Y, float* YOUT, float* e_stat, float* y_amax,
+                               alignn_stream_t stream);
+/* alignn_ln_silu_bwd(GY, M) + alignn_egc_bwd_lg_dense(MODE 2): GY is the adjoint of the edge OUTPUT (before the LayerNorm) */
+int alignn_egc_bwd_lg_dense_ln(const float* GY, const float* M, const float* P, const float* GS1, const float* GS0,
+                               const float* gamma, const float* beta, const float* e_stat, int64_t m_rows,
+                               const int32_t* grp_seg_ptr, const int32_t* grp_src_ptr, int64_t n_groups, int max_group_src,
+                               const int32_t* seg_ptr, const int32_t* seg_node, int H, float* GM, float* GP, float* gb_partial,
+                               float* ln_partial, float* gm_amax, float* gp_amax, alignn_stream_t stream);
+/* alignn_egc_gate_dual_fwd_tangent + the tangent of y' = y + silu(LN(m)) (alignn_ln_silu_dual_fwd with Y == NULL): Mt holds Ct
+ * on entry and mt on exit, Yt = Rt + d[silu o LN](m) . mt; amax2[1] is raised to max|Yt| */
+int alignn_egc_gate_dual_tan_ln(const float* P, const float* Pt, const float* M, float* Mt, const int32_t* seg_ptr,
+                                const int32_t* seg_node, const int32_t* src, int64_t n, int64_t m, int H, float* xpre_t,
+                                const float* s0, const float* hh, float* s0t, float* hht, const float* gamma, const float* beta,
+                                const float* e_stat, const float* Rt, float* Yt, float* amax2, alignn_stream_t stream);
+/* alignn_ln_silu_dual_bwd(GY, GYt, M, Mt) + alignn_egc_dual_bwd_lg_dense: GY / GYt are the adjoints of the edge output's value
+ * and tangent */
+int alignn_egc_dual_bwd_lg_dense_ln(const float* GY, const float* GYt, const float* M, const float* Mt, const float* P,
+                                    const float* Pt, const float* q1, const float* q0, const float* q1t, const float* q0t,
+                                    const float* gamma, const float* beta, const float* e_stat, int64_t m_rows,
+                                    const int32_t* grp_seg_ptr, const int32_t* grp_src_ptr, int64_t n_groups,
+                                    const int32_t* seg_ptr, const int32_t* seg_node, int H, float* GM, float* GMt, float* GP,
+                                    float* GPt, float* gb_partial, float* ln_partial, float* gm_amax2, float* gp_amax2,
+                                    alignn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Periodic k-nearest-neighbour bond lists on the device (csrc/knn.hip).
  * Replace alignn/graphs.py:155-264 (nearest_neighbor_edges on jarvis' get_all_neighbors, canonize_edge :128-153,
  * build_undirected_edgedata :230-264), which alignn/ff/calculators.py:280-291 re-runs at every MD step.
