@@ -21,15 +21,30 @@
 
 namespace {
 
-constexpr int kW = 4, kT = kW * ALIGNN_WAVE, kMaxBlocks = 1024, kK = 4, kB = 2;
+constexpr int kW = 4, kT = kW * ALIGNN_WAVE, kMaxBlocks = 1024, kK = 4;
 
+// Sum over the 64 lanes of a wavefront, the result in every lane.  Within a row of 16 lanes by DPP adds (xor 1, xor 2, mirror
+// of 8, mirror of 16: every lane of the row ends with the row's sum), the four rows by v_readlane - 4 DPP adds + 4 readlanes + 3
+// adds instead of the 6 ds_bpermute round trips of the __shfl_xor butterfly (the LayerNorm passes below take 2-7 such sums per
+// row).  Fixed order: ((r0 + r1) + (r2 + r3)) over the row sums.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float wave_sum1(float v) {
+    v += dpp_mov<0xB1>(v);   // quad_perm [1, 0, 3, 2]
+    v += dpp_mov<0x4E>(v);   // quad_perm [2, 3, 0, 1]
+    v += dpp_mov<0x141>(v);  // row_half_mirror
+    v += dpp_mov<0x140>(v);  // row_mirror
+    const int b = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+    return (r0 + r1) + (r2 + r3);
+}
 template <int K>
 __device__ __forceinline__ void wave_sum_k(float (&v)[K]) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-        for (int k = 0; k < K; ++k) v[k] += __shfl_xor(v[k], o, 64);
-    }
+    for (int k = 0; k < K; ++k) v[k] = wave_sum1(v[k]);
 }
 __device__ __forceinline__ float hsum4(float4 a) { return (a.x + a.y) + (a.z + a.w); }
 __device__ __forceinline__ float sig_f(float x) { return fast_sigmoid(x); }
@@ -153,7 +168,7 @@ __global__ __launch_bounds__(kT) void egc_gate_fwd_ln_kernel(
 // reverse: ln_silu_bwd_kernel on (GY, M) + egc_bwd_lg_dense_kernel<2, STREAM> (dense, source-sorted line-graph blocks: the
 // index arithmetic is explained there)
 // ---------------------------------------------------------------------------------------------------------------------
-template <bool STREAM>
+template <bool STREAM, int KS, int KB>
 __global__ __launch_bounds__(kT) void egc_bwd_lg_dense_ln_kernel(
     const float* __restrict__ GY, const float* __restrict__ M, const float* __restrict__ P, const float* __restrict__ GS1,
     const float* __restrict__ GS0, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -174,10 +189,10 @@ __global__ __launch_bounds__(kT) void egc_bwd_lg_dense_ln_kernel(
     const float4 lg = active ? f4_ld(gamma + f) : f4_zero(), lb = active ? f4_ld(beta + f) : f4_zero();
     float gm_am = 0.0f, gp_am = 0.0f;
     float4 gb = f4_zero(), db = f4_zero(), dg = f4_zero();
-    for (int qb = 0; qb < n_src || qb == 0; qb += kW * kK) {
-        float4 bh[kK], ga[kK], gbh[kK];
+    for (int qb = 0; qb < n_src || qb == 0; qb += kW * KS) {
+        float4 bh[KS], ga[KS], gbh[KS];
 #pragma unroll
-        for (int k = 0; k < kK; ++k) {
+        for (int k = 0; k < KS; ++k) {
             const int q = qb + wave + kW * k;
             bh[k] = (active && q < n_src) ? f4_ld(P + (int64_t)(p_beg + q) * ldp + 2 * H + f) : f4_zero();
             ga[k] = gbh[k] = f4_zero();
@@ -190,15 +205,15 @@ __global__ __launch_bounds__(kT) void egc_bwd_lg_dense_ln_kernel(
             const float4 g1 = active ? f4_ld(GS1 + (int64_t)i * H + f) : f4_zero();
             const float4 g0 = active ? f4_ld(GS0 + (int64_t)i * H + f) : f4_zero();
             float4 gbd = f4_zero();
-            // (rows in sub-batches of kB: the LayerNorm part keeps three rows' worth of registers per row alive across its
+            // (rows in sub-batches of KB: the LayerNorm part keeps three rows' worth of registers per row alive across its
             // wave reductions - all four at once cost the pass a wave per SIMD)
 #pragma unroll
-            for (int kb = 0; kb < kK; kb += kB) {
-                float4 m[kB], xh[kB], gh[kB];
-                float s1[kB], s2[kB], rs[kB];
-                int row[kB];
+            for (int kb = 0; kb < KS; kb += KB) {
+                float4 m[KB], xh[KB], gh[KB];
+                float s1[KB], s2[KB], rs[KB];
+                int row[KB];
 #pragma unroll
-                for (int kk = 0; kk < kB; ++kk) {
+                for (int kk = 0; kk < KB; ++kk) {
                     const int q = qb + wave + kW * (kb + kk);
                     row[kk] = (q < n_src && q != self_q) ? e0 + q - ((self_q >= 0 && q > self_q) ? 1 : 0) : -1;
                     m[kk] = xh[kk] = gh[kk] = f4_zero();
@@ -224,7 +239,7 @@ __global__ __launch_bounds__(kT) void egc_bwd_lg_dense_ln_kernel(
                 wave_sum_k(s1);
                 wave_sum_k(s2);
 #pragma unroll
-                for (int kk = 0; kk < kB; ++kk) {
+                for (int kk = 0; kk < KB; ++kk) {
                     const int k = kb + kk;
                     if (row[kk] >= 0 && active) {
                         const float c1 = s1[kk] * inv_f, c2 = s2[kk] * inv_f;
@@ -265,7 +280,7 @@ __global__ __launch_bounds__(kT) void egc_bwd_lg_dense_ln_kernel(
         }
         if (active) {
 #pragma unroll
-            for (int k = 0; k < kK; ++k) {
+            for (int k = 0; k < KS; ++k) {
                 const int q = qb + wave + kW * k;
                 if (q < n_src) {
                     f4_st(GP + (int64_t)(p_beg + q) * ldp + f, ga[k]);
@@ -375,7 +390,7 @@ __global__ __launch_bounds__(kT) void egc_gate_dual_tan_ln_kernel(
 // ---------------------------------------------------------------------------------------------------------------------
 // dual reverse: ln_silu_dual_bwd_kernel on (GY, GYt, M, Mt) + egc_dual_bwd_lg_dense_kernel<true, STREAM>
 // ---------------------------------------------------------------------------------------------------------------------
-template <bool STREAM>
+template <bool STREAM, int KS, int KB, bool EARLY>
 __global__ __launch_bounds__(kT) void egc_dual_bwd_lg_dense_ln_kernel(
     const float* __restrict__ GY, const float* __restrict__ GYt, const float* __restrict__ M, const float* __restrict__ Mt,
     const float* __restrict__ P, const float* __restrict__ Pt, const float* __restrict__ Q1, const float* __restrict__ Q0,
@@ -397,10 +412,10 @@ __global__ __launch_bounds__(kT) void egc_dual_bwd_lg_dense_ln_kernel(
     const float4 lg = active ? f4_ld(gamma + f) : f4_zero(), lb = active ? f4_ld(beta + f) : f4_zero();
     float am = 0.0f, amt = 0.0f, pam = 0.0f, pamt = 0.0f;
     float4 gb = f4_zero(), db = f4_zero(), dg = f4_zero();
-    for (int qb = 0; qb < n_src || qb == 0; qb += kW * kK) {
-        float4 bh[kK], bht[kK], ga[kK], gat[kK], gbh[kK], gbht[kK];
+    for (int qb = 0; qb < n_src || qb == 0; qb += kW * KS) {
+        float4 bh[KS], bht[KS], ga[KS], gat[KS], gbh[KS], gbht[KS];
 #pragma unroll
-        for (int k = 0; k < kK; ++k) {
+        for (int k = 0; k < KS; ++k) {
             const int q = qb + wave + kW * k;
             const bool have = active && q < n_src;
             bh[k] = have ? f4_ld(P + (int64_t)(p_beg + q) * ldp + 2 * H + f) : f4_zero();
@@ -415,14 +430,14 @@ __global__ __launch_bounds__(kT) void egc_dual_bwd_lg_dense_ln_kernel(
             const float4 q1 = active ? f4_ld(Q1 + (int64_t)i * H + f) : f4_zero(), q0 = active ? f4_ld(Q0 + (int64_t)i * H + f) : f4_zero();
             const float4 q1t = active ? f4_ld(Q1t + (int64_t)i * H + f) : f4_zero(), q0t = active ? f4_ld(Q0t + (int64_t)i * H + f) : f4_zero();
             float4 gbd = f4_zero(), gbdt = f4_zero();
-            // per row: m, x-hat, t = mt, the LayerNorm adjoints a (of t-hat) and b (of x-hat); rows in sub-batches of kB
+            // per row: m, x-hat, t = mt, the LayerNorm adjoints a (of t-hat) and b (of x-hat); rows in sub-batches of KB
 #pragma unroll
-            for (int kb = 0; kb < kK; kb += kB) {
-                float4 m[kB], xh[kB], t[kB], a[kB], b[kB];
-                float r0[kB], r1[kB], r2[kB], rs[kB], m2[kB];
-                int row[kB];
+            for (int kb = 0; kb < KS; kb += KB) {
+                float4 m[KB], xh[KB], t[KB], a[KB], b[KB], gye[EARLY ? KB : 1], gyte[EARLY ? KB : 1];
+                float r0[KB], r1[KB], r2[KB], rs[KB], m2[KB];
+                int row[KB];
 #pragma unroll
-                for (int kk = 0; kk < kB; ++kk) {
+                for (int kk = 0; kk < KB; ++kk) {
                     const int q = qb + wave + kW * (kb + kk);
                     row[kk] = (q < n_src && q != self_q) ? e0 + q - ((self_q >= 0 && q > self_q) ? 1 : 0) : -1;
                     m[kk] = xh[kk] = t[kk] = a[kk] = b[kk] = f4_zero();
@@ -433,6 +448,10 @@ __global__ __launch_bounds__(kT) void egc_dual_bwd_lg_dense_ln_kernel(
                         if (active) {
                             m[kk] = f4_lds<STREAM>(M + (int64_t)row[kk] * H + f);
                             t[kk] = f4_lds<STREAM>(Mt + (int64_t)row[kk] * H + f);
+                            if (EARLY) {  // (requested with m and mt: one exposed latency per sub-batch instead of two)
+                                gye[kk] = f4_lds<STREAM>(GY + (int64_t)row[kk] * H + f);
+                                gyte[kk] = f4_lds<STREAM>(GYt + (int64_t)row[kk] * H + f);
+                            }
                             xh[kk] = make_float4((m[kk].x - mean) * rs[kk], (m[kk].y - mean) * rs[kk], (m[kk].z - mean) * rs[kk],
                                                  (m[kk].w - mean) * rs[kk]);
                             r0[kk] = hsum4(t[kk]);
@@ -443,12 +462,13 @@ __global__ __launch_bounds__(kT) void egc_dual_bwd_lg_dense_ln_kernel(
                 wave_sum_k(r0);
                 wave_sum_k(r1);
 #pragma unroll
-                for (int kk = 0; kk < kB; ++kk) {
+                for (int kk = 0; kk < KB; ++kk) {
                     const float m1 = r0[kk] * inv_f;
                     m2[kk] = r1[kk] * inv_f;
                     r0[kk] = r1[kk] = r2[kk] = 0.0f;  // -> sum a, sum a x-hat, sum a t-hat
                     if (row[kk] >= 0 && active) {
-                        const float4 gy = f4_lds<STREAM>(GY + (int64_t)row[kk] * H + f), gyt = f4_lds<STREAM>(GYt + (int64_t)row[kk] * H + f);
+                        const float4 gy = EARLY ? gye[kk] : f4_lds<STREAM>(GY + (int64_t)row[kk] * H + f);
+                        const float4 gyt = EARLY ? gyte[kk] : f4_lds<STREAM>(GYt + (int64_t)row[kk] * H + f);
 #define ALIGNN_LN_DB(q)                                                                     \
     {                                                                                       \
         const float th = rs[kk] * (t[kk].q - m1 - xh[kk].q * m2[kk]);                       \
@@ -472,9 +492,9 @@ __global__ __launch_bounds__(kT) void egc_dual_bwd_lg_dense_ln_kernel(
                 wave_sum_k(r0);
                 wave_sum_k(r1);
                 wave_sum_k(r2);
-                float A1[kB], A2[kB], A3[kB];
+                float A1[KB], A2[KB], A3[KB];
 #pragma unroll
-                for (int kk = 0; kk < kB; ++kk) {
+                for (int kk = 0; kk < KB; ++kk) {
                     A1[kk] = r0[kk] * inv_f, A2[kk] = r1[kk] * inv_f, A3[kk] = r2[kk] * inv_f;
                     r0[kk] = r1[kk] = 0.0f;  // -> sum b, sum b x-hat
                     if (row[kk] >= 0 && active) {
@@ -489,7 +509,7 @@ __global__ __launch_bounds__(kT) void egc_dual_bwd_lg_dense_ln_kernel(
                 wave_sum_k(r0);
                 wave_sum_k(r1);
 #pragma unroll
-                for (int kk = 0; kk < kB; ++kk) {
+                for (int kk = 0; kk < KB; ++kk) {
                     const int k = kb + kk;
                     if (row[kk] >= 0 && active) {
                         const float B1 = r0[kk] * inv_f, B2 = r1[kk] * inv_f;
@@ -546,7 +566,7 @@ __global__ __launch_bounds__(kT) void egc_dual_bwd_lg_dense_ln_kernel(
         }
         if (active) {
 #pragma unroll
-            for (int k = 0; k < kK; ++k) {
+            for (int k = 0; k < KS; ++k) {
                 const int q = qb + wave + kW * k;
                 if (q < n_src) {
                     f4_st(GP + (int64_t)(p_beg + q) * ldp + f, ga[k]);
@@ -572,6 +592,13 @@ __global__ __launch_bounds__(kT) void egc_dual_bwd_lg_dense_ln_kernel(
     }
 }
 
+// sources per wave and pass / rows per sub-batch of the two reverse kernels (ALIGNN_AMD_LN_REV = "<value><dual>", A/B runs)
+inline int reverse_variant(int which) {  // (read per call: A/B runs inside one process)
+    const char* e = std::getenv("ALIGNN_AMD_LN_REV");
+    if (e == nullptr || e[0] < '0' || e[0] > '9') return 0;
+    if (which == 0) return e[0] - '0';
+    return (e[1] >= '0' && e[1] <= '9') ? e[1] - '0' : 0;
+}
 inline bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
@@ -581,10 +608,8 @@ extern "C" {
 /* 1 when the fused passes below apply to rows of H features (one feature panel per wavefront; ALIGNN_AMD_LN_FUSED=0 switches
    them off everywhere: the callers then run the separate LayerNorm kernels - same results up to summation order) */
 int alignn_egc_ln_fused_supported(int H) {
-    static const int on = [] {
-        const char* e = std::getenv("ALIGNN_AMD_LN_FUSED");
-        return (e == nullptr || e[0] != '0') ? 1 : 0;
-    }();
+    const char* e = std::getenv("ALIGNN_AMD_LN_FUSED");  // (read per call: tests and A/B runs flip it inside one process)
+    const bool on = e == nullptr || e[0] != '0';
     return (on && H >= 4 && (H & 3) == 0 && H <= 4 * ALIGNN_WAVE) ? 1 : 0;
 }
 
@@ -614,12 +639,18 @@ int alignn_egc_bwd_lg_dense_ln(const float* GY, const float* M, const float* P, 
         !ln_partial)
         return (int)hipErrorInvalidValue;
     const dim3 grid((int)n_groups), block(kT);
-    if (big_stream(m_rows, H))
-        hipLaunchKernelGGL(egc_bwd_lg_dense_ln_kernel<true>, grid, block, 0, (hipStream_t)stream, GY, M, P, GS1, GS0, gamma, beta,
-                           e_stat, grp_seg_ptr, grp_src_ptr, seg_ptr, seg_node, H, GM, GP, gb_partial, ln_partial, gm_amax, gp_amax);
-    else
-        hipLaunchKernelGGL(egc_bwd_lg_dense_ln_kernel<false>, grid, block, 0, (hipStream_t)stream, GY, M, P, GS1, GS0, gamma, beta,
-                           e_stat, grp_seg_ptr, grp_src_ptr, seg_ptr, seg_node, H, GM, GP, gb_partial, ln_partial, gm_amax, gp_amax);
+    const bool big = big_stream(m_rows, H);
+#define ALIGNN_LNV(ST_, KS_, KB_)                                                                                              \
+    hipLaunchKernelGGL((egc_bwd_lg_dense_ln_kernel<ST_, KS_, KB_>), grid, block, 0, (hipStream_t)stream, GY, M, P, GS1, GS0, gamma, \
+                       beta, e_stat, grp_seg_ptr, grp_src_ptr, seg_ptr, seg_node, H, GM, GP, gb_partial, ln_partial, gm_amax,    \
+                       gp_amax)
+    // (tools/ln_rev_time.py, line graph of 16 x 200 atoms: one row at a time 426 us, rows in pairs 478; separate kernels 715-745)
+    switch (reverse_variant(0)) {
+        case 1: if (big) ALIGNN_LNV(true, 4, 2); else ALIGNN_LNV(false, 4, 2); break;
+        case 2: if (big) ALIGNN_LNV(true, 2, 2); else ALIGNN_LNV(false, 2, 2); break;
+        default: if (big) ALIGNN_LNV(true, 4, 1); else ALIGNN_LNV(false, 4, 1); break;
+    }
+#undef ALIGNN_LNV
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }
@@ -648,14 +679,20 @@ int alignn_egc_dual_bwd_lg_dense_ln(const float* GY, const float* GYt, const flo
         return (int)hipErrorInvalidValue;
     if (n_groups == 0) return 0;
     const dim3 grid((unsigned)n_groups), block(kT);
-    if (big_stream(m_rows, H))
-        hipLaunchKernelGGL(egc_dual_bwd_lg_dense_ln_kernel<true>, grid, block, 0, (hipStream_t)stream, GY, GYt, M, Mt, P, Pt, q1, q0,
-                           q1t, q0t, gamma, beta, e_stat, grp_seg_ptr, grp_src_ptr, seg_ptr, seg_node, H, GM, GMt, GP, GPt,
-                           gb_partial, ln_partial, gm_amax2, gp_amax2);
-    else
-        hipLaunchKernelGGL(egc_dual_bwd_lg_dense_ln_kernel<false>, grid, block, 0, (hipStream_t)stream, GY, GYt, M, Mt, P, Pt, q1, q0,
-                           q1t, q0t, gamma, beta, e_stat, grp_seg_ptr, grp_src_ptr, seg_ptr, seg_node, H, GM, GMt, GP, GPt,
-                           gb_partial, ln_partial, gm_amax2, gp_amax2);
+    const bool big = big_stream(m_rows, H);
+#define ALIGNN_LND(ST_, KS_, KB_, EA_)                                                                                          \
+    hipLaunchKernelGGL((egc_dual_bwd_lg_dense_ln_kernel<ST_, KS_, KB_, EA_>), grid, block, 0, (hipStream_t)stream, GY, GYt, M, Mt, P, \
+                       Pt, q1, q0, q1t, q0t, gamma, beta, e_stat, grp_seg_ptr, grp_src_ptr, seg_ptr, seg_node, H, GM, GMt, GP, GPt, \
+                       gb_partial, ln_partial, gm_amax2, gp_amax2)
+    // measured on the line graph of 16 x 200 atoms (tools/ln_rev_time.py; separate kernels 1 390-1 450 us): 4 sources per wave
+    // and pass, one row at a time, all four loads of a row requested together: 850-900 us; rows in pairs 1 020-1 050; 2 sources
+    // per wave (two passes over the segments, three waves per SIMD) 875-940
+    switch (reverse_variant(1)) {
+        case 1: if (big) ALIGNN_LND(true, 4, 2, false); else ALIGNN_LND(false, 4, 2, false); break;
+        case 2: if (big) ALIGNN_LND(true, 2, 1, false); else ALIGNN_LND(false, 2, 1, false); break;
+        default: if (big) ALIGNN_LND(true, 4, 1, true); else ALIGNN_LND(false, 4, 1, true); break;
+    }
+#undef ALIGNN_LND
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }

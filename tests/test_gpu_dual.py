@@ -225,6 +225,55 @@ def test_dense_block_dual_reverse_equals_the_two_pass_kernels(shape):
     print(f"dense-block dual reverse vs two passes ({shape}): worst per-parameter gradient difference {worst:.2e}")
 
 
+@pytest.mark.parametrize("shape,hidden,path", [("small", 64, "c"), ("deg_over_16", 64, "c"), ("medium", 256, "c"), ("medium", 256, "ops"),
+                                               ("small", 64, "ops")])
+def test_edge_layernorm_inside_the_gate_passes_equals_the_separate_kernels(shape, hidden, path, monkeypatch):
+    """csrc/convln.hip (the edge LayerNorm of a line-graph convolution formed inside the gate passes: forward, reverse, dual
+    forward, dual reverse) against the separate LayerNorm kernels + gate passes it replaces (ALIGNN_AMD_LN_FUSED=0): energies,
+    forces, stresses and every parameter gradient of an energy + force + stress loss, up to summation order.  On the whole-model
+    C calls and on the per-operator path; with atoms of more than 16 in-edges (several passes of the dense reverse kernels); and
+    at 2 x 60 atoms / 256 features, where the edge projection adds the gathered rows in its epilogue and the forward pass with
+    the LayerNorm inside applies."""
+    from alignn_amd import ALIGNNAtomWise, ALIGNNAtomWiseConfig, cmodel
+
+    raw = {"small": lambda: make_batch(3, 14, seed0=31), "deg_over_16": lambda: make_batch(4, 3, seed0=11),
+           "medium": lambda: make_batch(2, 60, seed0=5)}[shape]()
+    batch = GraphBatch.from_raw(raw, device=DEV)
+    gen = torch.Generator().manual_seed(4)
+    B = raw.batch_size
+    te, tf, ts = (torch.randn(B, generator=gen).to(DEV), torch.randn(raw.num_nodes, 3, generator=gen).to(DEV),
+                  torch.randn(B, 3, 3, generator=gen).to(DEV))
+    monkeypatch.setattr(cmodel, "ENABLED", path == "c")
+    outs = []
+    for fused in ("0", "1"):
+        monkeypatch.setenv("ALIGNN_AMD_LN_FUSED", fused)
+        torch.manual_seed(7)
+        cfg = ALIGNNAtomWiseConfig(name="alignn_atomwise", alignn_layers=2, gcn_layers=1, hidden_features=hidden,
+                                   embedding_features=32, atom_input_features=92, calculate_gradient=True,
+                                   stresswise_weight=0.05)
+        model = ALIGNNAtomWise(cfg).to(DEV).train()
+        before = dict(cmodel.STATS)
+        res = model(batch)
+        loss = F.l1_loss(res["out"], te) + F.l1_loss(res["grad"], tf) + 0.05 * F.l1_loss(res["stresses"], ts)
+        loss.backward()
+        torch.cuda.synchronize()
+        if path == "c":
+            assert cmodel.STATS["ff_eval"] == before.get("ff_eval", 0) + 1, "the whole-model C calls did not take this model"
+        o = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+        o.update({"out": res["out"].detach().clone(), "grad": res["grad"].detach().clone(), "stresses": res["stresses"].detach().clone()})
+        outs.append(o)
+    ga, gb = outs
+    assert ga.keys() == gb.keys() and len(ga) > 40
+    gmax = max(float(v.abs().max()) for k, v in gb.items() if k not in ("out", "grad", "stresses"))
+    worst = 0.0
+    for k in ga:
+        e = float((ga[k] - gb[k]).abs().max()) / max(float(gb[k].abs().max()), 1e-3 * gmax)
+        worst = max(worst, e)
+        assert e < 2e-5, (k, e)
+    assert any(not torch.equal(ga[k], gb[k]) for k in ga), "both runs took the same kernels"
+    print(f"edge LayerNorm inside the gate passes vs separate kernels ({shape}, H={hidden}, {path}): worst difference {worst:.2e}")
+
+
 def test_tangent_only_dual_forward_equals_the_full_dual_forward():
     """ff2.REUSE_FORWARD: the dual forward takes its VALUES from the force evaluation that preceded it (ops.FORWARD_TAPE) and
     computes tangents only - same parameter gradients as the dual forward that recomputes both, up to the rounding of two
