@@ -605,19 +605,25 @@ inline bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) ==
 
 extern "C" {
 
-/* 1 when the fused passes below apply to rows of H features (one feature panel per wavefront; ALIGNN_AMD_LN_FUSED=0 switches
-   them off everywhere: the callers then run the separate LayerNorm kernels - same results up to summation order) */
-int alignn_egc_ln_fused_supported(int H) {
-    const char* e = std::getenv("ALIGNN_AMD_LN_FUSED");  // (read per call: tests and A/B runs flip it inside one process)
-    const bool on = e == nullptr || e[0] != '0';
-    return (on && H >= 4 && (H & 3) == 0 && H <= 4 * ALIGNN_WAVE) ? 1 : 0;
+/* 1 when the fused passes below are the ones to take for [m_rows, H] edge tensors: H % 4 == 0, H <= 256 (one feature panel per
+   wavefront), and tensors that cannot stay in the last-level cache (>= 64 MiB each) - there a pass less is time less; on
+   cache-resident line graphs (a 200-atom MD cell: 35 k rows) the separate LayerNorm kernels win by their finer grids (tools/
+   ln_rev_time.py: 70 vs 93 us at 1 x 200 atoms, 134 vs 130 at 8 x 60, 727 vs 426 at 16 x 200).  ALIGNN_AMD_LN_FUSED=0: never,
+   =2: whenever H allows (tests).  Read per call. */
+static bool ln_h_ok(int H) { return H >= 4 && (H & 3) == 0 && H <= 4 * ALIGNN_WAVE; }
+int alignn_egc_ln_fused_supported(int H, int64_t m_rows) {
+    const char* e = std::getenv("ALIGNN_AMD_LN_FUSED");
+    if (e != nullptr && e[0] == '0') return 0;
+    if (!ln_h_ok(H)) return 0;
+    if (e != nullptr && e[0] == '2') return 1;
+    return m_rows * (int64_t)H * 4 >= ((int64_t)64 << 20) ? 1 : 0;
 }
 
 int alignn_egc_gate_fwd_pre_ln(const float* P, const float* M, const int32_t* seg_ptr, const int32_t* seg_node, const int32_t* src,
                                int64_t n_seg, int64_t m_rows, int H, float* XPRE, float* S0, float* HH, const float* gamma,
                                const float* beta, float eps, const float* Y, float* YOUT, float* e_stat, float* y_amax,
                                alignn_stream_t stream) {
-    if (!alignn_egc_ln_fused_supported(H) || n_seg < 0 || n_seg > INT32_MAX || m_rows < 0 || !YOUT || !e_stat || !gamma || !beta)
+    if (!ln_h_ok(H) || n_seg < 0 || n_seg > INT32_MAX || m_rows < 0 || !YOUT || !e_stat || !gamma || !beta)
         return (int)hipErrorInvalidValue;
     if (n_seg == 0) return 0;
     if (big_stream(m_rows, H))
@@ -635,7 +641,7 @@ int alignn_egc_bwd_lg_dense_ln(const float* GY, const float* M, const float* P, 
                                const int32_t* grp_seg_ptr, const int32_t* grp_src_ptr, int64_t n_groups, int max_group_src,
                                const int32_t* seg_ptr, const int32_t* seg_node, int H, float* GM, float* GP, float* gb_partial,
                                float* ln_partial, float* gm_amax, float* gp_amax, alignn_stream_t stream) {
-    if (!alignn_egc_ln_fused_supported(H) || n_groups <= 0 || n_groups > INT32_MAX || max_group_src <= 0 || !GY || !e_stat ||
+    if (!ln_h_ok(H) || n_groups <= 0 || n_groups > INT32_MAX || max_group_src <= 0 || !GY || !e_stat ||
         !ln_partial)
         return (int)hipErrorInvalidValue;
     const dim3 grid((int)n_groups), block(kT);
@@ -659,7 +665,7 @@ int alignn_egc_gate_dual_tan_ln(const float* P, const float* Pt, const float* M,
                                 const int32_t* seg_node, const int32_t* src, int64_t n, int64_t m, int H, float* xpre_t,
                                 const float* s0, const float* hh, float* s0t, float* hht, const float* gamma, const float* beta,
                                 const float* e_stat, const float* Rt, float* Yt, float* amax2, alignn_stream_t stream) {
-    if (!alignn_egc_ln_fused_supported(H) || !a16(P) || !a16(M) || !e_stat || !Yt) return (int)hipErrorInvalidValue;
+    if (!ln_h_ok(H) || !a16(P) || !a16(M) || !e_stat || !Yt) return (int)hipErrorInvalidValue;
     (void)m;
     if (n == 0) return 0;
     hipLaunchKernelGGL(egc_gate_dual_tan_ln_kernel, dim3(seg_blocks(n)), dim3(kT), 0, (hipStream_t)stream, P, Pt, M, Mt, seg_ptr,
@@ -675,7 +681,7 @@ int alignn_egc_dual_bwd_lg_dense_ln(const float* GY, const float* GYt, const flo
                                     const int32_t* seg_ptr, const int32_t* seg_node, int H, float* GM, float* GMt, float* GP,
                                     float* GPt, float* gb_partial, float* ln_partial, float* gm_amax2, float* gp_amax2,
                                     alignn_stream_t stream) {
-    if (!alignn_egc_ln_fused_supported(H) || !GY || !GYt || !e_stat || !ln_partial || n_groups < 0 || n_groups > INT32_MAX)
+    if (!ln_h_ok(H) || !GY || !GYt || !e_stat || !ln_partial || n_groups < 0 || n_groups > INT32_MAX)
         return (int)hipErrorInvalidValue;
     if (n_groups == 0) return 0;
     const dim3 grid((unsigned)n_groups), block(kT);

@@ -169,6 +169,7 @@ struct Ctx {
     ptrdiff_t toff = 0;  // floats from a weight-gradient destination to its tangent twin (alignn_ff_grad)
     // `waiter` continues only after everything enqueued on `src` so far
     int n_sync = 0, n_launch = 0;
+    bool dual_lanes = true;  // the second-order pass of the force field puts its T-row kernels on lane T (ALIGNN_AMD_FF_DUAL_LANES=0: not)
     double t_sync = 0.0;
     bool timing = false;
     void sync(hipStream_t waiter, hipStream_t src) {
@@ -435,7 +436,7 @@ void conv_fwd_ln(Ctx& c, ConvTape& t, const alignn_conv_params& p, const alignn_
         } else
             L(alignn_gemm_nt_f16x3_gather(y.p, Kin, y.amax, p.weg_img, p.weg_amax, p.b_eg, t.M, H, m, H, Kin, t.P, 4 * H, g.src,
                                           g.dst, nullptr, T));
-        if (!(need_y && alignn_egc_ln_fused_supported(H)))
+        if (!(need_y && alignn_egc_ln_fused_supported(H, m)))
             L(alignn_egc_gate_fwd_pre(t.P, t.M, g.seg_ptr, g.seg_node, g.src, n, m, H, t.xpre, t.s0, t.hh, nullptr, nullptr, T));
     } else {
         L(alignn_gemm_nt(y.p, Kin, p.w_eg, Kin, p.b_eg, nullptr, 0, t.M, H, m, H, Kin, T));
@@ -448,7 +449,7 @@ void conv_fwd_ln(Ctx& c, ConvTape& t, const alignn_conv_params& p, const alignn_
         t.e_stat = c.alloc((size_t)m * 2);
         yo.on_T = t.lane;
     }
-    if (need_y && pre_added && alignn_egc_ln_fused_supported(H)) {
+    if (need_y && pre_added && alignn_egc_ln_fused_supported(H, m)) {
         // the edge LayerNorm inside the gate pass (csrc/convln.hip): one read of m less
         L(alignn_egc_gate_fwd_pre_ln(t.P, t.M, g.seg_ptr, g.seg_node, g.src, n, m, H, t.xpre, t.s0, t.hh, p.e_gamma, p.e_beta, c.d->eps,
                                      y.p, yo.p, t.e_stat, yo.amax, T));
@@ -845,7 +846,7 @@ void conv_bwd_ln(Ctx& c, const ConvTape& t, const Grad& gx_out, const Grad* gy_o
     if (t.lane && gy_out != nullptr && !gy_out->on_T) c.sync(T, main);
     const bool lg_blocks = g.grp_seg_ptr != nullptr;
     const bool dense = lg_blocks && g.dense_max_src > 0 && alignn_egc_bwd_lg_dense_supported(g.dense_max_src);
-    const bool ln_inside = gy != nullptr && dense && alignn_egc_ln_fused_supported(H);  // (csrc/convln.hip)
+    const bool ln_inside = gy != nullptr && dense && alignn_egc_ln_fused_supported(H, m);  // (csrc/convln.hip)
     float* g_branch = nullptr;
     if (gy != nullptr && !ln_inside) {
         g_branch = c.alloc((size_t)m * H);
@@ -1159,6 +1160,7 @@ void run_ff_eval(Ctx& c, Tape& tp, float* out, float* forces, float* stress) {
 // ---- the second-order pass (alignn_amd/ff2.py dual_pass, REUSE_FORWARD: tangents only - the values are alignn_ff_eval's tape)
 struct DAct {  // value p and tangent t of one activation + the max|.| scalars their producers tracked (or NULL)
     float *p = nullptr, *t = nullptr, *amax_p = nullptr, *amax_t = nullptr;
+    bool on_T = false;  // the tangent was last written on lane T
 };
 struct DMlpTape {
     const alignn_mlp_params* p = nullptr;
@@ -1171,12 +1173,12 @@ struct DConvTape {
     const alignn_graph_csr* g = nullptr;
     DAct x, y, P, M, xpre;
     float *s0 = nullptr, *hh = nullptr, *s0t = nullptr, *hht = nullptr, *n_stats = nullptr, *e_stats = nullptr;
-    bool need_y = true;
+    bool need_y = true, lane = false;
 };
 
 // ff2._ln_fwd with value_out: the tangent of y = res + silu(LayerNorm(x)); the value is `known`
 DAct dual_ln_fwd(Ctx& c, const DAct& x, const DAct* res, const float* gamma, const float* beta, const Act& known, int64_t rows, int F,
-                 float** stats_out) {
+                 float** stats_out, hipStream_t st) {
     DAct y;
     y.p = known.p;
     y.amax_p = known.amax;
@@ -1184,14 +1186,14 @@ DAct dual_ln_fwd(Ctx& c, const DAct& x, const DAct* res, const float* gamma, con
     float* stats = c.alloc((size_t)rows * 2);
     float* amax2 = c.track(rows) ? c.new_amax2() : nullptr;
     L(alignn_ln_silu_dual_fwd(x.p, x.t, F, res ? res->p : nullptr, res ? res->t : nullptr, res ? F : 0, gamma, beta, c.d->eps, nullptr,
-                              y.t, F, stats, rows, F, amax2, c.main));
+                              y.t, F, stats, rows, F, amax2, st));
     y.amax_t = amax2 ? amax2 + 1 : nullptr;
     if (y.amax_p == nullptr && amax2 != nullptr) y.amax_p = amax2;  // (Dual.am(0) falls back to the pair's first scalar)
     *stats_out = stats;
     return y;
 }
 
-DAct dual_mlp_fwd(Ctx& c, DMlpTape& t, const alignn_mlp_params& p, const MlpTape& fwd, const DAct& x) {
+DAct dual_mlp_fwd(Ctx& c, DMlpTape& t, const alignn_mlp_params& p, const MlpTape& fwd, const DAct& x, hipStream_t st) {
     const int F = p.out, K = p.in;
     const int64_t rows = fwd.rows;
     t.p = &p;
@@ -1199,8 +1201,10 @@ DAct dual_mlp_fwd(Ctx& c, DMlpTape& t, const alignn_mlp_params& p, const MlpTape
     t.rows = rows;
     t.pre.p = fwd.pre;
     t.pre.t = c.alloc((size_t)rows * F);
-    project(c, x.t, K, x.amax_t, p.W, K, p.img, p.w_amax, nullptr, t.pre.t, F, rows, F, K, c.main);  // the tangent of x W^T + b
-    return dual_ln_fwd(c, t.pre, nullptr, p.gamma, p.beta, fwd.y, rows, F, &t.stats);
+    project(c, x.t, K, x.amax_t, p.W, K, p.img, p.w_amax, nullptr, t.pre.t, F, rows, F, K, st);  // the tangent of x W^T + b
+    DAct y = dual_ln_fwd(c, t.pre, nullptr, p.gamma, p.beta, fwd.y, rows, F, &t.stats, st);
+    y.on_T = st != c.main;
+    return y;
 }
 
 void dual_conv_fwd(Ctx& c, DConvTape& t, const alignn_conv_params& p, const ConvTape& fwd, const DAct& x, const DAct& y, bool need_y,
@@ -1213,12 +1217,19 @@ void dual_conv_fwd(Ctx& c, DConvTape& t, const alignn_conv_params& p, const Conv
     t.x = x;
     t.y = y;
     t.need_y = need_y;
+    // lane T for the line graph (as in conv_fwd_ln): the T-row tangent projection and the gate pass run there, beside the
+    // bond-row kernels of the caller's stream - the next convolution's node side, the bond-graph convolution that follows
+    t.lane = c.dual_lanes && c.T != c.main && m >= c.d->lane_min_rows;
+    hipStream_t main = c.main, T = t.lane ? c.T : c.main;
+    if (x.on_T) c.sync(main, c.T);
+    if (!t.lane && y.on_T) c.sync(main, c.T);
     t.P.p = fwd.P;
     t.P.t = c.alloc((size_t)n * 4 * H);
-    project(c, x.t, Kin, x.amax_t, p.wcat, Kin, p.wcat_img, p.wcat_amax, nullptr, t.P.t, 4 * H, n, 4 * H, Kin, c.main);
+    project(c, x.t, Kin, x.amax_t, p.wcat, Kin, p.wcat_img, p.wcat_amax, nullptr, t.P.t, 4 * H, n, 4 * H, Kin, main);
+    if (t.lane) c.sync(T, main);
     t.M.p = fwd.M;
     t.M.t = c.alloc((size_t)m * H);
-    project(c, y.t, Kin, y.amax_t, p.w_eg, Kin, p.weg_img, p.weg_amax, nullptr, t.M.t, H, m, H, Kin, c.main);
+    project(c, y.t, Kin, y.amax_t, p.w_eg, Kin, p.weg_img, p.weg_amax, nullptr, t.M.t, H, m, H, Kin, T);
     t.xpre.p = fwd.xpre;
     t.xpre.t = c.alloc((size_t)n * H);
     t.s0 = fwd.s0;
@@ -1226,33 +1237,39 @@ void dual_conv_fwd(Ctx& c, DConvTape& t, const alignn_conv_params& p, const Conv
     t.s0t = c.alloc((size_t)n * H);
     t.hht = c.alloc((size_t)n * H);
     y_out = DAct{};
-    if (need_y && fwd.e_stat != nullptr && alignn_egc_ln_fused_supported(H)) {
+    if (need_y && fwd.e_stat != nullptr && alignn_egc_ln_fused_supported(H, m)) {
         // the tangent of the edge LayerNorm inside the gate pass (csrc/convln.hip); the row statistics are the evaluation's
         y_out.p = fwd.y_out.p;
         y_out.amax_p = fwd.y_out.amax;
         y_out.t = c.alloc((size_t)m * H);
         float* amax2 = c.track(m) ? c.new_amax2() : nullptr;
         L(alignn_egc_gate_dual_tan_ln(t.P.p, t.P.t, t.M.p, t.M.t, g.seg_ptr, g.seg_node, g.src, n, m, H, t.xpre.t, t.s0, t.hh, t.s0t,
-                                      t.hht, p.e_gamma, p.e_beta, fwd.e_stat, y.t, y_out.t, amax2, c.main));
+                                      t.hht, p.e_gamma, p.e_beta, fwd.e_stat, y.t, y_out.t, amax2, T));
         y_out.amax_t = amax2 ? amax2 + 1 : nullptr;
         if (y_out.amax_p == nullptr && amax2 != nullptr) y_out.amax_p = amax2;
+        y_out.on_T = t.lane;
         t.e_stats = fwd.e_stat;
-        x_out = dual_ln_fwd(c, t.xpre, &x, p.n_gamma, p.n_beta, fwd.x_out, n, H, &t.n_stats);
+        if (t.lane) c.sync(main, T);
+        x_out = dual_ln_fwd(c, t.xpre, &x, p.n_gamma, p.n_beta, fwd.x_out, n, H, &t.n_stats, main);
         return;
     }
     L(alignn_egc_gate_dual_fwd_tangent(t.P.p, t.P.t, t.M.p, t.M.t, g.seg_ptr, g.seg_node, g.src, n, m, H, t.xpre.t, t.s0, t.hh, t.s0t,
-                                       t.hht, c.main));
-    x_out = dual_ln_fwd(c, t.xpre, &x, p.n_gamma, p.n_beta, fwd.x_out, n, H, &t.n_stats);
-    if (need_y) y_out = dual_ln_fwd(c, t.M, &y, p.e_gamma, p.e_beta, fwd.y_out, m, H, &t.e_stats);
+                                       t.hht, T));
+    if (t.lane) c.sync(main, T);
+    x_out = dual_ln_fwd(c, t.xpre, &x, p.n_gamma, p.n_beta, fwd.x_out, n, H, &t.n_stats, main);
+    if (need_y) {
+        y_out = dual_ln_fwd(c, t.M, &y, p.e_gamma, p.e_beta, fwd.y_out, m, H, &t.e_stats, T);
+        y_out.on_T = t.lane;
+    }
 }
 
 // ff2._ln_bwd: (g, gt) -> (gx, gxt) into out_p / out_t (leading dimension ldo); dbeta | dgamma -> red
 DAct dual_ln_bwd(Ctx& c, const DAct& g, const DAct& x, const float* gamma, const float* beta, const float* stats, float* out_p,
-                 float* out_t, int64_t ldo, float* amax2, int64_t rows, int F, float* red) {
+                 float* out_t, int64_t ldo, float* amax2, int64_t rows, int F, float* red, hipStream_t st) {
     const int slabs = alignn_dual_slabs(rows);
     float* partial = c.alloc((size_t)slabs * 2 * F);
-    L(alignn_ln_silu_dual_bwd(g.p, g.t, F, x.p, x.t, F, gamma, beta, stats, out_p, out_t, ldo, partial, rows, F, amax2, c.main));
-    L(alignn_bn_bwd_finalize(partial, slabs, F, red, c.main));
+    L(alignn_ln_silu_dual_bwd(g.p, g.t, F, x.p, x.t, F, gamma, beta, stats, out_p, out_t, ldo, partial, rows, F, amax2, st));
+    L(alignn_bn_bwd_finalize(partial, slabs, F, red, st));
     DAct o;
     o.p = out_p;
     o.t = out_t;
@@ -1268,27 +1285,30 @@ void dual_wgrad(Ctx& c, const DAct& g, int64_t ldg, const DAct& x, int64_t ldx, 
 }
 
 DAct dual_dgrad(Ctx& c, const DAct& g, int64_t ldg, const float* w, int Nred, int Kout, const void* img_t, const float* w_amax,
-                const DAct* addend, int64_t M) {
+                const DAct* addend, int64_t M, hipStream_t st) {
     DAct o;
     o.p = c.alloc((size_t)M * Kout);
     o.t = c.alloc((size_t)M * Kout);
-    dgrad(c, g.p, ldg, g.amax_p, w, Nred, Kout, img_t, w_amax, addend ? addend->p : nullptr, Kout, o.p, M, c.main, nullptr, nullptr);
-    dgrad(c, g.t, ldg, g.amax_t, w, Nred, Kout, img_t, w_amax, addend ? addend->t : nullptr, Kout, o.t, M, c.main, nullptr, nullptr);
+    dgrad(c, g.p, ldg, g.amax_p, w, Nred, Kout, img_t, w_amax, addend ? addend->p : nullptr, Kout, o.p, M, st, nullptr, nullptr);
+    dgrad(c, g.t, ldg, g.amax_t, w, Nred, Kout, img_t, w_amax, addend ? addend->t : nullptr, Kout, o.t, M, st, nullptr, nullptr);
+    o.on_T = st != c.main;
     return o;
 }
 
-DAct dual_mlp_bwd(Ctx& c, const DMlpTape& t, const DAct& g, bool need_gx) {
+DAct dual_mlp_bwd(Ctx& c, const DMlpTape& t, const DAct& g, bool need_gx, hipStream_t st) {
     const alignn_mlp_params& p = *t.p;
     const int F = p.out, K = p.in;
     const int64_t rows = t.rows;
+    if (st == c.main && g.on_T) c.sync(c.main, c.T);
     float* amax2 = c.track(rows) ? c.new_amax2() : nullptr;
     float* gp = c.alloc((size_t)rows * F);
     float* gt = c.alloc((size_t)rows * F);
-    DAct gpre = dual_ln_bwd(c, g, t.pre, p.gamma, p.beta, t.stats, gp, gt, F, amax2, rows, F, p.red);
+    DAct gpre = dual_ln_bwd(c, g, t.pre, p.gamma, p.beta, t.stats, gp, gt, F, amax2, rows, F, p.red, st);
     DAct gx;
-    if (need_gx) gx = dual_dgrad(c, gpre, F, p.W, F, K, p.img_t, p.w_amax, nullptr, rows);
+    if (need_gx) gx = dual_dgrad(c, gpre, F, p.W, F, K, p.img_t, p.w_amax, nullptr, rows, st);
     hipStream_t sd = side_for(c, rows);
-    if (sd != c.main) c.sync(sd, c.main);
+    if (sd == c.main && st != c.main) sd = st;  // (no side stream for this size: stay where the operands are)
+    if (sd != st) c.sync(sd, st);
     c.tmp_reset(sd);
     dual_wgrad(c, gpre, F, t.x, K, p.gW, rows, F, K, sd);
     col_sum(c, gpre.p, F, rows, F, p.gb, sd);
@@ -1301,6 +1321,11 @@ void dual_conv_bwd(Ctx& c, const DConvTape& t, const DAct& gx, const DAct& gy, D
     const alignn_graph_csr& g = *t.g;
     const int H = c.d->H, Kin = H;
     const int64_t n = g.n, m = g.m;
+    // lane T for the line graph (as in conv_bwd_ln): the gate reverse and the edge input gradients - every T-row kernel - run
+    // there, the node branch, the node input gradient and whatever bond-row work follows on the caller's stream
+    hipStream_t main = c.main, T = t.lane ? c.T : c.main;
+    if (gx.on_T) c.sync(main, c.T);
+    if (!t.lane && gy.p != nullptr && gy.on_T) c.sync(main, c.T);
     DAct GP, GM;
     GP.p = c.alloc((size_t)n * 4 * H);
     GP.t = c.alloc((size_t)n * 4 * H);
@@ -1308,20 +1333,21 @@ void dual_conv_bwd(Ctx& c, const DConvTape& t, const DAct& gx, const DAct& gy, D
     GP.amax_t = GP.amax_p ? GP.amax_p + 1 : nullptr;
     // node branch: LayerNorm / SiLU reverse straight into the Ux blocks
     DAct gxpre = dual_ln_bwd(c, gx, t.xpre, p.n_gamma, p.n_beta, t.n_stats, GP.p + 3 * (size_t)H, GP.t + 3 * (size_t)H, 4 * H, GP.amax_p,
-                             n, H, p.n_red);
+                             n, H, p.n_red, main);
     float* q1 = c.alloc((size_t)n * H);
     float* q0 = c.alloc((size_t)n * H);
     float* q1t = c.alloc((size_t)n * H);
     float* q0t = c.alloc((size_t)n * H);
-    L(alignn_egc_node_dual_bwd(gxpre.p, gxpre.t, 4 * H, t.s0, t.hh, t.s0t, t.hht, q1, q0, q1t, q0t, n, H, c.main));
+    L(alignn_egc_node_dual_bwd(gxpre.p, gxpre.t, 4 * H, t.s0, t.hh, t.s0t, t.hht, q1, q0, q1t, q0t, n, H, main));
+    if (t.lane) c.sync(T, main);  // (the four adjoint rows per node; gy if the caller's stream wrote it)
     const bool dense = c.ff->dense_lg_reverse && g.grp_seg_ptr != nullptr && g.dense_max_src > 0;
-    const bool ln_inside = gy.p != nullptr && dense && alignn_egc_ln_fused_supported(H);  // (csrc/convln.hip)
+    const bool ln_inside = gy.p != nullptr && dense && alignn_egc_ln_fused_supported(H, m);  // (csrc/convln.hip)
     DAct GL;
     if (gy.p != nullptr && !ln_inside) {
         float* amax2 = c.track(m) ? c.new_amax2() : nullptr;
         float* lp = c.alloc((size_t)m * H);
         float* lt = c.alloc((size_t)m * H);
-        GL = dual_ln_bwd(c, gy, t.M, p.e_gamma, p.e_beta, t.e_stats, lp, lt, H, amax2, m, H, p.e_red);
+        GL = dual_ln_bwd(c, gy, t.M, p.e_gamma, p.e_beta, t.e_stats, lp, lt, H, amax2, m, H, p.e_red, T);
     }
     GM.p = c.alloc((size_t)m * H);
     GM.t = c.alloc((size_t)m * H);
@@ -1335,24 +1361,28 @@ void dual_conv_bwd(Ctx& c, const DConvTape& t, const DAct& gx, const DAct& gy, D
         float* e_part = c.alloc((size_t)slabs * 2 * H);
         L(alignn_egc_dual_bwd_lg_dense_ln(gy.p, gy.t, t.M.p, t.M.t, t.P.p, t.P.t, q1, q0, q1t, q0t, p.e_gamma, p.e_beta, t.e_stats, m,
                                           g.grp_seg_ptr, g.grp_src_ptr, slabs, g.seg_ptr, g.seg_node, H, GM.p, GM.t, GP.p, GP.t, gb_part,
-                                          e_part, GM.amax_p, GP.amax_p, c.main));
-        L(alignn_bn_bwd_finalize(e_part, slabs, H, p.e_red, c.main));
+                                          e_part, GM.amax_p, GP.amax_p, T));
+        L(alignn_bn_bwd_finalize(e_part, slabs, H, p.e_red, T));
     } else if (dense) {  // line graph: destination- and source-ordered halves in one pass over the dense blocks
         slabs = (int)g.n_groups;
         gb_part = c.alloc((size_t)slabs * H);
         L(alignn_egc_dual_bwd_lg_dense(GL.p, GL.t, t.M.p, t.M.t, t.P.p, t.P.t, q1, q0, q1t, q0t, m, g.grp_seg_ptr, g.grp_src_ptr, slabs,
-                                       g.seg_ptr, g.seg_node, H, GM.p, GM.t, GP.p, GP.t, gb_part, GM.amax_p, GP.amax_p, c.main));
+                                       g.seg_ptr, g.seg_node, H, GM.p, GM.t, GP.p, GP.t, gb_part, GM.amax_p, GP.amax_p, T));
     } else {
         slabs = alignn_dual_slabs(n);
         gb_part = c.alloc((size_t)slabs * H);
         L(alignn_egc_dual_bwd_dst(GL.p, GL.t, t.M.p, t.M.t, t.P.p, t.P.t, q1, q0, q1t, q0t, g.seg_ptr, g.seg_node, g.src, n, H, GM.p, GM.t,
-                                  GP.p, GP.t, gb_part, GM.amax_p, GP.amax_p, c.main));
-        L(alignn_egc_dual_bwd_src(GM.p, GM.t, t.M.p, t.M.t, q1, q1t, g.out_ptr, g.out_slot, g.dst, n, H, GP.p, GP.t, GP.amax_p, c.main));
+                                  GP.p, GP.t, gb_part, GM.amax_p, GP.amax_p, T));
+        L(alignn_egc_dual_bwd_src(GM.p, GM.t, t.M.p, t.M.t, q1, q1t, g.out_ptr, g.out_slot, g.dst, n, H, GP.p, GP.t, GP.amax_p, T));
     }
-    g_x = dual_dgrad(c, GP, 4 * H, p.wcat, 4 * H, Kin, p.wcat_img_t, p.wcat_amax, &gx, n);
-    g_y = dual_dgrad(c, GM, H, p.w_eg, H, Kin, p.weg_img_t, p.weg_amax, gy.p != nullptr ? &gy : nullptr, m);
+    // weight gradients on the side stream: GP / GM are complete here
     hipStream_t sd = side_for(c, m);
-    if (sd != c.main) c.sync(sd, c.main);
+    if (sd == main && t.lane) sd = T;
+    if (sd != main) c.sync(sd, main);
+    if (t.lane && sd != T) c.sync(sd, T);
+    if (t.lane) c.sync(main, T);  // GP complete: the node input gradient reads it
+    g_x = dual_dgrad(c, GP, 4 * H, p.wcat, 4 * H, Kin, p.wcat_img_t, p.wcat_amax, &gx, n, main);
+    g_y = dual_dgrad(c, GM, H, p.w_eg, H, Kin, p.weg_img_t, p.weg_amax, gy.p != nullptr ? &gy : nullptr, m, T);
     c.tmp_reset(sd);
     dual_wgrad(c, GP, 4 * H, t.x, Kin, p.g_wcat, n, 4 * H, Kin, sd);
     col_sum(c, GP.p, 4 * H, n, 4 * H, p.g_bcat, sd);
@@ -1371,6 +1401,12 @@ void run_ff_dual(Ctx& c, const Tape& tp, const float* g_out, const float* g_forc
     c.amax_next = 0;
     fill(c, c.amax_arena, kAmaxSlots, 0.0f, c.main);
     c.sync(c.side, c.main);
+    {
+        const char* e = getenv("ALIGNN_AMD_FF_DUAL_LANES");
+        c.dual_lanes = e == nullptr || e[0] != '0';
+    }
+    const bool lanes = c.dual_lanes && c.T != c.main && Tn >= c.d->lane_min_rows;  // the T-row kernels on lane T (dual_conv_fwd / _bwd)
+    hipStream_t sT = lanes ? c.T : c.main;
     // ---- w = dL/d(pair forces), the tangent direction rt = w / 2^k, the tangents of the geometry features
     float* wmax = c.new_amax();
     float* w = c.alloc((size_t)3 * E);
@@ -1387,22 +1423,23 @@ void run_ff_dual(Ctx& c, const Tape& tp, const float* g_out, const float* g_forc
     xa.p = const_cast<float*>(b.atom_features);
     xa.t = c.alloc((size_t)N * d.atom_in);
     fill(c, xa.t, N * d.atom_in, 0.0f, c.main);
-    DAct x = dual_mlp_fwd(c, mt[0], d.atom, tp.atom, xa);
+    DAct x = dual_mlp_fwd(c, mt[0], d.atom, tp.atom, xa, c.main);
     DAct ye;
     ye.p = tp.rbf_e;
     ye.t = c.alloc((size_t)E * d.edge_bins);
     L(alignn_rbf_tangent(tp.bl, dt, d.edge_centers, d.edge_gamma, ye.t, E, d.edge_bins, c.main));
-    DAct y = dual_mlp_fwd(c, mt[2], d.edge2, tp.e2, dual_mlp_fwd(c, mt[1], d.edge1, tp.e1, ye));
+    if (lanes) c.sync(sT, c.main);  // (rt: the bond-angle tangents below run beside the atom and bond embeddings)
+    DAct y = dual_mlp_fwd(c, mt[2], d.edge2, tp.e2, dual_mlp_fwd(c, mt[1], d.edge1, tp.e1, ye, c.main), c.main);
     float* ht = c.alloc((size_t)Tn);
     if (f.lg_on_fly)
-        L(alignn_bond_cosine_tangent(b.r, rt, b.lg.src, b.lg.dst, ht, Tn, c.main));
+        L(alignn_bond_cosine_tangent(b.r, rt, b.lg.src, b.lg.dst, ht, Tn, sT));
     else
-        fill(c, ht, Tn, 0.0f, c.main);
+        fill(c, ht, Tn, 0.0f, sT);
     DAct za;
     za.p = tp.rbf_a;
     za.t = c.alloc((size_t)Tn * d.angle_bins);
-    L(alignn_rbf_tangent(tp.hcos, ht, d.angle_centers, d.angle_gamma, za.t, Tn, d.angle_bins, c.main));
-    DAct z = dual_mlp_fwd(c, mt[4], d.angle2, tp.a2, dual_mlp_fwd(c, mt[3], d.angle1, tp.a1, za));
+    L(alignn_rbf_tangent(tp.hcos, ht, d.angle_centers, d.angle_gamma, za.t, Tn, d.angle_bins, sT));
+    DAct z = dual_mlp_fwd(c, mt[4], d.angle2, tp.a2, dual_mlp_fwd(c, mt[3], d.angle1, tp.a1, za, sT), sT);
     if (c.unsupported) return;
     int k = 0;
     for (int i = 0; i < d.alignn_layers; ++i) {
@@ -1447,12 +1484,14 @@ void run_ff_dual(Ctx& c, const Tape& tp, const float* g_out, const float* g_forc
         gx = nx, gy = ny;
         if (c.unsupported) return;
     }
-    DAct gz1 = dual_mlp_bwd(c, mt[4], gz, true);
-    dual_mlp_bwd(c, mt[3], gz1, false);
-    DAct gy1 = dual_mlp_bwd(c, mt[2], gy, true);
-    dual_mlp_bwd(c, mt[1], gy1, false);
-    dual_mlp_bwd(c, mt[0], gx, false);
+    if (lanes && !gz.on_T) c.sync(sT, c.main);
+    DAct gz1 = dual_mlp_bwd(c, mt[4], gz, true, sT);  // (the bond-angle embedding stays on lane T, beside the two below)
+    dual_mlp_bwd(c, mt[3], gz1, false, sT);
+    DAct gy1 = dual_mlp_bwd(c, mt[2], gy, true, c.main);
+    dual_mlp_bwd(c, mt[1], gy1, false, c.main);
+    dual_mlp_bwd(c, mt[0], gx, false, c.main);
     c.sync(c.main, c.side);
+    c.sync(c.main, c.T);
 }
 
 bool desc_ok(const alignn_model_desc* d, const alignn_model_batch* b) {

@@ -196,7 +196,7 @@ def conv_fwd(conv, graph: CSRGraph, x: Dual, y: Dual, need_y, tape, fwd=None):
         M = Dual(M_p.detach(), ops.project(y.t, conv.edge_gate.weight, None, a_amax=y.am(1)))
         xpre = Dual(xpre_p.detach(), _empty(n, H, like=x.p))
         s0t, hht = _empty(n, H, like=x.p), _empty(n, H, like=x.p)
-        if need_y and e_rows is not None and tuple(e_rows.shape) == (m, 2) and lib.alignn_egc_ln_fused_supported(H):
+        if need_y and e_rows is not None and tuple(e_rows.shape) == (m, 2) and lib.alignn_egc_ln_fused_supported(H, m):
             # the tangent of the edge LayerNorm inside the gate pass (csrc/convln.hip); row statistics from the evaluation
             yp, yp_amax = _taken_over(yo)
             yt = _empty(m, H, like=x.p)
@@ -253,7 +253,7 @@ def conv_bwd(entry, gx: Dual, gy, grads: _Grads):
                                        ptr(q0), ptr(q1t), ptr(q0t), n, H, stream()), "egc_node_dual_bwd")
     dense = (DENSE_LG_REVERSE and graph.grp_seg_ptr is not None and graph.dense_max_src > 0 and ops.FUSED_LG_BACKWARD
              and ops.DENSE_LG_BACKWARD)
-    ln_inside = bool(gy is not None and dense and lib.alignn_egc_ln_fused_supported(H))  # (csrc/convln.hip)
+    ln_inside = bool(gy is not None and dense and lib.alignn_egc_ln_fused_supported(H, m))  # (csrc/convln.hip)
     GL = None
     if gy is not None and not ln_inside:
         GL, e_red = _ln_bwd(gy, M, conv.bn_edges.weight, conv.bn_edges.bias, e_stats)

@@ -154,7 +154,8 @@ def on_side_stream(fn, inputs, params=(), wait=()):
 # ALIGNN_AMD_LANES: "auto" (default) = only while the step is being captured into a hipGraph - there the fork / join
 # events cost nothing at replay; eagerly launched steps are bound by the host's enqueue rate on most hosts and the extra
 # event / stream calls (+1-4 ms per step) cost more than the overlap returns (-0.5 ms) -, "1" = always, "0" = never.
-_LANE = {"enabled": _os.environ.get("ALIGNN_AMD_LANES", "auto"), "min_rows": 131072, "active": False,
+_LANE = {"enabled": _os.environ.get("ALIGNN_AMD_LANES", "auto"), "min_rows": int(_os.environ.get("ALIGNN_AMD_LANE_MIN_ROWS", "131072")),
+         "active": False,
          "streams": {}, "main": None, "T": None, "priority": 0}
 _ON_T = {}  # id -> weakref: tensors whose producer kernel ran on lane T (consumers on lane T need no event)
 
@@ -1567,7 +1568,7 @@ class EdgeGatedConvFn(torch.autograd.Function):
                     fused_out["y"] = set_amax(y_o, y_amax) if y_amax is not None else y_o
                     return
                 e_part = None  # dead edge output: plain pre-added gate pass, the statistics are already in e_stat
-            if norm == "layer" and pre_added and need_y and lib.alignn_egc_ln_fused_supported(H):
+            if norm == "layer" and pre_added and need_y and lib.alignn_egc_ln_fused_supported(H, m):
                 # LayerNorm flavour on a line graph: the edge LayerNorm inside the gate pass (csrc/convln.hip)
                 y_o = _empty(m, H, like=x)
                 y_amax = new_amax(x) if _track(m) else None
@@ -1864,7 +1865,7 @@ class EdgeGatedConvFn(torch.autograd.Function):
             gy_out = gy_out.contiguous()
         lg_blocks = graph.grp_seg_ptr is not None and FUSED_LG_BACKWARD
         dense = lg_blocks and DENSE_LG_BACKWARD and lib.alignn_egc_bwd_lg_dense_supported(graph.dense_max_src)
-        ln_inside = bool(layer and dense and gy_out is not None and lib.alignn_egc_ln_fused_supported(H))  # (csrc/convln.hip)
+        ln_inside = bool(layer and dense and gy_out is not None and lib.alignn_egc_ln_fused_supported(H, m))  # (csrc/convln.hip)
         fused_red = {}
 
         def edge_branch():

@@ -457,8 +457,9 @@ int alignn_egc_dual_bwd_lg_dense(const float* GL, const float* GLt, const float*
  * (alignn_ln_silu_fwd / _bwd, alignn_ln_silu_dual_fwd / _bwd + the gate passes); LayerNorm parameter gradients leave as
  * ln_partial [n_groups][2][H] (dbeta | dgamma per workgroup; alignn_bn_bwd_finalize sums the slabs in order).
  * e_stat [m][2] = (mean, rstd) per row, written by the forward, read by everything else.
- * alignn_egc_ln_fused_supported(H): 1 when they apply (H % 4 == 0, H <= 256, ALIGNN_AMD_LN_FUSED != 0). */
-int alignn_egc_ln_fused_supported(int H);
+ * alignn_egc_ln_fused_supported(H, m_rows): 1 when they are the ones to take (H % 4 == 0, H <= 256, edge tensors of >= 64 MiB:
+ * on cache-resident line graphs the separate kernels' finer grids win; ALIGNN_AMD_LN_FUSED = 0 never, 2 whenever H allows). */
+int alignn_egc_ln_fused_supported(int H, int64_t m_rows);
 /* alignn_egc_gate_fwd_pre (M holds m = A[u] + Bd[v] + C) + alignn_ln_silu_fwd(M, residual Y or NULL) -> YOUT, e_stat, y_amax */
 int alignn_egc_gate_fwd_pre_ln(const float* P, const float* M, const int32_t* seg_ptr, const int32_t* seg_node, const int32_t* src,
                                int64_t n_seg, int64_t m_rows, int H, float* XPRE, float* S0, float* HH, const float* gamma,
