@@ -137,7 +137,7 @@ SIGNATURES = {
     "alignn_debug_allocs": (_i32, [_p, _i32]),
     "alignn_ff_plan": (_i32, [_p, _p, _p, _p, _p]),
     "alignn_ff_eval": (_i32, [_p, _p, _p, _p, _sz, _p, _p, _p, _p]),
-    "alignn_ff_grad": (_i32, [_p, _p, _p, _p, _sz, _p, _p, _p, _p, _p, _i64, _p]),
+    "alignn_ff_grad": (_i32, [_p, _p, _p, _p, _sz, _p, _p, _p, _p, _p, _i64, _p, _p, _i64, _p]),
     "alignn_pair_force_reduce": (_i32, [_p, _f32, _p, _p, _p, _i32, _p, _i64, _p]),
     "alignn_virial_stress": (_i32, [_p, _p, _f32, _p, _p, _p, _f32, _p, _i32, _p]),
     "alignn_ff_energy": (_i32, [_p, _p, _p, _i32, _i64, _i32, _i32, _f32, _f32, _p, _p, _p]),

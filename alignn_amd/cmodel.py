@@ -765,13 +765,31 @@ class _FFFn(torch.autograd.Function):
         g_stress = None if (g_stress is None or not ctx.has_stress) else g_stress.reshape(-1, 3, 3).to(torch.float32).contiguous()
         gflat = torch.empty(2, bind.grad_floats, dtype=torch.float32, device=bind.device)
         base = gflat.data_ptr()
-        for owner, field, off in bind.grad_fields:
-            setattr(owner, field, base + 4 * off)
+        # straight into the optimizer's packed gradient buffer where it has one (as _ModelFn.backward; the tangent halves of the
+        # weight gradients of those blocks go to a scratch twin of the buffer and are added in place by the C call)
+        plan = bind.sink_plan() if GRAD_SINK else None
+        sink_buf = sink_t = None
+        if plan is not None and not any(p.grad is not None for p in bind.params):
+            ref = model_cache(bind.model).get("grad_sink")
+            sink = ref() if ref is not None else None
+            sink_buf = getattr(sink, "_grad_all", None)
+            if (sink_buf is None or sink_buf.dtype != torch.float32 or sink_buf.numel() % 4 or sink_buf.data_ptr() % 16
+                    or not sink_buf.is_contiguous()):
+                sink_buf = None
+        if sink_buf is None:
+            plan = None
+        else:
+            sink_t = torch.empty_like(sink_buf)
+        for k, (owner, field, off) in enumerate(bind.grad_fields):
+            dest = plan[0][k] if plan is not None else None
+            setattr(owner, field, dest if dest is not None else base + 4 * off)
+        STATS["ff_sink"] = STATS.get("ff_sink", 0) + (plan is not None)
         bind.set_mode()
         try:
             _lib.check(lib.alignn_ff_grad(bind.desc_addr, C.addressof(ctx.mb), C.addressof(ctx.ffd), ctx.arena.data_ptr(),
                                           ctx.arena_bytes, _ptr(g_out), _ptr(g_forces), _ptr(g_stress), gflat[0].data_ptr(),
-                                          gflat[1].data_ptr(), bind.grad_floats, _lib.stream()), "ff_grad")
+                                          gflat[1].data_ptr(), bind.grad_floats, _ptr(sink_buf), _ptr(sink_t),
+                                          sink_buf.numel() if sink_buf is not None else 0, _lib.stream()), "ff_grad")
         finally:
             ctx.lease.release()
             if not ctx.shared_gen:
@@ -779,8 +797,14 @@ class _FFFn(torch.autograd.Function):
         STATS["ff_grad"] = STATS.get("ff_grad", 0) + 1
         pieces = gflat[0].split_with_sizes(bind.sizes)
         grads = []
-        for i, shape, dead in zip(bind.keep, bind.shapes, bind.no_grad):
-            grads.append(None if dead else (pieces[i] if len(shape) == 1 else pieces[i].view(shape)))
+        slots = plan[1] if plan is not None else None
+        for j, (i, shape, dead) in enumerate(zip(bind.keep, bind.shapes, bind.no_grad)):
+            if dead:
+                grads.append(None)
+            elif slots is not None and slots[j] is not None:
+                grads.append(slots[j].view(shape))  # (a fresh view object: AccumulateGrad adopts it instead of cloning)
+            else:
+                grads.append(pieces[i] if len(shape) == 1 else pieces[i].view(shape))
         return (None,) * 7 + tuple(grads)
 
 

@@ -167,6 +167,11 @@ struct Ctx {
     float *g_rbf_e = nullptr, *g_rbf_a = nullptr;
     bool g_rbf_a_on_T = false;
     ptrdiff_t toff = 0;  // floats from a weight-gradient destination to its tangent twin (alignn_ff_grad)
+    // a second region of gradient destinations with tangent twins of its own: the optimizer's packed gradient buffer
+    float* sink = nullptr;
+    int64_t sink_floats = 0;
+    ptrdiff_t sink_toff = 0;
+    float* twin(float* dW) const { return dW + ((sink != nullptr && dW >= sink && dW < sink + sink_floats) ? sink_toff : toff); }
     // `waiter` continues only after everything enqueued on `src` so far
     int n_sync = 0, n_launch = 0;
     bool dual_lanes = true;  // the second-order pass of the force field puts its T-row kernels on lane T (ALIGNN_AMD_FF_DUAL_LANES=0: not)
@@ -1281,7 +1286,7 @@ DAct dual_ln_bwd(Ctx& c, const DAct& g, const DAct& x, const float* gamma, const
 // W-bar = g^T x + gt^T xt: the value half into dW, the tangent half into its twin (added once at the end of the call)
 void dual_wgrad(Ctx& c, const DAct& g, int64_t ldg, const DAct& x, int64_t ldx, float* dW, int64_t M, int N, int K, hipStream_t st) {
     gemm_tn(c, g.p, ldg, g.amax_p, x.p, ldx, x.amax_p, dW, M, N, K, st);
-    gemm_tn(c, g.t, ldg, g.amax_t, x.t, ldx, x.amax_t, dW + c.toff, M, N, K, st);
+    gemm_tn(c, g.t, ldg, g.amax_t, x.t, ldx, x.amax_t, c.twin(dW), M, N, K, st);
 }
 
 DAct dual_dgrad(Ctx& c, const DAct& g, int64_t ldg, const float* w, int Nred, int Kout, const void* img_t, const float* w_amax,
@@ -1641,8 +1646,11 @@ int alignn_ff_eval(const alignn_model_desc* d, const alignn_model_batch* b, cons
 
 int alignn_ff_grad(const alignn_model_desc* d, const alignn_model_batch* b, const alignn_ff_desc* f, void* workspace,
                    size_t workspace_bytes, const float* g_out, const float* g_forces, const float* g_stress, float* gflat,
-                   float* gflat_t, int64_t grad_floats, alignn_stream_t stream) {
+                   float* gflat_t, int64_t grad_floats, float* gsink, float* gsink_t, int64_t sink_floats, alignn_stream_t stream) {
     if (!ff_ok(d, b, f) || workspace == nullptr || gflat == nullptr || gflat_t == nullptr || grad_floats <= 0 || (grad_floats & 3))
+        return (int)hipErrorInvalidValue;
+    if (gsink != nullptr && (gsink_t == nullptr || sink_floats <= 0 || (sink_floats & 3) || (reinterpret_cast<uintptr_t>(gsink) & 15) ||
+                             (reinterpret_cast<uintptr_t>(gsink_t) & 15)))
         return (int)hipErrorInvalidValue;
     const Plan pl = make_ff_plan(d, b, f, stream);
     if (pl.unsupported) return (int)hipErrorNotSupported;
@@ -1659,9 +1667,16 @@ int alignn_ff_grad(const alignn_model_desc* d, const alignn_model_batch* b, cons
     c.launch = true;
     c.toff = gflat_t - gflat;
     fill(c, gflat_t, grad_floats, 0.0f, c.main);  // (only the weight blocks get a tangent half)
+    if (gsink != nullptr) {
+        c.sink = gsink;
+        c.sink_floats = sink_floats;
+        c.sink_toff = gsink_t - gsink;
+        fill(c, gsink_t, sink_floats, 0.0f, c.main);
+    }
     run_ff_dual(c, tp, g_out, g_forces, g_stress);
     if (c.unsupported) return (int)hipErrorNotSupported;
     if (c.rc == 0) c.rc = alignn_add_inplace(gflat, gflat_t, grad_floats, c.main);
+    if (c.rc == 0 && gsink != nullptr) c.rc = alignn_add_inplace(gsink, gsink_t, sink_floats, c.main);
     return c.rc;
 }
 

@@ -699,7 +699,10 @@ int alignn_model_infer(const alignn_model_desc* desc, const alignn_model_batch* 
  *                   backward; csrc/dual.hip).  The value halves are the tape alignn_ff_eval left in the workspace, which
  *                   must be the one that call filled for the same (desc, batch, ff).  Gradients go to the g_* / *red
  *                   pointers of desc, which must all lie inside gflat[0 .. grad_floats) ; gflat_t is scratch of the same
- *                   size (the tangent halves of the weight gradients, added on return).
+ *                   size (the tangent halves of the weight gradients, added on return).  Optionally a SECOND region of
+ *                   destinations, gsink[0 .. sink_floats) with scratch gsink_t of the same size: the optimizer's packed
+ *                   gradient buffer (alignn_amd/optim.py FlatAdamW) - desc pointers inside it get their tangent halves in
+ *                   gsink_t and the sum in place, so that no gather of per-parameter gradients follows (NULL, NULL, 0: none).
  *   alignn_ff_plan: workspace bytes for eval alone / eval + grad; 801 when a kernel choice is not carried here.
  * ------------------------------------------------------------------------------------------ */
 typedef struct alignn_ff_desc {
@@ -716,7 +719,7 @@ int alignn_ff_eval(const alignn_model_desc* desc, const alignn_model_batch* batc
                    size_t workspace_bytes, float* out, float* forces, float* stress, alignn_stream_t stream);
 int alignn_ff_grad(const alignn_model_desc* desc, const alignn_model_batch* batch, const alignn_ff_desc* ff, void* workspace,
                    size_t workspace_bytes, const float* g_out, const float* g_forces, const float* g_stress, float* gflat,
-                   float* gflat_t, int64_t grad_floats, alignn_stream_t stream);
+                   float* gflat_t, int64_t grad_floats, float* gsink, float* gsink_t, int64_t sink_floats, alignn_stream_t stream);
 
 /* The small kernels of the force-field head (csrc/ff.hip), also used one by one by the per-operator path
  * (alignn_amd/alignn_atomwise.py, alignn_amd/ff2.py) - they replace ~100 torch element-wise / index / reduce launches and a

@@ -245,3 +245,47 @@ def test_the_step_is_free_of_torch_and_vendor_kernels():
                and "copy" not in n.lower()]
     assert not foreign, foreign
     assert any("gemm_nt" in n or "egc_" in n for n in names), names[:10]
+
+
+def test_force_training_writes_into_the_packed_gradient_buffer_of_flat_adamw():
+    """alignn_ff_grad with a second region of destinations (gsink / gsink_t): from the second step on the loss gradient through
+    the forces lands in FlatAdamW's packed gradient buffer - value halves there, tangent halves in a scratch twin, added in place
+    by the C call - and no gather of per-parameter gradients follows.  Same training state as the per-operator path, bit for bit."""
+    from alignn_amd.optim import FlatAdamW, group_decay
+
+    raw = make_batch(3, 30, seed0=21)
+    batch = GraphBatch.from_raw(raw, device=DEV)
+    te, tf, ts = _targets(raw, 5)
+    l1 = torch.nn.functional.l1_loss
+
+    def run(use_c):
+        prev = cmodel.ENABLED
+        cmodel.ENABLED = use_c
+        try:
+            m = _mk(3)
+            opt = FlatAdamW(group_decay(m), lr=1e-3, weight_decay=1e-2, module=m)
+            _reset_stats()
+            cmodel.STATS["ff_sink"] = 0
+            in_place = n_live = 0
+            for _ in range(3):
+                opt.zero_grad(set_to_none=True)
+                o = m(batch)
+                (l1(o["out"], te) + l1(o["grad"], tf) + l1(o["stresses"], ts)).backward()
+                live = [p for p in m.parameters() if p.grad is not None]
+                n_live = len(live)
+                in_place = sum(1 for p in live if opt.gradient_slot(p) is not None
+                               and p.grad.data_ptr() == opt.gradient_slot(p).data_ptr())
+                opt.step()
+            torch.cuda.synchronize()
+            out = {"p." + k: p.detach().clone() for k, p in m.named_parameters()}
+            out.update({"g." + k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+            return out, dict(cmodel.STATS), in_place, n_live
+        finally:
+            cmodel.ENABLED = prev
+
+    a, stats, in_place, n_live = run(True)
+    b, _s, _i, _n = run(False)
+    _same(a, b, "FlatAdamW, force training")
+    assert stats.get("ff_grad", 0) == 3 and stats.get("ff_sink", 0) == 2, stats
+    assert in_place >= n_live - 10, (in_place, n_live)
+    print(f"force training into FlatAdamW's buffer: {in_place} of {n_live} gradients in place")
