@@ -273,6 +273,29 @@ __global__ void gemm_naive_kernel(const float* __restrict__ A, int64_t sai, int6
     C[i * ldc + j] = acc;
 }
 
+// The same for few outputs with a long contiguous reduction (the one-wide readout fc: [B, 256] x [256] -> [B]: 30 us on the
+// kernel above, one thread walking 256 dependent loads per output): one wavefront per output, lane l takes r = l, l + 64, ...,
+// fixed-order butterfly over the lanes.
+__global__ __launch_bounds__(256) void gemm_naive_wave_kernel(const float* __restrict__ A, int64_t sai, const float* __restrict__ B,
+                                                              int64_t sbj, const float* __restrict__ bias,
+                                                              const float* __restrict__ addend, int64_t ldadd, float* __restrict__ C,
+                                                              int64_t ldc, int64_t Mo, int No, int64_t R) {
+    const int lane = threadIdx.x & 63;
+    const int64_t idx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (idx >= Mo * No) return;  // (wave-uniform)
+    const int64_t i = idx / No;
+    const int j = (int)(idx - i * No);
+    float acc = 0.0f;
+    for (int64_t r = lane; r < R; r += 64) acc = fmaf(A[i * sai + r], B[j * sbj + r], acc);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) {
+        if (bias) acc += bias[j];
+        if (addend) acc += addend[i * ldadd + j];
+        C[i * ldc + j] = acc;
+    }
+}
+
 // out[idx] = sum_k ws[k][idx], 32 outputs x 32 slab-lanes per block, fp64 partials, fixed order
 __global__ __launch_bounds__(1024) void slab_reduce_kernel(const float* __restrict__ ws, int splits, int64_t count,
                                                            int cols, float* __restrict__ out, int64_t ldo) {
@@ -387,6 +410,12 @@ int naive(const float* A, int64_t sai, int64_t sar, const float* B, int64_t sbj,
           const float* addend, int64_t ldadd, float* C, int64_t ldc, int64_t Mo, int No, int64_t R,
           hipStream_t stream) {
     if (Mo * No == 0) return 0;
+    if (sar == 1 && sbr == 1 && R >= 128 && Mo * No <= 4096) {  // few outputs, long contiguous reduction: a wave per output
+        hipLaunchKernelGGL(gemm_naive_wave_kernel, dim3(alignn_ceil_div(Mo * No, 4)), dim3(256), 0, stream, A, sai, B, sbj, bias,
+                           addend, ldadd, C, ldc, Mo, No, R);
+        ALIGNN_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(gemm_naive_kernel, dim3(alignn_ceil_div(Mo * No, 256)), dim3(256), 0, stream, A, sai, sar, B,
                        sbj, sbr, bias, addend, ldadd, C, ldc, Mo, No, R);
     ALIGNN_CHECK_LAUNCH();
