@@ -20,8 +20,9 @@
 //
 // Shape of the work: a crystal of n atoms with an image box of I cells has n*I candidates per site (60 atoms, 27 images:
 // 1 620) - the "cell list" of a cell that is about as large as the cutoff IS the image loop.  One wave per site scans
-// its candidates 64 at a time; the k-th distance comes from at most k rounds of "smallest distance above the last one +
-// its multiplicity" (exact, no sort, no memory); the edge list is compacted in candidate order by ballot / popcount, so a
+// its candidates 64 at a time; the k-th distance is the k-th smallest of the few dozen distances inside the cutoff, which
+// the scan leaves in LDS (exact, ties included; beyond 1 024 of them: rounds of "smallest distance above the last one + its
+// multiplicity"); the edge list is compacted in candidate order by ballot / popcount, so a
 // site's bonds leave sorted by (neighbour, image) - the order torch.unique gives the torch builder.  No atomics on the
 // output, no host synchronisation inside (the host reads ONE number - the total bond count - to size the output).
 #include "common.h"
@@ -31,6 +32,7 @@ namespace {
 
 constexpr int kSitesPerBlock = 4;
 constexpr int kThreads = kSitesPerBlock * ALIGNN_WAVE;
+constexpr int kKthCap = 1024;  // distances inside the cutoff a site's wave keeps in LDS for the k-th smallest (more: the search by rounds)
 
 struct Cell {
     double lat[9];
@@ -146,10 +148,56 @@ __global__ __launch_bounds__(kThreads) void knn_kth_kernel(const double* __restr
     const Cell c = load_cell(lat, cut, reach, b, L, level);
     const double ci[3] = {cart[3 * (size_t)i], cart[3 * (size_t)i + 1], cart[3 * (size_t)i + 2]};
     const int total = n * c.nimg;
-    // ascending over the DISTINCT distances: `last` = the largest distance accounted for, `seen` = candidates <= last
-    double last = 1e-8;  // candidates must exceed 1e-8 anyway
-    int seen = 0;
     const double inf = __longlong_as_double(0x7ff0000000000000LL);
+    // ONE scan: the distances inside the cutoff (a few dozen of the n * I candidates) go to the wave's list in LDS, compacted
+    // by ballot / popcount; the k-th smallest of the list is the element x with #(y < x) < k <= #(y <= x) - ties included, the
+    // same number the round-by-round search below returns (round 5: 600 -> ~30 us for a 200-atom cell, where that search -
+    // up to k rounds of two scans each - was three quarters of the neighbour list's time).
+    __shared__ double sh_d[kSitesPerBlock][kKthCap];
+    double* buf = sh_d[threadIdx.x >> 6];
+    int M = 0;  // (wave-uniform)
+    for (int cand0 = 0; cand0 < total; cand0 += ALIGNN_WAVE) {
+        const int cand = cand0 + lane;
+        bool ok = false;
+        double d = 0.0;
+        if (cand < total) {
+            int j, i0, i1, i2;
+            split_candidate(c, cand, j, i0, i1, i2);
+            const double cj[3] = {cart[3 * (size_t)(base + j)], cart[3 * (size_t)(base + j) + 1], cart[3 * (size_t)(base + j) + 2]};
+            d = image_distance(c, ci, cj, i0, i1, i2);
+            ok = d > 1e-8 && d <= c.cutoff;
+        }
+        const unsigned long long mask = __ballot(ok);
+        const int pos = M + __popcll(mask & ((1ull << lane) - 1ull));
+        if (ok && pos < kKthCap) buf[pos] = d;
+        M += __popcll(mask);
+    }
+    double last = 1e-8;
+    if (M <= kKthCap) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        double best = inf, top = 1e-8;
+        for (int q = lane; q < M; q += ALIGNN_WAVE) {
+            const double x = buf[q];
+            int lt = 0, le = 0;
+            for (int t = 0; t < M; ++t) {
+                const double y = buf[t];
+                lt += y < x ? 1 : 0;
+                le += y <= x ? 1 : 0;
+            }
+            if (lt < k && k <= le) best = x;
+            top = fmax(top, x);
+        }
+        best = wave_min_d(best);
+        // (fewer than k candidates cannot happen - the level guarantees k -; the search below would end at the largest one)
+        last = best < inf ? best : -wave_min_d(-top);
+        if (lane == 0) kth[i] = last;
+        return;
+    }
+    // more candidates inside the cutoff than the list holds: ascending over the DISTINCT distances, `last` = the largest
+    // distance accounted for, `seen` = candidates <= last
+    int seen = 0;
     while (seen < k) {
         double mn = inf;
         for (int cand = lane; cand < total; cand += ALIGNN_WAVE) {
