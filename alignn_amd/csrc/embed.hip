@@ -35,16 +35,34 @@ __global__ void norm3_fwd_kernel(const float* __restrict__ v, float* __restrict_
     }
 }
 
-// one block per graph; threads own feature quads and walk the graph's nodes in order
-__global__ void segment_mean_fwd_kernel(const float* __restrict__ X, const int32_t* __restrict__ gptr,
-                                        float* __restrict__ out, int H) {
+// one block of four waves per graph; lane l owns feature quads l, l + 64, ...; wave w takes the graph's nodes beg + w, beg + w + 4,
+// ... (two interleaved partial sums each: eight independent chains instead of one walk over all nodes - 50 -> ~10 us for a
+// 200-atom cell), the partial sums are added in a fixed order: ((w0 + w1) + (w2 + w3)) of (even + odd)
+__global__ __launch_bounds__(256) void segment_mean_fwd_kernel(const float* __restrict__ X, const int32_t* __restrict__ gptr,
+                                                               float* __restrict__ out, int H) {
+    __shared__ float4 sh[4][64];
     const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int beg = gptr[b], end = gptr[b + 1];
     const float inv = end > beg ? 1.0f / (float)(end - beg) : 0.0f;
-    for (int q = threadIdx.x; q < (H >> 2); q += blockDim.x) {
-        float4 acc = f4_zero();
-        for (int i = beg; i < end; ++i) acc = f4_add(acc, f4_ld(X + (int64_t)i * H + q * 4));
-        f4_st(out + (int64_t)b * H + q * 4, make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv));
+    for (int q0 = 0; q0 < (H >> 2); q0 += 64) {
+        const int q = q0 + lane;
+        float4 a0 = f4_zero(), a1 = f4_zero();
+        if (q < (H >> 2)) {
+            int i = beg + wave;
+            for (; i + 4 < end; i += 8) {
+                a0 = f4_add(a0, f4_ld(X + (int64_t)i * H + q * 4));
+                a1 = f4_add(a1, f4_ld(X + (int64_t)(i + 4) * H + q * 4));
+            }
+            if (i < end) a0 = f4_add(a0, f4_ld(X + (int64_t)i * H + q * 4));
+        }
+        sh[wave][lane] = f4_add(a0, a1);
+        __syncthreads();
+        if (wave == 0 && q < (H >> 2)) {
+            const float4 acc = f4_add(f4_add(sh[0][lane], sh[1][lane]), f4_add(sh[2][lane], sh[3][lane]));
+            f4_st(out + (int64_t)b * H + q * 4, make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv));
+        }
+        __syncthreads();
     }
 }
 
@@ -232,7 +250,7 @@ int alignn_norm3_fwd(const float* v, float* out, int64_t rows, alignn_stream_t s
 int alignn_segment_mean_fwd(const float* X, const int32_t* graph_ptr, float* out, int B, int H,
                             alignn_stream_t stream) {
     if (B <= 0 || (H & 3)) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(segment_mean_fwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, X, graph_ptr, out, H);
+    hipLaunchKernelGGL(segment_mean_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, X, graph_ptr, out, H);
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }

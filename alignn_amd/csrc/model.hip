@@ -502,6 +502,11 @@ void run_forward(Ctx& c, Tape& tp, float* out) {
     c.amax_arena = c.alloc(kAmaxSlots);
     c.amax_next = 0;
     fill(c, c.amax_arena, kAmaxSlots, 0.0f, c.main);
+    // The fused bond-angle embedding (csrc/angle.hip) reads the two angle layers' float32 weights itself - no slice images -, so
+    // lane T may start it while the caller's stream still prepares the images (45 us at the head of lane T's chain otherwise).
+    const bool angle_first = c.ff == nullptr && d.norm == 0 && d.angle_fused != 0 && Tn > 0 && c.T != c.main && Tn >= d.lane_min_rows &&
+                             alignn_angle_embed_supported(d.angle_bins, d.angle1.out, d.angle2.out) != 0;
+    if (angle_first) c.sync(c.T, c.main);  // (the zeroed arena)
     if (d.n_weights > 0) L(alignn_prepare_weights(d.weight_descs, d.n_weights, d.weight_amax, c.main));
     if (d.n_bump > 0 && c.launch && c.rc == 0) {
         hipLaunchKernelGGL(bump_kernel, dim3((d.n_bump + 63) / 64), dim3(64), 0, c.main, (int64_t* const*)d.bump_ptrs, d.n_bump);
@@ -515,7 +520,7 @@ void run_forward(Ctx& c, Tape& tp, float* out) {
         L(alignn_bond_cosine_fwd(b.r, b.lg.src, b.lg.dst, tp.hcos_buf, Tn, c.main));
         tp.hcos = tp.hcos_buf;
     }
-    c.sync(c.T, c.main);  // parameters, weight images, the zeroed arena
+    if (!angle_first) c.sync(c.T, c.main);  // parameters, weight images, the zeroed arena
     // ---- angle embedding (T rows: lane T), alignn.py:215-222
     Act z;
     tp.angle_fused = d.norm == 0 && d.angle_fused != 0 && Tn > 0 &&
