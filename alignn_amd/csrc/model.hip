@@ -174,7 +174,6 @@ struct Ctx {
     float* twin(float* dW) const { return dW + ((sink != nullptr && dW >= sink && dW < sink + sink_floats) ? sink_toff : toff); }
     // `waiter` continues only after everything enqueued on `src` so far
     int n_sync = 0, n_launch = 0;
-    bool dual_lanes = true;  // the second-order pass of the force field puts its T-row kernels on lane T (ALIGNN_AMD_FF_DUAL_LANES=0: not)
     double t_sync = 0.0;
     bool timing = false;
     void sync(hipStream_t waiter, hipStream_t src) {
@@ -1229,7 +1228,7 @@ void dual_conv_fwd(Ctx& c, DConvTape& t, const alignn_conv_params& p, const Conv
     t.need_y = need_y;
     // lane T for the line graph (as in conv_fwd_ln): the T-row tangent projection and the gate pass run there, beside the
     // bond-row kernels of the caller's stream - the next convolution's node side, the bond-graph convolution that follows
-    t.lane = c.dual_lanes && c.T != c.main && m >= c.d->lane_min_rows;
+    t.lane = c.T != c.main && m >= c.d->lane_min_rows;
     hipStream_t main = c.main, T = t.lane ? c.T : c.main;
     if (x.on_T) c.sync(main, c.T);
     if (!t.lane && y.on_T) c.sync(main, c.T);
@@ -1411,11 +1410,7 @@ void run_ff_dual(Ctx& c, const Tape& tp, const float* g_out, const float* g_forc
     c.amax_next = 0;
     fill(c, c.amax_arena, kAmaxSlots, 0.0f, c.main);
     c.sync(c.side, c.main);
-    {
-        const char* e = getenv("ALIGNN_AMD_FF_DUAL_LANES");
-        c.dual_lanes = e == nullptr || e[0] != '0';
-    }
-    const bool lanes = c.dual_lanes && c.T != c.main && Tn >= c.d->lane_min_rows;  // the T-row kernels on lane T (dual_conv_fwd / _bwd)
+    const bool lanes = c.T != c.main && Tn >= c.d->lane_min_rows;  // the T-row kernels on lane T (dual_conv_fwd / _bwd)
     hipStream_t sT = lanes ? c.T : c.main;
     // ---- w = dL/d(pair forces), the tangent direction rt = w / 2^k, the tangents of the geometry features
     float* wmax = c.new_amax();
