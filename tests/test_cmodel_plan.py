@@ -180,3 +180,19 @@ def test_tape_reuse_saves_one_t_row_buffer_per_line_graph_convolution():
     saved = tot - tot2
     assert 4 * t_row + 8 * e_row - (1 << 20) < saved < 4 * t_row + 8 * e_row + (1 << 20), saved / t_row
     assert tot2 < 16.6e9 < tot  # (19.3 GB -> 16.5 GB)
+
+
+def test_where_the_fused_layernorm_passes_apply(monkeypatch):
+    """alignn_egc_ln_fused_supported (csrc/convln.hip, host arithmetic): one feature panel per wavefront (H <= 256, H % 4 == 0) and
+    edge tensors too large for the cache (>= 64 MiB); ALIGNN_AMD_LN_FUSED = 0 never, 2 whenever H allows; read per call."""
+    lib = cmodel._lib_model()
+    monkeypatch.delenv("ALIGNN_AMD_LN_FUSED", raising=False)
+    f = lib.alignn_egc_ln_fused_supported
+    assert f(256, 561792) == 1 and f(256, 676200) == 1          # BASELINE configs[3] / [1]: 575 / 692 MB per tensor
+    assert f(256, 35326) == 0 and f(256, 65535) == 0 and f(256, 65536) == 1  # a 200-atom MD cell stays on the separate kernels
+    assert f(64, 262144) == 1 and f(64, 200000) == 0
+    assert f(512, 10 ** 7) == 0 and f(258, 10 ** 7) == 0 and f(0, 10 ** 7) == 0
+    monkeypatch.setenv("ALIGNN_AMD_LN_FUSED", "2")
+    assert f(256, 100) == 1 and f(512, 10 ** 7) == 0
+    monkeypatch.setenv("ALIGNN_AMD_LN_FUSED", "0")
+    assert f(256, 10 ** 7) == 0
