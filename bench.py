@@ -858,6 +858,17 @@ def main():
             step_passes = {"bytes_x": 3.0, "flops_x": 7.0 / 3.0, "what": "force evaluation fwd + reverse w.r.t. r, tangent forward, "
                            "second-order reverse (value + tangent) - SURVEY 8(a) row 9"}
             step_bytes, step_flops = 3.0 * step_bytes, 7.0 / 3.0 * step_flops
+            # What THIS schedule moves over the T-row tensors (fp32, [T, hidden]): per line-graph convolution
+            # with a live edge output 5 (forward) + 6 (reverse) + 7 (tangent forward) + 16 (second-order reverse) passes, the last
+            # one (dead edge output) 3 + 4 + 5 + 12, the bond-angle embedding's two LayerNorm layers ~28.6 over the four phases -
+            # the op-by-op accounting above is what the reference's autograd would move, not what the chip sustained here.
+            cfg_ = getattr(model, "config", None)
+            la = int(getattr(cfg_, "alignn_layers", 4))
+            t_passes = max(la - 1, 0) * 34.0 + 24.0 + 28.6
+            t_bytes = t_passes * T * int(getattr(cfg_, "hidden_features", 256)) * 4.0
+            step_passes.update({"t_row_passes_of_this_schedule": round(t_passes, 1),
+                                "t_row_GB_per_step_of_this_schedule": round(t_bytes / 1e9, 1),
+                                "t_row_bytes_over_step_time_frac_of_8TBs": round(t_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
         metric_name, workload_name = workload_of(args, B)
         out = {
             "metric": metric_name,
