@@ -312,3 +312,93 @@ def test_tangent_only_dual_forward_equals_the_full_dual_forward():
         worst = max(worst, e)
         assert e < 2e-5, (k, e)
     print(f"tangent-only dual forward vs full dual forward: worst per-parameter gradient difference {worst:.2e}")
+
+
+@pytest.mark.parametrize("shape,H", [("small", 256), ("deg_over_16", 64)])
+def test_reverse_kernels_with_the_layernorm_inside_against_the_separate_kernels(shape, H):
+    """csrc/convln.hip at the kernel level: alignn_egc_bwd_lg_dense_ln and alignn_egc_dual_bwd_lg_dense_ln against
+    alignn_ln_silu_bwd + alignn_egc_bwd_lg_dense(MODE 2) and alignn_ln_silu_dual_bwd + alignn_egc_dual_bwd_lg_dense on the
+    same random operands - every output: the edge adjoints GM (GMt), all blocks of GP (GPt) the kernels write, the bias-gradient
+    slabs and the LayerNorm parameter gradients - and every launch variant of the two kernels (ALIGNN_AMD_LN_REV)."""
+    import os
+
+    from alignn_amd import _lib
+    from alignn_amd.ops import ptr, stream
+
+    lib = _lib.load()
+    raw = make_batch(3, 14, seed0=31) if shape == "small" else make_batch(4, 3, seed0=11)
+    lg = GraphBatch.from_raw(raw, device=DEV).lg
+    n, m = lg.n_nodes, lg.n_edges
+    groups = lg.grp_seg_ptr.numel() - 1
+    g = torch.Generator(device=DEV).manual_seed(2)
+    R = lambda *s: torch.randn(*s, device=DEV, generator=g)  # noqa: E731
+    M, Mt, GY, GYt = R(m, H), R(m, H), R(m, H), R(m, H)
+    P, Pt = R(n, 4 * H), R(n, 4 * H)
+    q1, q0, q1t, q0t = R(n, H), R(n, H), R(n, H), R(n, H)
+    gamma, beta = 1 + 0.1 * R(H), 0.1 * R(H)
+    e_stat = torch.stack([M.mean(1), 1.0 / torch.sqrt(M.var(1, unbiased=False) + 1e-5)], 1).contiguous()
+    st = stream()
+
+    def close(a, b, what, tol=2e-5):
+        e = float((a - b).abs().max()) / max(float(b.abs().max()), 1e-30)
+        assert e < tol, (what, e)
+
+    # ---- value reverse
+    GL, GMs, GPs = torch.empty(m, H, device=DEV), torch.empty(m, H, device=DEV), torch.zeros(n, 4 * H, device=DEV)
+    gbs = torch.empty(groups, H, device=DEV)
+    vslabs = lib.alignn_ln_slabs(m)
+    vpart, red_s = torch.empty(vslabs, 2, H, device=DEV), torch.empty(2, H, device=DEV)
+    assert lib.alignn_ln_silu_bwd(ptr(GY), H, ptr(M), H, ptr(gamma), ptr(beta), ptr(e_stat), ptr(GL), H, ptr(vpart), m, H, None, st) == 0
+    assert lib.alignn_bn_bwd_finalize(ptr(vpart), vslabs, H, ptr(red_s), st) == 0
+    assert lib.alignn_egc_bwd_lg_dense(ptr(GL), ptr(M), ptr(P), ptr(q1), ptr(q0), None, None, 0, m, ptr(lg.grp_seg_ptr),
+                                       ptr(lg.grp_src_ptr), groups, lg.dense_max_src, ptr(lg.seg_ptr), ptr(lg.seg_node), H, ptr(GMs),
+                                       ptr(GPs), ptr(gbs), None, None, st) == 0
+    prev = os.environ.get("ALIGNN_AMD_LN_REV")
+    try:
+        for v in "012":
+            os.environ["ALIGNN_AMD_LN_REV"] = v + "0"
+            GMf, GPf = torch.empty(m, H, device=DEV), torch.zeros(n, 4 * H, device=DEV)
+            gbf, lnp, red_f = torch.empty(groups, H, device=DEV), torch.empty(groups, 2, H, device=DEV), torch.empty(2, H, device=DEV)
+            assert lib.alignn_egc_bwd_lg_dense_ln(ptr(GY), ptr(M), ptr(P), ptr(q1), ptr(q0), ptr(gamma), ptr(beta), ptr(e_stat), m,
+                                                  ptr(lg.grp_seg_ptr), ptr(lg.grp_src_ptr), groups, lg.dense_max_src, ptr(lg.seg_ptr),
+                                                  ptr(lg.seg_node), H, ptr(GMf), ptr(GPf), ptr(gbf), ptr(lnp), None, None, st) == 0
+            assert lib.alignn_bn_bwd_finalize(ptr(lnp), groups, H, ptr(red_f), st) == 0
+            torch.cuda.synchronize()
+            close(GMf, GMs, "GM " + v)
+            close(GPf[:, :3 * H], GPs[:, :3 * H], "GP " + v)
+            close(gbf.sum(0), gbs.sum(0), "bias gradient " + v)
+            close(red_f, red_s, "LayerNorm parameter gradients " + v, 1e-4)
+        # ---- dual reverse
+        GLp, GLt = torch.empty(m, H, device=DEV), torch.empty(m, H, device=DEV)
+        dslabs = lib.alignn_dual_slabs(m)
+        dpart = torch.empty(dslabs, 2, H, device=DEV)
+        assert lib.alignn_ln_silu_dual_bwd(ptr(GY), ptr(GYt), H, ptr(M), ptr(Mt), H, ptr(gamma), ptr(beta), ptr(e_stat), ptr(GLp),
+                                           ptr(GLt), H, ptr(dpart), m, H, None, st) == 0
+        assert lib.alignn_bn_bwd_finalize(ptr(dpart), dslabs, H, ptr(red_s), st) == 0
+        outs_s = [torch.empty(m, H, device=DEV), torch.empty(m, H, device=DEV), torch.zeros(n, 4 * H, device=DEV),
+                  torch.zeros(n, 4 * H, device=DEV)]
+        assert lib.alignn_egc_dual_bwd_lg_dense(ptr(GLp), ptr(GLt), ptr(M), ptr(Mt), ptr(P), ptr(Pt), ptr(q1), ptr(q0), ptr(q1t), ptr(q0t),
+                                                m, ptr(lg.grp_seg_ptr), ptr(lg.grp_src_ptr), groups, ptr(lg.seg_ptr), ptr(lg.seg_node), H,
+                                                ptr(outs_s[0]), ptr(outs_s[1]), ptr(outs_s[2]), ptr(outs_s[3]), ptr(gbs), None, None,
+                                                st) == 0
+        for v in "012":
+            os.environ["ALIGNN_AMD_LN_REV"] = "0" + v
+            outs_f = [torch.empty(m, H, device=DEV), torch.empty(m, H, device=DEV), torch.zeros(n, 4 * H, device=DEV),
+                      torch.zeros(n, 4 * H, device=DEV)]
+            gbf, lnp, red_f = torch.empty(groups, H, device=DEV), torch.empty(groups, 2, H, device=DEV), torch.empty(2, H, device=DEV)
+            assert lib.alignn_egc_dual_bwd_lg_dense_ln(ptr(GY), ptr(GYt), ptr(M), ptr(Mt), ptr(P), ptr(Pt), ptr(q1), ptr(q0), ptr(q1t),
+                                                       ptr(q0t), ptr(gamma), ptr(beta), ptr(e_stat), m, ptr(lg.grp_seg_ptr),
+                                                       ptr(lg.grp_src_ptr), groups, ptr(lg.seg_ptr), ptr(lg.seg_node), H, ptr(outs_f[0]),
+                                                       ptr(outs_f[1]), ptr(outs_f[2]), ptr(outs_f[3]), ptr(gbf), ptr(lnp), None, None,
+                                                       st) == 0
+            assert lib.alignn_bn_bwd_finalize(ptr(lnp), groups, H, ptr(red_f), st) == 0
+            torch.cuda.synchronize()
+            for a, b, name in zip(outs_f, outs_s, ("GM", "GMt", "GP", "GPt")):
+                close(a[:, :3 * H] if a.shape[1] == 4 * H else a, b[:, :3 * H] if b.shape[1] == 4 * H else b, name + " dual " + v)
+            close(gbf.sum(0), gbs.sum(0), "bias gradient, dual " + v)
+            close(red_f, red_s, "LayerNorm parameter gradients, dual " + v, 1e-4)
+    finally:
+        if prev is None:
+            os.environ.pop("ALIGNN_AMD_LN_REV", None)
+        else:
+            os.environ["ALIGNN_AMD_LN_REV"] = prev
