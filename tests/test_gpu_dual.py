@@ -402,3 +402,57 @@ def test_reverse_kernels_with_the_layernorm_inside_against_the_separate_kernels(
             os.environ.pop("ALIGNN_AMD_LN_REV", None)
         else:
             os.environ["ALIGNN_AMD_LN_REV"] = prev
+
+
+@pytest.mark.parametrize("shape,H", [("small", 256), ("deg_over_16", 64)])
+def test_forward_kernels_with_the_layernorm_inside_against_the_separate_kernels(shape, H):
+    """csrc/convln.hip, forward side: alignn_egc_gate_fwd_pre_ln against alignn_egc_gate_fwd_pre + alignn_ln_silu_fwd, and
+    alignn_egc_gate_dual_tan_ln against alignn_egc_gate_dual_fwd_tangent + alignn_ln_silu_dual_fwd (tangent only): edge output,
+    row statistics, the node sums and pre-activations, the tangents."""
+    from alignn_amd import _lib
+    from alignn_amd.ops import ptr, stream
+
+    lib = _lib.load()
+    raw = make_batch(3, 14, seed0=31) if shape == "small" else make_batch(4, 3, seed0=11)
+    lg = GraphBatch.from_raw(raw, device=DEV).lg
+    n, m = lg.n_nodes, lg.n_edges
+    g = torch.Generator(device=DEV).manual_seed(5)
+    R = lambda *s: torch.randn(*s, device=DEV, generator=g)  # noqa: E731
+    M, Y, Yt, Ct = R(m, H), R(m, H), R(m, H), R(m, H)
+    P, Pt = R(n, 4 * H), R(n, 4 * H)
+    gamma, beta = 1 + 0.1 * R(H), 0.1 * R(H)
+    st = stream()
+    E = lambda *s: torch.empty(*s, device=DEV)  # noqa: E731
+
+    def close(a, b, what, tol=1e-5):
+        e = float((a - b).abs().max()) / max(float(b.abs().max()), 1e-30)
+        assert e < tol, (what, e)
+
+    # ---- values
+    xs, s0s, hhs, ys, sts = E(n, H), E(n, H), E(n, H), E(m, H), E(m, 2)
+    assert lib.alignn_egc_gate_fwd_pre(ptr(P), ptr(M), ptr(lg.seg_ptr), ptr(lg.seg_node), ptr(lg.src), n, m, H, ptr(xs), ptr(s0s),
+                                       ptr(hhs), None, None, st) == 0
+    assert lib.alignn_ln_silu_fwd(ptr(M), H, ptr(Y), H, ptr(gamma), ptr(beta), 1e-5, ptr(ys), H, ptr(sts), m, H, None, st) == 0
+    xf, s0f, hhf, yf, stf, am = E(n, H), E(n, H), E(n, H), E(m, H), E(m, 2), torch.zeros(2, device=DEV)
+    assert lib.alignn_egc_gate_fwd_pre_ln(ptr(P), ptr(M), ptr(lg.seg_ptr), ptr(lg.seg_node), ptr(lg.src), n, m, H, ptr(xf), ptr(s0f),
+                                          ptr(hhf), ptr(gamma), ptr(beta), 1e-5, ptr(Y), ptr(yf), ptr(stf), ptr(am), st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(xf, xs) and torch.equal(s0f, s0s) and torch.equal(hhf, hhs)  # (same sums in the same order)
+    close(yf, ys, "edge output")
+    close(stf, sts, "row statistics")
+    assert abs(float(am[0]) - float(yf.abs().max())) == 0.0
+    # ---- tangents (values known: M, the node sums and the row statistics of the pass above)
+    Mt_s, Mt_f = Ct.clone(), Ct.clone()
+    xts, s0ts, hhts, yts, st2 = E(n, H), E(n, H), E(n, H), E(m, H), E(m, 2)
+    assert lib.alignn_egc_gate_dual_fwd_tangent(ptr(P), ptr(Pt), ptr(M), ptr(Mt_s), ptr(lg.seg_ptr), ptr(lg.seg_node), ptr(lg.src), n, m,
+                                                H, ptr(xts), ptr(s0s), ptr(hhs), ptr(s0ts), ptr(hhts), st) == 0
+    assert lib.alignn_ln_silu_dual_fwd(ptr(M), ptr(Mt_s), H, ptr(Y), ptr(Yt), H, ptr(gamma), ptr(beta), 1e-5, None, ptr(yts), H, ptr(st2),
+                                       m, H, None, st) == 0
+    xtf, s0tf, hhtf, ytf, am2 = E(n, H), E(n, H), E(n, H), E(m, H), torch.zeros(2, device=DEV)
+    assert lib.alignn_egc_gate_dual_tan_ln(ptr(P), ptr(Pt), ptr(M), ptr(Mt_f), ptr(lg.seg_ptr), ptr(lg.seg_node), ptr(lg.src), n, m, H,
+                                           ptr(xtf), ptr(s0s), ptr(hhs), ptr(s0tf), ptr(hhtf), ptr(gamma), ptr(beta), ptr(stf), ptr(Yt),
+                                           ptr(ytf), ptr(am2), st) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(Mt_f, Mt_s) and torch.equal(xtf, xts) and torch.equal(s0tf, s0ts) and torch.equal(hhtf, hhts)
+    close(ytf, yts, "tangent of the edge output")
+    assert float(am2[0]) == 0.0 and abs(float(am2[1]) - float(ytf.abs().max())) == 0.0
