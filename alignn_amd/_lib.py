@@ -52,6 +52,7 @@ SIGNATURES = {
     "alignn_dual_slabs": (_i32, [_i64]),
     "alignn_ln_silu_dual_fwd": (_i32, [_p, _p, _i64, _p, _p, _i64, _p, _p, _f32, _p, _p, _i64, _p, _i64, _i32, _p, _p]),
     "alignn_ln_silu_dual_bwd": (_i32, [_p, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p, _i64, _p, _i64, _i32, _p, _p]),
+    "alignn_ln_silu_dual_bwd_node": (_i32, [_p, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p, _i64, _p, _i64, _i32, _p] + [_p] * 8 + [_p]),
     "alignn_egc_gate_dual_fwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p, _p]),
     "alignn_egc_gate_dual_fwd_tangent": (_i32, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p]),
     "alignn_egc_node_dual_bwd": (_i32, [_p, _p, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p]),
@@ -86,6 +87,7 @@ SIGNATURES = {
     "alignn_ln_slabs": (_i32, [_i64]),
     "alignn_ln_silu_fwd": (_i32, [_p, _i64, _p, _i64, _p, _p, _f32, _p, _i64, _p, _i64, _i32, _p, _p]),
     "alignn_ln_silu_bwd": (_i32, [_p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _p, _i64, _i32, _p, _p]),
+    "alignn_ln_silu_bwd_node": (_i32, [_p, _i64, _p, _i64, _p, _p, _p, _p, _i64, _p, _i64, _i32, _p, _p, _p, _p, _p, _p]),
     "alignn_bond_cosine_fwd": (_i32, [_p, _p, _p, _p, _i64, _p]),
     "alignn_egc_gate_infer": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p]),
     "alignn_rbf_bwd": (_i32, [_p, _p, _f32, _p, _p, _i64, _i32, _p]),

@@ -134,12 +134,16 @@ __global__ __launch_bounds__(kT) void ln_silu_dual_fwd_kernel(
 }
 
 // reverse: (gy, gyt) -> (gx, gxt) and slab partials of dbeta (row 0) / dgamma (row 1)
-template <int NC>
+// NODE: the rows are the node pre-activations of an edge-gated convolution - the reverse of the node-level quotient
+// (egc_node_dual_bwd_kernel's arithmetic) leaves with the gradient: (g, gt) -> Q1, Q0, Q1t, Q0t, one launch instead of two.
+template <int NC, bool NODE>
 __global__ __launch_bounds__(kT) void ln_silu_dual_bwd_kernel(
     const float* __restrict__ GY, const float* __restrict__ GYt, int64_t ldg, const float* __restrict__ X,
     const float* __restrict__ Xt, int64_t ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ stats, float* __restrict__ GX, float* __restrict__ GXt, int64_t ldo,
-    float* __restrict__ partial, int64_t rows, int F, float* __restrict__ amax2) {
+    float* __restrict__ partial, int64_t rows, int F, float* __restrict__ amax2, const float* __restrict__ S0,
+    const float* __restrict__ HH, const float* __restrict__ S0t, const float* __restrict__ HHt, float* __restrict__ Q1,
+    float* __restrict__ Q0, float* __restrict__ Q1t, float* __restrict__ Q0t) {
     __shared__ float4 sh[2][kW][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t w0 = (int64_t)blockIdx.x * kW + wave, stride = (int64_t)gridDim.x * kW;
@@ -222,6 +226,26 @@ __global__ __launch_bounds__(kT) void ln_silu_dual_bwd_kernel(
                 f4_st(GXt + r * ldo + f, gxt);
                 am = fmaxf(am, f4_absmax(gx));
                 amt = fmaxf(amt, f4_absmax(gxt));
+                if (NODE) {
+                    const float4 s0 = f4_ld(S0 + r * F + f), h = f4_ld(HH + r * F + f);
+                    const float4 s0t = f4_ld(S0t + r * F + f), ht = f4_ld(HHt + r * F + f);
+                    float4 q1, q0, q1t, q0t;
+#define ALIGNN_QN(c)                                    \
+    {                                                   \
+        const float d = s0.c + ALIGNN_EPS_GATE;         \
+        q1t.c = gxt.c / d;                              \
+        q0t.c = -q1t.c * h.c;                           \
+        const float gh = gx.c - q1t.c * s0t.c;          \
+        q1.c = gh / d;                                  \
+        q0.c = -q1t.c * ht.c - q1.c * h.c;              \
+    }
+                    ALIGNN_QN(x) ALIGNN_QN(y) ALIGNN_QN(z) ALIGNN_QN(w)
+#undef ALIGNN_QN
+                    f4_st(Q1 + r * F + f, q1);
+                    f4_st(Q0 + r * F + f, q0);
+                    f4_st(Q1t + r * F + f, q1t);
+                    f4_st(Q0t + r * F + f, q0t);
+                }
             }
         }
     }
@@ -674,9 +698,32 @@ int alignn_ln_silu_dual_bwd(const float* GY, const float* GYt, int64_t ldg, cons
     if (rows == 0) return 0;
     dim3 grid(row_blocks(rows)), block(kT);
     hipStream_t st = (hipStream_t)stream;
-#define ALIGNN_CASE(NC_)                                                                                             \
-    hipLaunchKernelGGL((ln_silu_dual_bwd_kernel<NC_>), grid, block, 0, st, GY, GYt, ldg, X, Xt, ldx, gamma, beta, stats, \
-                       GX, GXt, ldo, partial, rows, F, amax2)
+#define ALIGNN_CASE(NC_)                                                                                                    \
+    hipLaunchKernelGGL((ln_silu_dual_bwd_kernel<NC_, false>), grid, block, 0, st, GY, GYt, ldg, X, Xt, ldx, gamma, beta, stats, GX, \
+                       GXt, ldo, partial, rows, F, amax2, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr)
+    switch ((F + 255) / 256) {
+        case 1: ALIGNN_CASE(1); break;
+        case 2: ALIGNN_CASE(2); break;
+        case 3: ALIGNN_CASE(3); break;
+        default: ALIGNN_CASE(4); break;
+    }
+#undef ALIGNN_CASE
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_ln_silu_dual_bwd_node(const float* GY, const float* GYt, int64_t ldg, const float* X, const float* Xt, int64_t ldx,
+                                 const float* gamma, const float* beta, const float* stats, float* GX, float* GXt, int64_t ldo,
+                                 float* partial, int64_t rows, int F, float* amax2, const float* s0, const float* hh,
+                                 const float* s0t, const float* hht, float* q1, float* q0, float* q1t, float* q0t,
+                                 alignn_stream_t stream) {
+    if (!feat_ok(F) || !s0 || !hh || !s0t || !hht || !q1 || !q0 || !q1t || !q0t) return (int)hipErrorInvalidValue;
+    if (rows == 0) return 0;
+    dim3 grid(row_blocks(rows)), block(kT);
+    hipStream_t st = (hipStream_t)stream;
+#define ALIGNN_CASE(NC_)                                                                                                   \
+    hipLaunchKernelGGL((ln_silu_dual_bwd_kernel<NC_, true>), grid, block, 0, st, GY, GYt, ldg, X, Xt, ldx, gamma, beta, stats, GX, \
+                       GXt, ldo, partial, rows, F, amax2, s0, hh, s0t, hht, q1, q0, q1t, q0t)
     switch ((F + 255) / 256) {
         case 1: ALIGNN_CASE(1); break;
         case 2: ALIGNN_CASE(2); break;

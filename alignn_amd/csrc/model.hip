@@ -845,11 +845,11 @@ void conv_bwd_ln(Ctx& c, const ConvTape& t, const Grad& gx_out, const Grad* gy_o
     // ---- node branch: LayerNorm / SiLU backward straight into the Ux block of GP, the quotient's adjoints
     const int n_slabs = alignn_ln_slabs(n);
     float* n_part = c.alloc((size_t)n_slabs * 2 * H);
-    L(alignn_ln_silu_bwd(gx_out.p, H, t.xpre, H, p.n_gamma, p.n_beta, t.n_stat, g_xpre, 4 * H, n_part, n, H, gp_amax, main));
-    if (c.param_grads) L(alignn_bn_bwd_finalize(n_part, n_slabs, H, p.n_red, main));
     float* gs1 = c.alloc((size_t)n * H);
     float* gs0 = c.alloc((size_t)n * H);
-    L(alignn_egc_node_bwd(g_xpre, 4 * H, t.s0, t.hh, gs1, gs0, n, H, main));
+    L(alignn_ln_silu_bwd_node(gx_out.p, H, t.xpre, H, p.n_gamma, p.n_beta, t.n_stat, g_xpre, 4 * H, n_part, n, H, gp_amax, t.s0, t.hh,
+                              gs1, gs0, main));  // (+ the quotient's adjoints: alignn_egc_node_bwd in the same pass)
+    if (c.param_grads) L(alignn_bn_bwd_finalize(n_part, n_slabs, H, p.n_red, main));
     // ---- edge branch (lane T for the line graph): the finished normalised-branch gradient, handed over as it is
     const float* gy = gy_out != nullptr ? gy_out->p : nullptr;
     if (t.lane && gy_out != nullptr && !gy_out->on_T) c.sync(T, main);
@@ -1341,13 +1341,18 @@ void dual_conv_bwd(Ctx& c, const DConvTape& t, const DAct& gx, const DAct& gy, D
     GP.amax_p = c.track(n) ? c.new_amax2() : nullptr;
     GP.amax_t = GP.amax_p ? GP.amax_p + 1 : nullptr;
     // node branch: LayerNorm / SiLU reverse straight into the Ux blocks
-    DAct gxpre = dual_ln_bwd(c, gx, t.xpre, p.n_gamma, p.n_beta, t.n_stats, GP.p + 3 * (size_t)H, GP.t + 3 * (size_t)H, 4 * H, GP.amax_p,
-                             n, H, p.n_red, main);
     float* q1 = c.alloc((size_t)n * H);
     float* q0 = c.alloc((size_t)n * H);
     float* q1t = c.alloc((size_t)n * H);
     float* q0t = c.alloc((size_t)n * H);
-    L(alignn_egc_node_dual_bwd(gxpre.p, gxpre.t, 4 * H, t.s0, t.hh, t.s0t, t.hht, q1, q0, q1t, q0t, n, H, main));
+    {  // (ff2._ln_bwd + alignn_egc_node_dual_bwd in one pass)
+        const int slabs_n = alignn_dual_slabs(n);
+        float* partial = c.alloc((size_t)slabs_n * 2 * H);
+        L(alignn_ln_silu_dual_bwd_node(gx.p, gx.t, H, t.xpre.p, t.xpre.t, H, p.n_gamma, p.n_beta, t.n_stats, GP.p + 3 * (size_t)H,
+                                       GP.t + 3 * (size_t)H, 4 * H, partial, n, H, GP.amax_p, t.s0, t.hh, t.s0t, t.hht, q1, q0, q1t, q0t,
+                                       main));
+        L(alignn_bn_bwd_finalize(partial, slabs_n, H, p.n_red, main));
+    }
     if (t.lane) c.sync(T, main);  // (the four adjoint rows per node; gy if the caller's stream wrote it)
     const bool dense = c.ff->dense_lg_reverse && g.grp_seg_ptr != nullptr && g.dense_max_src > 0;
     const bool ln_inside = gy.p != nullptr && dense && alignn_egc_ln_fused_supported(H, m);  // (csrc/convln.hip)

@@ -592,7 +592,10 @@ __global__ __launch_bounds__(kThreads) void ln_silu_fwd_kernel(const float* __re
 
 // NOTE: this file is compiled with -fno-slp-vectorize (alignn_amd/build.py): with packed-fp32 instructions hipcc 7.2's code for
 // the kernel below was not bit-reproducible beside kernels of another stream.
-template <int NC>
+// NODE: the rows are the node pre-activations xpre = Ux + h of an edge-gated convolution, h = S1 / (S0 + eps): the adjoints of the
+// two segment sums leave with the gradient (alignn_egc_node_bwd's arithmetic: GS1 = g / (S0 + eps), GS0 = -GS1 * h) - one launch
+// instead of two on the bond-row chain of every LayerNorm-flavoured convolution's reverse.
+template <int NC, bool NODE>
 __global__ __launch_bounds__(kThreads) void ln_silu_bwd_kernel(const float* __restrict__ GY, int64_t ldgy,
                                                                const float* __restrict__ X, int64_t ldx,
                                                                const float* __restrict__ gamma,
@@ -600,7 +603,9 @@ __global__ __launch_bounds__(kThreads) void ln_silu_bwd_kernel(const float* __re
                                                                const float* __restrict__ stats,
                                                                float* __restrict__ GX, int64_t ldgx,
                                                                float* __restrict__ partial, int64_t rows, int F,
-                                                               float* __restrict__ amax) {
+                                                               float* __restrict__ amax, const float* __restrict__ S0,
+                                                               const float* __restrict__ HH, float* __restrict__ GS1,
+                                                               float* __restrict__ GS0) {
     __shared__ float4 sh[2][kThreads / 64][64];
     float am = 0.0f;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -643,6 +648,16 @@ __global__ __launch_bounds__(kThreads) void ln_silu_bwd_kernel(const float* __re
                 o.w = rstd * (gh[c].w - c1 - xh[c].w * c2);
                 f4_st(GX + r * ldgx + f, o);
                 am = fmaxf(am, f4_absmax(o));
+                if (NODE) {
+                    const float4 s0 = f4_ld(S0 + r * F + f), h = f4_ld(HH + r * F + f);
+                    float4 g1;
+                    g1.x = o.x / (s0.x + ALIGNN_EPS_GATE);
+                    g1.y = o.y / (s0.y + ALIGNN_EPS_GATE);
+                    g1.z = o.z / (s0.z + ALIGNN_EPS_GATE);
+                    g1.w = o.w / (s0.w + ALIGNN_EPS_GATE);
+                    f4_st(GS1 + r * F + f, g1);
+                    f4_st(GS0 + r * F + f, make_float4(-g1.x * h.x, -g1.y * h.y, -g1.z * h.z, -g1.w * h.w));
+                }
             }
         }
     }
@@ -863,12 +878,37 @@ int alignn_ln_silu_bwd(const float* GY, int64_t ldgy, const float* X, int64_t ld
     const int nc = (F + 255) / 256;
     dim3 grid(ln_blocks(rows)), block(kThreads);
     hipStream_t st = (hipStream_t)stream;
+#define ALIGNN_LNB(NC_)                                                                                                        \
+    hipLaunchKernelGGL((ln_silu_bwd_kernel<NC_, false>), grid, block, 0, st, GY, ldgy, X, ldx, gamma, beta, stats, GX, ldgx, partial, \
+                       rows, F, amax, nullptr, nullptr, nullptr, nullptr)
     switch (nc) {
-        case 1: hipLaunchKernelGGL(ln_silu_bwd_kernel<1>, grid, block, 0, st, GY, ldgy, X, ldx, gamma, beta, stats, GX, ldgx, partial, rows, F, amax); break;
-        case 2: hipLaunchKernelGGL(ln_silu_bwd_kernel<2>, grid, block, 0, st, GY, ldgy, X, ldx, gamma, beta, stats, GX, ldgx, partial, rows, F, amax); break;
-        case 3: hipLaunchKernelGGL(ln_silu_bwd_kernel<3>, grid, block, 0, st, GY, ldgy, X, ldx, gamma, beta, stats, GX, ldgx, partial, rows, F, amax); break;
-        default: hipLaunchKernelGGL(ln_silu_bwd_kernel<4>, grid, block, 0, st, GY, ldgy, X, ldx, gamma, beta, stats, GX, ldgx, partial, rows, F, amax); break;
+        case 1: ALIGNN_LNB(1); break;
+        case 2: ALIGNN_LNB(2); break;
+        case 3: ALIGNN_LNB(3); break;
+        default: ALIGNN_LNB(4); break;
     }
+#undef ALIGNN_LNB
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_ln_silu_bwd_node(const float* GY, int64_t ldgy, const float* X, int64_t ldx, const float* gamma, const float* beta,
+                            const float* stats, float* GX, int64_t ldgx, float* partial, int64_t rows, int F, float* amax,
+                            const float* S0, const float* HH, float* GS1, float* GS0, alignn_stream_t stream) {
+    if (!feat_ok(F) || !S0 || !HH || !GS1 || !GS0) return (int)hipErrorInvalidValue;
+    const int nc = (F + 255) / 256;
+    dim3 grid(ln_blocks(rows)), block(kThreads);
+    hipStream_t st = (hipStream_t)stream;
+#define ALIGNN_LNB(NC_)                                                                                                       \
+    hipLaunchKernelGGL((ln_silu_bwd_kernel<NC_, true>), grid, block, 0, st, GY, ldgy, X, ldx, gamma, beta, stats, GX, ldgx, partial, \
+                       rows, F, amax, S0, HH, GS1, GS0)
+    switch (nc) {
+        case 1: ALIGNN_LNB(1); break;
+        case 2: ALIGNN_LNB(2); break;
+        case 3: ALIGNN_LNB(3); break;
+        default: ALIGNN_LNB(4); break;
+    }
+#undef ALIGNN_LNB
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }

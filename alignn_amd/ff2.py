@@ -106,8 +106,9 @@ def _ln_fwd(x: Dual, res, gamma, beta, value_out=None):
     return Dual(yp, yt, amax, value_out[1] if known else None), stats
 
 
-def _ln_bwd(g: Dual, x: Dual, gamma, beta, stats, out_p=None, out_t=None, amax=None):
-    """-> (gx Dual, red [2,F] = dbeta | dgamma).  ``out_*``: write into these (possibly strided) blocks."""
+def _ln_bwd(g: Dual, x: Dual, gamma, beta, stats, out_p=None, out_t=None, amax=None, node=None):
+    """-> (gx Dual, red [2,F] = dbeta | dgamma).  ``out_*``: write into these (possibly strided) blocks.  ``node`` = (s0, hh, s0t,
+    hht, q1, q0, q1t, q0t): the reverse of the node-level quotient in the same pass (alignn_ln_silu_dual_bwd_node)."""
     lib = _lib.load()
     rows, F = x.p.shape
     if out_p is None:
@@ -116,9 +117,14 @@ def _ln_bwd(g: Dual, x: Dual, gamma, beta, stats, out_p=None, out_t=None, amax=N
         amax = _amax2(x.p)
     slabs = lib.alignn_dual_slabs(rows)
     partial = _empty(slabs, 2, F, like=x.p)
-    check(lib.alignn_ln_silu_dual_bwd(ptr(g.p), ptr(g.t), g.p.stride(0), ptr(x.p), ptr(x.t), x.p.stride(0), ptr(gamma),
-                                      ptr(beta), ptr(stats), ptr(out_p), ptr(out_t), out_p.stride(0), ptr(partial), rows,
-                                      F, ptr(amax), stream()), "ln_silu_dual_bwd")
+    if node is not None:
+        check(lib.alignn_ln_silu_dual_bwd_node(ptr(g.p), ptr(g.t), g.p.stride(0), ptr(x.p), ptr(x.t), x.p.stride(0), ptr(gamma),
+                                               ptr(beta), ptr(stats), ptr(out_p), ptr(out_t), out_p.stride(0), ptr(partial), rows,
+                                               F, ptr(amax), *[ptr(t_) for t_ in node], stream()), "ln_silu_dual_bwd_node")
+    else:
+        check(lib.alignn_ln_silu_dual_bwd(ptr(g.p), ptr(g.t), g.p.stride(0), ptr(x.p), ptr(x.t), x.p.stride(0), ptr(gamma),
+                                          ptr(beta), ptr(stats), ptr(out_p), ptr(out_t), out_p.stride(0), ptr(partial), rows,
+                                          F, ptr(amax), stream()), "ln_silu_dual_bwd")
     red = _empty(2, F, like=x.p)
     check(lib.alignn_bn_bwd_finalize(ptr(partial), slabs, F, ptr(red), stream()), "ln_dual_finalize")
     return Dual(out_p, out_t, amax), red
@@ -244,13 +250,11 @@ def conv_bwd(entry, gx: Dual, gy, grads: _Grads):
         gx = Dual(torch.zeros_like(x.p), torch.zeros_like(x.p))
     GP = Dual(_empty(n, 4 * H, like=x.p), _empty(n, 4 * H, like=x.p), _amax2(x.p) if _track(n) else None)
     # node branch: LayerNorm/SiLU reverse straight into the Ux blocks
-    gxpre, n_red = _ln_bwd(gx, xpre, conv.bn_nodes.weight, conv.bn_nodes.bias, n_stats, GP.p[:, 3 * H:], GP.t[:, 3 * H:],
-                           amax=GP.amax)
+    q1, q0, q1t, q0t = (_empty(n, H, like=x.p) for _ in range(4))
+    _gxpre, n_red = _ln_bwd(gx, xpre, conv.bn_nodes.weight, conv.bn_nodes.bias, n_stats, GP.p[:, 3 * H:], GP.t[:, 3 * H:],
+                            amax=GP.amax, node=(s0, hh, s0t, hht, q1, q0, q1t, q0t))
     grads.add(conv.bn_nodes.bias, n_red[0])
     grads.add(conv.bn_nodes.weight, n_red[1])
-    q1, q0, q1t, q0t = (_empty(n, H, like=x.p) for _ in range(4))
-    check(lib.alignn_egc_node_dual_bwd(ptr(gxpre.p), ptr(gxpre.t), 4 * H, ptr(s0), ptr(hh), ptr(s0t), ptr(hht), ptr(q1),
-                                       ptr(q0), ptr(q1t), ptr(q0t), n, H, stream()), "egc_node_dual_bwd")
     dense = (DENSE_LG_REVERSE and graph.grp_seg_ptr is not None and graph.dense_max_src > 0 and ops.FUSED_LG_BACKWARD
              and ops.DENSE_LG_BACKWARD)
     ln_inside = bool(gy is not None and dense and lib.alignn_egc_ln_fused_supported(H, m))  # (csrc/convln.hip)

@@ -1010,17 +1010,28 @@ def _ln_silu_fwd(x, res, gamma, beta, want_stats=True):
     return y, stats
 
 
-def _ln_silu_bwd(gy, x, gamma, beta, stats, out, amax=None):
-    """LayerNorm/SiLU backward into ``out`` (``amax``: raised to max|out|); returns red [2,F] = (dbeta, dgamma)."""
+def _ln_silu_bwd(gy, x, gamma, beta, stats, out, amax=None, node=None):
+    """LayerNorm/SiLU backward into ``out`` (``amax``: raised to max|out|); returns red [2,F] = (dbeta, dgamma).
+    ``node`` = (S0, HH, GS1, GS0): ``x`` is the node pre-activation of an edge-gated convolution - the adjoints of its two segment
+    sums are written in the same pass (alignn_ln_silu_bwd_node)."""
     lib = _lib.load()
     rows, F = x.shape
     slabs = lib.alignn_ln_slabs(rows)
     partial = _empty(slabs, 2, F, like=x)
-    check(
-        lib.alignn_ln_silu_bwd(ptr(gy), gy.stride(0), ptr(x), x.stride(0), ptr(gamma), ptr(beta), ptr(stats), ptr(out),
-                               out.stride(0), ptr(partial), rows, F, ptr(amax), stream()),
-        "ln_silu_bwd",
-    )
+    if node is not None:
+        s0, hh, gs1, gs0 = node
+        check(
+            lib.alignn_ln_silu_bwd_node(ptr(gy), gy.stride(0), ptr(x), x.stride(0), ptr(gamma), ptr(beta), ptr(stats), ptr(out),
+                                        out.stride(0), ptr(partial), rows, F, ptr(amax), ptr(s0), ptr(hh), ptr(gs1), ptr(gs0),
+                                        stream()),
+            "ln_silu_bwd_node",
+        )
+    else:
+        check(
+            lib.alignn_ln_silu_bwd(ptr(gy), gy.stride(0), ptr(x), x.stride(0), ptr(gamma), ptr(beta), ptr(stats), ptr(out),
+                                   out.stride(0), ptr(partial), rows, F, ptr(amax), stream()),
+            "ln_silu_bwd",
+        )
     red = _empty(2, F, like=x)
     check(lib.alignn_bn_bwd_finalize(ptr(partial), slabs, F, ptr(red), stream()), "ln_bwd_finalize")
     return red
@@ -1847,16 +1858,13 @@ class EdgeGatedConvFn(torch.autograd.Function):
         gm_amax = new_amax(x) if _track(m) else None
         # ---- node branch (caller's stream): SiLU/norm backward -> g_xpre (stored as the Ux block of GP)
         g_xpre = GP[:, 3 * H:]
-        if layer:
-            n_red = _ln_silu_bwd(gx_out, xpre, n_gamma, n_beta, n_stat, g_xpre, gp_amax)
-        else:
-            n_red = _bn_silu_bwd_reduce(gx_out, xpre, n_stat)
         gs1 = _empty(n, H, like=x)
         gs0 = _empty(n, H, like=x)
-        if layer:
-            check(lib.alignn_egc_node_bwd(ptr(g_xpre), 4 * H, ptr(s0), ptr(hh), ptr(gs1), ptr(gs0), n, H, stream()),
-                  "egc_node_bwd")
-        else:  # (norm backward and the quotient's adjoints in one pass)
+        if layer:  # (LayerNorm backward and the quotient's adjoints in one pass)
+            n_red = _ln_silu_bwd(gx_out, xpre, n_gamma, n_beta, n_stat, g_xpre, gp_amax, node=(s0, hh, gs1, gs0))
+        else:
+            n_red = _bn_silu_bwd_reduce(gx_out, xpre, n_stat)
+        if not layer:  # (norm backward and the quotient's adjoints in one pass)
             check(lib.alignn_bn_silu_bwd_apply_node(ptr(gx_out), gx_out.stride(0), ptr(xpre), xpre.stride(0), ptr(n_stat),
                                                     ptr(n_gamma), ptr(n_red), int(ev), ptr(g_xpre), g_xpre.stride(0), n, H,
                                                     ptr(gp_amax), ptr(s0), ptr(hh), ptr(gs1), ptr(gs0), stream()),

@@ -239,6 +239,12 @@ int alignn_ln_silu_fwd(const float* X, int64_t ldx, const float* R, int64_t ldr,
 int alignn_ln_silu_bwd(const float* GY, int64_t ldgy, const float* X, int64_t ldx, const float* gamma,
                        const float* beta, const float* stats, float* GX, int64_t ldgx, float* partial,
                        int64_t rows, int F, float* amax, alignn_stream_t stream);
+/* alignn_ln_silu_bwd on the node pre-activations xpre = Ux + S1 / (S0 + eps) of an edge-gated convolution, the adjoints of the two
+ * segment sums written in the same pass (alignn_egc_node_bwd's arithmetic on the gradient just formed: GS1 = g / (S0 + eps),
+ * GS0 = -GS1 * HH) - one launch instead of two on the reverse chain of every LayerNorm-flavoured convolution. */
+int alignn_ln_silu_bwd_node(const float* GY, int64_t ldgy, const float* X, int64_t ldx, const float* gamma, const float* beta,
+                            const float* stats, float* GX, int64_t ldgx, float* partial, int64_t rows, int F, float* amax,
+                            const float* S0, const float* HH, float* GS1, float* GS0, alignn_stream_t stream);
 /* out[f] = sum_s partial[s][f] over `slabs` slabs of `width` floats (fp64 accumulation, fixed order) */
 int alignn_slab_sum(const float* partial, int slabs, int width, float* out, alignn_stream_t stream);
 /* Pre-pass for very many slabs (one per row tile of a T-row projection): out[g][f] = sum of partial[k][f] over
@@ -398,6 +404,12 @@ int alignn_segment_sum(const float* vals, int64_t ldv, const int32_t* ptr, const
 int alignn_gather_rows(const float* in, const int32_t* perm, float* out, int64_t rows, int F,
                        alignn_stream_t stream);
 
+/* alignn_ln_silu_dual_bwd on the node pre-activations of an edge-gated convolution + alignn_egc_node_dual_bwd in the same pass */
+int alignn_ln_silu_dual_bwd_node(const float* GY, const float* GYt, int64_t ldg, const float* X, const float* Xt, int64_t ldx,
+                                 const float* gamma, const float* beta, const float* stats, float* GX, float* GXt, int64_t ldo,
+                                 float* partial, int64_t rows, int F, float* amax2, const float* s0, const float* hh,
+                                 const float* s0t, const float* hht, float* q1, float* q0, float* q1t, float* q0t,
+                                 alignn_stream_t stream);
 /* ------------------------------------------------------------------------------------------
  * Dual-number kernels (value + directional derivative along a bond-vector displacement) of the LayerNorm-flavoured
  * stack - training THROUGH the forces: the reference takes pair forces with autograd.grad(create_graph=True)
