@@ -60,6 +60,10 @@ SIGNATURES = {
     "alignn_egc_dual_bwd_src": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p, _p, _p, _p]),
     "alignn_egc_dual_bwd_lg_dense": (_i32, [_p] * 10 + [_i64, _p, _p, _i64, _p, _p, _i32] + [_p] * 7 + [_p]),
     "alignn_egc_ln_fused_supported": (_i32, [_i32, _i64]),
+    "alignn_egc_ln_dst_slabs": (_i32, [_i64]),
+    "alignn_egc_ln_dst_supported": (_i32, [_i32]),
+    "alignn_egc_bwd_dst_ln": (_i32, [_p] * 11 + [_i64, _i32] + [_p] * 6 + [_p]),
+    "alignn_egc_dual_bwd_dst_ln": (_i32, [_p] * 16 + [_i64, _i32] + [_p] * 8 + [_p]),
     "alignn_egc_gate_fwd_pre_ln": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _f32, _p, _p, _p, _p, _p]),
     "alignn_egc_bwd_lg_dense_ln": (_i32, [_p] * 8 + [_i64, _p, _p, _i64, _i32, _p, _p, _i32] + [_p] * 6 + [_p]),
     "alignn_egc_gate_dual_tan_ln": (_i32, [_p] * 7 + [_i64, _i64, _i32] + [_p] * 11 + [_p]),

@@ -592,6 +592,210 @@ __global__ __launch_bounds__(kT) void egc_dual_bwd_lg_dense_ln_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// the same for graphs WITHOUT dense blocks (the bond graph g; line graphs with the dense reverse switched off): the
+// destination-ordered halves egc_bwd_dst_kernel<2> / egc_dual_bwd_dst_kernel with the LayerNorm adjoint of the edge output formed
+// in the pass (one wavefront per destination segment, rows one at a time; the source-ordered halves egc_bwd_src / egc_dual_bwd_src
+// follow unchanged).  These are bond-row passes - cache-resident, launch- and latency-bound on the chain the T-row lane waits
+// for: what they save is a launch and a round trip of the branch gradient per convolution and reverse.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kT) void egc_bwd_dst_ln_kernel(
+    const float* __restrict__ GY, const float* __restrict__ M, const float* __restrict__ P, const float* __restrict__ GS1,
+    const float* __restrict__ GS0, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ e_stat, const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ seg_node,
+    const int32_t* __restrict__ src, int n_seg, int H, float* __restrict__ GM, float* __restrict__ GP,
+    float* __restrict__ gb_partial, float* __restrict__ ln_partial, float* __restrict__ gm_amax, float* __restrict__ gp_amax) {
+    __shared__ float4 sh[2][kW][ALIGNN_WAVE];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t ldp = 4 * (int64_t)H;
+    const int first = blockIdx.x * kW + wave, stride = gridDim.x * kW;
+    const int f = 4 * lane;
+    const bool active = f < H;
+    const float inv_f = 1.0f / (float)H;
+    const float4 lg = active ? f4_ld(gamma + f) : f4_zero(), lb = active ? f4_ld(beta + f) : f4_zero();
+    float gm_am = 0.0f, gp_am = 0.0f;
+    float4 gb = f4_zero(), db = f4_zero(), dg = f4_zero();
+    for (int s = first; s < n_seg; s += stride) {
+        const int beg = seg_ptr[s], end = seg_ptr[s + 1];
+        const int i = seg_node ? seg_node[s] : s;
+        const float4 gs1 = active ? f4_ld(GS1 + (int64_t)i * H + f) : f4_zero();
+        const float4 gs0 = active ? f4_ld(GS0 + (int64_t)i * H + f) : f4_zero();
+        float4 gbd = f4_zero();
+        for (int e = beg; e < end; ++e) {
+            const float mean = e_stat[2 * (int64_t)e], rstd = e_stat[2 * (int64_t)e + 1];
+            float4 m = f4_zero(), bh = f4_zero(), xh = f4_zero(), gh = f4_zero();
+            float s1 = 0.0f, s2 = 0.0f;
+            if (active) {
+                m = f4_ld(M + (int64_t)e * H + f);
+                bh = f4_ld(P + (int64_t)src[e] * ldp + 2 * H + f);
+                const float4 gy = f4_ld(GY + (int64_t)e * H + f);
+                xh = make_float4((m.x - mean) * rstd, (m.y - mean) * rstd, (m.z - mean) * rstd, (m.w - mean) * rstd);
+                const float4 z = f4_fma(xh, lg, lb);
+                const float4 gz = make_float4(gy.x * dsilu_f(z.x), gy.y * dsilu_f(z.y), gy.z * dsilu_f(z.z), gy.w * dsilu_f(z.w));
+                db = f4_add(db, gz);
+                dg = f4_fma(gz, xh, dg);
+                gh = f4_mul(gz, lg);
+                s1 = hsum4(gh);
+                s2 = hsum4(f4_mul(gh, xh));
+            }
+            const float c1 = wave_sum1(s1) * inv_f, c2 = wave_sum1(s2) * inv_f;
+            if (active) {
+                const float4 sg = f4_sigmoid(m);
+                const float4 gsig = f4_fma(gs1, bh, gs0);
+                float4 gm;
+                gm.x = gsig.x * sg.x * (1.0f - sg.x) + rstd * (gh.x - c1 - xh.x * c2);
+                gm.y = gsig.y * sg.y * (1.0f - sg.y) + rstd * (gh.y - c1 - xh.y * c2);
+                gm.z = gsig.z * sg.z * (1.0f - sg.z) + rstd * (gh.z - c1 - xh.z * c2);
+                gm.w = gsig.w * sg.w * (1.0f - sg.w) + rstd * (gh.w - c1 - xh.w * c2);
+                f4_st(GM + (int64_t)e * H + f, gm);
+                gm_am = fmaxf(gm_am, f4_absmax(gm));
+                gbd = f4_add(gbd, gm);
+            }
+        }
+        if (active) {
+            f4_st(GP + (int64_t)i * ldp + H + f, gbd);
+            gp_am = fmaxf(gp_am, f4_absmax(gbd));
+            gb = f4_add(gb, gbd);
+        }
+    }
+    sh[0][wave][lane] = gb;
+    __syncthreads();
+    if (wave == 0 && active && gb_partial) {
+        float4 a = sh[0][0][lane];
+#pragma unroll
+        for (int w = 1; w < kW; ++w) a = f4_add(a, sh[0][w][lane]);
+        f4_st(gb_partial + (size_t)blockIdx.x * H + f, a);
+    }
+    ln_slab_store(db, dg, sh, ln_partial + (size_t)blockIdx.x * 2 * H, H, f, active, wave, lane);
+    block_amax_commit(gm_am, gm_amax);
+    block_amax_commit(gp_am, gp_amax);
+}
+
+__global__ __launch_bounds__(kT) void egc_dual_bwd_dst_ln_kernel(
+    const float* __restrict__ GY, const float* __restrict__ GYt, const float* __restrict__ M, const float* __restrict__ Mt,
+    const float* __restrict__ P, const float* __restrict__ Pt, const float* __restrict__ Q1, const float* __restrict__ Q0,
+    const float* __restrict__ Q1t, const float* __restrict__ Q0t, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ e_stat, const int32_t* __restrict__ seg_ptr, const int32_t* __restrict__ seg_node,
+    const int32_t* __restrict__ src, int n_seg, int H, float* __restrict__ GM, float* __restrict__ GMt, float* __restrict__ GP,
+    float* __restrict__ GPt, float* __restrict__ gb_partial, float* __restrict__ ln_partial, float* __restrict__ gm_amax2,
+    float* __restrict__ gp_amax2) {
+    __shared__ float4 sh[2][kW][ALIGNN_WAVE];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t ldp = 4 * (int64_t)H;
+    const int first = blockIdx.x * kW + wave, stride = gridDim.x * kW;
+    const int f = 4 * lane;
+    const bool active = f < H;
+    const float inv_f = 1.0f / (float)H;
+    const float4 lg = active ? f4_ld(gamma + f) : f4_zero(), lb = active ? f4_ld(beta + f) : f4_zero();
+    float am = 0.0f, amt = 0.0f, pam = 0.0f, pamt = 0.0f;
+    float4 gb = f4_zero(), db = f4_zero(), dg = f4_zero();
+    for (int s = first; s < n_seg; s += stride) {
+        const int beg = seg_ptr[s], end = seg_ptr[s + 1];
+        const int i = seg_node ? seg_node[s] : s;
+        const float4 q1 = active ? f4_ld(Q1 + (int64_t)i * H + f) : f4_zero(), q0 = active ? f4_ld(Q0 + (int64_t)i * H + f) : f4_zero();
+        const float4 q1t = active ? f4_ld(Q1t + (int64_t)i * H + f) : f4_zero(), q0t = active ? f4_ld(Q0t + (int64_t)i * H + f) : f4_zero();
+        float4 gbd = f4_zero(), gbdt = f4_zero();
+        for (int e = beg; e < end; ++e) {
+            const float mean = e_stat[2 * (int64_t)e], rs = e_stat[2 * (int64_t)e + 1];
+            float4 m = f4_zero(), t = f4_zero(), xh = f4_zero(), a = f4_zero(), b = f4_zero(), bh = f4_zero(), bht = f4_zero();
+            float4 gy = f4_zero(), gyt = f4_zero();
+            float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f;
+            if (active) {
+                const int64_t u = src[e];
+                m = f4_ld(M + (int64_t)e * H + f);
+                t = f4_ld(Mt + (int64_t)e * H + f);
+                gy = f4_ld(GY + (int64_t)e * H + f);
+                gyt = f4_ld(GYt + (int64_t)e * H + f);
+                bh = f4_ld(P + u * ldp + 2 * H + f);
+                bht = f4_ld(Pt + u * ldp + 2 * H + f);
+                xh = make_float4((m.x - mean) * rs, (m.y - mean) * rs, (m.z - mean) * rs, (m.w - mean) * rs);
+                r0 = hsum4(t);
+                r1 = hsum4(f4_mul(xh, t));
+            }
+            const float m1 = wave_sum1(r0) * inv_f, m2 = wave_sum1(r1) * inv_f;
+            r0 = r1 = r2 = 0.0f;
+            if (active) {
+#define ALIGNN_LN_DB(q)                                              \
+    {                                                                \
+        const float th = rs * (t.q - m1 - xh.q * m2);                \
+        const float z = fmaf(xh.q, lg.q, lb.q), zt = lg.q * th;      \
+        float d1, d2;                                                \
+        dsilu2(z, d1, d2);                                           \
+        const float gzt = gyt.q * d1;                                \
+        const float gz = gy.q * d1 + gyt.q * d2 * zt;                \
+        db.q += gz;                                                  \
+        dg.q += gz * xh.q + gzt * th;                                \
+        a.q = lg.q * gzt;                                            \
+        b.q = lg.q * gz;                                             \
+        r0 += a.q;                                                   \
+        r1 += a.q * xh.q;                                            \
+        r2 += a.q * th;                                              \
+    }
+                ALIGNN_LN_DB(x) ALIGNN_LN_DB(y) ALIGNN_LN_DB(z) ALIGNN_LN_DB(w)
+#undef ALIGNN_LN_DB
+            }
+            const float A1 = wave_sum1(r0) * inv_f, A2 = wave_sum1(r1) * inv_f, A3 = wave_sum1(r2) * inv_f;
+            r0 = r1 = 0.0f;
+            if (active) {
+                b.x -= rs * (a.x * m2 + t.x * A2);
+                b.y -= rs * (a.y * m2 + t.y * A2);
+                b.z -= rs * (a.z * m2 + t.z * A2);
+                b.w -= rs * (a.w * m2 + t.w * A2);
+                r0 = hsum4(b);
+                r1 = hsum4(f4_mul(b, xh));
+            }
+            const float B1 = wave_sum1(r0) * inv_f, B2 = wave_sum1(r1) * inv_f;
+            if (active) {
+                float4 gm, gmt;
+#define ALIGNN_GD(c)                                                            \
+    {                                                                           \
+        gmt.c = rs * (a.c - A1 - xh.c * A2);                                    \
+        gm.c = rs * (b.c - B1 - xh.c * B2) - rs * xh.c * A3;                    \
+        const float sg = sig_f(m.c), sp = sg * (1.0f - sg);                     \
+        const float gs = q1.c * bh.c + q0.c + q1t.c * bht.c; /* adj. sigma */   \
+        const float gst = q1t.c * bh.c + q0t.c;              /* adj. sigma-dot */ \
+        gm.c += gs * sp + gst * sp * (1.0f - 2.0f * sg) * t.c;                  \
+        gmt.c += gst * sp;                                                      \
+    }
+                ALIGNN_GD(x) ALIGNN_GD(y) ALIGNN_GD(z) ALIGNN_GD(w)
+#undef ALIGNN_GD
+                f4_st(GM + (int64_t)e * H + f, gm);
+                f4_st(GMt + (int64_t)e * H + f, gmt);
+                am = fmaxf(am, f4_absmax(gm));
+                amt = fmaxf(amt, f4_absmax(gmt));
+                gbd = f4_add(gbd, gm);
+                gbdt = f4_add(gbdt, gmt);
+            }
+        }
+        if (active) {
+            f4_st(GP + (int64_t)i * ldp + H + f, gbd);
+            f4_st(GPt + (int64_t)i * ldp + H + f, gbdt);
+            pam = fmaxf(pam, f4_absmax(gbd));
+            pamt = fmaxf(pamt, f4_absmax(gbdt));
+            gb = f4_add(gb, gbd);
+        }
+    }
+    sh[0][wave][lane] = gb;
+    __syncthreads();
+    if (wave == 0 && active && gb_partial) {
+        float4 a = sh[0][0][lane];
+#pragma unroll
+        for (int w = 1; w < kW; ++w) a = f4_add(a, sh[0][w][lane]);
+        f4_st(gb_partial + (size_t)blockIdx.x * H + f, a);
+    }
+    ln_slab_store(db, dg, sh, ln_partial + (size_t)blockIdx.x * 2 * H, H, f, active, wave, lane);
+    if (gm_amax2 != nullptr) {
+        block_amax_commit(am, gm_amax2);
+        block_amax_commit(amt, gm_amax2 + 1);
+    }
+    if (gp_amax2 != nullptr) {
+        block_amax_commit(pam, gp_amax2);
+        block_amax_commit(pamt, gp_amax2 + 1);
+    }
+}
+
 // sources per wave and pass / rows per sub-batch of the two reverse kernels (ALIGNN_AMD_LN_REV = "<value><dual>", A/B runs)
 inline int reverse_variant(int which) {  // (read per call: A/B runs inside one process)
     const char* e = std::getenv("ALIGNN_AMD_LN_REV");
@@ -699,6 +903,42 @@ int alignn_egc_dual_bwd_lg_dense_ln(const float* GY, const float* GYt, const flo
         default: if (big) ALIGNN_LND(true, 4, 1, true); else ALIGNN_LND(false, 4, 1, true); break;
     }
 #undef ALIGNN_LND
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+/* Destination-ordered reverse passes with the LayerNorm inside, for graphs without dense blocks (the bond graph): what
+   alignn_ln_silu_bwd + alignn_egc_bwd_dst(e_stat = NULL) resp. alignn_ln_silu_dual_bwd + alignn_egc_dual_bwd_dst compute; the
+   source-ordered halves (alignn_egc_bwd_src / alignn_egc_dual_bwd_src) follow as before.  Slabs: alignn_egc_ln_dst_slabs(n_seg)
+   of [H] (bias gradient) and [2][H] (LayerNorm parameter gradients). */
+int alignn_egc_ln_dst_slabs(int64_t n_seg) { return seg_blocks(n_seg); }
+int alignn_egc_ln_dst_supported(int H) {  // (any size: these are bond-row passes; ALIGNN_AMD_LN_FUSED=0 switches them off too)
+    const char* e = std::getenv("ALIGNN_AMD_LN_FUSED");
+    return (e != nullptr && e[0] == '0') ? 0 : (ln_h_ok(H) ? 1 : 0);
+}
+
+int alignn_egc_bwd_dst_ln(const float* GY, const float* M, const float* P, const float* GS1, const float* GS0, const float* gamma,
+                          const float* beta, const float* e_stat, const int32_t* seg_ptr, const int32_t* seg_node,
+                          const int32_t* src, int64_t n_seg, int H, float* GM, float* GP, float* gb_partial, float* ln_partial,
+                          float* gm_amax, float* gp_amax, alignn_stream_t stream) {
+    if (!ln_h_ok(H) || n_seg < 0 || n_seg > INT32_MAX || !GY || !e_stat || !ln_partial) return (int)hipErrorInvalidValue;
+    if (n_seg == 0) return 0;
+    hipLaunchKernelGGL(egc_bwd_dst_ln_kernel, dim3(seg_blocks(n_seg)), dim3(kT), 0, (hipStream_t)stream, GY, M, P, GS1, GS0, gamma,
+                       beta, e_stat, seg_ptr, seg_node, src, (int)n_seg, H, GM, GP, gb_partial, ln_partial, gm_amax, gp_amax);
+    ALIGNN_CHECK_LAUNCH();
+    return 0;
+}
+
+int alignn_egc_dual_bwd_dst_ln(const float* GY, const float* GYt, const float* M, const float* Mt, const float* P, const float* Pt,
+                               const float* q1, const float* q0, const float* q1t, const float* q0t, const float* gamma,
+                               const float* beta, const float* e_stat, const int32_t* seg_ptr, const int32_t* seg_node,
+                               const int32_t* src, int64_t n_seg, int H, float* GM, float* GMt, float* GP, float* GPt,
+                               float* gb_partial, float* ln_partial, float* gm_amax2, float* gp_amax2, alignn_stream_t stream) {
+    if (!ln_h_ok(H) || n_seg < 0 || n_seg > INT32_MAX || !GY || !GYt || !e_stat || !ln_partial) return (int)hipErrorInvalidValue;
+    if (n_seg == 0) return 0;
+    hipLaunchKernelGGL(egc_dual_bwd_dst_ln_kernel, dim3(seg_blocks(n_seg)), dim3(kT), 0, (hipStream_t)stream, GY, GYt, M, Mt, P, Pt, q1,
+                       q0, q1t, q0t, gamma, beta, e_stat, seg_ptr, seg_node, src, (int)n_seg, H, GM, GMt, GP, GPt, gb_partial,
+                       ln_partial, gm_amax2, gp_amax2);
     ALIGNN_CHECK_LAUNCH();
     return 0;
 }

@@ -856,8 +856,9 @@ void conv_bwd_ln(Ctx& c, const ConvTape& t, const Grad& gx_out, const Grad* gy_o
     const bool lg_blocks = g.grp_seg_ptr != nullptr;
     const bool dense = lg_blocks && g.dense_max_src > 0 && alignn_egc_bwd_lg_dense_supported(g.dense_max_src);
     const bool ln_inside = gy != nullptr && dense && alignn_egc_ln_fused_supported(H, m);  // (csrc/convln.hip)
+    const bool ln_dst = gy != nullptr && !lg_blocks && alignn_egc_ln_dst_supported(H);       // (the bond graph: same file)
     float* g_branch = nullptr;
-    if (gy != nullptr && !ln_inside) {
+    if (gy != nullptr && !ln_inside && !ln_dst) {
         g_branch = c.alloc((size_t)m * H);
         const int e_slabs = alignn_ln_slabs(m);
         float* e_part = c.alloc((size_t)e_slabs * 2 * H);
@@ -866,9 +867,15 @@ void conv_bwd_ln(Ctx& c, const ConvTape& t, const Grad& gx_out, const Grad* gy_o
     }
     if (t.lane) c.sync(T, main);
     float* GM = c.alloc((size_t)m * H);
-    const int gslabs = lg_blocks ? (int)g.n_groups : alignn_egc_slabs(n);
+    const int gslabs = lg_blocks ? (int)g.n_groups : (ln_dst ? alignn_egc_ln_dst_slabs(n) : alignn_egc_slabs(n));
     float* gb_part = c.alloc((size_t)gslabs * H);
-    if (ln_inside) {
+    if (ln_dst) {
+        float* e_part = c.alloc((size_t)gslabs * 2 * H);
+        L(alignn_egc_bwd_dst_ln(gy, t.M, t.P, gs1, gs0, p.e_gamma, p.e_beta, t.e_stat, g.seg_ptr, g.seg_node, g.src, n, H, GM, GP, gb_part,
+                                e_part, gm_amax, gp_amax, T));
+        if (c.param_grads) L(alignn_bn_bwd_finalize(e_part, gslabs, H, p.e_red, T));
+        L(alignn_egc_bwd_src(GM, t.M, gs1, g.out_ptr, g.out_slot, g.dst, n, H, GP, gp_amax, T));
+    } else if (ln_inside) {
         float* e_part = c.alloc((size_t)gslabs * 2 * H);
         L(alignn_egc_bwd_lg_dense_ln(gy, t.M, t.P, gs1, gs0, p.e_gamma, p.e_beta, t.e_stat, m, g.grp_seg_ptr, g.grp_src_ptr, g.n_groups,
                                      g.dense_max_src, g.seg_ptr, g.seg_node, H, GM, GP, gb_part, e_part, gm_amax, gp_amax, T));
@@ -1356,8 +1363,9 @@ void dual_conv_bwd(Ctx& c, const DConvTape& t, const DAct& gx, const DAct& gy, D
     if (t.lane) c.sync(T, main);  // (the four adjoint rows per node; gy if the caller's stream wrote it)
     const bool dense = c.ff->dense_lg_reverse && g.grp_seg_ptr != nullptr && g.dense_max_src > 0;
     const bool ln_inside = gy.p != nullptr && dense && alignn_egc_ln_fused_supported(H, m);  // (csrc/convln.hip)
+    const bool ln_dst = gy.p != nullptr && !dense && alignn_egc_ln_dst_supported(H);           // (the bond graph: same file)
     DAct GL;
-    if (gy.p != nullptr && !ln_inside) {
+    if (gy.p != nullptr && !ln_inside && !ln_dst) {
         float* amax2 = c.track(m) ? c.new_amax2() : nullptr;
         float* lp = c.alloc((size_t)m * H);
         float* lt = c.alloc((size_t)m * H);
@@ -1382,6 +1390,14 @@ void dual_conv_bwd(Ctx& c, const DConvTape& t, const DAct& gx, const DAct& gy, D
         gb_part = c.alloc((size_t)slabs * H);
         L(alignn_egc_dual_bwd_lg_dense(GL.p, GL.t, t.M.p, t.M.t, t.P.p, t.P.t, q1, q0, q1t, q0t, m, g.grp_seg_ptr, g.grp_src_ptr, slabs,
                                        g.seg_ptr, g.seg_node, H, GM.p, GM.t, GP.p, GP.t, gb_part, GM.amax_p, GP.amax_p, T));
+    } else if (ln_dst) {
+        slabs = alignn_egc_ln_dst_slabs(n);
+        gb_part = c.alloc((size_t)slabs * H);
+        float* e_part = c.alloc((size_t)slabs * 2 * H);
+        L(alignn_egc_dual_bwd_dst_ln(gy.p, gy.t, t.M.p, t.M.t, t.P.p, t.P.t, q1, q0, q1t, q0t, p.e_gamma, p.e_beta, t.e_stats, g.seg_ptr,
+                                     g.seg_node, g.src, n, H, GM.p, GM.t, GP.p, GP.t, gb_part, e_part, GM.amax_p, GP.amax_p, T));
+        L(alignn_bn_bwd_finalize(e_part, slabs, H, p.e_red, T));
+        L(alignn_egc_dual_bwd_src(GM.p, GM.t, t.M.p, t.M.t, q1, q1t, g.out_ptr, g.out_slot, g.dst, n, H, GP.p, GP.t, GP.amax_p, T));
     } else {
         slabs = alignn_dual_slabs(n);
         gb_part = c.alloc((size_t)slabs * H);

@@ -258,8 +258,9 @@ def conv_bwd(entry, gx: Dual, gy, grads: _Grads):
     dense = (DENSE_LG_REVERSE and graph.grp_seg_ptr is not None and graph.dense_max_src > 0 and ops.FUSED_LG_BACKWARD
              and ops.DENSE_LG_BACKWARD)
     ln_inside = bool(gy is not None and dense and lib.alignn_egc_ln_fused_supported(H, m))  # (csrc/convln.hip)
+    ln_dst = bool(gy is not None and not dense and lib.alignn_egc_ln_dst_supported(H))  # (the bond graph: same file)
     GL = None
-    if gy is not None and not ln_inside:
+    if gy is not None and not ln_inside and not ln_dst:
         GL, e_red = _ln_bwd(gy, M, conv.bn_edges.weight, conv.bn_edges.bias, e_stats)
         grads.add(conv.bn_edges.bias, e_red[0])
         grads.add(conv.bn_edges.weight, e_red[1])
@@ -286,10 +287,26 @@ def conv_bwd(entry, gx: Dual, gy, grads: _Grads):
                                                ptr(graph.grp_seg_ptr), ptr(graph.grp_src_ptr), slabs, ptr(graph.seg_ptr),
                                                ptr(graph.seg_node), H, ptr(GM.p), ptr(GM.t), ptr(GP.p), ptr(GP.t),
                                                ptr(gb_part), ptr(GM.amax), ptr(GP.amax), stream()), "egc_dual_bwd_lg_dense")
+    elif ln_dst:  # bond graph: the LayerNorm reverse inside the destination-ordered half
+        slabs = lib.alignn_egc_ln_dst_slabs(n)
+        gb_part = _empty(slabs, H, like=x.p)
+        ln_part = _empty(slabs, 2, H, like=x.p)
+        check(lib.alignn_egc_dual_bwd_dst_ln(ptr(gy.p), ptr(gy.t), ptr(M.p), ptr(M.t), ptr(P.p), ptr(P.t), ptr(q1), ptr(q0), ptr(q1t),
+                                             ptr(q0t), ptr(conv.bn_edges.weight), ptr(conv.bn_edges.bias), ptr(e_stats),
+                                             ptr(graph.seg_ptr), ptr(graph.seg_node), ptr(graph.src), n, H, ptr(GM.p), ptr(GM.t),
+                                             ptr(GP.p), ptr(GP.t), ptr(gb_part), ptr(ln_part), ptr(GM.amax), ptr(GP.amax), stream()),
+              "egc_dual_bwd_dst_ln")
+        e_red = _empty(2, H, like=x.p)
+        check(lib.alignn_bn_bwd_finalize(ptr(ln_part), slabs, H, ptr(e_red), stream()), "ln_dual_finalize")
+        grads.add(conv.bn_edges.bias, e_red[0])
+        grads.add(conv.bn_edges.weight, e_red[1])
+        check(lib.alignn_egc_dual_bwd_src(ptr(GM.p), ptr(GM.t), ptr(M.p), ptr(M.t), ptr(q1), ptr(q1t), ptr(graph.out_ptr),
+                                          ptr(graph.out_slot), ptr(graph.dst), n, H, ptr(GP.p), ptr(GP.t), ptr(GP.amax),
+                                          stream()), "egc_dual_bwd_src")
     else:
         slabs = lib.alignn_dual_slabs(n)
         gb_part = _empty(slabs, H, like=x.p)
-    if not dense:
+    if not dense and not ln_dst:
         check(lib.alignn_egc_dual_bwd_dst(ptr(GL.p) if GL else None, ptr(GL.t) if GL else None, ptr(M.p), ptr(M.t), ptr(P.p),
                                           ptr(P.t), ptr(q1), ptr(q0), ptr(q1t), ptr(q0t), ptr(graph.seg_ptr),
                                           ptr(graph.seg_node), ptr(graph.src), n, H, ptr(GM.p), ptr(GM.t), ptr(GP.p),

@@ -1874,6 +1874,7 @@ class EdgeGatedConvFn(torch.autograd.Function):
         lg_blocks = graph.grp_seg_ptr is not None and FUSED_LG_BACKWARD
         dense = lg_blocks and DENSE_LG_BACKWARD and lib.alignn_egc_bwd_lg_dense_supported(graph.dense_max_src)
         ln_inside = bool(layer and dense and gy_out is not None and lib.alignn_egc_ln_fused_supported(H, m))  # (csrc/convln.hip)
+        ln_dst = bool(layer and not lg_blocks and gy_out is not None and lib.alignn_egc_ln_dst_supported(H))  # (the bond graph)
         fused_red = {}
 
         def edge_branch():
@@ -1882,7 +1883,7 @@ class EdgeGatedConvFn(torch.autograd.Function):
             e_red = None
             g_branch, e_stat_arg = gy_out, e_stat
             if gy_out is not None:
-                if ln_inside:
+                if ln_inside or ln_dst:
                     pass  # (LayerNorm backward inside the gate backward: gate_backward below)
                 elif layer:
                     # LayerNorm: finish the normalised-branch gradient here, hand it over as-is (e_stat = NULL)
@@ -1933,6 +1934,24 @@ class EdgeGatedConvFn(torch.autograd.Function):
                                                 ptr(graph.out_ptr), ptr(graph.out_slot), H, ptr(GM), ptr(GP), ptr(gb_part),
                                                 ptr(gm_amax), ptr(gp_amax), stream()),
                     "egc_bwd_lg_fused",
+                )
+            elif ln_dst:
+                gslabs = lib.alignn_egc_ln_dst_slabs(n)
+                gb_part = _empty(gslabs, H, like=x)
+                ln_part = _empty(gslabs, 2, H, like=x)
+                check(
+                    lib.alignn_egc_bwd_dst_ln(ptr(gy_out), ptr(M), ptr(P), ptr(gs1), ptr(gs0), ptr(e_gamma), ptr(e_beta), ptr(e_stat),
+                                              ptr(graph.seg_ptr), ptr(graph.seg_node), ptr(graph.src), n, H, ptr(GM), ptr(GP),
+                                              ptr(gb_part), ptr(ln_part), ptr(gm_amax), ptr(gp_amax), stream()),
+                    "egc_bwd_dst_ln",
+                )
+                red = _empty(2, H, like=x)
+                check(lib.alignn_bn_bwd_finalize(ptr(ln_part), gslabs, H, ptr(red), stream()), "ln_finalize")
+                fused_red["e"] = red
+                check(
+                    lib.alignn_egc_bwd_src(ptr(GM), ptr(M), ptr(gs1), ptr(graph.out_ptr), ptr(graph.out_slot),
+                                           ptr(graph.dst), n, H, ptr(GP), ptr(gp_amax), stream()),
+                    "egc_bwd_src",
                 )
             else:
                 gslabs = lib.alignn_egc_slabs(n)

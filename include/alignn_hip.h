@@ -483,6 +483,21 @@ int alignn_egc_bwd_lg_dense_ln(const float* GY, const float* M, const float* P, 
                                const int32_t* grp_seg_ptr, const int32_t* grp_src_ptr, int64_t n_groups, int max_group_src,
                                const int32_t* seg_ptr, const int32_t* seg_node, int H, float* GM, float* GP, float* gb_partial,
                                float* ln_partial, float* gm_amax, float* gp_amax, alignn_stream_t stream);
+/* The same for graphs without dense blocks (the bond graph g): the destination-ordered reverse halves with the LayerNorm adjoint
+ * of the edge output formed in the pass - alignn_ln_silu_bwd + alignn_egc_bwd_dst(e_stat = NULL), resp. alignn_ln_silu_dual_bwd +
+ * alignn_egc_dual_bwd_dst, as one launch; the source-ordered halves follow unchanged.  gb_partial [alignn_egc_ln_dst_slabs(n_seg)][H],
+ * ln_partial [...][2][H].  alignn_egc_ln_dst_supported(H): H % 4 == 0, H <= 256, ALIGNN_AMD_LN_FUSED != 0 (any row count). */
+int alignn_egc_ln_dst_slabs(int64_t n_seg);
+int alignn_egc_ln_dst_supported(int H);
+int alignn_egc_bwd_dst_ln(const float* GY, const float* M, const float* P, const float* GS1, const float* GS0, const float* gamma,
+                          const float* beta, const float* e_stat, const int32_t* seg_ptr, const int32_t* seg_node,
+                          const int32_t* src, int64_t n_seg, int H, float* GM, float* GP, float* gb_partial, float* ln_partial,
+                          float* gm_amax, float* gp_amax, alignn_stream_t stream);
+int alignn_egc_dual_bwd_dst_ln(const float* GY, const float* GYt, const float* M, const float* Mt, const float* P, const float* Pt,
+                               const float* q1, const float* q0, const float* q1t, const float* q0t, const float* gamma,
+                               const float* beta, const float* e_stat, const int32_t* seg_ptr, const int32_t* seg_node,
+                               const int32_t* src, int64_t n_seg, int H, float* GM, float* GMt, float* GP, float* GPt,
+                               float* gb_partial, float* ln_partial, float* gm_amax2, float* gp_amax2, alignn_stream_t stream);
 /* alignn_egc_gate_dual_fwd_tangent + the tangent of y' = y + silu(LN(m)) (alignn_ln_silu_dual_fwd with Y == NULL): Mt holds Ct
  * on entry and mt on exit, Yt = Rt + d[silu o LN](m) . mt; amax2[1] is raised to max|Yt| */
 int alignn_egc_gate_dual_tan_ln(const float* P, const float* Pt, const float* M, float* Mt, const int32_t* seg_ptr,
