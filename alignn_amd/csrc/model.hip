@@ -1352,13 +1352,18 @@ void dual_conv_bwd(Ctx& c, const DConvTape& t, const DAct& gx, const DAct& gy, D
     float* q0 = c.alloc((size_t)n * H);
     float* q1t = c.alloc((size_t)n * H);
     float* q0t = c.alloc((size_t)n * H);
+    // (the slab sums of the LayerNorm parameter gradients feed nothing on the way - they are issued with the weight gradients, on
+    // the side stream, instead of standing in the bond-row chain lane T waits for)
+    float *n_partial = nullptr, *e_partial = nullptr;
+    int n_slabs_fin = 0, e_slabs_fin = 0;
     {  // (ff2._ln_bwd + alignn_egc_node_dual_bwd in one pass)
         const int slabs_n = alignn_dual_slabs(n);
         float* partial = c.alloc((size_t)slabs_n * 2 * H);
         L(alignn_ln_silu_dual_bwd_node(gx.p, gx.t, H, t.xpre.p, t.xpre.t, H, p.n_gamma, p.n_beta, t.n_stats, GP.p + 3 * (size_t)H,
                                        GP.t + 3 * (size_t)H, 4 * H, partial, n, H, GP.amax_p, t.s0, t.hh, t.s0t, t.hht, q1, q0, q1t, q0t,
                                        main));
-        L(alignn_bn_bwd_finalize(partial, slabs_n, H, p.n_red, main));
+        n_partial = partial;
+        n_slabs_fin = slabs_n;
     }
     if (t.lane) c.sync(T, main);  // (the four adjoint rows per node; gy if the caller's stream wrote it)
     const bool dense = c.ff->dense_lg_reverse && g.grp_seg_ptr != nullptr && g.dense_max_src > 0;
@@ -1384,7 +1389,8 @@ void dual_conv_bwd(Ctx& c, const DConvTape& t, const DAct& gx, const DAct& gy, D
         L(alignn_egc_dual_bwd_lg_dense_ln(gy.p, gy.t, t.M.p, t.M.t, t.P.p, t.P.t, q1, q0, q1t, q0t, p.e_gamma, p.e_beta, t.e_stats, m,
                                           g.grp_seg_ptr, g.grp_src_ptr, slabs, g.seg_ptr, g.seg_node, H, GM.p, GM.t, GP.p, GP.t, gb_part,
                                           e_part, GM.amax_p, GP.amax_p, T));
-        L(alignn_bn_bwd_finalize(e_part, slabs, H, p.e_red, T));
+        e_partial = e_part;
+        e_slabs_fin = slabs;
     } else if (dense) {  // line graph: destination- and source-ordered halves in one pass over the dense blocks
         slabs = (int)g.n_groups;
         gb_part = c.alloc((size_t)slabs * H);
@@ -1396,7 +1402,8 @@ void dual_conv_bwd(Ctx& c, const DConvTape& t, const DAct& gx, const DAct& gy, D
         float* e_part = c.alloc((size_t)slabs * 2 * H);
         L(alignn_egc_dual_bwd_dst_ln(gy.p, gy.t, t.M.p, t.M.t, t.P.p, t.P.t, q1, q0, q1t, q0t, p.e_gamma, p.e_beta, t.e_stats, g.seg_ptr,
                                      g.seg_node, g.src, n, H, GM.p, GM.t, GP.p, GP.t, gb_part, e_part, GM.amax_p, GP.amax_p, T));
-        L(alignn_bn_bwd_finalize(e_part, slabs, H, p.e_red, T));
+        e_partial = e_part;
+        e_slabs_fin = slabs;
         L(alignn_egc_dual_bwd_src(GM.p, GM.t, t.M.p, t.M.t, q1, q1t, g.out_ptr, g.out_slot, g.dst, n, H, GP.p, GP.t, GP.amax_p, T));
     } else {
         slabs = alignn_dual_slabs(n);
@@ -1414,6 +1421,8 @@ void dual_conv_bwd(Ctx& c, const DConvTape& t, const DAct& gx, const DAct& gy, D
     g_x = dual_dgrad(c, GP, 4 * H, p.wcat, 4 * H, Kin, p.wcat_img_t, p.wcat_amax, &gx, n, main);
     g_y = dual_dgrad(c, GM, H, p.w_eg, H, Kin, p.weg_img_t, p.weg_amax, gy.p != nullptr ? &gy : nullptr, m, T);
     c.tmp_reset(sd);
+    if (n_partial != nullptr) L(alignn_bn_bwd_finalize(n_partial, n_slabs_fin, H, p.n_red, sd));
+    if (e_partial != nullptr) L(alignn_bn_bwd_finalize(e_partial, e_slabs_fin, H, p.e_red, sd));
     dual_wgrad(c, GP, 4 * H, t.x, Kin, p.g_wcat, n, 4 * H, Kin, sd);
     col_sum(c, GP.p, 4 * H, n, 4 * H, p.g_bcat, sd);
     dual_wgrad(c, GM, H, t.y, Kin, p.g_weg, m, H, Kin, sd);
