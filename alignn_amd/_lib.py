@@ -49,6 +49,11 @@ SIGNATURES = {
     "alignn_egc_gate_fwd_pre": (_i32, [_p, _p, _p, _p, _p, _i64, _i64, _i32, _p, _p, _p, _p, _p, _p]),
     "alignn_gemm_nt_x6_row_tiles": (_i32, [_i64, _i32, _i32]),
     "alignn_gemm_nt_f16x3_bnred": (_i32, [_p, _i64, _p, _p, _p, _p, _p, _i64, _p, _i64, _i64, _i32, _i32, _p, _i64, _p, _p, _p]),
+    "alignn_gemm_dgrad_wgrad_supported": (_i32, [_i64, _i32, _i32]),
+    "alignn_gemm_dgrad_wgrad_slabs": (_i32, [_i64]),
+    "alignn_gemm_dgrad_wgrad_workspace": (_sz, [_i64]),
+    "alignn_gemm_dgrad_wgrad_f16x3": (_i32, [_p, _i64, _p, _p, _i64, _p, _p, _p, _p, _i64, _p, _i64, _p, _i64, _p, _p, _p, _i64, _i64,
+                                              _p, _sz, _p]),
     "alignn_dual_slabs": (_i32, [_i64]),
     "alignn_ln_silu_dual_fwd": (_i32, [_p, _p, _i64, _p, _p, _i64, _p, _p, _f32, _p, _p, _i64, _p, _i64, _i32, _p, _p]),
     "alignn_ln_silu_dual_bwd": (_i32, [_p, _p, _i64, _p, _p, _i64, _p, _p, _p, _p, _p, _i64, _p, _i64, _i32, _p, _p]),

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libalignn_hip.so")
-SOURCES = ["norm.hip", "conv.hip", "gemm_f32.hip", "gemm_x6.hip", "embed.hip", "dual.hip", "knn.hip", "composite.hip", "model.hip", "stage.hip", "radius.hip", "angle.hip", "ff.hip", "convln.hip"]
+SOURCES = ["norm.hip", "conv.hip", "gemm_f32.hip", "gemm_x6.hip", "embed.hip", "dual.hip", "knn.hip", "composite.hip", "model.hip", "stage.hip", "radius.hip", "angle.hip", "ff.hip", "convln.hip", "gemm_dw.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # Per-file additions.  norm.hip / dual.hip (the LayerNorm kernels and their dual-number twins): no SLP vectorisation, i.e. no
 # packed-fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 with op_sel).  With them hipcc 7.2's code for

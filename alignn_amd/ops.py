@@ -642,6 +642,50 @@ def gemm_nt_f16x3_bnred(a, a_amax, ws, xn, nstat, bias=None, addend=None, out=No
     return out, red
 
 
+DGRAD_WGRAD_FUSED = _os.environ.get("ALIGNN_AMD_DW_FUSED", "1") != "0"  # csrc/gemm_dw.hip (tests / A-B runs flip it)
+DW_STATS = {"fused": 0}
+
+
+def dgrad_wgrad_applies(M, N, K, g_amax, y_amax):
+    """Would the backward of a ``[M, K] -> [M, N]`` Linear run as ONE pass over its output gradient (csrc/gemm_dw.hip)?"""
+    return bool(DGRAD_WGRAD_FUSED and F16X3 and g_amax is not None and y_amax is not None
+                and _lib.load().alignn_gemm_dgrad_wgrad_supported(M, N, K))
+
+
+def gemm_dgrad_wgrad(gm, g_amax, y, y_amax, wt, addend=None, xn=None, nstat=None, out=None):
+    """Backward of ``m = y W^T`` in one pass over ``gm`` = dL/dm [M, 256]: -> (g_y = gm W (+ addend), dW = gm^T y, red or None).
+    ``wt`` = ``split_f16x2(W, True)``.  With (xn, nstat) the BatchNorm-backward sums of g_y against the pre-activation ``xn`` come
+    along as ``red`` [2, 256] (see ``gemm_nt_f16x3_bnred``).  Replaces grad_input + grad_weight of the edge_gate Linear
+    (alignn/models/alignn.py:101), which each streamed ``gm`` from HBM."""
+    lib = _lib.load()
+    require_f32(gm, y, addend, xn, nstat)
+    M, N = gm.shape
+    K = y.shape[1]
+    if y.shape[0] != M or wt.n != K or wt.k != N:
+        raise ValueError(f"shape mismatch: gm {tuple(gm.shape)}, y {tuple(y.shape)}, W^T image [{wt.n},{wt.k}]")
+    if out is None:
+        out = _empty(M, K, like=gm)
+    dW = _empty(N, K, like=gm)
+    slabs = lib.alignn_gemm_dgrad_wgrad_slabs(M)
+    partial = _empty(2 * slabs, 2, K, like=gm) if xn is not None else None
+    nbytes = lib.alignn_gemm_dgrad_wgrad_workspace(M)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=gm.device)
+    label = ("dw_bnred" if xn is not None else "dw") + ("_addend" if addend is not None else "")
+    _timed(label, M, K, N, lambda: check(
+        lib.alignn_gemm_dgrad_wgrad_f16x3(ptr(gm), gm.stride(0), ptr(g_amax), ptr(y), y.stride(0), ptr(y_amax), ptr(wt.buf),
+                                          ptr(wt.amax), ptr(addend), addend.stride(0) if addend is not None else 0, ptr(out),
+                                          out.stride(0), ptr(xn), xn.stride(0) if xn is not None else 0, ptr(nstat), ptr(partial),
+                                          ptr(dW), dW.stride(0), M, ptr(ws), nbytes, stream()),
+        "gemm_dgrad_wgrad_f16x3",
+    ))
+    DW_STATS["fused"] += 1
+    red = None
+    if xn is not None:
+        red = _empty(2, K, like=gm)
+        check(lib.alignn_bn_bwd_finalize(ptr(partial), 2 * slabs, K, ptr(red), stream()), "bn_bwd_finalize")
+    return out, dW, red
+
+
 GATHER_FUSED = True  # EdgeGatedGraphConv: u_add_v folded into the edge-gate projection (tests flip it to compare: same bits)
 STATS_FUSED = True  # BatchNorm statistics from the epilogue of the projection that writes the tensor (tests flip it)
 

@@ -178,6 +178,25 @@ int alignn_gemm_nt_f16x3_bnred(const float* A, int64_t lda, const float* a_amax,
                                float* C, int64_t ldc, int64_t M, int N, int K, const float* Xn, int64_t ldxn,
                                const float* nstat, float* red_partial, alignn_stream_t stream);
 
+/* Input gradient AND weight gradient of a 256 -> 256 projection in one pass over the projection's output gradient G
+ * (csrc/gemm_dw.hip; replaces the pair alignn_gemm_nt_f16x3[_bnred] + alignn_gemm_tn, which each streamed G from HBM):
+ *     C[M,256]    = G[M,256] W[256,256] (+ addend)      autograd's grad_input of nn.Linear, alignn/models/alignn.py:101 (edge_gate)
+ *     dW[256,256] = G[M,256]^T Y[M,256]                 ... and its grad_weight; Y = the Linear's input
+ * f16x3 split products as alignn_gemm_nt_f16x3 (same bits for C): `Wt_split` = alignn_split_f16x2(W, transpose = 1) with its
+ * max|W| scalar, g_amax / y_amax = device scalars >= max|G|, max|Y|.  Optional, as alignn_gemm_nt_f16x3_bnred: Xn / nstat /
+ * red_partial - the BatchNorm-backward column sums of C against the pre-activation Xn, left as
+ * alignn_gemm_dgrad_wgrad_slabs(M) * 2 slabs of [2][256] for alignn_bn_bwd_finalize.  `workspace`:
+ * alignn_gemm_dgrad_wgrad_workspace(M) bytes (one 256 x 256 partial of dW per workgroup, summed in fp64 in slab order:
+ * bit-reproducible).  Shapes: N = K = 256, M >= 4096 (alignn_gemm_dgrad_wgrad_supported). */
+int alignn_gemm_dgrad_wgrad_supported(int64_t M, int N, int K);
+int alignn_gemm_dgrad_wgrad_slabs(int64_t M);
+size_t alignn_gemm_dgrad_wgrad_workspace(int64_t M);
+int alignn_gemm_dgrad_wgrad_f16x3(const float* G, int64_t ldg, const float* g_amax, const float* Y, int64_t ldy,
+                                  const float* y_amax, const void* Wt_split, const float* w_amax, const float* addend,
+                                  int64_t ldadd, float* C, int64_t ldc, const float* Xn, int64_t ldxn, const float* nstat,
+                                  float* red_partial, float* dW, int64_t lddw, int64_t M, void* workspace,
+                                  size_t workspace_bytes, alignn_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Column statistics / BatchNorm1d + SiLU (+ residual).
  * Replace nn.BatchNorm1d (training: batch statistics over ALL rows; eps 1e-5; momentum 0.1,
