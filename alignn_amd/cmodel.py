@@ -71,7 +71,7 @@ class ModelDesc(C.Structure):
         ("fc_W", _p), ("fc_b", _p), ("g_fc_W", _p), ("g_fc_b", _p),
         ("weight_descs", _p), ("weight_amax", _p), ("bump_ptrs", _p),
         ("n_weights", _i32), ("n_bump", _i32), ("x6_min_tiles", _i32), ("bd_segment_table", _i32),
-        ("angle_fused", _i32), ("norm", _i32), ("reuse_tape", _i32), ("pad_", _i32),
+        ("angle_fused", _i32), ("norm", _i32), ("reuse_tape", _i32), ("dw_fused", _i32),
         ("amax_min_rows", _i64), ("lane_min_rows", _i64), ("side_min_rows", _i64),
         ("lane_T", _p), ("side", _p), ("aux", _p)]
 
@@ -358,6 +358,7 @@ class Binding:
         d.aux = self.streams[2].cuda_stream if ops.FORK_DGRAD != "0" else None
         d.angle_fused = int(ops.ANGLE_FUSED)
         d.reuse_tape = int(REUSE_TAPE)
+        d.dw_fused = int(ops.DW_MIN_ROWS) if ops.DGRAD_WGRAD_FUSED else 0
         return capturing
 
     def batch_struct(self, b):
@@ -375,7 +376,7 @@ class Binding:
     def plan(self, mb):
         key = (mb.g.n, mb.g.m, mb.lg.m, mb.B, mb.lg.dense_max_src, bool(mb.lg.grp_seg_ptr), bool(mb.lg.seg_rank),
                bool(mb.g.seg_node), bool(self.desc.lane_T), bool(self.desc.side), bool(self.desc.aux),
-               self.desc.side_min_rows, self.desc.lane_min_rows, self.desc.angle_fused, self.desc.reuse_tape)
+               self.desc.side_min_rows, self.desc.lane_min_rows, self.desc.angle_fused, self.desc.reuse_tape, self.desc.dw_fused)
         hit = self.plans.get(key)
         if hit is None:
             fwd, tot = C.c_size_t(0), C.c_size_t(0)

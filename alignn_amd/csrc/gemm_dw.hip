@@ -35,6 +35,22 @@
 #include "common.h"
 #include "../../include/alignn_hip.h"
 
+// Ablation / tracing switches of tools/dw_ablate.py (never defined in the shipped build).  DW_ABL bits: 1 no W-stage DMA,
+// 2 no epilogue-stage DMA, 4 no input-gradient products, 8 no weight-gradient products, 16 no stores of C, 32 no Y-stage DMA,
+// 64 no G-row DMA (timing only: results are garbage).  DW_TRACE: wave 0 of every workgroup stamps the phases of its third tile.
+#ifndef DW_ABL
+#define DW_ABL 0
+#endif
+#ifndef DW_TRACE
+#define DW_TRACE 0
+#endif
+#ifndef DW_NS
+#define DW_NS 4
+#endif
+#if DW_TRACE
+__device__ unsigned long long dw_trace_buf[256 * 16];
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -45,7 +61,7 @@ typedef short s16x8 __attribute__((__vector_size__(8 * sizeof(short))));
 constexpr int H = 256;                   // features: N = K = 256
 constexpr int R = 64;                    // rows per tile
 constexpr int NW = 8, NTH = NW * 64;     // waves, threads
-constexpr int NS = 4;                    // ring slots
+constexpr int NS = DW_NS;                // ring slots
 constexpr int SLOT = 16384;
 constexpr int GBUF = 0;                                  // 64 rows x 1 KiB
 constexpr int RING = GBUF + R * 1024;                    // NS x 16 KiB
@@ -73,24 +89,33 @@ struct Sched {
     static constexpr int first(int s) { return s <= 20 ? s : 20 + (s - 20) * cons(20); }
     static constexpr int fill_lo(int s) { return (s == 0 ? first(STEPS - 1) - NSL : first(s - 1)) + NS; }
     static constexpr int fill_n(int s) { return s == 0 ? cons(STEPS - 1) : cons(s - 1); }
+    static constexpr int slot_ops(int n) {  // DMA instructions per wave for stage n (2; 0 under the ablation switches)
+        n = ((n % NSL) + NSL) % NSL;
+        if ((DW_ABL & 32) && n < 4) return 0;
+        if ((DW_ABL & 1) && n >= 4 && n < 20) return 0;
+        if ((DW_ABL & 2) && n >= 20) return 0;
+        return 2;
+    }
+    static constexpr int g_ops() { return (DW_ABL & 64) ? 0 : 8; }
+    static constexpr int store_ops() { return (DW_ABL & 16) ? 0 : STORES; }
     static constexpr Sched make() {
         Sched r{};
         constexpr int TILES = 3;
         int end_op[(TILES + 1) * NSL + NS] = {};
         int g_end[TILES + 2] = {};
         int ops = 0;
-        g_end[0] = (ops += 8);
+        g_end[0] = (ops += g_ops());
         r.prologue = fill_lo(0);
-        for (int n = 0; n < r.prologue; ++n) end_op[n] = (ops += 2);
+        for (int n = 0; n < r.prologue; ++n) end_op[n] = (ops += slot_ops(n));
         int w[TILES][STEPS] = {};
         int gw[TILES] = {};
         for (int t = 0; t < TILES; ++t) {
             gw[t] = ops - g_end[t];
             for (int s = 0; s < STEPS; ++s) {
                 if (cons(s) > 0) w[t][s] = ops - end_op[t * NSL + first(s) + cons(s) - 1];
-                for (int k = 0; k < fill_n(s); ++k) end_op[t * NSL + fill_lo(s) + k] = (ops += 2);
-                if (s == 20) g_end[t + 1] = (ops += 8);
-                if (s >= 20) ops += STORES;
+                for (int k = 0; k < fill_n(s); ++k) end_op[t * NSL + fill_lo(s) + k] = (ops += slot_ops(fill_lo(s) + k));
+                if (s == 20) g_end[t + 1] = (ops += g_ops());
+                if (s >= 20) ops += store_ops();
             }
         }
         for (int s = 0; s < STEPS; ++s) r.w0[s] = w[0][s], r.ws[s] = w[2][s];
@@ -234,12 +259,14 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         dma16(base + tr.m0 * ld, lane16 + (unsigned)(row * (int)ld) * 4u, dst);
     };
     auto issue_G = [&](const TileRef& tr) {
+        if constexpr (S::g_ops() == 0) return;
 #pragma unroll
         for (int i = 0; i < 8; ++i) row_dma(g.G, g.ldg, tr, wave * 8 + i, smem + GBUF + (wave * 8 + i) * 1024);
     };
     // stage n (0 .. NSL-1) of tile tr -> ring position n % NS
     auto issue_slot = [&](auto nc, const TileRef& tr) {
         constexpr int n = decltype(nc)::value;
+        if constexpr (S::slot_ops(n) == 0) return;
         unsigned char* dst = smem + RING + (n % NS) * SLOT;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -289,34 +316,117 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         static_for<0, kSched<NE>.prologue>([&](auto nc) { issue_slot(nc, tr0); });
     }
 
+#if DW_TRACE
+    unsigned long long tr_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tr_w[3] = {0, 0, 0}, tr_b[3] = {0, 0, 0};
+    int tr_j = 0;
+#define DW_STAMP(i) do { if (tr_j == 2) tr_t[i] = __builtin_readcyclecounter(); } while (0)
+#define DW_WAIT(ph, stmt) do { const unsigned long long t0_ = __builtin_readcyclecounter(); stmt; if (tr_j == 2) tr_w[ph] += __builtin_readcyclecounter() - t0_; } while (0)
+#define DW_BARRIER(ph) do { const unsigned long long t0_ = __builtin_readcyclecounter(); block_barrier(); if (tr_j == 2) tr_b[ph] += __builtin_readcyclecounter() - t0_; } while (0)
+#else
+#define DW_STAMP(i) do { } while (0)
+#define DW_WAIT(ph, stmt) stmt
+#define DW_BARRIER(ph) block_barrier()
+#endif
+    // (A two-team form - waves 4-7 multiplying one interval behind waves 0-3, so that on every SIMD one wave's matrix work runs
+    // beside its partner's LDS reads - was measured and removed: 739 vs 663 us for the plain variant, profiles/r06_dw_ablate_v2.txt.
+    // The products have to stand outside the team branches - a branch around MFMAs made hipcc copy the accumulators at the join,
+    // 1 700 registers spilled - which costs every wave a product of zeros at each phase boundary.)
+    f16x8 yah[2], yal[2], ybh[4], ybl[4];  // operands of a weight-gradient step (16 rows): G^T blocks, Y blocks
+    f16x8 wah, wal, wbh[2], wbl[2];        // operands of an input-gradient k-step
+    int ta_off[2], tb_off[2], a_base, b_off[2];
+    auto y_reads = [&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        int ta0 = ta_off[0], ta1 = ta_off[1], tb0 = tb_off[0], tb1 = tb_off[1];
+        asm volatile("" : "+v"(ta0), "+v"(ta1), "+v"(tb0), "+v"(tb1));  // (derive the 12 operand addresses here, not per tile)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const unsigned char* p0 = smem + (ta0 ^ (a << 6));
+            const unsigned char* p1 = smem + (ta1 ^ (a << 6));
+            yah[a] = tr_operand<s * SLOT>(p0, p1);
+            yal[a] = tr_operand<s * SLOT + 512>(p0, p1);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const unsigned char* p0 = smem + (tb0 ^ (b << 6));
+            const unsigned char* p1 = smem + (tb1 ^ (b << 6));
+            ybh[b] = tr_operand<(s % NS) * SLOT>(p0, p1);
+            ybl[b] = tr_operand<(s % NS) * SLOT + 512>(p0, p1);
+        }
+    };
+    auto y_mfma = [&]() {
+        if constexpr (!(DW_ABL & 8)) {
+#define DW_PASS(AA, BB)                                                                       \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int b = 0; b < 4; ++b) \
+        acc_dw[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AA[a], BB[b], acc_dw[a][b], 0, 0, 0);
+            DW_PASS(yal, ybh)
+            DW_PASS(yah, ybl)
+            DW_PASS(yah, ybh)
+#undef DW_PASS
+        } else {
+            acc_dw[0][0][0] += (float)yah[0][0] + (float)ybh[0][0] + (float)yal[1][0] + (float)ybl[3][0];  // (keeps the operand reads)
+        }
+    };
+    auto w_reads = [&](auto ktc) {
+        constexpr int kt = decltype(ktc)::value, s = kt + 4;
+        const unsigned char* slot = smem + RING + (s % NS) * SLOT;
+        int ab = a_base;
+        asm volatile("" : "+v"(ab));  // (one XOR per k-step instead of 16 addresses carried through the kernel)
+        const unsigned char* ap = smem + (ab ^ (kt << 5));
+        wah = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(ap));
+        wal = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(ap + 512));
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            wbh[b] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(slot + b_off[b]));
+            wbl[b] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(slot + b_off[b] + 8192));
+        }
+    };
+    auto w_mfma = [&]() {
+        if constexpr (!(DW_ABL & 4)) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc_c[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wah, wbh[b], acc_c[b], 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc_c[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wah, wbl[b], acc_c[b], 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc_c[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wal, wbh[b], acc_c[b], 0, 0, 0);
+        } else {
+            acc_c[0][0] += (float)wah[0] + (float)wal[0] + (float)wbh[0][0] + (float)wbl[1][0];  // (keeps the operand reads)
+        }
+    };
+
     // one tile; FIRST: the waits of the first tile count the prologue's operations instead of the previous tile's
     auto tile_body = [&](auto first_c) {
         constexpr bool FIRST = decltype(first_c)::value;
+        DW_STAMP(0);
         const TileRef cur = tile_ref(tile), nxt = tile_ref(tile + grid);
         const int64_t m0 = cur.m0;
         // ---- the tile's G rows: the wave slices the 8 rows it requested itself, in place
-        wait_vmcnt<FIRST ? kSched<NE>.g0 : kSched<NE>.gs>();
+        DW_WAIT(0, (wait_vmcnt<FIRST ? kSched<NE>.g0 : kSched<NE>.gs>()));
+        DW_STAMP(1);
         {
-            float4 v[8];
+            const int l = opaque_lane();  // (the eight swizzled write addresses are derived here, not carried through the kernel)
+            const int wslot = l >> 1, wsub = (l & 1) * 8;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const float4*>(smem + GBUF + (wave * 8 + i) * 1024 + lane * 16);
+            for (int i0 = 0; i0 < 8; i0 += 4) {  // (four rows at a time: 16 + 16 registers)
+                float4 v[4];
 #pragma unroll
-            for (int i = 0; i < 8; i += 2) {
-                uint4 hp, lp;
-                slice8(v[i], v[i + 1], sg, hp, lp);
-                const int ra = wave * 8 + i, rb = ra + 1;
-                unsigned char* pa = smem + GBUF + ra * 1024 + ((((lane >> 1) ^ swz(ra))) << 4) + (lane & 1) * 8;
-                unsigned char* pb = smem + GBUF + rb * 1024 + ((((lane >> 1) ^ swz(rb))) << 4) + (lane & 1) * 8;
-                *reinterpret_cast<uint2*>(pa) = make_uint2(hp.x, hp.y);
-                *reinterpret_cast<uint2*>(pa + 512) = make_uint2(lp.x, lp.y);
-                *reinterpret_cast<uint2*>(pb) = make_uint2(hp.z, hp.w);
-                *reinterpret_cast<uint2*>(pb + 512) = make_uint2(lp.z, lp.w);
+                for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const float4*>(smem + GBUF + (wave * 8 + i0 + i) * 1024 + l * 16);
+#pragma unroll
+                for (int i = 0; i < 4; i += 2) {
+                    uint4 hp, lp;
+                    slice8(v[i], v[i + 1], sg, hp, lp);
+                    const int ra = wave * 8 + i0 + i, rb = ra + 1;
+                    unsigned char* pa = smem + GBUF + ra * 1024 + ((wslot ^ swz(ra)) << 4) + wsub;
+                    unsigned char* pb = smem + GBUF + rb * 1024 + ((wslot ^ swz(rb)) << 4) + wsub;
+                    *reinterpret_cast<uint2*>(pa) = make_uint2(hp.x, hp.y);
+                    *reinterpret_cast<uint2*>(pa + 512) = make_uint2(lp.x, lp.y);
+                    *reinterpret_cast<uint2*>(pb) = make_uint2(hp.z, hp.w);
+                    *reinterpret_cast<uint2*>(pb + 512) = make_uint2(lp.z, lp.w);
+                }
             }
         }
         // ---- weight gradient: four stages of 16 rows of Y
         // transposing reads: lane (grp, i16): column 16 (grp & 1) + 4 (i16 & 3) .. + 3 of a 32-wide block, rows
         // 8 (grp >> 1) + 4 h + (i16 >> 2) of a 16-row stage
-        int ta_off[2], tb_off[2];
         {
             const int l = opaque_lane(), grp = l >> 4, i16 = l & 15;
 #pragma unroll
@@ -329,59 +439,33 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         static_for<0, 4>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
-            wait_vmcnt<FIRST ? kSched<NE>.w0[s] : kSched<NE>.ws[s]>();
+            if (s == 0) DW_STAMP(2);
+            DW_WAIT(0, (wait_vmcnt<FIRST ? kSched<NE>.w0[s] : kSched<NE>.ws[s]>()));
             unsigned char* slot = smem + RING + (s % NS) * SLOT;
             {  // slice the two rows this wave requested (rows past the end of the matrix: zeros)
                 const int ra = 2 * wave, rb = ra + 1;
-                float4 va = *reinterpret_cast<const float4*>(slot + ra * 1024 + lane * 16);
-                float4 vb = *reinterpret_cast<const float4*>(slot + rb * 1024 + lane * 16);
+                const int l = opaque_lane();
+                float4 va = *reinterpret_cast<const float4*>(slot + ra * 1024 + l * 16);
+                float4 vb = *reinterpret_cast<const float4*>(slot + rb * 1024 + l * 16);
                 const float ka = m0 + 16 * s + ra < g.M ? 1.0f : 0.0f, kb = m0 + 16 * s + rb < g.M ? 1.0f : 0.0f;
                 va = f4_scale(va, ka);
                 vb = f4_scale(vb, kb);
                 uint4 hp, lp;
                 slice8(va, vb, sy, hp, lp);
-                unsigned char* pa = slot + ra * 1024 + ((((lane >> 1) ^ swz(ra))) << 4) + (lane & 1) * 8;
-                unsigned char* pb = slot + rb * 1024 + ((((lane >> 1) ^ swz(rb))) << 4) + (lane & 1) * 8;
+                unsigned char* pa = slot + ra * 1024 + ((((l >> 1) ^ swz(ra))) << 4) + (l & 1) * 8;
+                unsigned char* pb = slot + rb * 1024 + ((((l >> 1) ^ swz(rb))) << 4) + (l & 1) * 8;
                 *reinterpret_cast<uint2*>(pa) = make_uint2(hp.x, hp.y);
                 *reinterpret_cast<uint2*>(pa + 512) = make_uint2(lp.x, lp.y);
                 *reinterpret_cast<uint2*>(pb) = make_uint2(hp.z, hp.w);
                 *reinterpret_cast<uint2*>(pb + 512) = make_uint2(lp.z, lp.w);
             }
-            block_barrier();  // the planes of this stage (and, s == 0, of G) are complete; step s-1's ring position is free
+            DW_BARRIER(0);  // the planes of this stage (and, s == 0, of G) are complete; step s-1's ring position is free
             static_for<0, S::fill_n(s)>([&](auto kc) {
                 constexpr int n = S::fill_lo(s) + decltype(kc)::value;
                 issue_slot(std::integral_constant<int, n % S::NSL>{}, n >= S::NSL ? nxt : cur);
             });
-            f16x8 ah[2], al[2];
-            int ta0 = ta_off[0], ta1 = ta_off[1], tb0 = tb_off[0], tb1 = tb_off[1];
-            asm volatile("" : "+v"(ta0), "+v"(ta1), "+v"(tb0), "+v"(tb1));  // (derive the 12 operand addresses here, not per tile)
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const unsigned char* p0 = smem + (ta0 ^ (a << 6));
-                const unsigned char* p1 = smem + (ta1 ^ (a << 6));
-                ah[a] = tr_operand<s * SLOT>(p0, p1);
-                al[a] = tr_operand<s * SLOT + 512>(p0, p1);
-            }
-            // the B operands in two halves (registers: 16 + 16 operand registers in flight beside 128 + 16 accumulators)
-#pragma unroll
-            for (int bb = 0; bb < 4; bb += 2) {
-                f16x8 bh[2], bl[2];
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const unsigned char* p0 = smem + (tb0 ^ ((bb + b) << 6));
-                    const unsigned char* p1 = smem + (tb1 ^ ((bb + b) << 6));
-                    bh[b] = tr_operand<(s % NS) * SLOT>(p0, p1);
-                    bl[b] = tr_operand<(s % NS) * SLOT + 512>(p0, p1);
-                }
-#define DW_PASS(AA, BB)                                                                       \
-    _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int b = 0; b < 2; ++b) \
-        acc_dw[a][bb + b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AA[a], BB[b], acc_dw[a][bb + b], 0, 0, 0);
-                DW_PASS(al, bh)
-                DW_PASS(ah, bl)
-                DW_PASS(ah, bh)
-                if (bb == 0) __builtin_amdgcn_sched_barrier(0);
-            }
-#undef DW_PASS
+            y_reads(sc);
+            y_mfma();
         });
         // ---- input gradient: 16 k-steps over the weight image
 #pragma unroll
@@ -390,7 +474,6 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int r = 0; r < 16; ++r) acc_c[b][r] = 0.0f;
         // A operand: row 32 wm + il of the planes, k-step kt: slot 2 kt + half -> (base ^ (kt << 5)); B operand (weight image:
         // [plane][n 256][2 chunks, swizzled][8]): n = 64 wn + 32 b + il
-        int a_base, b_off[2];
         {
             const int l = opaque_lane(), il = l & 31, half = l >> 5;
             const int a_row = 32 * wm + il;
@@ -403,34 +486,19 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         static_for<4, 20>([&](auto sc) {
             constexpr int s = decltype(sc)::value, kt = s - 4;
-            wait_vmcnt<FIRST ? kSched<NE>.w0[s] : kSched<NE>.ws[s]>();
-            block_barrier();
+            if (s == 4) DW_STAMP(3);
+            DW_WAIT(1, (wait_vmcnt<FIRST ? kSched<NE>.w0[s] : kSched<NE>.ws[s]>()));
+            DW_BARRIER(1);
             static_for<0, S::fill_n(s)>([&](auto kc) {
                 constexpr int n = S::fill_lo(s) + decltype(kc)::value;
                 issue_slot(std::integral_constant<int, n % S::NSL>{}, n >= S::NSL ? nxt : cur);
             });
-            const unsigned char* slot = smem + RING + (s % NS) * SLOT;
-            int ab = a_base;
-            asm volatile("" : "+v"(ab));  // (one XOR per k-step instead of 16 addresses carried through the kernel)
-            const unsigned char* ap = smem + (ab ^ (kt << 5));
-            const f16x8 ah = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(ap));
-            const f16x8 al = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(ap + 512));
-            f16x8 bh[2], bl[2];
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                bh[b] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(slot + b_off[b]));
-                bl[b] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(slot + b_off[b] + 8192));
-            }
-#pragma unroll
-            for (int b = 0; b < 2; ++b) acc_c[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[b], acc_c[b], 0, 0, 0);
-#pragma unroll
-            for (int b = 0; b < 2; ++b) acc_c[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[b], acc_c[b], 0, 0, 0);
-#pragma unroll
-            for (int b = 0; b < 2; ++b) acc_c[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[b], acc_c[b], 0, 0, 0);
+            w_reads(std::integral_constant<int, kt>{});
+            w_mfma();
         });
-        // ---- epilogue: four quarters of 8 rows per wave; operands of quarter q in the ring
-        // a quarter = 8 rows x 64 columns per wave through its patch; lane (prow, pc4) takes rows prow and prow + 4 at the columns
-        // 64 wn + pc4 .. + 3 - the SAME four columns in every round, so the BatchNorm-backward sums are 8 registers
+        // ---- epilogue: the operands of each step in the ring
+        // a step = 8 (4) rows x 64 columns per wave through its patch; lane (prow, pc4) takes rows prow (and prow + 4) at the
+        // columns 64 wn + pc4 .. + 3 - the SAME four columns in every round, so the BatchNorm-backward sums are 8 registers
         const int last_row = cur.last;
         float* c_t = g.C + m0 * g.ldc;
         const int le = opaque_lane();
@@ -440,8 +508,9 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             constexpr int s = decltype(sc)::value, e = s - 20;
             constexpr int QR = 32 / S::EST;                      // rows per wave and step: 8 (quarters) or 4 (eighths)
             constexpr int q = QR == 8 ? e : e / 2, hf = e & 1;   // accumulator registers 4 q .. 4 q + 3 (eighths: of half-wave hf)
-            if constexpr (NE > 0) wait_vmcnt<FIRST ? kSched<NE>.w0[s] : kSched<NE>.ws[s]>();
-            if constexpr (NE > 0 || e == 0) block_barrier();  // (e == 0: every wave has left the tile's planes)
+            if (e == 0) DW_STAMP(4);
+            if constexpr (NE > 0) DW_WAIT(2, (wait_vmcnt<FIRST ? kSched<NE>.w0[s] : kSched<NE>.ws[s]>()));
+            if constexpr (NE > 0 || e == 0) DW_BARRIER(2);  // (e == 0: every wave has left the tile's planes)
             static_for<0, S::fill_n(s)>([&](auto kc) {
                 constexpr int n = S::fill_lo(s) + decltype(kc)::value;
                 issue_slot(std::integral_constant<int, n % S::NSL>{}, n >= S::NSL ? nxt : cur);
@@ -474,14 +543,25 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     s0 = f4_add(s0, gz);
                     s1 = f4_fma(gz, xc, s1);
                 }
-                f4_sts<true>(c_t + (rowc * (int)g.ldc + ecol), v);
+                if (!(DW_ABL & 16) || v.x == 12345.678f) f4_sts<true>(c_t + (rowc * (int)g.ldc + ecol), v);
                 if constexpr (BNRED) __builtin_amdgcn_sched_barrier(0);  // (one row's transcendental chain at a time: registers)
             }
         });
+        DW_STAMP(5);
+#if DW_TRACE
+        ++tr_j;
+#endif
     };
     tile_body(std::true_type{});
     tile += grid;
     for (int j = 1; j < J; ++j, tile += grid) tile_body(std::false_type{});
+#if DW_TRACE
+    if (threadIdx.x == 0 && blockIdx.x < 256) {
+        unsigned long long* o = dw_trace_buf + blockIdx.x * 16;
+        for (int i = 0; i < 6; ++i) o[i] = tr_t[i];
+        for (int i = 0; i < 3; ++i) o[6 + i] = tr_w[i], o[9 + i] = tr_b[i];
+    }
+#endif
 
     wait_vmcnt<0>();  // (the phantom stages requested past the last tile: no DMA may outlive the workgroup's LDS allocation)
     // ---- the workgroup's dW partial -> slab blockIdx.x (accumulator layout: 32 consecutive columns per row and register)
@@ -549,6 +629,12 @@ inline int dw_grid(int64_t M) {
 inline bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
+
+#if DW_TRACE
+extern "C" int alignn_dw_trace_read(void* host, size_t bytes) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(dw_trace_buf), bytes < sizeof(dw_trace_buf) ? bytes : sizeof(dw_trace_buf));
+}
+#endif
 
 extern "C" {
 

@@ -670,6 +670,28 @@ float* edge_grad_buffer(Ctx& c, const ConvTape& t, int64_t m, int Kin) {
     return c.alloc((size_t)m * Kin);
 }
 
+// Backward of the edge-gate projection m = y W_eg^T (+ ...) in ONE pass over g_m (csrc/gemm_dw.hip) where its shape allows:
+// g_y = g_m W_eg (+ gy) with the BatchNorm-backward sums of `src`, and dW_eg = g_m^T y.  -> false: the caller takes the two
+// launches (dgrad + gemm_tn).  ops.gemm_dgrad_wgrad under the same rule (ops.dgrad_wgrad_applies).
+bool dgrad_wgrad(Ctx& c, const ConvTape& t, const float* GM, const float* gm_amax, const float* gy, float* g_y, int64_t m, int H,
+                 int Kin, hipStream_t st, const Act* src, bool* pre_red) {
+    const alignn_conv_params& p = *t.p;
+    if (c.d->dw_fused <= 0 || m < c.d->dw_fused || !c.param_grads || gm_amax == nullptr || t.y.amax == nullptr || p.weg_img_t == nullptr || Kin != H ||
+        !alignn_gemm_dgrad_wgrad_supported(m, H, Kin) || !x6_shape_ok(c, m, H, Kin, H))
+        return false;
+    const size_t nb = alignn_gemm_dgrad_wgrad_workspace(m);
+    c.tmp_reset(st);
+    float* ws = c.tmp(st, nb / 4);
+    const int slabs = 2 * alignn_gemm_dgrad_wgrad_slabs(m);
+    float* part = src != nullptr ? c.alloc((size_t)slabs * 2 * Kin) : nullptr;
+    L(alignn_gemm_dgrad_wgrad_f16x3(GM, H, gm_amax, t.y.p, Kin, t.y.amax, p.weg_img_t, p.weg_amax, gy, H, g_y, Kin,
+                                    src != nullptr ? src->xn : nullptr, Kin, src != nullptr ? src->stat : nullptr, part, p.g_weg, Kin, m,
+                                    ws, nb, st));
+    if (src != nullptr) bn_bwd_finalize_folded(c, part, slabs, Kin, src->red, st);
+    if (pre_red) *pre_red = src != nullptr;
+    return true;
+}
+
 // ops.MLPLayerFn.backward
 Grad mlp_bwd_ln(Ctx& c, const MlpTape& t, const Grad& gy, bool need_gx);
 Grad mlp_bwd(Ctx& c, const MlpTape& t, const Grad& gy, bool need_gx) {
@@ -779,7 +801,8 @@ void conv_bwd(Ctx& c, const ConvTape& t, const Grad& gx_out, const Grad* gy_out,
     }
     dgrad(c, GP, 4 * H, gp_amax, p.wcat, 4 * H, Kin, p.wcat_img_t, p.wcat_amax, gx_out.p, H, g_x.p, n, sx, nullptr, nullptr);
     const Act* src = (t.y.xn != nullptr && gm_amax != nullptr) ? &t.y : nullptr;
-    dgrad(c, GM, H, gm_amax, p.w_eg, H, Kin, p.weg_img_t, p.weg_amax, gy, H, g_y.p, m, T, src, &g_y.pre_red);
+    const bool dw = dgrad_wgrad(c, t, GM, gm_amax, gy, g_y.p, m, H, Kin, T, src, &g_y.pre_red);
+    if (!dw) dgrad(c, GM, H, gm_amax, p.w_eg, H, Kin, p.weg_img_t, p.weg_amax, gy, H, g_y.p, m, T, src, &g_y.pre_red);
     g_y.on_T = t.lane;
     g_x.on_T = false;
     if (sx != main) c.sync(main, sx);
@@ -792,7 +815,7 @@ void conv_bwd(Ctx& c, const ConvTape& t, const Grad& gx_out, const Grad* gy_out,
         c.sync(main, c.T);
     c.tmp_reset(sd);
     L(alignn_slab_sum(gb_part, gslabs, H, p.g_beg, sd));
-    gemm_tn(c, GM, H, gm_amax, t.y.p, Kin, t.y.amax, p.g_weg, m, H, Kin, sd);
+    if (!dw) gemm_tn(c, GM, H, gm_amax, t.y.p, Kin, t.y.amax, p.g_weg, m, H, Kin, sd);
     gemm_tn(c, GP, 4 * H, gp_amax, t.x.p, Kin, t.x.amax, p.g_wcat, n, 4 * H, Kin, sd);
     col_sum(c, GP, 4 * H, n, 4 * H, p.g_bcat, sd);
 }
@@ -903,7 +926,8 @@ void conv_bwd_ln(Ctx& c, const ConvTape& t, const Grad& gx_out, const Grad* gy_o
         }
         dgrad(c, GP, 4 * H, gp_amax, p.wcat, 4 * H, Kin, p.wcat_img_t, p.wcat_amax, gx_out.p, H, g_x.p, n, sx, nullptr, nullptr);
     }
-    dgrad(c, GM, H, gm_amax, p.w_eg, H, Kin, p.weg_img_t, p.weg_amax, gy, H, g_y.p, m, T, nullptr, nullptr);
+    const bool dw = dgrad_wgrad(c, t, GM, gm_amax, gy, g_y.p, m, H, Kin, T, nullptr, nullptr);
+    if (!dw) dgrad(c, GM, H, gm_amax, p.w_eg, H, Kin, p.weg_img_t, p.weg_amax, gy, H, g_y.p, m, T, nullptr, nullptr);
     g_y.on_T = t.lane;
     g_x.on_T = false;
     if (sx != main) c.sync(main, sx);
@@ -917,7 +941,7 @@ void conv_bwd_ln(Ctx& c, const ConvTape& t, const Grad& gx_out, const Grad* gy_o
         c.sync(main, c.T);
     c.tmp_reset(sd);
     L(alignn_slab_sum(gb_part, gslabs, H, p.g_beg, sd));
-    gemm_tn(c, GM, H, gm_amax, t.y.p, Kin, t.y.amax, p.g_weg, m, H, Kin, sd);
+    if (!dw) gemm_tn(c, GM, H, gm_amax, t.y.p, Kin, t.y.amax, p.g_weg, m, H, Kin, sd);
     gemm_tn(c, GP, 4 * H, gp_amax, t.x.p, Kin, t.x.amax, p.g_wcat, n, 4 * H, Kin, sd);
     col_sum(c, GP, 4 * H, n, 4 * H, p.g_bcat, sd);
 }

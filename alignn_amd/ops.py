@@ -643,12 +643,13 @@ def gemm_nt_f16x3_bnred(a, a_amax, ws, xn, nstat, bias=None, addend=None, out=No
 
 
 DGRAD_WGRAD_FUSED = _os.environ.get("ALIGNN_AMD_DW_FUSED", "1") != "0"  # csrc/gemm_dw.hip (tests / A-B runs flip it)
+DW_MIN_ROWS = int(_os.environ.get("ALIGNN_AMD_DW_MIN_ROWS", "65536"))  # edge rows from which a convolution takes it
 DW_STATS = {"fused": 0}
 
 
 def dgrad_wgrad_applies(M, N, K, g_amax, y_amax):
     """Would the backward of a ``[M, K] -> [M, N]`` Linear run as ONE pass over its output gradient (csrc/gemm_dw.hip)?"""
-    return bool(DGRAD_WGRAD_FUSED and F16X3 and g_amax is not None and y_amax is not None
+    return bool(DGRAD_WGRAD_FUSED and M >= DW_MIN_ROWS and F16X3 and g_amax is not None and y_amax is not None
                 and _lib.load().alignn_gemm_dgrad_wgrad_supported(M, N, K))
 
 
@@ -1783,6 +1784,8 @@ class EdgeGatedConvFn(torch.autograd.Function):
         H = w_eg.shape[0]
         if wcat.shape != (4 * H, Kin) or w_eg.shape[1] != Kin:
             return None
+        if ctx.param_grads and Kin == H and dgrad_wgrad_applies(m, H, Kin, True if _track(m) else None, ctx.y_amax):
+            return None  # (input + weight gradient of the edge-gate projection in one pass: the per-kernel path below)
         # kernel choices of the two input-gradient products, decided on shapes and on which maxima will exist (the arena
         # slots themselves are drawn only once the composite is certain to run)
         has_gp, has_gm = (True if _track(n) else None), (True if _track(m) else None)
@@ -2013,10 +2016,27 @@ class EdgeGatedConvFn(torch.autograd.Function):
                 )
             return GM, gb_part, gslabs
 
-        def edge_dgrad(GM):
-            return _dgrad_bnred(GM, w_eg, gy_out if (ctx.residual and gy_out is not None) else None, gm_amax, ctx.y_src)
+        fused_dw = {}
 
-        ev_d = None
+        def edge_dgrad(GM):
+            addend = gy_out if (ctx.residual and gy_out is not None) else None
+            Kin_ = y.shape[1]
+            if (ctx.param_grads and Kin_ == H and w_eg.shape == (H, Kin_) and GM.stride(0) % 4 == 0 and y.stride(0) % 4 == 0
+                    and dgrad_wgrad_applies(m, H, Kin_, gm_amax, ctx.y_amax) and _x6_shape_ok(_Shape(m, H), Kin_, H)):
+                # input gradient + weight gradient of the edge-gate projection in one pass over GM (csrc/gemm_dw.hip)
+                src = ctx.y_src if (ctx.y_src is not None and BNRED_FUSED and not layer and tuple(ctx.y_src[0].shape) == (m, Kin_)
+                                    and ctx.y_src[0].stride(0) % 4 == 0) else None
+                out, dW, red = gemm_dgrad_wgrad(GM, gm_amax, y, ctx.y_amax, split_f16x2(w_eg, True), addend,
+                                                src[0] if src is not None else None, src[1] if src is not None else None)
+                fused_dw["g_weg"] = dW
+                if src is not None:
+                    BNRED_STATS["fused"] += 1
+                    k = id(out)
+                    _PRE_RED[k] = (weakref.ref(out, lambda _r, k=k: _orphan_pre_red(k)), src[0], red)
+                return out
+            return _dgrad_bnred(GM, w_eg, addend, gm_amax, ctx.y_src)
+
+        ev_d = ev_w = None
         if ctx.lane:
             main, T = _lane_streams(x.device)
             ev_n = _event_after(main)  # gs1, gs0, the Ux block of GP and its amax are ready
@@ -2030,6 +2050,8 @@ class EdgeGatedConvFn(torch.autograd.Function):
                 e_red = fused_red.get("e", e_red)
                 ev_d = _event_after(T)
                 g_y = edge_dgrad(GM)
+                if "g_weg" in fused_dw:
+                    ev_w = _event_after(T)  # (the weight gradient came out of the same pass: the side stream hands it on)
             main.wait_event(ev_d)  # GP complete: the node input gradient below reads it
             # de_gamma / de_beta (e_red) and g_y come off lane T: they may stay there if y's producer takes its gradient
             # on lane T itself and nothing reads the two norm gradients before the end-of-backward join
@@ -2049,7 +2071,8 @@ class EdgeGatedConvFn(torch.autograd.Function):
         def _wgrads():
             g_beg_ = _empty(H, like=x)  # column sum of GM, accumulated inside the destination-order pass
             check(lib.alignn_slab_sum(ptr(gb_part), gslabs, H, ptr(g_beg_), stream()), "slab_sum")
-            return gemm_tn(GM, y, gm_amax, y_amax), g_beg_, gemm_tn(GP, x, gp_amax, x_amax), col_sum(GP)
+            g_weg_ = fused_dw["g_weg"] if "g_weg" in fused_dw else gemm_tn(GM, y, gm_amax, y_amax)
+            return g_weg_, g_beg_, gemm_tn(GP, x, gp_amax, x_amax), col_sum(GP)
 
         x_amax, y_amax = ctx.x_amax, ctx.y_amax
 
@@ -2062,7 +2085,7 @@ class EdgeGatedConvFn(torch.autograd.Function):
         if not ctx.param_grads:
             return (None, g_x, g_y) + (None,) * 24
         g_weg, g_beg, g_wcat, g_bcat = on_side_stream(_wgrads, [GM, y, GP, x, gb_part, gm_amax, gp_amax, x_amax, y_amax],
-                                                      ctx.leaves, wait=(ev_d,))
+                                                      ctx.leaves, wait=(ev_d, ev_w))
         dn_gamma, dn_beta = n_red[1], n_red[0]
         de_gamma = e_red[1] if e_red is not None else None
         de_beta = e_red[0] if e_red is not None else None

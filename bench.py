@@ -602,6 +602,8 @@ def main():
         # the kernel is doing well); bnred (+ the pre-activation read for the BatchNorm-backward sums) 3, with addend 4
         tables = 2.0 * raw.num_edges / raw.num_triplets
         rows_moved = {"plain": 2, "addend": 3, "gather": 2 + tables, "bnred": 3, "bnred_addend": 4, "stats": 2}
+        # csrc/gemm_dw.hip - input gradient AND weight gradient in one pass: read g_m and y, write g_y (+ residual, + pre-activation)
+        rows_moved.update({"dw": 3, "dw_addend": 4, "dw_bnred": 4, "dw_bnred_addend": 5})
         by = {}
         for (label, n_, k_, e0, e1) in ev:
             if n_ == H and k_ == H:

@@ -709,9 +709,12 @@ typedef struct alignn_model_desc {
     int32_t x6_min_tiles, bd_segment_table;    /* kernel-choice constants of the per-operator path (256, 1) */
     int32_t angle_fused, norm;                 /* 1: the angle embedding through alignn_angle_embed_fwd / _bwd where its shapes allow;
                                                   norm: 0 BatchNorm1d (ALIGNN), 1 LayerNorm (ALIGNNAtomWise: rm / rv / bump_ptrs unused) */
-    int32_t reuse_tape, pad_;                  /* 1: a convolution's edge input gradient is written over its own (then dead) gate
-                                                  pre-activation m - one T-row buffer per line-graph convolution less; the tape
-                                                  does not survive the backward (no second backward of a retained graph) */
+    int32_t reuse_tape, dw_fused;              /* reuse_tape 1: a convolution's edge input gradient is written over its own (then dead)
+                                                  gate pre-activation m - one T-row buffer per line-graph convolution less; the tape
+                                                  does not survive the backward (no second backward of a retained graph).
+                                                  dw_fused n > 0: the edge-gate projection's input gradient and weight gradient in one
+                                                  pass over g_m (csrc/gemm_dw.hip) for convolutions of >= n edge rows where
+                                                  alignn_gemm_dgrad_wgrad_supported; 0: always the two launches */
     int64_t amax_min_rows, lane_min_rows, side_min_rows; /* 4096; rows from which a kernel goes to lane_T / side */
     alignn_stream_t lane_T, side, aux;
 } alignn_model_desc;
