@@ -238,11 +238,19 @@ class Binding:
     # ---- the optimizer's packed gradient buffer as the destination of the backward (alignn_amd.optim.FlatAdamW registers
     # itself as the model's gradient sink): every block whose parameters sit adjacent and in order in that buffer is
     # written THERE - no 124-view gather in step(), and the data-parallel all-reduce runs on the buffer the backward wrote
-    def sink_plan(self):
-        """-> (per grad field: device address inside the sink's buffer or None, per parameter: its slot view or None) or None"""
+    def sink(self):
+        """The optimizer registered as this model's gradient sink (alignn_amd.optim.FlatAdamW), or None"""
         ref = model_cache(self.model).get("grad_sink")
-        sink = ref() if ref is not None else None
-        if sink is None or getattr(sink, "_inner", None) is None:
+        return ref() if ref is not None else None
+
+    def sink_plan(self):
+        """-> (per grad field: device address inside the sink's buffer or None, per parameter: its slot view or None) or None.
+        None also while an earlier backward of this step already wrote into the buffer (``sink.sink_in_flight``, cleared by the
+        optimizer's ``step()`` / ``zero_grad()``): a second autograd node of the same graph - ``(l(model(b1)) + l(model(b2)))
+        .backward()`` - runs before AccumulateGrad has filled any ``p.grad``, would find them all None and overwrite the first
+        node's gradients in place; it takes its private buffer instead and autograd adds the two."""
+        sink = self.sink()
+        if sink is None or getattr(sink, "_inner", None) is None or getattr(sink, "sink_in_flight", False):
             return None
         key = (id(sink), id(sink._grad_all), sink._grad_all.data_ptr())
         if self._sink_key != key:
@@ -494,6 +502,8 @@ class _ModelFn(torch.autograd.Function):
             dest = plan[0][k] if plan is not None else None
             setattr(owner, field, dest if dest is not None else base + 4 * off)
         STATS["sink"] = STATS.get("sink", 0) + (plan is not None)
+        if plan is not None:
+            bind.sink().sink_in_flight = True
         bind.set_mode()
         t0 = time.perf_counter() if TIMING is not None else 0.0
         try:
@@ -785,6 +795,8 @@ class _FFFn(torch.autograd.Function):
             dest = plan[0][k] if plan is not None else None
             setattr(owner, field, dest if dest is not None else base + 4 * off)
         STATS["ff_sink"] = STATS.get("ff_sink", 0) + (plan is not None)
+        if plan is not None:
+            bind.sink().sink_in_flight = True
         bind.set_mode()
         try:
             _lib.check(lib.alignn_ff_grad(bind.desc_addr, C.addressof(ctx.mb), C.addressof(ctx.ffd), ctx.arena.data_ptr(),

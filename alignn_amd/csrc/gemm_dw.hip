@@ -72,21 +72,22 @@ constexpr int LDS_BYTES = NSTAT + 4 * H * 4;             // 152 576 B
 static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
 
 // ---- the order of one wave's vector-memory operations, simulated at compile time -------------------------------------
-// Steps of a tile: 0-3 the Y stages, 4-19 the W stages, then EST epilogue steps of ONE stage each (NE == 1: four quarters of
-// 16 rows of the one operand; NE == 2: eight eighths of 8 rows of both operands, so that a step never needs two stages - the
-// ring would then prefetch only one step ahead; NE == 0: four quarters, no stage).  At the barrier of step s the wave requests
-// the stage that takes the ring position step s-1 released (two DMA instructions per stage and wave), at step 20 also the next
-// tile's G rows (8 instructions), and every epilogue step issues its stores (64 / EST rows: 2 or 1 per lane).  wait[s] = the
-// number of operations issued after the last DMA of the stage step s consumes = the immediate of its s_waitcnt vmcnt.
+// Steps of a tile: 0-3 the Y stages (one ring slot each), 4-11 PAIRS of W stages (two slots each: two k-steps per barrier),
+// then EST epilogue steps of ONE stage each (NE == 1: four quarters of the one operand; NE == 2: eight eighths of both operands,
+// so that a step never needs two stages - the ring would then prefetch only one step ahead; NE == 0: four quarters, no stage).
+// After the barrier of step s the wave requests the stages that take the ring positions step s-1 released (two DMA
+// instructions per stage and wave), at the first epilogue step also the next tile's G rows (8 instructions), and every epilogue
+// step issues its stores (2 or 1 per lane).  wait[s] = the number of operations issued after the last DMA of the last stage
+// step s consumes = the immediate of its s_waitcnt vmcnt.
 template <int NE>
 struct Sched {
-    static constexpr int EST = NE == 2 ? 8 : 4, STEPS = 20 + EST, NSL = 20 + (NE > 0 ? EST : 0), STORES = 8 / EST;
+    static constexpr int EST = NE == 2 ? 8 : 4, E0 = 12, STEPS = E0 + EST, NSL = 20 + (NE > 0 ? EST : 0), STORES = 8 / EST;
     static_assert(NSL % NS == 0, "ring positions are compile-time constants");
     int w0[STEPS], ws[STEPS];  // first tile / every later tile
     int g0, gs;                // ... for the tile's G rows
     int prologue;              // stages requested before the first tile
-    static constexpr int cons(int s) { return s < 20 ? 1 : (NE > 0 ? 1 : 0); }
-    static constexpr int first(int s) { return s <= 20 ? s : 20 + (s - 20) * cons(20); }
+    static constexpr int cons(int s) { return s < 4 ? 1 : s < E0 ? 2 : (NE > 0 ? 1 : 0); }
+    static constexpr int first(int s) { return s <= 4 ? s : s <= E0 ? 4 + 2 * (s - 4) : 20 + (s - E0) * cons(E0); }
     static constexpr int fill_lo(int s) { return (s == 0 ? first(STEPS - 1) - NSL : first(s - 1)) + NS; }
     static constexpr int fill_n(int s) { return s == 0 ? cons(STEPS - 1) : cons(s - 1); }
     static constexpr int slot_ops(int n) {  // DMA instructions per wave for stage n (2; 0 under the ablation switches)
@@ -114,8 +115,8 @@ struct Sched {
             for (int s = 0; s < STEPS; ++s) {
                 if (cons(s) > 0) w[t][s] = ops - end_op[t * NSL + first(s) + cons(s) - 1];
                 for (int k = 0; k < fill_n(s); ++k) end_op[t * NSL + fill_lo(s) + k] = (ops += slot_ops(fill_lo(s) + k));
-                if (s == 20) g_end[t + 1] = (ops += g_ops());
-                if (s >= 20) ops += store_ops();
+                if (s == E0) g_end[t + 1] = (ops += g_ops());
+                if (s >= E0) ops += store_ops();
             }
         }
         for (int s = 0; s < STEPS; ++s) r.w0[s] = w[0][s], r.ws[s] = w[2][s];
@@ -258,6 +259,11 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         row = row < tr.last ? row : tr.last;
         dma16(base + tr.m0 * ld, lane16 + (unsigned)(row * (int)ld) * 4u, dst);
     };
+    // ... one row per 16 lanes: lane-dependent row (clamped like row_dma's), byte offset col_b inside the row
+    auto lane_dma = [&](const float* base, int64_t ld, const TileRef& tr, int row, unsigned col_b, unsigned char* dst) {
+        row = row < tr.last ? row : tr.last;
+        dma16(base + tr.m0 * ld, col_b + (unsigned)(row * (int)ld) * 4u, dst);
+    };
     auto issue_G = [&](const TileRef& tr) {
         if constexpr (S::g_ops() == 0) return;
 #pragma unroll
@@ -275,20 +281,26 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 row_dma(g.Y, g.ldy, tr, 16 * n + lr, dst + lr * 1024);
             } else if constexpr (n < 20) {
                 dma16(g.Wt + (n - 4) * SLOT, lane16 + (unsigned)lr * 1024u, dst + lr * 1024);
-            } else if constexpr (NE == 1) {  // quarter q: rows 8 q .. + 7 and 32 + 8 q .. + 7 of the one operand
-                constexpr int q = n - 20;
-                const int trow = lr < 8 ? 8 * q + lr : 32 + 8 * q + (lr - 8);
-                if constexpr (HAS_ADD)
-                    row_dma(g.addend, g.ldadd, tr, trow, dst + lr * 1024);
-                else
-                    row_dma(g.xn, g.ldxn, tr, trow, dst + lr * 1024);
-            } else {  // eighth e: rows 4 e .. + 3 and 32 + 4 e .. + 3, [addend 1 KiB | xn 1 KiB] per row; this wave: local row `wave`
+            } else {
+                // epilogue stages: every wave requests exactly the rows it will read itself, into ITS 2 KiB of the slot - no
+                // barrier in the epilogue (the waves drift apart there: stores, transcendentals), and a refill never touches
+                // bytes another wave still reads.  One instruction = 4 rows x 256 B (lane: row l >> 4, 16-byte chunk l & 15).
                 constexpr int e = n - 20;
-                const int trow = wave < 4 ? 4 * e + wave : 32 + 4 * e + (wave - 4);
-                if (i == 0)
-                    row_dma(g.addend, g.ldadd, tr, trow, dst + wave * 2048);
-                else
-                    row_dma(g.xn, g.ldxn, tr, trow, dst + wave * 2048 + 1024);
+                const int r4 = lane >> 4;
+                const unsigned col_b = (unsigned)(64 * (wave & 3)) * 4u + (unsigned)(lane & 15) * 16u;
+                if constexpr (NE == 1) {  // quarter e: rows 32 wm + 8 e + 4 i + r4 of the one operand
+                    const int trow = 32 * (wave >> 2) + 8 * e + 4 * i + r4;
+                    if constexpr (HAS_ADD)
+                        lane_dma(g.addend, g.ldadd, tr, trow, col_b, dst + wave * 2048 + i * 1024);
+                    else
+                        lane_dma(g.xn, g.ldxn, tr, trow, col_b, dst + wave * 2048 + i * 1024);
+                } else {  // eighth e: rows 32 wm + 4 e + r4; i = 0 the addend, i = 1 the pre-activation
+                    const int trow = 32 * (wave >> 2) + 4 * e + r4;
+                    if (i == 0)
+                        lane_dma(g.addend, g.ldadd, tr, trow, col_b, dst + wave * 2048);
+                    else
+                        lane_dma(g.xn, g.ldxn, tr, trow, col_b, dst + wave * 2048 + 1024);
+                }
             }
         }
     };
@@ -484,8 +496,8 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 b_off[b] = n * 32 + ((half ^ ((n >> 3) & 1)) << 4);
             }
         }
-        static_for<4, 20>([&](auto sc) {
-            constexpr int s = decltype(sc)::value, kt = s - 4;
+        static_for<4, S::E0>([&](auto sc) {
+            constexpr int s = decltype(sc)::value, kt0 = 2 * (s - 4);  // two k-steps per barrier
             if (s == 4) DW_STAMP(3);
             DW_WAIT(1, (wait_vmcnt<FIRST ? kSched<NE>.w0[s] : kSched<NE>.ws[s]>()));
             DW_BARRIER(1);
@@ -493,7 +505,9 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 constexpr int n = S::fill_lo(s) + decltype(kc)::value;
                 issue_slot(std::integral_constant<int, n % S::NSL>{}, n >= S::NSL ? nxt : cur);
             });
-            w_reads(std::integral_constant<int, kt>{});
+            w_reads(std::integral_constant<int, kt0>{});
+            w_mfma();
+            w_reads(std::integral_constant<int, kt0 + 1>{});
             w_mfma();
         });
         // ---- epilogue: the operands of each step in the ring
@@ -504,19 +518,20 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int le = opaque_lane();
         const int prow_e = le >> 4, pc4 = (le & 15) * 4, ecol = 64 * wn + pc4, il = le & 31, half = le >> 5;
         float* patch = reinterpret_cast<float*>(smem + PATCH + wave * PATCH_W);
-        static_for<20, S::STEPS>([&](auto sc) {
-            constexpr int s = decltype(sc)::value, e = s - 20;
+        static_for<S::E0, S::STEPS>([&](auto sc) {
+            constexpr int s = decltype(sc)::value, e = s - S::E0;
             constexpr int QR = 32 / S::EST;                      // rows per wave and step: 8 (quarters) or 4 (eighths)
             constexpr int q = QR == 8 ? e : e / 2, hf = e & 1;   // accumulator registers 4 q .. 4 q + 3 (eighths: of half-wave hf)
+            constexpr int n_slot = 20 + e;                       // this step's stage (NE > 0)
             if (e == 0) DW_STAMP(4);
             if constexpr (NE > 0) DW_WAIT(2, (wait_vmcnt<FIRST ? kSched<NE>.w0[s] : kSched<NE>.ws[s]>()));
-            if constexpr (NE > 0 || e == 0) DW_BARRIER(2);  // (e == 0: every wave has left the tile's planes)
+            if constexpr (e == 0) DW_BARRIER(2);  // every wave has left the tile's planes and the last W stages
             static_for<0, S::fill_n(s)>([&](auto kc) {
                 constexpr int n = S::fill_lo(s) + decltype(kc)::value;
                 issue_slot(std::integral_constant<int, n % S::NSL>{}, n >= S::NSL ? nxt : cur);
             });
             if constexpr (e == 0) issue_G(nxt);
-            const unsigned char* slot = smem + RING + (s % NS) * SLOT;
+            const unsigned char* mine = smem + RING + (n_slot % NS) * SLOT + wave * 2048;  // this wave's rows of the stage
             // (eighths: the other half-wave's registers go to the patch's unused rows 4 .. 7 - no branch around the writes)
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
@@ -530,11 +545,11 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const int rowc = rrel < last_row ? rrel : last_row;
                 float4 v = f4_ld(patch + pr * PLD + pc4);
                 v = f4_scale(f4_scale(v, inv_sg), inv_sw);
-                // the stage's row of this lane: quarters [16 rows][1 KiB], eighths [8 rows][addend 1 KiB | xn 1 KiB]
-                const int e_off = NE == 2 ? (4 * wm + pr) * 2048 + ecol * 4 : (8 * wm + pr) * 1024 + ecol * 4;
-                if constexpr (HAS_ADD) v = f4_add(v, *reinterpret_cast<const float4*>(slot + e_off));
+                // the wave's part of the stage: quarters [2 x 4 rows][256 B] of the one operand, eighths [addend | xn][4 rows][256 B]
+                const int e_off = (NE == 2 ? prow_e : pr) * 256 + pc4 * 4;
+                if constexpr (HAS_ADD) v = f4_add(v, *reinterpret_cast<const float4*>(mine + e_off));
                 if constexpr (BNRED) {
-                    const float4 xv = *reinterpret_cast<const float4*>(slot + e_off + (NE == 2 ? 1024 : 0));
+                    const float4 xv = *reinterpret_cast<const float4*>(mine + e_off + (NE == 2 ? 1024 : 0));
                     const float4 xc = f4_sub(xv, *reinterpret_cast<const float4*>(smem + NSTAT + ecol * 4));
                     const float4 z = f4_fma(xc, *reinterpret_cast<const float4*>(smem + NSTAT + 2 * H * 4 + ecol * 4),
                                             *reinterpret_cast<const float4*>(smem + NSTAT + 3 * H * 4 + ecol * 4));

@@ -62,6 +62,25 @@ _SIDE = {"enabled": _os.environ.get("ALIGNN_AMD_SIDE_STREAM", "1") != "0", "stre
 GRAD_READ_AFTER_BACKWARD = "_alignn_grad_read_after_backward"
 
 
+# Forward passes that used a leaf since the last end-of-backward join.  Two autograd nodes of ONE backward that share a
+# parameter - (l(model(b1)) + l(model(b2))).backward() - make the engine ADD their gradients as soon as the second one
+# arrives, on the main stream: a gradient still being computed on the side stream would be read early (found in round 6:
+# 0.3 % of the gradient scale off, tools history in DESIGN section 4b).  A leaf seen by more than one forward joins at once.
+_FWD_USES = {}
+
+
+def _note_forward(leaves):
+    # (called from autograd.Function.forward, where grad mode is always off: count every forward that can have a backward)
+    for p in leaves:
+        if p is not None and p.requires_grad:
+            _FWD_USES[id(p)] = _FWD_USES.get(id(p), 0) + 1
+
+
+def _clear_forward_uses():
+    _FWD_USES.clear()
+    _SIDE["uses_armed"] = False
+
+
 def _join_side_streams():
     _SIDE["armed"] = False
     for dev, side in _SIDE["streams"].items():
@@ -79,13 +98,19 @@ def _deferred_join_is_safe(params):
     to (gradient accumulation, ``zero_grad(set_to_none=False)``), tensor / post-accumulate hooks, ``create_graph``
     (clone), a non-leaf weight (more autograd nodes downstream), DistributedDataParallel's reducer hooks - reads them
     on the main stream right away, so then the main stream joins the side stream before the node returns."""
+    if _FWD_USES and not _SIDE.get("uses_armed"):  # (forget the forward passes of this step when its backward is over)
+        _SIDE["uses_armed"] = True
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_clear_forward_uses)
+        except RuntimeError:  # not inside backward()
+            _clear_forward_uses()
     if torch.is_grad_enabled():
         return False
     ddp_possible = torch.distributed.is_available() and torch.distributed.is_initialized()
     for p in params:
         if p is None:
             continue
-        if (not p.is_leaf or p.grad is not None or p._backward_hooks
+        if (not p.is_leaf or p.grad is not None or p._backward_hooks or _FWD_USES.get(id(p), 0) > 1
                 or getattr(p, "_post_accumulate_grad_hooks", None)
                 or (ddp_possible and not getattr(p, GRAD_READ_AFTER_BACKWARD, False))):
             return False
@@ -1229,6 +1254,7 @@ class MLPLayerFn(torch.autograd.Function):
         ctx.norm = norm
         ctx.param_grads = _PARAM_GRADS["on"]
         ctx.wb = (w, b)  # the leaves whose gradients come off the side stream (see _deferred_join_is_safe)
+        _note_forward(ctx.wb)
         if FORWARD_TAPE is not None and norm == "layer":
             FORWARD_TAPE[w.data_ptr()] = ("mlp", x, pre, y)
         return y
@@ -1570,6 +1596,7 @@ class EdgeGatedConvFn(torch.autograd.Function):
                                                       e_gamma, e_beta, e_rm, e_rv, residual, need_y)
             if done is not None:
                 ctx.leaves = (w_sg, w_dg, w_du, w_su, b_sg, b_dg, b_du, b_su, w_eg, b_eg)
+                _note_forward(ctx.leaves)
                 return done
         slabs = lib.alignn_egc_slabs(n)
         _main_reads(x, None if lane is not None else y)
@@ -1696,6 +1723,7 @@ class EdgeGatedConvFn(torch.autograd.Function):
         ctx.norm = norm
         ctx.param_grads = _PARAM_GRADS["on"]
         ctx.leaves = (w_sg, w_dg, w_du, w_su, b_sg, b_dg, b_du, b_su, w_eg, b_eg)
+        _note_forward(ctx.leaves)
         ctx.save_for_backward(x, y, wcat, w_eg, P, M, xpre, s0, hh, n_stat, e_stat, n_gamma, e_gamma, n_beta, e_beta)
         if FORWARD_TAPE is not None and norm == "layer":
             FORWARD_TAPE[w_eg.data_ptr()] = ("conv", x, y, P, M, xpre, s0, hh, x_out, y_out, e_stat)

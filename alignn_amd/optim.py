@@ -94,6 +94,7 @@ class FlatAdamW(torch.optim.Optimizer):
                 for p in g["params"]:
                     setattr(p, GRAD_READ_AFTER_BACKWARD, True)
         self._flat_all = self._grad_all = None
+        self.sink_in_flight = False  # a backward of the current step has written into _grad_all in place (cmodel.Binding.sink_plan)
         self._flat: List[Optional[torch.nn.Parameter]] = []  # per group (None: no live parameter in it)
         self._live: List[List[torch.nn.Parameter]] = []
         self._live_idx: List[List[int]] = []
@@ -287,7 +288,12 @@ class FlatAdamW(torch.optim.Optimizer):
         if self.average_gradients:
             self._all_reduce()
         self._inner.step()
+        self.sink_in_flight = False  # (the packed gradient buffer may be written in place by the next backward again)
         return loss
+
+    def zero_grad(self, set_to_none: bool = True):
+        super().zero_grad(set_to_none=set_to_none)
+        self.sink_in_flight = False
 
     def _all_reduce(self):
         import torch.distributed as dist

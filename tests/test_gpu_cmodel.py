@@ -240,6 +240,58 @@ def test_flat_adamw_rehoming_is_followed():
             assert torch.equal(p.grad, once[k] + once[k]), k
 
 
+def test_one_backward_over_two_forwards_with_flat_adamw_adds_the_two_gradients():
+    """``(l(model(b1)) + l(model(b2))).backward()`` puts two autograd nodes of the model into one graph.  Both
+    run before AccumulateGrad has filled any ``p.grad``; the second must not overwrite the first one's gradients in the
+    optimizer's packed buffer (it takes its private buffer while ``sink_in_flight`` is set) - p.grad = G1 + G2, as with the
+    per-operator path and as without FlatAdamW."""
+    from alignn_amd.optim import FlatAdamW, group_decay
+
+    b1 = GraphBatch.from_raw(make_batch(10, 36, seed0=15), device=DEV)
+    b2 = GraphBatch.from_raw(make_batch(10, 36, seed0=16), device=DEV)
+    t1 = torch.randn(10, generator=torch.Generator().manual_seed(2)).to(DEV)
+    t2 = torch.randn(10, generator=torch.Generator().manual_seed(3)).to(DEV)
+    l1 = torch.nn.functional.l1_loss
+
+    def run(use_c):
+        prev = cmodel.ENABLED
+        cmodel.ENABLED = use_c
+        try:
+            m = _mk(4)
+            opt = FlatAdamW(group_decay(m), lr=1e-3, weight_decay=1e-2, module=m)
+            for _ in range(2):  # (the sink exists from the second step on)
+                opt.zero_grad(set_to_none=True)
+                l1(m(b1), t1).backward()
+                opt.step()
+            for k in cmodel.STATS:
+                cmodel.STATS[k] = 0
+            opt.zero_grad(set_to_none=True)
+            m.eval()  # (frozen running statistics: the two forwards do not feed each other)
+            m.train()
+            o1, o2 = m(b1), m(b2)
+            (l1(o1, t1) + l1(o2, t2)).backward()
+            torch.cuda.synchronize()
+            both = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+            stats = dict(cmodel.STATS)
+            opt.step()  # (and the step after it takes the in-place route again)
+            opt.zero_grad(set_to_none=True)
+            l1(m(b1), t1).backward()
+            return both, stats, dict(cmodel.STATS)
+        finally:
+            cmodel.ENABLED = prev
+
+    got, stats, after = run(True)
+    ref, _, _ = run(False)
+    assert stats["bwd"] == 2 and stats["sink"] == 1, stats  # one node wrote in place, the other into its own buffer
+    assert after["sink"] == 2, after
+    assert got.keys() == ref.keys()
+    # (the per-operator path used to be the WRONG one here: its weight gradients stayed on the side stream until the end of
+    # backward while the engine added the two nodes' gradients on the main stream - ops._FWD_USES, found with this test)
+    gscale = max(float(v.abs().max()) for v in ref.values())
+    for k in got:
+        assert float((got[k] - ref[k]).abs().max()) <= 2e-6 * gscale, k  # (the engine adds the two nodes in either order)
+
+
 def test_irregular_graphs_isolated_atoms_self_loops_single_graph():
     """A hand-made batch the synthetic generator never produces: atoms nobody points to, an atom with no bond at all, self
     loops, multi-edges, one graph of a single atom - through both launch paths, bit for bit."""
