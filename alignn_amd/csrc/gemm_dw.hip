@@ -47,6 +47,14 @@
 #ifndef DW_NS
 #define DW_NS 4
 #endif
+#ifndef DW_IL
+#define DW_IL 0  // 1 (lock-step form): the DMA requests of a step are issued BETWEEN its products, one per three MFMAs (measured
+                 // slower: 714 vs 660 us, profiles/r06_dw_ablate.txt)
+#endif
+#ifndef DW_PP
+#define DW_PP 0  // 1: two teams of four waves alternate matrix and load segments (see the kernel; measured slower: 721 vs 660 us);
+                 // 0: all eight waves in lock-step
+#endif
 #if DW_TRACE
 __device__ unsigned long long dw_trace_buf[256 * 16];
 #endif
@@ -270,12 +278,13 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int i = 0; i < 8; ++i) row_dma(g.G, g.ldg, tr, wave * 8 + i, smem + GBUF + (wave * 8 + i) * 1024);
     };
     // stage n (0 .. NSL-1) of tile tr -> ring position n % NS
-    auto issue_slot = [&](auto nc, const TileRef& tr) {
+    auto issue_slot = [&](auto nc, const TileRef& tr, int only = -1) {  // only: one of the stage's two instructions (-1: both)
         constexpr int n = decltype(nc)::value;
         if constexpr (S::slot_ops(n) == 0) return;
         unsigned char* dst = smem + RING + (n % NS) * SLOT;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
+            if (only >= 0 && only != i) continue;
             const int lr = 2 * wave + i;  // row of the stage / KiB piece of the weight block
             if constexpr (n < 4) {
                 row_dma(g.Y, g.ldy, tr, 16 * n + lr, dst + lr * 1024);
@@ -339,12 +348,8 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #define DW_WAIT(ph, stmt) stmt
 #define DW_BARRIER(ph) block_barrier()
 #endif
-    // (A two-team form - waves 4-7 multiplying one interval behind waves 0-3, so that on every SIMD one wave's matrix work runs
-    // beside its partner's LDS reads - was measured and removed: 739 vs 663 us for the plain variant, profiles/r06_dw_ablate_v2.txt.
-    // The products have to stand outside the team branches - a branch around MFMAs made hipcc copy the accumulators at the join,
-    // 1 700 registers spilled - which costs every wave a product of zeros at each phase boundary.)
     f16x8 yah[2], yal[2], ybh[4], ybl[4];  // operands of a weight-gradient step (16 rows): G^T blocks, Y blocks
-    f16x8 wah, wal, wbh[2], wbl[2];        // operands of an input-gradient k-step
+    f16x8 wah[2], wal[2], wbh[2][2], wbl[2][2];  // operands of a pair of input-gradient k-steps
     int ta_off[2], tb_off[2], a_base, b_off[2];
     auto y_reads = [&](auto sc) {
         constexpr int s = decltype(sc)::value;
@@ -365,49 +370,73 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             ybl[b] = tr_operand<(s % NS) * SLOT + 512>(p0, p1);
         }
     };
-    auto y_mfma = [&]() {
+    auto no_il = [](auto) {};
+    // (`between(k)`, k = 0, 1: called after the first and second of the three passes - the step's DMA requests go there, DW_IL)
+    auto y_mfma = [&](auto&& between) {
         if constexpr (!(DW_ABL & 8)) {
 #define DW_PASS(AA, BB)                                                                       \
     _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int b = 0; b < 4; ++b) \
         acc_dw[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AA[a], BB[b], acc_dw[a][b], 0, 0, 0);
             DW_PASS(yal, ybh)
+            between(std::integral_constant<int, 0>{});
             DW_PASS(yah, ybl)
+            between(std::integral_constant<int, 1>{});
             DW_PASS(yah, ybh)
 #undef DW_PASS
         } else {
             acc_dw[0][0][0] += (float)yah[0][0] + (float)ybh[0][0] + (float)yal[1][0] + (float)ybl[3][0];  // (keeps the operand reads)
+            between(std::integral_constant<int, 0>{});
+            between(std::integral_constant<int, 1>{});
         }
     };
-    auto w_reads = [&](auto ktc) {
-        constexpr int kt = decltype(ktc)::value, s = kt + 4;
-        const unsigned char* slot = smem + RING + (s % NS) * SLOT;
+    auto w_reads = [&](auto ktc) {  // both k-steps of the pair that starts at kt
+        constexpr int kt0 = decltype(ktc)::value;
         int ab = a_base;
         asm volatile("" : "+v"(ab));  // (one XOR per k-step instead of 16 addresses carried through the kernel)
-        const unsigned char* ap = smem + (ab ^ (kt << 5));
-        wah = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(ap));
-        wal = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(ap + 512));
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            wbh[b] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(slot + b_off[b]));
-            wbl[b] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(slot + b_off[b] + 8192));
+        for (int j = 0; j < 2; ++j) {
+            const unsigned char* slot = smem + RING + ((kt0 + j + 4) % NS) * SLOT;
+            const unsigned char* ap = smem + (ab ^ ((kt0 + j) << 5));
+            wah[j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(ap));
+            wal[j] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(ap + 512));
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                wbh[j][b] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(slot + b_off[b]));
+                wbl[j][b] = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(slot + b_off[b] + 8192));
+            }
         }
     };
-    auto w_mfma = [&]() {
-        if constexpr (!(DW_ABL & 4)) {
-#pragma unroll
-            for (int b = 0; b < 2; ++b) acc_c[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wah, wbh[b], acc_c[b], 0, 0, 0);
-#pragma unroll
-            for (int b = 0; b < 2; ++b) acc_c[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wah, wbl[b], acc_c[b], 0, 0, 0);
-#pragma unroll
-            for (int b = 0; b < 2; ++b) acc_c[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wal, wbh[b], acc_c[b], 0, 0, 0);
-        } else {
-            acc_c[0][0] += (float)wah[0] + (float)wal[0] + (float)wbh[0][0] + (float)wbl[1][0];  // (keeps the operand reads)
-        }
+    // (`between(k)`, k = 0 .. 3: called after every third product of the twelve)
+    auto w_mfma = [&](auto&& between) {
+        static_for<0, 2>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (!(DW_ABL & 4)) {
+                acc_c[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wah[j], wbh[j][0], acc_c[0], 0, 0, 0);
+                acc_c[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wah[j], wbh[j][1], acc_c[1], 0, 0, 0);
+                acc_c[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wah[j], wbl[j][0], acc_c[0], 0, 0, 0);
+                between(std::integral_constant<int, 2 * j>{});
+                acc_c[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wah[j], wbl[j][1], acc_c[1], 0, 0, 0);
+                acc_c[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wal[j], wbh[j][0], acc_c[0], 0, 0, 0);
+                acc_c[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wal[j], wbh[j][1], acc_c[1], 0, 0, 0);
+                between(std::integral_constant<int, 2 * j + 1>{});
+            } else {
+                acc_c[0][0] += (float)wah[j][0] + (float)wal[j][0] + (float)wbh[j][0][0] + (float)wbl[j][1][0];  // (keeps the reads)
+                between(std::integral_constant<int, 2 * j>{});
+                between(std::integral_constant<int, 2 * j + 1>{});
+            }
+        });
     };
+    // Two teams (DW_PP): waves 0-3 lead, waves 4-7 - their partners on the four SIMDs (tools/simd_map.hip: waves w and w + 4
+    // share one) - follow half an interval behind.  An interval has two barriers: in its first half the leaders fetch the
+    // operands of step s while the others multiply what they fetched in step s - 1; in its second half the leaders multiply and the
+    // others fetch.  On every SIMD one wave's matrix segment runs beside its partner's LDS segment (with all eight waves in
+    // lock-step a k-step took 720 cycles for 384 of matrix work: profiles/r06_dw_ablate_v3.txt).
+    // (the two teams run two COPIES of the tile loop, chosen once: with per-step team branches around the products hipcc copies
+    // the accumulators at every join - 2 500 registers spilled)
 
     // one tile; FIRST: the waits of the first tile count the prologue's operations instead of the previous tile's
-    auto tile_body = [&](auto first_c) {
-        constexpr bool FIRST = decltype(first_c)::value;
+    auto tile_body = [&](auto first_c, auto lead_c) {
+        constexpr bool FIRST = decltype(first_c)::value, lead = decltype(lead_c)::value;
         DW_STAMP(0);
         const TileRef cur = tile_ref(tile), nxt = tile_ref(tile + grid);
         const int64_t m0 = cur.m0;
@@ -449,35 +478,76 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 tb_off[h] = RING + row * 1024 + (((16 * wc + sl) ^ swz(row)) << 4) + (i16 & 1) * 8;  // ^ (b << 6); + ring position
             }
         }
-        static_for<0, 4>([&](auto sc) {
+        // slice the two rows of Y stage s this wave requested, in place (rows past the end of the matrix: zeros)
+        auto y_convert = [&](auto sc) {
             constexpr int s = decltype(sc)::value;
-            if (s == 0) DW_STAMP(2);
             DW_WAIT(0, (wait_vmcnt<FIRST ? kSched<NE>.w0[s] : kSched<NE>.ws[s]>()));
             unsigned char* slot = smem + RING + (s % NS) * SLOT;
-            {  // slice the two rows this wave requested (rows past the end of the matrix: zeros)
-                const int ra = 2 * wave, rb = ra + 1;
-                const int l = opaque_lane();
-                float4 va = *reinterpret_cast<const float4*>(slot + ra * 1024 + l * 16);
-                float4 vb = *reinterpret_cast<const float4*>(slot + rb * 1024 + l * 16);
-                const float ka = m0 + 16 * s + ra < g.M ? 1.0f : 0.0f, kb = m0 + 16 * s + rb < g.M ? 1.0f : 0.0f;
-                va = f4_scale(va, ka);
-                vb = f4_scale(vb, kb);
-                uint4 hp, lp;
-                slice8(va, vb, sy, hp, lp);
-                unsigned char* pa = slot + ra * 1024 + ((((l >> 1) ^ swz(ra))) << 4) + (l & 1) * 8;
-                unsigned char* pb = slot + rb * 1024 + ((((l >> 1) ^ swz(rb))) << 4) + (l & 1) * 8;
-                *reinterpret_cast<uint2*>(pa) = make_uint2(hp.x, hp.y);
-                *reinterpret_cast<uint2*>(pa + 512) = make_uint2(lp.x, lp.y);
-                *reinterpret_cast<uint2*>(pb) = make_uint2(hp.z, hp.w);
-                *reinterpret_cast<uint2*>(pb + 512) = make_uint2(lp.z, lp.w);
-            }
-            DW_BARRIER(0);  // the planes of this stage (and, s == 0, of G) are complete; step s-1's ring position is free
+            const int ra = 2 * wave, rb = ra + 1;
+            const int l = opaque_lane();
+            float4 va = *reinterpret_cast<const float4*>(slot + ra * 1024 + l * 16);
+            float4 vb = *reinterpret_cast<const float4*>(slot + rb * 1024 + l * 16);
+            const float ka = m0 + 16 * s + ra < g.M ? 1.0f : 0.0f, kb = m0 + 16 * s + rb < g.M ? 1.0f : 0.0f;
+            va = f4_scale(va, ka);
+            vb = f4_scale(vb, kb);
+            uint4 hp, lp;
+            slice8(va, vb, sy, hp, lp);
+            unsigned char* pa = slot + ra * 1024 + ((((l >> 1) ^ swz(ra))) << 4) + (l & 1) * 8;
+            unsigned char* pb = slot + rb * 1024 + ((((l >> 1) ^ swz(rb))) << 4) + (l & 1) * 8;
+            *reinterpret_cast<uint2*>(pa) = make_uint2(hp.x, hp.y);
+            *reinterpret_cast<uint2*>(pa + 512) = make_uint2(lp.x, lp.y);
+            *reinterpret_cast<uint2*>(pb) = make_uint2(hp.z, hp.w);
+            *reinterpret_cast<uint2*>(pb + 512) = make_uint2(lp.z, lp.w);
+        };
+        auto fills = [&](auto sc) {  // the stages that take the ring positions step s - 1 released
+            constexpr int s = decltype(sc)::value;
             static_for<0, S::fill_n(s)>([&](auto kc) {
                 constexpr int n = S::fill_lo(s) + decltype(kc)::value;
                 issue_slot(std::integral_constant<int, n % S::NSL>{}, n >= S::NSL ? nxt : cur);
             });
+        };
+        // ... one DMA instruction of them at a time (piece k of 2 fill_n(s)), fenced so that it stays between the products
+        auto fill_piece = [&](auto sc, auto kc) {
+            constexpr int s = decltype(sc)::value, k = decltype(kc)::value;
+            if constexpr (k < 2 * S::fill_n(s)) {
+                constexpr int n = S::fill_lo(s) + k / 2;
+                __builtin_amdgcn_sched_barrier(0);
+                issue_slot(std::integral_constant<int, n % S::NSL>{}, n >= S::NSL ? nxt : cur, k % 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        DW_STAMP(2);
+        y_convert(std::integral_constant<int, 0>{});
+        static_for<0, 4>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            DW_BARRIER(0);  // the planes of this stage (and, s == 0, of G) are complete; step s-1's ring position is free
+#if DW_PP
+            // the load segment of a team: DMA requests, operand reads, slicing of the next stage - beside the other team's products
+            if constexpr (lead) {
+                fills(sc);
+                y_reads(sc);
+                if constexpr (s < 3) y_convert(std::integral_constant<int, s + 1>{});
+            } else {
+                if constexpr (s > 0) y_mfma(no_il);  // (step s - 1's operands)
+            }
+            block_barrier();
+            if constexpr (lead) {
+                y_mfma(no_il);
+            } else {
+                fills(sc);
+                y_reads(sc);
+                if constexpr (s < 3) y_convert(std::integral_constant<int, s + 1>{});
+            }
+#elif DW_IL
             y_reads(sc);
-            y_mfma();
+            y_mfma([&](auto kc) { fill_piece(sc, kc); });
+            if constexpr (s < 3) y_convert(std::integral_constant<int, s + 1>{});
+#else
+            fills(sc);
+            y_reads(sc);
+            y_mfma(no_il);
+            if constexpr (s < 3) y_convert(std::integral_constant<int, s + 1>{});
+#endif
         });
         // ---- input gradient: 16 k-steps over the weight image
 #pragma unroll
@@ -501,14 +571,31 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (s == 4) DW_STAMP(3);
             DW_WAIT(1, (wait_vmcnt<FIRST ? kSched<NE>.w0[s] : kSched<NE>.ws[s]>()));
             DW_BARRIER(1);
-            static_for<0, S::fill_n(s)>([&](auto kc) {
-                constexpr int n = S::fill_lo(s) + decltype(kc)::value;
-                issue_slot(std::integral_constant<int, n % S::NSL>{}, n >= S::NSL ? nxt : cur);
-            });
+#if DW_PP
+            if constexpr (lead) {
+                fills(sc);
+                w_reads(std::integral_constant<int, kt0>{});
+            } else {
+                if constexpr (kt0 == 0)
+                    y_mfma(no_il);  // (the last weight-gradient step's operands)
+                else
+                    w_mfma(no_il);  // (the previous pair's operands)
+            }
+            block_barrier();
+            if constexpr (lead) {
+                w_mfma(no_il);
+            } else {
+                fills(sc);
+                w_reads(std::integral_constant<int, kt0>{});
+            }
+#elif DW_IL
             w_reads(std::integral_constant<int, kt0>{});
-            w_mfma();
-            w_reads(std::integral_constant<int, kt0 + 1>{});
-            w_mfma();
+            w_mfma([&](auto kc) { fill_piece(sc, kc); });
+#else
+            fills(sc);
+            w_reads(std::integral_constant<int, kt0>{});
+            w_mfma(no_il);
+#endif
         });
         // ---- epilogue: the operands of each step in the ring
         // a step = 8 (4) rows x 64 columns per wave through its patch; lane (prow, pc4) takes rows prow (and prow + 4) at the
@@ -526,10 +613,8 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (e == 0) DW_STAMP(4);
             if constexpr (NE > 0) DW_WAIT(2, (wait_vmcnt<FIRST ? kSched<NE>.w0[s] : kSched<NE>.ws[s]>()));
             if constexpr (e == 0) DW_BARRIER(2);  // every wave has left the tile's planes and the last W stages
-            static_for<0, S::fill_n(s)>([&](auto kc) {
-                constexpr int n = S::fill_lo(s) + decltype(kc)::value;
-                issue_slot(std::integral_constant<int, n % S::NSL>{}, n >= S::NSL ? nxt : cur);
-            });
+            if constexpr (e == 0 && DW_PP && !lead) w_mfma(no_il);  // (the last pair's operands)
+            fills(sc);
             if constexpr (e == 0) issue_G(nxt);
             const unsigned char* mine = smem + RING + (n_slot % NS) * SLOT + wave * 2048;  // this wave's rows of the stage
             // (eighths: the other half-wave's registers go to the patch's unused rows 4 .. 7 - no branch around the writes)
@@ -567,9 +652,15 @@ __global__ __launch_bounds__(NTH) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         ++tr_j;
 #endif
     };
-    tile_body(std::true_type{});
-    tile += grid;
-    for (int j = 1; j < J; ++j, tile += grid) tile_body(std::false_type{});
+    auto run_tiles = [&](auto lead_c) {
+        tile_body(std::true_type{}, lead_c);
+        tile += grid;
+        for (int j = 1; j < J; ++j, tile += grid) tile_body(std::false_type{}, lead_c);
+    };
+    if (!DW_PP || wave < 4)  // (wave-uniform: one scalar branch per kernel)
+        run_tiles(std::true_type{});
+    else
+        run_tiles(std::false_type{});
 #if DW_TRACE
     if (threadIdx.x == 0 && blockIdx.x < 256) {
         unsigned long long* o = dw_trace_buf + blockIdx.x * 16;

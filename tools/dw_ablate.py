@@ -23,6 +23,8 @@ VARIANTS = {
     "noStore": ["-DDW_ABL=16"],
     "noDMA_noMFMA": ["-DDW_ABL=111"],
     "noslp": ["-fno-slp-vectorize"],
+    "pingpong": ["-DDW_PP=1"],
+    "dma_between": ["-DDW_IL=1"],
     "trace": ["-DDW_TRACE=1"],
 }
 EXTRA = os.environ.get("DW_VARIANTS")  # e.g. "name:-DX=1 -DY=2;name2:..."
