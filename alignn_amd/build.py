@@ -7,8 +7,11 @@ rebuilds in seconds."""
 from __future__ import annotations
 
 import os
+import re
+import shutil
 import subprocess
 import sys
+import tempfile
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -17,14 +20,52 @@ OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libalignn_hip.so")
 SOURCES = ["norm.hip", "conv.hip", "gemm_f32.hip", "gemm_x6.hip", "embed.hip", "dual.hip", "knn.hip", "composite.hip", "model.hip", "stage.hip", "radius.hip", "angle.hip", "ff.hip", "convln.hip", "gemm_dw.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
-# Per-file additions.  norm.hip / dual.hip (the LayerNorm kernels and their dual-number twins): no SLP vectorisation, i.e. no
-# packed-fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 with op_sel).  With them hipcc 7.2's code for
-# ln_silu_bwd_kernel intermittently returned one float4 component of lanes 48-63 wrong when waves of ANOTHER kernel (an MFMA
-# projection on a second stream) shared the compute unit - run-to-run different forces and gradients of ALIGNNAtomWise on lanes;
-# compiled without them (or at -O1) every run is bit-identical (round 5: DESIGN.md section 4e, profiles/r05_ln_concurrency.txt).
-# The streaming kernels of these two files are memory-bound: no measurable cost (headline 14.89 vs 14.84-14.89 ms, force training
-# 37.30 vs 37.24-37.28 ms, same box).  The whole library without SLP costs the headline 0.55 ms (projection / gate epilogues).
-EXTRA_FLAGS = {"norm.hip": ["-fno-slp-vectorize"], "dual.hip": ["-fno-slp-vectorize"], "convln.hip": ["-fno-slp-vectorize"]}
+DEVICE_FLAGS: list = []
+# Per-file additions: no SLP vectorisation where hipcc 7.2 would otherwise emit the packed-fp32 form that MI355X gets wrong:
+#     v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 with op_sel selecting the HIGH half of src1 for the LOW result (op_sel:[_,1,_]).
+# Beside MFMA waves of another workgroup on the same SIMD that operand reads as +0.0 in lanes 48-63 (tools/pk_f32_repro2.hip,
+# profiles/r06_pk_f32_repro.txt: register-only victims, 5e5 wrong results per 2e9 beside an MFMA + ds_read_b128 kernel, none
+# alone; every other packed form - no op_sel, op_sel on src0 / src2, op_sel_hi, neg - clean).  Round 5 met it as run-to-run
+# different forces on lanes (ln_silu_bwd_kernel beside the T-row projection of the other lane: DESIGN.md section 4e).
+# The flag is a means, not the guarantee: build() disassembles the linked library and REFUSES it if the form is present anywhere
+# (faulting_packed_forms below; tests/test_build_isa.py does the same to the shipped file).  The files listed are the ones where
+# the vectoriser produced it; their kernels are memory-bound, the flag costs nothing measurable.  The thousands of packed
+# instructions of the projection / gate epilogues (gemm_x6.hip, conv.hip, angle.hip, gemm_dw.hip) are of the clean forms and stay.
+_NO_SLP = ["-fno-slp-vectorize"]
+EXTRA_FLAGS = {"norm.hip": _NO_SLP, "dual.hip": _NO_SLP, "convln.hip": _NO_SLP, "radius.hip": _NO_SLP, "ff.hip": _NO_SLP}
+
+_OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+_PK = re.compile(r"\b(v_pk_(?:fma|mul|add)_f32)\b(.*)$")
+_OPSEL = re.compile(r"op_sel:\[([01]),([01])")
+_SYM = re.compile(r"^[0-9a-f]+ <([^>]+)>:$")
+
+
+def faulting_packed_forms(lib: str = None) -> list:
+    """[(kernel symbol, instruction text)] for every packed-fp32 instruction of the faulting form in the gfx950 code objects of
+    ``lib`` (default: the in-tree library).  Works on the linked file: what is checked is what ships."""
+    lib = lib or LIB
+    found = []
+    with tempfile.TemporaryDirectory() as tmp:
+        copy = os.path.join(tmp, "lib.so")  # (llvm-objdump --offloading writes the bundles beside its input)
+        shutil.copy(lib, copy)
+        subprocess.run([_OBJDUMP, "--offloading", copy], check=True, capture_output=True)
+        bundles = sorted(f for f in os.listdir(tmp) if "gfx950" in f)
+        if not bundles:
+            raise RuntimeError(f"{lib}: no gfx950 code object found")
+        for b in bundles:
+            dis = subprocess.run([_OBJDUMP, "-d", "--no-show-raw-insn", os.path.join(tmp, b)], check=True, capture_output=True, text=True).stdout
+            cur = "?"
+            for line in dis.splitlines():
+                m = _SYM.match(line)
+                if m:
+                    cur = m.group(1)
+                    continue
+                m = _PK.search(line)
+                if m:
+                    o = _OPSEL.search(m.group(2))
+                    if o and o.group(2) == "1":
+                        found.append((cur, (m.group(1) + m.group(2)).split("//")[0].strip()))
+    return found
 
 
 def _headers():
@@ -52,7 +93,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     def compile_one(pair):
         src, obj = pair
         if force or _stale(obj, [os.path.join(CSRC, src), os.path.abspath(__file__)] + hdrs):
-            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+            cmd = [hipcc] + FLAGS + DEVICE_FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)
@@ -66,6 +107,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+        bad = faulting_packed_forms(LIB)
+        if bad:
+            os.replace(LIB, LIB + ".rejected")
+            raise RuntimeError("libalignn_hip.so contains the packed-fp32 form that MI355X gets wrong beside MFMA waves "
+                               "(see EXTRA_FLAGS in alignn_amd/build.py): " + "; ".join(f"{k}: {i}" for k, i in bad[:8]))
     return LIB
 
 

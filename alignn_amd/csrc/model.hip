@@ -1443,13 +1443,29 @@ void dual_conv_bwd(Ctx& c, const DConvTape& t, const DAct& gx, const DAct& gy, D
     if (t.lane && sd != T) c.sync(sd, T);
     if (t.lane) c.sync(main, T);  // GP complete: the node input gradient reads it
     g_x = dual_dgrad(c, GP, 4 * H, p.wcat, 4 * H, Kin, p.wcat_img_t, p.wcat_amax, &gx, n, main);
-    g_y = dual_dgrad(c, GM, H, p.w_eg, H, Kin, p.weg_img_t, p.weg_amax, gy.p != nullptr ? &gy : nullptr, m, T);
+    // value and tangent halves of the edge-gate projection's backward: input gradient + weight gradient in one pass over each
+    // half's g_m where the shape allows (csrc/gemm_dw.hip; the tangent half's weight gradient goes to the twin buffer as before)
+    bool dw = c.d->dw_fused > 0 && m >= c.d->dw_fused && GM.amax_p != nullptr && t.y.amax_p != nullptr && t.y.amax_t != nullptr &&
+              p.weg_img_t != nullptr && Kin == H && alignn_gemm_dgrad_wgrad_supported(m, H, Kin) && x6_shape_ok(c, m, H, Kin, H);
+    if (dw) {
+        g_y.p = c.alloc((size_t)m * Kin);
+        g_y.t = c.alloc((size_t)m * Kin);
+        g_y.on_T = T != c.main;
+        const size_t nb = alignn_gemm_dgrad_wgrad_workspace(m);
+        c.tmp_reset(T);
+        float* ws = c.tmp(T, nb / 4);
+        L(alignn_gemm_dgrad_wgrad_f16x3(GM.p, H, GM.amax_p, t.y.p, Kin, t.y.amax_p, p.weg_img_t, p.weg_amax, gy.p, H, g_y.p, Kin,
+                                        nullptr, 0, nullptr, nullptr, p.g_weg, Kin, m, ws, nb, T));
+        L(alignn_gemm_dgrad_wgrad_f16x3(GM.t, H, GM.amax_t, t.y.t, Kin, t.y.amax_t, p.weg_img_t, p.weg_amax, gy.t, H, g_y.t, Kin,
+                                        nullptr, 0, nullptr, nullptr, c.twin(p.g_weg), Kin, m, ws, nb, T));
+    } else
+        g_y = dual_dgrad(c, GM, H, p.w_eg, H, Kin, p.weg_img_t, p.weg_amax, gy.p != nullptr ? &gy : nullptr, m, T);
     c.tmp_reset(sd);
     if (n_partial != nullptr) L(alignn_bn_bwd_finalize(n_partial, n_slabs_fin, H, p.n_red, sd));
     if (e_partial != nullptr) L(alignn_bn_bwd_finalize(e_partial, e_slabs_fin, H, p.e_red, sd));
     dual_wgrad(c, GP, 4 * H, t.x, Kin, p.g_wcat, n, 4 * H, Kin, sd);
     col_sum(c, GP.p, 4 * H, n, 4 * H, p.g_bcat, sd);
-    dual_wgrad(c, GM, H, t.y, Kin, p.g_weg, m, H, Kin, sd);
+    if (!dw) dual_wgrad(c, GM, H, t.y, Kin, p.g_weg, m, H, Kin, sd);
     L(alignn_slab_sum(gb_part, slabs, H, p.g_beg, sd));
 }
 

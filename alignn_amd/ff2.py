@@ -317,13 +317,25 @@ def conv_bwd(entry, gx: Dual, gy, grads: _Grads):
     wcat, _ = conv._fused_node_projection()
     res = conv.residual
     g_x = _dgrad(GP, wcat, gx if res else None)
-    g_y = _dgrad(GM, conv.edge_gate.weight, gy if (res and gy is not None) else None)
+    w_eg = conv.edge_gate.weight
+    add = gy if (res and gy is not None) else None
+    Kin = y.p.shape[1]
+    g_weg = None
+    if (Kin == H and tuple(w_eg.shape) == (H, Kin) and GM.am(1) is not None and y.am(1) is not None
+            and ops.dgrad_wgrad_applies(m, H, Kin, GM.am(0), y.am(0)) and ops._x6_shape_ok(ops._Shape(m, H), Kin, H)):
+        # value and tangent halves: input gradient + weight gradient in one pass over each half's g_m (csrc/gemm_dw.hip)
+        wt = ops.split_f16x2(w_eg, True)
+        gyp, dwp, _ = ops.gemm_dgrad_wgrad(GM.p, GM.am(0), y.p, y.am(0), wt, add.p if add is not None else None)
+        gyt, dwt, _ = ops.gemm_dgrad_wgrad(GM.t, GM.am(1), y.t, y.am(1), wt, add.t if add is not None else None)
+        g_y, g_weg = Dual(gyp, gyt), dwp + dwt
+    else:
+        g_y = _dgrad(GM, w_eg, add)
     g_wcat = _wgrad(GP, x)
     g_bcat = ops.col_sum(GP.p)
     for i, lin in enumerate((conv.src_gate, conv.dst_gate, conv.dst_update, conv.src_update)):
         grads.add(lin.weight, g_wcat[i * H:(i + 1) * H])
         grads.add(lin.bias, g_bcat[i * H:(i + 1) * H])
-    grads.add(conv.edge_gate.weight, _wgrad(GM, y))
+    grads.add(conv.edge_gate.weight, g_weg if g_weg is not None else _wgrad(GM, y))
     g_beg = _empty(H, like=x.p)
     check(lib.alignn_slab_sum(ptr(gb_part), slabs, H, ptr(g_beg), stream()), "slab_sum")
     grads.add(conv.edge_gate.bias, g_beg)

@@ -601,9 +601,10 @@ def main():
         # A[u], Bd[v] it gathers from, counted ONCE (E/T rows each: they are re-read from L2/MALL, not from HBM, when
         # the kernel is doing well); bnred (+ the pre-activation read for the BatchNorm-backward sums) 3, with addend 4
         tables = 2.0 * raw.num_edges / raw.num_triplets
-        rows_moved = {"plain": 2, "addend": 3, "gather": 2 + tables, "bnred": 3, "bnred_addend": 4, "stats": 2}
-        # csrc/gemm_dw.hip - input gradient AND weight gradient in one pass: read g_m and y, write g_y (+ residual, + pre-activation)
-        rows_moved.update({"dw": 3, "dw_addend": 4, "dw_bnred": 4, "dw_bnred_addend": 5})
+        # dw*: csrc/gemm_dw.hip - input gradient AND weight gradient in one pass: read g_m and y, write g_y (+ residual addend,
+        # + the pre-activation for the BatchNorm-backward sums)
+        rows_moved = {"plain": 2, "addend": 3, "gather": 2 + tables, "bnred": 3, "bnred_addend": 4, "stats": 2,
+                      "dw": 3, "dw_addend": 4, "dw_bnred": 4, "dw_bnred_addend": 5}
         by = {}
         for (label, n_, k_, e0, e1) in ev:
             if n_ == H and k_ == H:

@@ -156,21 +156,79 @@ def test_energy_only_training_of_the_layernorm_model():
     assert float((a["out"] - c["out"]).abs().max()) < 1e-5 * float(a["out"].abs().max())
 
 
-@pytest.mark.parametrize("B,ff,use_c", [(16, True, True), (48, True, True), (64, False, True), (64, False, False)])
-def test_a_step_is_bit_reproducible_run_to_run(B, ff, use_c):
+class _ForeignMFMA:
+    """A kernel of SOMEBODY ELSE on its own stream while the step runs: fp16 matrix products of the vendor library (MFMA waves
+    that share the compute units with the step's kernels - the stand-in for a collective or a co-tenant)."""
+
+    def __init__(self, on, n=40):
+        self.on, self.n = on, n
+        if on:
+            self.s = torch.cuda.Stream()
+            self.a = torch.randn(4096, 4096, device=DEV, dtype=torch.float16)
+            self.c = torch.empty_like(self.a)
+
+    def __enter__(self):
+        if self.on:
+            self.s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.s):
+                for _ in range(self.n):
+                    torch.matmul(self.a, self.a, out=self.c)
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            torch.cuda.current_stream().wait_stream(self.s)
+        return False
+
+
+@pytest.mark.parametrize("B,ff,use_c,foreign", [(16, True, True, False), (48, True, True, False), (64, False, True, False),
+                                                (64, False, False, False), (48, True, True, True), (96, True, True, True),
+                                                (64, False, False, True)])
+def test_a_step_is_bit_reproducible_run_to_run(B, ff, use_c, foreign):
     """Round 5 found steps of the LayerNorm model NOT bit-reproducible on helper streams (forces off by 1e-3 run to run at 48
-    crystals, gradients by 1e-5; hipGraph replays already at 16) and traced it to the packed-fp32 code hipcc emitted for
-    ``ln_silu_bwd_kernel``: one float4 component of lanes 48-63 wrong while an MFMA kernel of another stream shared the compute
-    unit (profiles/r05_ln_concurrency.txt).  ``csrc/norm.hip`` / ``csrc/dual.hip`` are built without SLP vectorisation since
-    (alignn_amd/build.py): four runs of the same step - energies, forces, stresses, every gradient - are bit-identical with lane T,
-    the aux and the side stream in use, through the C calls and through the per-operator path (``ops.lanes`` + side stream)."""
+    crystals, gradients by 1e-5; hipGraph replays already at 16).  Round 6 reproduced the cause stand-alone
+    (tools/pk_f32_repro2.hip, profiles/r06_pk_f32_repro.txt): a packed-fp32 instruction whose op_sel takes the HIGH half of src1
+    for the LOW result reads that operand as +0.0 in lanes 48-63 while MFMA waves of another workgroup issue on the same SIMD -
+    in the model, ``ln_silu_bwd_kernel`` beside the T-row projection of the other lane.  No object of the library contains
+    that form any more (alignn_amd/build.py refuses to link one; tests/test_build_isa.py): four runs of the same step -
+    energies, forces, stresses, every gradient - are bit-identical with lane T, the aux and the side stream in use, through
+    the C calls and through the per-operator path, up to 96 crystals, and with a FOREIGN MFMA kernel (a vendor-library fp16
+    product on its own stream) running beside the step."""
     raw = make_batch(B, 60, seed0=11)
     batch = GraphBatch.from_raw(raw, device=DEV)
     tgt = _targets(raw, 6)
     m = _mk(9, ff=ff)
     ref = _train(m, [batch], [tgt], use_c, ff=ff, steps_opt=False)
     for _ in range(3):
-        _same(ref, _train(m, [batch], [tgt], use_c, ff=ff, steps_opt=False), "run to run")
+        with _ForeignMFMA(foreign):
+            got = _train(m, [batch], [tgt], use_c, ff=ff, steps_opt=False)
+        _same(ref, got, "run to run")
+
+
+def test_the_headline_step_is_bit_reproducible_beside_a_foreign_mfma_kernel():
+    """The same bar for the BatchNorm model of the headline (configs[1]: 64 crystals, T = 1.0 M rows) - its kernels share the
+    compute units with a foreign MFMA kernel in a multi-tenant / collective-overlapped deployment."""
+    from alignn_amd import ALIGNN, ALIGNNConfig
+    raw = make_batch(64, 60, seed0=0)
+    batch = GraphBatch.from_raw(raw, device=DEV)
+    torch.manual_seed(3)
+    model = ALIGNN(ALIGNNConfig(name="alignn")).to(DEV).train()
+    target = torch.randn(raw.batch_size, device=DEV)
+
+    def step(foreign):
+        for p in model.parameters():
+            p.grad = None
+        with _ForeignMFMA(foreign, n=30):
+            out = model(batch)
+            torch.nn.functional.mse_loss(out.view(-1), target).backward()
+        torch.cuda.synchronize()
+        res = {"out": out.detach().clone()}
+        res.update({"g." + k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+        return res
+
+    ref = step(False)
+    for rep in range(3):
+        _same(ref, step(True), f"headline beside foreign MFMA, run {rep}")
 
 
 def test_one_stream_and_helper_streams_give_the_same_bits_and_capture_replays():

@@ -33,12 +33,18 @@ VARIANT_KERNELS = {
     "stats": ["gemm_nt_f16p_stats_kernel", "gemm_nt_x6_stats_kernel<2>"],
     "bnred": ["gemm_nt_f16p_bnred_kernel<false>", "gemm_nt_x6_bnred_kernel<false, 2>"],
     "bnred_addend": ["gemm_nt_f16p_bnred_kernel<true>", "gemm_nt_x6_bnred_kernel<true, 2>"],
+    # csrc/gemm_dw.hip <HAS_ADD, BNRED>: the input gradient and the weight gradient of a T-row projection in one pass over g_m
+    "dw": ["gemm_dw_kernel<false, false>"],
+    "dw_addend": ["gemm_dw_kernel<true, false>"],
+    "dw_bnred": ["gemm_dw_kernel<false, true>"],
+    "dw_bnred_addend": ["gemm_dw_kernel<true, true>"],
 }
 # what ONE training step of the headline workload launches at T rows (bench.py `roofline.in_step` labels): every one of them
 # must have a PMC constant, or bench.py's `roofline.traffic` is null (tests/test_bench_launch.py, tests/test_gpu_cmodel.py)
-STEP_VARIANTS = ("gather", "bnred", "bnred_addend", "addend")
+STEP_VARIANTS = ("gather", "dw_bnred", "dw_bnred_addend", "dw_addend")
 # algorithmic H-wide fp32 rows moved per output row, by variant (bench.py uses the same table; gather: + 2 E/T for its tables)
-ROWS_MOVED = {"plain": 2, "addend": 3, "gather": 2.15, "stats": 2, "bnred": 3, "bnred_addend": 4}
+ROWS_MOVED = {"plain": 2, "addend": 3, "gather": 2.15, "stats": 2, "bnred": 3, "bnred_addend": 4,
+              "dw": 3, "dw_addend": 4, "dw_bnred": 4, "dw_bnred_addend": 5}
 GATHER_LAUNCHES_PER_STEP = 4  # one per line-graph convolution of the default 4-layer model: fixes steps-per-profile
 T_ROW_MIN_WRITE_MIB = 600.0  # a T = 676 200 x 256 fp32 output is 660 MiB
 
