@@ -508,11 +508,10 @@ class ALIGNNAtomWise(nn.Module):
         forces = torch.squeeze(forces)
         stress = torch.empty(1)
         if cfg.stresswise_weight != 0:
-            if b.volume is None:
-                raise ValueError("stress needs the cell volumes: g.ndata['V'] (or GraphBatch.volume)")
+            vol = b.cell_volumes()  # float32, contiguous, on the device, one per crystal (or ValueError)
             stress = torch.empty(b.batch_size, 3, 3, dtype=torch.float32, device=g_r.device)
             rr = r.detach().contiguous()
             _lib.check(lib.alignn_virial_stress(rr.data_ptr(), g_r.data_ptr(), scale, b.graph_ptr.data_ptr(), gg.seg_ptr.data_ptr(),
-                                                b.volume.data_ptr(), float(cfg.stress_multiplier) * (-160.21766208), stress.data_ptr(),
+                                                vol.data_ptr(), float(cfg.stress_multiplier) * (-160.21766208), stress.data_ptr(),
                                                 b.batch_size, _lib.stream()), "virial_stress")
         return forces, stress

@@ -174,6 +174,7 @@ class Binding:
         self.arena_gen = 0  # bumped by every forward that takes the shared block (a retained graph's second backward checks it)
         self.arena_stream = None
         self.pinned = []
+        self.spare = None  # the unpinned block of eager steps while the shared one belongs to captured graphs
         self.plans = {}
         self.bump = None
         self._sink_key = self._sink_plan = None
@@ -408,8 +409,22 @@ class Binding:
         block.  Forwards issued from different streams are ordered on the block by a stream wait."""
         if self.arena_busy:
             return torch.empty(nbytes, dtype=torch.uint8, device=self.device), False, 0
-        if (not capturing) and need_backward and self.arena is not None and any(a is self.arena for a in self.pinned):
-            self.arena = None
+        is_pinned = lambda a: a is not None and any(a is q for q in self.pinned)  # noqa: E731
+        if (not capturing) and need_backward and is_pinned(self.arena):
+            # park the graphs' block, take the unpinned one of the previous eager step back (alternating captures and eager
+            # steps swap the same two blocks instead of leaving one more block behind per alternation: ADVICE r05)
+            self.arena, self.spare = self.spare, self.arena
+            if is_pinned(self.arena):
+                self.arena = None
+            self.arena_stream = None
+        elif capturing and not is_pinned(self.arena):
+            # prefer a block some graph already replays into over pinning one more
+            best = min((a for a in self.pinned if a.numel() >= nbytes), key=lambda a: a.numel(), default=None)
+            if best is not None:
+                if self.arena is not None and (self.spare is None or self.spare.numel() < self.arena.numel() or is_pinned(self.spare)):
+                    self.spare = self.arena
+                self.arena = best
+                self.arena_stream = None
         if self.arena is None or self.arena.numel() < nbytes:
             if capturing:  # (the shared block would have to be allocated outside the capture: let the graph's pool own one)
                 return torch.empty(nbytes, dtype=torch.uint8, device=self.device), False, 0
@@ -417,9 +432,10 @@ class Binding:
             self.arena = torch.empty(int(nbytes * 1.05) + 4096, dtype=torch.uint8, device=self.device)
             self.arena_stream = None
             STATS["arena_bytes"] = self.arena.numel()
-        if capturing and not any(a is self.arena for a in self.pinned):
+        if capturing and not is_pinned(self.arena):
             # a captured graph replays into THIS block for as long as it lives: never free it (a later, larger batch
-            # allocates a new shared block; eager forwards in between only overwrite what every replay recomputes)
+            # allocates a new shared block; eager forwards in between only overwrite what every replay recomputes) - until the
+            # caller says the graphs are gone: release_captured_workspaces(model)
             self.pinned.append(self.arena)
         cur = torch.cuda.current_stream(self.device)
         if self.arena_stream is not None and self.arena_stream != cur and not capturing:
@@ -443,6 +459,20 @@ class _Lease:
             self.bind.arena_busy = False
 
     __del__ = release
+
+
+def release_captured_workspaces(model) -> int:
+    """Tell the binding that every hipGraph captured over ``model`` so far has been destroyed: the workspace blocks those graphs
+    replayed into are no longer kept alive (-> number of blocks released).  Without this call a block is kept for the life of
+    the model - a replay into freed memory would be silent corruption, and the binding cannot see a graph die."""
+    b = model_cache(model).get("binding")
+    if b is None:
+        return 0
+    n = len(b.pinned)
+    if b.arena is not None and any(b.arena is a for a in b.pinned) and b.spare is not None and not b.arena_busy:
+        b.arena, b.spare = b.spare, None
+    b.pinned = []
+    return n
 
 
 def binding_of(model) -> Binding:
@@ -604,7 +634,10 @@ def _structure_ok(model, b, need_grad, flavour="ALIGNN") -> bool:
                                for name, p in mod._parameters.items() if p is not None]
     for d, name, p in slots:
         if d.get(name) is not p:
+            sink = mc.get("grad_sink")
             mc.clear()
+            if sink is not None:  # (the optimizer registers itself once, in _build: a replaced Parameter has no slot in its
+                mc["grad_sink"] = sink  # buffer and sink_plan() routes that block to the private buffer - the rest stays)
             return _structure_ok(model, b, need_grad, flavour)
         if need_grad and not p.requires_grad:
             return False
@@ -689,11 +722,11 @@ def _ff_desc(model, b):
     f.dense_lg_reverse = int(ff2.DENSE_LG_REVERSE and ops.FUSED_LG_BACKWARD and ops.DENSE_LG_BACKWARD)
     f.grad_multiplier, f.stress_multiplier = float(cfg.grad_multiplier), float(cfg.stress_multiplier)
     f.penalty_factor, f.penalty_threshold = float(cfg.penalty_factor), float(cfg.penalty_threshold)
+    vol = None
     if f.has_stress:
-        if b.volume is None:
-            raise ValueError("stress needs the cell volumes: g.ndata['V'] (or GraphBatch.volume)")
-        f.volume = b.volume.data_ptr()
-    return f
+        vol = b.cell_volumes()  # float32, contiguous, on the device, one per crystal (or ValueError)
+        f.volume = vol.data_ptr()
+    return f, vol
 
 
 def _ff_prepare(model, b, need_grad):
@@ -707,7 +740,7 @@ def _ff_prepare(model, b, need_grad):
     if af.shape != (b.g.n_nodes, bind.desc.atom_in) or r.shape != (b.g.n_edges, 3) or (h is not None and h.numel() != b.lg.n_edges):
         raise ValueError("feature rows do not match the graphs")
     mb.atom_features, mb.r, mb.h = af.data_ptr(), r.data_ptr(), _ptr(h)
-    ffd = _ff_desc(model, b)
+    ffd, vol = _ff_desc(model, b)
     key = ("ff", mb.g.n, mb.g.m, mb.lg.m, mb.B, mb.lg.dense_max_src, bool(mb.lg.grp_seg_ptr), bool(mb.lg.seg_rank),
            bool(bind.desc.lane_T), bool(bind.desc.side), bool(bind.desc.aux), bind.desc.side_min_rows, bind.desc.lane_min_rows,
            ffd.lg_on_fly, ffd.has_stress, ffd.dense_lg_reverse)
@@ -727,7 +760,7 @@ def _ff_prepare(model, b, need_grad):
     nbytes = hit[1] if need_grad else hit[0]
     arena, owns, gen = bind.take_arena(nbytes, capturing, need_grad)
     ops.new_weight_generation()
-    return bind, mb, ffd, (b, af, r, h, b.volume), arena, nbytes, (owns, gen)
+    return bind, mb, ffd, (b, af, r, h, vol), arena, nbytes, (owns, gen)
 
 
 def _ff_outputs(bind, mb, ffd):

@@ -694,8 +694,9 @@ int alignn_ln_silu_dual_fwd(const float* X, const float* Xt, int64_t ldx, const 
 int alignn_ln_silu_dual_bwd(const float* GY, const float* GYt, int64_t ldg, const float* X, const float* Xt, int64_t ldx,
                             const float* gamma, const float* beta, const float* stats, float* GX, float* GXt,
                             int64_t ldo, float* partial, int64_t rows, int F, float* amax2, alignn_stream_t stream) {
-    if (!feat_ok(F)) return (int)hipErrorInvalidValue;
-    if (rows == 0) return 0;
+    if (!feat_ok(F) || rows < 0) return (int)hipErrorInvalidValue;
+    // rows == 0 still launches its one workgroup: alignn_dual_slabs(0) == 1 and the finalize pass reads that slab - it must hold
+    // zeros, not whatever the workspace held (same rule as alignn_ln_silu_bwd / _node in norm.hip)
     dim3 grid(row_blocks(rows)), block(kT);
     hipStream_t st = (hipStream_t)stream;
 #define ALIGNN_CASE(NC_)                                                                                                    \
@@ -717,8 +718,8 @@ int alignn_ln_silu_dual_bwd_node(const float* GY, const float* GYt, int64_t ldg,
                                  float* partial, int64_t rows, int F, float* amax2, const float* s0, const float* hh,
                                  const float* s0t, const float* hht, float* q1, float* q0, float* q1t, float* q0t,
                                  alignn_stream_t stream) {
-    if (!feat_ok(F) || !s0 || !hh || !s0t || !hht || !q1 || !q0 || !q1t || !q0t) return (int)hipErrorInvalidValue;
-    if (rows == 0) return 0;
+    if (!feat_ok(F) || rows < 0 || !s0 || !hh || !s0t || !hht || !q1 || !q0 || !q1t || !q0t) return (int)hipErrorInvalidValue;
+    // (rows == 0: one workgroup writes the zero slab, see alignn_ln_silu_dual_bwd)
     dim3 grid(row_blocks(rows)), block(kT);
     hipStream_t st = (hipStream_t)stream;
 #define ALIGNN_CASE(NC_)                                                                                                   \

@@ -46,15 +46,16 @@ __device__ __forceinline__ int owner_of(int k, const int32_t* __restrict__ outer
 __global__ void pair_force_reduce_kernel(const float* __restrict__ g_r, float scale, const int32_t* __restrict__ seg_ptr,
                                          const int32_t* __restrict__ out_ptr, const int32_t* __restrict__ out_slot,
                                          int add_reverse, float* __restrict__ forces, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 3 * n) return;
-    const int64_t node = i / 3;
-    const int c = (int)(i - 3 * node);
-    float in = 0.0f, out = 0.0f;
-    for (int k = seg_ptr[node]; k < seg_ptr[node + 1]; ++k) in += g_r[3 * (int64_t)k + c];
-    if (add_reverse)
-        for (int k = out_ptr[node]; k < out_ptr[node + 1]; ++k) out += g_r[3 * (int64_t)out_slot[k] + c];
-    forces[i] = scale * (in - out);
+    // (grid-stride: grid_for caps the launch at 65535 workgroups = 5.6 M atoms per pass)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 3 * n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t node = i / 3;
+        const int c = (int)(i - 3 * node);
+        float in = 0.0f, out = 0.0f;
+        for (int k = seg_ptr[node]; k < seg_ptr[node + 1]; ++k) in += g_r[3 * (int64_t)k + c];
+        if (add_reverse)
+            for (int k = out_ptr[node]; k < out_ptr[node + 1]; ++k) out += g_r[3 * (int64_t)out_slot[k] + c];
+        forces[i] = scale * (in - out);
+    }
 }
 
 // one workgroup per crystal; thread t walks bonds t, t + 256, ...; nine sums each, added across the workgroup in a fixed tree
@@ -115,8 +116,8 @@ __global__ __launch_bounds__(256) void ff_energy_kernel(const float* __restrict_
 }
 
 __global__ void ff_penalty_bwd_kernel(const float* __restrict__ bl, float* __restrict__ g_bl, int64_t E, float coef, float thr) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < E && bl[e] < thr) g_bl[e] += coef;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (int64_t)gridDim.x * blockDim.x)
+        if (bl[e] < thr) g_bl[e] += coef;
 }
 
 __global__ __launch_bounds__(256) void ff_pair_weights_kernel(const float* __restrict__ gF, const float* __restrict__ gS,

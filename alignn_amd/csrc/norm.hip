@@ -874,7 +874,9 @@ int alignn_ln_silu_fwd(const float* X, int64_t ldx, const float* R, int64_t ldr,
 int alignn_ln_silu_bwd(const float* GY, int64_t ldgy, const float* X, int64_t ldx, const float* gamma,
                        const float* beta, const float* stats, float* GX, int64_t ldgx, float* partial, int64_t rows,
                        int F, float* amax, alignn_stream_t stream) {
-    if (!feat_ok(F)) return (int)hipErrorInvalidValue;
+    if (!feat_ok(F) || rows < 0) return (int)hipErrorInvalidValue;
+    // rows == 0 is launched on purpose (ln_blocks(0) == 1): alignn_ln_slabs(0) == 1 and alignn_ln_bwd_finalize reads that slab,
+    // which this one workgroup writes as zeros
     const int nc = (F + 255) / 256;
     dim3 grid(ln_blocks(rows)), block(kThreads);
     hipStream_t st = (hipStream_t)stream;
@@ -895,8 +897,8 @@ int alignn_ln_silu_bwd(const float* GY, int64_t ldgy, const float* X, int64_t ld
 int alignn_ln_silu_bwd_node(const float* GY, int64_t ldgy, const float* X, int64_t ldx, const float* gamma, const float* beta,
                             const float* stats, float* GX, int64_t ldgx, float* partial, int64_t rows, int F, float* amax,
                             const float* S0, const float* HH, float* GS1, float* GS0, alignn_stream_t stream) {
-    if (!feat_ok(F) || !S0 || !HH || !GS1 || !GS0) return (int)hipErrorInvalidValue;
-    const int nc = (F + 255) / 256;
+    if (!feat_ok(F) || rows < 0 || !S0 || !HH || !GS1 || !GS0) return (int)hipErrorInvalidValue;
+    const int nc = (F + 255) / 256;  // (rows == 0: one workgroup writes the zero slab, as alignn_ln_silu_bwd)
     dim3 grid(ln_blocks(rows)), block(kThreads);
     hipStream_t st = (hipStream_t)stream;
 #define ALIGNN_LNB(NC_)                                                                                                       \

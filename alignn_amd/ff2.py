@@ -471,7 +471,7 @@ class ForcesFn(torch.autograd.Function):
             w = _empty(E, 3, like=r)
             wmax = torch.zeros(1, dtype=torch.float32, device=dev)
             check(lib.alignn_ff_pair_weights(ptr(gF), ptr(gS), ptr(r), ptr(gg.src), ptr(gg.dst), ptr(b.graph_ptr), ptr(gg.seg_ptr),
-                                             ptr(b.volume) if gS is not None else None, float(cfg.stress_multiplier) * (-160.21766208),
+                                             ptr(b.cell_volumes()) if gS is not None else None, float(cfg.stress_multiplier) * (-160.21766208),
                                              int(cfg.add_reverse_forces), b.batch_size, E, ptr(w), ptr(wmax), stream()), "ff_pair_weights")
             c = float(cfg.grad_multiplier) * (gg.n_nodes if cfg.force_mult_natoms else 1)
             ge = g_out.reshape(-1).to(torch.float32).contiguous() if g_out is not None else None

@@ -294,6 +294,25 @@ class GraphBatch:
     def device(self):
         return self.graph_ptr.device
 
+    def cell_volumes(self) -> torch.Tensor:
+        """``volume`` as the kernels take it by raw pointer: float32, contiguous, on the batch's device, ONE value per crystal.
+        Anything else a caller may have put there (float64, a CPU tensor, a [B, 1] view) is converted once and cached; a
+        tensor of another length (e.g. the per-atom g.ndata["V"]) is an error, not garbage stresses."""
+        v = self.volume
+        if v is None:
+            raise ValueError("stress needs the cell volumes: g.ndata['V'] (or GraphBatch.volume)")
+        if v.numel() != self.batch_size:
+            raise ValueError(f"GraphBatch.volume holds {v.numel()} values for {self.batch_size} crystals: one cell volume per crystal is needed")
+        dev = self.graph_ptr.device
+        if v.dtype == torch.float32 and v.device == dev and v.is_contiguous() and v.dim() == 1 and not v.requires_grad:
+            return v
+        key = ("volume_f32", v.data_ptr(), v._version)
+        hit = self.cache.get("volume_f32")
+        if hit is None or hit[0] != key:
+            hit = (key, v.detach().to(device=dev, dtype=torch.float32).reshape(-1).contiguous())
+            self.cache["volume_f32"] = hit
+        return hit[1]
+
     def topology_only(self) -> "GraphBatch":
         """The index structures without any feature tensor (what may be cached on a caller's graph object: features
         are re-read on every forward, like the reference does, so in-place edits of ``g.edata['r']`` etc. are seen)."""

@@ -127,6 +127,57 @@ class FlatAdamW(torch.optim.Optimizer):
     def flat_buffers(self):
         return [f for f in self._flat if f is not None]
 
+    @staticmethod
+    def _group_order(members, fused, runs):
+        """Order of a group's live parameters inside its flat range: fused runs first (each contiguous and in its owner's
+        order) - a run is the part of an owner's weight (or bias) list that lives in THIS group; the owner adopts the flat
+        slices only if BOTH its lists are complete -, then the (dbeta | dgamma) pairs the whole-model backward writes as one
+        block (layout 2; ``runs == []`` gives layout 1), then the rest in group order."""
+        ids = {id(p) for p in members}
+        order, seen = [], set()
+        for owner, ws, bs in fused:
+            for run in (ws, bs):
+                if all(id(p) in ids for p in run) and not any(id(p) in seen for p in run):
+                    for p in run:
+                        order.append(p)
+                        seen.add(id(p))
+        for run in runs:
+            if all(id(p) in ids for p in run) and not any(id(p) in seen for p in run):
+                for p in run:
+                    order.append(p)
+                    seen.add(id(p))
+        order += [p for p in members if id(p) not in seen]
+        return order
+
+    def _migrate_layout_1(self, inner):
+        """A state dict written before the gradient runs were laid out first (layout 1): the moments are per FLAT buffer, so
+        they are permuted parameter by parameter from the old order (the same rule without the runs) into this one."""
+        fused = _fused_groups(self.module) if self.module is not None else []
+        inner = {"state": {k: dict(v) for k, v in inner["state"].items()}, "param_groups": inner["param_groups"]}
+        k = 0
+        for g, idx, new_order, new_offs in zip(self.param_groups, self._live_idx, self._live, self._offsets):
+            if not idx:
+                continue
+            st = inner["state"].get(k)
+            k += 1
+            if st is None:
+                continue
+            pos = {id(p): i for i, p in enumerate(g["params"])}
+            old_order = self._group_order(sorted(new_order, key=lambda p: pos[id(p)]), fused, [])
+            old_off, off = {}, 0
+            for p in old_order:
+                old_off[id(p)] = off
+                off += p.numel()
+            for name in ("exp_avg", "exp_avg_sq", "max_exp_avg_sq"):
+                t = st.get(name)
+                if t is None or not torch.is_tensor(t) or t.numel() != off:
+                    continue
+                out = torch.empty_like(t)
+                for p, o in zip(new_order, new_offs):
+                    out[o:o + p.numel()] = t[old_off[id(p)]:old_off[id(p)] + p.numel()]
+                st[name] = out
+        return inner
+
     # ---- layout
     def _build(self, live_idx: Optional[List[List[int]]] = None):
         """Fix the layout: ``live_idx`` (from a checkpoint) or, by default, the parameters that hold a gradient now."""
@@ -157,22 +208,7 @@ class FlatAdamW(torch.optim.Optimizer):
                 self._live_idx.append([])
                 self._offsets.append([])
                 continue
-            ids = {id(p) for p in members}
-            order, seen = [], set()
-            # fused runs first (each contiguous and in its owner's order) - a run is the part of an owner's weight (or
-            # bias) list that lives in THIS group; the owner adopts the flat slices only if BOTH its lists are complete
-            for owner, ws, bs in fused:
-                for run in (ws, bs):
-                    if all(id(p) in ids for p in run) and not any(id(p) in seen for p in run):
-                        for p in run:
-                            order.append(p)
-                            seen.add(id(p))
-            for run in runs:  # (dbeta | dgamma) pairs the whole-model backward writes as one block
-                if all(id(p) in ids for p in run) and not any(id(p) in seen for p in run):
-                    for p in run:
-                        order.append(p)
-                        seen.add(id(p))
-            order += [p for p in members if id(p) not in seen]
+            order = self._group_order(members, fused, runs)
             if any(p.dtype != first.dtype or p.device != first.device for p in order):
                 raise ValueError("FlatAdamW needs all parameters on one device in one dtype")
             flat = self._flat_all[starts[gi]:starts[gi] + sizes[gi]]
@@ -335,9 +371,12 @@ class FlatAdamW(torch.optim.Optimizer):
             g.update({k: v for k, v in sg.items() if k != "params"})  # (never the saved index lists: 'params' stay the tensors)
         if state.get("inner") is None:
             return
-        if state.get("layout", 1) != LAYOUT_VERSION and self.module is not None and _gradient_runs(self.module):
-            raise ValueError(f"FlatAdamW state dict with parameter layout {state.get('layout', 1)}, this version lays the flat "
-                             f"buffers out as {LAYOUT_VERSION} (the moments would be misaligned): re-create the optimizer state")
+        layout = state.get("layout", 1)
+        if layout not in (1, LAYOUT_VERSION):
+            raise ValueError(f"FlatAdamW state dict with parameter layout {layout}: this version reads layouts 1 and {LAYOUT_VERSION}")
         if [list(ix) for ix in state["live_idx"]] != [list(ix) for ix in self._live_idx] or self._inner is None:
             self._build(state["live_idx"])  # (compared by CONTENT: an equal-length but different live set is another layout)
-        self._inner.load_state_dict(state["inner"])
+        inner = state["inner"]
+        if layout == 1 and self.module is not None and _gradient_runs(self.module):
+            inner = self._migrate_layout_1(inner)  # (checkpoints from before the gradient runs were placed first)
+        self._inner.load_state_dict(inner)

@@ -129,6 +129,51 @@ def test_replayed_from_a_hipgraph_equals_eager():
     _same(ref, got, "replay")
 
 
+def test_alternating_captures_and_eager_steps_keep_two_workspace_blocks():
+    """an eager training step must not run in the block a captured graph replays into (a replay between its forward
+    and backward would overwrite the tape) - but alternating captures and eager steps swap the SAME two blocks; nothing is left
+    behind per alternation, and ``release_captured_workspaces`` lets the graphs' block go once the graphs are gone."""
+    raw = make_batch(4, 20, seed0=3)
+    batch = GraphBatch.from_raw(raw, device=DEV)
+    target = torch.randn(4, generator=torch.Generator().manual_seed(2)).to(DEV)
+    model = _mk(alignn_layers=2, gcn_layers=2)
+    l1 = torch.nn.functional.l1_loss
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        l1(model(batch), target).backward()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    bind = cmodel.binding_of(model)
+    seen, graphs = set(), []
+    for _ in range(3):
+        for p in model.parameters():
+            p.grad = None
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            l1(model(batch), target).backward()
+        graphs.append(g)
+        seen.add(bind.arena.data_ptr())
+        assert any(bind.arena is a for a in bind.pinned)
+        for p in model.parameters():
+            p.grad = None
+        l1(model(batch), target).backward()  # eager, with a backward: not in the graphs' block
+        assert not any(bind.arena is a for a in bind.pinned)
+        seen.add(bind.arena.data_ptr())
+        assert len(bind.pinned) == 1 and len(seen) == 2, (len(bind.pinned), seen)
+    ref = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    for g in graphs:
+        g.replay()
+    torch.cuda.synchronize()
+    del graphs, g
+    assert cmodel.release_captured_workspaces(model) == 1 and bind.pinned == []
+    for p in model.parameters():
+        p.grad = None
+    l1(model(batch), target).backward()
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None) and len(ref) > 50
+
+
 def test_autograd_semantics_accumulation_two_forwards_no_grad():
     raw1, raw2 = make_batch(10, 30, seed0=3), make_batch(6, 50, seed0=4)
     b1, b2 = GraphBatch.from_raw(raw1, device=DEV), GraphBatch.from_raw(raw2, device=DEV)

@@ -283,12 +283,18 @@ def test_alignn_ff_training_step_at_cfg4_size_vs_reference_class():
     model.load_state_dict({k: v for k, v in sd.items() if "running" not in k and "tracked" not in k})
     model = model.to(DEV).train()
     batch = GraphBatch.from_raw(raw, device=DEV)
+    from alignn_amd import cmodel
+
+    before = dict(cmodel.STATS)
     res = model(batch)
     L = torch.nn.functional.l1_loss
     t = lambda k: torch.from_numpy(z[k]).to(DEV)  # noqa: E731
     loss = L(res["out"], t("t_energy")) + L(res["grad"], t("t_forces")) + L(res["stresses"], t("t_stress"))
     loss.backward()
     torch.cuda.synchronize()
+    # what is compared with the reference class below is the whole-model C path (alignn_ff_eval + alignn_ff_grad), not a fallback
+    assert cmodel.STATS.get("ff_eval", 0) == before.get("ff_eval", 0) + 1, (before, cmodel.STATS)
+    assert cmodel.STATS.get("ff_grad", 0) == before.get("ff_grad", 0) + 1, (before, cmodel.STATS)
     report = [f"cfg4: N={raw.num_nodes} E={raw.num_edges} T={raw.num_triplets}"]
     try:
         for key, mine, tol in (("pred", res["out"], 1e-4), ("forces", res["grad"], 2e-4), ("stresses", res["stresses"], 2e-4)):
@@ -452,8 +458,19 @@ def test_force_training_at_cfg4_size_every_element_against_the_float64_torch_pat
 
     ref = run(copy.deepcopy(model).double().to(DEV).train(), torch.float64)
     torch.cuda.empty_cache()
-    got = run(model.to(DEV).train(), torch.float32)
-    report = [f"cfg4, every element vs the float64 torch path: N={raw.num_nodes} E={raw.num_edges} T={raw.num_triplets}"]
+    from torch.profiler import ProfilerActivity, profile
+
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        got = run(model.to(DEV).train(), torch.float32)
+    launched = {e.key for e in prof.key_averages()}
+    # every kernel of csrc/convln.hip (the edge / atom LayerNorm formed inside the gate passes: forward, reverse,
+    # tangent forward, dual reverse, and the destination-ordered reverse passes of the bond graph) ran in THIS float64 comparison
+    convln = ("egc_gate_fwd_ln_kernel", "egc_bwd_lg_dense_ln_kernel", "egc_gate_dual_tan_ln_kernel", "egc_dual_bwd_lg_dense_ln_kernel",
+              "egc_bwd_dst_ln_kernel", "egc_dual_bwd_dst_ln_kernel")
+    missing = [k for k in convln if not any(k in name for name in launched)]
+    report = [f"cfg4, every element vs the float64 torch path: N={raw.num_nodes} E={raw.num_edges} T={raw.num_triplets}",
+              f"csrc/convln.hip kernels launched in the compared step: {[k for k in convln if k not in missing]}"]
+    assert not missing, missing
     fails = []
     try:
         for key, tol in (("out", 1e-5), ("grad", 1e-4), ("stresses", 1e-4)):

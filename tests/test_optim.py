@@ -215,3 +215,59 @@ def test_flat_adamw_refuses_a_plain_torch_state_dict_and_compares_layouts_by_con
         opt.load_state_dict({"param_groups": sd["param_groups"]})
     opt.load_state_dict(sd)  # round trip still works
     assert all(isinstance(p, torch.nn.Parameter) for g in opt.param_groups for p in g["params"])
+
+
+class _RunNet(torch.nn.Module):
+    """A module that declares gradient runs (as the LayerNorm / BatchNorm layers of the models do): layout 2 places them first."""
+
+    def __init__(self):
+        super().__init__()
+        self.a = torch.nn.Linear(8, 16)
+        self.norm = torch.nn.LayerNorm(16)
+        self.b = torch.nn.Linear(16, 4)
+
+    def _gradient_runs(self):
+        return [[self.norm.bias, self.norm.weight]]
+
+    def forward(self, x):
+        return self.b(torch.tanh(self.norm(self.a(x))))
+
+
+def test_flat_adamw_reads_a_layout_1_state_dict_and_permutes_the_moments(monkeypatch):
+    """checkpoints written before the gradient runs were placed first (no 'layout' key = layout 1) load - the moments
+    are permuted parameter by parameter - and training continues exactly as the old optimizer would have."""
+    import alignn_amd.optim as O
+
+    torch.manual_seed(0)
+    m_old = _RunNet()
+    m_new = copy.deepcopy(m_old)
+    xs = [torch.randn(5, 8) for _ in range(5)]
+    with monkeypatch.context() as mp:  # the old layout: the same rule without the runs
+        mp.setattr(O, "_gradient_runs", lambda module: [])
+        o_old = FlatAdamW(m_old, lr=1e-2, weight_decay=0.05)
+        for x in xs[:3]:
+            o_old.zero_grad()
+            m_old(x).square().mean().backward()
+            o_old.step()
+        sd = copy.deepcopy(o_old.state_dict())
+        sd.pop("layout")
+        weights = copy.deepcopy(m_old.state_dict())
+        for x in xs[3:]:
+            o_old.zero_grad()
+            m_old(x).square().mean().backward()
+            o_old.step()
+    m_new.load_state_dict(weights)
+    o_new = FlatAdamW(m_new, lr=1e-2, weight_decay=0.05)
+    m_new(xs[0]).square().mean().backward()  # (fixes the live set)
+    o_new.load_state_dict(sd)
+    assert [id(p) for p in o_new._live[0]][:2] == [id(m_new.norm.bias), id(m_new.norm.weight)]  # layout 2: the run comes first
+    assert [id(p) for p in o_old._live[0]][:2] != [id(m_old.norm.bias), id(m_old.norm.weight)]
+    m_new.load_state_dict(weights)
+    for x in xs[3:]:
+        o_new.zero_grad()
+        m_new(x).square().mean().backward()
+        o_new.step()
+    for (k, p), q in zip(m_old.named_parameters(), m_new.parameters()):
+        assert torch.equal(p, q), k
+    with pytest.raises(ValueError):
+        o_new.load_state_dict(dict(sd, layout=7))
