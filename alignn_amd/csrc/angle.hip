@@ -583,6 +583,9 @@ __device__ __forceinline__ int bfrag_idx(int rb, int jb, int s, int hl, int lane
 // scale, multiplied into a fresh accumulator and added to dW2's with the inverse scale - the fp32 addition the MFMA itself
 // would have made.
 constexpr int kDwThreads = 512, kDwTile = 256, kDwGrid = 256;
+#ifndef DW2_PIPE
+#define DW2_PIPE 0  // (measured: 314 us with the recompute issued one block ahead - 256 registers, 27 spilled - against 295 us without)
+#endif
 
 __global__ __launch_bounds__(kDwThreads, 1) void angle_sums_dw2_kernel(P p) {
     __shared__ L1Shared sh;
@@ -612,19 +615,34 @@ __global__ __launch_bounds__(kDwThreads, 1) void angle_sums_dw2_kernel(P p) {
     float am0 = 0.0f, am1 = 0.0f;
     f32x16 dw[2] = {zero16(), zero16()};
     const int64_t ntiles = (p.rows + kDwTile - 1) / kDwTile;
+    // (a tile that lies wholly inside the tensor: one 64-bit base per row block and group of eight rows, the rest immediate
+    // offsets - the clamped form spent 3 compares / selects and a 64-bit multiply-add per load: 130 of the loop's 530 instructions)
     auto load_g = [&](int64_t row0, int rb, float (&g)[16]) {
+        if (row0 + kDwTile <= p.rows) {  // uniform
+            const float* base = p.gz + (row0 + 32 * rb + 4 * hh) * kH + f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int64_t row = row0 + n_row(rb, r, hh);
-            row = row < p.rows ? row : p.rows - 1;
-            g[r] = __builtin_nontemporal_load(p.gz + row * kH + f);
+            for (int q = 0; q < 4; ++q) {
+                const float* bq = base + 8 * q * kH;
+                asm volatile("" : "+v"(bq));  // (keep it ONE pointer per group: offsets 0 / 1 / 2 / 3 KiB are immediates)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[4 * q + e] = __builtin_nontemporal_load(bq + e * kH);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int64_t row = row0 + n_row(rb, r, hh);
+                row = row < p.rows ? row : p.rows - 1;
+                g[r] = __builtin_nontemporal_load(p.gz + row * kH + f);
+            }
         }
     };
     // one row block: recompute the wave's 32 features, gz and the sums, its share of G
     // (g: g_z of this row block on entry; refilled with the NEXT block's - of row0n / rbn - as soon as it has been consumed, so
     // one set of registers is both the operand and the prefetch: a second set spilled 85-91 registers)
-    auto block = [&](auto full_c, int64_t row0, int rb, float (&g)[16], int64_t row0n, int rbn) {
-        constexpr bool FULL = decltype(full_c)::value;
+    // the wave's 32 features of row block rb, recomputed: issued one block AHEAD of its use (DW2_PIPE), so that the matrix
+    // pipe works on block rb + 1 while the vector pipe runs the element chain of block rb - with two waves per SIMD there is
+    // nobody else to fill either pipe
+    auto recompute = [&](int rb) {
         f32x16 acc = zero16();
 #pragma unroll
         for (int s2 = 0; s2 < 4; ++s2) {
@@ -632,6 +650,13 @@ __global__ __launch_bounds__(kDwThreads, 1) void angle_sums_dw2_kernel(P p) {
             const f16x8 al = __builtin_bit_cast(f16x8, a_frag[afrag_idx(rb, s2, 1, lane)]);
             acc = mfma3(ah, al, w_hi[s2], w_lo[s2], acc);
         }
+        return acc;
+    };
+    auto block = [&](auto full_c, int64_t row0, int rb, float (&g)[16], int64_t row0n, int rbn, f32x16& acc) {
+        constexpr bool FULL = decltype(full_c)::value;
+#if !DW2_PIPE
+        acc = recompute(rb);
+#endif
         float gzv[16], s0 = 0.0f, s1 = 0.0f, mx = 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -648,6 +673,9 @@ __global__ __launch_bounds__(kDwThreads, 1) void angle_sums_dw2_kernel(P p) {
             am1 = fmaxf(am1, fabsf(xh));
         }
         load_g(row0n, rbn, g);
+#if DW2_PIPE
+        if (rb < 7) acc = recompute(rb + 1);  // (acc's values are all in gzv / the sums by now)
+#endif
         c0 += (double)s0;
         c1 += (double)s1;
         am0 = fmaxf(am0, mx);
@@ -698,8 +726,12 @@ __global__ __launch_bounds__(kDwThreads, 1) void angle_sums_dw2_kernel(P p) {
         __syncthreads();
         const int64_t row0_next = row0 + (int64_t)gridDim.x * kDwTile;
         auto row_blocks = [&](auto full_c) {
+            f32x16 acc;
+#if DW2_PIPE
+            acc = recompute(0);
+#endif
 #pragma unroll 1
-            for (int rb = 0; rb < 8; ++rb) block(full_c, row0, rb, g0, rb < 7 ? row0 : row0_next, rb < 7 ? rb + 1 : 0);
+            for (int rb = 0; rb < 8; ++rb) block(full_c, row0, rb, g0, rb < 7 ? row0 : row0_next, rb < 7 ? rb + 1 : 0, acc);
         };
         if (full)
             row_blocks(std::true_type{});

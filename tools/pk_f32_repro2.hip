@@ -60,6 +60,16 @@ __device__ __forceinline__ v2f packed_op(v2f x, v2f y, v2f a, v2f b) {
     if (KIND == 11) asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0]" : "=&v"(r) : "v"(a), "v"(b), "v"(x));
     if (KIND == 12) asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1]" : "=&v"(r) : "v"(a), "v"(b), "v"(x));
     if (KIND == 13) asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "=&v"(r) : "v"(a), "v"(b), "v"(x));
+    if (KIND == 14 || KIND == 15 || KIND == 16) {  // fp16 payloads: y.x's bits hold two halves made from (y.x, y.y)
+        unsigned hp, out;
+        asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(hp) : "v"(y.x), "v"(y.y));
+        if (KIND == 14)  // the low-slice instruction of split8s: f32 x - f16 high half of a packed register
+            asm volatile("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %0, %3, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]"
+                         : "=&v"(out) : "v"(x.x), "v"(hp), "v"(x.y));
+        if (KIND == 15) asm volatile("v_pk_mul_f16 %0, %1, %2 op_sel:[0,1]" : "=&v"(out) : "v"(hp), "v"(hp));
+        if (KIND == 16) asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "=&v"(out) : "v"(x.x), "v"(hp), "v"(x.y));
+        r.x = __uint_as_float(out), r.y = 0.0f;
+    }
     if (KIND == 5) {  // control: unpacked instructions standing in for the "packed" side too
         float r0, r1;
         asm volatile("v_fma_f32 %0, %2, %4, %6\n\tv_fma_f32 %1, %3, %5, %7" : "=&v"(r0), "=&v"(r1) : "v"(a.x), "v"(a.y), "v"(b.x), "v"(b.y), "v"(x.x), "v"(x.y));
@@ -87,6 +97,26 @@ __device__ __forceinline__ v2f scalar_op(v2f x, v2f y, v2f a, v2f b) {
     if (KIND == 11) fma2(a.y, b.x, x.x, a.y, b.y, x.y);
     if (KIND == 12) fma2(a.x, b.x, x.y, a.y, b.y, x.y);
     if (KIND == 13) fma2(a.x, b.y, x.x, a.y, b.x, x.y);
+    if (KIND == 14 || KIND == 15 || KIND == 16) {  // the same values through unpacked / un-swizzled instructions
+        unsigned hp, out;
+        asm volatile("v_cvt_pkrtz_f16_f32 %0, %1, %2" : "=v"(hp) : "v"(y.x), "v"(y.y));
+        unsigned hi_only = hp >> 16, lo_only = hp & 0xffffu;
+        asm volatile("" : "+v"(hi_only), "+v"(lo_only));
+        if (KIND == 14) {
+            unsigned o0, o1;
+            asm volatile("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=&v"(o0) : "v"(x.x), "v"(hi_only), "0"(0u));
+            asm volatile("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=&v"(o1) : "v"(x.y), "v"(lo_only), "0"(0u));
+            out = (o0 & 0xffffu) | (o1 << 16);
+        }
+        if (KIND == 15) {
+            const unsigned swz = hi_only | (hi_only << 16);  // (src1: high half for BOTH results? no: op_sel:[0,1] = low result from src1.hi)
+            unsigned b = hi_only | (hp & 0xffff0000u);       // low lane takes src1.hi, high lane takes src1.hi (op_sel_hi default 1)
+            (void)swz;
+            asm volatile("v_pk_mul_f16 %0, %1, %2" : "=&v"(out) : "v"(hp), "v"(b));
+        }
+        if (KIND == 16) asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,0]" : "=&v"(out) : "v"(x.x), "v"(hi_only), "v"(x.y));
+        r0 = __uint_as_float(out), r1 = 0.0f;
+    }
     v2f r = {r0, r1};
     return r;
 }
@@ -378,6 +408,9 @@ int main(int argc, char** argv) {
             run("P10 v_pk_fma_f32 op_sel:[1,0,0]", nb, VICTIM(11));
             run("P11 v_pk_fma_f32 op_sel:[0,0,1]", nb, VICTIM(12));
             run("P12 v_pk_fma_f32 op_sel:[0,1,0] op_sel_hi:[1,0,1]", nb, VICTIM(13));
+            run("M1  v_fma_mixlo/hi_f16 op_sel:[0,0,1] (split8s)", nb, VICTIM(14));
+            run("M2  v_pk_mul_f16 op_sel:[0,1]", nb, VICTIM(15));
+            run("M3  v_fma_mix_f32 op_sel:[0,1,0] op_sel_hi:[0,1,0]", nb, VICTIM(16));
         }
         if (brief && nb < 8) continue;
         run("P1 v_pk_add_f32", nb, [&] { hipLaunchKernelGGL(victim_kernel<1>, dim3(2048), dim3(256), 0, sa, (const float*)d_in, n, 400, d_rep); });
