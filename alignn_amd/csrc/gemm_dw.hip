@@ -59,6 +59,10 @@
 __device__ unsigned long long dw_trace_buf[256 * 16];
 #endif
 
+#ifndef DW_GRID_DEFAULT
+#define DW_GRID_DEFAULT 192  // (headline step, eagerly launched, same box: 256: 14.75-14.97 ms, 224: 14.37-14.55, 208: 14.48, 192: 14.41-14.43, 160: 14.60; force training 32.3 -> 32.1)
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -727,10 +731,24 @@ __global__ __launch_bounds__(1024) void dw_slab_reduce_kernel(const float* __res
     }
 }
 
-constexpr int kGridMax = 256;  // one workgroup per compute unit
+// One workgroup per compute unit - and each takes ALL of its compute unit (8 waves x 256 registers, 149 KiB of LDS): whatever
+// another stream launches while this kernel runs waits for a compute unit the launch does not use.  With all 256 taken the small
+// kernels of the bond-graph chain beside it (column reductions, slab sums: 10-20 us alone) were measured at 470-740 us in the
+// step - they ran when this kernel ended.  ALIGNN_AMD_DW_GRID (a multiple of 8: the XCDs stay balanced) leaves the rest to them.
+constexpr int kGridMax = 256;
+inline int dw_grid_cap() {
+    static const int cap = [] {
+        const char* e = getenv("ALIGNN_AMD_DW_GRID");
+        int v = e ? atoi(e) : DW_GRID_DEFAULT;
+        v = v < 8 ? 8 : (v > kGridMax ? kGridMax : v);
+        return v & ~7;
+    }();
+    return cap;
+}
 inline int dw_grid(int64_t M) {
     const int64_t tiles = (M + R - 1) / R;
-    return (int)(tiles < kGridMax ? tiles : kGridMax);
+    const int cap = dw_grid_cap();
+    return (int)(tiles < cap ? tiles : cap);
 }
 inline bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
