@@ -287,6 +287,12 @@ def make_batch(
 
     ``n_atoms`` may be an inclusive ``(lo, hi)`` range (ragged batches / cfg 5).
     """
+    return batch_raw(make_graphs(batch_size, n_atoms, seed0, kind, n_features))
+
+
+def make_graphs(batch_size: int = 64, n_atoms: int | tuple[int, int] = 60, seed0: int = 1234, kind: str = "crystal",
+                n_features: int = 92) -> list:
+    """The single graphs of ``make_batch`` (graph ``i`` uses seed ``seed0 + i``), e.g. to shard a global batch by cost."""
     graphs = []
     for i in range(batch_size):
         if isinstance(n_atoms, tuple):
@@ -294,4 +300,4 @@ def make_batch(
         else:
             n = int(n_atoms)
         graphs.append(_one(n, seed0 + i, kind, n_features))
-    return batch_raw(graphs)
+    return graphs

@@ -38,6 +38,20 @@ def load_pmc_traffic():
 
 
 PMC = load_pmc_traffic()
+
+
+def pmc_for(triplets, model):
+    """The PMC section that was profiled on THIS workload: the headline one, or one of `workloads` (BASELINE configs[3] / [4])."""
+    if PMC is None:
+        return None
+    if triplets == PMC.get("triplets") and model == "alignn":
+        return PMC
+    for w in (PMC.get("workloads") or {}).values():
+        if w.get("triplets") == triplets and w.get("model") == model:
+            return w
+    return None
+
+
 # (bf16x6 variant of the bare projection: round-1 measurement, profiles/r01_pmc_split_gemm.txt)
 PMC_TRAFFIC_X6_T676200 = (2 * 360721.0 + 676200.0) * 1024
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
@@ -70,6 +84,15 @@ def parse():
                     help="1: after the headline run also the force-field (BASELINE configs[3]) and molecule (configs[4]) "
                          "workloads, 5 replayed steps each in a child process, and put their lines under `other_configs` "
                          "(default: on for the plain `python bench.py` headline run at N=1, off otherwise)")
+    ap.add_argument("--shard", default="auto", choices=["auto", "cost", "rank"],
+                    help="N > 1: how the GLOBAL batch (N x --batch graphs) is split.  rank: every rank generates its own --batch "
+                         "graphs (regular crystals: all ranks alike); cost: one global batch, split with ddp.shard_by_cost on the "
+                         "line-graph rows T of each graph - the irregular molecules of configs[4], where load imbalance is real; "
+                         "auto = cost for --kind molecule, rank otherwise")
+    ap.add_argument("--ddp", default="flat", choices=["flat", "torch"],
+                    help="N > 1 gradient exchange.  flat: ONE all-reduce of FlatAdamW's packed gradient buffer per step (default); "
+                         "torch: the model wrapped in torch DistributedDataParallel(find_unused_parameters=True) exactly as the "
+                         "reference does (alignn/train.py:207), per-tensor fused AdamW, eager steps - the reference's wrap beside ours")
     ap.add_argument("--eager-steps", type=int, default=5,
                     help="extra informational run of this many eagerly launched steps on the resident batch (0: skip)")
     return ap.parse_args()
@@ -475,8 +498,37 @@ def main():
     from alignn_amd.synthetic import make_batch
 
     B = args.batch
+    global_B = world * args.batch
     n_atoms = (9, 27) if args.kind == "molecule" else args.atoms
-    raw = make_batch(B, n_atoms, seed0=1234 + rank * B, kind=args.kind)  # every rank its own crystals
+    shard_mode = args.shard if args.shard != "auto" else ("cost" if args.kind == "molecule" else "rank")
+    sharding = None
+    loss_scale = 1.0
+    if world > 1 and shard_mode == "cost":
+        # ONE global batch (every rank generates the same N x B graphs from the same seeds and computes the same partition:
+        # nothing is communicated), split so that every rank gets the same number of line-graph rows T - what the step time
+        # is proportional to.  Ranks then hold different NUMBERS of graphs: the local mean loss is weighted by graphs / (global
+        # batch / N), so that the average over ranks the all-reduce forms is the gradient of the global mean.
+        from alignn_amd.ddp import shard_by_cost
+        from alignn_amd.synthetic import batch_raw, make_graphs
+
+        graphs = make_graphs(global_B, n_atoms, seed0=1234, kind=args.kind)
+        t_of = [int(g.batch_num_triplets[0]) for g in graphs]
+        parts = shard_by_cost(t_of, world)
+        mine = parts[rank]
+        raw = batch_raw([graphs[i] for i in mine])
+        B = len(mine)
+        loss_scale = B * world / float(global_B)
+        t_rank = [sum(t_of[i] for i in part) for part in parts]
+        per = global_B // world
+        t_naive = [sum(t_of[r * per:(r + 1) * per]) for r in range(world)]  # (the contiguous split a sampler would make)
+        sharding = {"by": "ddp.shard_by_cost on the line-graph rows T of each graph (longest-processing-time-first)",
+                    "graphs_per_rank": [len(part) for part in parts], "T_per_rank": t_rank, "T_min": min(t_rank), "T_max": max(t_rank),
+                    "T_max_over_mean": round(max(t_rank) * world / float(sum(t_rank)), 4),
+                    "contiguous_split_T_min": min(t_naive), "contiguous_split_T_max": max(t_naive),
+                    "contiguous_split_T_max_over_mean": round(max(t_naive) * world / float(sum(t_naive)), 4)}
+        del graphs
+    else:
+        raw = make_batch(B, n_atoms, seed0=1234 + rank * B, kind=args.kind)  # every rank its own crystals
     batch = GraphBatch.from_raw(raw, device=dev)  # staged + canonicalised once: inputs resident in HBM
     torch.manual_seed(0)
     if args.model == "alignn":
@@ -491,6 +543,19 @@ def main():
                                                     calculate_gradient=ff, stresswise_weight=0.05 if ff else 0.0)).to(dev).train()
         predict = lambda b: model(b)["out"]  # noqa: E731
     broadcast_parameters(model)
+    ddp_torch = world > 1 and args.ddp == "torch"
+    if ddp_torch:
+        # the reference's own wrap (alignn/train.py:207: DistributedDataParallel(net, device_ids=[rank], find_unused_parameters=True)):
+        # bucketed all-reduces fired from autograd hooks while backward runs; the steps are launched eagerly
+        from torch.nn.parallel import DistributedDataParallel
+
+        net = model
+        model = DistributedDataParallel(net, device_ids=[dev_index] if backend == "nccl" else None, find_unused_parameters=True)
+        os.environ["ALIGNN_BENCH_EAGER"] = "1"
+        if args.model == "alignn":
+            predict = lambda b: model(b)  # noqa: E731
+        else:
+            predict = lambda b: model(b)["out"]  # noqa: E731
     target = torch.randn(B, generator=torch.Generator().manual_seed(1 + rank)).to(dev)
     # AdamW on the reference's parameter groups (alignn/train.py:209-210 -> alignn/utils.py:77-108 ``group_decay``: no
     # weight decay on names containing bias / bn / norm), torch's fused kernel either way - over ONE flat parameter buffer
@@ -500,7 +565,12 @@ def main():
     from alignn_amd.optim import FlatAdamW, group_decay
 
     LR, WD = float(os.environ.get("ALIGNN_BENCH_LR", "1e-3")), 1e-2
-    if os.environ.get("ALIGNN_BENCH_FLAT_ADAMW", "1") != "0":
+    if ddp_torch:
+        opt = torch.optim.AdamW(group_decay(net), lr=LR, weight_decay=WD, fused=True)
+        sync = None
+        opt_desc = ("torch.optim.AdamW(fused) over group_decay(model) behind torch DistributedDataParallel(find_unused_parameters=True): "
+                    "lr 1e-3, weight_decay 1e-2 / 0 on bias|bn|norm")
+    elif os.environ.get("ALIGNN_BENCH_FLAT_ADAMW", "1") != "0":
         opt = FlatAdamW(group_decay(model), lr=LR, weight_decay=WD, module=model, average_gradients=True)
         sync = None
         opt_desc = "FlatAdamW (torch fused AdamW on one flat buffer) over group_decay(model): lr 1e-3, weight_decay 1e-2 / 0 on bias|bn|norm"
@@ -528,14 +598,14 @@ def main():
             o = model(batch)
             l1 = torch.nn.functional.l1_loss
             loss = l1(o["out"], target) + l1(o["grad"], f_tgt) + l1(o["stresses"], s_tgt)
-            loss.backward()
+            (loss if loss_scale == 1.0 else loss * loss_scale).backward()
             reduce_and_update()
             return loss
     else:
         def step():
             zero_grad()
             loss = torch.nn.functional.l1_loss(predict(batch), target)
-            loss.backward()
+            (loss if loss_scale == 1.0 else loss * loss_scale).backward()
             reduce_and_update()
             return loss
 
@@ -578,7 +648,7 @@ def main():
             t = torch.tensor([edt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             edt = float(t.item())
-        eager = {"ms_per_step": round(edt * 1e3, 3), "graphs_per_s": round(world * B / edt, 1), "steps": n_eager,
+        eager = {"ms_per_step": round(edt * 1e3, 3), "graphs_per_s": round(global_B / edt, 1), "steps": n_eager,
                  "host_enqueue_ms_per_step": round(e_enq / n_eager * 1e3, 3)}
         log(f"eager launches: {edt * 1e3:.2f} ms/step")
 
@@ -627,7 +697,8 @@ def main():
             t_all = sum(sum(ts) for ts in by.values())
             b_all = sum(rows_moved[label] * row_bytes * len(ts) for label, ts in by.items())
             pmc = None
-            pv = PMC["variants"] if (PMC is not None and raw.num_triplets == PMC["triplets"]) else {}
+            pw = pmc_for(raw.num_triplets, args.model)
+            pv = pw["variants"] if pw is not None else {}
             if pv and all(label in pv for label in by):
                 pmc = sum(pv[label]["bytes_per_launch"] * len(ts) for label, ts in by.items()) / n_l
             in_step["family"] = {"launches_per_step": n_l, "ms_per_launch": t_all / n_l, "algorithmic_bytes_per_launch": b_all / n_l,
@@ -703,7 +774,7 @@ def main():
                     g_loss = l1_(o_["out"], target) + l1_(o_["grad"], f_tgt) + l1_(o_["stresses"], s_tgt)
                 else:
                     g_loss = torch.nn.functional.l1_loss(predict(batch), target)
-                g_loss.backward()
+                (g_loss if loss_scale == 1.0 else g_loss * loss_scale).backward()
             ops.reset_amax_arena()
             g_grads = [p_.grad for p_ in params]  # static buffers the replays write into (None: parameter unused)
 
@@ -778,10 +849,46 @@ def main():
                  "allreduce_bytes": buf.numel() * buf.element_size(),
                  "allreduce_ms_in_step_incl_divide": None if ar_in_step is None else round(ar_in_step, 4),
                  "allreduce_ms_standalone": round(e0.elapsed_time(e1) / 10, 4),
-                 "collectives_per_step": 1}
+                 "collectives_per_step": None if ddp_torch else 1}
+        # per-rank time of the timed steps (each rank's own clock around its K steps) and the rows it owned: where the batch is
+        # irregular (molecules) the skew between ranks IS the load imbalance the cost-based split is there to remove
+        # (inside the timed steps the collective makes every rank wait for the slowest: the imbalance shows in forward + backward
+        # ALONE - three eagerly launched passes without the gradient exchange, each rank's own HIP events)
+        import contextlib
+
+        def fwd_bwd_only():
+            zero_grad()
+            with (model.no_sync() if ddp_torch else contextlib.nullcontext()):
+                if args.model == "alignn_ff":
+                    o_ = model(batch)
+                    l1_ = torch.nn.functional.l1_loss
+                    (l1_(o_["out"], target) + l1_(o_["grad"], f_tgt) + l1_(o_["stresses"], s_tgt)).backward()
+                else:
+                    torch.nn.functional.l1_loss(predict(batch), target).backward()
+
+        fwd_bwd_only()
+        torch.cuda.synchronize()
+        f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        f0.record()
+        for _ in range(3):
+            fwd_bwd_only()
+        f1.record()
+        torch.cuda.synchronize()
+        zero_grad()
+        own_ms = f0.elapsed_time(f1) / 3
+        mine_ms = torch.tensor([own_ms, float(raw.num_triplets), float(B)], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine_ms) for _ in range(world)]
+        dist.all_gather(allr, mine_ms)
+        multi["rank_fwd_bwd_ms"] = [round(float(a[0]), 3) for a in allr]
+        multi["rank_T"] = [int(a[1]) for a in allr]
+        multi["rank_graphs"] = [int(a[2]) for a in allr]
+        multi["rank_fwd_bwd_ms_max_over_min"] = round(max(multi["rank_fwd_bwd_ms"]) / max(min(multi["rank_fwd_bwd_ms"]), 1e-9), 4)
+        multi["sharding"] = sharding if sharding is not None else {"by": "rank: every rank generates its own --batch graphs"}
+        multi["gradient_exchange"] = ("torch DistributedDataParallel(find_unused_parameters=True), as alignn/train.py:207" if ddp_torch
+                                      else "one all-reduce of the packed gradient buffer (alignn_amd/optim.py FlatAdamW)")
         assert multi["ranks_seen"] == world, multi
     ms = dt / args.steps * 1e3
-    gps = world * B * args.steps / dt
+    gps = global_B * args.steps / dt
     # Launch mode of the headline, chosen per host the way a training script would: the SAME K steps were timed eagerly
     # launched (before any capture; two C calls per step for the default model) and replayed from the hipGraph, with the same
     # barrier + synchronize protocol.  Replays do not depend on the host at all; eager launches are what a loop over
@@ -796,7 +903,7 @@ def main():
     headline_eager = (use_graph and eager is not None and eager["steps"] >= args.steps
                       and eager["ms_per_step"] < ms and os.environ.get("ALIGNN_BENCH_HEADLINE", "auto") != "replay")
     if headline_eager:
-        ms, gps = eager["ms_per_step"], world * B * 1e3 / eager["ms_per_step"]
+        ms, gps = eager["ms_per_step"], global_B * 1e3 / eager["ms_per_step"]
         t_enq = eager["host_enqueue_ms_per_step"] * 1e-3 * args.steps
         log(f"headline: eagerly launched steps ({ms:.2f} ms) beat the replays ({replayed['ms_per_step']:.2f} ms) on this host")
     peak_train_bytes = torch.cuda.max_memory_allocated(dev)  # (before the informational per-operator / micro-timing runs below)
@@ -848,7 +955,8 @@ def main():
         gbs = gemm_bytes / (t_h3 * 1e-3) / 1e9
         plain_traffic = (PMC["variants"]["plain"]["bytes_per_launch"]
                          if (PMC is not None and T == PMC["triplets"] and "plain" in PMC["variants"]) else None)
-        pmc_step = PMC["pmc_bytes_per_step"] if (PMC is not None and T == PMC["triplets"] and args.model == "alignn") else None
+        pw_step = pmc_for(T, args.model)
+        pmc_step = pw_step["pmc_bytes_per_step"] if pw_step is not None else None
         step_bytes = algorithmic_bytes_per_step(N, E, T)
         step_flops = algorithmic_flops_per_step(N, E, T)
         step_passes = None
@@ -888,7 +996,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": workload_name,
-                "global_batch": world * B,
+                "global_batch": global_B,
                 "nodes": N,
                 "edges": E,
                 "triplets": T,
@@ -908,7 +1016,7 @@ def main():
                            "step: edge projection + u_add_v + BN statistics / input gradient + residual + BN-backward sums",
                  "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "in_step": in_step,
                  "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + --pmc WRITE_SIZE over bench.py, "
-                                   + (" + ".join(PMC["source"]) if PMC is not None else "profiles/") +
+                                   + (" + ".join((pmc_for(T, args.model) or PMC)["source"]) if PMC is not None else "profiles/") +
                                    " via tools/pmc_constants.py -> profiles/pmc_traffic.json (per variant, averaged over the launches)"},
                 **({"achieved": round(in_step["family"]["GBps"], 1),
                     "frac": round(in_step["family"]["GBps"] / HBM_PEAK_GBS, 4),
@@ -942,14 +1050,17 @@ def main():
                 # the launches of one step (profiles/pmc_traffic.json) - divided by the step time
                 "pmc_GB_per_step": None if pmc_step is None else round(pmc_step / 1e9, 2),
                 "pmc_hbm_frac_of_8TBs": None if pmc_step is None else round(pmc_step / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "pmc_source": None if pmc_step is None else PMC["source"],
+                "pmc_source": None if pmc_step is None else pw_step["source"],
                 # SURVEY 8(d)'s algorithmic bytes of a maximally fused schedule over the same time: NOT a bandwidth the chip
                 # sustained (the schedule needs fewer passes than that accounting: 5 forward passes per line-graph
                 # convolution, dead last-layer outputs, fused reductions) - a distance to the 10.2 ms ceiling
                 "passes": step_passes,
                 "algorithmic_GB_per_step": round(step_bytes / 1e9, 2),
                 "algorithmic_GFLOP_per_step": round(step_flops / 1e9, 1),
-                "algorithmic_bytes_over_step_time_frac_of_8TBs": round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                # (force training: SURVEY's per-pass accounting x 3 counts rows this schedule never moves - the figure is a
+                # distance to that accounting's ceiling, not a bandwidth; the achieved one is pmc_hbm_frac_of_8TBs above)
+                ("accounting_bytes_over_step_time_over_8TBs_not_a_bandwidth" if args.model == "alignn_ff" else
+                 "algorithmic_bytes_over_step_time_frac_of_8TBs"): round(step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "mfma_frac_of_157TF": round(step_flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4),
             },
             "host_calibration": host_calibration(dev),  # (+ gpu_copy_GBps: this GPU's streaming-copy rate)

@@ -148,6 +148,36 @@ def test_eight_ranks_on_one_gpu_rehearsal_of_the_drivers_scaling_run():
     assert out["loss"] == out["loss"]
 
 
+def test_eight_ranks_molecules_sharded_by_cost_rehearsal():
+    """``bench.py --gpus 8 --kind molecule`` splits ONE global batch of irregular molecules with
+    ``ddp.shard_by_cost`` on the line-graph rows T (every rank computes the same partition, nothing is communicated) and reports
+    the rows and graphs each rank owns and each rank's own forward + backward time.  Eight ranks on this box's one GPU, gloo."""
+    out, err = _bench(["--gpus", "8", "--kind", "molecule", "--steps", "3", "--warmup", "1", "--batch", "16", "--no-cpu-baseline",
+                       "--eager-steps", "2", "--streamed-steps", "0"], {"ALIGNN_BENCH_BACKEND": "gloo"}, timeout=1500)
+    assert out["n_gpus"] == 8 and out["config"]["global_batch"] == 128
+    mg = out["multi_gpu"]
+    sh = mg["sharding"]
+    assert mg["ranks_seen"] == 8 and mg["parameters_bit_equal_across_ranks"] is True, mg
+    assert sum(sh["graphs_per_rank"]) == 128 and sum(mg["rank_graphs"]) == 128
+    assert mg["rank_T"] == sh["T_per_rank"] and sh["T_min"] == min(mg["rank_T"]) and sh["T_max"] == max(mg["rank_T"])
+    # the cost-based split is what it is for: tighter than the contiguous split a sampler would make
+    assert sh["T_max_over_mean"] <= sh["contiguous_split_T_max_over_mean"] and sh["T_max_over_mean"] < 1.05, sh
+    assert len(mg["rank_fwd_bwd_ms"]) == 8 and min(mg["rank_fwd_bwd_ms"]) > 0 and mg["rank_fwd_bwd_ms_max_over_min"] >= 1.0
+    assert out["loss"] == out["loss"]
+
+
+def test_eight_ranks_with_the_references_ddp_wrap_rehearsal():
+    """``--ddp torch`` wraps the model in torch DistributedDataParallel(find_unused_parameters=True) as the
+    reference does (alignn/train.py:207) instead of the one flat all-reduce: eight ranks on one GPU, gloo, eager steps; the
+    replicas stay bit-identical."""
+    out, err = _bench(["--gpus", "8", "--ddp", "torch"] + SMALL, {"ALIGNN_BENCH_BACKEND": "gloo"}, timeout=1500)
+    mg = out["multi_gpu"]
+    assert out["n_gpus"] == 8 and mg["ranks_seen"] == 8 and mg["collectives_per_step"] is None
+    assert "DistributedDataParallel" in mg["gradient_exchange"] and "DistributedDataParallel" in out["optimizer"]
+    assert mg["parameters_bit_equal_across_ranks"] is True, mg
+    assert out["step_launch"] == "eager" and out["loss"] == out["loss"]
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: exercised by the driver's multi-GPU box")
 def test_bench_two_ranks_over_rccl():
     """The real thing wherever >= 2 GPUs are visible: one rank per GPU, RCCL all-reduce of the packed gradient buffer

@@ -73,11 +73,14 @@ def newest_round():
     return rounds[-1]
 
 
-def build(rnd=None):
-    rnd = newest_round() if rnd is None else rnd
-    ff = os.path.join(PROFILES, f"r{rnd:02d}_pmc_fetch_size.txt")
-    wf = os.path.join(PROFILES, f"r{rnd:02d}_pmc_write_size.txt")
+# other workloads of BASELINE.json benched beside the headline (bench.py `other_configs`): name -> (triplets, model); their PMC
+# passes are profiles/rNN_pmc_<name>_fetch_size.txt / _write_size.txt (tools/gpu/r6_pmc.sh with BARGS / SUFFIX)
+WORKLOADS = {"cfg3_ff": (561792, "alignn_ff"), "cfg4_mol": (909126, "alignn")}
+
+
+def build_one(ff, wf, triplets):
     fetch, write = parse(ff), parse(wf)
+    min_write = T_ROW_MIN_WRITE_MIB * triplets / 676200.0
 
     def find(rows, names):
         # T-row launches of the kernel: the row of that kernel with the largest per-launch maximum
@@ -90,7 +93,7 @@ def build(rnd=None):
     variants = {}
     for v, names in VARIANT_KERNELS.items():
         f, w = find(fetch, names), find(write, names)
-        if f is None or w is None or w["max_MiB"] < T_ROW_MIN_WRITE_MIB:
+        if f is None or w is None or w["max_MiB"] < min_write:
             continue
         # the T-row launches of a kernel that also runs at E rows are its largest ones -> per-launch maximum; for a kernel
         # only launched at T rows max ~= avg
@@ -102,17 +105,29 @@ def build(rnd=None):
     if steps:
         tot = sum(2 * r["avg_MiB"] * r["calls"] for r in fetch) + sum(r["avg_MiB"] * r["calls"] for r in write)
         total = tot * 1048576 / steps
-    return {
-        "source": [os.path.relpath(ff, ROOT), os.path.relpath(wf, ROOT)],
+    return {"source": [os.path.relpath(ff, ROOT), os.path.relpath(wf, ROOT)], "triplets": triplets, "steps_profiled": steps,
+            "variants": variants, "pmc_bytes_per_step": None if total is None else round(total)}
+
+
+def build(rnd=None):
+    rnd = newest_round() if rnd is None else rnd
+    ff = os.path.join(PROFILES, f"r{rnd:02d}_pmc_fetch_size.txt")
+    wf = os.path.join(PROFILES, f"r{rnd:02d}_pmc_write_size.txt")
+    out = build_one(ff, wf, 676200)
+    out.update({
         "round": rnd,
-        "triplets": 676200,
         "fetch_correction": "FETCH_SIZE x2 (gfx950, 16 B/lane streaming reads; MI355X_MICROARCH.md)",
-        "steps_profiled": steps,
-        "variants": variants,
-        "pmc_bytes_per_step": None if total is None else round(total),
         "pmc_bytes_per_step_covers": "every launch listed in the two summaries (those whose largest launch moved >= the "
                                      "summary's min_MiB cut-off; see the header of the .txt files)",
-    }
+    })
+    workloads = {}
+    for name, (trip, model) in WORKLOADS.items():
+        f2 = os.path.join(PROFILES, f"r{rnd:02d}_pmc_{name}_fetch_size.txt")
+        w2 = os.path.join(PROFILES, f"r{rnd:02d}_pmc_{name}_write_size.txt")
+        if os.path.exists(f2) and os.path.exists(w2):
+            workloads[name] = dict(build_one(f2, w2, trip), model=model)
+    out["workloads"] = workloads
+    return out
 
 
 def main():
