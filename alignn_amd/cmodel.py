@@ -475,11 +475,33 @@ def release_captured_workspaces(model) -> int:
     return n
 
 
+_SLOT = [0]
+
+
+class slot:
+    """``with cmodel.slot(k):`` - forwards issued inside use the model's k-th binding: its own workspace block and its own helper
+    streams (lane T, side, aux).  Two forwards of ONE model under different slots, each on its own torch stream, overlap on the GPU
+    - what alignn_amd/microbatch.py uses to run the bond-row chains of one part of a batch under the triplet-row kernels of
+    another.  (Slot 0 is the default; a backward finds its binding through the forward's context, not through the slot.)"""
+
+    def __init__(self, k):
+        self.k, self.prev = int(k), 0
+
+    def __enter__(self):
+        self.prev, _SLOT[0] = _SLOT[0], self.k
+        return self
+
+    def __exit__(self, *exc):
+        _SLOT[0] = self.prev
+        return False
+
+
 def binding_of(model) -> Binding:
     mc = model_cache(model)
-    b = mc.get("binding")
+    key = "binding" if _SLOT[0] == 0 else f"binding{_SLOT[0]}"
+    b = mc.get(key)
     if b is None or b.device != model.fc.weight.device:
-        b = mc["binding"] = Binding(model)
+        b = mc[key] = Binding(model)
     return b
 
 
