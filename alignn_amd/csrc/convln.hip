@@ -13,7 +13,7 @@
 //
 // H <= 256 (one feature panel per wave: the row statistics are wave reductions) - alignn_egc_ln_fused_supported.
 //
-// NOTE: this file is compiled with -fno-slp-vectorize like norm.hip / dual.hip (alignn_amd/build.py, DESIGN.md section 4e).
+// NOTE: this file is compiled with -fno-slp-vectorize like norm.hip / dual.hip (alignn_amd/build.py, DESIGN.md section 4.6).
 #include <cstdlib>
 
 #include "common.h"

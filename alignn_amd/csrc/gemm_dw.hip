@@ -60,7 +60,7 @@ __device__ unsigned long long dw_trace_buf[256 * 16];
 #endif
 
 #ifndef DW_GRID_DEFAULT
-#define DW_GRID_DEFAULT 192  // (headline step, eagerly launched, same box: 256: 14.75-14.97 ms, 224: 14.37-14.55, 208: 14.48, 192: 14.41-14.43, 160: 14.60; force training 32.3 -> 32.1)
+#define DW_GRID_DEFAULT 224  // (profiles/r06_dw_grid_ab.txt - headline step, eager / replayed ms, three boxes: 256: 14.56-14.97 / 14.56-14.67; 224: 14.37-14.58 / 14.54-14.68; 192: 14.41-14.53 / 14.81-14.93; 160: 14.60)
 #endif
 
 namespace {

@@ -275,7 +275,7 @@ __device__ __forceinline__ void dma16(const void* sbase, unsigned lane_off, unsi
 // STATUS: compiled only with -DX6_PERSIST=1.  Results are bit-identical to the one-tile kernel (tools/ablate_x6.py,
 // ABL_CHECK=1, T x 256 x 256), but it measured no faster (374 vs 378 us, interleaved rounds): the second k-step's
 // vmcnt(0) still meets the stores one step later.  Kept as the base for a deeper walk (three stages: two prefetched
-// ahead of the stores) - see DESIGN.md section 8.
+// ahead of the stores) - see HISTORY.md section 8.
 // EPI == 1: the output C is a gradient g_y = dL/dy of a tensor y = r + silu(BatchNorm(xn)) (the edge output of the previous
 // line-graph convolution, or an MLPLayer output without r).  BatchNorm's backward needs the column sums
 // sum_rows gz and sum_rows gz*xhat (gz = g_y * silu'(z)) over ALL rows before anything else can happen - a separate

@@ -1584,7 +1584,7 @@ void set_streams(Ctx& c, alignn_stream_t st) {
     // LayerNorm flavour: helper streams like the BatchNorm flavour's.  (Round 5 found its steps not bit-reproducible on helper
     // streams - forces off by 1e-3, run to run - and traced it to the packed-fp32 code hipcc emitted for ln_silu_bwd_kernel: one
     // float4 component of lanes 48-63 wrong while an MFMA kernel of another stream shared the compute unit; csrc/norm.hip and
-    // csrc/dual.hip are built without SLP vectorisation since - alignn_amd/build.py, DESIGN.md section 4e.)
+    // csrc/dual.hip are built without SLP vectorisation since - alignn_amd/build.py, DESIGN.md section 4.6.)
     // ALIGNN_AMD_LN_STREAMS=0 puts the LayerNorm flavour on ONE stream (bit 0: lane T + aux, bit 1: side).
     if (c.d->norm == 1) {
         static int ln_streams = -1;

@@ -591,7 +591,7 @@ __global__ __launch_bounds__(kThreads) void ln_silu_fwd_kernel(const float* __re
 }
 
 // NOTE: this file is compiled with -fno-slp-vectorize (alignn_amd/build.py): with packed-fp32 instructions hipcc 7.2's code for
-// the kernel below was not bit-reproducible beside kernels of another stream (DESIGN.md section 4e).
+// the kernel below was not bit-reproducible beside kernels of another stream (DESIGN.md section 4.6).
 // NODE: the rows are the node pre-activations xpre = Ux + h of an edge-gated convolution, h = S1 / (S0 + eps): the adjoints of the
 // two segment sums leave with the gradient (alignn_egc_node_bwd's arithmetic: GS1 = g / (S0 + eps), GS0 = -GS1 * h) - one launch
 // instead of two on the bond-row chain of every LayerNorm-flavoured convolution's reverse.

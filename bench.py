@@ -969,7 +969,7 @@ def main():
             step_passes = {"bytes_x": 3.0, "flops_x": 7.0 / 3.0, "what": "force evaluation fwd + reverse w.r.t. r, tangent forward, "
                            "second-order reverse (value + tangent) - SURVEY 8(a) row 9"}
             step_bytes, step_flops = 3.0 * step_bytes, 7.0 / 3.0 * step_flops
-            # What THIS schedule moves over the T-row tensors (fp32, [T, hidden]): per line-graph convolution
+            # What THIS schedule moves over the T-row tensors (HISTORY.md section 4f; fp32, [T, hidden]): per line-graph convolution
             # with a live edge output 5 (forward) + 6 (reverse) + 7 (tangent forward) + 16 (second-order reverse) passes, the last
             # one (dead edge output) 3 + 4 + 5 + 12, the bond-angle embedding's two LayerNorm layers ~28.6 over the four phases -
             # the op-by-op accounting above is what the reference's autograd would move, not what the chip sustained here.

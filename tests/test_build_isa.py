@@ -1,5 +1,5 @@
 """The shipped library must not contain the packed-fp32 instruction form that MI355X executes wrongly beside MFMA waves of another
-workgroup (alignn_amd/build.py, DESIGN.md section 4e, tools/pk_f32_repro2.hip): v_pk_{fma,mul,add}_f32 with op_sel taking the
+workgroup (alignn_amd/build.py, DESIGN.md section 4.6, tools/pk_f32_repro2.hip): v_pk_{fma,mul,add}_f32 with op_sel taking the
 HIGH half of src1 for the LOW result.  The check disassembles the gfx950 code objects of the linked file - no GPU needed."""
 import os
 

@@ -8,7 +8,7 @@ for i in 1 2; do
     python - <<PY
 import json
 d=json.load(open("gpurun_out/r6_ab_dwgrid_${v}_$i.json"))
-print("DW_GRID=$v run $i:", d["step_launch"], d["ms_per_step"], "replay", (d.get("replayed_steps") or {}).get("ms_per_step"), "eager", (d.get("eager_launches") or {}).get("ms_per_step"))
+print("DW_GRID=$v run $i:", d["ms_per_step"], "replay", (d.get("replayed_steps") or {}).get("ms_per_step"), "eager", (d.get("eager_launches") or {}).get("ms_per_step"), "roofline.frac", d["roofline"].get("frac"), {k: v["ms_per_launch"] for k, v in d["roofline"]["in_step"].items() if isinstance(v, dict) and "launches" in v})
 PY
   done
 done

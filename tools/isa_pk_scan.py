@@ -1,5 +1,5 @@
 """Scan the gfx950 ISA of every source of libalignn_hip.so for the packed-fp32 instruction form that tools/pk_f32_repro2.hip shows
-to return wrong values on MI355X (DESIGN.md section 4e):
+to return wrong values on MI355X (DESIGN.md section 4.6):
 
     v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 whose op_sel selects the HIGH half of src1 for the LOW result  (op_sel:[_,1,...])
 

@@ -1,4 +1,4 @@
-// Stand-alone reproducer for the packed-fp32 fault of DESIGN.md section 4e (round 5: ln_silu_bwd_kernel<1> returned one float4
+// Stand-alone reproducer for the packed-fp32 fault of DESIGN.md section 4.6 (round 5: ln_silu_bwd_kernel<1> returned one float4
 // component of lanes 48-63 wrong when an MFMA kernel of another stream shared the compute unit; worked around by building
 // norm.hip / dual.hip / convln.hip with -fno-slp-vectorize).  Three experiments, each run ALONE and BESIDE an MFMA spinner on a
 // second stream (the stand-in for a projection of another lane, or an RCCL kernel):
