@@ -34,6 +34,10 @@
 
 #include "common.h"
 
+#ifndef ANGLE_GRID_DEFAULT
+#define ANGLE_GRID_DEFAULT 224  // (headline step eager, one box, two rounds: 256: 14.45 / 14.59, 224: 14.31 / 14.55, 192: 14.38 / 14.54, 160: 14.56 / 14.56)
+#endif
+
 namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -1266,9 +1270,22 @@ inline int grid_for(int64_t rows, int rows_per_block) {
     return (int)(need < kGrid ? (need > 0 ? need : 1) : kGrid);
 }
 inline size_t al256(size_t b) { return (b + 255) / 256 * 256; }
+// The T x 256 passes take whole compute units (512 threads, 64-142 KiB of LDS, up to 250 registers per lane): what the caller's
+// other streams launch beside them waits for a unit they do not use.  ALIGNN_AMD_ANGLE_GRID (default kAngleGridDefault, a
+// multiple of 8) caps their grids; every pass walks its tiles with a grid stride and hands the launched count to its reductions.
+inline int angle_grid_cap() {
+    static const int cap = [] {
+        const char* e = getenv("ALIGNN_AMD_ANGLE_GRID");
+        int v = e ? atoi(e) : ANGLE_GRID_DEFAULT;
+        v = v < 8 ? 8 : (v > kRbGrid ? kRbGrid : v);
+        return v & ~7;
+    }();
+    return cap;
+}
 inline int rb_grid(int64_t rows, int mode) {
     const int g = grid_for(rows, 32 * (rb_threads(mode) / 64));
-    return g < kRbGrid ? g : kRbGrid;
+    const int cap = angle_grid_cap();
+    return g < cap ? g : cap;
 }
 
 P make_params(const alignn_angle_args& a) {
@@ -1409,7 +1426,7 @@ int alignn_angle_embed_bwd(const alignn_angle_args* a, alignn_stream_t stream) {
     // layer 2: BatchNorm-backward sums and G = sum gz (a1 - mean) in one pass over g_z, then dW2 from G once c1 is known
     p.partial = dw2;
     p.partial_d = sums;
-    const int gdw = grid_for(a->rows, kDwTile) < kDwGrid ? grid_for(a->rows, kDwTile) : kDwGrid;
+    const int gdw = grid_for(a->rows, kDwTile) < angle_grid_cap() ? grid_for(a->rows, kDwTile) : angle_grid_cap();
     hipLaunchKernelGGL(angle_sums_dw2_kernel, dim3(gdw), dim3(kDwThreads), 0, st, p);
     hipLaunchKernelGGL(angle_red_finalize_kernel, dim3(kH / 4), dim3(256), 0, st, (const double*)sums, gdw, a->rows, kH, a->stat2,
                        a->l2.red, a->scal, kAmaxGz2, kAmaxXh2, kBoundDx2);
