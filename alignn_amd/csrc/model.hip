@@ -506,7 +506,16 @@ void run_forward(Ctx& c, Tape& tp, float* out) {
     const bool angle_first = c.ff == nullptr && d.norm == 0 && d.angle_fused != 0 && Tn > 0 && c.T != c.main && Tn >= d.lane_min_rows &&
                              alignn_angle_embed_supported(d.angle_bins, d.angle1.out, d.angle2.out) != 0;
     if (angle_first) c.sync(c.T, c.main);  // (the zeroed arena)
-    if (d.n_weights > 0) L(alignn_prepare_weights(d.weight_descs, d.n_weights, d.weight_amax, c.main));
+    // The slice images of the weights (max|W| + two images each: 3 launches, ~55 us) are first read by the second bond-embedding
+    // layer: with a helper stream they are made BESIDE the atom embedding and the first bond-embedding layer (exact-fp32
+    // products, no images) instead of in front of them - the caller's stream is the critical chain at the head of a step (the
+    // first bond-graph convolution hangs on it; lane T's angle embedding finishes earlier).
+    const bool prep_aside = angle_first && c.aux != c.main && d.n_weights > 0 && c.ff == nullptr &&
+                            !x6_shape_ok(c, N, d.atom.in, d.atom.out, d.atom.in) &&     // (the layers in between take the
+                            !x6_shape_ok(c, E, d.edge1.in, d.edge1.out, d.edge1.in);    //  exact-fp32 product: no image read)
+    hipStream_t prep_st = prep_aside ? c.aux : c.main;
+    if (prep_aside) c.sync(c.aux, c.main);
+    if (d.n_weights > 0) L(alignn_prepare_weights(d.weight_descs, d.n_weights, d.weight_amax, prep_st));
     if (d.n_bump > 0 && c.launch && c.rc == 0) {
         hipLaunchKernelGGL(bump_kernel, dim3((d.n_bump + 63) / 64), dim3(64), 0, c.main, (int64_t* const*)d.bump_ptrs, d.n_bump);
         c.rc = (int)hipGetLastError();
@@ -557,7 +566,9 @@ void run_forward(Ctx& c, Tape& tp, float* out) {
     L(alignn_rbf_fwd(tp.bl, d.edge_centers, d.edge_gamma, tp.rbf_e, E, d.edge_bins, c.main));
     Act ye;
     ye.p = tp.rbf_e;
-    Act y = mlp_fwd(c, tp.e2, d.edge2, mlp_fwd(c, tp.e1, d.edge1, ye, E), E);
+    Act y1 = mlp_fwd(c, tp.e1, d.edge1, ye, E);
+    if (prep_aside) c.sync(c.main, c.aux);  // the weight images: everything later is ordered behind the caller's stream from here
+    Act y = mlp_fwd(c, tp.e2, d.edge2, y1, E);
     if (c.unsupported) return;
     // ---- ALIGNN layers (alignn.py:317-319), then GCN layers (:322-323); dead last-layer outputs are not materialised
     tp.convs.assign(conv_count(d), ConvTape{});
