@@ -1015,6 +1015,12 @@ def main():
                 {"kernel": "gemm_nt_x6 family (f16x3 split-product projection, M=T, N=K=256) as launched inside a training "
                            "step: edge projection + u_add_v + BN statistics / input gradient + residual + BN-backward sums",
                  "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "in_step": in_step,
+                 "note": ("since round 6 the input-gradient launches of the family are csrc/gemm_dw.hip (labels dw*): ONE pass that also "
+                          "forms the weight gradient, credited with its unique footprint only (read g_m, read y, write g_y [+ addend] "
+                          "[+ pre-activation] = 3-5 rows; the two launches it replaces were credited 3-4 + 2 rows, the weight-gradient "
+                          "product outside this family).  It runs on 224 of the 256 compute units so that the bond-row chain of the other "
+                          "streams shares the chip (profiles/r06_dw_grid_ab.txt): its own rate is 0.44-0.47 of 8 TB/s in the step "
+                          "(0.50-0.55 on all units), the step is 0.2-0.3 ms faster"),
                  "traffic_source": "rocprofv3 --pmc FETCH_SIZE (x2 gfx950 correction) + --pmc WRITE_SIZE over bench.py, "
                                    + (" + ".join((pmc_for(T, args.model) or PMC)["source"]) if PMC is not None else "profiles/") +
                                    " via tools/pmc_constants.py -> profiles/pmc_traffic.json (per variant, averaged over the launches)"},
