@@ -174,6 +174,43 @@ def test_alternating_captures_and_eager_steps_keep_two_workspace_blocks():
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None) and len(ref) > 50
 
 
+def test_two_bindings_of_one_model_on_two_streams():
+    """``cmodel.slot(k)``: a second binding (workspace + helper streams) of the same model, so that two forwards on two torch
+    streams are independent on the GPU; predictions have the bits of the one-binding run, the summed gradients agree."""
+    raws = [make_batch(4, 20, seed0=3 + 10 * i) for i in range(2)]
+    batches = [GraphBatch.from_raw(r, device=DEV) for r in raws]
+    targets = [torch.randn(4, generator=torch.Generator().manual_seed(i)).to(DEV) for i in range(2)]
+    l1 = torch.nn.functional.l1_loss
+
+    def run(slots):
+        model = _mk(alignn_layers=2, gcn_layers=2)
+        streams = [torch.cuda.Stream() for _ in range(2)]
+        cur = torch.cuda.current_stream()
+        losses, preds = [], []
+        for i, (b, t) in enumerate(zip(batches, targets)):
+            if slots:
+                streams[i].wait_stream(cur)
+                with cmodel.slot(i), torch.cuda.stream(streams[i]):
+                    preds.append(model(b))
+                    losses.append(l1(preds[-1], t))
+            else:
+                preds.append(model(b))
+                losses.append(l1(preds[-1], t))
+        if slots:
+            for st in streams:
+                cur.wait_stream(st)
+            assert cmodel.model_cache(model).get("binding1") is not None
+        (losses[0] + losses[1]).backward()
+        torch.cuda.synchronize()
+        return [p.detach().clone() for p in preds], {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    (pa, ga), (pb, gb) = run(False), run(True)
+    assert all(torch.equal(a, b) for a, b in zip(pa, pb))
+    gmax = max(float(v.abs().max()) for v in ga.values())
+    for k in ga:
+        assert float((ga[k] - gb[k]).abs().max()) <= 1e-5 * max(float(ga[k].abs().max()), 1e-3 * gmax), k
+
+
 def test_autograd_semantics_accumulation_two_forwards_no_grad():
     raw1, raw2 = make_batch(10, 30, seed0=3), make_batch(6, 50, seed0=4)
     b1, b2 = GraphBatch.from_raw(raw1, device=DEV), GraphBatch.from_raw(raw2, device=DEV)
